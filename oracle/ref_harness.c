@@ -1,0 +1,76 @@
+/*
+ * ref_harness.c -- thin exported wrappers around the REFERENCE's own
+ * caribou_smi.c, compiled from where it lies under /root/reference by
+ * oracle/Makefile into oracle/_ref/libref_smi.so (git-ignored).
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file contains no reference code: it
+ * #includes the reference translation unit at build time so that its
+ * `static` functions (rx_data_analyze, find_buffer_offset, generate_data)
+ * are reachable, and drives caribou_smi_read() from an ordinary fd.
+ * Used to pin oracle/cl_oracle.c and to generate tests/golden/ fixtures.
+ */
+#include "caribou_smi/caribou_smi.c" /* -I$(REF)/software/libcariboulite/src */
+
+#include <fcntl.h>
+
+static void ref_dev_init(caribou_smi_st *dev, int fd, size_t native_batch_len)
+{
+    memset(dev, 0, sizeof(*dev));
+    dev->initialized = 1;
+    dev->filedesc = fd;
+    dev->native_batch_len = native_batch_len;
+    dev->sample_rate = CARIBOU_SMI_SAMPLE_RATE;
+    dev->debug_mode = caribou_smi_none;
+    dev->read_temp_buffer = malloc(native_batch_len + 1024);
+    dev->write_temp_buffer = malloc(native_batch_len + 1024);
+}
+
+static void ref_dev_free(caribou_smi_st *dev)
+{
+    free(dev->read_temp_buffer);
+    free(dev->write_temp_buffer);
+}
+
+int ref_find_buffer_offset(uint8_t *buffer, size_t len)
+{
+    caribou_smi_st dev;
+    memset(&dev, 0, sizeof dev);
+    dev.debug_mode = caribou_smi_none;
+    return caribou_smi_find_buffer_offset(&dev, buffer, len);
+}
+
+/* channel: 0 = caribou_smi_channel_900 (S1G), 1 = caribou_smi_channel_2400 (HiF) */
+int ref_rx_data_analyze(int channel, uint8_t *data, size_t data_length,
+                        int16_t *iq_out, uint8_t *meta_out)
+{
+    caribou_smi_st dev;
+    memset(&dev, 0, sizeof dev);
+    dev.debug_mode = caribou_smi_none;
+    return caribou_smi_rx_data_analyze(&dev, (caribou_smi_channel_en)channel, data, data_length,
+                                       (caribou_smi_sample_complex_int16 *)iq_out,
+                                       (caribou_smi_sample_meta *)meta_out);
+}
+
+/* caribou_smi_read() driven from a regular file holding the byte stream. */
+int ref_smi_read_file(const char *path, int channel, int16_t *iq, uint8_t *meta,
+                      size_t length_samples, size_t native_batch_len)
+{
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return -100;
+    caribou_smi_st dev;
+    ref_dev_init(&dev, fd, native_batch_len);
+    int ret = caribou_smi_read(&dev, (caribou_smi_channel_en)channel,
+                               (caribou_smi_sample_complex_int16 *)iq,
+                               (caribou_smi_sample_meta *)meta, length_samples);
+    ref_dev_free(&dev);
+    close(fd);
+    return ret;
+}
+
+void ref_generate_data(const int16_t *iq, size_t n_samples, uint8_t *out)
+{
+    caribou_smi_st dev;
+    memset(&dev, 0, sizeof dev);
+    caribou_smi_generate_data(&dev, out, n_samples * CARIBOU_SMI_BYTES_PER_SAMPLE,
+                              (caribou_smi_sample_complex_int16 *)iq);
+}
