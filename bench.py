@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py -- Msamples/s through the RX pipe unpack + FIR(64) + resample(3/2)
+(BASELINE.json metric, config 2) on N MI355X GPUs of one node.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch of synthetic SMI bytes that
+is already resident in HBM: the per-chunk sync check (clhip_smi_find_offsets,
+2048 native 512 KiB chunks) plus ONE launch of the fused kernel over a
+2^28-sample stream (1 GiB in, 3 GiB CF32 out -- larger than the 256 MiB
+Infinity Cache).  Streams are independent, so N GPUs run N such streams with
+no data-path collective (weak scaling); the only collectives are the timing
+barrier and the max-over-ranks reduction.
+
+One JSON line on rank 0.  `roofline` prices the fused kernel against HBM
+(16 algorithmic bytes per input sample: 4 read + 12 written); `cpu_baseline`
+is the oracle's fp32 CPU pipe (oracle/cl_oracle.c, "port") on this host's cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("OMP_WAIT_POLICY", "active")     # libgomp barriers spin (sandboxed futexes are slow)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+ALGO_BYTES_PER_SAMPLE = 16.0      # R 4 B + W 8*3/2 B
+FLOP_PER_SAMPLE = 304.0           # 64*2*2 (FIR) + 1.5*8*2*2 (3/2 polyphase)
+HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec
+VALU_PEAK_TFLOPS = 157.3
+NATIVE_CHUNK_SAMPLES = 131072     # caribou_smi.c:78 / cariboulite_radio.c:1310-1315
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log2-samples", type=int, default=28, help="samples per GPU per step (2^k)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--no-cpu", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(taps, d_words, budget_s):
+    """Oracle fp32 pipe on host cores over a bounded sample of the SAME bytes."""
+    from oracle import oracle as orc
+    orc.lib()
+    n = 1 << 24                                    # 16.8 M samples = 128 native chunks (4.2 s of stream)
+    b = d_words[:n].cpu().numpy().view(np.uint8)
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    out, bufs = orc.rx_pipe_f32_mt(0, b, taps["fir64_c2"], taps["rs_3_2"], 3, 2, cores)      # warm (page faults)
+    res = {}
+    for label, nt in (("all", cores), ("1t", 1)):
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            out, bufs = orc.rx_pipe_f32_mt(0, b, taps["fir64_c2"], taps["rs_3_2"], 3, 2, nt, bufs=bufs)
+            reps += 1
+            dt = time.perf_counter() - t0
+            if dt > budget_s * (0.6 if label == "all" else 0.4):
+                break
+        res[label] = reps * n / dt / 1e6
+    return {"value": round(res["all"], 1), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "value_1_thread": round(res["1t"], 1),
+            "sample": f"first 2^24 samples (128 native chunks) of the GPU input, oracle/cl_oracle.c "
+                      f"orc_rx_pipe_f32_mt (unpack+sync -> /4096 -> FIR64 -> 3/2, fp32 AVX2, OpenMP)"}, out
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with --nproc-per-node {a.gpus} (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)       # RCCL; used only for barrier + max
+
+    from cariboulite_amd import hip, synth
+    arch = hip.require_gpu()
+    taps = np.load(os.path.join(ROOT, "tests", "golden", "taps.npz"))
+
+    n = 1 << a.log2_samples
+    n_chunks = n // NATIVE_CHUNK_SAMPLES
+    words = synth.torch_smi_words(n, dev, channel=0, stream=rank)             # int32 RX words in HBM
+    pipe = hip.RxPipe(1, hip.CHANNEL_S1G, taps["fir64_c2"], taps["rs_3_2"], 3, 2, hip.PIPE_OUT_IQ)
+    n_out = pipe.out_count(n)
+    out = torch.empty((n_out, 2), dtype=torch.float32, device=dev)
+    offs = torch.full((max(n_chunks, 1),), -1, dtype=torch.int32, device=dev)
+    bad = torch.zeros(1, dtype=torch.int32, device=dev)
+    pipe.set_sync_check(offs, NATIVE_CHUNK_SAMPLES, bad)
+    assert pipe.uses_fused(n), "fused gfx950 kernel not selected"
+    stream = torch.cuda.current_stream().cuda_stream
+    L = hip.lib()
+
+    def step():
+        hip.smi_find_offsets(words, 4 * n, 4 * NATIVE_CHUNK_SAMPLES, 4 * NATIVE_CHUNK_SAMPLES, max(n_chunks, 1),
+                             offs, stream)
+        got = pipe.run(hip.PIPE_IN_SMI_WORDS, words, 0, n, out, 0, stream)
+        assert got == n_out
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    assert int(bad.item()) == 0 and int(offs.abs().max().item()) == 0, "synthetic stream lost sync?"
+
+    # per-launch duration of the pipe with HIP events on the launch stream
+    evs = [(L.clhip_event_create(), L.clhip_event_create()) for _ in range(a.steps)]
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        hip.smi_find_offsets(words, 4 * n, 4 * NATIVE_CHUNK_SAMPLES, 4 * NATIVE_CHUNK_SAMPLES, max(n_chunks, 1),
+                             offs, stream)
+        L.clhip_event_record(evs[k][0], stream)
+        pipe.run(hip.PIPE_IN_SMI_WORDS, words, 0, n, out, 0, stream)
+        L.clhip_event_record(evs[k][1], stream)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert int(bad.item()) == 0
+    kern_ms = [L.clhip_event_elapsed_ms(e0, e1) for e0, e1 in evs]
+    for e0, e1 in evs:
+        L.clhip_event_destroy(e0); L.clhip_event_destroy(e1)
+    kern_avg_s = float(np.mean(kern_ms)) / 1e3
+
+    if rank == 0:
+        value = world * n * a.steps / dt / 1e6
+        achieved = ALGO_BYTES_PER_SAMPLE * n / kern_avg_s / 1e9
+        res = {
+            "metric": "Msamples/s through unpack+FIR(64)+resample(3/2) pipe",
+            "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"config 2: 1 ch/GPU, 4 MS/s stream replayed as one 2^{a.log2_samples}-sample "
+                                   f"buffer per GPU ({n_chunks} native 512 KiB chunks), sync check + int13 unpack + "
+                                   f"64-tap FIR + 3/2 polyphase resample, CF32 out",
+                       "samples_per_gpu_per_step": n, "fir_taps": 64, "resample": "3/2", "arch": arch,
+                       "parallelism": f"{world} independent stream(s), no data-path collective"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "rx_pipe_fused_kernel<PipeCfg<64,3,2,8,0,16,256>>",
+                         "kernel_ms_avg": round(kern_avg_s * 1e3, 4), "kernel_ms_min": round(float(np.min(kern_ms)), 4),
+                         "algorithmic_bytes_per_sample": ALGO_BYTES_PER_SAMPLE,
+                         "valu_tflops": round(FLOP_PER_SAMPLE * n / kern_avg_s / 1e12, 2),
+                         "valu_frac_of_fp32_peak": round(FLOP_PER_SAMPLE * n / kern_avg_s / 1e12 / VALU_PEAK_TFLOPS, 4)},
+        }
+        if world == 1 and not a.no_cpu:
+            cb, cpu_out = cpu_baseline(taps, words, a.cpu_seconds)
+            res["cpu_baseline"] = cb
+            res["gpu_over_cpu"] = round(value / cb["value"], 1)
+            # the CPU leg doubles as a parity check of the benchmarked GPU path (zero state, same bytes)
+            pipe.reset()
+            step()
+            torch.cuda.synchronize()
+            g = out[: cpu_out.shape[0]].cpu().numpy()
+            res["max_abs_diff_vs_cpu_port"] = float(np.max(np.abs(g - cpu_out)))
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,83 @@
+"""Build the in-tree native libraries (no JIT cache: the .so files travel with the tree).
+
+    libcariboulite_hip.so   HIP kernels + C-ABI shim, hipcc --offload-arch=gfx950
+    libcariboulite_host.so  host C layer with the reference's call surface (gcc)
+"""
+import os
+import shutil
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+ROOT = os.path.dirname(PKG)
+INC = os.path.join(ROOT, "include")
+OBJ = os.path.join(CSRC, "build")
+HIP_LIB = os.path.join(PKG, "libcariboulite_hip.so")
+HOST_LIB = os.path.join(PKG, "libcariboulite_host.so")
+ARCH = "gfx950"
+
+
+def _hipcc():
+    return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_hip(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs.append(os.path.join(INC, "cariboulite_hip.h"))
+    jobs = []
+    for f in srcs:
+        src = os.path.join(CSRC, f)
+        obj = os.path.join(OBJ, f[:-4] + ".o")
+        if force or _newer(obj, [src] + hdrs):
+            jobs.append([_hipcc(), "-O3", f"--offload-arch={ARCH}", "-fPIC", "-std=c++17",
+                         "-Wall", "-Wno-unused-function", "-I", INC, "-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    objs = [os.path.join(OBJ, f[:-4] + ".o") for f in srcs]
+    if force or jobs or _newer(HIP_LIB, objs):
+        run([_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", HIP_LIB] + objs)
+    return HIP_LIB
+
+
+def build_host(force=False, verbose=False):
+    hdir = os.path.join(CSRC, "host")
+    if not os.path.isdir(hdir):
+        return None
+    srcs = sorted(os.path.join(hdir, f) for f in os.listdir(hdir) if f.endswith(".c"))
+    if not srcs:
+        return None
+    deps = srcs + [os.path.join(INC, "cariboulite_hip.h")] + \
+        [os.path.join(hdir, f) for f in os.listdir(hdir) if f.endswith(".h")]
+    if force or _newer(HOST_LIB, deps + [HIP_LIB]):
+        cmd = ["gcc", "-O2", "-g", "-std=gnu11", "-Wall", "-Wextra", "-fPIC", "-shared", "-I", INC,
+               "-o", HOST_LIB] + srcs + ["-L", PKG, "-lcariboulite_hip", "-Wl,-rpath,$ORIGIN", "-lm", "-lpthread"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return HOST_LIB
+
+
+def build_all(force=False, verbose=False):
+    build_hip(force, verbose)
+    build_host(force, verbose)
+
+
+if __name__ == "__main__":
+    import sys
+    build_all(force="--force" in sys.argv, verbose=True)

@@ -1,0 +1,126 @@
+// clhip_runtime.hip -- runtime plumbing of the C-ABI shim: device selection,
+// memory, streams, events, error string.  No kernels here.
+#include <stdarg.h>
+#include <string.h>
+
+#include "clhip_common.h"
+
+static thread_local char g_err[512] = "";
+
+extern "C" void clhip_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *clhip_last_error(void) { return g_err; }
+
+extern "C" int clhip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int clhip_set_device(int device)
+{
+    CLHIP_CHECK(hipSetDevice(device));
+    return 0;
+}
+
+extern "C" const char *clhip_arch_name(void)
+{
+    static thread_local char name[256];
+    hipDeviceProp_t prop;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return "";
+    strncpy(name, prop.gcnArchName, sizeof name - 1);
+    name[sizeof name - 1] = 0;
+    return name;
+}
+
+extern "C" void *clhip_malloc(size_t bytes)
+{
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+    if (e != hipSuccess) {
+        clhip_set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return nullptr;
+    }
+    return p;
+}
+
+extern "C" void clhip_free(void *p) { if (p) (void)hipFree(p); }
+
+extern "C" void *clhip_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        clhip_set_error("hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return nullptr;
+    }
+    return p;
+}
+
+extern "C" void clhip_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
+extern "C" int clhip_memcpy_h2d(void *d, const void *h, size_t n, void *s)
+{
+    CLHIP_CHECK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, (hipStream_t)s));
+    return 0;
+}
+extern "C" int clhip_memcpy_d2h(void *h, const void *d, size_t n, void *s)
+{
+    CLHIP_CHECK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, (hipStream_t)s));
+    return 0;
+}
+extern "C" int clhip_memcpy_d2d(void *dd, const void *ds, size_t n, void *s)
+{
+    CLHIP_CHECK(hipMemcpyAsync(dd, ds, n, hipMemcpyDeviceToDevice, (hipStream_t)s));
+    return 0;
+}
+extern "C" int clhip_memset(void *d, int v, size_t n, void *s)
+{
+    CLHIP_CHECK(hipMemsetAsync(d, v, n, (hipStream_t)s));
+    return 0;
+}
+
+extern "C" void *clhip_stream_create(void)
+{
+    hipStream_t s = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        clhip_set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+        return nullptr;
+    }
+    return (void *)s;
+}
+extern "C" void clhip_stream_destroy(void *s) { if (s) (void)hipStreamDestroy((hipStream_t)s); }
+extern "C" int clhip_stream_sync(void *s)
+{
+    CLHIP_CHECK(hipStreamSynchronize((hipStream_t)s));
+    return 0;
+}
+
+extern "C" void *clhip_event_create(void)
+{
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return (void *)e;
+}
+extern "C" void clhip_event_destroy(void *e) { if (e) (void)hipEventDestroy((hipEvent_t)e); }
+extern "C" int clhip_event_record(void *e, void *s)
+{
+    CLHIP_CHECK(hipEventRecord((hipEvent_t)e, (hipStream_t)s));
+    return 0;
+}
+extern "C" float clhip_event_elapsed_ms(void *a, void *b)
+{
+    float ms = -1.0f;
+    if (hipEventSynchronize((hipEvent_t)b) != hipSuccess) return -1.0f;
+    if (hipEventElapsedTime(&ms, (hipEvent_t)a, (hipEvent_t)b) != hipSuccess) return -1.0f;
+    return ms;
+}

@@ -1,0 +1,679 @@
+// clhip_rx_pipe.hip -- the RX pipe on gfx950:
+//   raw SMI words -> int13 I/Q (caribou_smi.c:338-378) -> x/4096
+//   (CaribouliteStream.cpp:315-321) -> FIR(T) -> [L/M polyphase | FM demod]
+//
+// Fused kernel (one launch, intermediates never leave the CU):
+//   * a workgroup owns NT*R consecutive FIR outputs of one stream; the raw
+//     words of that tile plus T + HFA samples of halo are loaded with 16-byte
+//     coalesced loads, unpacked ONCE, and staged in LDS as (I,Q) float pairs
+//     (bank-conflict-free padded layout, see lds_off());
+//   * every lane then computes R consecutive FIR outputs from a sliding
+//     window: each staged sample is read from LDS once per lane and feeds up
+//     to R packed-f32 FMAs (taps live in SGPRs, pre-scaled by 1/4096 so the
+//     int->float scale costs nothing and stays bit-identical);
+//   * the last K-1 FIR outputs of each lane are handed to the next lane
+//     through LDS, the polyphase legs (or the phase-difference demod) run
+//     from registers, and the results leave with 16-byte stores.
+// No MFMA: these are 1-D tap dot products (BASELINE.json north_star).
+//
+// Generic path (gen_* kernels): a second, plain implementation of the same
+// spec -- any T / L / M / call length / phase -- used when no fused
+// instantiation matches and as an independent cross-check in tests.
+#include <math.h>
+#include <string.h>
+
+#include <new>
+
+#include "clhip_common.h"
+
+#define MODE_IQ 0
+#define MODE_FM 1
+
+constexpr int cgcd(int a, int b) { return b == 0 ? a : cgcd(b, a % b); }
+constexpr int clcm(int a, int b) { return a / cgcd(a, b) * b; }
+constexpr int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+#define PIPE_MAX_FIR 128
+#define PIPE_MAX_RS 40
+
+struct PipeArgs {
+    const void *in;          // stream s at in + s*in_stride elements of in_kind
+    long in_stride;
+    const f32x2 *hist_in;    // [n_streams][halo] pre-FIR samples (CF32 scale) preceding `in`
+    void *out;               // f32x2 (MODE_IQ) or float (MODE_FM)
+    long out_stride;
+    long n_in;               // new input samples per stream
+    long n_out;              // outputs per stream for this call
+    int in_kind;             // CL_PIPE_IN_*
+    int channel;             // CL_CHANNEL_*
+    float in_scale;          // 4096 for integer inputs (taps carry 1/4096), 1 for CF32
+    const float *fir;        // T taps, pre-multiplied by 1/in_scale (device, read-only)
+    const float *rs;         // resampler prototype taps (device, read-only)
+    // optional device-side sync validation of raw-word input: the fused path is
+    // only valid for chunks whose sync offset is 0 (caribou_smi.c:235-292)
+    const int32_t *chunk_offs;   // [n_streams][chunks_per_stream] from clhip_smi_find_offsets, or NULL
+    long chunk_samples;          // samples per chunk
+    long chunks_per_stream;
+    int32_t *bad_flag;           // set to 1 when a needed chunk has offs != 0 (tile writes nothing)
+};
+
+template <int T_, int L_, int M_, int KP_, int MODE_, int R_, int NT_>
+struct PipeCfg {
+    static constexpr int T = T_, L = L_, M = M_, KP = KP_, MODE = MODE_, R = R_, NT = NT_;
+    static constexpr bool RESAMP = !(L == 1 && M == 1);
+    static constexpr int HF = MODE == MODE_FM ? 1 : (RESAMP ? KP - 1 : 0);   // FIR outputs of history
+    static constexpr int HFA = HF == 0 ? 0 : round_up(HF, clcm(4, M));      // recomputed per tile
+    static constexpr int NFIR = NT * R;             // FIR outputs per tile
+    static constexpr int TILE_IN = NFIR - HFA;      // new inputs per tile
+    static constexpr int HALO = T + HFA;            // local 0 <-> global S - HALO
+    static constexpr int NLOAD = NFIR + T;          // staged samples
+    static constexpr int NOUT = MODE == MODE_FM ? R : R * L / M;             // outputs per lane
+    static constexpr int SKIP0 = MODE == MODE_FM ? HFA : HFA * L / M;        // lane 0's history-only outputs
+    static constexpr int TSTRIDE = (R * 8 + 16);    // bytes between lanes' windows in LDS
+    static constexpr int IN_BYTES = NLOAD * 8 + (NLOAD / R + 1) * 16;
+    static constexpr int TAIL_STRIDE = 80;          // 8 float2 + 16 B pad: conflict-free b128
+    static constexpr int TAIL_BYTES = HF ? NT * TAIL_STRIDE : 0;
+    static constexpr int LDS_BYTES = IN_BYTES > TAIL_BYTES ? IN_BYTES : TAIL_BYTES;
+    static_assert(T % 4 == 0 && R % 4 == 0, "T and R must be multiples of 4");
+    static_assert((R * L) % M == 0 && (HFA * L) % M == 0, "lane outputs must be integral");
+    static_assert(HF <= 8 && HF <= R, "history too long for the tail exchange");
+    static_assert(MODE == MODE_FM || (NOUT % 2 == 0 && SKIP0 % 2 == 0), "16-byte stores of float2 pairs");
+    static_assert(MODE != MODE_FM || (NOUT % 4 == 0 && SKIP0 % 4 == 0), "16-byte stores of 4 floats");
+};
+
+// LDS byte offset of staged sample j: 8 B per (I,Q) pair plus a 16-byte pad
+// after every R samples, so that lane windows start 8R+16 bytes apart and the
+// 16 lanes a ds_read_b128 services together hit 64 distinct banks.
+template <int R> __device__ __forceinline__ int lds_off(int j) { return j * 8 + (j / R) * 16; }
+
+__device__ __forceinline__ f32x2 load_sample(const PipeArgs &a, const void *base, long g)
+{
+    // one pre-FIR sample in the LDS domain (unscaled integers for integer inputs)
+    if (a.in_kind == CL_PIPE_IN_SMI_WORDS) {
+        const uint32_t w = ((const uint32_t *)base)[g];
+        const int fa = clhip_field_a(w), fb = clhip_field_b(w);
+        f32x2 r = {(float)(a.channel == CL_CHANNEL_HIF ? fb : fa), (float)(a.channel == CL_CHANNEL_HIF ? fa : fb)};
+        return r;
+    } else if (a.in_kind == CL_PIPE_IN_CS16) {
+        const uint32_t w = ((const uint32_t *)base)[g];
+        f32x2 r = {(float)(int16_t)(w & 0xFFFF), (float)(int16_t)(w >> 16)};
+        return r;
+    } else {
+        return ((const f32x2 *)base)[g];
+    }
+}
+
+template <int KIND>
+__device__ __forceinline__ void convert4(const PipeArgs &a, const u32x4 w, f32x2 (&v)[4])
+{
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if constexpr (KIND == CL_PIPE_IN_SMI_WORDS) {
+            const int fa = clhip_field_a(w[k]), fb = clhip_field_b(w[k]);
+            v[k].x = (float)(a.channel == CL_CHANNEL_HIF ? fb : fa);
+            v[k].y = (float)(a.channel == CL_CHANNEL_HIF ? fa : fb);
+        } else {
+            v[k].x = (float)(int16_t)(w[k] & 0xFFFF);
+            v[k].y = (float)(int16_t)(w[k] >> 16);
+        }
+    }
+}
+
+template <int R>
+__device__ __forceinline__ void lds_put4(unsigned char *lds, int j, const f32x2 (&v)[4])
+{
+    unsigned char *d = lds + lds_off<R>(j);
+    f32x4 q0 = {v[0].x, v[0].y, v[1].x, v[1].y}, q1 = {v[2].x, v[2].y, v[3].x, v[3].y};
+    *(f32x4 *)d = q0;
+    *(f32x4 *)(d + 16) = q1;
+}
+
+// Stage samples [S - HALO, S - HALO + NLOAD) of one stream into LDS, unpacked
+// to (I,Q) floats in the LDS domain.  Interior tiles issue all their 16-byte
+// loads before the first conversion; edge tiles (stream start: history;
+// stream end: zero fill) take the checked path.
+template <class C, int KIND>
+__device__ __forceinline__ void stage_tile(const PipeArgs &a, const void *in, const f32x2 *hist, long S,
+                                           unsigned char *lds, int t)
+{
+    constexpr int R = C::R, NT = C::NT;
+    constexpr int NG = C::NLOAD / 4;                 // groups of 4 samples
+    constexpr int IT = (NG + NT - 1) / NT;
+    const long g0 = S - C::HALO;
+    if (g0 >= 0 && g0 + C::NLOAD <= a.n_in) {        // wave-uniform
+        if constexpr (KIND == CL_PIPE_IN_CF32) {
+            f32x4 p0[IT], p1[IT];
+#pragma unroll
+            for (int it = 0; it < IT; it++) {
+                const int grp = t + it * NT;
+                if (grp < NG) {
+                    p0[it] = *(const f32x4 *)((const f32x2 *)in + g0 + 4 * grp);
+                    p1[it] = *(const f32x4 *)((const f32x2 *)in + g0 + 4 * grp + 2);
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < IT; it++) {
+                const int grp = t + it * NT;
+                if (grp < NG) {
+                    unsigned char *d = lds + lds_off<R>(4 * grp);
+                    *(f32x4 *)d = p0[it];
+                    *(f32x4 *)(d + 16) = p1[it];
+                }
+            }
+        } else {
+            u32x4 w[IT];
+#pragma unroll
+            for (int it = 0; it < IT; it++) {
+                const int grp = t + it * NT;
+                if (grp < NG) w[it] = __builtin_nontemporal_load((const u32x4 *)((const uint32_t *)in + g0 + 4 * grp));
+            }
+#pragma unroll
+            for (int it = 0; it < IT; it++) {
+                const int grp = t + it * NT;
+                if (grp < NG) {
+                    f32x2 v[4];
+                    convert4<KIND>(a, w[it], v);
+                    lds_put4<R>(lds, 4 * grp, v);
+                }
+            }
+        }
+        return;
+    }
+    for (int j = t * 4; j < C::NLOAD; j += NT * 4) {
+        const long g = g0 + j;
+        f32x2 v[4];
+        if (g < 0) {                       // HALO % 4 == 0: the whole group is history
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = hist[C::HALO + g + k] * a.in_scale;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                f32x2 z = {0.f, 0.f};
+                v[k] = (g + k < a.n_in) ? load_sample(a, in, g + k) : z;
+            }
+        }
+        lds_put4<R>(lds, j, v);
+    }
+}
+
+template <class C>
+__global__ __launch_bounds__(C::NT) void rx_pipe_fused_kernel(const PipeArgs a)
+{
+    constexpr int T = C::T, R = C::R, NT = C::NT, L = C::L, M = C::M, KP = C::KP, HF = C::HF;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+    const int t = threadIdx.x;
+    const int s = blockIdx.y;
+    const long S = (long)blockIdx.x * C::TILE_IN;           // first new input of this tile
+    const void *in = a.in_kind == CL_PIPE_IN_CF32
+                         ? (const void *)((const f32x2 *)a.in + (long)s * a.in_stride)
+                         : (const void *)((const uint32_t *)a.in + (long)s * a.in_stride);
+    const f32x2 *hist = a.hist_in + (long)s * C::HALO;
+
+    if (a.chunk_offs) {                    // wave-uniform: validate the chunks this tile reads
+        const long first = S - C::HALO > 0 ? S - C::HALO : 0;
+        const long last = (S + C::TILE_IN < a.n_in ? S + C::TILE_IN : a.n_in) - 1;
+        int bad = 0;
+        for (long c = first / a.chunk_samples; c <= last / a.chunk_samples; c++)
+            bad |= a.chunk_offs[(long)s * a.chunks_per_stream + c] != 0;
+        if (bad) {
+            if (t == 0) atomicOr(a.bad_flag, 1);
+            return;
+        }
+    }
+
+    // ---------------- stage [S - HALO, S - HALO + NLOAD) into LDS ----------------
+    switch (a.in_kind) {                   // wave-uniform
+    case CL_PIPE_IN_SMI_WORDS: stage_tile<C, CL_PIPE_IN_SMI_WORDS>(a, in, hist, S, lds, t); break;
+    case CL_PIPE_IN_CS16: stage_tile<C, CL_PIPE_IN_CS16>(a, in, hist, S, lds, t); break;
+    default: stage_tile<C, CL_PIPE_IN_CF32>(a, in, hist, S, lds, t); break;
+    }
+    __syncthreads();
+
+    // ---------------- FIR: R outputs per lane from a sliding window ----------------
+    // lane window w = 0..T+R-1 is staged sample R*t + w; output r (FIR index
+    // R*t + r of the tile) uses tap k = T + r - w of window sample w.  The
+    // window is walked in blocks of R samples: block b pairs sample j of the
+    // block with tap (T - R*b) + (r - j), so each block needs 2R-1 consecutive
+    // taps (scalar loads -> SGPRs) and R samples (one ds_read_b128 per pair).
+    // Every accumulator sees its taps in descending k order.
+    static_assert(T % R == 0, "window is walked in blocks of R samples");
+    f32x2 acc[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) { acc[r].x = 0.f; acc[r].y = 0.f; }
+    const unsigned char *win = lds + t * C::TSTRIDE;
+    const float *__restrict__ h = a.fir;
+    f32x2 x[R];
+#define LOAD_BLOCK(B)                                                              \
+    _Pragma("unroll") for (int j = 0; j < R; j += 2) {                             \
+        const f32x4 xx = *(const f32x4 *)(win + (B) * C::TSTRIDE + j * 8);         \
+        x[j] = xx.xy; x[j + 1] = xx.zw;                                            \
+    }
+    {   // first block: k = T + r - j < T  <=>  r < j
+        LOAD_BLOCK(0)
+        float tp[R];
+#pragma unroll
+        for (int i = 1; i < R; i++) tp[i] = h[T - i];            // tp[i] = h[T - i]
+#pragma unroll
+        for (int j = 1; j < R; j++)
+#pragma unroll
+            for (int r = 0; r < j; r++) acc[r] += x[j] * tp[j - r];
+    }
+#pragma unroll 1
+    for (int b = 1; b < T / R; b++) {
+        LOAD_BLOCK(b)
+        const float *__restrict__ hb = h + (T - R * b);          // k = hb index (r - j) in [-(R-1), R-1]
+        float tp[2 * R - 1];
+#pragma unroll
+        for (int i = 0; i < 2 * R - 1; i++) tp[i] = hb[i - (R - 1)];
+#pragma unroll
+        for (int j = 0; j < R; j++)
+#pragma unroll
+            for (int r = 0; r < R; r++) acc[r] += x[j] * tp[(R - 1) + r - j];
+    }
+    {   // last block: k = r - j >= 0
+        LOAD_BLOCK(T / R)
+        float tp[R];
+#pragma unroll
+        for (int i = 0; i < R; i++) tp[i] = h[i];
+#pragma unroll
+        for (int j = 0; j < R; j++)
+#pragma unroll
+            for (int r = j; r < R; r++) acc[r] += x[j] * tp[r - j];
+    }
+#undef LOAD_BLOCK
+
+    // ---------------- second stage ----------------
+    // yy[i], i = -HF..R-1: FIR outputs R*t + i of the tile
+    f32x2 yh[HF > 0 ? HF : 1];
+    if constexpr (HF > 0) {
+        __syncthreads();                       // every wave is done with the staged inputs
+        unsigned char *tl = lds + t * C::TAIL_STRIDE;
+#pragma unroll
+        for (int i = 0; i < HF; i++) *(f32x2 *)(tl + 8 * i) = acc[R - HF + i];
+        __syncthreads();
+        const unsigned char *pl = lds + (t > 0 ? t - 1 : 0) * C::TAIL_STRIDE;
+#pragma unroll
+        for (int i = 0; i < HF; i++) yh[i] = *(const f32x2 *)(pl + 8 * i);
+    }
+#define YY(i) ((i) < 0 ? yh[HF + (i)] : acc[(i)])
+
+    const long fir0 = S - C::HFA + (long)R * t;          // global index of acc[0]
+    if constexpr (C::MODE == MODE_IQ) {
+        constexpr int NOUT = C::NOUT;
+        f32x2 o[NOUT];
+        if constexpr (C::RESAMP) {
+            float rsv[KP * L];
+#pragma unroll
+            for (int i = 0; i < KP * L; i++) rsv[i] = a.rs[i];
+#pragma unroll
+            for (int m = 0; m < NOUT; m++) {
+                const int tp = m * M, b = tp / L, p = tp % L;
+                f32x2 sacc = {0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < KP; i++) sacc += YY(b - i) * rsv[p + i * L];
+                o[m] = sacc;
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < NOUT; m++) o[m] = acc[m];
+        }
+        // global output index of o[0]; lane 0 of every tile starts with SKIP0 history-only outputs
+        const long o0 = (S - C::HFA) / M * L + (long)NOUT * t;   // (S-HFA)*L/M, exact
+        const long lo = S / M * L, hi = a.n_out;
+        f32x2 *out = (f32x2 *)a.out + (long)s * a.out_stride;
+#pragma unroll
+        for (int m = 0; m < NOUT; m += 2) {
+            const long gi = o0 + m;
+            if (gi >= lo && gi + 2 <= hi) {
+                f32x4 v = {o[m].x, o[m].y, o[m + 1].x, o[m + 1].y};
+                __builtin_nontemporal_store(v, (f32x4 *)(out + gi));
+            } else {
+                if (gi >= lo && gi < hi) out[gi] = o[m];
+                if (gi + 1 >= lo && gi + 1 < hi) out[gi + 1] = o[m + 1];
+            }
+        }
+    } else {
+        // FM phase-difference demod: atan2(Im z, Re z), z = y[n] conj(y[n-1])
+        float o[R];
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+            const f32x2 c = YY(i), p = YY(i - 1);
+            const float re = c.x * p.x + c.y * p.y, im = c.y * p.x - c.x * p.y;
+            o[i] = atan2f(im, re);
+        }
+        const long lo = S, hi = a.n_out;
+        float *out = (float *)a.out + (long)s * a.out_stride;
+#pragma unroll
+        for (int m = 0; m < R; m += 4) {
+            const long gi = fir0 + m;
+            if (gi >= lo && gi + 4 <= hi) {
+                f32x4 v = {o[m], o[m + 1], o[m + 2], o[m + 3]};
+                __builtin_nontemporal_store(v, (f32x4 *)(out + gi));
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (gi + k >= lo && gi + k < hi) out[gi + k] = o[m + k];
+            }
+        }
+    }
+#undef YY
+}
+
+// ---------------------------------------------------------------------------
+// history update: hist_out = last `halo` samples of [hist_in | in[0..n_in)]
+// ---------------------------------------------------------------------------
+__global__ void pipe_update_hist_kernel(PipeArgs a, int halo, f32x2 *__restrict__ hist_out)
+{
+    const int s = blockIdx.x;
+    const void *in = a.in_kind == CL_PIPE_IN_CF32
+                         ? (const void *)((const f32x2 *)a.in + (long)s * a.in_stride)
+                         : (const void *)((const uint32_t *)a.in + (long)s * a.in_stride);
+    const float inv = 1.0f / a.in_scale;
+    for (int j = threadIdx.x; j < halo; j += blockDim.x) {
+        const long g = a.n_in - halo + j;         // position in the new-input index space
+        f32x2 v;
+        if (g >= 0) v = load_sample(a, in, g) * inv;
+        else if (halo + g >= 0) v = a.hist_in[(long)s * halo + halo + g];
+        else { v.x = 0.f; v.y = 0.f; }
+        hist_out[(long)s * halo + j] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// generic path: three plain kernels through device workspaces
+//   X[s] = [hist (halo) | converted input (n)]           (CF32 scale)
+//   Y[s][i] = FIR output at input index i - HFg,  i in [0, HFg + n)
+//   out: resampler / FM demod / copy of Y
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gen_stage_kernel(PipeArgs a, int halo, f32x2 *__restrict__ X, long x_stride)
+{
+    const int s = blockIdx.y;
+    const void *in = a.in_kind == CL_PIPE_IN_CF32
+                         ? (const void *)((const f32x2 *)a.in + (long)s * a.in_stride)
+                         : (const void *)((const uint32_t *)a.in + (long)s * a.in_stride);
+    const float inv = 1.0f / a.in_scale;
+    f32x2 *x = X + (long)s * x_stride;
+    const long total = halo + a.n_in;
+    for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += (long)gridDim.x * blockDim.x)
+        x[j] = j < halo ? a.hist_in[(long)s * halo + j] : load_sample(a, in, j - halo) * inv;
+}
+
+__global__ __launch_bounds__(256) void gen_fir_kernel(const f32x2 *__restrict__ X, long x_stride, int halo,
+                                                      const float *__restrict__ taps, int T, int hfg,
+                                                      long n_in, f32x2 *__restrict__ Y, long y_stride)
+{
+    const int s = blockIdx.y;
+    const f32x2 *x = X + (long)s * x_stride + halo;      // x[0] = first new input; negative = history
+    f32x2 *y = Y + (long)s * y_stride;
+    const long total = hfg + n_in;
+    for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += (long)gridDim.x * blockDim.x) {
+        const long n = j - hfg;
+        f32x2 accv = {0.f, 0.f};
+        for (int k = T - 1; k >= 0; k--) accv += x[n - k] * taps[k];   // same order as the fused kernel
+        y[j] = accv;
+    }
+}
+
+__global__ __launch_bounds__(256) void gen_resample_kernel(const f32x2 *__restrict__ Y, long y_stride, int hfg,
+                                                           const float *__restrict__ rs, int n_rs, int L, int M,
+                                                           unsigned long long n0, long n_out,
+                                                           f32x2 *__restrict__ out, long out_stride)
+{
+    const int s = blockIdx.y;
+    const f32x2 *y = Y + (long)s * y_stride + hfg;       // y[0] = FIR output at the first new input
+    f32x2 *o = out + (long)s * out_stride;
+    const unsigned long long m0 = (n0 * L + M - 1) / M;
+    const int KP = (n_rs + L - 1) / L;
+    for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < n_out; j += (long)gridDim.x * blockDim.x) {
+        const unsigned long long tp = (m0 + j) * M;
+        const long b = (long)(tp / L - n0);
+        const int p = (int)(tp % L);
+        f32x2 accv = {0.f, 0.f};
+        for (int i = 0; i < KP; i++) {
+            const int k = p + i * L;
+            if (k < n_rs) accv += y[b - i] * rs[k];
+        }
+        o[j] = accv;
+    }
+}
+
+__global__ __launch_bounds__(256) void gen_fm_kernel(const f32x2 *__restrict__ Y, long y_stride, int hfg,
+                                                     long n, float *__restrict__ out, long out_stride)
+{
+    const int s = blockIdx.y;
+    const f32x2 *y = Y + (long)s * y_stride + hfg;
+    float *o = out + (long)s * out_stride;
+    for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (long)gridDim.x * blockDim.x) {
+        const f32x2 c = y[j], p = y[j - 1];
+        o[j] = atan2f(c.y * p.x - c.x * p.y, c.x * p.x + c.y * p.y);
+    }
+}
+
+__global__ __launch_bounds__(256) void gen_copy_kernel(const f32x2 *__restrict__ Y, long y_stride, int hfg, long n,
+                                                       f32x2 *__restrict__ out, long out_stride)
+{
+    const int s = blockIdx.y;
+    const f32x2 *y = Y + (long)s * y_stride + hfg;
+    f32x2 *o = out + (long)s * out_stride;
+    for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (long)gridDim.x * blockDim.x) o[j] = y[j];
+}
+
+// ---------------------------------------------------------------------------
+// host side of the pipe object
+// ---------------------------------------------------------------------------
+typedef PipeCfg<64, 3, 2, 8, MODE_IQ, 16, 256> CfgC2;     // config 2: FIR64 + 3/2
+typedef PipeCfg<64, 1, 1, 1, MODE_FM, 16, 256> CfgC3;     // config 3: FIR64 + FM demod
+typedef PipeCfg<128, 5, 4, 8, MODE_IQ, 16, 256> CfgC4;    // config 4: FIR128 + 5/4
+typedef PipeCfg<64, 1, 1, 1, MODE_IQ, 16, 256> CfgF64;    // FIR64 only
+typedef PipeCfg<128, 1, 1, 1, MODE_IQ, 16, 256> CfgF128;  // FIR128 only
+
+struct clhip_rx_pipe {
+    int n_streams, channel, T, n_rs, L, M, mode;
+    float fir[PIPE_MAX_FIR], rs[PIPE_MAX_RS];
+    int halo;                      // history length kept per stream (pre-FIR samples)
+    int hfg;                       // FIR-output history the second stage needs
+    f32x2 *hist[2];                // ping-pong [n_streams][halo]
+    int cur;
+    unsigned long long n_total;    // inputs consumed so far (per stream)
+    bool force_generic;
+    int fused_id;                  // -1 = none
+    // generic workspaces
+    const int32_t *chk_offs; size_t chk_chunk_samples; int32_t *chk_flag;   // optional sync validation
+    float *d_fir, *d_fir_int, *d_rs;   // taps; d_fir_int = taps/4096 for integer inputs
+    f32x2 *X, *Y;
+    size_t x_cap, y_cap;           // elements per stream
+};
+
+static int fused_lookup(int T, int L, int M, int n_rs, int mode, int *halo)
+{
+    const bool rs = !(L == 1 && M == 1);
+    if (mode == CL_PIPE_OUT_IQ && T == 64 && L == 3 && M == 2 && n_rs == 24) { *halo = CfgC2::HALO; return 0; }
+    if (mode == CL_PIPE_OUT_FM_DEMOD && T == 64 && !rs) { *halo = CfgC3::HALO; return 1; }
+    if (mode == CL_PIPE_OUT_IQ && T == 128 && L == 5 && M == 4 && n_rs == 40) { *halo = CfgC4::HALO; return 2; }
+    if (mode == CL_PIPE_OUT_IQ && T == 64 && !rs) { *halo = CfgF64::HALO; return 3; }
+    if (mode == CL_PIPE_OUT_IQ && T == 128 && !rs) { *halo = CfgF128::HALO; return 4; }
+    return -1;
+}
+
+extern "C" clhip_rx_pipe *clhip_rx_pipe_create(int n_streams, int channel, const float *h_fir, int n_fir,
+                                               const float *h_rs, int n_rs, int up, int down, int out_mode)
+{
+    if (n_streams <= 0 || n_fir <= 0 || n_fir > PIPE_MAX_FIR || !h_fir || up <= 0 || down <= 0) {
+        clhip_set_error("clhip_rx_pipe_create: bad arguments (1..%d FIR taps)", PIPE_MAX_FIR);
+        return nullptr;
+    }
+    const bool resamp = !(up == 1 && down == 1);
+    if (resamp && (!h_rs || n_rs <= 0 || n_rs > PIPE_MAX_RS)) {
+        clhip_set_error("clhip_rx_pipe_create: resampler needs 1..%d prototype taps", PIPE_MAX_RS);
+        return nullptr;
+    }
+    if (out_mode == CL_PIPE_OUT_FM_DEMOD && resamp) {
+        clhip_set_error("clhip_rx_pipe_create: FM demod output does not take a resampler");
+        return nullptr;
+    }
+    clhip_rx_pipe *p = new (std::nothrow) clhip_rx_pipe();
+    if (!p) return nullptr;
+    memset(p, 0, sizeof *p);
+    p->n_streams = n_streams; p->channel = channel; p->T = n_fir; p->L = up; p->M = down;
+    p->n_rs = resamp ? n_rs : 0; p->mode = out_mode;
+    memcpy(p->fir, h_fir, sizeof(float) * n_fir);
+    if (resamp) memcpy(p->rs, h_rs, sizeof(float) * n_rs);
+    const int kp = resamp ? (n_rs + up - 1) / up : 1;
+    p->hfg = out_mode == CL_PIPE_OUT_FM_DEMOD ? 1 : (resamp ? kp - 1 : 0);
+    int halo = 0;
+    p->fused_id = fused_lookup(n_fir, up, down, p->n_rs, out_mode, &halo);
+    p->halo = p->fused_id >= 0 ? halo : round_up(n_fir - 1 + p->hfg, 4) + 4;
+    const size_t hb = sizeof(f32x2) * (size_t)n_streams * p->halo;
+    for (int i = 0; i < 2; i++) {
+        p->hist[i] = (f32x2 *)clhip_malloc(hb);
+        if (!p->hist[i]) { clhip_rx_pipe_destroy(p); return nullptr; }
+        (void)hipMemset(p->hist[i], 0, hb);
+    }
+    p->d_fir = (float *)clhip_malloc(sizeof(float) * PIPE_MAX_FIR);
+    p->d_fir_int = (float *)clhip_malloc(sizeof(float) * PIPE_MAX_FIR);
+    p->d_rs = (float *)clhip_malloc(sizeof(float) * PIPE_MAX_RS);
+    if (!p->d_fir || !p->d_fir_int || !p->d_rs) { clhip_rx_pipe_destroy(p); return nullptr; }
+    float scaled[PIPE_MAX_FIR];
+    for (int k = 0; k < PIPE_MAX_FIR; k++) scaled[k] = p->fir[k] / 4096.0f;   // exact: power of two
+    (void)hipMemcpy(p->d_fir, p->fir, sizeof(float) * PIPE_MAX_FIR, hipMemcpyHostToDevice);
+    (void)hipMemcpy(p->d_fir_int, scaled, sizeof(float) * PIPE_MAX_FIR, hipMemcpyHostToDevice);
+    (void)hipMemcpy(p->d_rs, p->rs, sizeof(float) * PIPE_MAX_RS, hipMemcpyHostToDevice);
+    return p;
+}
+
+extern "C" void clhip_rx_pipe_destroy(clhip_rx_pipe *p)
+{
+    if (!p) return;
+    clhip_free(p->hist[0]); clhip_free(p->hist[1]);
+    clhip_free(p->d_fir); clhip_free(p->d_fir_int); clhip_free(p->d_rs);
+    clhip_free(p->X); clhip_free(p->Y);
+    delete p;
+}
+
+extern "C" void clhip_rx_pipe_reset(clhip_rx_pipe *p)
+{
+    const size_t hb = sizeof(f32x2) * (size_t)p->n_streams * p->halo;
+    (void)hipMemset(p->hist[0], 0, hb);
+    (void)hipMemset(p->hist[1], 0, hb);
+    p->cur = 0; p->n_total = 0;
+}
+
+extern "C" void clhip_rx_pipe_force_generic(clhip_rx_pipe *p, int on) { p->force_generic = on != 0; }
+
+extern "C" void clhip_rx_pipe_set_sync_check(clhip_rx_pipe *p, const int32_t *d_offs, size_t chunk_samples,
+                                             int32_t *d_bad_flag)
+{
+    p->chk_offs = d_offs; p->chk_chunk_samples = chunk_samples; p->chk_flag = d_bad_flag;
+}
+
+extern "C" size_t clhip_rx_pipe_out_count(const clhip_rx_pipe *p, size_t n_in)
+{
+    if (p->mode == CL_PIPE_OUT_FM_DEMOD || (p->L == 1 && p->M == 1)) return n_in;
+    const unsigned long long n0 = p->n_total, n1 = n0 + n_in;
+    return (size_t)((n1 * p->L + p->M - 1) / p->M - (n0 * p->L + p->M - 1) / p->M);
+}
+
+extern "C" int clhip_rx_pipe_uses_fused(const clhip_rx_pipe *p, size_t n_in, int in_kind)
+{
+    (void)n_in;
+    if (p->force_generic || p->fused_id < 0) return 0;
+    if (in_kind < 0 || in_kind > 2) return 0;
+    // the tile-local polyphase pattern needs the call to start on a phase-0 input
+    if (((p->n_total % (unsigned long long)p->M) * p->L) % p->M != 0) return 0;
+    return 1;
+}
+
+template <class C>
+static int launch_fused(const PipeArgs &a, int n_streams, hipStream_t s)
+{
+    const long tiles = (a.n_in + C::TILE_IN - 1) / C::TILE_IN;
+    if (tiles <= 0) return 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)rx_pipe_fused_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  C::LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(rx_pipe_fused_kernel<C>, dim3((unsigned)tiles, n_streams), dim3(C::NT), C::LDS_BYTES, s, a);
+    CLHIP_CHECK_LAUNCH();
+    return 0;
+}
+
+static int ensure_ws(clhip_rx_pipe *p, size_t n_in)
+{
+    const size_t xe = p->halo + n_in, ye = p->hfg + n_in;
+    if (xe > p->x_cap) {
+        clhip_free(p->X);
+        p->X = (f32x2 *)clhip_malloc(sizeof(f32x2) * xe * p->n_streams);
+        p->x_cap = p->X ? xe : 0;
+        if (!p->X) return -1;
+    }
+    if (ye > p->y_cap) {
+        clhip_free(p->Y);
+        p->Y = (f32x2 *)clhip_malloc(sizeof(f32x2) * ye * p->n_streams);
+        p->y_cap = p->Y ? ye : 0;
+        if (!p->Y) return -1;
+    }
+    return 0;
+}
+
+extern "C" long clhip_rx_pipe_run(clhip_rx_pipe *p, int in_kind, const void *d_in, size_t in_stride,
+                                  size_t n_in, void *d_out, size_t out_stride, void *stream)
+{
+    if (!p || in_kind < 0 || in_kind > 2) { clhip_set_error("clhip_rx_pipe_run: bad arguments"); return -1; }
+    if (n_in == 0) return 0;
+    if (!d_in || !d_out) { clhip_set_error("clhip_rx_pipe_run: null buffer"); return -1; }
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n_out = clhip_rx_pipe_out_count(p, n_in);
+
+    PipeArgs a;
+    memset(&a, 0, sizeof a);
+    a.in = d_in; a.in_stride = (long)in_stride;
+    a.hist_in = p->hist[p->cur];
+    a.out = d_out; a.out_stride = (long)out_stride;
+    a.n_in = (long)n_in; a.n_out = (long)n_out;
+    a.in_kind = in_kind; a.channel = p->channel;
+    a.in_scale = in_kind == CL_PIPE_IN_CF32 ? 1.0f : 4096.0f;
+    a.fir = in_kind == CL_PIPE_IN_CF32 ? p->d_fir : p->d_fir_int;
+    a.rs = p->d_rs;
+    if (in_kind == CL_PIPE_IN_SMI_WORDS && p->chk_offs && p->chk_flag && p->chk_chunk_samples) {
+        a.chunk_offs = p->chk_offs; a.chunk_samples = (long)p->chk_chunk_samples;
+        a.chunks_per_stream = (long)clhip_div_up(n_in, p->chk_chunk_samples);
+        a.bad_flag = p->chk_flag;
+    }
+
+    if (clhip_rx_pipe_uses_fused(p, n_in, in_kind)) {
+        int rc = -1;
+        switch (p->fused_id) {
+        case 0: rc = launch_fused<CfgC2>(a, p->n_streams, s); break;
+        case 1: rc = launch_fused<CfgC3>(a, p->n_streams, s); break;
+        case 2: rc = launch_fused<CfgC4>(a, p->n_streams, s); break;
+        case 3: rc = launch_fused<CfgF64>(a, p->n_streams, s); break;
+        case 4: rc = launch_fused<CfgF128>(a, p->n_streams, s); break;
+        }
+        if (rc) return -1;
+    } else {
+        if (ensure_ws(p, n_in)) return -1;
+        const unsigned gx = (unsigned)(clhip_div_up(p->halo + n_in, 256) > 4096 ? 4096 : clhip_div_up(p->halo + n_in, 256));
+        dim3 grid(gx, p->n_streams), block(256);
+        hipLaunchKernelGGL(gen_stage_kernel, grid, block, 0, s, a, p->halo, p->X, (long)p->x_cap);
+        hipLaunchKernelGGL(gen_fir_kernel, grid, block, 0, s, p->X, (long)p->x_cap, p->halo, p->d_fir, p->T, p->hfg,
+                           (long)n_in, p->Y, (long)p->y_cap);
+        if (p->mode == CL_PIPE_OUT_FM_DEMOD)
+            hipLaunchKernelGGL(gen_fm_kernel, grid, block, 0, s, p->Y, (long)p->y_cap, p->hfg, (long)n_in,
+                               (float *)d_out, (long)out_stride);
+        else if (p->L == 1 && p->M == 1)
+            hipLaunchKernelGGL(gen_copy_kernel, grid, block, 0, s, p->Y, (long)p->y_cap, p->hfg, (long)n_in,
+                               (f32x2 *)d_out, (long)out_stride);
+        else
+            hipLaunchKernelGGL(gen_resample_kernel, grid, block, 0, s, p->Y, (long)p->y_cap, p->hfg, p->d_rs, p->n_rs,
+                               p->L, p->M, p->n_total, (long)n_out, (f32x2 *)d_out, (long)out_stride);
+        CLHIP_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(pipe_update_hist_kernel, dim3(p->n_streams), dim3(128), 0, s, a, p->halo, p->hist[p->cur ^ 1]);
+    CLHIP_CHECK_LAUNCH();
+    p->cur ^= 1;
+    p->n_total += n_in;
+    return (long)n_out;
+}

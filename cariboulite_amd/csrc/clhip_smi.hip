@@ -1,0 +1,404 @@
+// clhip_smi.hip -- SMI byte-stream integer stages for gfx950:
+//   sync search   (caribou_smi.c:235-292)
+//   int13 unpack  (caribou_smi.c:295-393) fused with the Soapy RX conversions
+//                 (soapy_api/CaribouliteStream.cpp:304-367)
+//   TX pack       (caribou_smi.c:684-717)
+//   CS16 <-> CF32 / CF64 / CS8 conversions (CaribouliteStream.cpp:199-244)
+// All HBM-bound byte/integer work: one 16-byte load per lane, bit-field
+// extracts, 16-byte stores; results are bit-exact with the reference.
+#include "clhip_common.h"
+
+#define SYNC_MASK 0xC001C000u
+#define SYNC_BITS 0x80004000u
+
+// ---------------------------------------------------------------------------
+// sync search
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t ld_u32_bytes(const uint8_t *p)
+{
+    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+
+__device__ __forceinline__ bool sync4_bytes(const uint8_t *p)
+{
+    bool ok = true;
+#pragma unroll
+    for (int w = 0; w < 4; w++) ok = ok && ((ld_u32_bytes(p + 4 * w) & SYNC_MASK) == SYNC_BITS);
+    return ok;
+}
+
+// One workgroup per chunk.  Common case (aligned stream): the first test
+// passes and the kernel ends after 16 bytes.  Otherwise the chunk is scanned
+// in segments with first-match (smallest offset) semantics.
+__global__ __launch_bounds__(256) void smi_find_offsets_kernel(
+    const uint8_t *__restrict__ bytes, size_t total, size_t stride, size_t chunk_len,
+    int n_chunks, int32_t *__restrict__ offs_out)
+{
+    const int c = blockIdx.x;
+    const int tid = threadIdx.x;
+    if (c >= n_chunks) return;
+    const size_t start = (size_t)c * stride;
+    const size_t len = start >= total ? 0 : (chunk_len < total - start ? chunk_len : total - start);
+    const uint8_t *p = bytes + start;
+    if (len <= 16) {                    // caribou_smi.c:240-243
+        if (tid == 0) offs_out[c] = 0;
+        return;
+    }
+    const size_t limit = len - 16;      // candidates: offs in [0, limit)
+
+    __shared__ int s_found;
+    if (tid == 0) s_found = sync4_bytes(p) ? 0 : 0x7fffffff;
+    __syncthreads();
+    if (s_found == 0) {
+        if (tid == 0) offs_out[c] = 0;
+        return;
+    }
+
+    const bool aligned = (((uintptr_t)p) & 3) == 0;
+    if (aligned) {
+        // word j covers byte offsets 4j..4j+3; the test at offset 4j+s needs
+        // aligned words j..j+4 (funnel-shifted by s bytes).
+        const uint32_t *w = (const uint32_t *)p;
+        const size_t n_words_cand = (limit + 3) / 4;       // words holding candidate offsets
+        for (size_t base = 0; base < n_words_cand; base += 256) {
+            size_t j = base + tid;
+            int best = 0x7fffffff;
+            if (j < n_words_cand) {
+                // words j..j+3 are always inside the chunk (4j < len-16); the
+                // fifth one may straddle its end
+                uint32_t v[5];
+#pragma unroll
+                for (int k = 0; k < 4; k++) v[k] = w[j + k];
+                const size_t b4 = 4 * (j + 4);
+                if (b4 + 4 <= len) v[4] = w[j + 4];
+                else {               // ragged chunk tail: assemble the bytes that exist
+                    v[4] = 0;
+                    for (int t = 0; t < 4; t++)
+                        if (b4 + t < len) v[4] |= (uint32_t)p[b4 + t] << (8 * t);
+                }
+#pragma unroll
+                for (int s = 3; s >= 0; s--) {
+                    size_t o = 4 * j + s;
+                    bool ok = o < limit;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        uint32_t x = s ? __builtin_amdgcn_alignbyte(v[k + 1], v[k], s) : v[k];
+                        ok = ok && ((x & SYNC_MASK) == SYNC_BITS);
+                    }
+                    if (ok) best = (int)o;
+                }
+            }
+            if (best != 0x7fffffff) atomicMin(&s_found, best);
+            __syncthreads();
+            const int f = s_found;      // every lane reads before anyone moves on
+            __syncthreads();
+            if (f != 0x7fffffff) break;
+        }
+    } else {
+        for (size_t base = 0; base < limit; base += 256) {
+            size_t o = base + tid;
+            if (o < limit && sync4_bytes(p + o)) atomicMin(&s_found, (int)o);
+            __syncthreads();
+            const int f = s_found;
+            __syncthreads();
+            if (f != 0x7fffffff) break;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) offs_out[c] = (s_found == 0x7fffffff) ? -1 : s_found;
+}
+
+extern "C" int clhip_smi_find_offsets(const uint8_t *d_bytes, size_t total_bytes,
+                                      size_t chunk_stride_bytes, size_t chunk_len_bytes,
+                                      int n_chunks, int32_t *d_offs, void *stream)
+{
+    if (n_chunks <= 0) return 0;
+    if (!d_bytes || !d_offs || chunk_stride_bytes == 0) {
+        clhip_set_error("clhip_smi_find_offsets: bad arguments");
+        return -1;
+    }
+    hipLaunchKernelGGL(smi_find_offsets_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream,
+                       d_bytes, total_bytes, chunk_stride_bytes, chunk_len_bytes, n_chunks, d_offs);
+    CLHIP_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// unpack (+ conversion)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void unpack_word(uint32_t w, int channel, int &i, int &q)
+{
+    const int a = clhip_field_a(w), b = clhip_field_b(w);
+    i = channel == CL_CHANNEL_HIF ? b : a;   // caribou_smi.c:342-378
+    q = channel == CL_CHANNEL_HIF ? a : b;
+}
+
+template <int FMT> struct OutElem;
+template <> struct OutElem<CL_FORMAT_CS16> { typedef uint32_t type; };   // int16 pair
+template <> struct OutElem<CL_FORMAT_CF32> { typedef f32x2 type; };
+template <> struct OutElem<CL_FORMAT_CS8> { typedef uint16_t type; };    // int8 pair
+template <> struct OutElem<CL_FORMAT_CF64> { typedef double2 type; };
+
+template <int FMT>
+__device__ __forceinline__ typename OutElem<FMT>::type make_elem(int i, int q)
+{
+    if constexpr (FMT == CL_FORMAT_CS16) {
+        return ((uint32_t)(uint16_t)(int16_t)i) | ((uint32_t)(uint16_t)(int16_t)q << 16);
+    } else if constexpr (FMT == CL_FORMAT_CF32) {
+        // (float)v / 4096.0f  CaribouliteStream.cpp:319-320 (exact: power of two)
+        f32x2 r = {(float)i / 4096.0f, (float)q / 4096.0f};
+        return r;
+    } else if constexpr (FMT == CL_FORMAT_CS8) {
+        // (int8_t)((v >> 5) & 0xFF)  CaribouliteStream.cpp:362-363
+        return (uint16_t)(((uint32_t)(i >> 5) & 0xFFu) | (((uint32_t)(q >> 5) & 0xFFu) << 8));
+    } else {
+        return make_double2((double)i / 4096.0, (double)q / 4096.0);     // :341-342
+    }
+}
+
+// grid = (blocks per chunk, n_chunks); each lane handles 4 consecutive samples
+template <int FMT>
+__global__ __launch_bounds__(256) void smi_unpack_kernel(
+    int channel, const uint8_t *__restrict__ bytes, size_t total, size_t stride, size_t chunk_len,
+    const int32_t *__restrict__ offs_in, typename OutElem<FMT>::type *__restrict__ out,
+    uint8_t *__restrict__ meta)
+{
+    typedef typename OutElem<FMT>::type elem_t;
+    const int c = blockIdx.y;
+    const size_t start = (size_t)c * stride;
+    if (start >= total) return;
+    const size_t len = chunk_len < total - start ? chunk_len : total - start;
+    const int offs = offs_in ? offs_in[c] : 0;
+    if (offs < 0) return;                                    // sync failure: nothing written
+    const size_t shortening = offs > 0 ? (size_t)(offs / 4 + 1) : 0;   // caribou_smi.c:319
+    const size_t n = (len - 4 * shortening) / 4;             // :320,344
+    const uint8_t *p = bytes + start + offs;
+    const size_t slot0 = start / 4;
+    elem_t *o = out ? out + slot0 : nullptr;
+    uint8_t *m = meta ? meta + slot0 : nullptr;
+
+    const size_t g0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const size_t gstep = (size_t)gridDim.x * blockDim.x * 4;
+    const bool aligned = (((uintptr_t)p) & 15) == 0 &&
+                         (!o || (((uintptr_t)o) & (4 * sizeof(elem_t) - 1)) == 0) &&
+                         (!m || (((uintptr_t)m) & 3) == 0);
+    for (size_t k = g0; k < n; k += gstep) {
+        if (aligned && k + 4 <= n) {
+            const u32x4 w = __builtin_nontemporal_load((const u32x4 *)(p + 4 * k));
+            elem_t e[4];
+            uint32_t mm = 0;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                int i, q;
+                unpack_word(w[t], channel, i, q);
+                e[t] = make_elem<FMT>(i, q);
+                mm |= (w[t] & 1u) << (8 * t);                // meta.sync = s & 1  :348
+            }
+            if (o) {
+                if constexpr (sizeof(elem_t) == 4) {
+                    u32x4 v = {(uint32_t)e[0], (uint32_t)e[1], (uint32_t)e[2], (uint32_t)e[3]};
+                    *(u32x4 *)(o + k) = v;
+                } else if constexpr (sizeof(elem_t) == 2) {
+                    u32x2 v = {(uint32_t)e[0] | ((uint32_t)e[1] << 16), (uint32_t)e[2] | ((uint32_t)e[3] << 16)};
+                    *(u32x2 *)(o + k) = v;
+                } else if constexpr (sizeof(elem_t) == 8) {
+                    f32x4 v0 = {e[0].x, e[0].y, e[1].x, e[1].y}, v1 = {e[2].x, e[2].y, e[3].x, e[3].y};
+                    *(f32x4 *)(o + k) = v0;
+                    *(f32x4 *)(o + k + 2) = v1;
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; t++) o[k + t] = e[t];
+                }
+            }
+            if (m) *(uint32_t *)(m + k) = mm;
+        } else {
+            for (size_t t = k; t < n && t < k + 4; t++) {
+                const uint32_t w = ld_u32_bytes(p + 4 * t);
+                int i, q;
+                unpack_word(w, channel, i, q);
+                if (o) o[t] = make_elem<FMT>(i, q);
+                if (m) m[t] = (uint8_t)(w & 1u);
+            }
+        }
+    }
+    // one extrapolated sample after a re-synchronised chunk (:382-389); the
+    // reference needs n >= 2 (it reads slots n-1 and n-2)
+    if (shortening > 0 && o && n >= 2 && blockIdx.x == 0 && threadIdx.x == 0) {
+        int i1, q1, i2, q2;
+        unpack_word(ld_u32_bytes(p + 4 * (n - 1)), channel, i1, q1);
+        unpack_word(ld_u32_bytes(p + 4 * (n - 2)), channel, i2, q2);
+        const int ie = (int16_t)(110 * i1 / 100 - i2 / 10);
+        const int qe = (int16_t)(110 * q1 / 100 - q2 / 10);
+        o[n] = make_elem<FMT>(ie, qe);
+    }
+}
+
+extern "C" int clhip_smi_unpack(int channel, const uint8_t *d_bytes, size_t total_bytes,
+                                size_t chunk_stride_bytes, size_t chunk_len_bytes, int n_chunks,
+                                const int32_t *d_offs, int format, void *d_out, uint8_t *d_meta,
+                                void *stream)
+{
+    if (n_chunks <= 0 || total_bytes == 0) return 0;
+    if (!d_bytes || chunk_stride_bytes == 0 || (chunk_stride_bytes & 3)) {
+        clhip_set_error("clhip_smi_unpack: bad arguments (stride must be a multiple of 4)");
+        return -1;
+    }
+    const size_t per_chunk = chunk_len_bytes / 4;
+    unsigned bx = (unsigned)clhip_div_up(per_chunk ? per_chunk : 1, 256 * 4);
+    if (bx > 2048) bx = 2048;
+    if ((size_t)bx * n_chunks > (1u << 20)) bx = (unsigned)((1u << 20) / n_chunks) + 1;
+    dim3 grid(bx, n_chunks), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(F)                                                                              \
+    hipLaunchKernelGGL(smi_unpack_kernel<F>, grid, block, 0, s, channel, d_bytes, total_bytes, \
+                       chunk_stride_bytes, chunk_len_bytes, d_offs,                            \
+                       (OutElem<F>::type *)d_out, d_meta)
+    switch (format) {
+    case CL_FORMAT_CS16: LAUNCH(CL_FORMAT_CS16); break;
+    case CL_FORMAT_CF32: LAUNCH(CL_FORMAT_CF32); break;
+    case CL_FORMAT_CS8: LAUNCH(CL_FORMAT_CS8); break;
+    case CL_FORMAT_CF64: LAUNCH(CL_FORMAT_CF64); break;
+    default: clhip_set_error("clhip_smi_unpack: unknown format %d", format); return -1;
+    }
+#undef LAUNCH
+    CLHIP_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// CS16 <-> other formats
+// ---------------------------------------------------------------------------
+template <int FMT>
+__global__ __launch_bounds__(256) void from_cs16_kernel(const uint32_t *__restrict__ in, size_t n,
+                                                        typename OutElem<FMT>::type *__restrict__ out)
+{
+    size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; k < n; k += step) {
+        const uint32_t w = in[k];
+        out[k] = make_elem<FMT>((int)(int16_t)(w & 0xFFFF), (int)(int16_t)(w >> 16));
+    }
+}
+
+extern "C" int clhip_convert_from_cs16(const int16_t *d_iq, size_t n, int format, void *d_out, void *stream)
+{
+    if (n == 0) return 0;
+    unsigned grid = (unsigned)clhip_div_up(n, 256);
+    if (grid > 8192) grid = 8192;
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t *in = (const uint32_t *)d_iq;
+    switch (format) {
+    case CL_FORMAT_CS16: CLHIP_CHECK(hipMemcpyAsync(d_out, d_iq, 4 * n, hipMemcpyDeviceToDevice, s)); return 0;
+    case CL_FORMAT_CF32: hipLaunchKernelGGL(from_cs16_kernel<CL_FORMAT_CF32>, dim3(grid), dim3(256), 0, s, in, n, (f32x2 *)d_out); break;
+    case CL_FORMAT_CS8: hipLaunchKernelGGL(from_cs16_kernel<CL_FORMAT_CS8>, dim3(grid), dim3(256), 0, s, in, n, (uint16_t *)d_out); break;
+    case CL_FORMAT_CF64: hipLaunchKernelGGL(from_cs16_kernel<CL_FORMAT_CF64>, dim3(grid), dim3(256), 0, s, in, n, (double2 *)d_out); break;
+    default: clhip_set_error("clhip_convert_from_cs16: unknown format %d", format); return -1;
+    }
+    CLHIP_CHECK_LAUNCH();
+    return 0;
+}
+
+// (int16_t)(f * 4096.0f) as the reference binary computes it on its x86-64
+// build host: truncate toward zero to int32 (out of range / NaN -> 0x80000000),
+// keep the low 16 bits (CaribouliteStream.cpp:207-208,223-224).
+__device__ __forceinline__ uint32_t f2i16(float v)
+{
+    int t = (v >= -2147483648.0f && v < 2147483648.0f) ? (int)v : (int)0x80000000;
+    return (uint32_t)t & 0xFFFFu;
+}
+__device__ __forceinline__ uint32_t d2i16(double v)
+{
+    int t = (v > -2147483649.0 && v < 2147483648.0) ? (int)v : (int)0x80000000;
+    return (uint32_t)t & 0xFFFFu;
+}
+
+template <int FMT>
+__global__ __launch_bounds__(256) void to_cs16_kernel(const typename OutElem<FMT>::type *__restrict__ in,
+                                                      size_t n, uint32_t *__restrict__ out)
+{
+    size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; k < n; k += step) {
+        if constexpr (FMT == CL_FORMAT_CF32) {
+            const f32x2 v = in[k];
+            out[k] = f2i16(v.x * 4096.0f) | (f2i16(v.y * 4096.0f) << 16);
+        } else if constexpr (FMT == CL_FORMAT_CF64) {
+            const double2 v = in[k];
+            out[k] = d2i16(v.x * 4096.0) | (d2i16(v.y * 4096.0) << 16);
+        } else {   // CS8: ((int16_t)v) << 5   CaribouliteStream.cpp:238-239
+            const uint16_t v = in[k];
+            const int i = (int8_t)(v & 0xFF), q = (int8_t)(v >> 8);
+            out[k] = ((uint32_t)(i << 5) & 0xFFFFu) | (((uint32_t)(q << 5) & 0xFFFFu) << 16);
+        }
+    }
+}
+
+extern "C" int clhip_convert_to_cs16(const void *d_in, int format, size_t n, int16_t *d_iq, void *stream)
+{
+    if (n == 0) return 0;
+    unsigned grid = (unsigned)clhip_div_up(n, 256);
+    if (grid > 8192) grid = 8192;
+    hipStream_t s = (hipStream_t)stream;
+    uint32_t *out = (uint32_t *)d_iq;
+    switch (format) {
+    case CL_FORMAT_CS16: CLHIP_CHECK(hipMemcpyAsync(d_iq, d_in, 4 * n, hipMemcpyDeviceToDevice, s)); return 0;
+    case CL_FORMAT_CF32: hipLaunchKernelGGL(to_cs16_kernel<CL_FORMAT_CF32>, dim3(grid), dim3(256), 0, s, (const f32x2 *)d_in, n, out); break;
+    case CL_FORMAT_CS8: hipLaunchKernelGGL(to_cs16_kernel<CL_FORMAT_CS8>, dim3(grid), dim3(256), 0, s, (const uint16_t *)d_in, n, out); break;
+    case CL_FORMAT_CF64: hipLaunchKernelGGL(to_cs16_kernel<CL_FORMAT_CF64>, dim3(grid), dim3(256), 0, s, (const double2 *)d_in, n, out); break;
+    default: clhip_set_error("clhip_convert_to_cs16: unknown format %d", format); return -1;
+    }
+    CLHIP_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// TX pack (caribou_smi.c:684-717)
+//   byte0 [SOF TXC CTX I12..I8] byte1 [0 I7..I1] byte2 [0 I0 Q12..Q7] byte3 [0 Q6..Q0]
+//   built MSB-first in a u32, byte-swapped so byte0 is first in memory.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t pack_tx_word(int mode, uint32_t iq)
+{
+    uint32_t ii = iq & 0xFFFFu, qq = iq >> 16;
+    if (mode == CL_TX_AS_WRITTEN) { ii = 0xFFFFu; qq = 0; }   // :700-701 as shipped
+    ii &= 0x1FFFu; qq &= 0x1FFFu;
+    const uint32_t s = (0x7u << 29) | ((ii >> 8) << 24) | (((ii >> 1) & 0x7Fu) << 16) |
+                       ((ii & 1u) << 14) | ((qq >> 7) << 8) | (qq & 0x7Fu);
+    return __builtin_bswap32(s);
+}
+
+__global__ __launch_bounds__(256) void smi_pack_kernel(int mode, const uint32_t *__restrict__ iq, size_t n,
+                                                       uint32_t *__restrict__ out)
+{
+    const size_t n4 = n / 4;
+    size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    const bool aligned = ((((uintptr_t)iq) | ((uintptr_t)out)) & 15) == 0;
+    if (aligned) {
+        for (size_t j = k; j < n4; j += step) {
+            const u32x4 v = ((const u32x4 *)iq)[j];
+            u32x4 r;
+#pragma unroll
+            for (int t = 0; t < 4; t++) r[t] = pack_tx_word(mode, v[t]);
+            ((u32x4 *)out)[j] = r;
+        }
+        for (size_t j = 4 * n4 + k; j < n; j += step) out[j] = pack_tx_word(mode, iq[j]);
+    } else {
+        for (size_t j = k; j < n; j += step) out[j] = pack_tx_word(mode, iq[j]);
+    }
+}
+
+extern "C" int clhip_smi_pack(int mode, const int16_t *d_iq, size_t n, uint8_t *d_bytes, void *stream)
+{
+    if (n == 0) return 0;
+    if ((((uintptr_t)d_iq) | ((uintptr_t)d_bytes)) & 3) {
+        clhip_set_error("clhip_smi_pack: buffers must be 4-byte aligned");
+        return -1;
+    }
+    unsigned grid = (unsigned)clhip_div_up(clhip_div_up(n, 4), 256);
+    if (grid > 8192) grid = 8192;
+    if (grid == 0) grid = 1;
+    hipLaunchKernelGGL(smi_pack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, mode,
+                       (const uint32_t *)d_iq, n, (uint32_t *)d_bytes);
+    CLHIP_CHECK_LAUNCH();
+    return 0;
+}

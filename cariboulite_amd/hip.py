@@ -1,0 +1,191 @@
+"""ctypes binding of libcariboulite_hip.so (layer 1 of include/cariboulite_hip.h).
+
+Accepts torch CUDA(HIP) tensors or raw integer device pointers.  Fails loudly
+(ImportError / RuntimeError) when the library is absent -- there is no CPU path.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "libcariboulite_hip.so")
+
+CHANNEL_S1G, CHANNEL_HIF = 0, 1
+FORMAT_CF32, FORMAT_CS16, FORMAT_CS8, FORMAT_CF64 = 0, 1, 2, 3
+PIPE_IN_SMI_WORDS, PIPE_IN_CS16, PIPE_IN_CF32 = 0, 1, 2
+PIPE_OUT_IQ, PIPE_OUT_FM_DEMOD = 0, 1
+TX_DOCUMENTED, TX_AS_WRITTEN = 0, 1
+TXPIPE_IN_FM_MESSAGE, TXPIPE_IN_CF32 = 0, 1
+NATIVE_BATCH_LEN = 524288
+
+_lib = None
+
+_SIGS = {
+    "clhip_device_count": (C.c_int, []),
+    "clhip_set_device": (C.c_int, [C.c_int]),
+    "clhip_last_error": (C.c_char_p, []),
+    "clhip_arch_name": (C.c_char_p, []),
+    "clhip_malloc": (C.c_void_p, [C.c_size_t]),
+    "clhip_free": (None, [C.c_void_p]),
+    "clhip_host_alloc": (C.c_void_p, [C.c_size_t]),
+    "clhip_host_free": (None, [C.c_void_p]),
+    "clhip_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "clhip_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "clhip_memcpy_d2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "clhip_memset": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]),
+    "clhip_stream_create": (C.c_void_p, []),
+    "clhip_stream_destroy": (None, [C.c_void_p]),
+    "clhip_stream_sync": (C.c_int, [C.c_void_p]),
+    "clhip_event_create": (C.c_void_p, []),
+    "clhip_event_destroy": (None, [C.c_void_p]),
+    "clhip_event_record": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "clhip_event_elapsed_ms": (C.c_float, [C.c_void_p, C.c_void_p]),
+    "clhip_smi_find_offsets": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]),
+    "clhip_smi_unpack": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p,
+                                   C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "clhip_convert_from_cs16": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]),
+    "clhip_convert_to_cs16": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "clhip_smi_pack": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "clhip_iir_cs16": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "clhip_iir_workspace_bytes": (C.c_size_t, [C.c_size_t, C.c_int]),
+    "clhip_rx_pipe_create": (C.c_void_p, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "clhip_rx_pipe_destroy": (None, [C.c_void_p]),
+    "clhip_rx_pipe_reset": (None, [C.c_void_p]),
+    "clhip_rx_pipe_out_count": (C.c_size_t, [C.c_void_p, C.c_size_t]),
+    "clhip_rx_pipe_uses_fused": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int]),
+    "clhip_rx_pipe_run": (C.c_long, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "clhip_rx_pipe_force_generic": (None, [C.c_void_p, C.c_int]),
+    "clhip_rx_pipe_set_sync_check": (None, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "clhip_tx_pipe_create": (C.c_void_p, [C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "clhip_tx_pipe_destroy": (None, [C.c_void_p]),
+    "clhip_tx_pipe_reset": (None, [C.c_void_p]),
+    "clhip_tx_pipe_out_count": (C.c_size_t, [C.c_void_p, C.c_size_t]),
+    "clhip_tx_pipe_run": (C.c_long, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
+                                     C.c_void_p, C.c_size_t, C.c_void_p]),
+    "clhip_fm_demod": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "clhip_fm_mod": (C.c_int, [C.c_void_p, C.c_size_t, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "clhip_fm_mod_workspace_bytes": (C.c_size_t, [C.c_size_t]),
+    "clhip_cw_tone": (C.c_int, [C.c_double, C.c_double, C.c_double, C.c_size_t, C.c_void_p, C.c_void_p]),
+}
+
+
+def exported_symbols():
+    """Every layer-1 symbol include/cariboulite_hip.h declares."""
+    return sorted(_SIGS)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(the HIP extension is required; there is no CPU fallback)")
+        _lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(_lib, name)          # AttributeError if the .so lacks a declared symbol
+            fn.restype, fn.argtypes = res, args
+    return _lib
+
+
+def last_error():
+    return lib().clhip_last_error().decode()
+
+
+def _check(rc, what):
+    if rc is None or rc < 0:
+        raise RuntimeError(f"{what} failed: {last_error()}")
+    return rc
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or pass through an int / None)."""
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return t
+    return t.data_ptr()
+
+
+def current_stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu():
+    l = lib()
+    if l.clhip_device_count() <= 0:
+        raise RuntimeError("no HIP device visible: the cariboulite_amd hot path needs an MI355X")
+    return l.clhip_arch_name().decode()
+
+
+# ------------------------------------------------------------------ stages
+def smi_find_offsets(d_bytes, total_bytes, chunk_stride, chunk_len, n_chunks, d_offs, stream=None):
+    _check(lib().clhip_smi_find_offsets(ptr(d_bytes), total_bytes, chunk_stride, chunk_len, n_chunks,
+                                        ptr(d_offs), stream if stream is not None else current_stream()),
+           "clhip_smi_find_offsets")
+
+
+def smi_unpack(channel, d_bytes, total_bytes, chunk_stride, chunk_len, n_chunks, d_offs, fmt, d_out,
+               d_meta=None, stream=None):
+    _check(lib().clhip_smi_unpack(channel, ptr(d_bytes), total_bytes, chunk_stride, chunk_len, n_chunks,
+                                  ptr(d_offs), fmt, ptr(d_out), ptr(d_meta),
+                                  stream if stream is not None else current_stream()), "clhip_smi_unpack")
+
+
+def convert_from_cs16(d_iq, n, fmt, d_out, stream=None):
+    _check(lib().clhip_convert_from_cs16(ptr(d_iq), n, fmt, ptr(d_out),
+                                         stream if stream is not None else current_stream()), "clhip_convert_from_cs16")
+
+
+def convert_to_cs16(d_in, fmt, n, d_iq, stream=None):
+    _check(lib().clhip_convert_to_cs16(ptr(d_in), fmt, n, ptr(d_iq),
+                                       stream if stream is not None else current_stream()), "clhip_convert_to_cs16")
+
+
+def smi_pack(mode, d_iq, n, d_bytes, stream=None):
+    _check(lib().clhip_smi_pack(mode, ptr(d_iq), n, ptr(d_bytes),
+                                stream if stream is not None else current_stream()), "clhip_smi_pack")
+
+
+class RxPipe:
+    """clhip_rx_pipe: unpack -> FIR -> [L/M resample | FM demod] for n_streams streams."""
+
+    def __init__(self, n_streams, channel, fir_taps, rs_taps=None, up=1, down=1, out_mode=PIPE_OUT_IQ):
+        fir = np.ascontiguousarray(fir_taps, dtype=np.float32)
+        rs = np.ascontiguousarray(rs_taps, dtype=np.float32) if rs_taps is not None else None
+        self.n_streams, self.up, self.down, self.out_mode = n_streams, up, down, out_mode
+        self.h = lib().clhip_rx_pipe_create(n_streams, channel, fir.ctypes.data, fir.size,
+                                            rs.ctypes.data if rs is not None else None,
+                                            rs.size if rs is not None else 0, up, down, out_mode)
+        if not self.h:
+            raise RuntimeError("clhip_rx_pipe_create failed: " + last_error())
+
+    def close(self):
+        if self.h:
+            lib().clhip_rx_pipe_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def reset(self):
+        lib().clhip_rx_pipe_reset(self.h)
+
+    def out_count(self, n_in):
+        return lib().clhip_rx_pipe_out_count(self.h, n_in)
+
+    def uses_fused(self, n_in, in_kind=PIPE_IN_SMI_WORDS):
+        return bool(lib().clhip_rx_pipe_uses_fused(self.h, n_in, in_kind))
+
+    def force_generic(self, on=True):
+        lib().clhip_rx_pipe_force_generic(self.h, int(on))
+
+    def set_sync_check(self, d_offs, chunk_samples, d_bad_flag):
+        self._chk = (d_offs, d_bad_flag)          # keep the tensors alive
+        lib().clhip_rx_pipe_set_sync_check(self.h, ptr(d_offs), chunk_samples, ptr(d_bad_flag))
+
+    def run(self, in_kind, d_in, in_stride, n_in, d_out, out_stride, stream=None):
+        return _check(lib().clhip_rx_pipe_run(self.h, in_kind, ptr(d_in), in_stride, n_in, ptr(d_out), out_stride,
+                                              stream if stream is not None else current_stream()),
+                      "clhip_rx_pipe_run")

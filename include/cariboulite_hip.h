@@ -1,0 +1,296 @@
+/*
+ * cariboulite_hip.h -- C-ABI of the MI355X (gfx950) sample-stream hot path.
+ *
+ * Two layers, both plain C (pointers and sizes only; no HIP, torch or C++
+ * types cross this boundary; `void *stream` is a hipStream_t, NULL = the
+ * default stream):
+ *
+ *   clhip_*   libcariboulite_hip.so -- the thin shim over the hand-written HIP
+ *             kernels.  Every data pointer is a DEVICE pointer unless the
+ *             name says `h_`.  Launches are asynchronous on `stream`.
+ *   cl_* /    libcariboulite_host.so -- host C code that keeps the reference's
+ *   caribou_  own call surface: the SMI user-driver seam, the radio
+ *   cariboul  pass-through trio, and the SoapySDR device/stream calls, with the
+ *             /dev/smi fd replaced by an injected byte stream.
+ *
+ * Each entry point cites the reference interface it replaces (paths relative
+ * to /root/reference/software/libcariboulite/src).  INTEGRATION.md shows the
+ * reference-side binding.
+ */
+#ifndef CARIBOULITE_HIP_H
+#define CARIBOULITE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------ */
+/* Types shared with the reference                                          */
+/* ------------------------------------------------------------------------ */
+
+/* caribou_smi/caribou_smi.h:53-65, cariboulite_radio.h:119-128 */
+#pragma pack(push, 1)
+typedef struct { int16_t i; int16_t q; } cl_sample_complex_int16;
+typedef struct { uint8_t sync; } cl_sample_meta;
+typedef struct { int8_t i; int8_t q; } cl_sample_complex_int8;     /* soapy_api/CaribouliteStream.hpp:28-32 */
+typedef struct { float i; float q; } cl_sample_complex_float;      /* :49-53 */
+typedef struct { double i; double q; } cl_sample_complex_double;   /* :56-60 */
+#pragma pack(pop)
+
+#define CL_BYTES_PER_SAMPLE   4          /* caribou_smi.h:42 CARIBOU_SMI_BYTES_PER_SAMPLE */
+#define CL_SAMPLE_RATE        4000000    /* caribou_smi.h:43 CARIBOU_SMI_SAMPLE_RATE      */
+#define CL_NATIVE_BATCH_LEN   524288     /* caribou_smi.c:78 default native_batch_len     */
+#define CL_NATIVE_MTU_SAMPLES 131072     /* cariboulite_radio.c:1310-1315                 */
+
+/* caribou_smi.h:45-49 caribou_smi_channel_en */
+#define CL_CHANNEL_S1G 0   /* caribou_smi_channel_900  */
+#define CL_CHANNEL_HIF 1   /* caribou_smi_channel_2400 */
+
+/* soapy_api/CaribouliteStream.hpp:68-74 CaribouliteFormat */
+#define CL_FORMAT_CF32 0
+#define CL_FORMAT_CS16 1
+#define CL_FORMAT_CS8  2
+#define CL_FORMAT_CF64 3
+
+/* soapy_api/CaribouliteStream.hpp:77-84 DigitalFilterType */
+#define CL_DIGFILT_NONE   0
+#define CL_DIGFILT_20KHZ  1
+#define CL_DIGFILT_50KHZ  2
+#define CL_DIGFILT_100KHZ 3
+
+/* caribou_smi.c:653-675 return codes of caribou_smi_read */
+#define CL_SMI_ERR_IO        (-1)
+#define CL_SMI_ERR_DEBUGMODE (-2)
+#define CL_SMI_ERR_SYNC      (-3)
+
+/* SoapySDR/Errors.h values the reference returns (CaribouliteStreamFunctions.cpp:248-251) */
+#define CL_SOAPY_SDR_RX 1
+#define CL_SOAPY_SDR_TX 0
+#define CL_SOAPY_SDR_NOT_SUPPORTED (-5)
+#define CL_SOAPY_SDR_TIMEOUT (-1)
+
+/* TX packer behaviour (caribou_smi.c:684-717) */
+#define CL_TX_DOCUMENTED 0  /* layout of :693-696 applied to the caller's samples          */
+#define CL_TX_AS_WRITTEN 1  /* :700-701 as shipped (ii=0xFFFF, qq=0): FF 7F 40 00 per sample */
+
+/* ======================================================================== */
+/* Layer 1: clhip_* -- HIP kernel shim (libcariboulite_hip.so)              */
+/* ======================================================================== */
+
+/* runtime plumbing so that C callers need no HIP headers */
+int         clhip_device_count(void);
+int         clhip_set_device(int device);
+const char *clhip_last_error(void);
+const char *clhip_arch_name(void);                  /* "gfx950" on the target       */
+void       *clhip_malloc(size_t bytes);             /* device memory                */
+void        clhip_free(void *d_ptr);
+void       *clhip_host_alloc(size_t bytes);         /* pinned, device-visible host  */
+void        clhip_host_free(void *h_ptr);
+int         clhip_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream);
+int         clhip_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream);
+int         clhip_memcpy_d2d(void *d_dst, const void *d_src, size_t bytes, void *stream);
+int         clhip_memset(void *d_dst, int value, size_t bytes, void *stream);
+void       *clhip_stream_create(void);
+void        clhip_stream_destroy(void *stream);
+int         clhip_stream_sync(void *stream);
+/* HIP-event timing on the stream the kernels are launched on (bench.py) */
+void       *clhip_event_create(void);
+void        clhip_event_destroy(void *event);
+int         clhip_event_record(void *event, void *stream);
+float       clhip_event_elapsed_ms(void *start, void *stop); /* synchronises on stop */
+
+/*
+ * Sync search -- replaces caribou_smi_find_buffer_offset
+ * (caribou_smi/caribou_smi.c:235-292, debug_mode none).  One result per chunk:
+ * d_offs[c] = smallest byte offset in [0, len_c-16) whose four unaligned LE
+ * words all satisfy (w & 0xC001C000) == 0x80004000; 0 if len_c <= 16; -1 if
+ * none.  Chunk c starts at d_bytes + c*chunk_stride_bytes and is
+ * len_c = min(chunk_len_bytes, total_bytes - c*chunk_stride_bytes) long.
+ */
+int clhip_smi_find_offsets(const uint8_t *d_bytes, size_t total_bytes,
+                           size_t chunk_stride_bytes, size_t chunk_len_bytes,
+                           int n_chunks, int32_t *d_offs, void *stream);
+
+/*
+ * Unpack -- replaces caribou_smi_rx_data_analyze (caribou_smi.c:295-393) fused
+ * with the Soapy RX conversions (soapy_api/CaribouliteStream.cpp:304-367).
+ * Per chunk c (same chunking as above, offsets from clhip_smi_find_offsets):
+ * words start at chunk + offs; n = (len_c - 4*short)/4, short = offs>0 ?
+ * offs/4+1 : 0; sample k of chunk c lands in slot c*chunk_stride_bytes/4 + k;
+ * one extrapolated sample (110*a/100 - b/10) follows when short > 0; slots
+ * the reference leaves untouched are left untouched; chunks with offs < 0
+ * write nothing.  d_out is in `format` (CL_FORMAT_*); d_meta may be NULL.
+ */
+int clhip_smi_unpack(int channel, const uint8_t *d_bytes, size_t total_bytes,
+                     size_t chunk_stride_bytes, size_t chunk_len_bytes, int n_chunks,
+                     const int32_t *d_offs, int format, void *d_out, uint8_t *d_meta,
+                     void *stream);
+
+/* RX/TX format conversions on native CS16 (CaribouliteStream.cpp:199-244,304-367) */
+int clhip_convert_from_cs16(const int16_t *d_iq, size_t n_samples, int format, void *d_out, void *stream);
+int clhip_convert_to_cs16(const void *d_in, int format, size_t n_samples, int16_t *d_iq, void *stream);
+
+/* TX pack -- replaces caribou_smi_generate_data (caribou_smi.c:684-717) */
+int clhip_smi_pack(int mode, const int16_t *d_iq, size_t n_samples, uint8_t *d_bytes, void *stream);
+
+/*
+ * IIR -- replaces the per-sample iir1 loop of Stream::ReadSamples
+ * (CaribouliteStream.cpp:291-298): y = (int16)(float)LP(float(x)) on both
+ * rails, Direct-Form-II biquad cascade in fp64, state carried in d_state
+ * (n_stages * 2 rails * 2 doubles, layout [rail][stage]{v1,v2}).
+ * sos = n_stages rows of {b0,b1,b2,a1,a2} (host pointer, a0 = 1).
+ */
+int clhip_iir_cs16(const double *h_sos, int n_stages, double *d_state,
+                   int16_t *d_iq, size_t n_samples, void *d_workspace, size_t workspace_bytes,
+                   void *stream);
+size_t clhip_iir_workspace_bytes(size_t n_samples, int n_stages);
+
+/*
+ * The RX pipe: raw SMI words -> int13 I/Q -> x/4096 -> FIR(T) -> [L/M polyphase
+ * resampler | FM phase-difference demod | nothing] -> fp32, for n_streams
+ * independent streams in one launch.  The stages after the unpack have no
+ * reference implementation (SURVEY.md section 8 row a13 is their spec); they
+ * sit where a client of readStream(CF32) would apply them.
+ */
+#define CL_PIPE_IN_SMI_WORDS 0   /* aligned raw RX words, 4 B/sample            */
+#define CL_PIPE_IN_CS16      1   /* native int16 pairs (after IIR / re-sync)    */
+#define CL_PIPE_IN_CF32      2   /* already-converted complex float            */
+#define CL_PIPE_OUT_IQ       0   /* FIR (+ resampler) -> complex float          */
+#define CL_PIPE_OUT_FM_DEMOD 1   /* FIR -> atan2(x[n] conj x[n-1]) -> float     */
+
+typedef struct clhip_rx_pipe clhip_rx_pipe;   /* opaque, owns taps + per-stream state */
+
+clhip_rx_pipe *clhip_rx_pipe_create(int n_streams, int channel,
+                                    const float *h_fir_taps, int n_fir_taps,
+                                    const float *h_rs_taps, int n_rs_taps, int up, int down,
+                                    int out_mode);
+void   clhip_rx_pipe_destroy(clhip_rx_pipe *p);
+void   clhip_rx_pipe_reset(clhip_rx_pipe *p);                    /* zero history, phase 0      */
+size_t clhip_rx_pipe_out_count(const clhip_rx_pipe *p, size_t n_in); /* outputs the next run yields */
+int    clhip_rx_pipe_uses_fused(const clhip_rx_pipe *p, size_t n_in, int in_kind);
+/* d_in: stream s at d_in + s*in_stride_elems (elements of in_kind);
+ * d_out: stream s at d_out + s*out_stride_elems (complex float or float).
+ * Returns outputs per stream (>= 0) or a negative error. */
+long   clhip_rx_pipe_run(clhip_rx_pipe *p, int in_kind, const void *d_in, size_t in_stride_elems,
+                         size_t n_in, void *d_out, size_t out_stride_elems, void *stream);
+/* force the multi-kernel generic path (second implementation, used by tests) */
+void   clhip_rx_pipe_force_generic(clhip_rx_pipe *p, int on);
+/* Device-side sync validation for CL_PIPE_IN_SMI_WORDS runs: d_offs holds the
+ * per-chunk results of clhip_smi_find_offsets ([n_streams][ceil(n_in/chunk_samples)]).
+ * A tile that needs a chunk with offs != 0 writes nothing and sets *d_bad_flag = 1;
+ * the caller then re-runs that call through clhip_smi_unpack + CL_PIPE_IN_CS16.
+ * Pass NULL to disable. */
+void   clhip_rx_pipe_set_sync_check(clhip_rx_pipe *p, const int32_t *d_offs, size_t chunk_samples,
+                                    int32_t *d_bad_flag);
+
+/*
+ * The TX pipe: fp32 message -> FM modulate (fp64 phase) -> L/M resample ->
+ * x*4096 truncate -> int13 pack -> SMI TX bytes (config 5), or complex float
+ * -> resample -> pack.  Returns samples packed per stream.
+ */
+#define CL_TXPIPE_IN_FM_MESSAGE 0
+#define CL_TXPIPE_IN_CF32       1
+typedef struct clhip_tx_pipe clhip_tx_pipe;
+clhip_tx_pipe *clhip_tx_pipe_create(int n_streams, double fm_kf_hz, double fs_hz,
+                                    const float *h_rs_taps, int n_rs_taps, int up, int down,
+                                    int pack_mode);
+void   clhip_tx_pipe_destroy(clhip_tx_pipe *p);
+void   clhip_tx_pipe_reset(clhip_tx_pipe *p);
+size_t clhip_tx_pipe_out_count(const clhip_tx_pipe *p, size_t n_in);
+long   clhip_tx_pipe_run(clhip_tx_pipe *p, int in_kind, const void *d_in, size_t in_stride_elems,
+                         size_t n_in, uint8_t *d_bytes, size_t out_stride_bytes,
+                         float *d_iq_tap, size_t iq_tap_stride, void *stream);
+
+/* standalone FM / CW stages on device buffers */
+int clhip_fm_demod(const float *d_iq, size_t n, float *d_prev_iq /*2 floats, in/out*/, float *d_out, void *stream);
+int clhip_fm_mod(const float *d_msg, size_t n, double kf_hz, double fs_hz,
+                 double *d_phase /*1 double, in/out*/, float *d_iq_out,
+                 void *d_workspace, size_t workspace_bytes, void *stream);
+size_t clhip_fm_mod_workspace_bytes(size_t n);
+int clhip_cw_tone(double f_hz, double fs_hz, double phase0, size_t n, float *d_iq_out, void *stream);
+
+/* ======================================================================== */
+/* Layer 2: host C code with the reference's call surface                   */
+/* (libcariboulite_host.so; links libcariboulite_hip.so)                    */
+/* ======================================================================== */
+
+/* --- SMI user-driver seam: caribou_smi/caribou_smi.h:85-106 ------------- */
+typedef struct cl_smi cl_smi;   /* stands where caribou_smi_st stands */
+
+cl_smi *cl_smi_init(int device);                       /* caribou_smi_init  caribou_smi.c:513-581 */
+int     cl_smi_close(cl_smi *dev);                     /* caribou_smi_close :584-595              */
+/* injection points replacing the /dev/smi fd: bytes
+ * queued here are what read() on the fd would have returned, in order */
+int     cl_smi_feed_bytes(cl_smi *dev, const uint8_t *h_bytes, size_t n_bytes);
+size_t  cl_smi_pending_bytes(const cl_smi *dev);
+void    cl_smi_set_max_read(cl_smi *dev, size_t max_bytes_per_read); /* model short reads */
+/* bytes write() on the fd would have received */
+size_t  cl_smi_drain_bytes(cl_smi *dev, uint8_t *h_bytes, size_t max_bytes);
+void    cl_smi_set_tx_mode(cl_smi *dev, int cl_tx_mode);
+/* caribou_smi_read  caribou_smi.c:632-682 (same arguments and return codes) */
+int     cl_smi_read(cl_smi *dev, int channel, cl_sample_complex_int16 *buffer,
+                    cl_sample_meta *metadata, size_t length_samples);
+/* caribou_smi_write caribou_smi.c:720-762 */
+int     cl_smi_write(cl_smi *dev, int channel, cl_sample_complex_int16 *buffer, size_t length_samples);
+/* caribou_smi_get_native_batch_samples caribou_smi.c:765-769 */
+size_t  cl_smi_get_native_batch_samples(cl_smi *dev);
+
+/* --- radio pass-through trio: cariboulite_radio.h:592-619 ---------------- */
+typedef struct cl_radio cl_radio;   /* stands where cariboulite_radio_state_st stands */
+cl_radio *cl_radio_create(cl_smi *smi, int channel);
+void      cl_radio_destroy(cl_radio *radio);
+int    cl_radio_read_samples(cl_radio *radio, cl_sample_complex_int16 *buffer,
+                             cl_sample_meta *metadata, size_t length);    /* cariboulite_radio.c:1258-1285 */
+int    cl_radio_write_samples(cl_radio *radio, cl_sample_complex_int16 *buffer,
+                              size_t length);                             /* :1288-1307 */
+size_t cl_radio_get_native_mtu_size_samples(cl_radio *radio);             /* :1310-1315 */
+
+/* --- SoapySDR device/stream calls: soapy_api/Cariboulite.hpp:65-93 ------- */
+typedef struct cl_device cl_device;   /* stands where class Cariboulite stands        */
+typedef struct cl_stream cl_stream;   /* stands where class SoapySDR::Stream stands   */
+
+/* makeCariboulite / Cariboulite::Cariboulite (Cariboulite.cpp:10-35):
+ * kwargs "channel=S1G|HiF" selects the radio; anything else fails (NULL), as
+ * the reference throws.  "gpu=N" picks the HIP device (extension). */
+cl_device *cl_device_make(const char *const *keys, const char *const *vals, size_t n_kwargs);
+void       cl_device_unmake(cl_device *dev);
+cl_smi    *cl_device_smi(cl_device *dev);      /* to feed / drain SMI bytes */
+const char *cl_device_last_error(cl_device *dev);
+
+/* getStreamFormats CaribouliteStreamFunctions.cpp:11-19: returns count, fills up to max */
+size_t cl_getStreamFormats(const cl_device *dev, int direction, size_t channel,
+                           const char **formats, size_t max_formats);
+/* getNativeStreamFormat :31-35 */
+const char *cl_getNativeStreamFormat(const cl_device *dev, int direction, size_t channel, double *fullScale);
+/* setupStream :100-139 -- NULL + cl_device_last_error() where the reference throws.
+ * Extension kwargs (SURVEY.md section 5 "Config / flags"): FIR=<ntaps>:<cutoff_hz>,
+ * RESAMP=<L>/<M>, DEMOD=FM, MOD=FM:<kf_hz>; defaults = reference behaviour. */
+cl_stream *cl_setupStream(cl_device *dev, int direction, const char *format,
+                          const size_t *channels, size_t n_channels,
+                          const char *const *keys, const char *const *vals, size_t n_kwargs);
+void   cl_closeStream(cl_device *dev, cl_stream *stream);                         /* :147-150 */
+size_t cl_getStreamMTU(const cl_device *dev, cl_stream *stream);                  /* :162-165 */
+int    cl_activateStream(cl_device *dev, cl_stream *stream, int flags,
+                         long long timeNs, size_t numElems);                      /* :186-195 */
+int    cl_deactivateStream(cl_device *dev, cl_stream *stream, int flags, long long timeNs); /* :212-216 */
+int    cl_readStream(cl_device *dev, cl_stream *stream, void *const *buffs, size_t numElems,
+                     int *flags, long long *timeNs, long timeoutUs);              /* :239-254 */
+int    cl_writeStream(cl_device *dev, cl_stream *stream, const void *const *buffs, size_t numElems,
+                      int *flags, long long timeNs, long timeoutUs);              /* :276-291 */
+/* setBandwidth Cariboulite.cpp:395-417: RX bw < 160 kHz selects the IIR */
+void   cl_setBandwidth(cl_device *dev, int direction, size_t channel, double bw);
+int    cl_getDigitalFilter(const cl_device *dev);
+
+/* host helper: scipy.signal.firwin(ntaps, cutoff, window="hamming", fs=fs)
+ * (the tap design SURVEY.md section 8 a13 specifies), rounded to fp32 */
+int    cl_design_lowpass(int n_taps, double cutoff_hz, double fs_hz, double gain, float *taps_out);
+/* host helper: iir1-style Butterworth low-pass as n/2 biquads {b0,b1,b2,a1,a2} */
+int    cl_design_butter_lowpass(int order, double fs_hz, double fc_hz, double *sos_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CARIBOULITE_HIP_H */

@@ -325,14 +325,46 @@ void orc_fir_f64(orc_fir *f, const float *x, size_t n, double *y)
     }
 }
 
+/* y[i] for i in [0, n) reading x[i-k] directly (x must have T-1 valid samples
+ * before index 0).  Blocks of 8 complex outputs = 16 floats so that gcc turns
+ * the inner loop into two 8-wide FMAs per tap. */
+typedef float orc_v8f __attribute__((vector_size(32), aligned(4)));   /* unaligned 8-float vector */
+
+static void fir_f32_contig(const float *taps, int T, const float *x, size_t n, float *y)
+{
+    size_t i = 0;
+    for (; i + 16 <= n; i += 16) {                   /* 16 complex outputs = 4 x 8 floats */
+        orc_v8f a0 = {0, 0, 0, 0, 0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
+        const float *px = x + 2 * (long)i;
+        for (int k = T - 1; k >= 0; k--) {           /* descending k, like the HIP kernels */
+            const float h = taps[k];
+            a0 += h * *(const orc_v8f *)(px - 2 * k);
+            a1 += h * *(const orc_v8f *)(px - 2 * k + 8);
+            a2 += h * *(const orc_v8f *)(px - 2 * k + 16);
+            a3 += h * *(const orc_v8f *)(px - 2 * k + 24);
+        }
+        *(orc_v8f *)(y + 2 * i) = a0;
+        *(orc_v8f *)(y + 2 * i + 8) = a1;
+        *(orc_v8f *)(y + 2 * i + 16) = a2;
+        *(orc_v8f *)(y + 2 * i + 24) = a3;
+    }
+    for (; i < n; i++) {
+        float ar = 0, ai = 0;
+        for (int k = T - 1; k >= 0; k--) {
+            ar += taps[k] * x[2 * ((long)i - k)]; ai += taps[k] * x[2 * ((long)i - k) + 1];
+        }
+        y[2 * i] = ar; y[2 * i + 1] = ai;
+    }
+}
+
 void orc_fir_f32(const float *taps, int T, float *hist, const float *x, size_t n, float *y)
 {
     int H = T - 1;
-    /* contiguous [hist | x] view would need a copy; handle the head separately */
+    /* head: outputs that reach into the carried history */
     size_t head = n < (size_t)H ? n : (size_t)H;
     for (size_t i = 0; i < head; i++) {
         float ar = 0, ai = 0;
-        for (int k = 0; k < T; k++) {
+        for (int k = T - 1; k >= 0; k--) {
             long j = (long)i - k;
             float xr, xi;
             if (j >= 0) { xr = x[2 * j]; xi = x[2 * j + 1]; }
@@ -341,15 +373,7 @@ void orc_fir_f32(const float *taps, int T, float *hist, const float *x, size_t n
         }
         y[2 * i] = ar; y[2 * i + 1] = ai;
     }
-    for (size_t i = head; i < n; i++) {
-        const float *p = x + 2 * (i - H); /* oldest of the window */
-        float ar = 0, ai = 0;
-        for (int k = 0; k < T; k++) { /* h[T-1-k] pairs with x[i-H+k] */
-            float h = taps[T - 1 - k];
-            ar += h * p[2 * k]; ai += h * p[2 * k + 1];
-        }
-        y[2 * i] = ar; y[2 * i + 1] = ai;
-    }
+    if (n > head) fir_f32_contig(taps, T, x + 2 * head, n - head, y + 2 * head);
     if (H > 0) {
         if (n >= (size_t)H) memcpy(hist, x + 2 * (n - H), sizeof(float) * 2 * H);
         else {
@@ -503,4 +527,57 @@ size_t orc_rx_pipe_f32(int channel, const uint8_t *bytes, size_t n_bytes,
     orc_cs16_to_cf32(tmp_iq, tmp_cf32, n);
     orc_fir_f32(fir_taps, fir_n, fir_hist, tmp_cf32, n, tmp_fir);
     return orc_resamp_f32(rs_taps, rs_n, L, M, rs_hist, rs_n_in, tmp_fir, n, out);
+}
+
+/* All-cores variant of the same pipe over ONE long stream from zero state:
+ * native chunks are analysed/converted in parallel (each chunk re-synchronised
+ * on its own, caribou_smi.c:643-679), then FIR and resampler run in parallel
+ * over blocks of the contiguous CF32 sequence.  x_buf: 2*(n+T) floats,
+ * y_buf: 2*(n+8) floats, out: 2*ceil(n*L/M) floats.  Returns outputs. */
+size_t orc_rx_pipe_f32_mt(int channel, const uint8_t *bytes, size_t n_bytes, size_t native_batch_len,
+                          const float *fir_taps, int fir_n, const float *rs_taps, int rs_n, int L, int M,
+                          int16_t *iq_buf, float *x_buf, float *y_buf, float *out, int n_threads)
+{
+    const size_t n = n_bytes / ORC_BYTES_PER_SAMPLE;
+    const long n_chunks = (long)((n_bytes + native_batch_len - 1) / native_batch_len);
+    const int H = fir_n - 1, K = (rs_n + L - 1) / L, HR = K - 1;
+    float *x = x_buf + 2 * H;                /* x[-H..-1] = zero history */
+    float *y = y_buf + 2 * HR;
+    memset(x_buf, 0, sizeof(float) * 2 * H);
+    memset(y_buf, 0, sizeof(float) * 2 * HR);
+    int bad = 0;
+#pragma omp parallel for num_threads(n_threads) schedule(dynamic, 1) reduction(|:bad)
+    for (long c = 0; c < n_chunks; c++) {
+        size_t off = (size_t)c * native_batch_len;
+        size_t len = n_bytes - off < native_batch_len ? n_bytes - off : native_batch_len;
+        int16_t *iq = iq_buf + 2 * (off / 4);
+        if (orc_rx_data_analyze(channel, bytes + off, len, iq, NULL) < 0) { bad = 1; continue; }
+        orc_cs16_to_cf32(iq, x + 2 * (off / 4), len / 4);
+    }
+    if (bad) return 0;
+    const size_t blk = 16384;
+    const long n_blk = (long)((n + blk - 1) / blk);
+#pragma omp parallel for num_threads(n_threads) schedule(dynamic, 4)
+    for (long b = 0; b < n_blk; b++) {
+        size_t i0 = (size_t)b * blk, cnt = n - i0 < blk ? n - i0 : blk;
+        fir_f32_contig(fir_taps, fir_n, x + 2 * i0, cnt, y + 2 * i0);
+    }
+    const size_t n_out = (n * (size_t)L + M - 1) / M;
+    const size_t oblk = 16384;
+    const long n_oblk = (long)((n_out + oblk - 1) / oblk);
+#pragma omp parallel for num_threads(n_threads) schedule(dynamic, 4)
+    for (long b = 0; b < n_oblk; b++) {
+        size_t m0 = (size_t)b * oblk, m1 = m0 + oblk < n_out ? m0 + oblk : n_out;
+        for (size_t m = m0; m < m1; m++) {
+            uint64_t t = (uint64_t)m * M; long bi = (long)(t / L); int p = (int)(t % L);
+            float ar = 0, ai = 0;
+            for (int i = 0; i < K; i++) {
+                int k = p + i * L;
+                if (k >= rs_n) break;
+                ar += rs_taps[k] * y[2 * (bi - i)]; ai += rs_taps[k] * y[2 * (bi - i) + 1];
+            }
+            out[2 * m] = ar; out[2 * m + 1] = ai;
+        }
+    }
+    return n_out;
 }

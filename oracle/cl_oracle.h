@@ -113,6 +113,10 @@ size_t orc_rx_pipe_f32(int channel, const uint8_t *bytes, size_t n_bytes,
                        uint64_t *rs_n_in, int16_t *tmp_iq, float *tmp_cf32,
                        float *tmp_fir, float *out);
 
+size_t orc_rx_pipe_f32_mt(int channel, const uint8_t *bytes, size_t n_bytes, size_t native_batch_len,
+                          const float *fir_taps, int fir_n, const float *rs_taps, int rs_n, int L, int M,
+                          int16_t *iq_buf, float *x_buf, float *y_buf, float *out, int n_threads);
+
 #ifdef __cplusplus
 }
 #endif

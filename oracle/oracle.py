@@ -260,6 +260,23 @@ class RxPipeF32:
         return self.out[:n]
 
 
+def rx_pipe_f32_mt(channel, b, fir_taps, rs_taps, L, M, n_threads, native_batch_len=NATIVE_BATCH_LEN, bufs=None):
+    """All-cores CPU pipe over one long stream from zero state.  Returns (out, bufs)."""
+    b = np.ascontiguousarray(b, np.uint8)
+    fir = np.ascontiguousarray(fir_taps, np.float32); rs = np.ascontiguousarray(rs_taps, np.float32)
+    n = b.size // 4
+    if bufs is None:
+        bufs = (np.empty((n + 2, 2), np.int16), np.empty((n + fir.size + 8, 2), np.float32),
+                np.empty((n + 16, 2), np.float32), np.empty((n * L // M + 2, 2), np.float32))
+    iq, x, y, out = bufs
+    lib().orc_rx_pipe_f32_mt.restype = C.c_size_t
+    no = lib().orc_rx_pipe_f32_mt(int(channel), _p(b, C.c_uint8), C.c_size_t(b.size), C.c_size_t(native_batch_len),
+                                  _p(fir, C.c_float), fir.size, _p(rs, C.c_float), rs.size, int(L), int(M),
+                                  _p(iq, C.c_int16), _p(x, C.c_float), _p(y, C.c_float), _p(out, C.c_float),
+                                  int(n_threads))
+    return out[:no], bufs
+
+
 # ------------------------------------------------- compiled reference (_ref)
 def ref_find_buffer_offset(buf):
     buf = np.ascontiguousarray(buf, dtype=np.uint8).copy()

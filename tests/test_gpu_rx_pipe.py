@@ -1,0 +1,188 @@
+"""-m gpu: the fused RX pipe (unpack -> FIR -> resample | FM demod) through the C-ABI vs the
+fp64 oracle (tolerance 1e-5 of the stage peak, BASELINE.json north_star), vs the committed
+scipy fixtures, and vs the generic kernels (bit-identical by construction)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def G():
+    import torch
+    from cariboulite_amd import hip
+    import gpu_util
+    assert torch.cuda.is_available() and hip.require_gpu().startswith("gfx950")
+    return gpu_util
+
+
+CONFIGS = {
+    "c2": dict(fir="fir64_c2", rs="rs_3_2", L=3, M=2, mode=0),
+    "c3": dict(fir="fir64_c3", rs=None, L=1, M=1, mode=1),
+    "c4": dict(fir="fir128_c4", rs="rs_5_4", L=5, M=4, mode=0),
+    "f64": dict(fir="fir64_c2", rs=None, L=1, M=1, mode=0),
+    "f128": dict(fir="fir128_c4", rs=None, L=1, M=1, mode=0),
+}
+
+
+def make_pipe(cfg, n_streams=1, channel=0):
+    from cariboulite_amd import hip
+    t = load_golden("taps.npz")
+    c = CONFIGS[cfg]
+    return hip.RxPipe(n_streams, channel, t[c["fir"]], t[c["rs"]] if c["rs"] else None, c["L"], c["M"], c["mode"])
+
+
+def oracle_chain(orc, cfg, x_cf32):
+    """fp64 oracle of the float stages on CF32 input (streaming objects returned for chunk tests)."""
+    t = load_golden("taps.npz")
+    c = CONFIGS[cfg]
+    y = orc.FIR(t[c["fir"]]).f64(x_cf32)
+    if c["mode"] == 1:
+        return orc.fm_demod_f64(y)[0]
+    if c["rs"]:
+        return orc.Resampler(t[c["rs"]], c["L"], c["M"]).f64(y)
+    return y
+
+
+def run_pipe(G, pipe, words_u8, n, in_kind=None, chunks=None):
+    import torch
+    from cariboulite_amd import hip
+    in_kind = hip.PIPE_IN_SMI_WORDS if in_kind is None else in_kind
+    d_in = torch.from_numpy(np.ascontiguousarray(words_u8)).to(G.DEV)
+    cols = 1 if pipe.out_mode == hip.PIPE_OUT_FM_DEMOD else 2
+    outs = []
+    pos = 0
+    esz = 8 if in_kind == hip.PIPE_IN_CF32 else 4
+    for cn in (chunks or [n]):
+        no = pipe.out_count(cn)
+        out = torch.full((no + 8, cols), float("nan"), dtype=torch.float32, device=G.DEV)
+        got = pipe.run(in_kind, d_in.data_ptr() + pos * esz, 0, cn, out, 0)
+        assert got == no
+        torch.cuda.synchronize()
+        o = out.cpu().numpy()
+        assert np.all(np.isnan(o[no:])), "wrote past the end"
+        outs.append(o[:no])
+        pos += cn
+    return np.concatenate(outs)
+
+
+@pytest.mark.parametrize("cfg", list(CONFIGS))
+@pytest.mark.parametrize("channel", [0, 1])
+def test_fused_vs_oracle(G, orc, cfg, channel):
+    from cariboulite_amd import hip, synth
+    n = 3 * 4088 + 1234 if cfg != "c4" else 2 * 4088 + 600   # several tiles + ragged tail
+    n -= n % 4
+    b, i, q = synth.smi_stream_bytes(n, channel, stream=11)
+    pipe = make_pipe(cfg, 1, channel)
+    assert pipe.uses_fused(n)
+    got = run_pipe(G, pipe, b, n)
+    offs, iq, _ = orc.rx_data_analyze(channel, b)
+    want = oracle_chain(orc, cfg, orc.cs16_to_cf32(iq[:n]))
+    want = want.reshape(got.shape)
+    peak = np.max(np.abs(want))
+    assert got.shape == want.shape
+    assert np.max(np.abs(got - want)) <= TOL * peak, (np.max(np.abs(got - want)), peak)
+
+
+def test_c2_vs_scipy_fixture(G, orc):
+    from cariboulite_amd import hip
+    g = load_golden("dsp_float.npz")
+    pipe = make_pipe("c2")
+    got = run_pipe(G, pipe, g["bytes"], 8192)
+    want = g["fir64_c2__rs_3_2"]
+    assert np.max(np.abs(got - want)) <= TOL * np.max(np.abs(want))
+    pipe = make_pipe("c3")
+    got = run_pipe(G, pipe, g["bytes"], 8192)[:, 0]
+    assert np.max(np.abs(got - g["fir64_c3__fm_demod"])) <= TOL * np.pi
+    pipe = make_pipe("c4")
+    got = run_pipe(G, pipe, g["bytes"], 8192)
+    want = g["fir128_c4__rs_5_4"]
+    assert np.max(np.abs(got - want)) <= TOL * np.max(np.abs(want))
+
+
+@pytest.mark.parametrize("cfg", list(CONFIGS))
+def test_fused_equals_generic_bitwise(G, orc, cfg):
+    """Two implementations of one spec with the same summation order: identical bits."""
+    from cariboulite_amd import hip, synth
+    n = 2 * 4088 + 36
+    b, _, _ = synth.smi_stream_bytes(n, 0, stream=2)
+    p1, p2 = make_pipe(cfg), make_pipe(cfg)
+    p2.force_generic(True)
+    assert p1.uses_fused(n) and not p2.uses_fused(n)
+    a, g = run_pipe(G, p1, b, n), run_pipe(G, p2, b, n)
+    if CONFIGS[cfg]["mode"] == 1:
+        assert np.max(np.abs(a - g)) <= 2e-6          # atan2f on identical inputs
+    else:
+        assert np.array_equal(a, g)
+
+
+@pytest.mark.parametrize("cfg", ["c2", "c3", "c4"])
+def test_streaming_chunks_equal_one_shot(G, orc, cfg):
+    """History carried across calls: chunked == one big call (SURVEY.md section 5 checkpoint row)."""
+    from cariboulite_amd import hip, synth
+    n = 4 * 4096
+    b, _, _ = synth.smi_stream_bytes(n, 0, stream=5)
+    one = run_pipe(G, make_pipe(cfg), b, n)
+    chunks = [4096, 8, 4088, 4, 2048, 6140]          # all multiples of M=4/2: fused path
+    assert sum(chunks) == n
+    p = make_pipe(cfg)
+    many = run_pipe(G, p, b, n, chunks=chunks)
+    assert np.array_equal(one, many)
+    # ragged chunk lengths (odd phases) go through the generic kernels; same spec
+    chunks2 = [1, 2, 3, 4091, 5, 4090, 8192 - 8, 4]
+    assert sum(chunks2) == n
+    many2 = run_pipe(G, make_pipe(cfg), b, n, chunks=chunks2)
+    if CONFIGS[cfg]["mode"] == 1:
+        assert np.max(np.abs(one - many2)) <= 2e-6
+    else:
+        assert np.array_equal(one, many2)
+
+
+def test_multi_stream_and_input_kinds(G, orc):
+    import torch
+    from cariboulite_amd import hip, synth
+    n, ns = 4088 + 512, 5
+    t = load_golden("taps.npz")
+    words = np.stack([synth.smi_stream_bytes(n, 0, stream=s)[0].view(np.uint32) for s in range(ns)])
+    d_in = torch.from_numpy(words.view(np.int32)).to(G.DEV)
+    pipe = hip.RxPipe(ns, 0, t["fir64_c2"], t["rs_3_2"], 3, 2, 0)
+    no = pipe.out_count(n)
+    out = torch.zeros((ns, no + 4, 2), dtype=torch.float32, device=G.DEV)
+    assert pipe.run(hip.PIPE_IN_SMI_WORDS, d_in, n, n, out, no + 4) == no
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    single = [run_pipe(G, make_pipe("c2"), words[s].view(np.uint8), n) for s in range(ns)]
+    for s in range(ns):
+        assert np.array_equal(got[s, :no], single[s])
+    # CS16 and CF32 inputs give the same bits as raw words (exact conversions)
+    _, iq, _ = orc.rx_data_analyze(0, words[0].view(np.uint8))
+    cs16 = iq[:n].copy()
+    a = run_pipe(G, make_pipe("c2"), cs16.view(np.uint8), n, in_kind=hip.PIPE_IN_CS16)
+    assert np.array_equal(a, single[0])
+    cf32 = orc.cs16_to_cf32(cs16)
+    b = run_pipe(G, make_pipe("c2"), cf32.view(np.uint8), n, in_kind=hip.PIPE_IN_CF32)
+    assert np.max(np.abs(b - single[0])) <= 1e-6 * np.max(np.abs(single[0]))
+
+
+def test_linearity_and_impulse_full_size(G, orc):
+    """Size-independent properties at a bench-like size: an impulse returns the taps;
+    response to a constant settles at the DC gain."""
+    import torch
+    from cariboulite_amd import hip, synth
+    t = load_golden("taps.npz")
+    n = 1 << 22
+    i = np.zeros(n, np.int64); q = np.zeros(n, np.int64)
+    i[1000] = 4095; q[1000] = -4096
+    i[2_000_000] = 2048
+    words = synth.iq_to_words(i, q, 0)
+    pipe = hip.RxPipe(1, 0, t["fir64_c2"], None, 1, 1, 0)
+    got = run_pipe(G, pipe, words.view(np.uint8), n)
+    h = t["fir64_c2"].astype(np.float64)
+    assert np.max(np.abs(got[1000:1064, 0] - h * (4095 / 4096))) < 1e-6
+    assert np.max(np.abs(got[1000:1064, 1] - h * (-1.0))) < 1e-6
+    assert np.max(np.abs(got[2_000_000:2_000_064, 0] - h * 0.5)) < 1e-6
+    nz = np.zeros(n, bool); nz[1000:1064] = True; nz[2_000_000:2_000_064] = True
+    assert np.all(got[~nz] == 0)
