@@ -327,7 +327,7 @@ __global__ __launch_bounds__(C::NT) void rx_pipe_fused_kernel(const PipeArgs a)
             const long gi = o0 + m;
             if (gi >= lo && gi + 2 <= hi) {
                 f32x4 v = {o[m].x, o[m].y, o[m + 1].x, o[m + 1].y};
-                __builtin_nontemporal_store(v, (f32x4 *)(out + gi));
+                *(f32x4 *)(out + gi) = v;
             } else {
                 if (gi >= lo && gi < hi) out[gi] = o[m];
                 if (gi + 1 >= lo && gi + 1 < hi) out[gi + 1] = o[m + 1];
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(C::NT) void rx_pipe_fused_kernel(const PipeArgs a)
             const long gi = fir0 + m;
             if (gi >= lo && gi + 4 <= hi) {
                 f32x4 v = {o[m], o[m + 1], o[m + 2], o[m + 3]};
-                __builtin_nontemporal_store(v, (f32x4 *)(out + gi));
+                *(f32x4 *)(out + gi) = v;
             } else {
 #pragma unroll
                 for (int k = 0; k < 4; k++)

@@ -47,6 +47,28 @@ def oracle_chain(orc, cfg, x_cf32):
     return y
 
 
+def check_fm(G, orc, got, words_u8, n, channel, y_oracle):
+    """FM demod parity.  atan2 is ill-conditioned where |y| -> 0 (a 1e-7 error of the fp32 FIR
+    output becomes an arbitrary angle error), so the 1e-5 bound is applied (a) to the demod
+    stage in isolation -- oracle demod of the SAME fp32 FIR outputs the fused kernel produced
+    (the FIR-only config runs the identical FIR code) -- and (b) end to end on the
+    magnitude-weighted phasor, which is well conditioned."""
+    from cariboulite_amd import hip
+    t = load_golden("taps.npz")
+    fir_only = hip.RxPipe(1, channel, t["fir64_c3"], None, 1, 1, hip.PIPE_OUT_IQ)
+    y_gpu = run_pipe(G, fir_only, words_u8, n)
+    want_iso = orc.fm_demod_f64(y_gpu.astype(np.float64))[0]
+    d = np.abs(got - want_iso)
+    d = np.minimum(d, 2 * np.pi - d)                      # +-pi wrap is the same angle
+    assert np.max(d) <= TOL * np.pi, np.max(d)
+    want = orc.fm_demod_f64(y_oracle)[0]
+    mag = np.hypot(y_oracle[:, 0], y_oracle[:, 1])
+    mag_prev = np.concatenate([[0.0], mag[:-1]])
+    w = np.minimum(mag, mag_prev)
+    err = np.abs(np.exp(1j * got) - np.exp(1j * want)) * w
+    assert np.max(err) <= TOL * np.max(mag), (np.max(err), np.max(mag))
+
+
 def run_pipe(G, pipe, words_u8, n, in_kind=None, chunks=None):
     import torch
     from cariboulite_amd import hip
@@ -80,6 +102,10 @@ def test_fused_vs_oracle(G, orc, cfg, channel):
     assert pipe.uses_fused(n)
     got = run_pipe(G, pipe, b, n)
     offs, iq, _ = orc.rx_data_analyze(channel, b)
+    if cfg == "c3":
+        y = orc.FIR(load_golden("taps.npz")["fir64_c3"]).f64(orc.cs16_to_cf32(iq[:n]))
+        check_fm(G, orc, got[:, 0], b, n, channel, y)
+        return
     want = oracle_chain(orc, cfg, orc.cs16_to_cf32(iq[:n]))
     want = want.reshape(got.shape)
     peak = np.max(np.abs(want))
@@ -96,7 +122,10 @@ def test_c2_vs_scipy_fixture(G, orc):
     assert np.max(np.abs(got - want)) <= TOL * np.max(np.abs(want))
     pipe = make_pipe("c3")
     got = run_pipe(G, pipe, g["bytes"], 8192)[:, 0]
-    assert np.max(np.abs(got - g["fir64_c3__fm_demod"])) <= TOL * np.pi
+    check_fm(G, orc, got, g["bytes"], 8192, 0, g["fir64_c3__y"])
+    big = np.hypot(g["fir64_c3__y"][:, 0], g["fir64_c3__y"][:, 1]) > 0.05      # well-conditioned samples
+    big[1:] &= big[:-1]
+    assert np.max(np.abs(got - g["fir64_c3__fm_demod"])[big]) <= TOL * np.pi
     pipe = make_pipe("c4")
     got = run_pipe(G, pipe, g["bytes"], 8192)
     want = g["fir128_c4__rs_5_4"]
@@ -132,7 +161,7 @@ def test_streaming_chunks_equal_one_shot(G, orc, cfg):
     many = run_pipe(G, p, b, n, chunks=chunks)
     assert np.array_equal(one, many)
     # ragged chunk lengths (odd phases) go through the generic kernels; same spec
-    chunks2 = [1, 2, 3, 4091, 5, 4090, 8192 - 8, 4]
+    chunks2 = [1, 2, 3, 4091, 5, 4090, 8184, 8]
     assert sum(chunks2) == n
     many2 = run_pipe(G, make_pipe(cfg), b, n, chunks=chunks2)
     if CONFIGS[cfg]["mode"] == 1:
