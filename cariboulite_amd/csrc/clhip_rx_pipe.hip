@@ -20,6 +20,7 @@
 // spec -- any T / L / M / call length / phase -- used when no fused
 // instantiation matches and as an independent cross-check in tests.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -463,6 +464,8 @@ __global__ __launch_bounds__(256) void gen_copy_kernel(const f32x2 *__restrict__
 // host side of the pipe object
 // ---------------------------------------------------------------------------
 typedef PipeCfg<64, 3, 2, 8, MODE_IQ, 16, 256> CfgC2;     // config 2: FIR64 + 3/2
+typedef PipeCfg<64, 3, 2, 8, MODE_IQ, 16, 128> CfgC2b;    // experiment: 2 waves per workgroup
+typedef PipeCfg<64, 3, 2, 8, MODE_IQ, 16, 64> CfgC2c;     // experiment: 1 wave per workgroup
 typedef PipeCfg<64, 1, 1, 1, MODE_FM, 16, 256> CfgC3;     // config 3: FIR64 + FM demod
 typedef PipeCfg<128, 5, 4, 8, MODE_IQ, 16, 256> CfgC4;    // config 4: FIR128 + 5/4
 typedef PipeCfg<64, 1, 1, 1, MODE_IQ, 16, 256> CfgF64;    // FIR64 only
@@ -643,10 +646,17 @@ extern "C" long clhip_rx_pipe_run(clhip_rx_pipe *p, int in_kind, const void *d_i
         a.bad_flag = p->chk_flag;
     }
 
+    if (getenv("CLHIP_DEBUG_NOSTORE")) a.n_out = 0;     // timing ablation only: every store masked off
     if (clhip_rx_pipe_uses_fused(p, n_in, in_kind)) {
         int rc = -1;
         switch (p->fused_id) {
-        case 0: rc = launch_fused<CfgC2>(a, p->n_streams, s); break;
+        case 0: {
+            static int variant = getenv("CLHIP_C2_VARIANT") ? atoi(getenv("CLHIP_C2_VARIANT")) : 0;
+            if (variant == 1) rc = launch_fused<CfgC2b>(a, p->n_streams, s);
+            else if (variant == 2) rc = launch_fused<CfgC2c>(a, p->n_streams, s);
+            else rc = launch_fused<CfgC2>(a, p->n_streams, s);
+            break;
+        }
         case 1: rc = launch_fused<CfgC3>(a, p->n_streams, s); break;
         case 2: rc = launch_fused<CfgC4>(a, p->n_streams, s); break;
         case 3: rc = launch_fused<CfgF64>(a, p->n_streams, s); break;

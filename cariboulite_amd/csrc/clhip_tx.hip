@@ -1,0 +1,392 @@
+// clhip_tx.hip -- FM / CW stages and the TX pipe (BASELINE.json config 5):
+//   fp32 message -> FM modulate (phase accumulated in fp64) -> L/M polyphase resample
+//   -> (int16_t)(f * 4096.0f)  (soapy_api/CaribouliteStream.cpp:199-212)
+//   -> int13 pack to SMI TX bytes (caribou_smi.c:684-717)
+// FM / CW / resampling have no reference implementation (SURVEY.md section 8
+// row a13 is the spec); the quantise + pack tail is bit-exact integer work.
+//
+// The phase recursion phi[n] = phi[n-1] + w m[n] is a prefix sum: per-block
+// fp64 partial sums, a scan of the block sums, then a per-block scan that adds
+// the block offset, wraps to (-pi, pi] and evaluates sincos in fp32.
+#include <math.h>
+#include <string.h>
+
+#include <new>
+
+#include "clhip_common.h"
+
+#define TWO_PI 6.283185307179586476925286766559
+#define FM_BLOCK 256
+#define FM_PER_THREAD 4
+#define FM_ELEMS (FM_BLOCK * FM_PER_THREAD)
+
+__device__ __forceinline__ double wrap_pi(double ph) { return ph - TWO_PI * rint(ph * (1.0 / TWO_PI)); }
+
+__device__ __forceinline__ f32x2 phasor(double ph)
+{
+    // reduce in fp64, evaluate in fp32: |err| ~ 2e-7, far inside the 1e-5 bar
+    const float r = (float)(wrap_pi(ph) * (1.0 / 3.14159265358979323846));   // in [-1, 1]
+    float sn, cs;
+    sincospif(r, &sn, &cs);
+    f32x2 o = {cs, sn};
+    return o;
+}
+
+// ---------------------------------------------------------------------------
+// FM demod (standalone stage): y[n] = atan2(Im z, Re z), z = x[n] conj(x[n-1])
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fm_demod_kernel(const f32x2 *__restrict__ x, size_t n,
+                                                       const float *__restrict__ prev, float *__restrict__ out)
+{
+    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; j < n; j += step) {
+        const f32x2 c = x[j];
+        f32x2 p;
+        if (j > 0) p = x[j - 1];
+        else { p.x = prev[0]; p.y = prev[1]; }
+        out[j] = atan2f(c.y * p.x - c.x * p.y, c.x * p.x + c.y * p.y);
+    }
+}
+__global__ void fm_demod_carry_kernel(const f32x2 *__restrict__ x, size_t n, float *__restrict__ prev)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) { prev[0] = x[n - 1].x; prev[1] = x[n - 1].y; }
+}
+
+extern "C" int clhip_fm_demod(const float *d_iq, size_t n, float *d_prev, float *d_out, void *stream)
+{
+    if (n == 0) return 0;
+    if (!d_iq || !d_prev || !d_out) { clhip_set_error("clhip_fm_demod: null buffer"); return -1; }
+    unsigned grid = (unsigned)clhip_div_up(n, 256);
+    if (grid > 8192) grid = 8192;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(fm_demod_kernel, dim3(grid), dim3(256), 0, s, (const f32x2 *)d_iq, n, d_prev, d_out);
+    hipLaunchKernelGGL(fm_demod_carry_kernel, dim3(1), dim3(64), 0, s, (const f32x2 *)d_iq, n, d_prev);
+    CLHIP_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// CW tone: I = cos(2 pi f n / fs + phase0), Q = sin(...)   (examples/cpp_api/sync_tx_api/main.cpp:42-55)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cw_tone_kernel(double w, double phase0, size_t n, f32x2 *__restrict__ out)
+{
+    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    // keep the product exact-ish for huge n: reduce w*j modulo 2pi in "turns"
+    const double turns = w * (1.0 / TWO_PI);
+    for (; j < n; j += step) {
+        double t = turns * (double)j;
+        t -= rint(t);
+        out[j] = phasor(phase0 + t * TWO_PI);
+    }
+}
+
+extern "C" int clhip_cw_tone(double f_hz, double fs_hz, double phase0, size_t n, float *d_iq_out, void *stream)
+{
+    if (n == 0) return 0;
+    if (!d_iq_out || fs_hz <= 0) { clhip_set_error("clhip_cw_tone: bad arguments"); return -1; }
+    unsigned grid = (unsigned)clhip_div_up(n, 256);
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(cw_tone_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, TWO_PI * f_hz / fs_hz, phase0, n,
+                       (f32x2 *)d_iq_out);
+    CLHIP_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// FM modulate
+// ---------------------------------------------------------------------------
+// pass 1: per-block sum of w*m  (grid.y = stream)
+__global__ __launch_bounds__(FM_BLOCK) void fm_block_sum_kernel(const float *__restrict__ m, long m_stride, size_t n,
+                                                              double w, double *__restrict__ bsum, long n_blocks)
+{
+    __shared__ double sh[FM_BLOCK / 64];
+    const float *mm = m + (long)blockIdx.y * m_stride;
+    const size_t base = (size_t)blockIdx.x * FM_ELEMS + (size_t)threadIdx.x * FM_PER_THREAD;
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < FM_PER_THREAD; k++)
+        if (base + k < n) s += w * (double)mm[base + k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int k = 0; k < FM_BLOCK / 64; k++) t += sh[k];
+        bsum[(long)blockIdx.y * n_blocks + blockIdx.x] = t;
+    }
+}
+
+// pass 2: exclusive scan of the block sums of one stream (one workgroup per stream);
+// boff[b] = phase0 + sum_{b'<b} bsum[b'];  new phase = wrap(phase0 + total)
+__global__ __launch_bounds__(256) void fm_block_scan_kernel(double *__restrict__ bsum, long n_blocks,
+                                                            const double *__restrict__ phase_in,
+                                                            double *__restrict__ phase_new)
+{
+    __shared__ double sh[256];
+    double *b = bsum + (long)blockIdx.x * n_blocks;
+    const int t = threadIdx.x;
+    const long per = (n_blocks + 255) / 256;
+    const long lo = (long)t * per, hi = lo + per < n_blocks ? lo + per : n_blocks;
+    double s = 0.0;
+    for (long k = lo; k < hi; k++) s += b[k];
+    sh[t] = s;
+    __syncthreads();
+    if (t == 0) {                       // 256 partials: serial exclusive scan is plenty
+        double run = phase_in[blockIdx.x];
+        for (int k = 0; k < 256; k++) { const double v = sh[k]; sh[k] = run; run += v; }
+        phase_new[blockIdx.x] = wrap_pi(run);
+    }
+    __syncthreads();
+    double run = sh[t];
+    for (long k = lo; k < hi; k++) { const double v = b[k]; b[k] = run; run += v; }
+}
+
+// pass 3: per-block inclusive scan + offset -> phasor
+__global__ __launch_bounds__(FM_BLOCK) void fm_apply_kernel(const float *__restrict__ m, long m_stride, size_t n,
+                                                          double w, const double *__restrict__ boff, long n_blocks,
+                                                          f32x2 *__restrict__ out, long out_stride)
+{
+    __shared__ double sh[FM_BLOCK / 64];
+    const float *mm = m + (long)blockIdx.y * m_stride;
+    f32x2 *oo = out + (long)blockIdx.y * out_stride;
+    const size_t base = (size_t)blockIdx.x * FM_ELEMS + (size_t)threadIdx.x * FM_PER_THREAD;
+    double v[FM_PER_THREAD], s = 0.0;
+#pragma unroll
+    for (int k = 0; k < FM_PER_THREAD; k++) {
+        s += (base + k < n) ? w * (double)mm[base + k] : 0.0;
+        v[k] = s;                                      // inclusive within the lane
+    }
+    // inclusive scan of lane totals across the wave, then across waves
+    double incl = s;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
+    }
+    if (lane == 63) sh[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    double wave_off = 0.0;
+    for (int k = 0; k < (int)(threadIdx.x >> 6); k++) wave_off += sh[k];
+    const double excl = boff[(long)blockIdx.y * n_blocks + blockIdx.x] + wave_off + (incl - s);
+#pragma unroll
+    for (int k = 0; k < FM_PER_THREAD; k++)
+        if (base + k < n) oo[base + k] = phasor(excl + v[k]);
+}
+
+extern "C" size_t clhip_fm_mod_workspace_bytes(size_t n) { return (clhip_div_up(n, FM_ELEMS) + 2) * sizeof(double); }
+
+static int fm_mod_launch(const float *d_msg, long m_stride, size_t n, int n_streams, double w, double *d_phase,
+                         f32x2 *d_out, long out_stride, double *ws, hipStream_t s)
+{
+    const long n_blocks = (long)clhip_div_up(n, FM_ELEMS);
+    dim3 grid((unsigned)n_blocks, n_streams);
+    hipLaunchKernelGGL(fm_block_sum_kernel, grid, dim3(FM_BLOCK), 0, s, d_msg, m_stride, n, w, ws, n_blocks);
+    // phase_new is written to a scratch slot first: pass 3 of other streams may still need nothing from
+    // d_phase, but keep in/out distinct within the launch that reads it
+    double *phase_new = ws + (size_t)n_blocks * n_streams;
+    hipLaunchKernelGGL(fm_block_scan_kernel, dim3(n_streams), dim3(256), 0, s, ws, n_blocks, d_phase, phase_new);
+    hipLaunchKernelGGL(fm_apply_kernel, grid, dim3(FM_BLOCK), 0, s, d_msg, m_stride, n, w, ws, n_blocks, d_out,
+                       out_stride);
+    CLHIP_CHECK(hipMemcpyAsync(d_phase, phase_new, sizeof(double) * n_streams, hipMemcpyDeviceToDevice, s));
+    CLHIP_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int clhip_fm_mod(const float *d_msg, size_t n, double kf_hz, double fs_hz, double *d_phase,
+                            float *d_iq_out, void *d_ws, size_t ws_bytes, void *stream)
+{
+    if (n == 0) return 0;
+    if (!d_msg || !d_phase || !d_iq_out || !d_ws || fs_hz <= 0 || ws_bytes < clhip_fm_mod_workspace_bytes(n)) {
+        clhip_set_error("clhip_fm_mod: bad arguments or workspace too small");
+        return -1;
+    }
+    return fm_mod_launch(d_msg, 0, n, 1, TWO_PI * kf_hz / fs_hz, d_phase, (f32x2 *)d_iq_out, 0, (double *)d_ws,
+                         (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------
+// TX pipe
+// ---------------------------------------------------------------------------
+#define TX_MAX_RS 40
+
+struct clhip_tx_pipe {
+    int n_streams, n_rs, L, M, kp, pack_mode;
+    double w;                        // 2 pi kf / fs
+    float rs[TX_MAX_RS];
+    float *d_rs;
+    f32x2 *hist[2]; int cur;         // [n_streams][kp-1] modulated samples preceding the call
+    double *d_phase;                 // [n_streams]
+    unsigned long long n_total;
+    f32x2 *Y; size_t y_cap;          // modulated signal workspace (per stream)
+    double *ws; size_t ws_cap;
+};
+
+__device__ __forceinline__ uint32_t tx_f2i16(float v)
+{
+    const int t = (v >= -2147483648.0f && v < 2147483648.0f) ? (int)v : (int)0x80000000;
+    return (uint32_t)t & 0xFFFFu;
+}
+
+__device__ __forceinline__ uint32_t tx_pack_word(int mode, uint32_t ii, uint32_t qq)
+{
+    if (mode == CL_TX_AS_WRITTEN) { ii = 0xFFFFu; qq = 0; }       // caribou_smi.c:700-701
+    ii &= 0x1FFFu; qq &= 0x1FFFu;
+    const uint32_t s = (0x7u << 29) | ((ii >> 8) << 24) | (((ii >> 1) & 0x7Fu) << 16) | ((ii & 1u) << 14) |
+                       ((qq >> 7) << 8) | (qq & 0x7Fu);
+    return __builtin_bswap32(s);
+}
+
+// one output per lane: upfirdn polyphase leg -> quantise -> pack
+__global__ __launch_bounds__(256) void tx_resample_pack_kernel(const f32x2 *__restrict__ x, long x_stride,
+                                                               const f32x2 *__restrict__ hist, int H,
+                                                               const float *__restrict__ rs, int n_rs, int L, int M,
+                                                               unsigned long long n0, long n_out, int pack_mode,
+                                                               uint32_t *__restrict__ words, long w_stride,
+                                                               f32x2 *__restrict__ tap, long tap_stride)
+{
+    const int s = blockIdx.y;
+    const f32x2 *xs = x + (long)s * x_stride;
+    const f32x2 *hs = hist + (long)s * H;
+    const unsigned long long m0 = (n0 * L + M - 1) / M;
+    const int KP = (n_rs + L - 1) / L;
+    for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < n_out; j += (long)gridDim.x * blockDim.x) {
+        const unsigned long long tp = (m0 + j) * M;
+        const long b = (long)(tp / L - n0);
+        const int p = (int)(tp % L);
+        f32x2 acc = {0.f, 0.f};
+        for (int i = 0; i < KP; i++) {
+            const int k = p + i * L;
+            if (k >= n_rs) break;
+            const long idx = b - i;
+            f32x2 v;
+            if (idx >= 0) v = xs[idx];
+            else if (H + idx >= 0) v = hs[H + idx];
+            else { v.x = 0.f; v.y = 0.f; }
+            acc += v * rs[k];
+        }
+        if (tap) tap[(long)s * tap_stride + j] = acc;
+        // (int16_t)(f * 4096.0f)  CaribouliteStream.cpp:207-208
+        words[(long)s * w_stride + j] = tx_pack_word(pack_mode, tx_f2i16(acc.x * 4096.0f), tx_f2i16(acc.y * 4096.0f));
+    }
+}
+
+__global__ void tx_update_hist_kernel(const f32x2 *__restrict__ x, long x_stride, long n, const f32x2 *__restrict__ hin,
+                                      f32x2 *__restrict__ hout, int H)
+{
+    const int s = blockIdx.x;
+    for (int j = threadIdx.x; j < H; j += blockDim.x) {
+        const long g = n - H + j;
+        f32x2 v;
+        if (g >= 0) v = x[(long)s * x_stride + g];
+        else v = hin[(long)s * H + H + g];
+        hout[(long)s * H + j] = v;
+    }
+}
+
+extern "C" clhip_tx_pipe *clhip_tx_pipe_create(int n_streams, double fm_kf_hz, double fs_hz, const float *h_rs,
+                                               int n_rs, int up, int down, int pack_mode)
+{
+    if (n_streams <= 0 || up <= 0 || down <= 0 || fs_hz <= 0) { clhip_set_error("clhip_tx_pipe_create: bad arguments"); return nullptr; }
+    const bool resamp = !(up == 1 && down == 1);
+    if (resamp && (!h_rs || n_rs <= 0 || n_rs > TX_MAX_RS)) {
+        clhip_set_error("clhip_tx_pipe_create: resampler needs 1..%d prototype taps", TX_MAX_RS);
+        return nullptr;
+    }
+    clhip_tx_pipe *p = new (std::nothrow) clhip_tx_pipe();
+    if (!p) return nullptr;
+    memset(p, 0, sizeof *p);
+    p->n_streams = n_streams; p->L = up; p->M = down; p->pack_mode = pack_mode;
+    p->w = TWO_PI * fm_kf_hz / fs_hz;
+    if (resamp) { p->n_rs = n_rs; memcpy(p->rs, h_rs, sizeof(float) * n_rs); }
+    else { p->n_rs = 1; p->rs[0] = 1.0f; }
+    p->kp = (p->n_rs + up - 1) / up;
+    const int H = p->kp - 1 > 0 ? p->kp - 1 : 1;
+    p->d_rs = (float *)clhip_malloc(sizeof p->rs);
+    p->d_phase = (double *)clhip_malloc(sizeof(double) * n_streams);
+    for (int i = 0; i < 2; i++) p->hist[i] = (f32x2 *)clhip_malloc(sizeof(f32x2) * H * n_streams);
+    if (!p->d_rs || !p->d_phase || !p->hist[0] || !p->hist[1]) { clhip_tx_pipe_destroy(p); return nullptr; }
+    (void)hipMemcpy(p->d_rs, p->rs, sizeof p->rs, hipMemcpyHostToDevice);
+    clhip_tx_pipe_reset(p);
+    return p;
+}
+
+extern "C" void clhip_tx_pipe_destroy(clhip_tx_pipe *p)
+{
+    if (!p) return;
+    clhip_free(p->d_rs); clhip_free(p->d_phase); clhip_free(p->hist[0]); clhip_free(p->hist[1]);
+    clhip_free(p->Y); clhip_free(p->ws);
+    delete p;
+}
+
+extern "C" void clhip_tx_pipe_reset(clhip_tx_pipe *p)
+{
+    const int H = p->kp - 1 > 0 ? p->kp - 1 : 1;
+    (void)hipMemset(p->d_phase, 0, sizeof(double) * p->n_streams);
+    (void)hipMemset(p->hist[0], 0, sizeof(f32x2) * H * p->n_streams);
+    (void)hipMemset(p->hist[1], 0, sizeof(f32x2) * H * p->n_streams);
+    p->cur = 0; p->n_total = 0;
+}
+
+extern "C" size_t clhip_tx_pipe_out_count(const clhip_tx_pipe *p, size_t n_in)
+{
+    const unsigned long long n0 = p->n_total, n1 = n0 + n_in;
+    return (size_t)((n1 * p->L + p->M - 1) / p->M - (n0 * p->L + p->M - 1) / p->M);
+}
+
+extern "C" long clhip_tx_pipe_run(clhip_tx_pipe *p, int in_kind, const void *d_in, size_t in_stride, size_t n_in,
+                                  uint8_t *d_bytes, size_t out_stride_bytes, float *d_iq_tap, size_t iq_tap_stride,
+                                  void *stream)
+{
+    if (!p || (in_kind != CL_TXPIPE_IN_FM_MESSAGE && in_kind != CL_TXPIPE_IN_CF32)) {
+        clhip_set_error("clhip_tx_pipe_run: bad arguments");
+        return -1;
+    }
+    if (n_in == 0) return 0;
+    if (!d_in || !d_bytes || (out_stride_bytes & 3) || (((uintptr_t)d_bytes) & 3)) {
+        clhip_set_error("clhip_tx_pipe_run: null / misaligned buffer");
+        return -1;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n_out = clhip_tx_pipe_out_count(p, n_in);
+    const int H = p->kp - 1;
+    const f32x2 *x = (const f32x2 *)d_in;
+    long x_stride = (long)in_stride;
+    if (in_kind == CL_TXPIPE_IN_FM_MESSAGE) {
+        if (n_in > p->y_cap) {
+            clhip_free(p->Y);
+            p->Y = (f32x2 *)clhip_malloc(sizeof(f32x2) * n_in * p->n_streams);
+            p->y_cap = p->Y ? n_in : 0;
+            if (!p->Y) return -1;
+        }
+        const size_t wsn = (clhip_div_up(n_in, FM_ELEMS) + 2) * p->n_streams + 8;
+        if (wsn > p->ws_cap) {
+            clhip_free(p->ws);
+            p->ws = (double *)clhip_malloc(sizeof(double) * wsn);
+            p->ws_cap = p->ws ? wsn : 0;
+            if (!p->ws) return -1;
+        }
+        if (fm_mod_launch((const float *)d_in, (long)in_stride, n_in, p->n_streams, p->w, p->d_phase, p->Y,
+                          (long)p->y_cap, p->ws, s))
+            return -1;
+        x = p->Y; x_stride = (long)p->y_cap;
+    }
+    if (n_out) {
+        unsigned gx = (unsigned)clhip_div_up(n_out, 256);
+        if (gx > 4096) gx = 4096;
+        hipLaunchKernelGGL(tx_resample_pack_kernel, dim3(gx, p->n_streams), dim3(256), 0, s, x, x_stride,
+                           p->hist[p->cur], H, p->d_rs, p->n_rs, p->L, p->M, p->n_total, (long)n_out, p->pack_mode,
+                           (uint32_t *)d_bytes, (long)(out_stride_bytes / 4), (f32x2 *)d_iq_tap, (long)iq_tap_stride);
+    }
+    if (H > 0) {
+        hipLaunchKernelGGL(tx_update_hist_kernel, dim3(p->n_streams), dim3(64), 0, s, x, x_stride, (long)n_in,
+                           p->hist[p->cur], p->hist[p->cur ^ 1], H);
+        p->cur ^= 1;
+    }
+    CLHIP_CHECK_LAUNCH();
+    p->n_total += n_in;
+    return (long)n_out;
+}

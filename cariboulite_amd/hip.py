@@ -49,6 +49,8 @@ _SIGS = {
     "clhip_smi_pack": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "clhip_iir_cs16": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
     "clhip_iir_workspace_bytes": (C.c_size_t, [C.c_size_t, C.c_int]),
+    "clhip_iir_cs16_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int,
+                                       C.c_void_p, C.c_size_t, C.c_void_p]),
     "clhip_rx_pipe_create": (C.c_void_p, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "clhip_rx_pipe_destroy": (None, [C.c_void_p]),
     "clhip_rx_pipe_reset": (None, [C.c_void_p]),
@@ -189,3 +191,74 @@ class RxPipe:
         return _check(lib().clhip_rx_pipe_run(self.h, in_kind, ptr(d_in), in_stride, n_in, ptr(d_out), out_stride,
                                               stream if stream is not None else current_stream()),
                       "clhip_rx_pipe_run")
+
+
+class IIR:
+    """clhip_iir_cs16: in-place fp64 biquad cascade on CS16 streams (state carried on device)."""
+
+    def __init__(self, sos, n_streams=1, device="cuda:0"):
+        import torch
+        sos = np.asarray(sos, dtype=np.float64)
+        if sos.shape[1] == 6:                       # scipy layout b0 b1 b2 a0 a1 a2 -> {b0,b1,b2,a1,a2}
+            sos = np.concatenate([sos[:, :3] / sos[:, 3:4], sos[:, 4:] / sos[:, 3:4]], 1)
+        self.sos = np.ascontiguousarray(sos)
+        self.n_streams = n_streams
+        self.state = torch.zeros((n_streams, 16), dtype=torch.float64, device=device)
+        self.ws = None
+        self.device = device
+
+    def run(self, d_iq, n, stride=None, stream=None):
+        import torch
+        need = lib().clhip_iir_workspace_bytes(n, self.sos.shape[0]) * self.n_streams
+        if self.ws is None or self.ws.numel() < need:
+            self.ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        _check(lib().clhip_iir_cs16_batch(self.sos.ctypes.data, self.sos.shape[0], ptr(self.state), ptr(d_iq),
+                                          n if stride is None else stride, n, self.n_streams, ptr(self.ws),
+                                          self.ws.numel(), stream if stream is not None else current_stream()),
+               "clhip_iir_cs16_batch")
+
+
+class TxPipe:
+    """clhip_tx_pipe: [FM modulate] -> L/M resample -> quantise -> int13 pack."""
+
+    def __init__(self, n_streams, kf_hz, fs_hz, rs_taps=None, up=1, down=1, pack_mode=TX_DOCUMENTED):
+        rs = np.ascontiguousarray(rs_taps, dtype=np.float32) if rs_taps is not None else None
+        self.h = lib().clhip_tx_pipe_create(n_streams, kf_hz, fs_hz, rs.ctypes.data if rs is not None else None,
+                                            rs.size if rs is not None else 0, up, down, pack_mode)
+        if not self.h:
+            raise RuntimeError("clhip_tx_pipe_create failed: " + last_error())
+
+    def close(self):
+        if self.h:
+            lib().clhip_tx_pipe_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def reset(self):
+        lib().clhip_tx_pipe_reset(self.h)
+
+    def out_count(self, n_in):
+        return lib().clhip_tx_pipe_out_count(self.h, n_in)
+
+    def run(self, in_kind, d_in, in_stride, n_in, d_bytes, out_stride_bytes, d_tap=None, tap_stride=0, stream=None):
+        return _check(lib().clhip_tx_pipe_run(self.h, in_kind, ptr(d_in), in_stride, n_in, ptr(d_bytes),
+                                              out_stride_bytes, ptr(d_tap), tap_stride,
+                                              stream if stream is not None else current_stream()),
+                      "clhip_tx_pipe_run")
+
+
+def fm_demod(d_iq, n, d_prev, d_out, stream=None):
+    _check(lib().clhip_fm_demod(ptr(d_iq), n, ptr(d_prev), ptr(d_out),
+                                stream if stream is not None else current_stream()), "clhip_fm_demod")
+
+
+def fm_mod(d_msg, n, kf_hz, fs_hz, d_phase, d_iq_out, d_ws, stream=None):
+    _check(lib().clhip_fm_mod(ptr(d_msg), n, kf_hz, fs_hz, ptr(d_phase), ptr(d_iq_out), ptr(d_ws),
+                              d_ws.numel() * d_ws.element_size(),
+                              stream if stream is not None else current_stream()), "clhip_fm_mod")
+
+
+def cw_tone(f_hz, fs_hz, phase0, n, d_iq_out, stream=None):
+    _check(lib().clhip_cw_tone(f_hz, fs_hz, phase0, n, ptr(d_iq_out),
+                               stream if stream is not None else current_stream()), "clhip_cw_tone")

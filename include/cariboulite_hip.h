@@ -140,13 +140,19 @@ int clhip_smi_pack(int mode, const int16_t *d_iq, size_t n_samples, uint8_t *d_b
  * IIR -- replaces the per-sample iir1 loop of Stream::ReadSamples
  * (CaribouliteStream.cpp:291-298): y = (int16)(float)LP(float(x)) on both
  * rails, Direct-Form-II biquad cascade in fp64, state carried in d_state
- * (n_stages * 2 rails * 2 doubles, layout [rail][stage]{v1,v2}).
+ * (16 doubles per stream: [rail I|Q][8] with entry 2*stage+0 = v1, 2*stage+1 = v2,
+ * up to 4 biquads; zero it to reset).
  * sos = n_stages rows of {b0,b1,b2,a1,a2} (host pointer, a0 = 1).
  */
 int clhip_iir_cs16(const double *h_sos, int n_stages, double *d_state,
                    int16_t *d_iq, size_t n_samples, void *d_workspace, size_t workspace_bytes,
                    void *stream);
-size_t clhip_iir_workspace_bytes(size_t n_samples, int n_stages);
+size_t clhip_iir_workspace_bytes(size_t n_samples, int n_stages);   /* per stream */
+/* the same for n_streams independent streams (stream s at d_iq + s*stride_samples,
+ * state s at d_state + s*16 doubles); workspace = n_streams * clhip_iir_workspace_bytes() */
+int clhip_iir_cs16_batch(const double *h_sos, int n_stages, double *d_state, int16_t *d_iq,
+                         size_t stride_samples, size_t n_samples, int n_streams,
+                         void *d_workspace, size_t workspace_bytes, void *stream);
 
 /*
  * The RX pipe: raw SMI words -> int13 I/Q -> x/4096 -> FIR(T) -> [L/M polyphase

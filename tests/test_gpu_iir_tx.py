@@ -1,0 +1,199 @@
+"""-m gpu: IIR (fp64 blocked scan), FM mod/demod, CW tone and the TX pipe through the C-ABI."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def G():
+    import torch
+    from cariboulite_amd import hip
+    import gpu_util
+    assert torch.cuda.is_available() and hip.require_gpu().startswith("gfx950")
+    return gpu_util
+
+
+def _sos5(orc_iir):
+    s = orc_iir.sos()
+    return np.concatenate([s[:, :3], s[:, 4:]], 1)
+
+
+@pytest.mark.parametrize("bw_khz", [20, 50, 100])
+def test_iir_vs_oracle_and_scipy(G, orc, bw_khz):
+    """CaribouliteStream.cpp:291-298 semantics; int16 outputs equal the sequential fp64 oracle
+    (+-1 LSB allowed only at truncation boundaries: 'Truncation cliffs')."""
+    import torch
+    from cariboulite_amd import hip, synth
+    n = 131072 + 777                       # one native batch + ragged tail, several scan tiles
+    _, i, q = synth.smi_stream_bytes(n, 0, stream=4)
+    iq = np.stack([i, q], 1).astype(np.int16)
+    ref = orc.IIR(6, 4e6, bw_khz * 1e3 / 2)
+    want = ref.apply_cs16(iq)
+    f = hip.IIR(_sos5(orc.IIR(6, 4e6, bw_khz * 1e3 / 2)))
+    d = torch.from_numpy(iq.copy()).to(G.DEV)
+    f.run(d, n)
+    torch.cuda.synchronize()
+    got = d.cpu().numpy()
+    diff = np.abs(got.astype(np.int32) - want.astype(np.int32))
+    assert diff.max() <= 1 and np.mean(diff != 0) < 1e-5, (diff.max(), np.mean(diff != 0))
+    # the carried state equals the oracle's DF-II state
+    st = f.state.cpu().numpy()[0]
+    for s in range(3):
+        assert abs(st[2 * s] - ref.fi.v1[s]) <= 1e-9 * max(1.0, abs(ref.fi.v1[s]))
+        assert abs(st[8 + 2 * s + 1] - ref.fq.v2[s]) <= 1e-9 * max(1.0, abs(ref.fq.v2[s]))
+    # scipy fixture (first 8192 samples, different input): +-1 LSB
+    g = load_golden("dsp_float.npz")
+    f2 = hip.IIR(_sos5(orc.IIR(6, 4e6, bw_khz * 1e3 / 2)))
+    d2 = torch.from_numpy(g["iq_int16"].copy()).to(G.DEV)
+    f2.run(d2, 8192)
+    got2 = d2.cpu().numpy()
+    assert np.max(np.abs(got2[:, 0] - np.trunc(g[f"iir_{bw_khz}k__y_i"]))) <= 1
+    assert np.max(np.abs(got2[:, 1] - np.trunc(g[f"iir_{bw_khz}k__y_q"]))) <= 1
+
+
+def test_iir_streaming_and_batch(G, orc):
+    """State persists across calls (never reset: SURVEY.md section 8 a6); streams are independent."""
+    import torch
+    from cariboulite_amd import hip, synth
+    n, ns = 40000, 3
+    iqs = [np.stack(synth.smi_stream_bytes(n, 0, stream=20 + s)[1:], 1).astype(np.int16) for s in range(ns)]
+    sos = _sos5(orc.IIR(6, 4e6, 25e3))
+    want = [orc.IIR(6, 4e6, 25e3).apply_cs16(x) for x in iqs]
+    # batch, one shot
+    f = hip.IIR(sos, ns)
+    d = torch.from_numpy(np.stack(iqs)).to(G.DEV)
+    f.run(d, n, stride=n)
+    got = d.cpu().numpy()
+    for s in range(ns):
+        assert np.max(np.abs(got[s].astype(int) - want[s].astype(int))) <= 1
+        assert np.mean(got[s] != want[s]) < 1e-4
+    # chunked on stream 0: identical to one shot except at rare truncation boundaries
+    f1 = hip.IIR(sos, 1)
+    outs, pos = [], 0
+    for cn in (1, 63, 64, 65, 16384, 7, 23416):
+        dd = torch.from_numpy(iqs[0][pos:pos + cn].copy()).to(G.DEV)
+        f1.run(dd, cn)
+        outs.append(dd.cpu().numpy()); pos += cn
+    assert pos == n
+    chunked = np.concatenate(outs)
+    assert np.max(np.abs(chunked.astype(int) - want[0].astype(int))) <= 1
+    assert np.mean(chunked != want[0]) < 1e-4
+    # zeros in -> zeros out, impulse decays (sanity of the scan tables)
+    z = torch.zeros((70000, 2), dtype=torch.int16, device=G.DEV)
+    z[5, 0] = 4000
+    fz = hip.IIR(sos, 1); fz.run(z, 70000)
+    zz = z.cpu().numpy()
+    assert np.all(zz[:, 1] == 0) and np.all(zz[60000:, 0] == 0) and zz[:2000, 0].max() > 0
+
+
+def test_fm_demod_and_cw(G, orc):
+    import torch
+    from cariboulite_amd import hip
+    rng = np.random.default_rng(3)
+    n = 100003
+    x = (rng.standard_normal((n, 2)) * 0.3).astype(np.float32)
+    want, _ = orc.fm_demod_f64(x.astype(np.float64))
+    d = torch.from_numpy(x).to(G.DEV)
+    prev = torch.zeros(2, dtype=torch.float32, device=G.DEV)
+    out = torch.empty(n, dtype=torch.float32, device=G.DEV)
+    # two calls: the last sample is carried
+    hip.fm_demod(d, 50000, prev, out)
+    hip.fm_demod(d[50000:], n - 50000, prev, out[50000:])
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    dd = np.abs(got - want); dd = np.minimum(dd, 2 * np.pi - dd)
+    assert got[0] == 0.0 and np.max(dd) <= TOL * np.pi
+    tone = torch.empty((4_000_000, 2), dtype=torch.float32, device=G.DEV)
+    hip.cw_tone(100e3, 4e6, 0.25, 4_000_000, tone)
+    t = tone.cpu().numpy()
+    k = np.arange(4_000_000)
+    ph = 2 * np.pi * 100e3 * k / 4e6 + 0.25
+    assert np.max(np.abs(t[:, 0] - np.cos(ph))) <= TOL and np.max(np.abs(t[:, 1] - np.sin(ph))) <= TOL
+    o, _ = orc.cw_tone(100e3, 4e6, 4096, 0.25)
+    assert np.max(np.abs(t[:4096] - o)) <= 1e-6
+
+
+def test_fm_mod_vs_oracle(G, orc):
+    import torch
+    from cariboulite_amd import hip
+    g = load_golden("dsp_float.npz")
+    m = g["fm_msg"]; kf = float(g["fm_mod_kf"])
+    d = torch.from_numpy(m).to(G.DEV)
+    ws = torch.empty(hip.lib().clhip_fm_mod_workspace_bytes(m.size) // 8 + 1, dtype=torch.float64, device=G.DEV)
+    ph = torch.zeros(1, dtype=torch.float64, device=G.DEV)
+    out = torch.empty((m.size, 2), dtype=torch.float32, device=G.DEV)
+    hip.fm_mod(d, m.size, kf, 4e6, ph, out, ws)
+    torch.cuda.synchronize()
+    assert np.max(np.abs(out.cpu().numpy() - g["fm_mod_iq"])) <= TOL
+    _, want_ph = orc.fm_mod_f64(m, kf, 4e6)
+    dph = abs(float(ph[0]) - want_ph); dph = min(dph, 2 * np.pi - dph)
+    assert dph < 1e-9
+    # long message, chunked with carried phase == oracle's sequential fp64 accumulation
+    rng = np.random.default_rng(12)
+    n = 1_000_003
+    msg = (0.5 * np.sin(2 * np.pi * 3e3 * np.arange(n) / 4e6) + 0.2 * rng.standard_normal(n)).astype(np.float32)
+    want, _ = orc.fm_mod_f64(msg, 75e3, 4e6)
+    dm = torch.from_numpy(msg).to(G.DEV)
+    ph.zero_()
+    o = torch.empty((n, 2), dtype=torch.float32, device=G.DEV)
+    ws = torch.empty(hip.lib().clhip_fm_mod_workspace_bytes(n) // 8 + 1, dtype=torch.float64, device=G.DEV)
+    pos = 0
+    for cn in (1, 1023, 1024, 1025, 500000, n - 503073):
+        hip.fm_mod(dm[pos:], cn, 75e3, 4e6, ph, o[pos:], ws); pos += cn
+    assert pos == n
+    torch.cuda.synchronize()
+    assert np.max(np.abs(o.cpu().numpy() - want)) <= TOL
+
+
+def test_tx_pipe_config5(G, orc):
+    """float message -> FM mod -> 2/3 resample -> x4096 truncate -> int13 pack (BASELINE config 5).
+    Float stages to 1e-5 (tap output); the integer tail is bit-exact on the GPU's own floats."""
+    import torch
+    from cariboulite_amd import hip
+    g, t = load_golden("dsp_float.npz"), load_golden("taps.npz")
+    m = g["fm_msg"]; n = m.size
+    pipe = hip.TxPipe(1, float(g["fm_mod_kf"]), 4e6, t["rs_2_3"], 2, 3, hip.TX_DOCUMENTED)
+    no = pipe.out_count(n)
+    assert no == -(-n * 2 // 3)
+    d = torch.from_numpy(m).to(G.DEV)
+    by = torch.zeros(4 * no, dtype=torch.uint8, device=G.DEV)
+    tap = torch.zeros((no, 2), dtype=torch.float32, device=G.DEV)
+    assert pipe.run(hip.TXPIPE_IN_FM_MESSAGE, d, 0, n, by, 4 * no, tap, no) == no
+    torch.cuda.synchronize()
+    tp = tap.cpu().numpy()
+    assert np.max(np.abs(tp - g["fm_mod_rs_2_3"])) <= TOL * np.max(np.abs(g["fm_mod_rs_2_3"]))
+    # integer tail in isolation: oracle quantise + pack of the SAME floats -> identical bytes
+    want_bytes = orc.generate_data(orc.cf32_to_cs16(tp), orc.TX_DOCUMENTED)
+    assert np.array_equal(by.cpu().numpy(), want_bytes)
+    # FPGA parser round trip recovers the quantised samples
+    w = orc.fpga_tx_parse(by.cpu().numpy())
+    _, iq, _ = orc.rx_data_analyze(0, (w & ~np.uint32(1 << 16)).view(np.uint8))
+    q13 = ((orc.cf32_to_cs16(tp).astype(np.int32) + 4096) & 0x1FFF) - 4096     # the packer keeps 13 bits (& 0x1FFF)
+    assert np.array_equal(iq[:no], q13)
+    # chunked == one shot (phase + resampler history carried)
+    pipe2 = hip.TxPipe(1, float(g["fm_mod_kf"]), 4e6, t["rs_2_3"], 2, 3, hip.TX_DOCUMENTED)
+    outs, pos = [], 0
+    for cn in (3, 1, 2, 4093, 4093):
+        k = pipe2.out_count(cn)
+        b2 = torch.zeros(4 * max(k, 1), dtype=torch.uint8, device=G.DEV)
+        assert pipe2.run(hip.TXPIPE_IN_FM_MESSAGE, d[pos:], 0, cn, b2, 4 * max(k, 1)) == k
+        outs.append(b2.cpu().numpy()[:4 * k]); pos += cn
+    assert pos == n
+    chunked = np.concatenate(outs).view(np.uint32)
+    one = by.cpu().numpy().view(np.uint32)
+    # identical up to rare 1-LSB truncation flips from the re-associated fp64 phase sums
+    assert chunked.size == one.size and np.mean(chunked != one) < 1e-3
+    # as-written mode reproduces the reference's constant output
+    pipe3 = hip.TxPipe(1, 75e3, 4e6, t["rs_2_3"], 2, 3, hip.TX_AS_WRITTEN)
+    assert pipe3.run(hip.TXPIPE_IN_FM_MESSAGE, d, 0, 300, by, 4 * no) == 200
+    assert by.cpu().numpy()[:800].reshape(-1, 4).tolist() == [[0xFF, 0x7F, 0x40, 0x00]] * 200
+    # CF32 input, no resampler: pure Soapy writeStream(CF32) tail
+    x = (np.random.default_rng(0).standard_normal((5000, 2)) * 0.4).astype(np.float32)
+    pipe4 = hip.TxPipe(1, 0.0, 4e6, None, 1, 1, hip.TX_DOCUMENTED)
+    b4 = torch.zeros(4 * 5000, dtype=torch.uint8, device=G.DEV)
+    assert pipe4.run(hip.TXPIPE_IN_CF32, torch.from_numpy(x).to(G.DEV), 0, 5000, b4, 4 * 5000) == 5000
+    assert np.array_equal(b4.cpu().numpy(), orc.generate_data(orc.cf32_to_cs16(x), orc.TX_DOCUMENTED))
