@@ -1,0 +1,69 @@
+/* cl_internal.h -- shared internals of the host C layer (libcariboulite_host.so).
+ * Host code stays C (BASELINE.json north_star); every GPU operation goes
+ * through the clhip_* C-ABI of libcariboulite_hip.so. */
+#ifndef CL_INTERNAL_H
+#define CL_INTERNAL_H
+
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "cariboulite_hip.h"
+
+/* growable byte FIFO standing where the /dev/smi kernel kfifo stands */
+typedef struct {
+    uint8_t *data;
+    size_t cap, head, len;       /* bytes [head, head+len) are pending (linear, compacted on demand) */
+} cl_fifo;
+
+void   cl_fifo_free(cl_fifo *f);
+int    cl_fifo_push(cl_fifo *f, const uint8_t *src, size_t n);
+size_t cl_fifo_pop(cl_fifo *f, uint8_t *dst, size_t n);      /* dst may be NULL (discard) */
+
+#define CL_MAX_CHUNKS_INLINE 64
+
+/* one read() of the reference's chunk loop (caribou_smi.c:643-679) */
+typedef struct {
+    size_t stage_off;   /* byte offset of the chunk inside the device staging buffer */
+    size_t len;         /* bytes read() returned                                      */
+    size_t slot0;       /* read_so_far when the chunk was analysed                     */
+    int32_t offs;       /* sync offset found on the GPU (-1 = none)                    */
+} cl_chunk;
+
+struct cl_smi {
+    int device;
+    void *stream;                 /* hipStream_t of this SMI instance */
+    size_t native_batch_len;      /* caribou_smi.c:74-81 */
+    uint32_t sample_rate;
+    cl_fifo rx, tx;
+    size_t max_read;
+    int tx_mode;
+    /* device / pinned buffers, grown on demand */
+    uint8_t *d_bytes; size_t bytes_cap;
+    int16_t *d_iq; size_t iq_cap;         /* samples */
+    uint8_t *d_meta; size_t meta_cap;
+    uint8_t *h_stage; size_t h_stage_cap; /* pinned host staging */
+    int32_t *d_offs; size_t offs_cap; int32_t *h_offs; size_t h_offs_cap;
+    cl_chunk *chunks; size_t chunks_cap, n_chunks;
+    /* statistics (SURVEY.md section 5 "Metrics"): */
+    uint64_t stat_samples, stat_resyncs, stat_sync_failures;
+    char err[256];
+};
+
+/* device-resident read: runs the chunk loop, leaves CS16 (+meta) in dev->d_iq /
+ * dev->d_meta, fills dev->chunks.  Returns read_so_far, or CL_SMI_ERR_*;
+ * *all_aligned = 1 when every chunk had offs == 0 and a whole number of samples. */
+int cl_smi_read_device(cl_smi *dev, int channel, size_t length_samples, int want_meta, int *all_aligned);
+/* copy the slots the reference writes from the device results to host buffers */
+int cl_smi_copy_out(cl_smi *dev, cl_sample_complex_int16 *buffer, cl_sample_meta *metadata, int upto_chunk);
+int cl_ensure(void **p, size_t *cap, size_t need, size_t elem, int pinned);
+void cl_seterr(char *dst, size_t n, const char *fmt, ...);
+
+struct cl_radio {
+    cl_smi *smi;
+    int channel;
+};
+
+#endif

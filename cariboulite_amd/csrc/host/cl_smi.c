@@ -1,0 +1,276 @@
+/* cl_smi.c -- the SMI user-driver seam (caribou_smi/caribou_smi.h:85-106) on
+ * the GPU: same arguments, chunking, return codes and "untouched slot"
+ * behaviour as caribou_smi_read / caribou_smi_write, with the /dev/smi fd
+ * replaced by an injected byte FIFO and the per-chunk analysis
+ * (caribou_smi.c:235-393) / packing (:684-717) done by HIP kernels. */
+#include "cl_internal.h"
+
+void cl_seterr(char *dst, size_t n, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(dst, n, fmt, ap);
+    va_end(ap);
+}
+
+/* ------------------------------------------------------------------ FIFO */
+void cl_fifo_free(cl_fifo *f) { free(f->data); memset(f, 0, sizeof *f); }
+
+int cl_fifo_push(cl_fifo *f, const uint8_t *src, size_t n)
+{
+    if (f->head && f->head + f->len + n > f->cap) {          /* compact */
+        memmove(f->data, f->data + f->head, f->len);
+        f->head = 0;
+    }
+    if (f->head + f->len + n > f->cap) {
+        size_t cap = f->cap ? f->cap : 1 << 16;
+        while (cap < f->head + f->len + n) cap *= 2;
+        uint8_t *p = (uint8_t *)realloc(f->data, cap);
+        if (!p) return -1;
+        f->data = p; f->cap = cap;
+    }
+    memcpy(f->data + f->head + f->len, src, n);
+    f->len += n;
+    return 0;
+}
+
+size_t cl_fifo_pop(cl_fifo *f, uint8_t *dst, size_t n)
+{
+    if (n > f->len) n = f->len;
+    if (dst && n) memcpy(dst, f->data + f->head, n);
+    f->head += n; f->len -= n;
+    if (f->len == 0) f->head = 0;
+    return n;
+}
+
+/* put bytes back at the FRONT of the FIFO (bytes read ahead but not consumed) */
+static int cl_fifo_unpop(cl_fifo *f, const uint8_t *src, size_t n)
+{
+    if (n == 0) return 0;
+    if (f->head >= n) {
+        f->head -= n; f->len += n;
+        memcpy(f->data + f->head, src, n);
+        return 0;
+    }
+    uint8_t *p = (uint8_t *)malloc(f->len + n + (1 << 16));
+    if (!p) return -1;
+    memcpy(p, src, n);
+    if (f->len) memcpy(p + n, f->data + f->head, f->len);
+    free(f->data);
+    f->data = p; f->cap = f->len + n + (1 << 16); f->head = 0; f->len += n;
+    return 0;
+}
+
+/* ------------------------------------------------------------ allocation */
+int cl_ensure(void **p, size_t *cap, size_t need, size_t elem, int pinned)
+{
+    if (need <= *cap) return 0;
+    size_t ncap = *cap ? *cap : 1024;
+    while (ncap < need) ncap *= 2;
+    void *np = pinned == 1 ? clhip_host_alloc(ncap * elem) : pinned == 2 ? malloc(ncap * elem) : clhip_malloc(ncap * elem);
+    if (!np) return -1;
+    if (*p) { if (pinned == 1) clhip_host_free(*p); else if (pinned == 2) free(*p); else clhip_free(*p); }
+    *p = np; *cap = ncap;
+    return 0;
+}
+
+/* ----------------------------------------------------------- init / close */
+cl_smi *cl_smi_init(int device)
+{
+    if (clhip_device_count() <= 0 || clhip_set_device(device) != 0) return NULL;   /* no GPU: fail loudly */
+    cl_smi *dev = (cl_smi *)calloc(1, sizeof *dev);
+    if (!dev) return NULL;
+    dev->device = device;
+    dev->native_batch_len = CL_NATIVE_BATCH_LEN;       /* caribou_smi.c:78 */
+    dev->sample_rate = CL_SAMPLE_RATE;
+    dev->tx_mode = CL_TX_DOCUMENTED;
+    dev->stream = clhip_stream_create();
+    if (!dev->stream) { free(dev); return NULL; }
+    return dev;
+}
+
+int cl_smi_close(cl_smi *dev)
+{
+    if (!dev) return -1;
+    clhip_set_device(dev->device);
+    clhip_stream_sync(dev->stream);
+    clhip_free(dev->d_bytes); clhip_free(dev->d_iq); clhip_free(dev->d_meta); clhip_free(dev->d_offs);
+    clhip_host_free(dev->h_stage); clhip_host_free(dev->h_offs);
+    free(dev->chunks);
+    cl_fifo_free(&dev->rx); cl_fifo_free(&dev->tx);
+    clhip_stream_destroy(dev->stream);
+    free(dev);
+    return 0;
+}
+
+int    cl_smi_feed_bytes(cl_smi *dev, const uint8_t *b, size_t n) { return cl_fifo_push(&dev->rx, b, n); }
+size_t cl_smi_pending_bytes(const cl_smi *dev) { return dev->rx.len; }
+void   cl_smi_set_max_read(cl_smi *dev, size_t m) { dev->max_read = m; }
+size_t cl_smi_drain_bytes(cl_smi *dev, uint8_t *b, size_t max) { return cl_fifo_pop(&dev->tx, b, max); }
+void   cl_smi_set_tx_mode(cl_smi *dev, int mode) { dev->tx_mode = mode; }
+size_t cl_smi_get_native_batch_samples(cl_smi *dev) { return dev->native_batch_len / CL_BYTES_PER_SAMPLE; }
+
+/* --------------------------------------------------------------- RX path */
+int cl_smi_read_device(cl_smi *dev, int channel, size_t length_samples, int want_meta, int *all_aligned)
+{
+    clhip_set_device(dev->device);
+    size_t left = length_samples * CL_BYTES_PER_SAMPLE, read_so_far = 0, stage_off = 0;
+    dev->n_chunks = 0;
+    if (all_aligned) *all_aligned = 1;
+    /* worst-case staging: every chunk rounded up to 256 B */
+    const size_t max_chunks = left / (dev->max_read && dev->max_read < dev->native_batch_len ? dev->max_read : dev->native_batch_len) + 2;
+    if (cl_ensure((void **)&dev->chunks, &dev->chunks_cap, max_chunks, sizeof(cl_chunk), 2)) return CL_SMI_ERR_IO;
+    const size_t need_bytes = left + 256 * max_chunks + 256;
+    if (cl_ensure((void **)&dev->h_stage, &dev->h_stage_cap, need_bytes, 1, 1) ||
+        cl_ensure((void **)&dev->d_bytes, &dev->bytes_cap, need_bytes, 1, 0) ||
+        cl_ensure((void **)&dev->d_iq, &dev->iq_cap, length_samples + 8, 4, 0) ||
+        (want_meta && cl_ensure((void **)&dev->d_meta, &dev->meta_cap, length_samples + 8, 1, 0)) ||
+        cl_ensure((void **)&dev->d_offs, &dev->offs_cap, max_chunks, 4, 0))
+        return CL_SMI_ERR_IO;
+    if (cl_ensure((void **)&dev->h_offs, &dev->h_offs_cap, max_chunks, 4, 1)) return CL_SMI_ERR_IO;
+
+    /* the reference's chunk loop, caribou_smi.c:643-679; read() = FIFO pop */
+    while (left) {
+        size_t cur = left > dev->native_batch_len ? dev->native_batch_len : left;
+        size_t want = cur;
+        if (dev->max_read && want > dev->max_read) want = dev->max_read;
+        size_t ret = cl_fifo_pop(&dev->rx, dev->h_stage + stage_off, want);
+        if (ret == 0) break;                                   /* :657-661 "Reading timed-out" */
+        cl_chunk *c = &dev->chunks[dev->n_chunks++];
+        c->stage_off = stage_off; c->len = ret; c->slot0 = read_so_far; c->offs = 0;
+        stage_off += (ret + 255) & ~(size_t)255;
+        read_so_far += ret / CL_BYTES_PER_SAMPLE;              /* :677 */
+        left -= ret;                                           /* :678 */
+    }
+    if (dev->n_chunks == 0) return 0;
+    if (clhip_memcpy_h2d(dev->d_bytes, dev->h_stage, stage_off, dev->stream)) return CL_SMI_ERR_IO;
+
+    /* runs of full native chunks go out as ONE batched launch each */
+    size_t i = 0;
+    while (i < dev->n_chunks) {
+        size_t j = i + 1;
+        if (dev->chunks[i].len == dev->native_batch_len)
+            while (j < dev->n_chunks && dev->chunks[j].len == dev->native_batch_len) j++;
+        const cl_chunk *c = &dev->chunks[i];
+        const size_t stride = dev->native_batch_len, total = (j - i - 1) * stride + dev->chunks[j - 1].len;
+        if (clhip_smi_find_offsets(dev->d_bytes + c->stage_off, total, stride, stride, (int)(j - i), dev->d_offs + i, dev->stream) ||
+            clhip_smi_unpack(channel, dev->d_bytes + c->stage_off, total, stride, stride, (int)(j - i), dev->d_offs + i,
+                             CL_FORMAT_CS16, dev->d_iq + 2 * c->slot0, want_meta ? dev->d_meta + c->slot0 : NULL, dev->stream))
+            return CL_SMI_ERR_IO;
+        i = j;
+    }
+    if (clhip_memcpy_d2h(dev->h_offs, dev->d_offs, dev->n_chunks * 4, dev->stream) || clhip_stream_sync(dev->stream))
+        return CL_SMI_ERR_IO;
+    for (i = 0; i < dev->n_chunks; i++) {
+        dev->chunks[i].offs = dev->h_offs[i];
+        /* "aligned" = the staged bytes ARE the sample sequence: in sync, whole samples, no staging gaps */
+        if (dev->h_offs[i] != 0 || (dev->chunks[i].len & 3) || dev->chunks[i].stage_off != 4 * dev->chunks[i].slot0) { if (all_aligned) *all_aligned = 0; }
+        if (dev->h_offs[i] > 0) dev->stat_resyncs++;
+        if (dev->h_offs[i] < 0) {                               /* :665-668 -> -3 */
+            dev->stat_sync_failures++;
+            /* the reference returns at this chunk: what was read ahead of it goes back to the FIFO */
+            for (size_t k = dev->n_chunks; k-- > i + 1;)
+                if (cl_fifo_unpop(&dev->rx, dev->h_stage + dev->chunks[k].stage_off, dev->chunks[k].len)) return CL_SMI_ERR_IO;
+            dev->n_chunks = i;                                  /* chunks before the failure were delivered */
+            return CL_SMI_ERR_SYNC;
+        }
+    }
+    dev->stat_samples += read_so_far;
+    return (int)read_so_far;
+}
+
+/* Copy exactly the slots the reference writes (caribou_smi.c:344-389): n unpacked
+ * samples per chunk, plus one extrapolated I/Q sample (no meta) after a re-sync. */
+int cl_smi_copy_out(cl_smi *dev, cl_sample_complex_int16 *buffer, cl_sample_meta *metadata, int upto_chunk)
+{
+    const size_t nch = upto_chunk < 0 ? dev->n_chunks : (size_t)upto_chunk;
+    if (nch == 0) return 0;
+    int simple = 1;
+    for (size_t i = 0; i < nch; i++)
+        if (dev->chunks[i].offs != 0 || (dev->chunks[i].len & 3)) simple = 0;
+    if (simple) {                       /* aligned stream: every slot is written, one copy */
+        const cl_chunk *l = &dev->chunks[nch - 1];
+        const size_t n = l->slot0 + l->len / 4;
+        if (buffer && clhip_memcpy_d2h(buffer, dev->d_iq, n * 4, dev->stream)) return -1;
+        if (metadata && clhip_memcpy_d2h(metadata, dev->d_meta, n, dev->stream)) return -1;
+        return clhip_stream_sync(dev->stream);
+    }
+    for (size_t i = 0; i < nch; i++) {
+        const cl_chunk *c = &dev->chunks[i];
+        const size_t shortening = c->offs > 0 ? (size_t)(c->offs / 4 + 1) : 0;
+        const size_t n = (c->len - 4 * shortening) / 4;
+        const size_t n_iq = n + (shortening > 0 && n >= 2 ? 1 : 0);
+        if (buffer && n_iq && clhip_memcpy_d2h(buffer + c->slot0, dev->d_iq + 2 * c->slot0, n_iq * 4, dev->stream)) return -1;
+        if (metadata && n && clhip_memcpy_d2h(metadata + c->slot0, dev->d_meta + c->slot0, n, dev->stream)) return -1;
+    }
+    return clhip_stream_sync(dev->stream);
+}
+
+/* caribou_smi_read  caribou_smi.c:632-682 */
+int cl_smi_read(cl_smi *dev, int channel, cl_sample_complex_int16 *buffer, cl_sample_meta *metadata, size_t length_samples)
+{
+    if (!dev) return CL_SMI_ERR_IO;
+    int ret = cl_smi_read_device(dev, channel, length_samples, metadata != NULL, NULL);
+    if (ret == CL_SMI_ERR_SYNC) { cl_smi_copy_out(dev, buffer, metadata, -1); return ret; }
+    if (ret <= 0) return ret;
+    if (cl_smi_copy_out(dev, buffer, metadata, -1)) return CL_SMI_ERR_IO;
+    return ret;
+}
+
+/* --------------------------------------------------------------- TX path */
+/* caribou_smi_write caribou_smi.c:720-762 */
+int cl_smi_write(cl_smi *dev, int channel, cl_sample_complex_int16 *buffer, size_t length_samples)
+{
+    (void)channel;
+    if (!dev) return CL_SMI_ERR_IO;
+    clhip_set_device(dev->device);
+    size_t left = length_samples * CL_BYTES_PER_SAMPLE, written_so_far = 0;
+    if (length_samples == 0) return 0;
+    if (cl_ensure((void **)&dev->d_iq, &dev->iq_cap, length_samples + 8, 4, 0) ||
+        cl_ensure((void **)&dev->d_bytes, &dev->bytes_cap, left + 256, 1, 0) ||
+        cl_ensure((void **)&dev->h_stage, &dev->h_stage_cap, left + 256, 1, 1))
+        return CL_SMI_ERR_IO;
+    /* the chunk loop only slices the same contiguous arrays (len &= ~3 never bites: 4 B/sample), so
+     * the whole call is one pack launch; the FIFO then receives it in native-batch writes */
+    if (clhip_memcpy_h2d(dev->d_iq, buffer, left, dev->stream) ||
+        clhip_smi_pack(dev->tx_mode, dev->d_iq, length_samples, dev->d_bytes, dev->stream) ||
+        clhip_memcpy_d2h(dev->h_stage, dev->d_bytes, left, dev->stream) || clhip_stream_sync(dev->stream))
+        return CL_SMI_ERR_IO;
+    while (left) {
+        size_t cur = left > dev->native_batch_len ? dev->native_batch_len : left;
+        cur &= 0xFFFFFFFCu;                                     /* :745 */
+        if (!cur) break;
+        if (cl_fifo_push(&dev->tx, dev->h_stage + written_so_far * 4, cur)) return CL_SMI_ERR_IO;
+        written_so_far += cur / CL_BYTES_PER_SAMPLE;            /* :757 */
+        left -= cur;                                            /* :758 (ret == len) */
+    }
+    return (int)written_so_far;
+}
+
+/* ----------------------------------------------------- radio pass-through */
+cl_radio *cl_radio_create(cl_smi *smi, int channel)
+{
+    if (!smi) return NULL;
+    cl_radio *r = (cl_radio *)calloc(1, sizeof *r);
+    if (r) { r->smi = smi; r->channel = channel; }
+    return r;
+}
+void cl_radio_destroy(cl_radio *r) { free(r); }
+
+/* cariboulite_radio.c:1258-1285 */
+int cl_radio_read_samples(cl_radio *radio, cl_sample_complex_int16 *buffer, cl_sample_meta *metadata, size_t length)
+{
+    int ret = cl_smi_read(radio->smi, radio->channel, buffer, metadata, length);
+    if (ret == CL_SMI_ERR_IO) fprintf(stderr, "SMI reading operation failed\n");
+    else if (ret == CL_SMI_ERR_SYNC) fprintf(stderr, "SMI data synchronization failed\n");
+    return ret;
+}
+/* cariboulite_radio.c:1288-1307 */
+int cl_radio_write_samples(cl_radio *radio, cl_sample_complex_int16 *buffer, size_t length)
+{
+    int ret = cl_smi_write(radio->smi, radio->channel, buffer, length);
+    if (ret < 0) fprintf(stderr, "SMI writing operation failed\n");
+    return ret;
+}
+/* cariboulite_radio.c:1310-1315 */
+size_t cl_radio_get_native_mtu_size_samples(cl_radio *radio) { return cl_smi_get_native_batch_samples(radio->smi); }

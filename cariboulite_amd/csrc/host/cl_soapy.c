@@ -1,0 +1,420 @@
+/* cl_soapy.c -- the SoapySDR device/stream calls of the reference plugin
+ * (soapy_api/Cariboulite.hpp:65-93, CaribouliteStreamFunctions.cpp,
+ * CaribouliteStream.cpp) as a C API over opaque handles: same names, argument
+ * meaning, clamping, error squashing and return codes.  Where the reference
+ * throws std::runtime_error this API returns NULL and records the message.
+ * The data path (unpack, IIR, conversions, FIR / resample / FM, pack) runs
+ * on the GPU through the clhip_* shim. */
+#include <math.h>
+
+#include "cl_internal.h"
+
+#define DIG_FILT_ORDER 6     /* CaribouliteStream.hpp:24 */
+
+typedef struct {
+    int enabled;
+    int n_fir; float fir[128];
+    int up, down, n_rs; float rs[40];
+    int demod_fm;
+    int mod_fm; double mod_kf;
+} cl_dsp_cfg;
+
+struct cl_stream {
+    cl_device *dev;
+    int format;                  /* CL_FORMAT_*                                 */
+    int native_dir;              /* CL_SOAPY_SDR_RX / TX (setInnerStreamType)    */
+    int stream_active;
+    size_t mtu_size;
+    int filter_type;             /* CL_DIGFILT_*                                 */
+    double sos[3][15];           /* filt20 / filt50 / filt100: 3 biquads x {b0,b1,b2,a1,a2} */
+    double *d_iir_state[3];      /* per filter, I and Q rails: never reset (CaribouliteStream.cpp:127-141) */
+    void *d_iir_ws; size_t iir_ws_cap;
+    void *d_conv; size_t conv_cap;       /* converted output / TX input staging (bytes) */
+    void *h_conv; size_t h_conv_cap;     /* pinned host mirror */
+    cl_dsp_cfg dsp;
+    clhip_rx_pipe *rx_pipe;
+    clhip_tx_pipe *tx_pipe;
+};
+
+struct cl_device {
+    cl_smi *smi;
+    cl_radio *radio;
+    int channel;
+    cl_stream *stream;           /* ONE preallocated stream per device (Cariboulite.cpp:30) */
+    char err[256];
+};
+
+/* ------------------------------------------------------------- filter design */
+/* scipy.signal.firwin(n, cutoff, window="hamming", fs=fs) * gain, rounded to fp32 */
+int cl_design_lowpass(int n_taps, double cutoff_hz, double fs_hz, double gain, float *taps_out)
+{
+    if (n_taps < 1 || n_taps > 4096 || !(cutoff_hz > 0) || !(cutoff_hz < fs_hz / 2) || !taps_out) return -1;
+    const double pi = 3.14159265358979323846, c = cutoff_hz / (fs_hz / 2), alpha = 0.5 * (n_taps - 1);
+    double *h = (double *)malloc(sizeof(double) * n_taps), sum = 0;
+    if (!h) return -1;
+    for (int i = 0; i < n_taps; i++) {
+        const double m = i - alpha, x = c * m;
+        const double sinc = x == 0.0 ? 1.0 : sin(pi * x) / (pi * x);
+        const double w = n_taps == 1 ? 1.0 : 0.54 - 0.46 * cos(2 * pi * i / (n_taps - 1));
+        h[i] = c * sinc * w;
+        sum += h[i];
+    }
+    for (int i = 0; i < n_taps; i++) taps_out[i] = (float)(gain * h[i] / sum);
+    free(h);
+    return 0;
+}
+
+/* iir1 Butterworth::LowPass<order>::setup(fs, fc) as published: analog prototype poles
+ * exp(j(pi/2 + (2i+1)pi/(2N))), bilinear low-pass map, one biquad per conjugate pair with
+ * a double zero at z=-1, unit DC gain folded into the first section. sos_out: order/2 x 5. */
+int cl_design_butter_lowpass(int order, double fs_hz, double fc_hz, double *sos_out)
+{
+    if (order < 2 || (order & 1) || order > 8 || !(fc_hz > 0) || !(fc_hz < fs_hz / 2) || !sos_out) return -1;
+    const double pi = 3.14159265358979323846, k = tan(pi * fc_hz / fs_hz);
+    const int pairs = order / 2;
+    double gain = 1.0;
+    for (int i = 0; i < pairs; i++) {
+        const double th = pi / 2 + (2 * i + 1) * pi / (2.0 * order);
+        const double pr = cos(th), pim = sin(th);
+        const double nr = 1 + k * pr, ni = k * pim, dr = 1 - k * pr, di = -k * pim, den = dr * dr + di * di;
+        const double zr = (nr * dr + ni * di) / den, zi = (ni * dr - nr * di) / den;
+        double *s = sos_out + 5 * i;
+        s[0] = 1; s[1] = 2; s[2] = 1; s[3] = -2 * zr; s[4] = zr * zr + zi * zi;
+        gain *= (s[0] + s[1] + s[2]) / (1 + s[3] + s[4]);
+    }
+    const double scale = 1.0 / fabs(gain);
+    sos_out[0] *= scale; sos_out[1] *= scale; sos_out[2] *= scale;
+    return 0;
+}
+
+/* -------------------------------------------------------------------- kwargs */
+static const char *kw(const char *const *keys, const char *const *vals, size_t n, const char *key)
+{
+    for (size_t i = 0; i < n; i++)
+        if (keys[i] && vals[i] && !strcmp(keys[i], key)) return vals[i];
+    return NULL;
+}
+
+/* ------------------------------------------------------------ device / stream */
+static void stream_free(cl_stream *st)
+{
+    if (!st) return;
+    for (int i = 0; i < 3; i++) clhip_free(st->d_iir_state[i]);
+    clhip_free(st->d_iir_ws); clhip_free(st->d_conv); clhip_host_free(st->h_conv);
+    if (st->rx_pipe) clhip_rx_pipe_destroy(st->rx_pipe);
+    if (st->tx_pipe) clhip_tx_pipe_destroy(st->tx_pipe);
+    free(st);
+}
+
+/* SoapySDR::Stream::Stream  CaribouliteStream.cpp:52-98 */
+static cl_stream *stream_new(cl_device *dev)
+{
+    cl_stream *st = (cl_stream *)calloc(1, sizeof *st);
+    if (!st) return NULL;
+    st->dev = dev;
+    st->mtu_size = cl_radio_get_native_mtu_size_samples(dev->radio);
+    st->format = CL_FORMAT_CS16;                       /* :77 */
+    st->native_dir = CL_SOAPY_SDR_RX;
+    st->filter_type = CL_DIGFILT_NONE;                 /* :84 */
+    const double bw[3] = {20e3, 50e3, 100e3};          /* :85-91 setup(4e6, bw/2) */
+    for (int i = 0; i < 3; i++) {
+        cl_design_butter_lowpass(DIG_FILT_ORDER, 4e6, bw[i] / 2, st->sos[i]);
+        st->d_iir_state[i] = (double *)clhip_malloc(16 * sizeof(double));
+        if (!st->d_iir_state[i] || clhip_memset(st->d_iir_state[i], 0, 16 * sizeof(double), dev->smi->stream)) { stream_free(st); return NULL; }
+    }
+    clhip_stream_sync(dev->smi->stream);
+    return st;
+}
+
+cl_device *cl_device_make(const char *const *keys, const char *const *vals, size_t n)
+{
+    const char *ch = kw(keys, vals, n, "channel");
+    int channel;
+    if (ch && !strcmp(ch, "HiF")) channel = CL_CHANNEL_HIF;           /* Cariboulite.cpp:17-24 */
+    else if (ch && !strcmp(ch, "S1G")) channel = CL_CHANNEL_S1G;
+    else return NULL;                                                  /* "Channel type is not specified correctly" :27 */
+    const char *g = kw(keys, vals, n, "gpu");
+    cl_device *dev = (cl_device *)calloc(1, sizeof *dev);
+    if (!dev) return NULL;
+    dev->channel = channel;
+    dev->smi = cl_smi_init(g ? atoi(g) : 0);
+    if (!dev->smi) { free(dev); return NULL; }
+    dev->radio = cl_radio_create(dev->smi, channel);
+    dev->stream = dev->radio ? stream_new(dev) : NULL;
+    if (!dev->stream) { cl_device_unmake(dev); return NULL; }          /* "Stream allocation failed" :33 */
+    return dev;
+}
+
+void cl_device_unmake(cl_device *dev)
+{
+    if (!dev) return;
+    if (dev->smi) clhip_set_device(dev->smi->device);
+    stream_free(dev->stream);                                          /* Cariboulite.cpp:38-41 */
+    cl_radio_destroy(dev->radio);
+    cl_smi_close(dev->smi);
+    free(dev);
+}
+
+cl_smi *cl_device_smi(cl_device *dev) { return dev ? dev->smi : NULL; }
+const char *cl_device_last_error(cl_device *dev) { return dev ? dev->err : "no device"; }
+
+/* CaribouliteStreamFunctions.cpp:11-19 */
+size_t cl_getStreamFormats(const cl_device *dev, int direction, size_t channel, const char **formats, size_t max)
+{
+    (void)dev; (void)direction; (void)channel;
+    static const char *f[4] = {"CS16", "CS8", "CF32", "CF64"};
+    for (size_t i = 0; i < 4 && i < max; i++) formats[i] = f[i];
+    return 4;
+}
+
+/* CaribouliteStreamFunctions.cpp:31-35 */
+const char *cl_getNativeStreamFormat(const cl_device *dev, int direction, size_t channel, double *fullScale)
+{
+    (void)dev; (void)direction; (void)channel;
+    if (fullScale) *fullScale = (double)((1 << 12) - 1);
+    return "CS16";
+}
+
+/* Stream::setFormat  CaribouliteStream.cpp:158-173 */
+static int set_format(cl_stream *st, const char *fmt)
+{
+    if (!fmt) return -1;
+    if (!strcmp(fmt, "CS16")) st->format = CL_FORMAT_CS16;
+    else if (!strcmp(fmt, "CS8")) st->format = CL_FORMAT_CS8;
+    else if (!strcmp(fmt, "CF32")) st->format = CL_FORMAT_CF32;
+    else if (!strcmp(fmt, "CF64")) st->format = CL_FORMAT_CF64;
+    else return -1;
+    return 0;
+}
+
+static int parse_dsp(cl_device *dev, cl_dsp_cfg *d, const char *const *keys, const char *const *vals, size_t n)
+{
+    memset(d, 0, sizeof *d);
+    d->up = d->down = 1;
+    const char *fir = kw(keys, vals, n, "FIR"), *rs = kw(keys, vals, n, "RESAMP"),
+               *dm = kw(keys, vals, n, "DEMOD"), *md = kw(keys, vals, n, "MOD");
+    if (fir) {                                   /* FIR=<ntaps>:<cutoff_hz> */
+        int nt = 0; double fc = 0;
+        if (sscanf(fir, "%d:%lf", &nt, &fc) != 2 || nt < 1 || nt > 128 || cl_design_lowpass(nt, fc, 4e6, 1.0, d->fir)) {
+            cl_seterr(dev->err, sizeof dev->err, "setupStream invalid FIR spec %s", fir);
+            return -1;
+        }
+        d->n_fir = nt; d->enabled = 1;
+    }
+    if (rs) {                                    /* RESAMP=<L>/<M>: 8 taps per phase, gain L */
+        int L = 0, M = 0;
+        if (sscanf(rs, "%d/%d", &L, &M) != 2 || L < 1 || M < 1 || 8 * L > 40) {
+            cl_seterr(dev->err, sizeof dev->err, "setupStream invalid RESAMP spec %s", rs);
+            return -1;
+        }
+        d->up = L; d->down = M; d->n_rs = 8 * L;
+        /* scipy firwin(8L, 1/max(L,M)) with the cut-off normalised to Nyquist = 1 */
+        if (cl_design_lowpass(8 * L, 1.0 / (L > M ? L : M), 2.0, (double)L, d->rs)) return -1;
+        d->enabled = 1;
+    }
+    if (dm) {
+        if (strcmp(dm, "FM")) { cl_seterr(dev->err, sizeof dev->err, "setupStream invalid DEMOD %s", dm); return -1; }
+        d->demod_fm = 1; d->enabled = 1;
+    }
+    if (md) {
+        if (sscanf(md, "FM:%lf", &d->mod_kf) != 1) { cl_seterr(dev->err, sizeof dev->err, "setupStream invalid MOD %s", md); return -1; }
+        d->mod_fm = 1; d->enabled = 1;
+    }
+    if (d->enabled && !d->n_fir && (d->demod_fm || (d->up != 1 || d->down != 1)) ) {
+        /* RX stages hang off the FIR kernel: a 1-tap identity FIR stands in when none is requested */
+        d->n_fir = 1; d->fir[0] = 1.0f;
+    }
+    return 0;
+}
+
+/* CaribouliteStreamFunctions.cpp:100-139 */
+cl_stream *cl_setupStream(cl_device *dev, int direction, const char *format, const size_t *channels, size_t n_channels,
+                          const char *const *keys, const char *const *vals, size_t n_kwargs)
+{
+    (void)channels; (void)n_channels;
+    if (!dev) return NULL;
+    cl_stream *st = dev->stream;                       /* the preallocated stream :105 */
+    if (set_format(st, format) != 0) {                 /* :109-115 throws */
+        cl_seterr(dev->err, sizeof dev->err, "setupStream invalid format %s", format ? format : "(null)");
+        return NULL;
+    }
+    st->native_dir = direction == CL_SOAPY_SDR_TX ? CL_SOAPY_SDR_TX : CL_SOAPY_SDR_RX;   /* :117 */
+    /* "CW" kwarg drives a modem hardware override (:123-135): no host data-path effect */
+    cl_dsp_cfg d;
+    if (parse_dsp(dev, &d, keys, vals, n_kwargs)) return NULL;
+    if (d.enabled && st->format != CL_FORMAT_CF32) {
+        cl_seterr(dev->err, sizeof dev->err, "setupStream: FIR/RESAMP/DEMOD/MOD stages need format CF32");
+        return NULL;
+    }
+    clhip_set_device(dev->smi->device);
+    if (st->rx_pipe) { clhip_rx_pipe_destroy(st->rx_pipe); st->rx_pipe = NULL; }
+    if (st->tx_pipe) { clhip_tx_pipe_destroy(st->tx_pipe); st->tx_pipe = NULL; }
+    st->dsp = d;
+    if (d.enabled && st->native_dir == CL_SOAPY_SDR_RX) {
+        st->rx_pipe = clhip_rx_pipe_create(1, dev->channel, d.fir, d.n_fir, d.n_rs ? d.rs : NULL, d.n_rs, d.up, d.down,
+                                           d.demod_fm ? CL_PIPE_OUT_FM_DEMOD : CL_PIPE_OUT_IQ);
+        if (!st->rx_pipe) { cl_seterr(dev->err, sizeof dev->err, "setupStream: %s", clhip_last_error()); return NULL; }
+    } else if (d.enabled) {
+        st->tx_pipe = clhip_tx_pipe_create(1, d.mod_fm ? d.mod_kf : 0.0, 4e6, d.n_rs ? d.rs : NULL, d.n_rs, d.up, d.down,
+                                           dev->smi->tx_mode);
+        if (!st->tx_pipe) { cl_seterr(dev->err, sizeof dev->err, "setupStream: %s", clhip_last_error()); return NULL; }
+    }
+    st->stream_active = 0;                             /* :137 activate_channel(..., false) */
+    return st;
+}
+
+void   cl_closeStream(cl_device *dev, cl_stream *stream) { (void)dev; if (stream) stream->stream_active = 0; }   /* :147-150 */
+size_t cl_getStreamMTU(const cl_device *dev, cl_stream *stream) { (void)stream; return cl_radio_get_native_mtu_size_samples(dev->radio); }
+int    cl_activateStream(cl_device *dev, cl_stream *stream, int flags, long long timeNs, size_t numElems)
+{
+    (void)dev; (void)flags; (void)timeNs; (void)numElems;
+    stream->stream_active = 1;                         /* :191; the 20 ms settle sleep is modem hardware */
+    return 0;
+}
+int    cl_deactivateStream(cl_device *dev, cl_stream *stream, int flags, long long timeNs)
+{
+    (void)dev; (void)flags; (void)timeNs;
+    stream->stream_active = 0;
+    return 0;
+}
+
+/* Cariboulite.cpp:395-417 */
+void cl_setBandwidth(cl_device *dev, int direction, size_t channel, double bw)
+{
+    (void)channel;
+    if (direction != CL_SOAPY_SDR_RX) return;
+    cl_stream *st = dev->stream;
+    if (bw < 160000.0) {
+        if (bw <= 20000.0) st->filter_type = CL_DIGFILT_20KHZ;
+        else if (bw <= 50000.0) st->filter_type = CL_DIGFILT_50KHZ;
+        else if (bw <= 100000.0) st->filter_type = CL_DIGFILT_100KHZ;
+        else st->filter_type = CL_DIGFILT_NONE;
+    } else st->filter_type = CL_DIGFILT_NONE;
+}
+int cl_getDigitalFilter(const cl_device *dev) { return dev->stream->filter_type; }
+
+/* ------------------------------------------------------------------- RX path */
+static size_t fmt_bytes(int fmt) { return fmt == CL_FORMAT_CF32 ? 8 : fmt == CL_FORMAT_CF64 ? 16 : fmt == CL_FORMAT_CS8 ? 2 : 4; }
+
+/* Stream::Read + Stream::ReadSamples(int16*)  CaribouliteStream.cpp:260-301:
+ * native read (errors squashed to 0) then the optional IIR, result left on the device */
+static int read_native_device(cl_stream *st, size_t n, int *aligned)
+{
+    cl_smi *smi = st->dev->smi;
+    int ret = cl_smi_read_device(smi, st->dev->channel, n, 0, aligned);
+    if (ret < 0) {
+        if (ret == CL_SMI_ERR_IO) printf("reader thread failed to read SMI!\n");    /* :270 */
+        ret = 0;                                                                    /* :266-276 */
+    }
+    if (ret > 0 && st->filter_type != CL_DIGFILT_NONE) {                            /* :291-298 */
+        const int f = st->filter_type - 1;
+        const size_t need = clhip_iir_workspace_bytes((size_t)ret, 3);
+        if (cl_ensure(&st->d_iir_ws, &st->iir_ws_cap, need, 1, 0)) return 0;
+        /* NOTE: slots the reference leaves untouched after a re-sync hold stale samples there too;
+         * the filter runs over all `ret` slots exactly as the reference loop does */
+        if (clhip_iir_cs16(st->sos[f], 3, st->d_iir_state[f], smi->d_iq, (size_t)ret, st->d_iir_ws, st->iir_ws_cap, smi->stream)) return 0;
+        if (aligned) *aligned = 0;     /* filtered samples: the fused raw-word path no longer applies */
+    }
+    return ret;
+}
+
+/* Stream::ReadSamplesGen  CaribouliteStream.cpp:370-382 */
+int cl_readStream(cl_device *dev, cl_stream *st, void *const *buffs, size_t numElems, int *flags, long long *timeNs, long timeoutUs)
+{
+    (void)flags; (void)timeNs; (void)timeoutUs;        /* never written / ignored on the sync path */
+    if (st->native_dir != CL_SOAPY_SDR_RX) return CL_SOAPY_SDR_NOT_SUPPORTED;       /* :248-251 */
+    cl_smi *smi = dev->smi;
+    clhip_set_device(smi->device);
+    void *out = buffs[0];
+    if (st->format == CL_FORMAT_CS16) {                /* :282-301, no MTU clamp */
+        int aligned = 0;
+        int res = read_native_device(st, numElems, &aligned);
+        if (res <= 0) return res;
+        if (st->filter_type == CL_DIGFILT_NONE) { if (cl_smi_copy_out(smi, (cl_sample_complex_int16 *)out, NULL, -1)) return 0; }
+        else if (clhip_memcpy_d2h(out, smi->d_iq, (size_t)res * 4, smi->stream) || clhip_stream_sync(smi->stream)) return 0;
+        return res;
+    }
+    if (numElems > st->mtu_size) numElems = st->mtu_size;                          /* :306,328,351 */
+    int aligned = 0;
+    int res = read_native_device(st, numElems, &aligned);
+    if (res <= 0) return res;
+    const size_t n = (size_t)res;
+    if (st->rx_pipe) {
+        /* extension stages where a client of readStream(CF32) would apply them */
+        const size_t n_out = clhip_rx_pipe_out_count(st->rx_pipe, n);
+        const size_t ob = st->dsp.demod_fm ? 4 : 8;
+        if (cl_ensure(&st->d_conv, &st->conv_cap, n_out * ob + 64, 1, 0)) return 0;
+        long got;
+        if (aligned)   /* every chunk in sync: one fused launch straight from the raw SMI words */
+            got = clhip_rx_pipe_run(st->rx_pipe, CL_PIPE_IN_SMI_WORDS, smi->d_bytes, 0, n, st->d_conv, 0, smi->stream);
+        else           /* re-synchronised or IIR-filtered: from the native int16 samples */
+            got = clhip_rx_pipe_run(st->rx_pipe, CL_PIPE_IN_CS16, smi->d_iq, 0, n, st->d_conv, 0, smi->stream);
+        if (got < 0) return 0;
+        if (got && (clhip_memcpy_d2h(out, st->d_conv, (size_t)got * ob, smi->stream) || clhip_stream_sync(smi->stream))) return 0;
+        return (int)got;
+    }
+    /* :304-367: every one of the `res` slots is converted, stale ones included */
+    if (cl_ensure(&st->d_conv, &st->conv_cap, n * 16 + 64, 1, 0)) return 0;
+    if (clhip_convert_from_cs16(smi->d_iq, n, st->format, st->d_conv, smi->stream) ||
+        clhip_memcpy_d2h(out, st->d_conv, n * fmt_bytes(st->format), smi->stream) || clhip_stream_sync(smi->stream))
+        return 0;
+    return res;
+}
+
+/* ------------------------------------------------------------------- TX path */
+/* Stream::WriteSamplesGen  CaribouliteStream.cpp:247-258 */
+int cl_writeStream(cl_device *dev, cl_stream *st, const void *const *buffs, size_t numElems, int *flags, long long timeNs, long timeoutUs)
+{
+    (void)flags; (void)timeNs; (void)timeoutUs;
+    if (st->native_dir != CL_SOAPY_SDR_TX) return CL_SOAPY_SDR_NOT_SUPPORTED;       /* :285-288 */
+    cl_smi *smi = dev->smi;
+    clhip_set_device(smi->device);
+    const void *in = buffs[0];
+    if (st->format == CL_FORMAT_CS16) {                /* :182-196 */
+        int ret = cl_radio_write_samples(dev->radio, (cl_sample_complex_int16 *)in, numElems);
+        if (ret < 0) { if (ret == -1) printf("Failed to write\n"); ret = 0; }
+        return ret;
+    }
+    if (numElems > st->mtu_size) numElems = st->mtu_size;                          /* :201,217,234 */
+    if (numElems == 0) return 0;
+    const size_t n = numElems, ib = fmt_bytes(st->format);
+    if (cl_ensure(&st->d_conv, &st->conv_cap, n * 16 + 64, 1, 0) ||
+        cl_ensure((void **)&smi->d_iq, &smi->iq_cap, n + 8, 4, 0) ||
+        cl_ensure((void **)&smi->d_bytes, &smi->bytes_cap, 4 * n * (size_t)(st->tx_pipe ? st->dsp.up : 1) + 256, 1, 0) ||
+        cl_ensure((void **)&smi->h_stage, &smi->h_stage_cap, 4 * n * (size_t)(st->tx_pipe ? st->dsp.up : 1) + 256, 1, 1))
+        return 0;
+    if (!(st->tx_pipe && st->dsp.mod_fm) && clhip_memcpy_h2d(st->d_conv, in, n * ib, smi->stream)) return 0;
+    size_t n_packed = n;
+    if (st->tx_pipe) {
+        /* MOD=FM: the I component carries the real message (SURVEY.md a13 "if given I/Q, use I");
+         * stride 2 floats walks the I rail of the CF32 buffer */
+        long got;
+        if (st->dsp.mod_fm) {
+            /* gather I into a dense message: reuse the upper half of d_conv via a strided D2D is not
+             * available in the C-ABI, so the message is compacted on the host side of the copy */
+            float *tmp = (float *)malloc(sizeof(float) * n);
+            if (!tmp) return 0;
+            for (size_t k = 0; k < n; k++) tmp[k] = ((const float *)in)[2 * k];
+            int bad = clhip_memcpy_h2d(st->d_conv, tmp, n * 4, smi->stream) || clhip_stream_sync(smi->stream);
+            free(tmp);
+            if (bad) return 0;
+            got = clhip_tx_pipe_run(st->tx_pipe, CL_TXPIPE_IN_FM_MESSAGE, st->d_conv, 0, n, smi->d_bytes, 0, NULL, 0, smi->stream);
+        } else
+            got = clhip_tx_pipe_run(st->tx_pipe, CL_TXPIPE_IN_CF32, st->d_conv, 0, n, smi->d_bytes, 0, NULL, 0, smi->stream);
+        if (got < 0) return 0;
+        n_packed = (size_t)got;
+    } else {
+        if (clhip_convert_to_cs16(st->d_conv, st->format, n, smi->d_iq, smi->stream) ||      /* :199-244 */
+            clhip_smi_pack(smi->tx_mode, smi->d_iq, n, smi->d_bytes, smi->stream))            /* caribou_smi.c:684-717 */
+            return 0;
+    }
+    if (n_packed && (clhip_memcpy_d2h(smi->h_stage, smi->d_bytes, 4 * n_packed, smi->stream) || clhip_stream_sync(smi->stream))) return 0;
+    /* caribou_smi_write's chunk loop (caribou_smi.c:738-759) over the packed bytes */
+    size_t left = 4 * n_packed, done = 0;
+    while (left) {
+        size_t cur = left > smi->native_batch_len ? smi->native_batch_len : left;
+        if (cl_fifo_push(&smi->tx, smi->h_stage + done, cur)) return 0;
+        done += cur; left -= cur;
+    }
+    return (int)n;      /* elements consumed from the caller's buffer */
+}

@@ -1,0 +1,208 @@
+"""SoapySDR-shaped Python face of libcariboulite_host.so (layer 2 of
+include/cariboulite_hip.h) so that tests and examples read like the reference's
+own SoapySDR clients (examples/python/read_test.py):
+
+    sdr = Device(dict(driver="Cariboulite", channel="S1G"))
+    rx = sdr.setupStream(SOAPY_SDR_RX, SOAPY_SDR_CS16)
+    sdr.activateStream(rx)
+    sr = sdr.readStream(rx, [buf], len(buf))      # sr.ret
+
+The only addition is the byte injection that replaces /dev/smi:
+sdr.feedSmiBytes(b) / sdr.drainSmiBytes().
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import hip as _hip
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "libcariboulite_host.so")
+
+SOAPY_SDR_TX, SOAPY_SDR_RX = 0, 1
+SOAPY_SDR_CS16, SOAPY_SDR_CS8, SOAPY_SDR_CF32, SOAPY_SDR_CF64 = "CS16", "CS8", "CF32", "CF64"
+SOAPY_SDR_NOT_SUPPORTED = -5
+SMI_ERR_IO, SMI_ERR_DEBUGMODE, SMI_ERR_SYNC = -1, -2, -3
+
+_SIGS = {
+    "cl_smi_init": (C.c_void_p, [C.c_int]),
+    "cl_smi_close": (C.c_int, [C.c_void_p]),
+    "cl_smi_feed_bytes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "cl_smi_pending_bytes": (C.c_size_t, [C.c_void_p]),
+    "cl_smi_set_max_read": (None, [C.c_void_p, C.c_size_t]),
+    "cl_smi_drain_bytes": (C.c_size_t, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "cl_smi_set_tx_mode": (None, [C.c_void_p, C.c_int]),
+    "cl_smi_read": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "cl_smi_write": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
+    "cl_smi_get_native_batch_samples": (C.c_size_t, [C.c_void_p]),
+    "cl_radio_create": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "cl_radio_destroy": (None, [C.c_void_p]),
+    "cl_radio_read_samples": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "cl_radio_write_samples": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "cl_radio_get_native_mtu_size_samples": (C.c_size_t, [C.c_void_p]),
+    "cl_device_make": (C.c_void_p, [C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_size_t]),
+    "cl_device_unmake": (None, [C.c_void_p]),
+    "cl_device_smi": (C.c_void_p, [C.c_void_p]),
+    "cl_device_last_error": (C.c_char_p, [C.c_void_p]),
+    "cl_getStreamFormats": (C.c_size_t, [C.c_void_p, C.c_int, C.c_size_t, C.POINTER(C.c_char_p), C.c_size_t]),
+    "cl_getNativeStreamFormat": (C.c_char_p, [C.c_void_p, C.c_int, C.c_size_t, C.POINTER(C.c_double)]),
+    "cl_setupStream": (C.c_void_p, [C.c_void_p, C.c_int, C.c_char_p, C.c_void_p, C.c_size_t,
+                                    C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_size_t]),
+    "cl_closeStream": (None, [C.c_void_p, C.c_void_p]),
+    "cl_getStreamMTU": (C.c_size_t, [C.c_void_p, C.c_void_p]),
+    "cl_activateStream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_size_t]),
+    "cl_deactivateStream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_longlong]),
+    "cl_readStream": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t, C.POINTER(C.c_int),
+                                C.POINTER(C.c_longlong), C.c_long]),
+    "cl_writeStream": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t, C.POINTER(C.c_int),
+                                 C.c_longlong, C.c_long]),
+    "cl_setBandwidth": (None, [C.c_void_p, C.c_int, C.c_size_t, C.c_double]),
+    "cl_getDigitalFilter": (C.c_int, [C.c_void_p]),
+    "cl_design_lowpass": (C.c_int, [C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p]),
+    "cl_design_butter_lowpass": (C.c_int, [C.c_int, C.c_double, C.c_double, C.c_void_p]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _hip.lib()                       # RTLD_GLOBAL: libcariboulite_hip.so first
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: run __graft_entry__.build()")
+        _lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(_lib, name)
+            fn.restype, fn.argtypes = res, args
+    return _lib
+
+
+def _kwargs(d):
+    d = {str(k): str(v) for k, v in (d or {}).items()}
+    n = len(d)
+    K = (C.c_char_p * max(n, 1))(*[k.encode() for k in d])
+    V = (C.c_char_p * max(n, 1))(*[v.encode() for v in d.values()])
+    return K, V, n
+
+
+def design_lowpass(n_taps, cutoff_hz, fs_hz, gain=1.0):
+    out = np.empty(n_taps, dtype=np.float32)
+    if lib().cl_design_lowpass(n_taps, cutoff_hz, fs_hz, gain, out.ctypes.data) != 0:
+        raise ValueError("cl_design_lowpass: bad arguments")
+    return out
+
+
+def design_butter_lowpass(order, fs_hz, fc_hz):
+    out = np.empty((order // 2, 5), dtype=np.float64)
+    if lib().cl_design_butter_lowpass(order, fs_hz, fc_hz, out.ctypes.data) != 0:
+        raise ValueError("cl_design_butter_lowpass: bad arguments")
+    return out
+
+
+class StreamResult:
+    def __init__(self, ret, flags=0, timeNs=0):
+        self.ret, self.flags, self.timeNs = ret, flags, timeNs
+
+
+class Device:
+    """Stands where SoapySDR.Device(dict(driver="Cariboulite", ...)) stands."""
+
+    def __init__(self, args):
+        K, V, n = _kwargs(args)
+        self.h = lib().cl_device_make(K, V, n)
+        if not self.h:
+            # Cariboulite.cpp:25-34 throws; no GPU also lands here (there is no CPU fallback)
+            raise RuntimeError("Cariboulite device make failed: channel must be S1G or HiF and an MI355X must be visible")
+        self.smi = lib().cl_device_smi(self.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().cl_device_unmake(self.h)
+            self.h = None
+
+    __del__ = close
+
+    # ---- injection replacing /dev/smi
+    def feedSmiBytes(self, b):
+        b = np.ascontiguousarray(b, dtype=np.uint8)
+        return lib().cl_smi_feed_bytes(self.smi, b.ctypes.data, b.size)
+
+    def pendingSmiBytes(self):
+        return lib().cl_smi_pending_bytes(self.smi)
+
+    def setMaxRead(self, n):
+        lib().cl_smi_set_max_read(self.smi, n)
+
+    def setTxMode(self, mode):
+        lib().cl_smi_set_tx_mode(self.smi, mode)
+
+    def drainSmiBytes(self, max_bytes=1 << 26):
+        out = np.empty(max_bytes, dtype=np.uint8)
+        n = lib().cl_smi_drain_bytes(self.smi, out.ctypes.data, max_bytes)
+        return out[:n].copy()
+
+    # ---- lower seam (caribou_smi_read / caribou_smi_write)
+    def smiRead(self, channel, n, want_meta=True, fill=-21846):
+        iq = np.full((n + 2, 2), fill, dtype=np.int16)
+        meta = np.full(n + 2, 0xAA, dtype=np.uint8) if want_meta else None
+        ret = lib().cl_smi_read(self.smi, channel, iq.ctypes.data, meta.ctypes.data if want_meta else None, n)
+        return ret, iq, meta
+
+    def smiWrite(self, channel, iq):
+        iq = np.ascontiguousarray(iq, dtype=np.int16).reshape(-1, 2)
+        return lib().cl_smi_write(self.smi, channel, iq.ctypes.data, iq.shape[0])
+
+    # ---- SoapySDR::Device surface
+    def getStreamFormats(self, direction, channel):
+        arr = (C.c_char_p * 8)()
+        n = lib().cl_getStreamFormats(self.h, direction, channel, arr, 8)
+        return [arr[i].decode() for i in range(n)]
+
+    def getNativeStreamFormat(self, direction, channel):
+        fs = C.c_double(0)
+        f = lib().cl_getNativeStreamFormat(self.h, direction, channel, C.byref(fs))
+        return f.decode(), fs.value
+
+    def setupStream(self, direction, fmt, channels=(0,), args=None):
+        K, V, n = _kwargs(args)
+        ch = (C.c_size_t * max(len(channels), 1))(*channels)
+        st = lib().cl_setupStream(self.h, direction, fmt.encode(), ch, len(channels), K, V, n)
+        if not st:
+            raise RuntimeError(lib().cl_device_last_error(self.h).decode())     # std::runtime_error in the reference
+        return st
+
+    def closeStream(self, st):
+        lib().cl_closeStream(self.h, st)
+
+    def getStreamMTU(self, st):
+        return lib().cl_getStreamMTU(self.h, st)
+
+    def activateStream(self, st, flags=0, timeNs=0, numElems=0):
+        return lib().cl_activateStream(self.h, st, flags, timeNs, numElems)
+
+    def deactivateStream(self, st, flags=0, timeNs=0):
+        return lib().cl_deactivateStream(self.h, st, flags, timeNs)
+
+    def readStream(self, st, buffs, numElems, flags=0, timeoutUs=100000):
+        p = (C.c_void_p * 1)(buffs[0].ctypes.data)
+        fl, tn = C.c_int(flags), C.c_longlong(0)
+        ret = lib().cl_readStream(self.h, st, p, numElems, C.byref(fl), C.byref(tn), timeoutUs)
+        return StreamResult(ret, fl.value, tn.value)
+
+    def writeStream(self, st, buffs, numElems, flags=0, timeNs=0, timeoutUs=100000):
+        p = (C.c_void_p * 1)(buffs[0].ctypes.data)
+        fl = C.c_int(flags)
+        ret = lib().cl_writeStream(self.h, st, p, numElems, C.byref(fl), timeNs, timeoutUs)
+        return StreamResult(ret, fl.value, timeNs)
+
+    def setBandwidth(self, direction, channel, bw):
+        lib().cl_setBandwidth(self.h, direction, channel, bw)
+
+    def getDigitalFilter(self):
+        return lib().cl_getDigitalFilter(self.h)

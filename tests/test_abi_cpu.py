@@ -1,0 +1,93 @@
+"""not-gpu: the C-ABI libraries load and export every symbol include/cariboulite_hip.h declares;
+host-side design helpers agree with scipy / the oracle; no GPU => loud failure, no CPU fallback."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "cariboulite_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b((?:clhip|cl)_[A-Za-z0-9_]+)\s*\(", src)))
+
+
+def _exports(path):
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return {l.split()[-1] for l in out.splitlines() if " T " in l}
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    from cariboulite_amd import hip, soapy
+    hip.lib(); soapy.lib()                       # both load without a GPU
+    decl = _declared()
+    exp = _exports(hip.LIB_PATH) | _exports(soapy.LIB_PATH)
+    missing = [s for s in decl if s not in exp]
+    assert not missing, missing
+    assert len(decl) > 60
+    bound = set(hip.exported_symbols()) | set(soapy.exported_symbols())
+    assert not [s for s in decl if s not in bound], "python binding lags the header"
+    # layer split: HIP shim exports clhip_*, host layer exports cl_*
+    assert all(s in _exports(hip.LIB_PATH) for s in decl if s.startswith("clhip_"))
+    assert all(s in _exports(soapy.LIB_PATH) for s in decl if not s.startswith("clhip_"))
+
+
+def test_product_does_not_link_or_import_the_oracle():
+    from cariboulite_amd import hip, soapy
+    for lib in (hip.LIB_PATH, soapy.LIB_PATH):
+        dyn = subprocess.run(["ldd", lib], capture_output=True, text=True).stdout
+        assert "liboracle" not in dyn and "libref_smi" not in dyn
+        assert not [s for s in _exports(lib) if s.startswith("orc_") or s.startswith("ref_")]
+    for dp, _, fs in os.walk(os.path.join(ROOT, "cariboulite_amd")):
+        for f in fs:
+            if f.endswith((".py", ".c", ".h", ".hip", ".cpp")):
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "cl_oracle" not in txt, f
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from cariboulite_amd import hip, soapy
+    assert hip.lib().clhip_device_count() == 0
+    with pytest.raises(RuntimeError):
+        hip.require_gpu()
+    with pytest.raises(RuntimeError):
+        soapy.Device(dict(driver="Cariboulite", channel="S1G"))
+    assert not soapy.lib().cl_smi_init(0)
+
+
+def test_design_lowpass_matches_scipy_firwin():
+    from cariboulite_amd import soapy
+    t = load_golden("taps.npz")
+    for name, n, fc in (("fir64_c2", 64, 1.0e6), ("fir64_c3", 64, 100e3), ("fir128_c4", 128, 1.2e6)):
+        h = soapy.design_lowpass(n, fc, 4e6)
+        assert np.max(np.abs(h.astype(np.float64) - t[name + "__f64"])) < 4e-8       # fp32 rounding of 0.5-ish taps
+        assert np.max(np.abs(h - t[name])) <= 6e-8 and np.mean(h != t[name]) < 0.1    # vs scipy's own fp32 rounding
+    for L, M in ((3, 2), (5, 4), (2, 3)):
+        h = soapy.design_lowpass(8 * L, 1.0 / max(L, M), 2.0, gain=L)
+        assert np.max(np.abs(h.astype(np.float64) - t[f"rs_{L}_{M}__f64"])) < 1e-7
+    with pytest.raises(ValueError):
+        soapy.design_lowpass(64, 3e6, 4e6)
+
+
+def test_design_butter_matches_oracle_and_scipy(orc):
+    from cariboulite_amd import soapy
+    g = load_golden("dsp_float.npz")
+    import numpy.polynomial.polynomial as P
+    for bw in (20, 50, 100):
+        sos = soapy.design_butter_lowpass(6, 4e6, bw * 1e3 / 2)
+        o = orc.IIR(6, 4e6, bw * 1e3 / 2).sos()
+        # same algorithm, different compiler flags (FMA contraction): agree to rounding
+        assert np.allclose(sos[:, :3], o[:, :3], rtol=1e-9, atol=0) and np.allclose(sos[:, 3:], o[:, 4:], rtol=1e-13, atol=0)
+        den = np.array([1.0]); den_s = np.array([1.0])
+        for s in sos:
+            den = P.polymul(den, [1.0, s[3], s[4]])
+        for s in g[f"iir_{bw}k__sos"]:
+            den_s = P.polymul(den_s, s[3:])
+        assert np.allclose(den, den_s, rtol=1e-9, atol=0)

@@ -1,0 +1,244 @@
+"""-m gpu: the SoapySDR stream calls and the SMI seam of the host C layer, driven like the
+reference's own clients (examples/python/read_test.py), checked against the oracle."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+NB = 524288          # native batch bytes (caribou_smi.c:78)
+MTU = 131072
+SENT = -21846
+
+
+@pytest.fixture(scope="module")
+def S():
+    import torch
+    from cariboulite_amd import hip, soapy
+    assert torch.cuda.is_available() and hip.require_gpu().startswith("gfx950")
+    return soapy
+
+
+def words(n, ch=0, seed=0):
+    from cariboulite_amd import synth
+    rng = np.random.default_rng(seed)
+    return synth.iq_to_words(rng.integers(-4096, 4096, n), rng.integers(-4096, 4096, n), ch,
+                             rng.integers(0, 2, n)).view(np.uint8)
+
+
+def test_device_and_stream_api_surface(S):
+    with pytest.raises(RuntimeError):
+        S.Device(dict(driver="Cariboulite", channel="XYZ"))          # Cariboulite.cpp:25-28 throws
+    with pytest.raises(RuntimeError):
+        S.Device(dict(driver="Cariboulite"))
+    sdr = S.Device(dict(driver="Cariboulite", channel="HiF", device_id="0", label="x"))
+    assert sdr.getStreamFormats(S.SOAPY_SDR_RX, 0) == ["CS16", "CS8", "CF32", "CF64"]
+    assert sdr.getNativeStreamFormat(S.SOAPY_SDR_RX, 0) == ("CS16", 4095.0)
+    with pytest.raises(RuntimeError, match="invalid format"):
+        sdr.setupStream(S.SOAPY_SDR_RX, "CS12")                       # CaribouliteStreamFunctions.cpp:111-115
+    rx = sdr.setupStream(S.SOAPY_SDR_RX, S.SOAPY_SDR_CS16, args={"CW": "0"})
+    assert sdr.getStreamMTU(rx) == MTU
+    assert sdr.activateStream(rx) == 0
+    buf = np.zeros((16, 2), np.int16)
+    assert sdr.readStream(rx, [buf], 16).ret == 0                     # nothing pending: timeout -> 0 samples
+    assert sdr.writeStream(rx, [buf], 16).ret == S.SOAPY_SDR_NOT_SUPPORTED
+    tx = sdr.setupStream(S.SOAPY_SDR_TX, S.SOAPY_SDR_CS16)
+    assert tx == rx                                                   # THE preallocated stream (:105,138)
+    assert sdr.readStream(tx, [buf], 16).ret == S.SOAPY_SDR_NOT_SUPPORTED
+    assert sdr.deactivateStream(tx) == 0
+    sdr.closeStream(tx)
+    sdr.close()
+
+
+@pytest.mark.parametrize("ch,name", [(0, "S1G"), (1, "HiF")])
+def test_read_cs16_like_read_test_py(S, orc, ch, name):
+    sdr = S.Device(dict(driver="Cariboulite", channel=name))
+    rx = sdr.setupStream(S.SOAPY_SDR_RX, S.SOAPY_SDR_CS16)
+    sdr.activateStream(rx)
+    n = 3 * MTU + 1000
+    b = words(n, ch, seed=1)
+    sdr.feedSmiBytes(b)
+    buf = np.full((n + 2, 2), SENT, np.int16)
+    sr = sdr.readStream(rx, [buf], n, timeoutUs=int(5e6))             # CS16 is NOT clamped to the MTU
+    ret, want, _ = orc.smi_read(ch, b, n, NB)
+    assert sr.ret == ret == n and np.array_equal(buf, want)
+    assert sdr.pendingSmiBytes() == 0
+    sdr.close()
+
+
+def test_read_converted_formats_clamp_to_mtu(S, orc):
+    for fmt, dt, conv in (("CF32", np.float32, orc.cs16_to_cf32), ("CF64", np.float64, orc.cs16_to_cf64),
+                          ("CS8", np.int8, orc.cs16_to_cs8)):
+        sdr = S.Device(dict(driver="Cariboulite", channel="S1G"))
+        rx = sdr.setupStream(S.SOAPY_SDR_RX, fmt)
+        b = words(MTU + 5000, 0, seed=2)
+        sdr.feedSmiBytes(b)
+        buf = np.zeros((200000, 2), dt)
+        sr = sdr.readStream(rx, [buf], 200000)
+        assert sr.ret == MTU                                          # CaribouliteStream.cpp:306
+        _, iq, _ = orc.rx_data_analyze(0, b[:NB])
+        assert np.array_equal(buf[:MTU], conv(iq[:MTU])) and not buf[MTU:].any()
+        assert sdr.readStream(rx, [buf], 200000).ret == 5000          # the rest of the FIFO, then drained
+        sdr.close()
+
+
+def test_smi_seam_return_codes_and_untouched_slots(S, orc):
+    g = load_golden("smi_read_cases.npz")
+    sdr = S.Device(dict(driver="Cariboulite", channel="S1G"))
+    # the reference's own outputs, at the native batch size
+    for seed, mis in ((3, 0), (4, 2), (5, 6), (6, 4097)):
+        n = 2 * MTU
+        body = words(n, 0, seed=seed)
+        stream = np.concatenate([body[:NB], np.zeros(mis, np.uint8), body[NB:]])[: 4 * n]
+        sdr.feedSmiBytes(stream)
+        ret, iq, meta = sdr.smiRead(0, n)
+        wret, wiq, wmeta = orc.smi_read(0, stream, n, NB)
+        assert ret == wret == n
+        assert np.array_equal(iq, wiq) and np.array_equal(meta, wmeta)   # sentinel slots stay untouched
+    # sync failure in the second chunk: -3, first chunk delivered, later bytes still pending
+    n = 3 * MTU
+    bad = words(n, 0, seed=7).copy(); bad[NB:2 * NB] = 0
+    sdr.feedSmiBytes(bad)
+    ret, iq, meta = sdr.smiRead(0, n)
+    wret, wiq, wmeta = orc.smi_read(0, bad, n, NB)
+    assert ret == wret == S.SMI_ERR_SYNC
+    assert np.array_equal(iq, wiq) and np.array_equal(meta, wmeta)
+    assert sdr.pendingSmiBytes() == NB                                 # the reference stops reading at the bad chunk
+    ret, iq2, _ = sdr.smiRead(0, MTU)
+    assert ret == MTU and np.array_equal(iq2[:MTU], orc.rx_data_analyze(0, bad[2 * NB:])[1][:MTU])
+    # through Soapy the same failure is squashed to 0 samples (CaribouliteStream.cpp:266-276)
+    rx = sdr.setupStream(S.SOAPY_SDR_RX, S.SOAPY_SDR_CS16)
+    sdr.feedSmiBytes(bad[NB:2 * NB])
+    buf = np.zeros((MTU, 2), np.int16)
+    assert sdr.readStream(rx, [buf], MTU).ret == 0
+    # short reads of the fd (max_read) and a drained source (timeout -> partial count)
+    for name in ("five_chunks_aligned", "eof_timeout", "partial_last_chunk", "zero_length"):
+        ch, nn, batch = [int(v) for v in g[f"{name}__args"]]
+        sdr.setMaxRead(batch)                                          # emulate the fixture's 4 KiB native batch
+        sdr.feedSmiBytes(g[f"{name}__bytes"])
+        ret, iq, meta = sdr.smiRead(ch, nn)
+        assert ret == int(g[f"{name}__ret"])
+        assert np.array_equal(iq, g[f"{name}__iq"]) and np.array_equal(meta, g[f"{name}__meta"])
+        sdr.drainSmiBytes(); sdr.smiRead(0, 1 << 16)                   # flush leftovers
+        sdr.setMaxRead(0)
+    sdr.close()
+
+
+def test_iir_via_set_bandwidth_state_persists(S, orc):
+    """Cariboulite.cpp:395-417 -> CaribouliteStream.cpp:291-298; states are never reset on a swap."""
+    sdr = S.Device(dict(driver="Cariboulite", channel="S1G"))
+    rx = sdr.setupStream(S.SOAPY_SDR_RX, S.SOAPY_SDR_CS16)
+    from cariboulite_amd import synth
+    b, i, q = synth.smi_stream_bytes(3 * MTU, 0, stream=9)
+    iq = np.stack([i, q], 1).astype(np.int16)
+    f20, f100 = orc.IIR(6, 4e6, 10e3), orc.IIR(6, 4e6, 50e3)
+    sdr.feedSmiBytes(b)
+    buf = np.zeros((MTU, 2), np.int16)
+    for bw, filt, want_type, k in ((15e3, f20, 1, 0), (90e3, f100, 3, 1), (20e3, f20, 1, 2)):
+        sdr.setBandwidth(S.SOAPY_SDR_RX, 0, bw)
+        assert sdr.getDigitalFilter() == want_type
+        assert sdr.readStream(rx, [buf], MTU).ret == MTU
+        want = filt.apply_cs16(iq[k * MTU:(k + 1) * MTU])              # f20 keeps its state from call 0 to call 2
+        d = np.abs(buf.astype(int) - want.astype(int))
+        assert d.max() <= 1 and np.mean(d != 0) < 1e-4
+    sdr.setBandwidth(S.SOAPY_SDR_RX, 0, 200e3)
+    assert sdr.getDigitalFilter() == 0
+    sdr.setBandwidth(S.SOAPY_SDR_RX, 0, 120e3)
+    assert sdr.getDigitalFilter() == 0                                 # 100k < bw < 160k -> none (:404)
+    # IIR + CF32: filter on int16, truncate, then /4096
+    sdr.setBandwidth(S.SOAPY_SDR_RX, 0, 50e3)
+    rx = sdr.setupStream(S.SOAPY_SDR_RX, S.SOAPY_SDR_CF32)
+    b2, i2, q2 = synth.smi_stream_bytes(MTU, 0, stream=10)
+    sdr.feedSmiBytes(b2)
+    fb = np.zeros((MTU, 2), np.float32)
+    assert sdr.readStream(rx, [fb], MTU).ret == MTU
+    want = orc.cs16_to_cf32(orc.IIR(6, 4e6, 25e3).apply_cs16(np.stack([i2, q2], 1)))
+    assert np.max(np.abs(fb - want)) <= 1.0 / 4096 + 1e-9 and np.mean(fb != want) < 1e-4
+    sdr.close()
+
+
+def test_rx_extension_stages_via_kwargs(S, orc):
+    """FIR / RESAMP / DEMOD kwargs (SURVEY.md section 5 'Config / flags'), default = reference behaviour."""
+    from cariboulite_amd import synth
+    t = load_golden("taps.npz")
+    sdr = S.Device(dict(driver="Cariboulite", channel="S1G"))
+    rx = sdr.setupStream(S.SOAPY_SDR_RX, S.SOAPY_SDR_CF32, args={"FIR": "64:1000000", "RESAMP": "3/2"})
+    b, i, q = synth.smi_stream_bytes(2 * MTU, 0, stream=12)
+    sdr.feedSmiBytes(b)
+    x = orc.cs16_to_cf32(np.stack([i, q], 1))
+    fir, rs = orc.FIR(t["fir64_c2"]), orc.Resampler(t["rs_3_2"], 3, 2)
+    for k in range(2):
+        out = np.zeros((MTU * 3 // 2 + 8, 2), np.float32)
+        sr = sdr.readStream(rx, [out], MTU)
+        assert sr.ret == MTU * 3 // 2
+        want = rs.f64(fir.f64(x[k * MTU:(k + 1) * MTU]))
+        assert np.max(np.abs(out[:sr.ret] - want)) <= 1e-5 * np.max(np.abs(want))
+    # misaligned chunk -> CS16 route through the same stages (re-sync + extrapolated sample)
+    rx = sdr.setupStream(S.SOAPY_SDR_RX, S.SOAPY_SDR_CF32, args={"FIR": "64:100000", "DEMOD": "FM"})
+    mis = np.concatenate([np.zeros(3, np.uint8), b])[:NB]
+    sdr.smiRead(0, 1 << 20)
+    sdr.feedSmiBytes(mis)
+    outf = np.zeros(MTU + 8, np.float32)
+    sr = sdr.readStream(rx, [outf], MTU)
+    assert sr.ret == MTU
+    _, iqm, _ = orc.rx_data_analyze(0, mis)
+    xm = orc.cs16_to_cf32(iqm[:MTU - 1])            # slot MTU-1 is an untouched (stale) slot: compare the rest
+    y = orc.FIR(t["fir64_c3"]).f64(xm)
+    want = orc.fm_demod_f64(y)[0]
+    mag = np.hypot(y[:, 0], y[:, 1]); ok = mag > 0.02; ok[1:] &= ok[:-1]
+    d = np.abs(outf[:MTU - 1] - want); d = np.minimum(d, 2 * np.pi - d)
+    assert np.max(d[ok]) <= 1e-4 and ok.mean() > 0.5
+    with pytest.raises(RuntimeError, match="need format CF32"):
+        sdr.setupStream(S.SOAPY_SDR_RX, S.SOAPY_SDR_CS16, args={"FIR": "64:1000000"})
+    with pytest.raises(RuntimeError, match="invalid RESAMP"):
+        sdr.setupStream(S.SOAPY_SDR_RX, S.SOAPY_SDR_CF32, args={"RESAMP": "x"})
+    sdr.close()
+
+
+def test_write_stream_all_formats(S, orc):
+    from cariboulite_amd import hip
+    sdr = S.Device(dict(driver="Cariboulite", channel="S1G"))
+    rng = np.random.default_rng(21)
+    n = MTU + 777
+    iq = rng.integers(-4096, 4096, (n, 2)).astype(np.int16)
+    tx = sdr.setupStream(S.SOAPY_SDR_TX, S.SOAPY_SDR_CS16)
+    assert sdr.writeStream(tx, [iq], n).ret == n                        # CS16: no MTU clamp (:182-196)
+    assert np.array_equal(sdr.drainSmiBytes(), orc.generate_data(iq, orc.TX_DOCUMENTED))
+    f = (rng.standard_normal((n, 2)) * 0.4).astype(np.float32)
+    tx = sdr.setupStream(S.SOAPY_SDR_TX, S.SOAPY_SDR_CF32)
+    assert sdr.writeStream(tx, [f], n).ret == MTU                       # clamped (:201)
+    assert np.array_equal(sdr.drainSmiBytes(), orc.generate_data(orc.cf32_to_cs16(f[:MTU]), orc.TX_DOCUMENTED))
+    d = f.astype(np.float64) * 1.00001
+    tx = sdr.setupStream(S.SOAPY_SDR_TX, S.SOAPY_SDR_CF64)
+    assert sdr.writeStream(tx, [d], 5000).ret == 5000
+    assert np.array_equal(sdr.drainSmiBytes(), orc.generate_data(orc.cf64_to_cs16(d[:5000]), orc.TX_DOCUMENTED))
+    i8 = rng.integers(-128, 128, (5000, 2)).astype(np.int8)
+    tx = sdr.setupStream(S.SOAPY_SDR_TX, S.SOAPY_SDR_CS8)
+    assert sdr.writeStream(tx, [i8], 5000).ret == 5000
+    assert np.array_equal(sdr.drainSmiBytes(), orc.generate_data(orc.cs8_to_cs16(i8), orc.TX_DOCUMENTED))
+    # compat mode: the packer exactly as shipped (caribou_smi.c:700-701)
+    sdr.setTxMode(hip.TX_AS_WRITTEN)
+    tx = sdr.setupStream(S.SOAPY_SDR_TX, S.SOAPY_SDR_CS16)
+    sdr.writeStream(tx, [iq], 256)
+    g = load_golden("smi_tx_as_written.npz")
+    assert np.array_equal(sdr.drainSmiBytes(), g["bytes"])
+    sdr.setTxMode(hip.TX_DOCUMENTED)
+    # lower seam
+    assert sdr.smiWrite(0, iq[:1000]) == 1000
+    assert np.array_equal(sdr.drainSmiBytes(), orc.generate_data(iq[:1000]))
+    # config 5 through kwargs: FM modulate the I rail, 2/3 resample, pack
+    t = load_golden("taps.npz"); g = load_golden("dsp_float.npz")
+    tx = sdr.setupStream(S.SOAPY_SDR_TX, S.SOAPY_SDR_CF32, args={"MOD": "FM:75000", "RESAMP": "2/3"})
+    m = g["fm_msg"]
+    msg_iq = np.stack([m, np.zeros_like(m)], 1)
+    assert sdr.writeStream(tx, [msg_iq], m.size).ret == m.size
+    by = sdr.drainSmiBytes()
+    assert by.size == 4 * (-(-m.size * 2 // 3))
+    w = orc.fpga_tx_parse(by)
+    _, got, _ = orc.rx_data_analyze(0, (w & ~np.uint32(1 << 16)).view(np.uint8))
+    want = g["fm_mod_rs_2_3"] * 4096.0
+    wq = ((np.trunc(want).astype(np.int64) + 4096) & 0x1FFF) - 4096
+    dd = np.abs(got[:wq.shape[0]].astype(np.int64) - wq)
+    dd = np.minimum(dd, 8192 - dd)
+    assert dd.max() <= 1                                               # float->int boundary: +-1 LSB
+    sdr.close()
