@@ -122,26 +122,20 @@ def main():
     assert int(bad.item()) == 0 and int(offs.abs().max().item()) == 0, "synthetic stream lost sync?"
 
     # per-launch duration of the pipe with HIP events on the launch stream
+    from cariboulite_amd import shard
     evs = [(L.clhip_event_create(), L.clhip_event_create()) for _ in range(a.steps)]
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(a.steps):
+    counter = [0]
+
+    def timed_step():
+        k = counter[0]; counter[0] += 1
         hip.smi_find_offsets(words, 4 * n, 4 * NATIVE_CHUNK_SAMPLES, 4 * NATIVE_CHUNK_SAMPLES, max(n_chunks, 1),
                              offs, stream)
         L.clhip_event_record(evs[k][0], stream)
         pipe.run(hip.PIPE_IN_SMI_WORDS, words, 0, n, out, 0, stream)
         L.clhip_event_record(evs[k][1], stream)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+
+    # barrier + synchronize on both sides, EXACTLY `steps` steps, max over ranks
+    dt = shard.timed_steps(timed_step, a.steps, sync_fn=torch.cuda.synchronize, dist=dist, device=dev)
     assert int(bad.item()) == 0
     kern_ms = [L.clhip_event_elapsed_ms(e0, e1) for e0, e1 in evs]
     for e0, e1 in evs:
@@ -149,7 +143,7 @@ def main():
     kern_avg_s = float(np.mean(kern_ms)) / 1e3
 
     if rank == 0:
-        value = world * n * a.steps / dt / 1e6
+        value = shard.job_throughput(n, a.steps, dt, world) / 1e6
         achieved = ALGO_BYTES_PER_SAMPLE * n / kern_avg_s / 1e9
         res = {
             "metric": "Msamples/s through unpack+FIR(64)+resample(3/2) pipe",

@@ -1,0 +1,48 @@
+"""Stream sharding and timing for one-process-per-GPU runs.
+
+Channel streams are independent units (the reference models each channel as its
+own Soapy device), so N GPUs need no data-path collective: stream s runs on
+rank s mod N with all of its state (sync offsets, FIR / resampler history, IIR
+and FM state).  torch.distributed (RCCL on GPUs, gloo in the CPU tests) carries
+only the timing barrier and the max-over-ranks reduction.
+"""
+import time
+
+
+def assign_streams(n_streams, world, rank):
+    """Streams owned by `rank`: s with s mod world == rank (config 4: 256 streams -> 32 per GPU)."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world {world}")
+    return list(range(rank, n_streams, world))
+
+
+def owner_of(stream, world):
+    return stream % world
+
+
+def timed_steps(step_fn, steps, sync_fn=None, dist=None, device=None):
+    """Time EXACTLY `steps` calls of step_fn, bracketed by barrier + device sync on both
+    sides; returns the MAX wall time over ranks (seconds)."""
+    import torch
+    sync_fn = sync_fn or (lambda: None)
+    if dist is not None:
+        dist.barrier()
+    sync_fn()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_fn()
+    sync_fn()
+    if dist is not None:
+        dist.barrier()
+    sync_fn()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def job_throughput(units_per_rank_per_step, steps, dt_max, world):
+    """Whole-job units per second: every rank processed the same per-step units (weak scaling)."""
+    return world * units_per_rank_per_step * steps / dt_max
