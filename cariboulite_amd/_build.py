@@ -40,7 +40,7 @@ def build_hip(force=False, verbose=False):
         obj = os.path.join(OBJ, f[:-4] + ".o")
         if force or _newer(obj, [src] + hdrs):
             jobs.append([_hipcc(), "-O3", f"--offload-arch={ARCH}", "-fPIC", "-std=c++17",
-                         "-Wall", "-Wno-unused-function", "-I", INC, "-c", src, "-o", obj])
+                         "-Wall", "-Wno-unused-function", "-fno-slp-vectorize", "-I", INC, "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

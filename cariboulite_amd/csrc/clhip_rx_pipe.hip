@@ -27,6 +27,8 @@
 
 #include "clhip_common.h"
 
+typedef __attribute__((address_space(4))) float cfloat_t;   // constant address space (scalar-loadable)
+
 #define MODE_IQ 0
 #define MODE_FM 1
 
@@ -58,8 +60,9 @@ struct PipeArgs {
     int32_t *bad_flag;           // set to 1 when a needed chunk has offs != 0 (tile writes nothing)
 };
 
-template <int T_, int L_, int M_, int KP_, int MODE_, int R_, int NT_>
+template <int T_, int L_, int M_, int KP_, int MODE_, int R_, int NT_, bool PK_ = true>
 struct PipeCfg {
+    static constexpr bool PK = PK_;
     static constexpr int T = T_, L = L_, M = M_, KP = KP_, MODE = MODE_, R = R_, NT = NT_;
     static constexpr bool RESAMP = !(L == 1 && M == 1);
     static constexpr int HF = MODE == MODE_FM ? 1 : (RESAMP ? KP - 1 : 0);   // FIR outputs of history
@@ -71,10 +74,9 @@ struct PipeCfg {
     static constexpr int NOUT = MODE == MODE_FM ? R : R * L / M;             // outputs per lane
     static constexpr int SKIP0 = MODE == MODE_FM ? HFA : HFA * L / M;        // lane 0's history-only outputs
     static constexpr int TSTRIDE = (R * 8 + 16);    // bytes between lanes' windows in LDS
-    static constexpr int IN_BYTES = NLOAD * 8 + (NLOAD / R + 1) * 16;
-    static constexpr int TAIL_STRIDE = 80;          // 8 float2 + 16 B pad: conflict-free b128
-    static constexpr int TAIL_BYTES = HF ? NT * TAIL_STRIDE : 0;
-    static constexpr int LDS_BYTES = IN_BYTES > TAIL_BYTES ? IN_BYTES : TAIL_BYTES;
+    static constexpr int IN_BYTES = (NLOAD * 8 + (NLOAD / R + 1) * 16 + 63) / 64 * 64;
+    static constexpr int TAIL_BYTES = (NT / 64) * 8 * 8;   // one 8-sample tail slot per wave
+    static constexpr int LDS_BYTES = IN_BYTES + TAIL_BYTES;
     static_assert(T % 4 == 0 && R % 4 == 0, "T and R must be multiples of 4");
     static_assert((R * L) % M == 0 && (HFA * L) % M == 0, "lane outputs must be integral");
     static_assert(HF <= 8 && HF <= R, "history too long for the tail exchange");
@@ -101,6 +103,17 @@ __device__ __forceinline__ f32x2 load_sample(const PipeArgs &a, const void *base
         return r;
     } else {
         return ((const f32x2 *)base)[g];
+    }
+}
+
+// acc += x * tap on an (I,Q) pair: one v_pk_fma_f32 (PK) or two v_fmac_f32.
+template <bool PK>
+__device__ __forceinline__ void fma2(f32x2 &acc, const f32x2 x, const float tap)
+{
+    if constexpr (PK) acc += x * tap;
+    else {
+        acc.x = __builtin_fmaf(x.x, tap, acc.x);
+        acc.y = __builtin_fmaf(x.y, tap, acc.y);
     }
 }
 
@@ -243,7 +256,9 @@ __global__ __launch_bounds__(C::NT) void rx_pipe_fused_kernel(const PipeArgs a)
 #pragma unroll
     for (int r = 0; r < R; r++) { acc[r].x = 0.f; acc[r].y = 0.f; }
     const unsigned char *win = lds + t * C::TSTRIDE;
-    const float *__restrict__ h = a.fir;
+    // taps are read-only for the whole launch: the constant address space makes every uniform tap
+    // load a scalar (SMEM) load into SGPRs, never a vector load into VGPRs
+    const cfloat_t *__restrict__ h = (const cfloat_t *)a.fir;
     f32x2 x[R];
 #define LOAD_BLOCK(B)                                                              \
     _Pragma("unroll") for (int j = 0; j < R; j += 2) {                             \
@@ -258,19 +273,19 @@ __global__ __launch_bounds__(C::NT) void rx_pipe_fused_kernel(const PipeArgs a)
 #pragma unroll
         for (int j = 1; j < R; j++)
 #pragma unroll
-            for (int r = 0; r < j; r++) acc[r] += x[j] * tp[j - r];
+            for (int r = 0; r < j; r++) fma2<C::PK>(acc[r], x[j], tp[j - r]);
     }
 #pragma unroll 1
     for (int b = 1; b < T / R; b++) {
         LOAD_BLOCK(b)
-        const float *__restrict__ hb = h + (T - R * b);          // k = hb index (r - j) in [-(R-1), R-1]
+        const cfloat_t *__restrict__ hb = h + (T - R * b);          // k = hb index (r - j) in [-(R-1), R-1]
         float tp[2 * R - 1];
 #pragma unroll
         for (int i = 0; i < 2 * R - 1; i++) tp[i] = hb[i - (R - 1)];
 #pragma unroll
         for (int j = 0; j < R; j++)
 #pragma unroll
-            for (int r = 0; r < R; r++) acc[r] += x[j] * tp[(R - 1) + r - j];
+            for (int r = 0; r < R; r++) fma2<C::PK>(acc[r], x[j], tp[(R - 1) + r - j]);
     }
     {   // last block: k = r - j >= 0
         LOAD_BLOCK(T / R)
@@ -280,85 +295,119 @@ __global__ __launch_bounds__(C::NT) void rx_pipe_fused_kernel(const PipeArgs a)
 #pragma unroll
         for (int j = 0; j < R; j++)
 #pragma unroll
-            for (int r = j; r < R; r++) acc[r] += x[j] * tp[r - j];
+            for (int r = j; r < R; r++) fma2<C::PK>(acc[r], x[j], tp[r - j]);
     }
 #undef LOAD_BLOCK
 
     // ---------------- second stage ----------------
-    // yy[i], i = -HF..R-1: FIR outputs R*t + i of the tile
+    // yy[i], i = -HF..R-1: FIR outputs R*t + i of the tile.  The HF outputs before a lane's own
+    // come from the previous lane: a one-lane shuffle inside the wave, an LDS slot across waves.
+    const int lane = t & 63, wave = t >> 6;
     f32x2 yh[HF > 0 ? HF : 1];
     if constexpr (HF > 0) {
-        __syncthreads();                       // every wave is done with the staged inputs
-        unsigned char *tl = lds + t * C::TAIL_STRIDE;
+        f32x2 *tslot = (f32x2 *)(lds + C::IN_BYTES);        // [waves][8], past the input tile
+        if (lane == 63) {
 #pragma unroll
-        for (int i = 0; i < HF; i++) *(f32x2 *)(tl + 8 * i) = acc[R - HF + i];
-        __syncthreads();
-        const unsigned char *pl = lds + (t > 0 ? t - 1 : 0) * C::TAIL_STRIDE;
+            for (int i = 0; i < HF; i++) tslot[wave * 8 + i] = acc[R - HF + i];
+        }
+    }
+    __syncthreads();       // FIR reads of the staged tile are done (its LDS is reused below); tail slots visible
+    if constexpr (HF > 0) {
+        const f32x2 *tslot = (const f32x2 *)(lds + C::IN_BYTES);
 #pragma unroll
-        for (int i = 0; i < HF; i++) yh[i] = *(const f32x2 *)(pl + 8 * i);
+        for (int i = 0; i < HF; i++) {
+            const f32x2 v = acc[R - HF + i];
+            yh[i].x = __shfl_up(v.x, 1, 64);
+            yh[i].y = __shfl_up(v.y, 1, 64);
+            if (lane == 0) yh[i] = tslot[(wave > 0 ? wave - 1 : 0) * 8 + i];   // wave 0 / lane 0: history-only outputs
+        }
     }
 #define YY(i) ((i) < 0 ? yh[HF + (i)] : acc[(i)])
 
-    const long fir0 = S - C::HFA + (long)R * t;          // global index of acc[0]
+    // Per-lane results: NOUT elements of OB bytes, contiguous in the output stream.
+    constexpr int NOUT = C::NOUT;
+    constexpr int OB = C::MODE == MODE_FM ? 4 : 8;
+    constexpr int LB = NOUT * OB;             // bytes per lane (multiple of 16)
+    constexpr int PL = LB / 16;               // 16-byte pieces per lane
+    f32x4 pc[PL];
     if constexpr (C::MODE == MODE_IQ) {
-        constexpr int NOUT = C::NOUT;
         f32x2 o[NOUT];
         if constexpr (C::RESAMP) {
             float rsv[KP * L];
 #pragma unroll
-            for (int i = 0; i < KP * L; i++) rsv[i] = a.rs[i];
+            for (int i = 0; i < KP * L; i++) rsv[i] = ((const cfloat_t *)a.rs)[i];
 #pragma unroll
             for (int m = 0; m < NOUT; m++) {
                 const int tp = m * M, b = tp / L, p = tp % L;
                 f32x2 sacc = {0.f, 0.f};
 #pragma unroll
-                for (int i = 0; i < KP; i++) sacc += YY(b - i) * rsv[p + i * L];
+                for (int i = 0; i < KP; i++) fma2<C::PK>(sacc, YY(b - i), rsv[p + i * L]);
                 o[m] = sacc;
             }
         } else {
 #pragma unroll
             for (int m = 0; m < NOUT; m++) o[m] = acc[m];
         }
-        // global output index of o[0]; lane 0 of every tile starts with SKIP0 history-only outputs
-        const long o0 = (S - C::HFA) / M * L + (long)NOUT * t;   // (S-HFA)*L/M, exact
-        const long lo = S / M * L, hi = a.n_out;
-        f32x2 *out = (f32x2 *)a.out + (long)s * a.out_stride;
 #pragma unroll
-        for (int m = 0; m < NOUT; m += 2) {
-            const long gi = o0 + m;
-            if (gi >= lo && gi + 2 <= hi) {
-                f32x4 v = {o[m].x, o[m].y, o[m + 1].x, o[m + 1].y};
-                *(f32x4 *)(out + gi) = v;
-            } else {
-                if (gi >= lo && gi < hi) out[gi] = o[m];
-                if (gi + 1 >= lo && gi + 1 < hi) out[gi + 1] = o[m + 1];
-            }
-        }
+        for (int k = 0; k < PL; k++) { pc[k].x = o[2 * k].x; pc[k].y = o[2 * k].y; pc[k].z = o[2 * k + 1].x; pc[k].w = o[2 * k + 1].y; }
     } else {
         // FM phase-difference demod: atan2(Im z, Re z), z = y[n] conj(y[n-1])
         float o[R];
 #pragma unroll
         for (int i = 0; i < R; i++) {
             const f32x2 c = YY(i), p = YY(i - 1);
-            const float re = c.x * p.x + c.y * p.y, im = c.y * p.x - c.x * p.y;
-            o[i] = atan2f(im, re);
+            o[i] = atan2f(c.y * p.x - c.x * p.y, c.x * p.x + c.y * p.y);
         }
-        const long lo = S, hi = a.n_out;
-        float *out = (float *)a.out + (long)s * a.out_stride;
 #pragma unroll
-        for (int m = 0; m < R; m += 4) {
-            const long gi = fir0 + m;
-            if (gi >= lo && gi + 4 <= hi) {
-                f32x4 v = {o[m], o[m + 1], o[m + 2], o[m + 3]};
-                *(f32x4 *)(out + gi) = v;
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if (gi + k >= lo && gi + k < hi) out[gi + k] = o[m + k];
-            }
-        }
+        for (int k = 0; k < PL; k++) { pc[k].x = o[4 * k]; pc[k].y = o[4 * k + 1]; pc[k].z = o[4 * k + 2]; pc[k].w = o[4 * k + 3]; }
     }
 #undef YY
+
+    // ---------------- coalesced store ----------------
+    // A lane's LB output bytes are contiguous but lane-strided stores would hand the memory system
+    // 64 separate 16-byte pieces per instruction.  Each wave therefore transposes through its own
+    // slice of the (now dead) input tile, half a wave at a time: 32 lanes write their pieces
+    // (LB+16 B pitch: conflict-free), then all 64 lanes read consecutive pieces and store
+    // 1 KiB-contiguous runs.  Wave-private LDS, in-order DS pipe: no workgroup barrier.
+    constexpr int EPP = 16 / OB;                         // elements per piece
+    constexpr int PITCH = LB + 16;
+    constexpr int HALF_PIECES = 32 * PL;                 // pieces per half wave
+    static_assert(32 * PITCH * (NT / 64) <= C::IN_BYTES, "per-wave transpose slices must fit the input tile");
+    unsigned char *scr = lds + wave * (32 * PITCH);
+    // element index (in the stream's output space) of this tile's first FIR position, scaled by L/M
+    const long tile_e0 = C::MODE == MODE_FM ? (S - C::HFA) : (S - C::HFA) / M * L;
+    const long lo = C::MODE == MODE_FM ? S : S / M * L, hi = a.n_out;
+    unsigned char *outb = (unsigned char *)a.out + (long)s * a.out_stride * OB;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        if ((lane >> 5) == h) {
+            unsigned char *w = scr + (lane & 31) * PITCH;
+#pragma unroll
+            for (int k = 0; k < PL; k++) *(f32x4 *)(w + 16 * k) = pc[k];
+        }
+        __builtin_amdgcn_wave_barrier();
+        const long half_e0 = tile_e0 + (long)NOUT * (wave * 64 + h * 32);      // first element of this half wave
+#pragma unroll
+        for (int j = 0; j < (HALF_PIECES + 63) / 64; j++) {
+            const int p = lane + 64 * j;
+            if (HALF_PIECES % 64 == 0 || p < HALF_PIECES) {
+                const f32x4 v = *(const f32x4 *)(scr + (p / PL) * PITCH + (p % PL) * 16);
+                const long e = half_e0 + (long)p * EPP;
+                if (e >= lo && e + EPP <= hi) {
+                    *(f32x4 *)(outb + e * OB) = v;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < EPP; k++) {
+                        if (e + k >= lo && e + k < hi) {
+                            if constexpr (OB == 8) { f32x2 q = {v[2 * k], v[2 * k + 1]}; *(f32x2 *)(outb + (e + k) * OB) = q; }
+                            else *(float *)(outb + (e + k) * OB) = v[k];
+                        }
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -466,6 +515,7 @@ __global__ __launch_bounds__(256) void gen_copy_kernel(const f32x2 *__restrict__
 typedef PipeCfg<64, 3, 2, 8, MODE_IQ, 16, 256> CfgC2;     // config 2: FIR64 + 3/2
 typedef PipeCfg<64, 3, 2, 8, MODE_IQ, 16, 128> CfgC2b;    // experiment: 2 waves per workgroup
 typedef PipeCfg<64, 3, 2, 8, MODE_IQ, 16, 64> CfgC2c;     // experiment: 1 wave per workgroup
+typedef PipeCfg<64, 3, 2, 8, MODE_IQ, 16, 256, false> CfgC2d;   // experiment: scalar v_fmac_f32
 typedef PipeCfg<64, 1, 1, 1, MODE_FM, 16, 256> CfgC3;     // config 3: FIR64 + FM demod
 typedef PipeCfg<128, 5, 4, 8, MODE_IQ, 16, 256> CfgC4;    // config 4: FIR128 + 5/4
 typedef PipeCfg<64, 1, 1, 1, MODE_IQ, 16, 256> CfgF64;    // FIR64 only
@@ -654,6 +704,7 @@ extern "C" long clhip_rx_pipe_run(clhip_rx_pipe *p, int in_kind, const void *d_i
             static int variant = getenv("CLHIP_C2_VARIANT") ? atoi(getenv("CLHIP_C2_VARIANT")) : 0;
             if (variant == 1) rc = launch_fused<CfgC2b>(a, p->n_streams, s);
             else if (variant == 2) rc = launch_fused<CfgC2c>(a, p->n_streams, s);
+            else if (variant == 3) rc = launch_fused<CfgC2d>(a, p->n_streams, s);
             else rc = launch_fused<CfgC2>(a, p->n_streams, s);
             break;
         }
