@@ -48,6 +48,8 @@ struct PipeArgs {
     long n_in;               // new input samples per stream
     long n_out;              // outputs per stream for this call
     int in_kind;             // CL_PIPE_IN_*
+    int n_streams;
+    int n_int;               // tiles 1 .. n_int-1 of every stream are interior (no bounds checks)
     int channel;             // CL_CHANNEL_*
     float in_scale;          // 4096 for integer inputs (taps carry 1/4096), 1 for CF32
     const float *fir;        // T taps, pre-multiplied by 1/in_scale (device, read-only)
@@ -55,7 +57,7 @@ struct PipeArgs {
     // optional device-side sync validation of raw-word input: the fused path is
     // only valid for chunks whose sync offset is 0 (caribou_smi.c:235-292)
     const int32_t *chunk_offs;   // [n_streams][chunks_per_stream] from clhip_smi_find_offsets, or NULL
-    long chunk_samples;          // samples per chunk
+    int chunk_shift;             // log2(samples per chunk): chunks are a power of two (native = 2^17)
     long chunks_per_stream;
     int32_t *bad_flag;           // set to 1 when a needed chunk has offs != 0 (tile writes nothing)
 };
@@ -117,15 +119,17 @@ __device__ __forceinline__ void fma2(f32x2 &acc, const f32x2 x, const float tap)
     }
 }
 
-template <int KIND>
-__device__ __forceinline__ void convert4(const PipeArgs &a, const u32x4 w, f32x2 (&v)[4])
+// One 16-byte group = 4 samples.  KIND and the channel type are compile-time here so that the
+// per-sample cost is exactly v_bfe_i32 x2 + v_cvt_f32_i32 x2 (no per-sample selects).
+template <int KIND, bool HIF>
+__device__ __forceinline__ void convert4(const u32x4 w, f32x2 (&v)[4])
 {
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         if constexpr (KIND == CL_PIPE_IN_SMI_WORDS) {
             const int fa = clhip_field_a(w[k]), fb = clhip_field_b(w[k]);
-            v[k].x = (float)(a.channel == CL_CHANNEL_HIF ? fb : fa);
-            v[k].y = (float)(a.channel == CL_CHANNEL_HIF ? fa : fb);
+            v[k].x = (float)(HIF ? fb : fa);        // caribou_smi.c:342-378
+            v[k].y = (float)(HIF ? fa : fb);
         } else {
             v[k].x = (float)(int16_t)(w[k] & 0xFFFF);
             v[k].y = (float)(int16_t)(w[k] >> 16);
@@ -142,58 +146,63 @@ __device__ __forceinline__ void lds_put4(unsigned char *lds, int j, const f32x2 
     *(f32x4 *)(d + 16) = q1;
 }
 
-// Stage samples [S - HALO, S - HALO + NLOAD) of one stream into LDS, unpacked
-// to (I,Q) floats in the LDS domain.  Interior tiles issue all their 16-byte
-// loads before the first conversion; edge tiles (stream start: history;
-// stream end: zero fill) take the checked path.
+// Register image of one interior tile's raw input: IT 16-byte groups per lane
+// (integer kinds) or 2*IT (CF32).  Loads are issued here and consumed one tile
+// later, so HBM latency hides under the previous tile's FIR.
 template <class C, int KIND>
-__device__ __forceinline__ void stage_tile(const PipeArgs &a, const void *in, const f32x2 *hist, long S,
-                                           unsigned char *lds, int t)
+struct TileRegs {
+    static constexpr int NG = C::NLOAD / 4;
+    static constexpr int IT = (NG + C::NT - 1) / C::NT;
+    static constexpr int NV = KIND == CL_PIPE_IN_CF32 ? 2 * IT : IT;
+    u32x4 w[NV];
+};
+
+template <class C, int KIND>
+__device__ __forceinline__ void tile_issue_loads(TileRegs<C, KIND> &r, const void *in, long g0, int t)
 {
-    constexpr int R = C::R, NT = C::NT;
-    constexpr int NG = C::NLOAD / 4;                 // groups of 4 samples
-    constexpr int IT = (NG + NT - 1) / NT;
-    const long g0 = S - C::HALO;
-    if (g0 >= 0 && g0 + C::NLOAD <= a.n_in) {        // wave-uniform
-        if constexpr (KIND == CL_PIPE_IN_CF32) {
-            f32x4 p0[IT], p1[IT];
+    constexpr int NG = TileRegs<C, KIND>::NG, IT = TileRegs<C, KIND>::IT;
 #pragma unroll
-            for (int it = 0; it < IT; it++) {
-                const int grp = t + it * NT;
-                if (grp < NG) {
-                    p0[it] = *(const f32x4 *)((const f32x2 *)in + g0 + 4 * grp);
-                    p1[it] = *(const f32x4 *)((const f32x2 *)in + g0 + 4 * grp + 2);
-                }
-            }
-#pragma unroll
-            for (int it = 0; it < IT; it++) {
-                const int grp = t + it * NT;
-                if (grp < NG) {
-                    unsigned char *d = lds + lds_off<R>(4 * grp);
-                    *(f32x4 *)d = p0[it];
-                    *(f32x4 *)(d + 16) = p1[it];
-                }
-            }
-        } else {
-            u32x4 w[IT];
-#pragma unroll
-            for (int it = 0; it < IT; it++) {
-                const int grp = t + it * NT;
-                if (grp < NG) w[it] = __builtin_nontemporal_load((const u32x4 *)((const uint32_t *)in + g0 + 4 * grp));
-            }
-#pragma unroll
-            for (int it = 0; it < IT; it++) {
-                const int grp = t + it * NT;
-                if (grp < NG) {
-                    f32x2 v[4];
-                    convert4<KIND>(a, w[it], v);
-                    lds_put4<R>(lds, 4 * grp, v);
-                }
+    for (int it = 0; it < IT; it++) {
+        const int grp = t + it * C::NT;
+        if (NG % C::NT == 0 || it < IT - 1 || grp < NG) {
+            if constexpr (KIND == CL_PIPE_IN_CF32) {
+                r.w[2 * it] = *(const u32x4 *)((const f32x2 *)in + g0 + 4 * grp);
+                r.w[2 * it + 1] = *(const u32x4 *)((const f32x2 *)in + g0 + 4 * grp + 2);
+            } else {
+                r.w[it] = __builtin_nontemporal_load((const u32x4 *)((const uint32_t *)in + g0 + 4 * grp));
             }
         }
-        return;
     }
-    for (int j = t * 4; j < C::NLOAD; j += NT * 4) {
+}
+
+template <class C, int KIND, bool HIF>
+__device__ __forceinline__ void tile_regs_to_lds(const TileRegs<C, KIND> &r, unsigned char *lds, int t)
+{
+    constexpr int NG = TileRegs<C, KIND>::NG, IT = TileRegs<C, KIND>::IT;
+#pragma unroll
+    for (int it = 0; it < IT; it++) {
+        const int grp = t + it * C::NT;
+        if (NG % C::NT == 0 || it < IT - 1 || grp < NG) {
+            if constexpr (KIND == CL_PIPE_IN_CF32) {
+                unsigned char *d = lds + lds_off<C::R>(4 * grp);
+                *(u32x4 *)d = r.w[2 * it];
+                *(u32x4 *)(d + 16) = r.w[2 * it + 1];
+            } else {
+                f32x2 v[4];
+                convert4<KIND, HIF>(r.w[it], v);
+                lds_put4<C::R>(lds, 4 * grp, v);
+            }
+        }
+    }
+}
+
+// Edge tiles (stream start: history; stream end: zero fill): checked, un-prefetched path.
+template <class C>
+__device__ __forceinline__ void stage_tile_slow(const PipeArgs &a, const void *in, const f32x2 *hist, long S,
+                                             unsigned char *lds, int t)
+{
+    const long g0 = S - C::HALO;
+    for (int j = t * 4; j < C::NLOAD; j += C::NT * 4) {
         const long g = g0 + j;
         f32x2 v[4];
         if (g < 0) {                       // HALO % 4 == 0: the whole group is history
@@ -206,59 +215,30 @@ __device__ __forceinline__ void stage_tile(const PipeArgs &a, const void *in, co
                 v[k] = (g + k < a.n_in) ? load_sample(a, in, g + k) : z;
             }
         }
-        lds_put4<R>(lds, j, v);
+        lds_put4<C::R>(lds, j, v);
     }
 }
 
+// ---------------------------------------------------------------------------
+// compute phases shared by the interior (persistent) and edge kernels
+// ---------------------------------------------------------------------------
+
+// FIR: R outputs per lane from a sliding window.  Lane window w = 0..T+R-1 is staged sample
+// R*t + w; output r (FIR index R*t + r of the tile) uses tap k = T + r - w of window sample w.
+// The window is walked in blocks of R samples: block b pairs sample j of the block with tap
+// (T - R*b) + (r - j), so each block needs 2R-1 consecutive taps (scalar loads -> SGPRs) and R
+// samples (one ds_read_b128 per pair).  Every accumulator sees its taps in descending k order.
 template <class C>
-__global__ __launch_bounds__(C::NT) void rx_pipe_fused_kernel(const PipeArgs a)
+__device__ __forceinline__ void fir_tile(const unsigned char *lds, int t, const float *fir, f32x2 (&acc)[C::R])
 {
-    constexpr int T = C::T, R = C::R, NT = C::NT, L = C::L, M = C::M, KP = C::KP, HF = C::HF;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-
-    const int t = threadIdx.x;
-    const int s = blockIdx.y;
-    const long S = (long)blockIdx.x * C::TILE_IN;           // first new input of this tile
-    const void *in = a.in_kind == CL_PIPE_IN_CF32
-                         ? (const void *)((const f32x2 *)a.in + (long)s * a.in_stride)
-                         : (const void *)((const uint32_t *)a.in + (long)s * a.in_stride);
-    const f32x2 *hist = a.hist_in + (long)s * C::HALO;
-
-    if (a.chunk_offs) {                    // wave-uniform: validate the chunks this tile reads
-        const long first = S - C::HALO > 0 ? S - C::HALO : 0;
-        const long last = (S + C::TILE_IN < a.n_in ? S + C::TILE_IN : a.n_in) - 1;
-        int bad = 0;
-        for (long c = first / a.chunk_samples; c <= last / a.chunk_samples; c++)
-            bad |= a.chunk_offs[(long)s * a.chunks_per_stream + c] != 0;
-        if (bad) {
-            if (t == 0) atomicOr(a.bad_flag, 1);
-            return;
-        }
-    }
-
-    // ---------------- stage [S - HALO, S - HALO + NLOAD) into LDS ----------------
-    switch (a.in_kind) {                   // wave-uniform
-    case CL_PIPE_IN_SMI_WORDS: stage_tile<C, CL_PIPE_IN_SMI_WORDS>(a, in, hist, S, lds, t); break;
-    case CL_PIPE_IN_CS16: stage_tile<C, CL_PIPE_IN_CS16>(a, in, hist, S, lds, t); break;
-    default: stage_tile<C, CL_PIPE_IN_CF32>(a, in, hist, S, lds, t); break;
-    }
-    __syncthreads();
-
-    // ---------------- FIR: R outputs per lane from a sliding window ----------------
-    // lane window w = 0..T+R-1 is staged sample R*t + w; output r (FIR index
-    // R*t + r of the tile) uses tap k = T + r - w of window sample w.  The
-    // window is walked in blocks of R samples: block b pairs sample j of the
-    // block with tap (T - R*b) + (r - j), so each block needs 2R-1 consecutive
-    // taps (scalar loads -> SGPRs) and R samples (one ds_read_b128 per pair).
-    // Every accumulator sees its taps in descending k order.
+    constexpr int T = C::T, R = C::R;
     static_assert(T % R == 0, "window is walked in blocks of R samples");
-    f32x2 acc[R];
 #pragma unroll
     for (int r = 0; r < R; r++) { acc[r].x = 0.f; acc[r].y = 0.f; }
     const unsigned char *win = lds + t * C::TSTRIDE;
     // taps are read-only for the whole launch: the constant address space makes every uniform tap
     // load a scalar (SMEM) load into SGPRs, never a vector load into VGPRs
-    const cfloat_t *__restrict__ h = (const cfloat_t *)a.fir;
+    const cfloat_t *__restrict__ h = (const cfloat_t *)fir;
     f32x2 x[R];
 #define LOAD_BLOCK(B)                                                              \
     _Pragma("unroll") for (int j = 0; j < R; j += 2) {                             \
@@ -298,10 +278,18 @@ __global__ __launch_bounds__(C::NT) void rx_pipe_fused_kernel(const PipeArgs a)
             for (int r = j; r < R; r++) fma2<C::PK>(acc[r], x[j], tp[r - j]);
     }
 #undef LOAD_BLOCK
+}
 
-    // ---------------- second stage ----------------
-    // yy[i], i = -HF..R-1: FIR outputs R*t + i of the tile.  The HF outputs before a lane's own
-    // come from the previous lane: a one-lane shuffle inside the wave, an LDS slot across waves.
+// Second stage: polyphase resampler / FM demod / pass-through from registers.  The HF FIR
+// outputs before a lane's own come from the previous lane: a one-lane shuffle inside the wave,
+// an LDS slot across waves.  Contains the workgroup barrier that retires the staged input tile.
+// Result: the lane's NOUT output elements as PL 16-byte pieces.
+template <class C>
+__device__ __forceinline__ void second_stage(unsigned char *lds, int t, const float *rs, f32x2 (&acc)[C::R],
+                                             f32x4 (&pc)[C::NOUT * (C::MODE == MODE_FM ? 4 : 8) / 16])
+{
+    constexpr int R = C::R, L = C::L, M = C::M, KP = C::KP, HF = C::HF, NOUT = C::NOUT;
+    constexpr int PL = NOUT * (C::MODE == MODE_FM ? 4 : 8) / 16;
     const int lane = t & 63, wave = t >> 6;
     f32x2 yh[HF > 0 ? HF : 1];
     if constexpr (HF > 0) {
@@ -323,19 +311,12 @@ __global__ __launch_bounds__(C::NT) void rx_pipe_fused_kernel(const PipeArgs a)
         }
     }
 #define YY(i) ((i) < 0 ? yh[HF + (i)] : acc[(i)])
-
-    // Per-lane results: NOUT elements of OB bytes, contiguous in the output stream.
-    constexpr int NOUT = C::NOUT;
-    constexpr int OB = C::MODE == MODE_FM ? 4 : 8;
-    constexpr int LB = NOUT * OB;             // bytes per lane (multiple of 16)
-    constexpr int PL = LB / 16;               // 16-byte pieces per lane
-    f32x4 pc[PL];
     if constexpr (C::MODE == MODE_IQ) {
         f32x2 o[NOUT];
         if constexpr (C::RESAMP) {
             float rsv[KP * L];
 #pragma unroll
-            for (int i = 0; i < KP * L; i++) rsv[i] = ((const cfloat_t *)a.rs)[i];
+            for (int i = 0; i < KP * L; i++) rsv[i] = ((const cfloat_t *)rs)[i];
 #pragma unroll
             for (int m = 0; m < NOUT; m++) {
                 const int tp = m * M, b = tp / L, p = tp % L;
@@ -362,22 +343,26 @@ __global__ __launch_bounds__(C::NT) void rx_pipe_fused_kernel(const PipeArgs a)
         for (int k = 0; k < PL; k++) { pc[k].x = o[4 * k]; pc[k].y = o[4 * k + 1]; pc[k].z = o[4 * k + 2]; pc[k].w = o[4 * k + 3]; }
     }
 #undef YY
+}
 
-    // ---------------- coalesced store ----------------
-    // A lane's LB output bytes are contiguous but lane-strided stores would hand the memory system
-    // 64 separate 16-byte pieces per instruction.  Each wave therefore transposes through its own
-    // slice of the (now dead) input tile, half a wave at a time: 32 lanes write their pieces
-    // (LB+16 B pitch: conflict-free), then all 64 lanes read consecutive pieces and store
-    // 1 KiB-contiguous runs.  Wave-private LDS, in-order DS pipe: no workgroup barrier.
+// Coalesced store.  A lane's LB output bytes are contiguous but lane-strided stores would hand
+// the memory system 64 separate 16-byte pieces per instruction.  Each wave therefore transposes
+// through its own slice of the (now dead) input tile, half a wave at a time: 32 lanes write
+// their pieces (LB+16 B pitch: conflict-free), then all 64 lanes read consecutive pieces and
+// store 1 KiB-contiguous runs.  Wave-private LDS, in-order DS pipe: no workgroup barrier.
+// CHECKED = per-element bounds [lo, hi) (edge tiles); interior tiles only mask the history-only
+// outputs of the tile's first lane (e < lo).
+template <class C, bool CHECKED>
+__device__ __forceinline__ void store_tile(unsigned char *lds, int t, unsigned char *outb, long tile_e0, long lo, long hi,
+                                           const f32x4 (&pc)[C::NOUT * (C::MODE == MODE_FM ? 4 : 8) / 16])
+{
+    constexpr int NOUT = C::NOUT, OB = C::MODE == MODE_FM ? 4 : 8, LB = NOUT * OB, PL = LB / 16;
     constexpr int EPP = 16 / OB;                         // elements per piece
     constexpr int PITCH = LB + 16;
     constexpr int HALF_PIECES = 32 * PL;                 // pieces per half wave
-    static_assert(32 * PITCH * (NT / 64) <= C::IN_BYTES, "per-wave transpose slices must fit the input tile");
+    static_assert(32 * PITCH * (C::NT / 64) <= C::IN_BYTES, "per-wave transpose slices must fit the input tile");
+    const int lane = t & 63, wave = t >> 6;
     unsigned char *scr = lds + wave * (32 * PITCH);
-    // element index (in the stream's output space) of this tile's first FIR position, scaled by L/M
-    const long tile_e0 = C::MODE == MODE_FM ? (S - C::HFA) : (S - C::HFA) / M * L;
-    const long lo = C::MODE == MODE_FM ? S : S / M * L, hi = a.n_out;
-    unsigned char *outb = (unsigned char *)a.out + (long)s * a.out_stride * OB;
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         if ((lane >> 5) == h) {
@@ -387,20 +372,23 @@ __global__ __launch_bounds__(C::NT) void rx_pipe_fused_kernel(const PipeArgs a)
         }
         __builtin_amdgcn_wave_barrier();
         const long half_e0 = tile_e0 + (long)NOUT * (wave * 64 + h * 32);      // first element of this half wave
+        unsigned char *hb = outb + half_e0 * OB;
 #pragma unroll
         for (int j = 0; j < (HALF_PIECES + 63) / 64; j++) {
             const int p = lane + 64 * j;
             if (HALF_PIECES % 64 == 0 || p < HALF_PIECES) {
                 const f32x4 v = *(const f32x4 *)(scr + (p / PL) * PITCH + (p % PL) * 16);
                 const long e = half_e0 + (long)p * EPP;
-                if (e >= lo && e + EPP <= hi) {
-                    *(f32x4 *)(outb + e * OB) = v;
+                if constexpr (!CHECKED) {
+                    if ((wave | h) != 0 || e >= lo) *(f32x4 *)(hb + p * 16) = v;    // wave-uniform short-circuit
+                } else if (e >= lo && e + EPP <= hi) {
+                    *(f32x4 *)(hb + p * 16) = v;
                 } else {
 #pragma unroll
                     for (int k = 0; k < EPP; k++) {
                         if (e + k >= lo && e + k < hi) {
-                            if constexpr (OB == 8) { f32x2 q = {v[2 * k], v[2 * k + 1]}; *(f32x2 *)(outb + (e + k) * OB) = q; }
-                            else *(float *)(outb + (e + k) * OB) = v[k];
+                            if constexpr (OB == 8) { f32x2 q = {v[2 * k], v[2 * k + 1]}; *(f32x2 *)(hb + p * 16 + k * OB) = q; }
+                            else *(float *)(hb + p * 16 + k * OB) = v[k];
                         }
                     }
                 }
@@ -408,6 +396,102 @@ __global__ __launch_bounds__(C::NT) void rx_pipe_fused_kernel(const PipeArgs a)
         }
         __builtin_amdgcn_wave_barrier();
     }
+}
+
+// wave-uniform: do the chunks this tile reads all have sync offset 0?  (device-side validation)
+template <class C>
+__device__ __forceinline__ bool tile_sync_bad(const PipeArgs &a, int s, long S)
+{
+    bool bad = false;
+    if (a.chunk_offs) {
+        const long first = S - C::HALO > 0 ? S - C::HALO : 0;
+        const long last = (S + C::TILE_IN < a.n_in ? S + C::TILE_IN : a.n_in) - 1;
+        const int32_t *o = a.chunk_offs + (long)s * a.chunks_per_stream;
+        for (int c = (int)(first >> a.chunk_shift); c <= (int)(last >> a.chunk_shift); c++) bad |= o[c] != 0;
+        if (bad && threadIdx.x == 0) atomicOr(a.bad_flag, 1);          // the tile writes nothing
+    }
+    return bad;
+}
+
+// ---------------------------------------------------------------------------
+// interior kernel: persistent workgroups over the tiles that lie fully inside a stream
+// (tile index 1 .. n_int-1).  No bounds checks; the raw words of the NEXT item are loaded
+// into registers while the current one computes, so HBM latency hides under the FIR.
+// One kernel per (config, input kind, channel type): each gets its own register allocation.
+// ---------------------------------------------------------------------------
+template <class C, int KIND, bool HIF>
+__global__ __launch_bounds__(C::NT) void rx_pipe_fused_kernel(const PipeArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int OB = C::MODE == MODE_FM ? 4 : 8, PL = C::NOUT * OB / 16;
+    const int per_stream = a.n_int - 1;                      // interior tiles per stream: 1 .. n_int-1
+    const int items = per_stream * a.n_streams;
+    const int step = gridDim.x;
+
+    TileRegs<C, KIND> regs;
+    int item = blockIdx.x;
+    if (item < items) {
+        const int s0 = item / per_stream, tile0 = 1 + item % per_stream;
+        const void *in0 = KIND == CL_PIPE_IN_CF32 ? (const void *)((const f32x2 *)a.in + (long)s0 * a.in_stride)
+                                                 : (const void *)((const uint32_t *)a.in + (long)s0 * a.in_stride);
+        tile_issue_loads<C, KIND>(regs, in0, (long)tile0 * C::TILE_IN - C::HALO, threadIdx.x);
+    }
+    for (; item < items; item += step) {
+        // Keep per-iteration values per-iteration: without these the compiler hoists every tap load
+        // (88 SGPRs -> spilled to VGPR lanes) and every lane address computation (50+ VGPRs) out of
+        // the persistent loop, which costs two waves of occupancy.
+        int t = threadIdx.x;
+        const float *fir = a.fir, *rs = a.rs;
+        asm volatile("" : "+v"(t));
+        asm volatile("" : "+s"(fir), "+s"(rs));
+        const int s = item / per_stream, tile = 1 + item % per_stream;
+        const long S = (long)tile * C::TILE_IN;              // first new input of this tile
+        const bool bad = tile_sync_bad<C>(a, s, S);
+
+        tile_regs_to_lds<C, KIND, HIF>(regs, lds, t);
+        __syncthreads();
+        if (item + step < items) {                           // prefetch the next item's raw words
+            const int nx = item + step, sn = nx / per_stream, tn = 1 + nx % per_stream;
+            const void *inn = KIND == CL_PIPE_IN_CF32 ? (const void *)((const f32x2 *)a.in + (long)sn * a.in_stride)
+                                                     : (const void *)((const uint32_t *)a.in + (long)sn * a.in_stride);
+            tile_issue_loads<C, KIND>(regs, inn, (long)tn * C::TILE_IN - C::HALO, t);
+        }
+        f32x2 acc[C::R];
+        f32x4 pc[PL];
+        fir_tile<C>(lds, t, fir, acc);
+        second_stage<C>(lds, t, rs, acc, pc);
+        const long tile_e0 = C::MODE == MODE_FM ? (S - C::HFA) : (S - C::HFA) / C::M * C::L;
+        const long lo = C::MODE == MODE_FM ? S : S / C::M * C::L;
+        if (!bad) store_tile<C, false>(lds, t, (unsigned char *)a.out + (long)s * a.out_stride * OB, tile_e0, lo, 0, pc);
+        __syncthreads();                                     // the next item's staging overwrites this LDS
+    }
+}
+
+// ---------------------------------------------------------------------------
+// edge kernel: tile 0 of every stream (history) and the tiles at the stream end (zero fill,
+// partial outputs): checked staging and checked stores.  grid = (edge tiles, streams).
+// ---------------------------------------------------------------------------
+template <class C>
+__global__ __launch_bounds__(C::NT) void rx_pipe_edge_kernel(const PipeArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int OB = C::MODE == MODE_FM ? 4 : 8, PL = C::NOUT * OB / 16;
+    const int t = threadIdx.x;
+    const int s = blockIdx.y;
+    const int tile = blockIdx.x == 0 ? 0 : a.n_int + (int)blockIdx.x - 1;
+    const long S = (long)tile * C::TILE_IN;
+    const void *in = a.in_kind == CL_PIPE_IN_CF32 ? (const void *)((const f32x2 *)a.in + (long)s * a.in_stride)
+                                                  : (const void *)((const uint32_t *)a.in + (long)s * a.in_stride);
+    const bool bad = tile_sync_bad<C>(a, s, S);
+    stage_tile_slow<C>(a, in, a.hist_in + (long)s * C::HALO, S, lds, t);
+    __syncthreads();
+    f32x2 acc[C::R];
+    f32x4 pc[PL];
+    fir_tile<C>(lds, t, a.fir, acc);
+    second_stage<C>(lds, t, a.rs, acc, pc);
+    const long tile_e0 = C::MODE == MODE_FM ? (S - C::HFA) : (S - C::HFA) / C::M * C::L;
+    const long lo = C::MODE == MODE_FM ? S : S / C::M * C::L;
+    store_tile<C, true>(lds, t, (unsigned char *)a.out + (long)s * a.out_stride * OB, tile_e0, lo, bad ? 0 : a.n_out, pc);
 }
 
 // ---------------------------------------------------------------------------
@@ -513,9 +597,6 @@ __global__ __launch_bounds__(256) void gen_copy_kernel(const f32x2 *__restrict__
 // host side of the pipe object
 // ---------------------------------------------------------------------------
 typedef PipeCfg<64, 3, 2, 8, MODE_IQ, 16, 256> CfgC2;     // config 2: FIR64 + 3/2
-typedef PipeCfg<64, 3, 2, 8, MODE_IQ, 16, 128> CfgC2b;    // experiment: 2 waves per workgroup
-typedef PipeCfg<64, 3, 2, 8, MODE_IQ, 16, 64> CfgC2c;     // experiment: 1 wave per workgroup
-typedef PipeCfg<64, 3, 2, 8, MODE_IQ, 16, 256, false> CfgC2d;   // experiment: scalar v_fmac_f32
 typedef PipeCfg<64, 1, 1, 1, MODE_FM, 16, 256> CfgC3;     // config 3: FIR64 + FM demod
 typedef PipeCfg<128, 5, 4, 8, MODE_IQ, 16, 256> CfgC4;    // config 4: FIR128 + 5/4
 typedef PipeCfg<64, 1, 1, 1, MODE_IQ, 16, 256> CfgF64;    // FIR64 only
@@ -617,6 +698,7 @@ extern "C" void clhip_rx_pipe_force_generic(clhip_rx_pipe *p, int on) { p->force
 extern "C" void clhip_rx_pipe_set_sync_check(clhip_rx_pipe *p, const int32_t *d_offs, size_t chunk_samples,
                                              int32_t *d_bad_flag)
 {
+    if (chunk_samples & (chunk_samples - 1)) { d_offs = nullptr; clhip_set_error("sync check needs a power-of-two chunk size"); }
     p->chk_offs = d_offs; p->chk_chunk_samples = chunk_samples; p->chk_flag = d_bad_flag;
 }
 
@@ -637,18 +719,64 @@ extern "C" int clhip_rx_pipe_uses_fused(const clhip_rx_pipe *p, size_t n_in, int
     return 1;
 }
 
+template <class C, int KIND, bool HIF>
+static int launch_interior(const PipeArgs &a, hipStream_t s)
+{
+    const long items = (long)(a.n_int - 1) * a.n_streams;
+    if (items <= 0) return 0;
+    // persistent grid: as many workgroups as stay resident, each walking items blockIdx.x, +grid, ...
+    static int resident = 0;
+    if (!resident) {
+        (void)hipFuncSetAttribute((const void *)rx_pipe_fused_kernel<C, KIND, HIF>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        int dev = 0, cus = 256, per_cu = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)rx_pipe_fused_kernel<C, KIND, HIF>,
+                                                         C::NT, C::LDS_BYTES) != hipSuccess || per_cu < 1)
+            per_cu = 2;
+        // the API under-reports here (LDS 4 x 37.5 KB and 4 waves/SIMD both fit); an oversubscribed
+        // persistent grid is still correct (no inter-workgroup waits), so prefer the measured optimum
+        const int by_lds = (160 * 1024) / C::LDS_BYTES;
+        if (per_cu < 4 && by_lds >= 4) per_cu = 4;
+        const char *e = getenv("CLHIP_WG_PER_CU");
+        if (e && atoi(e) > 0) per_cu = atoi(e);
+        resident = cus * per_cu;
+    }
+    const unsigned grid = (unsigned)(items < resident ? items : resident);
+    hipLaunchKernelGGL((rx_pipe_fused_kernel<C, KIND, HIF>), dim3(grid), dim3(C::NT), C::LDS_BYTES, s, a);
+    CLHIP_CHECK_LAUNCH();
+    return 0;
+}
+
 template <class C>
-static int launch_fused(const PipeArgs &a, int n_streams, hipStream_t s)
+static int launch_fused(PipeArgs &a, hipStream_t s)
 {
     const long tiles = (a.n_in + C::TILE_IN - 1) / C::TILE_IN;
     if (tiles <= 0) return 0;
+    // interior tile: 1 <= tile and tile*TILE_IN - HALO + NLOAD <= n_in (then S + TILE_IN <= n_in too)
+    long n_int = a.n_in >= C::NLOAD - C::HALO ? (a.n_in - C::NLOAD + C::HALO) / C::TILE_IN + 1 : 1;
+    if (n_int < 1) n_int = 1;
+    if (n_int > tiles) n_int = tiles;
+    a.n_int = (int)n_int;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)rx_pipe_fused_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void *)rx_pipe_edge_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   C::LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL(rx_pipe_fused_kernel<C>, dim3((unsigned)tiles, n_streams), dim3(C::NT), C::LDS_BYTES, s, a);
+    int rc;
+    switch (a.in_kind) {
+    case CL_PIPE_IN_SMI_WORDS:
+        rc = a.channel == CL_CHANNEL_HIF ? launch_interior<C, CL_PIPE_IN_SMI_WORDS, true>(a, s)
+                                         : launch_interior<C, CL_PIPE_IN_SMI_WORDS, false>(a, s);
+        break;
+    case CL_PIPE_IN_CS16: rc = launch_interior<C, CL_PIPE_IN_CS16, false>(a, s); break;
+    default: rc = launch_interior<C, CL_PIPE_IN_CF32, false>(a, s); break;
+    }
+    if (rc) return rc;
+    const unsigned n_edge = (unsigned)(1 + (tiles - n_int));        // tile 0 + the tail tiles
+    hipLaunchKernelGGL(rx_pipe_edge_kernel<C>, dim3(n_edge, a.n_streams), dim3(C::NT), C::LDS_BYTES, s, a);
     CLHIP_CHECK_LAUNCH();
     return 0;
 }
@@ -686,12 +814,14 @@ extern "C" long clhip_rx_pipe_run(clhip_rx_pipe *p, int in_kind, const void *d_i
     a.hist_in = p->hist[p->cur];
     a.out = d_out; a.out_stride = (long)out_stride;
     a.n_in = (long)n_in; a.n_out = (long)n_out;
-    a.in_kind = in_kind; a.channel = p->channel;
+    a.in_kind = in_kind; a.channel = p->channel; a.n_streams = p->n_streams;
     a.in_scale = in_kind == CL_PIPE_IN_CF32 ? 1.0f : 4096.0f;
     a.fir = in_kind == CL_PIPE_IN_CF32 ? p->d_fir : p->d_fir_int;
     a.rs = p->d_rs;
     if (in_kind == CL_PIPE_IN_SMI_WORDS && p->chk_offs && p->chk_flag && p->chk_chunk_samples) {
-        a.chunk_offs = p->chk_offs; a.chunk_samples = (long)p->chk_chunk_samples;
+        int sh = 0;
+        while (((size_t)1 << sh) < p->chk_chunk_samples) sh++;
+        a.chunk_offs = p->chk_offs; a.chunk_shift = sh;
         a.chunks_per_stream = (long)clhip_div_up(n_in, p->chk_chunk_samples);
         a.bad_flag = p->chk_flag;
     }
@@ -700,18 +830,11 @@ extern "C" long clhip_rx_pipe_run(clhip_rx_pipe *p, int in_kind, const void *d_i
     if (clhip_rx_pipe_uses_fused(p, n_in, in_kind)) {
         int rc = -1;
         switch (p->fused_id) {
-        case 0: {
-            static int variant = getenv("CLHIP_C2_VARIANT") ? atoi(getenv("CLHIP_C2_VARIANT")) : 0;
-            if (variant == 1) rc = launch_fused<CfgC2b>(a, p->n_streams, s);
-            else if (variant == 2) rc = launch_fused<CfgC2c>(a, p->n_streams, s);
-            else if (variant == 3) rc = launch_fused<CfgC2d>(a, p->n_streams, s);
-            else rc = launch_fused<CfgC2>(a, p->n_streams, s);
-            break;
-        }
-        case 1: rc = launch_fused<CfgC3>(a, p->n_streams, s); break;
-        case 2: rc = launch_fused<CfgC4>(a, p->n_streams, s); break;
-        case 3: rc = launch_fused<CfgF64>(a, p->n_streams, s); break;
-        case 4: rc = launch_fused<CfgF128>(a, p->n_streams, s); break;
+        case 0: rc = launch_fused<CfgC2>(a, s); break;
+        case 1: rc = launch_fused<CfgC3>(a, s); break;
+        case 2: rc = launch_fused<CfgC4>(a, s); break;
+        case 3: rc = launch_fused<CfgF64>(a, s); break;
+        case 4: rc = launch_fused<CfgF128>(a, s); break;
         }
         if (rc) return -1;
     } else {
