@@ -62,9 +62,10 @@ struct PipeArgs {
     int32_t *bad_flag;           // set to 1 when a needed chunk has offs != 0 (tile writes nothing)
 };
 
-template <int T_, int L_, int M_, int KP_, int MODE_, int R_, int NT_, bool PK_ = true>
+template <int T_, int L_, int M_, int KP_, int MODE_, int R_, int NT_, bool FFA_ = false, bool PK_ = true>
 struct PipeCfg {
     static constexpr bool PK = PK_;
+    static constexpr bool FFA = FFA_;      // 2-parallel fast FIR: 3 half-length sub-filters instead of 4
     static constexpr int T = T_, L = L_, M = M_, KP = KP_, MODE = MODE_, R = R_, NT = NT_;
     static constexpr bool RESAMP = !(L == 1 && M == 1);
     static constexpr int HF = MODE == MODE_FM ? 1 : (RESAMP ? KP - 1 : 0);   // FIR outputs of history
@@ -280,6 +281,86 @@ __device__ __forceinline__ void fir_tile(const unsigned char *lds, int t, const 
 #undef LOAD_BLOCK
 }
 
+// 2-parallel fast FIR (FFA).  Split window, taps and outputs by parity:
+//   X0[j] = x[2j], X1[j] = x[2j+1];  H0[v] = h[2v], H1[v] = h[2v+1], HS = H0 + H1 (host, fp32)
+//   A[u] = sum_v H0[v] X0[T/2+u-v]   B[u] = sum_v H1[v] X1[T/2+u-v]   C[u] = sum_v HS[v] (X0+X1)[T/2+u-v]
+//   y[2u] = A[u] + B[u-1]            y[2u+1] = C[u] - A[u] - B[u]
+// Three (T/2)-tap sub-filters for R/2 outputs each instead of four: 800 packed FMAs + 64 adds per
+// lane instead of 1024 at T=64, R=16.  Same results to rounding (not bit-identical to the direct
+// form: the summation order differs), well inside the 1e-5 bar.  `ffa` = [H0 | H1 | HS], T/2 each.
+template <class C>
+__device__ __forceinline__ void fir_tile_ffa(const unsigned char *lds, int t, const float *ffa, f32x2 (&acc)[C::R])
+{
+    constexpr int T = C::T, R = C::R, TH = T / 2, RH = R / 2;      // decimated: TH taps, RH outputs, blocks of RH
+    static_assert(TH % RH == 0 && R % 4 == 0, "FFA walks the decimated window in blocks of R/2");
+    const unsigned char *win = lds + t * C::TSTRIDE;
+    const cfloat_t *__restrict__ h0 = (const cfloat_t *)ffa, *__restrict__ h1 = h0 + TH, *__restrict__ hs = h0 + 2 * TH;
+    f32x2 A[RH], Bm[RH + 1], Cc[RH];              // Bm[u+1] = B[u], u = -1..RH-1
+#pragma unroll
+    for (int u = 0; u < RH; u++) { A[u].x = A[u].y = 0.f; Cc[u].x = Cc[u].y = 0.f; }
+#pragma unroll
+    for (int u = 0; u <= RH; u++) { Bm[u].x = Bm[u].y = 0.f; }
+    f32x2 x0[RH], x1[RH];
+    // decimated block b holds j = RH*b + jj (window samples 2j, 2j+1 = one ds_read_b128);
+    // sample jj meets output u through tap d = (TH - RH*b) + (u - jj)
+#define LOAD_DBLOCK(B)                                                                      \
+    _Pragma("unroll") for (int jj = 0; jj < RH; jj++) {                                     \
+        const int w = 2 * (RH * (B) + jj);                                                  \
+        const f32x4 xx = *(const f32x4 *)(win + w * 8 + (w / R) * 16);                      \
+        x0[jj] = xx.xy; x1[jj] = xx.zw;                                                     \
+    }
+#define FFA_BLOCK(TAPBASE, LO, HI)                                                          \
+    _Pragma("unroll") for (int jj = 0; jj < RH; jj++) {                                     \
+        const f32x2 xs = x0[jj] + x1[jj];                                                   \
+        _Pragma("unroll") for (int u = -1; u < RH; u++) {                                   \
+            const int d = (TAPBASE) + u - jj;         /* relative to the block's tap window */ \
+            if (d >= (LO) && d <= (HI)) {                                                   \
+                fma2<C::PK>(Bm[u + 1], x1[jj], t1[d - (LO)]);                               \
+                if (u >= 0) { fma2<C::PK>(A[u], x0[jj], t0[d - (LO)]); fma2<C::PK>(Cc[u], xs, ts[d - (LO)]); } \
+            }                                                                               \
+        }                                                                                   \
+    }
+    {   // first block (b = 0): taps d = TH + u - jj, valid d <= TH-1; window of taps [TH-RH-1 .. TH-1]
+        LOAD_DBLOCK(0)
+        float t0[RH + 1], t1[RH + 1], ts[RH + 1];
+#pragma unroll
+        for (int i = 0; i <= RH; i++) { t0[i] = h0[TH - RH - 1 + i]; t1[i] = h1[TH - RH - 1 + i]; ts[i] = hs[TH - RH - 1 + i]; }
+        FFA_BLOCK(TH, TH - RH - 1, TH - 1)
+    }
+#pragma unroll 1
+    for (int b = 1; b < TH / RH; b++) {
+        LOAD_DBLOCK(b)
+        const int base = TH - RH * b;               // d = base + u - jj in [base-RH, base+RH-1]
+        float t0[2 * RH], t1[2 * RH], ts[2 * RH];
+#pragma unroll
+        for (int i = 0; i < 2 * RH; i++) { t0[i] = h0[base - RH + i]; t1[i] = h1[base - RH + i]; ts[i] = hs[base - RH + i]; }
+#pragma unroll
+        for (int jj = 0; jj < RH; jj++) {
+            const f32x2 xs = x0[jj] + x1[jj];
+#pragma unroll
+            for (int u = -1; u < RH; u++) {
+                const int i = RH + u - jj;          // d - (base - RH), always in [0, 2RH-1]
+                fma2<C::PK>(Bm[u + 1], x1[jj], t1[i]);
+                if (u >= 0) { fma2<C::PK>(A[u], x0[jj], t0[i]); fma2<C::PK>(Cc[u], xs, ts[i]); }
+            }
+        }
+    }
+    {   // last block (b = TH/RH): d = u - jj >= 0; taps [0 .. RH-1]
+        LOAD_DBLOCK(TH / RH)
+        float t0[RH], t1[RH], ts[RH];
+#pragma unroll
+        for (int i = 0; i < RH; i++) { t0[i] = h0[i]; t1[i] = h1[i]; ts[i] = hs[i]; }
+        FFA_BLOCK(0, 0, RH - 1)
+    }
+#undef LOAD_DBLOCK
+#undef FFA_BLOCK
+#pragma unroll
+    for (int u = 0; u < RH; u++) {
+        acc[2 * u] = A[u] + Bm[u];                  // A[u] + B[u-1]
+        acc[2 * u + 1] = Cc[u] - A[u] - Bm[u + 1];  // C[u] - A[u] - B[u]
+    }
+}
+
 // Second stage: polyphase resampler / FM demod / pass-through from registers.  The HF FIR
 // outputs before a lane's own come from the previous lane: a one-lane shuffle inside the wave,
 // an LDS slot across waves.  Contains the workgroup barrier that retires the staged input tile.
@@ -458,7 +539,7 @@ __global__ __launch_bounds__(C::NT) void rx_pipe_fused_kernel(const PipeArgs a)
         }
         f32x2 acc[C::R];
         f32x4 pc[PL];
-        fir_tile<C>(lds, t, fir, acc);
+        if constexpr (C::FFA) fir_tile_ffa<C>(lds, t, fir, acc); else fir_tile<C>(lds, t, fir, acc);
         second_stage<C>(lds, t, rs, acc, pc);
         const long tile_e0 = C::MODE == MODE_FM ? (S - C::HFA) : (S - C::HFA) / C::M * C::L;
         const long lo = C::MODE == MODE_FM ? S : S / C::M * C::L;
@@ -487,7 +568,7 @@ __global__ __launch_bounds__(C::NT) void rx_pipe_edge_kernel(const PipeArgs a)
     __syncthreads();
     f32x2 acc[C::R];
     f32x4 pc[PL];
-    fir_tile<C>(lds, t, a.fir, acc);
+    if constexpr (C::FFA) fir_tile_ffa<C>(lds, t, a.fir, acc); else fir_tile<C>(lds, t, a.fir, acc);
     second_stage<C>(lds, t, a.rs, acc, pc);
     const long tile_e0 = C::MODE == MODE_FM ? (S - C::HFA) : (S - C::HFA) / C::M * C::L;
     const long lo = C::MODE == MODE_FM ? S : S / C::M * C::L;
@@ -597,8 +678,13 @@ __global__ __launch_bounds__(256) void gen_copy_kernel(const f32x2 *__restrict__
 // host side of the pipe object
 // ---------------------------------------------------------------------------
 typedef PipeCfg<64, 3, 2, 8, MODE_IQ, 16, 256> CfgC2;     // config 2: FIR64 + 3/2
+typedef PipeCfg<64, 3, 2, 8, MODE_IQ, 16, 256, true> CfgC2f;   // the same with the 2-parallel fast FIR
 typedef PipeCfg<64, 1, 1, 1, MODE_FM, 16, 256> CfgC3;     // config 3: FIR64 + FM demod
 typedef PipeCfg<128, 5, 4, 8, MODE_IQ, 16, 256> CfgC4;    // config 4: FIR128 + 5/4
+typedef PipeCfg<64, 1, 1, 1, MODE_FM, 16, 256, true> CfgC3f;
+typedef PipeCfg<128, 5, 4, 8, MODE_IQ, 16, 256, true> CfgC4f;
+typedef PipeCfg<64, 1, 1, 1, MODE_IQ, 16, 256, true> CfgF64f;
+typedef PipeCfg<128, 1, 1, 1, MODE_IQ, 16, 256, true> CfgF128f;
 typedef PipeCfg<64, 1, 1, 1, MODE_IQ, 16, 256> CfgF64;    // FIR64 only
 typedef PipeCfg<128, 1, 1, 1, MODE_IQ, 16, 256> CfgF128;  // FIR128 only
 
@@ -615,6 +701,8 @@ struct clhip_rx_pipe {
     // generic workspaces
     const int32_t *chk_offs; size_t chk_chunk_samples; int32_t *chk_flag;   // optional sync validation
     float *d_fir, *d_fir_int, *d_rs;   // taps; d_fir_int = taps/4096 for integer inputs
+    float *d_ffa, *d_ffa_int;          // [H0 | H1 | H0+H1] for the 2-parallel fast FIR, same two scalings
+    bool ffa;                          // the selected fused instantiation uses them
     f32x2 *X, *Y;
     size_t x_cap, y_cap;           // elements per stream
 };
@@ -672,6 +760,21 @@ extern "C" clhip_rx_pipe *clhip_rx_pipe_create(int n_streams, int channel, const
     for (int k = 0; k < PIPE_MAX_FIR; k++) scaled[k] = p->fir[k] / 4096.0f;   // exact: power of two
     (void)hipMemcpy(p->d_fir, p->fir, sizeof(float) * PIPE_MAX_FIR, hipMemcpyHostToDevice);
     (void)hipMemcpy(p->d_fir_int, scaled, sizeof(float) * PIPE_MAX_FIR, hipMemcpyHostToDevice);
+    if ((n_fir & 1) == 0) {
+        const int th = n_fir / 2;
+        float f[2][3 * PIPE_MAX_FIR / 2];
+        for (int v = 0; v < th; v++) {
+            for (int k = 0; k < 2; k++) {
+                const float *src = k ? scaled : p->fir;
+                f[k][v] = src[2 * v]; f[k][th + v] = src[2 * v + 1]; f[k][2 * th + v] = src[2 * v] + src[2 * v + 1];
+            }
+        }
+        p->d_ffa = (float *)clhip_malloc(sizeof f[0]);
+        p->d_ffa_int = (float *)clhip_malloc(sizeof f[0]);
+        if (!p->d_ffa || !p->d_ffa_int) { clhip_rx_pipe_destroy(p); return nullptr; }
+        (void)hipMemcpy(p->d_ffa, f[0], sizeof f[0], hipMemcpyHostToDevice);
+        (void)hipMemcpy(p->d_ffa_int, f[1], sizeof f[1], hipMemcpyHostToDevice);
+    }
     (void)hipMemcpy(p->d_rs, p->rs, sizeof(float) * PIPE_MAX_RS, hipMemcpyHostToDevice);
     return p;
 }
@@ -680,7 +783,7 @@ extern "C" void clhip_rx_pipe_destroy(clhip_rx_pipe *p)
 {
     if (!p) return;
     clhip_free(p->hist[0]); clhip_free(p->hist[1]);
-    clhip_free(p->d_fir); clhip_free(p->d_fir_int); clhip_free(p->d_rs);
+    clhip_free(p->d_fir); clhip_free(p->d_fir_int); clhip_free(p->d_rs); clhip_free(p->d_ffa); clhip_free(p->d_ffa_int);
     clhip_free(p->X); clhip_free(p->Y);
     delete p;
 }
@@ -817,6 +920,7 @@ extern "C" long clhip_rx_pipe_run(clhip_rx_pipe *p, int in_kind, const void *d_i
     a.in_kind = in_kind; a.channel = p->channel; a.n_streams = p->n_streams;
     a.in_scale = in_kind == CL_PIPE_IN_CF32 ? 1.0f : 4096.0f;
     a.fir = in_kind == CL_PIPE_IN_CF32 ? p->d_fir : p->d_fir_int;
+    const float *ffa_taps = in_kind == CL_PIPE_IN_CF32 ? p->d_ffa : p->d_ffa_int;
     a.rs = p->d_rs;
     if (in_kind == CL_PIPE_IN_SMI_WORDS && p->chk_offs && p->chk_flag && p->chk_chunk_samples) {
         int sh = 0;
@@ -829,12 +933,17 @@ extern "C" long clhip_rx_pipe_run(clhip_rx_pipe *p, int in_kind, const void *d_i
     if (getenv("CLHIP_DEBUG_NOSTORE")) a.n_out = 0;     // timing ablation only: every store masked off
     if (clhip_rx_pipe_uses_fused(p, n_in, in_kind)) {
         int rc = -1;
+        // 2-parallel fast FIR by default (CLHIP_FFA=0: direct form).  Its lane parity is tied to the
+        // absolute sample index, so a call that starts on an odd index uses the direct form.
+        static const int ffa_env = getenv("CLHIP_FFA") ? atoi(getenv("CLHIP_FFA")) : 1;
+        const bool ffa = ffa_env && ffa_taps && (p->n_total & 1) == 0;
+        if (ffa) a.fir = ffa_taps;
         switch (p->fused_id) {
-        case 0: rc = launch_fused<CfgC2>(a, s); break;
-        case 1: rc = launch_fused<CfgC3>(a, s); break;
-        case 2: rc = launch_fused<CfgC4>(a, s); break;
-        case 3: rc = launch_fused<CfgF64>(a, s); break;
-        case 4: rc = launch_fused<CfgF128>(a, s); break;
+        case 0: rc = ffa ? launch_fused<CfgC2f>(a, s) : launch_fused<CfgC2>(a, s); break;
+        case 1: rc = ffa ? launch_fused<CfgC3f>(a, s) : launch_fused<CfgC3>(a, s); break;
+        case 2: rc = ffa ? launch_fused<CfgC4f>(a, s) : launch_fused<CfgC4>(a, s); break;
+        case 3: rc = ffa ? launch_fused<CfgF64f>(a, s) : launch_fused<CfgF64>(a, s); break;
+        case 4: rc = ffa ? launch_fused<CfgF128f>(a, s) : launch_fused<CfgF128>(a, s); break;
         }
         if (rc) return -1;
     } else {

@@ -133,8 +133,10 @@ def test_c2_vs_scipy_fixture(G, orc):
 
 
 @pytest.mark.parametrize("cfg", list(CONFIGS))
-def test_fused_equals_generic_bitwise(G, orc, cfg):
-    """Two implementations of one spec with the same summation order: identical bits."""
+def test_fused_vs_generic_second_implementation(G, orc, cfg, monkeypatch):
+    """Two implementations of one spec.  The direct-form fused kernel uses the generic kernels'
+    summation order: identical bits.  The default 2-parallel fast FIR re-associates the sums:
+    equal to rounding (a few 1e-7 of the peak)."""
     from cariboulite_amd import hip, synth
     n = 2 * 4088 + 36
     b, _, _ = synth.smi_stream_bytes(n, 0, stream=2)
@@ -143,9 +145,13 @@ def test_fused_equals_generic_bitwise(G, orc, cfg):
     assert p1.uses_fused(n) and not p2.uses_fused(n)
     a, g = run_pipe(G, p1, b, n), run_pipe(G, p2, b, n)
     if CONFIGS[cfg]["mode"] == 1:
-        assert np.max(np.abs(a - g)) <= 2e-6          # atan2f on identical inputs
+        d = np.abs(a - g); d = np.minimum(d, 2 * np.pi - d)
+        big = np.abs(orc.FIR(load_golden("taps.npz")["fir64_c3"]).f64(
+            orc.cs16_to_cf32(orc.rx_data_analyze(0, b)[1][:n]))).max(axis=1) > 0.02
+        big[1:] &= big[:-1]
+        assert np.max(d[big]) <= 2e-5
     else:
-        assert np.array_equal(a, g)
+        assert np.max(np.abs(a - g)) <= 2e-6 * np.max(np.abs(g))
 
 
 @pytest.mark.parametrize("cfg", ["c2", "c3", "c4"])
@@ -155,19 +161,47 @@ def test_streaming_chunks_equal_one_shot(G, orc, cfg):
     n = 4 * 4096
     b, _, _ = synth.smi_stream_bytes(n, 0, stream=5)
     one = run_pipe(G, make_pipe(cfg), b, n)
-    chunks = [4096, 8, 4088, 4, 2048, 6140]          # all multiples of M=4/2: fused path
+    chunks = [4096, 8, 4088, 4, 2048, 6140]          # all multiples of M=4/2: fused path, same lane parity
     assert sum(chunks) == n
     p = make_pipe(cfg)
     many = run_pipe(G, p, b, n, chunks=chunks)
-    assert np.array_equal(one, many)
-    # ragged chunk lengths (odd phases) go through the generic kernels; same spec
+    assert np.array_equal(one, many)                 # bit-identical: state is exact, arithmetic identical
+    # ragged chunk lengths (odd phases) go through the generic / direct-form kernels: same spec, equal to rounding
     chunks2 = [1, 2, 3, 4091, 5, 4090, 8184, 8]
     assert sum(chunks2) == n
     many2 = run_pipe(G, make_pipe(cfg), b, n, chunks=chunks2)
     if CONFIGS[cfg]["mode"] == 1:
-        assert np.max(np.abs(one - many2)) <= 2e-6
+        d = np.abs(one - many2); d = np.minimum(d, 2 * np.pi - d)
+        assert np.mean(d > 2e-5) < 0.05               # ill-conditioned only where |y| ~ 0
     else:
-        assert np.array_equal(one, many2)
+        assert np.max(np.abs(one - many2)) <= 2e-6 * np.max(np.abs(one))
+
+
+def test_direct_form_is_bit_identical_to_generic(G, orc):
+    """CLHIP_FFA=0 (direct-form FIR) keeps the generic kernels' summation order: identical bits.
+    Run in a child process because the variant is latched from the environment at first use."""
+    import subprocess, sys, os, textwrap
+    code = textwrap.dedent("""
+        import sys, numpy as np, torch
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        from cariboulite_amd import hip, synth
+        t = np.load(%r)
+        n = 2 * 4088 + 36
+        b = synth.smi_stream_bytes(n, 0, stream=2)[0]
+        d = torch.from_numpy(b.copy()).to("cuda:0")
+        outs = []
+        for gen in (False, True):
+            p = hip.RxPipe(1, 0, t["fir64_c2"], t["rs_3_2"], 3, 2, 0)
+            p.force_generic(gen)
+            o = torch.zeros((p.out_count(n), 2), dtype=torch.float32, device="cuda:0")
+            p.run(hip.PIPE_IN_SMI_WORDS, d, 0, n, o, 0); torch.cuda.synchronize()
+            outs.append(o.cpu().numpy())
+        assert np.array_equal(outs[0], outs[1]), float(np.max(np.abs(outs[0] - outs[1])))
+        print("bit-identical")
+    """) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)),
+            os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "taps.npz"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CLHIP_FFA="0"), capture_output=True, text=True)
+    assert r.returncode == 0 and "bit-identical" in r.stdout, r.stderr[-2000:]
 
 
 def test_multi_stream_and_input_kinds(G, orc):
