@@ -40,8 +40,8 @@ NATIVE_CHUNK_SAMPLES = 131072     # caribou_smi.c:78 / cariboulite_radio.c:1310-
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--log2-samples", type=int, default=28, help="samples per GPU per step (2^k)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
@@ -159,6 +159,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "kernel": "rx_pipe_fused_kernel<PipeCfg<64,3,2,8,0,16,256>>",
                          "kernel_ms_avg": round(kern_avg_s * 1e3, 4), "kernel_ms_min": round(float(np.min(kern_ms)), 4),
+                         "kernel_ms_each": [round(float(v), 3) for v in kern_ms],
                          "algorithmic_bytes_per_sample": ALGO_BYTES_PER_SAMPLE,
                          "valu_tflops": round(FLOP_PER_SAMPLE * n / kern_avg_s / 1e12, 2),
                          "valu_frac_of_fp32_peak": round(FLOP_PER_SAMPLE * n / kern_avg_s / 1e12 / VALU_PEAK_TFLOPS, 4)},

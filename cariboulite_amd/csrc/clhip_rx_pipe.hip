@@ -179,19 +179,26 @@ __device__ __forceinline__ void tile_issue_loads(TileRegs<C, KIND> &r, const voi
 template <class C, int KIND, bool HIF>
 __device__ __forceinline__ void tile_regs_to_lds(const TileRegs<C, KIND> &r, unsigned char *lds, int t)
 {
-    constexpr int NG = TileRegs<C, KIND>::NG, IT = TileRegs<C, KIND>::IT;
+    constexpr int NG = TileRegs<C, KIND>::NG, IT = TileRegs<C, KIND>::IT, R = C::R, NT = C::NT;
+    // group grp = t + it*NT holds samples 4*grp..: lds_off = 32*grp + 16*(4*grp/R).  With NT*4 a
+    // multiple of R the per-iteration stride is a compile-time constant: one lane base, immediates after.
+    static_assert((NT * 4) % R == 0, "staging stride must be a whole number of padded rows");
+    constexpr int STRIDE = NT * 32 + (NT * 4 / R) * 16;
+    unsigned char *base = lds + 32 * t + 16 * ((4 * t) / R);
 #pragma unroll
     for (int it = 0; it < IT; it++) {
-        const int grp = t + it * C::NT;
-        if (NG % C::NT == 0 || it < IT - 1 || grp < NG) {
+        const int grp = t + it * NT;
+        if (NG % NT == 0 || it < IT - 1 || grp < NG) {
+            unsigned char *d = base + it * STRIDE;
             if constexpr (KIND == CL_PIPE_IN_CF32) {
-                unsigned char *d = lds + lds_off<C::R>(4 * grp);
                 *(u32x4 *)d = r.w[2 * it];
                 *(u32x4 *)(d + 16) = r.w[2 * it + 1];
             } else {
                 f32x2 v[4];
                 convert4<KIND, HIF>(r.w[it], v);
-                lds_put4<C::R>(lds, 4 * grp, v);
+                f32x4 q0 = {v[0].x, v[0].y, v[1].x, v[1].y}, q1 = {v[2].x, v[2].y, v[3].x, v[3].y};
+                *(f32x4 *)d = q0;
+                *(f32x4 *)(d + 16) = q1;
             }
         }
     }
@@ -441,9 +448,13 @@ __device__ __forceinline__ void store_tile(unsigned char *lds, int t, unsigned c
     constexpr int EPP = 16 / OB;                         // elements per piece
     constexpr int PITCH = LB + 16;
     constexpr int HALF_PIECES = 32 * PL;                 // pieces per half wave
+    constexpr int NJ = (HALF_PIECES + 63) / 64;
     static_assert(32 * PITCH * (C::NT / 64) <= C::IN_BYTES, "per-wave transpose slices must fit the input tile");
     const int lane = t & 63, wave = t >> 6;
     unsigned char *scr = lds + wave * (32 * PITCH);
+    // piece p = lane + 64 j sits at row p / PL, column p % PL of the scratch: divide once, then step
+    const int row0 = lane / PL, col0 = lane % PL;
+    const unsigned char *rd0 = scr + row0 * PITCH + col0 * 16;
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         if ((lane >> 5) == h) {
@@ -453,23 +464,38 @@ __device__ __forceinline__ void store_tile(unsigned char *lds, int t, unsigned c
         }
         __builtin_amdgcn_wave_barrier();
         const long half_e0 = tile_e0 + (long)NOUT * (wave * 64 + h * 32);      // first element of this half wave
-        unsigned char *hb = outb + half_e0 * OB;
+        unsigned char *hb = outb + half_e0 * OB + lane * 16;
+        f32x4 v[NJ];
+        int col = col0;
+        const unsigned char *rd = rd0;
 #pragma unroll
-        for (int j = 0; j < (HALF_PIECES + 63) / 64; j++) {
-            const int p = lane + 64 * j;
-            if (HALF_PIECES % 64 == 0 || p < HALF_PIECES) {
-                const f32x4 v = *(const f32x4 *)(scr + (p / PL) * PITCH + (p % PL) * 16);
-                const long e = half_e0 + (long)p * EPP;
-                if constexpr (!CHECKED) {
-                    if ((wave | h) != 0 || e >= lo) *(f32x4 *)(hb + p * 16) = v;    // wave-uniform short-circuit
-                } else if (e >= lo && e + EPP <= hi) {
-                    *(f32x4 *)(hb + p * 16) = v;
-                } else {
+        for (int j = 0; j < NJ; j++) {
+            if (HALF_PIECES % 64 == 0 || lane + 64 * j < HALF_PIECES) v[j] = *(const f32x4 *)rd;
+            // advance 64 pieces: 64 = (64 / PL) rows + (64 % PL) columns, with carry
+            col += 64 % PL;
+            rd += (64 / PL) * PITCH + (64 % PL) * 16;
+            if (col >= PL) { col -= PL; rd += PITCH - PL * 16; }
+        }
+        const bool plain = !CHECKED && (wave | h) != 0;      // wave-uniform: nothing to mask in this half
+        if (plain) {
 #pragma unroll
-                    for (int k = 0; k < EPP; k++) {
-                        if (e + k >= lo && e + k < hi) {
-                            if constexpr (OB == 8) { f32x2 q = {v[2 * k], v[2 * k + 1]}; *(f32x2 *)(hb + p * 16 + k * OB) = q; }
-                            else *(float *)(hb + p * 16 + k * OB) = v[k];
+            for (int j = 0; j < NJ; j++)
+                if (HALF_PIECES % 64 == 0 || lane + 64 * j < HALF_PIECES) *(f32x4 *)(hb + j * 1024) = v[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < NJ; j++) {
+                const int p = lane + 64 * j;
+                if (HALF_PIECES % 64 == 0 || p < HALF_PIECES) {
+                    const long e = half_e0 + (long)p * EPP;
+                    if (e >= lo && (!CHECKED || e + EPP <= hi)) {
+                        *(f32x4 *)(hb + j * 1024) = v[j];
+                    } else if (CHECKED) {
+#pragma unroll
+                        for (int k = 0; k < EPP; k++) {
+                            if (e + k >= lo && e + k < hi) {
+                                if constexpr (OB == 8) { f32x2 q = {v[j][2 * k], v[j][2 * k + 1]}; *(f32x2 *)(hb + j * 1024 + k * OB) = q; }
+                                else *(float *)(hb + j * 1024 + k * OB) = v[j][k];
+                            }
                         }
                     }
                 }
@@ -842,6 +868,7 @@ static int launch_interior(const PipeArgs &a, hipStream_t s)
         // persistent grid is still correct (no inter-workgroup waits), so prefer the measured optimum
         const int by_lds = (160 * 1024) / C::LDS_BYTES;
         if (per_cu < 4 && by_lds >= 4) per_cu = 4;
+        per_cu *= 4;      // 4x oversubscribed: queued workgroups back-fill as residents finish (measured best)
         const char *e = getenv("CLHIP_WG_PER_CU");
         if (e && atoi(e) > 0) per_cu = atoi(e);
         resident = cus * per_cu;
