@@ -50,6 +50,10 @@ struct PipeArgs {
     int in_kind;             // CL_PIPE_IN_*
     int n_streams;
     int n_int;               // tiles 1 .. n_int-1 of every stream are interior (no bounds checks)
+    int n_edge;              // edge tiles per stream: tile 0 and tiles n_int .. (checked path)
+    int grid_int;            // workgroups [0, grid_int) are persistent interior workers, the rest edge workers
+    int halo;                // history samples per stream
+    f32x2 *hist_out;         // [n_streams][halo] history for the NEXT call (ping-pong with hist_in)
     int channel;             // CL_CHANNEL_*
     float in_scale;          // 4096 for integer inputs (taps carry 1/4096), 1 for CF32
     const float *fir;        // T taps, pre-multiplied by 1/in_scale (device, read-only)
@@ -521,22 +525,57 @@ __device__ __forceinline__ bool tile_sync_bad(const PipeArgs &a, int s, long S)
 }
 
 // ---------------------------------------------------------------------------
+// edge worker: tile 0 of a stream (history) or a tile at the stream end (zero fill, partial
+// outputs): checked staging and checked stores.  The worker of tile 0 also writes the stream's
+// history for the next call.  Runs in the same launch as the interior workers (extra workgroups
+// at the end of the grid), so a call is ONE kernel.
+// ---------------------------------------------------------------------------
+template <class C>
+__device__ __forceinline__ void rx_pipe_edge_worker(const PipeArgs &a, unsigned char *lds, int e)
+{
+    constexpr int OB = C::MODE == MODE_FM ? 4 : 8, PL = C::NOUT * OB / 16;
+    const int t = threadIdx.x;
+    const int s = e / a.n_edge, ei = e % a.n_edge;
+    const int tile = ei == 0 ? 0 : a.n_int + ei - 1;
+    const long S = (long)tile * C::TILE_IN;
+    const void *in = a.in_kind == CL_PIPE_IN_CF32 ? (const void *)((const f32x2 *)a.in + (long)s * a.in_stride)
+                                                  : (const void *)((const uint32_t *)a.in + (long)s * a.in_stride);
+    const bool bad = tile_sync_bad<C>(a, s, S);
+    stage_tile_slow<C>(a, in, a.hist_in + (long)s * C::HALO, S, lds, t);
+    __syncthreads();
+    f32x2 acc[C::R];
+    f32x4 pc[PL];
+    if constexpr (C::FFA) fir_tile_ffa<C>(lds, t, a.fir, acc); else fir_tile<C>(lds, t, a.fir, acc);
+    second_stage<C>(lds, t, a.rs, acc, pc);
+    const long tile_e0 = C::MODE == MODE_FM ? (S - C::HFA) : (S - C::HFA) / C::M * C::L;
+    const long lo = C::MODE == MODE_FM ? S : S / C::M * C::L;
+    store_tile<C, true>(lds, t, (unsigned char *)a.out + (long)s * a.out_stride * OB, tile_e0, lo, bad ? 0 : a.n_out, pc);
+    if (ei == 0) pipe_update_hist(a, s, t, C::NT);
+}
+
+// ---------------------------------------------------------------------------
 // interior kernel: persistent workgroups over the tiles that lie fully inside a stream
 // (tile index 1 .. n_int-1).  No bounds checks; the raw words of the NEXT item are loaded
 // into registers while the current one computes, so HBM latency hides under the FIR.
 // One kernel per (config, input kind, channel type): each gets its own register allocation.
 // ---------------------------------------------------------------------------
 template <class C, int KIND, bool HIF>
-__global__ __launch_bounds__(C::NT) void rx_pipe_fused_kernel(const PipeArgs a)
+__global__ __launch_bounds__(C::NT, KIND == CL_PIPE_IN_CF32 ? 3 : 4)      // integer inputs: 4 waves/SIMD (<= 128 VGPRs)
+void rx_pipe_fused_kernel(const PipeArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int OB = C::MODE == MODE_FM ? 4 : 8, PL = C::NOUT * OB / 16;
+    const int n_edge_wg = a.n_edge * a.n_streams;
+    if ((int)blockIdx.x < n_edge_wg) {                       // workgroup-uniform: the first workgroups are edge workers
+        rx_pipe_edge_worker<C>(a, lds, (int)blockIdx.x);     // (dispatched first, they overlap the interior work)
+        return;
+    }
     const int per_stream = a.n_int - 1;                      // interior tiles per stream: 1 .. n_int-1
     const int items = per_stream * a.n_streams;
-    const int step = gridDim.x;
+    const int step = a.grid_int;
 
     TileRegs<C, KIND> regs;
-    int item = blockIdx.x;
+    int item = (int)blockIdx.x - n_edge_wg;
     if (item < items) {
         const int s0 = item / per_stream, tile0 = 1 + item % per_stream;
         const void *in0 = KIND == CL_PIPE_IN_CF32 ? (const void *)((const f32x2 *)a.in + (long)s0 * a.in_stride)
@@ -575,50 +614,28 @@ __global__ __launch_bounds__(C::NT) void rx_pipe_fused_kernel(const PipeArgs a)
 }
 
 // ---------------------------------------------------------------------------
-// edge kernel: tile 0 of every stream (history) and the tiles at the stream end (zero fill,
-// partial outputs): checked staging and checked stores.  grid = (edge tiles, streams).
-// ---------------------------------------------------------------------------
-template <class C>
-__global__ __launch_bounds__(C::NT) void rx_pipe_edge_kernel(const PipeArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    constexpr int OB = C::MODE == MODE_FM ? 4 : 8, PL = C::NOUT * OB / 16;
-    const int t = threadIdx.x;
-    const int s = blockIdx.y;
-    const int tile = blockIdx.x == 0 ? 0 : a.n_int + (int)blockIdx.x - 1;
-    const long S = (long)tile * C::TILE_IN;
-    const void *in = a.in_kind == CL_PIPE_IN_CF32 ? (const void *)((const f32x2 *)a.in + (long)s * a.in_stride)
-                                                  : (const void *)((const uint32_t *)a.in + (long)s * a.in_stride);
-    const bool bad = tile_sync_bad<C>(a, s, S);
-    stage_tile_slow<C>(a, in, a.hist_in + (long)s * C::HALO, S, lds, t);
-    __syncthreads();
-    f32x2 acc[C::R];
-    f32x4 pc[PL];
-    if constexpr (C::FFA) fir_tile_ffa<C>(lds, t, a.fir, acc); else fir_tile<C>(lds, t, a.fir, acc);
-    second_stage<C>(lds, t, a.rs, acc, pc);
-    const long tile_e0 = C::MODE == MODE_FM ? (S - C::HFA) : (S - C::HFA) / C::M * C::L;
-    const long lo = C::MODE == MODE_FM ? S : S / C::M * C::L;
-    store_tile<C, true>(lds, t, (unsigned char *)a.out + (long)s * a.out_stride * OB, tile_e0, lo, bad ? 0 : a.n_out, pc);
-}
-
-// ---------------------------------------------------------------------------
 // history update: hist_out = last `halo` samples of [hist_in | in[0..n_in)]
 // ---------------------------------------------------------------------------
-__global__ void pipe_update_hist_kernel(PipeArgs a, int halo, f32x2 *__restrict__ hist_out)
+__device__ __forceinline__ void pipe_update_hist(const PipeArgs &a, int s, int t, int nt)
 {
-    const int s = blockIdx.x;
+    const int halo = a.halo;
     const void *in = a.in_kind == CL_PIPE_IN_CF32
                          ? (const void *)((const f32x2 *)a.in + (long)s * a.in_stride)
                          : (const void *)((const uint32_t *)a.in + (long)s * a.in_stride);
     const float inv = 1.0f / a.in_scale;
-    for (int j = threadIdx.x; j < halo; j += blockDim.x) {
+    for (int j = t; j < halo; j += nt) {
         const long g = a.n_in - halo + j;         // position in the new-input index space
         f32x2 v;
         if (g >= 0) v = load_sample(a, in, g) * inv;
         else if (halo + g >= 0) v = a.hist_in[(long)s * halo + halo + g];
         else { v.x = 0.f; v.y = 0.f; }
-        hist_out[(long)s * halo + j] = v;
+        a.hist_out[(long)s * halo + j] = v;
     }
+}
+
+__global__ void pipe_update_hist_kernel(PipeArgs a)     // generic path only
+{
+    pipe_update_hist(a, blockIdx.x, threadIdx.x, blockDim.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -849,11 +866,11 @@ extern "C" int clhip_rx_pipe_uses_fused(const clhip_rx_pipe *p, size_t n_in, int
 }
 
 template <class C, int KIND, bool HIF>
-static int launch_interior(const PipeArgs &a, hipStream_t s)
+static int launch_pipe(PipeArgs &a, hipStream_t s)
 {
     const long items = (long)(a.n_int - 1) * a.n_streams;
-    if (items <= 0) return 0;
-    // persistent grid: as many workgroups as stay resident, each walking items blockIdx.x, +grid, ...
+    // persistent interior grid: a multiple of what stays resident; each worker walks items
+    // blockIdx.x, +grid_int, ...; edge workers follow in the same launch
     static int resident = 0;
     if (!resident) {
         (void)hipFuncSetAttribute((const void *)rx_pipe_fused_kernel<C, KIND, HIF>,
@@ -873,7 +890,8 @@ static int launch_interior(const PipeArgs &a, hipStream_t s)
         if (e && atoi(e) > 0) per_cu = atoi(e);
         resident = cus * per_cu;
     }
-    const unsigned grid = (unsigned)(items < resident ? items : resident);
+    a.grid_int = (int)(items < resident ? items : resident);
+    const unsigned grid = (unsigned)a.grid_int + (unsigned)a.n_edge * a.n_streams;
     hipLaunchKernelGGL((rx_pipe_fused_kernel<C, KIND, HIF>), dim3(grid), dim3(C::NT), C::LDS_BYTES, s, a);
     CLHIP_CHECK_LAUNCH();
     return 0;
@@ -889,26 +907,14 @@ static int launch_fused(PipeArgs &a, hipStream_t s)
     if (n_int < 1) n_int = 1;
     if (n_int > tiles) n_int = tiles;
     a.n_int = (int)n_int;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)rx_pipe_edge_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  C::LDS_BYTES);
-        attr_set = true;
-    }
-    int rc;
+    a.n_edge = (int)(1 + (tiles - n_int));                  // tile 0 + the tail tiles
     switch (a.in_kind) {
     case CL_PIPE_IN_SMI_WORDS:
-        rc = a.channel == CL_CHANNEL_HIF ? launch_interior<C, CL_PIPE_IN_SMI_WORDS, true>(a, s)
-                                         : launch_interior<C, CL_PIPE_IN_SMI_WORDS, false>(a, s);
-        break;
-    case CL_PIPE_IN_CS16: rc = launch_interior<C, CL_PIPE_IN_CS16, false>(a, s); break;
-    default: rc = launch_interior<C, CL_PIPE_IN_CF32, false>(a, s); break;
+        return a.channel == CL_CHANNEL_HIF ? launch_pipe<C, CL_PIPE_IN_SMI_WORDS, true>(a, s)
+                                           : launch_pipe<C, CL_PIPE_IN_SMI_WORDS, false>(a, s);
+    case CL_PIPE_IN_CS16: return launch_pipe<C, CL_PIPE_IN_CS16, false>(a, s);
+    default: return launch_pipe<C, CL_PIPE_IN_CF32, false>(a, s);
     }
-    if (rc) return rc;
-    const unsigned n_edge = (unsigned)(1 + (tiles - n_int));        // tile 0 + the tail tiles
-    hipLaunchKernelGGL(rx_pipe_edge_kernel<C>, dim3(n_edge, a.n_streams), dim3(C::NT), C::LDS_BYTES, s, a);
-    CLHIP_CHECK_LAUNCH();
-    return 0;
 }
 
 static int ensure_ws(clhip_rx_pipe *p, size_t n_in)
@@ -945,6 +951,7 @@ extern "C" long clhip_rx_pipe_run(clhip_rx_pipe *p, int in_kind, const void *d_i
     a.out = d_out; a.out_stride = (long)out_stride;
     a.n_in = (long)n_in; a.n_out = (long)n_out;
     a.in_kind = in_kind; a.channel = p->channel; a.n_streams = p->n_streams;
+    a.halo = p->halo; a.hist_out = p->hist[p->cur ^ 1];
     a.in_scale = in_kind == CL_PIPE_IN_CF32 ? 1.0f : 4096.0f;
     a.fir = in_kind == CL_PIPE_IN_CF32 ? p->d_fir : p->d_fir_int;
     const float *ffa_taps = in_kind == CL_PIPE_IN_CF32 ? p->d_ffa : p->d_ffa_int;
@@ -958,8 +965,10 @@ extern "C" long clhip_rx_pipe_run(clhip_rx_pipe *p, int in_kind, const void *d_i
     }
 
     if (getenv("CLHIP_DEBUG_NOSTORE")) a.n_out = 0;     // timing ablation only: every store masked off
+    bool fused_done = false;
     if (clhip_rx_pipe_uses_fused(p, n_in, in_kind)) {
         int rc = -1;
+        fused_done = true;
         // 2-parallel fast FIR by default (CLHIP_FFA=0: direct form).  Its lane parity is tied to the
         // absolute sample index, so a call that starts on an odd index uses the direct form.
         static const int ffa_env = getenv("CLHIP_FFA") ? atoi(getenv("CLHIP_FFA")) : 1;
@@ -991,8 +1000,10 @@ extern "C" long clhip_rx_pipe_run(clhip_rx_pipe *p, int in_kind, const void *d_i
                                p->L, p->M, p->n_total, (long)n_out, (f32x2 *)d_out, (long)out_stride);
         CLHIP_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(pipe_update_hist_kernel, dim3(p->n_streams), dim3(128), 0, s, a, p->halo, p->hist[p->cur ^ 1]);
-    CLHIP_CHECK_LAUNCH();
+    if (!fused_done) {
+        hipLaunchKernelGGL(pipe_update_hist_kernel, dim3(p->n_streams), dim3(128), 0, s, a);
+        CLHIP_CHECK_LAUNCH();
+    }
     p->cur ^= 1;
     p->n_total += n_in;
     return (long)n_out;
