@@ -143,6 +143,16 @@ def main():
     kern_avg_s = float(np.mean(kern_ms)) / 1e3
 
     if rank == 0:
+        # HBM traffic of the fused kernel from PMC counters: measured in separate rocprofv3 --pmc passes
+        # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; tools/pmc_summ.py) and committed under profiles/
+        traffic, traffic_src = None, None
+        pmc_file = os.path.join(ROOT, "profiles", "r01", "b_pmc.json")
+        if a.log2_samples == 28 and os.path.exists(pmc_file):
+            try:
+                traffic = round(json.load(open(pmc_file))["_derived"]["traffic_bytes_per_launch"])
+                traffic_src = "profiles/r01/b_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+            except Exception:
+                traffic = None
         value = shard.job_throughput(n, a.steps, dt, world) / 1e6
         achieved = ALGO_BYTES_PER_SAMPLE * n / kern_avg_s / 1e9
         res = {
@@ -156,13 +166,14 @@ def main():
                        "samples_per_gpu_per_step": n, "fir_taps": 64, "resample": "3/2", "arch": arch,
                        "parallelism": f"{world} independent stream(s), no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "rx_pipe_fused_kernel<PipeCfg<64,3,2,8,0,16,256>>",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch",
+                         "traffic_source": traffic_src,
+                         "kernel": "rx_pipe_fused_kernel<PipeCfg<64,3,2,8,MODE_IQ,16,256,FFA>, SMI_WORDS, S1G>",
                          "kernel_ms_avg": round(kern_avg_s * 1e3, 4), "kernel_ms_min": round(float(np.min(kern_ms)), 4),
                          "kernel_ms_each": [round(float(v), 3) for v in kern_ms],
                          "algorithmic_bytes_per_sample": ALGO_BYTES_PER_SAMPLE,
-                         "valu_tflops": round(FLOP_PER_SAMPLE * n / kern_avg_s / 1e12, 2),
-                         "valu_frac_of_fp32_peak": round(FLOP_PER_SAMPLE * n / kern_avg_s / 1e12 / VALU_PEAK_TFLOPS, 4)},
+                         "algorithmic_tflops": round(FLOP_PER_SAMPLE * n / kern_avg_s / 1e12, 2),
+                         "algorithmic_frac_of_fp32_valu_peak": round(FLOP_PER_SAMPLE * n / kern_avg_s / 1e12 / VALU_PEAK_TFLOPS, 4)},
         }
         if world == 1 and not a.no_cpu:
             cb, cpu_out = cpu_baseline(taps, words, a.cpu_seconds)
