@@ -65,13 +65,60 @@ __device__ __forceinline__ void matvec(const double *__restrict__ m, const doubl
     }
 }
 
+// A tile is IIR_TILE segments x IIR_SEG samples = 16384 int16 pairs (64 KiB).  Lanes walk their own
+// segment sequentially, so direct global access would touch 64 cache lines per load instruction;
+// instead the tile is copied through LDS: coalesced 16-byte global accesses on one side, a
+// (IIR_SEG+1)-dword row pitch on the other so that lane t reading word k of row t hits bank (t+k)%32.
+#define IIR_PITCH (IIR_SEG + 1)
+#define IIR_LDS_WORDS (IIR_TILE * IIR_PITCH)
+
+__device__ __forceinline__ void iir_tile_load(const uint32_t *__restrict__ x, long n_left, uint32_t *sm, int t)
+{
+    // n_left = samples of this stream from the tile start (>= 1); words beyond it are not read
+    constexpr int TOTAL = IIR_TILE * IIR_SEG;
+    const bool vec = ((uintptr_t)x & 15) == 0;
+    for (int i = t * 4; i < TOTAL; i += IIR_TILE * 4) {
+        uint32_t w[4] = {0, 0, 0, 0};
+        if (vec && i + 4 <= n_left) {
+            const u32x4 v = *(const u32x4 *)(x + i);
+            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+        } else {
+            for (int k = 0; k < 4; k++) if (i + k < n_left) w[k] = x[i + k];
+        }
+        const int row = i / IIR_SEG, col = i % IIR_SEG;          // 4 consecutive words stay in one row
+        for (int k = 0; k < 4; k++) sm[row * IIR_PITCH + col + k] = w[k];
+    }
+}
+
+__device__ __forceinline__ void iir_tile_store(uint32_t *__restrict__ x, long n_left, const uint32_t *sm, int t)
+{
+    constexpr int TOTAL = IIR_TILE * IIR_SEG;
+    const bool vec = ((uintptr_t)x & 15) == 0;
+    for (int i = t * 4; i < TOTAL; i += IIR_TILE * 4) {
+        const int row = i / IIR_SEG, col = i % IIR_SEG;
+        uint32_t w[4];
+        for (int k = 0; k < 4; k++) w[k] = sm[row * IIR_PITCH + col + k];
+        if (vec && i + 4 <= n_left) {
+            u32x4 v = {w[0], w[1], w[2], w[3]};
+            *(u32x4 *)(x + i) = v;
+        } else {
+            for (int k = 0; k < 4; k++) if (i + k < n_left) x[i + k] = w[k];
+        }
+    }
+}
+
 // pass 1: zero-state response of every segment.  ws_seg[stream][seg][rail][dim]
 __global__ __launch_bounds__(IIR_TILE) void iir_pass1_kernel(IirCoef c, const uint32_t *__restrict__ iq, long stride,
                                                            long n, long n_seg, double *__restrict__ ws_seg)
 {
-    const long seg = (long)blockIdx.x * IIR_TILE + threadIdx.x;
+    extern __shared__ uint32_t iir_sm[];
+    const int t = threadIdx.x;
+    const long tile0 = (long)blockIdx.x * IIR_TILE * IIR_SEG;
+    iir_tile_load(iq + (long)blockIdx.y * stride + tile0, n - tile0, iir_sm, t);
+    __syncthreads();
+    const long seg = (long)blockIdx.x * IIR_TILE + t;
     if (seg >= n_seg) return;
-    const uint32_t *x = iq + (long)blockIdx.y * stride + seg * IIR_SEG;
+    const uint32_t *x = iir_sm + t * IIR_PITCH;
     const long cnt = n - seg * IIR_SEG < IIR_SEG ? n - seg * IIR_SEG : IIR_SEG;
     double zi[IIR_MAX_DIM], zq[IIR_MAX_DIM];
 #pragma unroll
@@ -86,18 +133,12 @@ __global__ __launch_bounds__(IIR_TILE) void iir_pass1_kernel(IirCoef c, const ui
     for (int k = 0; k < IIR_MAX_DIM; k++) { o[k] = zi[k]; o[IIR_MAX_DIM + k] = zq[k]; }
 }
 
-// pass 2a: inclusive scan inside each tile (zero carry), in place:
-//   E[i] = sum_{j<=i} P^(i-j) zs[j]     powers[d] = P^(2^d)
-__global__ __launch_bounds__(IIR_TILE) void iir_pass2a_kernel(const double *__restrict__ pow2, long n_seg,
-                                                            double *__restrict__ ws_seg)
+// Kogge-Stone inclusive scan over the 256 lanes of a workgroup for the recurrence
+//   v_i <- v_i + M^(2^d) v_(i - 2^d),   pow2[d] = M^(2^d)
+// leaving v_i = sum_{j<=i} M^(i-j) v_j (both rails).  sh: [IIR_TILE][2*IIR_MAX_DIM+1] doubles.
+__device__ __forceinline__ void ks_scan(double (&v)[2 * IIR_MAX_DIM], const double *__restrict__ pow2,
+                                        double (*sh)[2 * IIR_MAX_DIM + 1], int t)
 {
-    __shared__ double sh[IIR_TILE][2 * IIR_MAX_DIM + 1];
-    const int t = threadIdx.x;
-    const long seg = (long)blockIdx.x * IIR_TILE + t;
-    double *o = ws_seg + ((long)blockIdx.y * n_seg + seg) * 2 * IIR_MAX_DIM;
-    double v[2 * IIR_MAX_DIM];
-#pragma unroll
-    for (int k = 0; k < 2 * IIR_MAX_DIM; k++) v[k] = seg < n_seg ? o[k] : 0.0;
     for (int d = 0; d < 8; d++) {
 #pragma unroll
         for (int k = 0; k < 2 * IIR_MAX_DIM; k++) sh[t][k] = v[k];
@@ -117,44 +158,77 @@ __global__ __launch_bounds__(IIR_TILE) void iir_pass2a_kernel(const double *__re
         }
         __syncthreads();
     }
+}
+
+// pass 2a: inclusive scan inside each tile (zero carry), in place:
+//   E[i] = sum_{j<=i} P^(i-j) zs[j]     pow2[d] = P^(2^d)
+__global__ __launch_bounds__(IIR_TILE) void iir_pass2a_kernel(const double *__restrict__ pow2, long n_seg,
+                                                            double *__restrict__ ws_seg)
+{
+    __shared__ double sh[IIR_TILE][2 * IIR_MAX_DIM + 1];
+    const int t = threadIdx.x;
+    const long seg = (long)blockIdx.x * IIR_TILE + t;
+    double *o = ws_seg + ((long)blockIdx.y * n_seg + seg) * 2 * IIR_MAX_DIM;
+    double v[2 * IIR_MAX_DIM];
+#pragma unroll
+    for (int k = 0; k < 2 * IIR_MAX_DIM; k++) v[k] = seg < n_seg ? o[k] : 0.0;
+    ks_scan(v, pow2, sh, t);
     if (seg < n_seg) {
 #pragma unroll
         for (int k = 0; k < 2 * IIR_MAX_DIM; k++) o[k] = v[k];
     }
 }
 
-// pass 2b: chain the tiles of one stream: carry[0] = state_in; carry[k+1] = Q carry[k] + E[last seg of tile k]
-// one workgroup per stream; lane r < 2*dim owns one state component.
-__global__ __launch_bounds__(64) void iir_pass2b_kernel(int dim, const double *__restrict__ qmat /* P^TILE */,
-                                                        const double *__restrict__ ppow /* P^i, i<=TILE */,
-                                                        long n_seg, long n_tiles, const double *__restrict__ ws_seg,
-                                                        double *__restrict__ carry, double *__restrict__ state)
+// pass 2b: chain the tiles of one stream.  carry[k] = state entering tile k:
+//   carry[0] = state_in,  carry[k+1] = Q carry[k] + E[last segment of tile k],  Q = P^TILE
+// The same scan one level up: 256 tiles per step with Q^(2^d), then Q^(i+1) times the step's
+// carry-in.  One workgroup per stream; a 2^26-sample stream is 16 steps.
+__global__ __launch_bounds__(IIR_TILE) void iir_pass2b_kernel(const double *__restrict__ qpow2 /* Q^(2^d) */,
+                                                            const double *__restrict__ qpow /* Q^i, i<=TILE */,
+                                                            long n_seg, long n_tiles, const double *__restrict__ ws_seg,
+                                                            double *__restrict__ carry, const double *__restrict__ state)
 {
-    __shared__ double cur[2][IIR_MAX_DIM];
+    __shared__ double sh[IIR_TILE][2 * IIR_MAX_DIM + 1];
+    __shared__ double cc[2 * IIR_MAX_DIM];
     const int s = blockIdx.x, t = threadIdx.x;
-    const int rail = t / IIR_MAX_DIM, r = t % IIR_MAX_DIM;
-    const bool act = t < 2 * IIR_MAX_DIM && r < dim;
-    double *st = state + (long)s * 2 * IIR_MAX_DIM;
-    if (t < 2 * IIR_MAX_DIM) cur[rail][r] = r < dim ? st[rail * IIR_MAX_DIM + r] : 0.0;
+    if (t < 2 * IIR_MAX_DIM) cc[t] = state[(long)s * 2 * IIR_MAX_DIM + t];
     __syncthreads();
-    for (long k = 0; k < n_tiles; k++) {
-        double *c = carry + ((long)s * n_tiles + k) * 2 * IIR_MAX_DIM;
-        if (t < 2 * IIR_MAX_DIM) c[t] = cur[rail][r];
-        const long first = k * IIR_TILE;
-        const long cnt = n_seg - first < IIR_TILE ? n_seg - first : IIR_TILE;      // segments in this tile
-        // state after the tile = P^cnt * carry + E[first + cnt - 1]
-        const double *m = cnt == IIR_TILE ? qmat : ppow + cnt * IIR_MAX_DIM * IIR_MAX_DIM;
-        double nv = 0.0;
-        if (act) {
-            for (int cc = 0; cc < dim; cc++) nv += m[r * IIR_MAX_DIM + cc] * cur[rail][cc];
-            nv += ws_seg[((long)s * n_seg + first + cnt - 1) * 2 * IIR_MAX_DIM + rail * IIR_MAX_DIM + r];
+    for (long base = 0; base < n_tiles; base += IIR_TILE) {
+        const long tile = base + t;
+        double v[2 * IIR_MAX_DIM];
+        // E of the tile's last segment (a ragged last tile only feeds the unused carry after the stream)
+        const long last = (tile + 1) * IIR_TILE - 1 < n_seg ? (tile + 1) * IIR_TILE - 1 : n_seg - 1;
+#pragma unroll
+        for (int k = 0; k < 2 * IIR_MAX_DIM; k++)
+            v[k] = tile < n_tiles ? ws_seg[((long)s * n_seg + last) * 2 * IIR_MAX_DIM + k] : 0.0;
+        ks_scan(v, qpow2, sh, t);
+        // state entering tile+1 = v + Q^(t+1) * carry-in of this step
+        double c[2 * IIR_MAX_DIM], add[IIR_MAX_DIM];
+#pragma unroll
+        for (int k = 0; k < 2 * IIR_MAX_DIM; k++) c[k] = cc[k];
+        const double *m = qpow + (long)(t + 1) * IIR_MAX_DIM * IIR_MAX_DIM;
+        matvec(m, c, add);
+#pragma unroll
+        for (int k = 0; k < IIR_MAX_DIM; k++) v[k] += add[k];
+        matvec(m, c + IIR_MAX_DIM, add);
+#pragma unroll
+        for (int k = 0; k < IIR_MAX_DIM; k++) v[IIR_MAX_DIM + k] += add[k];
+        double *cr = carry + ((long)s * (n_tiles + 1)) * 2 * IIR_MAX_DIM;
+        if (t == 0) {
+#pragma unroll
+            for (int k = 0; k < 2 * IIR_MAX_DIM; k++) cr[base * 2 * IIR_MAX_DIM + k] = c[k];
+        }
+        if (tile + 1 <= n_tiles && tile < n_tiles) {
+#pragma unroll
+            for (int k = 0; k < 2 * IIR_MAX_DIM; k++) cr[(tile + 1) * 2 * IIR_MAX_DIM + k] = v[k];
         }
         __syncthreads();
-        if (t < 2 * IIR_MAX_DIM) cur[rail][r] = nv;
+        if (t == IIR_TILE - 1) {
+#pragma unroll
+            for (int k = 0; k < 2 * IIR_MAX_DIM; k++) cc[k] = v[k];
+        }
         __syncthreads();
     }
-    // NOTE: with a ragged last segment the "state after the tile" above would be wrong (the last
-    // segment is shorter than SEG); pass 3 therefore writes the true final state itself.
 }
 
 // pass 3: true start state per segment, re-run, write int16 in place; the lane
@@ -164,39 +238,47 @@ __global__ __launch_bounds__(IIR_TILE) void iir_pass3_kernel(IirCoef c, uint32_t
                                                            const double *__restrict__ ws_seg,
                                                            const double *__restrict__ carry, double *__restrict__ state)
 {
+    extern __shared__ uint32_t iir_sm[];
     const int t = threadIdx.x;
+    const long tile0 = (long)blockIdx.x * IIR_TILE * IIR_SEG;
+    uint32_t *xt = iq + (long)blockIdx.y * stride + tile0;
+    iir_tile_load(xt, n - tile0, iir_sm, t);
+    __syncthreads();
     const long seg = (long)blockIdx.x * IIR_TILE + t;
-    if (seg >= n_seg) return;
-    const double *cr = carry + ((long)blockIdx.y * n_tiles + blockIdx.x) * 2 * IIR_MAX_DIM;
-    const double *m = ppow + (long)t * IIR_MAX_DIM * IIR_MAX_DIM;          // P^t
-    double zi[IIR_MAX_DIM], zq[IIR_MAX_DIM], cv[IIR_MAX_DIM];
+    if (seg < n_seg) {
+        const double *cr = carry + ((long)blockIdx.y * (n_tiles + 1) + blockIdx.x) * 2 * IIR_MAX_DIM;
+        const double *m = ppow + (long)t * IIR_MAX_DIM * IIR_MAX_DIM;          // P^t
+        double zi[IIR_MAX_DIM], zq[IIR_MAX_DIM], cv[IIR_MAX_DIM];
 #pragma unroll
-    for (int k = 0; k < IIR_MAX_DIM; k++) { zi[k] = 0.0; zq[k] = 0.0; }
+        for (int k = 0; k < IIR_MAX_DIM; k++) { zi[k] = 0.0; zq[k] = 0.0; }
 #pragma unroll
-    for (int k = 0; k < IIR_MAX_DIM; k++) cv[k] = cr[k];
-    matvec(m, cv, zi);
+        for (int k = 0; k < IIR_MAX_DIM; k++) cv[k] = cr[k];
+        matvec(m, cv, zi);
 #pragma unroll
-    for (int k = 0; k < IIR_MAX_DIM; k++) cv[k] = cr[IIR_MAX_DIM + k];
-    matvec(m, cv, zq);
-    if (t > 0) {
-        const double *e = ws_seg + ((long)blockIdx.y * n_seg + seg - 1) * 2 * IIR_MAX_DIM;
+        for (int k = 0; k < IIR_MAX_DIM; k++) cv[k] = cr[IIR_MAX_DIM + k];
+        matvec(m, cv, zq);
+        if (t > 0) {
+            const double *e = ws_seg + ((long)blockIdx.y * n_seg + seg - 1) * 2 * IIR_MAX_DIM;
 #pragma unroll
-        for (int k = 0; k < IIR_MAX_DIM; k++) { zi[k] += e[k]; zq[k] += e[IIR_MAX_DIM + k]; }
+            for (int k = 0; k < IIR_MAX_DIM; k++) { zi[k] += e[k]; zq[k] += e[IIR_MAX_DIM + k]; }
+        }
+        uint32_t *x = iir_sm + t * IIR_PITCH;
+        const long cnt = n - seg * IIR_SEG < IIR_SEG ? n - seg * IIR_SEG : IIR_SEG;
+        for (long k = 0; k < cnt; k++) {
+            const uint32_t w = x[k];
+            // filter((float)x): int16 -> float -> double is exact
+            const double yi = iir_step(c, zi, (double)(int16_t)(w & 0xFFFF));
+            const double yq = iir_step(c, zq, (double)(int16_t)(w >> 16));
+            x[k] = iir_to_i16(yi) | (iir_to_i16(yq) << 16);
+        }
+        if (seg == n_seg - 1) {
+            double *st = state + (long)blockIdx.y * 2 * IIR_MAX_DIM;
+#pragma unroll
+            for (int k = 0; k < IIR_MAX_DIM; k++) { st[k] = zi[k]; st[IIR_MAX_DIM + k] = zq[k]; }
+        }
     }
-    uint32_t *x = iq + (long)blockIdx.y * stride + seg * IIR_SEG;
-    const long cnt = n - seg * IIR_SEG < IIR_SEG ? n - seg * IIR_SEG : IIR_SEG;
-    for (long k = 0; k < cnt; k++) {
-        const uint32_t w = x[k];
-        // filter((float)x): int16 -> float -> double is exact
-        const double yi = iir_step(c, zi, (double)(int16_t)(w & 0xFFFF));
-        const double yq = iir_step(c, zq, (double)(int16_t)(w >> 16));
-        x[k] = iir_to_i16(yi) | (iir_to_i16(yq) << 16);
-    }
-    if (seg == n_seg - 1) {
-        double *st = state + (long)blockIdx.y * 2 * IIR_MAX_DIM;
-#pragma unroll
-        for (int k = 0; k < IIR_MAX_DIM; k++) { st[k] = zi[k]; st[IIR_MAX_DIM + k] = zq[k]; }
-    }
+    __syncthreads();
+    iir_tile_store(xt, n - tile0, iir_sm, t);
 }
 
 // ---------------------------------------------------------------------------
@@ -218,6 +300,8 @@ struct IirPlan {
     IirCoef coef;
     double pow2[8][IIR_MAX_DIM * IIR_MAX_DIM];              // P^(2^d)
     double ppow[IIR_TILE + 1][IIR_MAX_DIM * IIR_MAX_DIM];   // P^i
+    double qpow2[8][IIR_MAX_DIM * IIR_MAX_DIM];             // Q^(2^d), Q = P^TILE
+    double qpow[IIR_TILE + 1][IIR_MAX_DIM * IIR_MAX_DIM];   // Q^i
 };
 
 static void iir_plan_build(const double *sos, int n_stages, IirPlan *pl)
@@ -245,6 +329,11 @@ static void iir_plan_build(const double *sos, int n_stages, IirPlan *pl)
     for (int d = 1; d < 8; d++) mat_mul(dim, pl->pow2[d - 1], pl->pow2[d - 1], pl->pow2[d]);
     for (int r = 0; r < dim; r++) pl->ppow[0][r * IIR_MAX_DIM + r] = 1.0;
     for (int i = 1; i <= IIR_TILE; i++) mat_mul(dim, pl->ppow[i - 1], P, pl->ppow[i]);
+    const double *Q = pl->ppow[IIR_TILE];
+    memcpy(pl->qpow2[0], Q, sizeof pl->qpow2[0]);
+    for (int d = 1; d < 8; d++) mat_mul(dim, pl->qpow2[d - 1], pl->qpow2[d - 1], pl->qpow2[d]);
+    for (int r = 0; r < dim; r++) pl->qpow[0][r * IIR_MAX_DIM + r] = 1.0;
+    for (int i = 1; i <= IIR_TILE; i++) mat_mul(dim, pl->qpow[i - 1], Q, pl->qpow[i]);
 }
 
 extern "C" size_t clhip_iir_workspace_bytes(size_t n_samples, int n_stages)
@@ -293,14 +382,21 @@ extern "C" int clhip_iir_cs16_batch(const double *h_sos, int n_stages, double *d
     double *carry = ws_seg + n_seg * n_streams * 2 * IIR_MAX_DIM;
     const double *d_pow2 = &d_plan->pow2[0][0];
     const double *d_ppow = &d_plan->ppow[0][0];
-    const double *d_q = &d_plan->ppow[IIR_TILE][0];
+    const double *d_qpow2 = &d_plan->qpow2[0][0];
+    const double *d_qpow = &d_plan->qpow[0][0];
     dim3 grid((unsigned)n_tiles, n_streams), block(IIR_TILE);
-    hipLaunchKernelGGL(iir_pass1_kernel, grid, block, 0, s, plan.coef, (const uint32_t *)d_iq, (long)stride_samples,
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void *)iir_pass1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, IIR_LDS_WORDS * 4);
+        (void)hipFuncSetAttribute((const void *)iir_pass3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, IIR_LDS_WORDS * 4);
+        attr = true;
+    }
+    hipLaunchKernelGGL(iir_pass1_kernel, grid, block, IIR_LDS_WORDS * 4, s, plan.coef, (const uint32_t *)d_iq, (long)stride_samples,
                        (long)n_samples, (long)n_seg, ws_seg);
     hipLaunchKernelGGL(iir_pass2a_kernel, grid, block, 0, s, d_pow2, (long)n_seg, ws_seg);
-    hipLaunchKernelGGL(iir_pass2b_kernel, dim3(n_streams), dim3(64), 0, s, plan.coef.dim, d_q, d_ppow, (long)n_seg,
-                       (long)n_tiles, ws_seg, carry, d_state);
-    hipLaunchKernelGGL(iir_pass3_kernel, grid, block, 0, s, plan.coef, (uint32_t *)d_iq, (long)stride_samples,
+    hipLaunchKernelGGL(iir_pass2b_kernel, dim3(n_streams), dim3(IIR_TILE), 0, s, d_qpow2, d_qpow, (long)n_seg,
+                       (long)n_tiles, ws_seg, carry, (const double *)d_state);
+    hipLaunchKernelGGL(iir_pass3_kernel, grid, block, IIR_LDS_WORDS * 4, s, plan.coef, (uint32_t *)d_iq, (long)stride_samples,
                        (long)n_samples, (long)n_seg, (long)n_tiles, d_ppow, ws_seg, carry, d_state);
     CLHIP_CHECK_LAUNCH();
     return 0;

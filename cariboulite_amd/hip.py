@@ -165,9 +165,9 @@ class RxPipe:
             raise RuntimeError("clhip_rx_pipe_create failed: " + last_error())
 
     def close(self):
-        if self.h:
-            lib().clhip_rx_pipe_destroy(self.h)
-            self.h = None
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.clhip_rx_pipe_destroy(self.h)
+        self.h = None
 
     __del__ = close
 
@@ -229,9 +229,9 @@ class TxPipe:
             raise RuntimeError("clhip_tx_pipe_create failed: " + last_error())
 
     def close(self):
-        if self.h:
-            lib().clhip_tx_pipe_destroy(self.h)
-            self.h = None
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.clhip_tx_pipe_destroy(self.h)
+        self.h = None
 
     __del__ = close
 
