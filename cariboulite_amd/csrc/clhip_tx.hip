@@ -177,6 +177,116 @@ __global__ __launch_bounds__(FM_BLOCK) void fm_apply_kernel(const float *__restr
         if (base + k < n) oo[base + k] = phasor(excl + v[k]);
 }
 
+__device__ __forceinline__ uint32_t tx_f2i16(float v)
+{
+    const int t = (v >= -2147483648.0f && v < 2147483648.0f) ? (int)v : (int)0x80000000;
+    return (uint32_t)t & 0xFFFFu;
+}
+
+__device__ __forceinline__ uint32_t tx_pack_word(int mode, uint32_t ii, uint32_t qq)
+{
+    if (mode == CL_TX_AS_WRITTEN) { ii = 0xFFFFu; qq = 0; }       // caribou_smi.c:700-701
+    ii &= 0x1FFFu; qq &= 0x1FFFu;
+    const uint32_t s = (0x7u << 29) | ((ii >> 8) << 24) | (((ii >> 1) & 0x7Fu) << 16) | ((ii & 1u) << 14) |
+                       ((qq >> 7) << 8) | (qq & 0x7Fu);
+    return __builtin_bswap32(s);
+}
+
+// pass 3 fused with the TX tail (config 5): per 1024-message block
+//   phase scan + offset -> phasors (kept in LDS, with the KP-1 samples before the block)
+//   -> L/M polyphase leg per output -> (int16_t)(f*4096.0f) -> 13-bit pack -> one 4-byte store.
+// The modulated CF32 signal never goes to HBM.  Samples before the block come from the carried
+// history (first block of a call) or are rebuilt backwards from the block's phase offset.
+#define TXF_HMAX 8
+__global__ __launch_bounds__(FM_BLOCK) void tx_fm_fused_kernel(
+    const float *__restrict__ m, long m_stride, size_t n, double w, const double *__restrict__ boff, long n_blocks,
+    const f32x2 *__restrict__ hist_in, f32x2 *__restrict__ hist_out, int H,
+    const float *__restrict__ rs, int n_rs, int L, int M, unsigned long long n0, long n_out, int pack_mode,
+    uint32_t *__restrict__ words, long w_stride, f32x2 *__restrict__ tap, long tap_stride)
+{
+    __shared__ double sh[FM_BLOCK / 64];
+    __shared__ f32x2 xs[TXF_HMAX + FM_ELEMS];          // xs[TXF_HMAX + i] = modulated sample base+i
+    const int s = blockIdx.y, t = threadIdx.x;
+    const float *mm = m + (long)s * m_stride;
+    const size_t base = (size_t)blockIdx.x * FM_ELEMS, tb = base + (size_t)t * FM_PER_THREAD;
+    const double off = boff[(long)s * n_blocks + blockIdx.x];      // phase after sample base-1
+    double v[FM_PER_THREAD], sum = 0.0;
+#pragma unroll
+    for (int k = 0; k < FM_PER_THREAD; k++) {
+        sum += (tb + k < n) ? w * (double)mm[tb + k] : 0.0;
+        v[k] = sum;
+    }
+    double incl = sum;
+    const int lane = t & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
+    }
+    if (lane == 63) sh[t >> 6] = incl;
+    // the H samples before the block
+    if (t < H) {
+        const int k = t + 1;                             // sample base - k
+        f32x2 hv;
+        if (base >= (size_t)k) {                         // inside this call: phase = off - sum of the k-1 increments after it
+            double ph = off;
+            for (int i = 1; i < k; i++) ph -= w * (double)mm[base - i];
+            hv = phasor(ph);
+        } else {                                         // before this call: carried history (oldest first, H entries)
+            const long idx = (long)H - (long)(k - (long)base);
+            hv = idx >= 0 ? hist_in[(long)s * H + idx] : f32x2{0.f, 0.f};
+        }
+        xs[TXF_HMAX - k] = hv;
+    }
+    __syncthreads();
+    double wave_off = 0.0;
+    for (int k = 0; k < (t >> 6); k++) wave_off += sh[k];
+    const double excl = off + wave_off + (incl - sum);
+#pragma unroll
+    for (int k = 0; k < FM_PER_THREAD; k++)
+        xs[TXF_HMAX + t * FM_PER_THREAD + k] = (tb + k < n) ? phasor(excl + v[k]) : f32x2{0.f, 0.f};
+    __syncthreads();
+    // history for the next call: the last H modulated samples of the stream
+    if (H > 0 && base + FM_ELEMS >= n && t < H) {
+        const long g = (long)n - H + t;                  // sample index inside this call
+        const long rel = g - (long)base;                 // relative to this block
+        f32x2 hv;
+        if (rel >= -TXF_HMAX) hv = xs[TXF_HMAX + rel];
+        else hv = f32x2{0.f, 0.f};                       // call shorter than H spanning >1 block cannot happen (H <= 7 < FM_ELEMS)
+        if (g < 0) {                                     // call shorter than H: shift the old history
+            const long idx = (long)H + g;
+            hv = idx >= 0 ? hist_in[(long)s * H + idx] : f32x2{0.f, 0.f};
+        }
+        hist_out[(long)s * H + t] = hv;
+    }
+    // outputs whose newest input sample lies in this block: b in [base, base + FM_ELEMS) and b < n
+    const unsigned long long g0 = n0 + base, g1 = n0 + ((base + FM_ELEMS < n) ? base + FM_ELEMS : n);
+    const unsigned long long m_first = (g0 * L + M - 1) / M, m_end = (g1 * L + M - 1) / M;
+    const unsigned long long m_call0 = (n0 * L + M - 1) / M;
+    const int KP = (n_rs + L - 1) / L;
+    // 64-bit index arithmetic once per block (uniform); 32-bit per output:
+    //   mo*M - g0*L = r0 + dm*M with r0 = m_first*M - g0*L in [0, M)
+    const unsigned r0 = (unsigned)(m_first * M - g0 * L);
+    const unsigned n_mo = (unsigned)(m_end - m_first);
+    for (unsigned dm = t; dm < n_mo; dm += FM_BLOCK) {
+        const unsigned long long mo = m_first + dm;
+        const unsigned tp = r0 + dm * (unsigned)M;
+        const int b = (int)(tp / (unsigned)L);           // newest input, relative to the block
+        const int p = (int)(tp % (unsigned)L);
+        f32x2 acc = {0.f, 0.f};
+        for (int i = 0; i < KP; i++) {
+            const int k = p + i * L;
+            if (k >= n_rs) break;
+            acc += xs[TXF_HMAX + b - i] * rs[k];
+        }
+        const long j = (long)(mo - m_call0);
+        if (j < n_out) {
+            if (tap) tap[(long)s * tap_stride + j] = acc;
+            words[(long)s * w_stride + j] = tx_pack_word(pack_mode, tx_f2i16(acc.x * 4096.0f), tx_f2i16(acc.y * 4096.0f));
+        }
+    }
+}
+
 extern "C" size_t clhip_fm_mod_workspace_bytes(size_t n) { return (clhip_div_up(n, FM_ELEMS) + 2) * sizeof(double); }
 
 static int fm_mod_launch(const float *d_msg, long m_stride, size_t n, int n_streams, double w, double *d_phase,
@@ -224,21 +334,6 @@ struct clhip_tx_pipe {
     f32x2 *Y; size_t y_cap;          // modulated signal workspace (per stream)
     double *ws; size_t ws_cap;
 };
-
-__device__ __forceinline__ uint32_t tx_f2i16(float v)
-{
-    const int t = (v >= -2147483648.0f && v < 2147483648.0f) ? (int)v : (int)0x80000000;
-    return (uint32_t)t & 0xFFFFu;
-}
-
-__device__ __forceinline__ uint32_t tx_pack_word(int mode, uint32_t ii, uint32_t qq)
-{
-    if (mode == CL_TX_AS_WRITTEN) { ii = 0xFFFFu; qq = 0; }       // caribou_smi.c:700-701
-    ii &= 0x1FFFu; qq &= 0x1FFFu;
-    const uint32_t s = (0x7u << 29) | ((ii >> 8) << 24) | (((ii >> 1) & 0x7Fu) << 16) | ((ii & 1u) << 14) |
-                       ((qq >> 7) << 8) | (qq & 0x7Fu);
-    return __builtin_bswap32(s);
-}
 
 // one output per lane: upfirdn polyphase leg -> quantise -> pack
 __global__ __launch_bounds__(256) void tx_resample_pack_kernel(const f32x2 *__restrict__ x, long x_stride,
@@ -355,7 +450,32 @@ extern "C" long clhip_tx_pipe_run(clhip_tx_pipe *p, int in_kind, const void *d_i
     const int H = p->kp - 1;
     const f32x2 *x = (const f32x2 *)d_in;
     long x_stride = (long)in_stride;
-    if (in_kind == CL_TXPIPE_IN_FM_MESSAGE) {
+    if (in_kind == CL_TXPIPE_IN_FM_MESSAGE && H <= TXF_HMAX - 1) {
+        // fused path: block sums -> block scan -> phasor + resample + quantise + pack in one kernel
+        const long n_blocks = (long)clhip_div_up(n_in, FM_ELEMS);
+        const size_t wsn = (size_t)(n_blocks + 2) * p->n_streams + 8;
+        if (wsn > p->ws_cap) {
+            clhip_free(p->ws);
+            p->ws = (double *)clhip_malloc(sizeof(double) * wsn);
+            p->ws_cap = p->ws ? wsn : 0;
+            if (!p->ws) return -1;
+        }
+        dim3 grid((unsigned)n_blocks, p->n_streams);
+        double *phase_new = p->ws + (size_t)n_blocks * p->n_streams;
+        hipLaunchKernelGGL(fm_block_sum_kernel, grid, dim3(FM_BLOCK), 0, s, (const float *)d_in, (long)in_stride, n_in,
+                           p->w, p->ws, n_blocks);
+        hipLaunchKernelGGL(fm_block_scan_kernel, dim3(p->n_streams), dim3(256), 0, s, p->ws, n_blocks, p->d_phase, phase_new);
+        hipLaunchKernelGGL(tx_fm_fused_kernel, grid, dim3(FM_BLOCK), 0, s, (const float *)d_in, (long)in_stride, n_in, p->w,
+                           p->ws, n_blocks, p->hist[p->cur], p->hist[p->cur ^ 1], H, p->d_rs, p->n_rs, p->L, p->M,
+                           p->n_total, (long)n_out, p->pack_mode, (uint32_t *)d_bytes, (long)(out_stride_bytes / 4),
+                           (f32x2 *)d_iq_tap, (long)iq_tap_stride);
+        CLHIP_CHECK(hipMemcpyAsync(p->d_phase, phase_new, sizeof(double) * p->n_streams, hipMemcpyDeviceToDevice, s));
+        CLHIP_CHECK_LAUNCH();
+        if (H > 0) p->cur ^= 1;
+        p->n_total += n_in;
+        return (long)n_out;
+    }
+    if (in_kind == CL_TXPIPE_IN_FM_MESSAGE) {           // long resampler history: unfused fallback
         if (n_in > p->y_cap) {
             clhip_free(p->Y);
             p->Y = (f32x2 *)clhip_malloc(sizeof(f32x2) * n_in * p->n_streams);
