@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--settle", type=int, default=40, help="untimed steps before the warm-up (DVFS settle)")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal on one GPU)")
     return ap.parse_args()
 
 
@@ -87,16 +88,22 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with --nproc-per-node {a.gpus} (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible")
+    if os.environ.get("CLHIP_BENCH_ALL_ON_GPU0"):          # rehearsal of the N>1 path on a one-GPU box (gloo)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist = None
+    dist, red_dev = None, dev
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)       # RCCL; used only for barrier + max
+        if a.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # RCCL; used only for barrier + max
+        else:
+            dist.init_process_group(a.dist_backend)
+            red_dev = torch.device("cpu")
         # build the communicator NOW: a lazy first barrier right before the timed region would idle the GPU
         # for seconds and restart the DVFS transient
         dist.barrier()
-        dist.all_reduce(torch.zeros(1, dtype=torch.float64, device=dev), op=dist.ReduceOp.MAX)
+        dist.all_reduce(torch.zeros(1, dtype=torch.float64, device=red_dev), op=dist.ReduceOp.MAX)
 
     from cariboulite_amd import hip, synth
     arch = hip.require_gpu()
@@ -144,7 +151,7 @@ def main():
         L.clhip_event_record(evs[k][1], stream)
 
     # barrier + synchronize on both sides, EXACTLY `steps` steps, max over ranks
-    dt = shard.timed_steps(timed_step, a.steps, sync_fn=torch.cuda.synchronize, dist=dist, device=dev)
+    dt = shard.timed_steps(timed_step, a.steps, sync_fn=torch.cuda.synchronize, dist=dist, device=red_dev)
     assert int(bad.item()) == 0 and int(offs.abs().max().item()) == 0, "synthetic stream lost sync?"
     kern_ms = [L.clhip_event_elapsed_ms(e0, e1) for e0, e1 in evs]
     for e0, e1 in evs:
