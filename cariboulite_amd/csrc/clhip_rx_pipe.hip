@@ -54,6 +54,7 @@ struct PipeArgs {
     int grid_int;            // workgroups [0, grid_int) are persistent interior workers, the rest edge workers
     int halo;                // history samples per stream
     f32x2 *hist_out;         // [n_streams][halo] history for the NEXT call (ping-pong with hist_in)
+    unsigned long long *diag; // diagnostic build only: per-wave cycle sums per phase [grid*4][8]
     int channel;             // CL_CHANNEL_*
     float in_scale;          // 4096 for integer inputs (taps carry 1/4096), 1 for CF32
     const float *fir;        // T taps, pre-multiplied by 1/in_scale (device, read-only)
@@ -559,10 +560,15 @@ __device__ __forceinline__ void rx_pipe_edge_worker(const PipeArgs &a, unsigned 
 // into registers while the current one computes, so HBM latency hides under the FIR.
 // One kernel per (config, input kind, channel type): each gets its own register allocation.
 // ---------------------------------------------------------------------------
-template <class C, int KIND, bool HIF>
+// s_memtime stamp (diagnostic build only; the shipped kernels execute none)
+#define DIAG_STAMP(T) do { if constexpr (DIAG) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(T) :: "memory"); __builtin_amdgcn_sched_barrier(0); } } while (0)
+
+template <class C, int KIND, bool HIF, bool DIAG = false>
 __global__ __launch_bounds__(C::NT, KIND == CL_PIPE_IN_CF32 ? 3 : 4)      // integer inputs: 4 waves/SIMD (<= 128 VGPRs)
 void rx_pipe_fused_kernel(const PipeArgs a)
 {
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0, ts6 = 0;
+    unsigned long long d_stage = 0, d_bar0 = 0, d_fir = 0, d_second = 0, d_store = 0, d_bar2 = 0, d_tiles = 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int OB = C::MODE == MODE_FM ? 4 : 8, PL = C::NOUT * OB / 16;
     const int n_edge_wg = a.n_edge * a.n_streams;
@@ -594,8 +600,11 @@ void rx_pipe_fused_kernel(const PipeArgs a)
         const long S = (long)tile * C::TILE_IN;              // first new input of this tile
         const bool bad = tile_sync_bad<C>(a, s, S);
 
+        DIAG_STAMP(ts0);
         tile_regs_to_lds<C, KIND, HIF>(regs, lds, t);
+        DIAG_STAMP(ts1);
         __syncthreads();
+        DIAG_STAMP(ts2);
         if (item + step < items) {                           // prefetch the next item's raw words
             const int nx = item + step, sn = nx / per_stream, tn = 1 + nx % per_stream;
             const void *inn = KIND == CL_PIPE_IN_CF32 ? (const void *)((const f32x2 *)a.in + (long)sn * a.in_stride)
@@ -605,11 +614,34 @@ void rx_pipe_fused_kernel(const PipeArgs a)
         f32x2 acc[C::R];
         f32x4 pc[PL];
         if constexpr (C::FFA) fir_tile_ffa<C>(lds, t, fir, acc); else fir_tile<C>(lds, t, fir, acc);
+        if constexpr (DIAG) {                                // pin the phase's results before its stamp
+#pragma unroll
+            for (int k = 0; k < C::R; k++) asm volatile("" : "+v"(acc[k]));
+        }
+        DIAG_STAMP(ts3);
         second_stage<C>(lds, t, rs, acc, pc);
+        if constexpr (DIAG) {
+#pragma unroll
+            for (int k = 0; k < PL; k++) asm volatile("" : "+v"(pc[k]));
+        }
+        DIAG_STAMP(ts4);
         const long tile_e0 = C::MODE == MODE_FM ? (S - C::HFA) : (S - C::HFA) / C::M * C::L;
         const long lo = C::MODE == MODE_FM ? S : S / C::M * C::L;
         if (!bad) store_tile<C, false>(lds, t, (unsigned char *)a.out + (long)s * a.out_stride * OB, tile_e0, lo, 0, pc);
+        DIAG_STAMP(ts5);
         __syncthreads();                                     // the next item's staging overwrites this LDS
+        DIAG_STAMP(ts6);
+        if constexpr (DIAG) {
+            d_stage += ts1 - ts0; d_bar0 += ts2 - ts1; d_fir += ts3 - ts2; d_second += ts4 - ts3;
+            d_store += ts5 - ts4; d_bar2 += ts6 - ts5; d_tiles += 1;
+        }
+    }
+    if constexpr (DIAG) {
+        if (a.diag && (threadIdx.x & 63) == 0) {
+            unsigned long long *o = a.diag + ((size_t)blockIdx.x * (C::NT / 64) + (threadIdx.x >> 6)) * 8;
+            o[0] = d_stage; o[1] = d_bar0; o[2] = d_fir; o[3] = d_second; o[4] = d_store; o[5] = d_bar2; o[6] = d_tiles;
+            o[7] = __builtin_amdgcn_s_memrealtime();
+        }
     }
 }
 
@@ -746,6 +778,7 @@ struct clhip_rx_pipe {
     float *d_fir, *d_fir_int, *d_rs;   // taps; d_fir_int = taps/4096 for integer inputs
     float *d_ffa, *d_ffa_int;          // [H0 | H1 | H0+H1] for the 2-parallel fast FIR, same two scalings
     bool ffa;                          // the selected fused instantiation uses them
+    unsigned long long *diag;          // optional stamp buffer (diagnostic kernel build)
     f32x2 *X, *Y;
     size_t x_cap, y_cap;           // elements per stream
 };
@@ -841,6 +874,10 @@ extern "C" void clhip_rx_pipe_reset(clhip_rx_pipe *p)
 
 extern "C" void clhip_rx_pipe_force_generic(clhip_rx_pipe *p, int on) { p->force_generic = on != 0; }
 
+// Diagnostic only (tools/phase_stamps.py): run config 2 through the s_memtime-stamped build of the fused
+// kernel; d_buf receives, per wave, the cycle sums of {stage, barrier, FIR, second stage, store, barrier, tiles}.
+extern "C" void clhip_rx_pipe_set_diag(clhip_rx_pipe *p, unsigned long long *d_buf) { p->diag = d_buf; }
+
 extern "C" void clhip_rx_pipe_set_sync_check(clhip_rx_pipe *p, const int32_t *d_offs, size_t chunk_samples,
                                              int32_t *d_bad_flag)
 {
@@ -865,7 +902,7 @@ extern "C" int clhip_rx_pipe_uses_fused(const clhip_rx_pipe *p, size_t n_in, int
     return 1;
 }
 
-template <class C, int KIND, bool HIF>
+template <class C, int KIND, bool HIF, bool DIAG = false>
 static int launch_pipe(PipeArgs &a, hipStream_t s)
 {
     const long items = (long)(a.n_int - 1) * a.n_streams;
@@ -873,12 +910,12 @@ static int launch_pipe(PipeArgs &a, hipStream_t s)
     // blockIdx.x, +grid_int, ...; edge workers follow in the same launch
     static int resident = 0;
     if (!resident) {
-        (void)hipFuncSetAttribute((const void *)rx_pipe_fused_kernel<C, KIND, HIF>,
+        (void)hipFuncSetAttribute((const void *)rx_pipe_fused_kernel<C, KIND, HIF, DIAG>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         int dev = 0, cus = 256, per_cu = 0;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)rx_pipe_fused_kernel<C, KIND, HIF>,
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)rx_pipe_fused_kernel<C, KIND, HIF, DIAG>,
                                                          C::NT, C::LDS_BYTES) != hipSuccess || per_cu < 1)
             per_cu = 2;
         // the API under-reports here (LDS 4 x 37.5 KB and 4 waves/SIMD both fit); an oversubscribed
@@ -892,7 +929,7 @@ static int launch_pipe(PipeArgs &a, hipStream_t s)
     }
     a.grid_int = (int)(items < resident ? items : resident);
     const unsigned grid = (unsigned)a.grid_int + (unsigned)a.n_edge * a.n_streams;
-    hipLaunchKernelGGL((rx_pipe_fused_kernel<C, KIND, HIF>), dim3(grid), dim3(C::NT), C::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((rx_pipe_fused_kernel<C, KIND, HIF, DIAG>), dim3(grid), dim3(C::NT), C::LDS_BYTES, s, a);
     CLHIP_CHECK_LAUNCH();
     return 0;
 }
@@ -910,6 +947,9 @@ static int launch_fused(PipeArgs &a, hipStream_t s)
     a.n_edge = (int)(1 + (tiles - n_int));                  // tile 0 + the tail tiles
     switch (a.in_kind) {
     case CL_PIPE_IN_SMI_WORDS:
+        if constexpr (C::FFA && C::T == 64 && C::L == 3) {      // the one diagnostic (stamped) instantiation
+            if (a.diag && a.channel != CL_CHANNEL_HIF) return launch_pipe<C, CL_PIPE_IN_SMI_WORDS, false, true>(a, s);
+        }
         return a.channel == CL_CHANNEL_HIF ? launch_pipe<C, CL_PIPE_IN_SMI_WORDS, true>(a, s)
                                            : launch_pipe<C, CL_PIPE_IN_SMI_WORDS, false>(a, s);
     case CL_PIPE_IN_CS16: return launch_pipe<C, CL_PIPE_IN_CS16, false>(a, s);
@@ -951,7 +991,7 @@ extern "C" long clhip_rx_pipe_run(clhip_rx_pipe *p, int in_kind, const void *d_i
     a.out = d_out; a.out_stride = (long)out_stride;
     a.n_in = (long)n_in; a.n_out = (long)n_out;
     a.in_kind = in_kind; a.channel = p->channel; a.n_streams = p->n_streams;
-    a.halo = p->halo; a.hist_out = p->hist[p->cur ^ 1];
+    a.halo = p->halo; a.hist_out = p->hist[p->cur ^ 1]; a.diag = p->diag;
     a.in_scale = in_kind == CL_PIPE_IN_CF32 ? 1.0f : 4096.0f;
     a.fir = in_kind == CL_PIPE_IN_CF32 ? p->d_fir : p->d_fir_int;
     const float *ffa_taps = in_kind == CL_PIPE_IN_CF32 ? p->d_ffa : p->d_ffa_int;

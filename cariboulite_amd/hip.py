@@ -58,6 +58,7 @@ _SIGS = {
     "clhip_rx_pipe_uses_fused": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int]),
     "clhip_rx_pipe_run": (C.c_long, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
     "clhip_rx_pipe_force_generic": (None, [C.c_void_p, C.c_int]),
+    "clhip_rx_pipe_set_diag": (None, [C.c_void_p, C.c_void_p]),
     "clhip_rx_pipe_set_sync_check": (None, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "clhip_tx_pipe_create": (C.c_void_p, [C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "clhip_tx_pipe_destroy": (None, [C.c_void_p]),
@@ -182,6 +183,10 @@ class RxPipe:
 
     def force_generic(self, on=True):
         lib().clhip_rx_pipe_force_generic(self.h, int(on))
+
+    def set_diag(self, d_buf):
+        self._diag = d_buf
+        lib().clhip_rx_pipe_set_diag(self.h, ptr(d_buf))
 
     def set_sync_check(self, d_offs, chunk_samples, d_bad_flag):
         self._chk = (d_offs, d_bad_flag)          # keep the tensors alive

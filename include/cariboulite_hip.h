@@ -182,6 +182,8 @@ int    clhip_rx_pipe_uses_fused(const clhip_rx_pipe *p, size_t n_in, int in_kind
  * Returns outputs per stream (>= 0) or a negative error. */
 long   clhip_rx_pipe_run(clhip_rx_pipe *p, int in_kind, const void *d_in, size_t in_stride_elems,
                          size_t n_in, void *d_out, size_t out_stride_elems, void *stream);
+/* diagnostic: route config 2 through the s_memtime-stamped build (tools/phase_stamps.py); NULL = off */
+void   clhip_rx_pipe_set_diag(clhip_rx_pipe *p, unsigned long long *d_buf);
 /* force the multi-kernel generic path (second implementation, used by tests) */
 void   clhip_rx_pipe_force_generic(clhip_rx_pipe *p, int on);
 /* Device-side sync validation for CL_PIPE_IN_SMI_WORDS runs: d_offs holds the
