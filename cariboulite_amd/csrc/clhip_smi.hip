@@ -402,3 +402,84 @@ extern "C" int clhip_smi_pack(int mode, const int16_t *d_iq, size_t n, uint8_t *
     CLHIP_CHECK_LAUNCH();
     return 0;
 }
+
+// ---------------------------------------------------------------------------
+// link-integrity (debug) modes: caribou_smi.c:172-215 (analyse), :266-283 (search)
+//   LFSR  : every byte must be lfsr(previous byte) and non-zero (smi_utils.c:220-224)
+//   push / pull : every word must be 0xABCDEF01; the search accepts < 4 flipped bits
+// res[0] = offs (-1: none), res[1] = erroneous bytes, res[2] = first error (byte index, -1: none),
+// res[3] = last byte seen (carried into the next call's LFSR check)
+// ---------------------------------------------------------------------------
+#define SMI_DEBUG_WORD 0xABCDEF01u
+
+__global__ __launch_bounds__(256) void smi_debug_find_kernel(int mode, const uint8_t *__restrict__ p, size_t len,
+                                                             uint32_t last_in, int32_t *__restrict__ res)
+{
+    __shared__ int s_found;
+    const int tid = threadIdx.x;
+    if (tid == 0) { res[1] = 0; res[2] = 0x7fffffff; res[3] = (int32_t)last_in; s_found = 0x7fffffff; }
+    __syncthreads();
+    if (len <= 16 || mode == 1 /* lfsr: no search */) {
+        if (tid == 0) res[0] = 0;
+        return;
+    }
+    const size_t limit = len - 4;                    // :268  offs < len - BYTES_PER_SAMPLE
+    for (size_t base = 0; base < limit; base += 256) {
+        const size_t o = base + tid;
+        if (o < limit && __popc(ld_u32_bytes(p + o) ^ SMI_DEBUG_WORD) < 4) atomicMin(&s_found, (int)o);
+        __syncthreads();
+        const int f = s_found;
+        __syncthreads();
+        if (f != 0x7fffffff) break;
+    }
+    if (tid == 0) res[0] = s_found == 0x7fffffff ? -1 : s_found;
+}
+
+__global__ __launch_bounds__(256) void smi_debug_count_kernel(int mode, const uint8_t *__restrict__ data, size_t len,
+                                                              uint32_t last_in, int32_t *__restrict__ res)
+{
+    const int offs = res[0];
+    if (offs < 0) return;
+    const size_t shortening = offs > 0 ? (size_t)(offs / 4 + 1) : 0;     // caribou_smi.c:319
+    const size_t alen = len - 4 * shortening;
+    const uint8_t *p = data + offs;
+    size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    unsigned cnt = 0;
+    int first = 0x7fffffff;
+    if (mode == 1) {
+        for (size_t i = k; i < alen; i += step) {
+            const uint32_t prev = i ? p[i - 1] : last_in;
+            const uint32_t want = ((prev >> 1) | ((((prev >> 2) ^ (prev >> 3)) & 1u) << 7)) & 0xFFu;
+            if (p[i] != want || p[i] == 0) { cnt++; if ((int)i < first) first = (int)i; }
+        }
+        if (k == 0 && alen) res[3] = p[alen - 1];
+    } else {
+        for (size_t i = k; i < alen / 4; i += step)
+            if (ld_u32_bytes(p + 4 * i) != SMI_DEBUG_WORD) { cnt += 4; if ((int)(4 * i) < first) first = (int)(4 * i); }
+    }
+    // wave-level reduction, one atomic per wave
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        cnt += __shfl_down(cnt, o, 64);
+        const int f2 = __shfl_down(first, o, 64);
+        first = f2 < first ? f2 : first;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (cnt) atomicAdd((unsigned *)&res[1], cnt);
+        if (first != 0x7fffffff) atomicMin(&res[2], first);
+    }
+}
+
+extern "C" int clhip_smi_debug_analyze(int mode, const uint8_t *d_bytes, size_t len, uint32_t last_correct_byte,
+                                       int32_t *d_res, void *stream)
+{
+    if (mode < 1 || mode > 3 || !d_bytes || !d_res) { clhip_set_error("clhip_smi_debug_analyze: bad arguments"); return -1; }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(smi_debug_find_kernel, dim3(1), dim3(256), 0, s, mode, d_bytes, len, last_correct_byte, d_res);
+    unsigned grid = (unsigned)clhip_div_up(len ? len : 1, 256 * 16);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(smi_debug_count_kernel, dim3(grid), dim3(256), 0, s, mode, d_bytes, len, last_correct_byte, d_res);
+    CLHIP_CHECK_LAUNCH();
+    return 0;
+}

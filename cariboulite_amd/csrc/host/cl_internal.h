@@ -47,6 +47,9 @@ struct cl_smi {
     uint8_t *h_stage; size_t h_stage_cap; /* pinned host staging */
     int32_t *d_offs; size_t offs_cap; int32_t *h_offs; size_t h_offs_cap;
     cl_chunk *chunks; size_t chunks_cap, n_chunks;
+    int debug_mode;               /* caribou_smi_debug_mode_en */
+    cl_smi_debug_data debug_data;
+    int32_t *d_dbg; int32_t *h_dbg; /* 4 ints each */
     /* statistics (SURVEY.md section 5 "Metrics"): */
     uint64_t stat_samples, stat_resyncs, stat_sync_failures;
     char err[256];

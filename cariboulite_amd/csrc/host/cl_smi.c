@@ -95,7 +95,7 @@ int cl_smi_close(cl_smi *dev)
     clhip_set_device(dev->device);
     clhip_stream_sync(dev->stream);
     clhip_free(dev->d_bytes); clhip_free(dev->d_iq); clhip_free(dev->d_meta); clhip_free(dev->d_offs);
-    clhip_host_free(dev->h_stage); clhip_host_free(dev->h_offs);
+    clhip_host_free(dev->h_stage); clhip_host_free(dev->h_offs); clhip_free(dev->d_dbg); clhip_host_free(dev->h_dbg);
     free(dev->chunks);
     cl_fifo_free(&dev->rx); cl_fifo_free(&dev->tx);
     clhip_stream_destroy(dev->stream);
@@ -109,6 +109,40 @@ void   cl_smi_set_max_read(cl_smi *dev, size_t m) { dev->max_read = m; }
 size_t cl_smi_drain_bytes(cl_smi *dev, uint8_t *b, size_t max) { return cl_fifo_pop(&dev->tx, b, max); }
 void   cl_smi_set_tx_mode(cl_smi *dev, int mode) { dev->tx_mode = mode; }
 size_t cl_smi_get_native_batch_samples(cl_smi *dev) { return dev->native_batch_len / CL_BYTES_PER_SAMPLE; }
+void   cl_smi_set_debug_mode(cl_smi *dev, int mode) { dev->debug_mode = mode; }       /* caribou_smi.c:612-615 */
+const cl_smi_debug_data *cl_smi_get_debug_data(const cl_smi *dev) { return &dev->debug_data; }
+
+/* debug modes: one chunk is read and analysed, then the call returns -2 (caribou_smi.c:650-675) */
+static int cl_smi_read_debug(cl_smi *dev, size_t length_samples)
+{
+    clhip_set_device(dev->device);
+    size_t left = length_samples * CL_BYTES_PER_SAMPLE;
+    if (!left) return 0;
+    size_t cur = left > dev->native_batch_len ? dev->native_batch_len : left;
+    if (dev->max_read && cur > dev->max_read) cur = dev->max_read;
+    if (cl_ensure((void **)&dev->h_stage, &dev->h_stage_cap, cur + 256, 1, 1) ||
+        cl_ensure((void **)&dev->d_bytes, &dev->bytes_cap, cur + 256, 1, 0))
+        return CL_SMI_ERR_IO;
+    if (!dev->d_dbg) { dev->d_dbg = (int32_t *)clhip_malloc(16); dev->h_dbg = (int32_t *)clhip_host_alloc(16); }
+    if (!dev->d_dbg || !dev->h_dbg) return CL_SMI_ERR_IO;
+    const size_t ret = cl_fifo_pop(&dev->rx, dev->h_stage, cur);
+    if (ret == 0) return 0;                                   /* "Reading timed-out" */
+    if (clhip_memcpy_h2d(dev->d_bytes, dev->h_stage, ret, dev->stream) ||
+        clhip_smi_debug_analyze(dev->debug_mode, dev->d_bytes, ret, dev->debug_data.last_correct_byte, dev->d_dbg, dev->stream) ||
+        clhip_memcpy_d2h(dev->h_dbg, dev->d_dbg, 16, dev->stream) || clhip_stream_sync(dev->stream))
+        return CL_SMI_ERR_IO;
+    const int offs = dev->h_dbg[0];
+    if (offs < 0) { dev->stat_sync_failures++; return CL_SMI_ERR_SYNC; }            /* :665-668 */
+    const size_t shortening = offs > 0 ? (size_t)(offs / 4 + 1) : 0;
+    const size_t alen = ret - 4 * shortening;
+    cl_smi_debug_data *d = &dev->debug_data;                  /* caribou_smi.c:188-214 */
+    d->cur_err_cnt = (uint32_t)dev->h_dbg[1];
+    d->error_accum_counter += d->cur_err_cnt;
+    d->last_correct_byte = (uint8_t)dev->h_dbg[3];
+    d->error_rate = d->error_rate * 0.9 + (double)d->cur_err_cnt / (double)alen * 0.1;
+    if (d->error_rate < 1e-8) d->error_rate = 0.0;
+    return CL_SMI_ERR_DEBUGMODE;
+}
 
 /* --------------------------------------------------------------- RX path */
 int cl_smi_read_device(cl_smi *dev, int channel, size_t length_samples, int want_meta, int *all_aligned)
@@ -210,6 +244,7 @@ int cl_smi_copy_out(cl_smi *dev, cl_sample_complex_int16 *buffer, cl_sample_meta
 int cl_smi_read(cl_smi *dev, int channel, cl_sample_complex_int16 *buffer, cl_sample_meta *metadata, size_t length_samples)
 {
     if (!dev) return CL_SMI_ERR_IO;
+    if (dev->debug_mode != CL_SMI_DEBUG_NONE) return cl_smi_read_debug(dev, length_samples);
     int ret = cl_smi_read_device(dev, channel, length_samples, metadata != NULL, NULL);
     if (ret == CL_SMI_ERR_SYNC) { cl_smi_copy_out(dev, buffer, metadata, -1); return ret; }
     if (ret <= 0) return ret;

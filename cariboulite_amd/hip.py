@@ -46,6 +46,7 @@ _SIGS = {
                                    C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "clhip_convert_from_cs16": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]),
     "clhip_convert_to_cs16": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "clhip_smi_debug_analyze": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p]),
     "clhip_smi_pack": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "clhip_iir_cs16": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
     "clhip_iir_workspace_bytes": (C.c_size_t, [C.c_size_t, C.c_int]),

@@ -36,6 +36,8 @@ _SIGS = {
     "cl_smi_read": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
     "cl_smi_write": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
     "cl_smi_get_native_batch_samples": (C.c_size_t, [C.c_void_p]),
+    "cl_smi_set_debug_mode": (None, [C.c_void_p, C.c_int]),
+    "cl_smi_get_debug_data": (C.c_void_p, [C.c_void_p]),
     "cl_radio_create": (C.c_void_p, [C.c_void_p, C.c_int]),
     "cl_radio_destroy": (None, [C.c_void_p]),
     "cl_radio_read_samples": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -105,6 +107,11 @@ def design_butter_lowpass(order, fs_hz, fc_hz):
     return out
 
 
+class SmiDebugData(C.Structure):
+    _fields_ = [("error_accum_counter", C.c_uint32), ("cur_err_cnt", C.c_uint32),
+                ("last_correct_byte", C.c_uint8), ("error_rate", C.c_double)]
+
+
 class StreamResult:
     def __init__(self, ret, flags=0, timeNs=0):
         self.ret, self.flags, self.timeNs = ret, flags, timeNs
@@ -146,6 +153,13 @@ class Device:
         out = np.empty(max_bytes, dtype=np.uint8)
         n = lib().cl_smi_drain_bytes(self.smi, out.ctypes.data, max_bytes)
         return out[:n].copy()
+
+    def setSmiDebugMode(self, mode):
+        lib().cl_smi_set_debug_mode(self.smi, mode)
+
+    def smiDebugData(self):
+        d = C.cast(lib().cl_smi_get_debug_data(self.smi), C.POINTER(SmiDebugData)).contents
+        return (d.error_accum_counter, d.cur_err_cnt, d.last_correct_byte, d.error_rate)
 
     # ---- lower seam (caribou_smi_read / caribou_smi_write)
     def smiRead(self, channel, n, want_meta=True, fill=-21846):

@@ -129,6 +129,19 @@ int clhip_smi_unpack(int channel, const uint8_t *d_bytes, size_t total_bytes,
                      const int32_t *d_offs, int format, void *d_out, uint8_t *d_meta,
                      void *stream);
 
+/*
+ * Link-integrity (debug) modes -- replaces caribou_smi_anayze_smi_debug and the debug branches of
+ * caribou_smi_find_buffer_offset (caribou_smi.c:172-215, 266-283) for one read() chunk.
+ * mode = CL_SMI_DEBUG_LFSR / _PUSH / _PULL.  d_res (4 x int32, device): [0] sync offset (-1 none),
+ * [1] erroneous bytes in the chunk, [2] first erroneous byte (0x7fffffff none), [3] last byte seen.
+ */
+#define CL_SMI_DEBUG_NONE 0   /* caribou_smi.h:22-28 caribou_smi_debug_mode_en */
+#define CL_SMI_DEBUG_LFSR 1
+#define CL_SMI_DEBUG_PUSH 2
+#define CL_SMI_DEBUG_PULL 3
+int clhip_smi_debug_analyze(int mode, const uint8_t *d_bytes, size_t len, uint32_t last_correct_byte,
+                            int32_t *d_res, void *stream);
+
 /* RX/TX format conversions on native CS16 (CaribouliteStream.cpp:199-244,304-367) */
 int clhip_convert_from_cs16(const int16_t *d_iq, size_t n_samples, int format, void *d_out, void *stream);
 int clhip_convert_to_cs16(const void *d_in, int format, size_t n_samples, int16_t *d_iq, void *stream);
@@ -243,6 +256,16 @@ int     cl_smi_read(cl_smi *dev, int channel, cl_sample_complex_int16 *buffer,
                     cl_sample_meta *metadata, size_t length_samples);
 /* caribou_smi_write caribou_smi.c:720-762 */
 int     cl_smi_write(cl_smi *dev, int channel, cl_sample_complex_int16 *buffer, size_t length_samples);
+/* caribou_smi_set_debug_mode caribou_smi.c:612-615; in a debug mode cl_smi_read analyses ONE chunk,
+ * updates the counters and returns CL_SMI_ERR_DEBUGMODE (-2), like caribou_smi.c:670-675 */
+typedef struct {                /* caribou_smi_debug_data_st (caribou_smi.h:30-39) minus the wall-clock fields */
+    uint32_t error_accum_counter;
+    uint32_t cur_err_cnt;
+    uint8_t  last_correct_byte;
+    double   error_rate;
+} cl_smi_debug_data;
+void    cl_smi_set_debug_mode(cl_smi *dev, int cl_smi_debug_mode);
+const cl_smi_debug_data *cl_smi_get_debug_data(const cl_smi *dev);
 /* caribou_smi_get_native_batch_samples caribou_smi.c:765-769 */
 size_t  cl_smi_get_native_batch_samples(cl_smi *dev);
 

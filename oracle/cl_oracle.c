@@ -581,3 +581,51 @@ size_t orc_rx_pipe_f32_mt(int channel, const uint8_t *bytes, size_t n_bytes, siz
     }
     return n_out;
 }
+
+/* ======================================================================== */
+/* Link-integrity (debug) modes -- SURVEY.md section 8(f) rank 3            */
+/* ======================================================================== */
+static unsigned popcount32(uint32_t x) { unsigned c = 0; while (x) { c += x & 1u; x >>= 1; } return c; }
+
+/* smi_utils.c:220-224 */
+uint8_t orc_lfsr(uint8_t n)
+{
+    uint8_t bit = ((n >> 2) ^ (n >> 3)) & 1;
+    return (uint8_t)((n >> 1) | (bit << 7));
+}
+
+/* caribou_smi.c:235-292, debug branches (:266-283): push/pull search the first byte offset whose
+ * unaligned word is within 3 bit flips of 0xABCDEF01; lfsr mode does not search. */
+int orc_debug_find_offset(int mode, const uint8_t *buffer, size_t len)
+{
+    if (len <= ORC_BYTES_PER_SAMPLE * 4) return 0;
+    if (mode == ORC_DEBUG_LFSR) return 0;
+    for (size_t offs = 0; offs < len - ORC_BYTES_PER_SAMPLE; offs++)
+        if (popcount32(ld_u32_le(buffer + offs) ^ 0xABCDEF01u) < 4) return (int)offs;
+    return -1;
+}
+
+/* caribou_smi_rx_data_analyze (:295-330) + caribou_smi_anayze_smi_debug (:172-215) for one read()
+ * chunk; the wall-clock bitrate EMA is not modelled.  Returns offs (or -1). */
+int orc_debug_analyze(orc_debug_data *d, int mode, const uint8_t *data, size_t len)
+{
+    int offs = orc_debug_find_offset(mode, data, len);
+    if (offs < 0) return -1;
+    size_t shortening = offs > 0 ? (size_t)(offs / ORC_BYTES_PER_SAMPLE + 1) : 0;
+    size_t alen = len - shortening * ORC_BYTES_PER_SAMPLE;
+    const uint8_t *p = data + offs;
+    uint32_t cur = 0;
+    if (mode == ORC_DEBUG_LFSR) {
+        for (size_t i = 0; i < alen; i++) {
+            if (p[i] != orc_lfsr(d->last_correct_byte) || p[i] == 0) { d->error_accum_counter++; cur++; }
+            d->last_correct_byte = p[i];
+        }
+    } else {
+        for (size_t i = 0; i < alen / 4; i++)
+            if (ld_u32_le(p + 4 * i) != 0xABCDEF01u) { d->error_accum_counter += 4; cur += 4; }
+    }
+    d->cur_err_cnt = cur;
+    d->error_rate = d->error_rate * 0.9 + (double)cur / (double)alen * 0.1;
+    if (d->error_rate < 1e-8) d->error_rate = 0.0;
+    return offs;
+}

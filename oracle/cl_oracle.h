@@ -113,6 +113,21 @@ size_t orc_rx_pipe_f32(int channel, const uint8_t *bytes, size_t n_bytes,
                        uint64_t *rs_n_in, int16_t *tmp_iq, float *tmp_cf32,
                        float *tmp_fir, float *out);
 
+/* ---- link-integrity (debug) modes: caribou_smi.h:22-28, caribou_smi.c:172-215,266-283 ---- */
+#define ORC_DEBUG_NONE 0
+#define ORC_DEBUG_LFSR 1
+#define ORC_DEBUG_PUSH 2
+#define ORC_DEBUG_PULL 3
+typedef struct {
+    uint32_t error_accum_counter;
+    uint32_t cur_err_cnt;
+    uint8_t last_correct_byte;
+    double error_rate;
+} orc_debug_data;
+uint8_t orc_lfsr(uint8_t n);
+int orc_debug_find_offset(int mode, const uint8_t *buffer, size_t len);
+int orc_debug_analyze(orc_debug_data *d, int mode, const uint8_t *data, size_t len);
+
 size_t orc_rx_pipe_f32_mt(int channel, const uint8_t *bytes, size_t n_bytes, size_t native_batch_len,
                           const float *fir_taps, int fir_n, const float *rs_taps, int rs_n, int L, int M,
                           int16_t *iq_buf, float *x_buf, float *y_buf, float *out, int n_threads);

@@ -173,6 +173,48 @@ def gen_tx():
                         bytes=orc.ref_generate_data(iq))
 
 
+def gen_debug():
+    """Link-integrity modes through the reference's own caribou_smi_read (returns -2) on files:
+    chained calls carry last_correct_byte / error EMA exactly as caribou_smi_st does."""
+    rng = np.random.default_rng(0xD1A6)
+    nb = 8192
+    res = {}; names = []
+
+    def add(name, mode, stream, n_calls, length_samples):
+        stream = np.ascontiguousarray(stream, np.uint8)
+        state = (0, 0, 0, 0.0)
+        rets, states = [], []
+        pos = 0
+        for _ in range(n_calls):
+            ret, state = orc.ref_debug_read(mode, stream[pos:], length_samples, state, nb)
+            rets.append(ret); states.append(state)
+            pos += min(nb, 4 * length_samples)        # the reference consumes one chunk per call
+        names.append(name)
+        res[f"{name}__bytes"] = stream
+        res[f"{name}__args"] = np.array([mode, n_calls, length_samples, nb], dtype=np.int64)
+        res[f"{name}__rets"] = np.array(rets, dtype=np.int32)
+        res[f"{name}__states"] = np.array([[s[0], s[1], s[2]] for s in states], dtype=np.int64)
+        res[f"{name}__rates"] = np.array([s[3] for s in states], dtype=np.float64)
+
+    lf = orc.lfsr_stream(4 * nb)
+    add("lfsr_clean", orc.DEBUG_LFSR, lf, 4, 4096)
+    bad = lf.copy(); bad[[5, 100, 9000, 9001, 20000]] ^= np.array([1, 0x80, 0xFF, 3, 0x10], np.uint8); bad[12345] = 0
+    add("lfsr_errors", orc.DEBUG_LFSR, bad, 4, 4096)
+    add("lfsr_short_calls", orc.DEBUG_LFSR, bad, 6, 700)
+    add("lfsr_zeros", orc.DEBUG_LFSR, np.zeros(nb, np.uint8), 1, 2048)
+    w = np.full(4 * nb // 4, 0xABCDEF01, np.uint32)
+    add("push_clean", orc.DEBUG_PUSH, w.view(np.uint8), 3, 2048)
+    w2 = w.copy(); w2[[3, 500, 2100, 4000]] ^= np.array([1, 0x80000000, 0xF0F0, 0xFFFFFFFF], np.uint32)
+    add("push_errors", orc.DEBUG_PUSH, w2.view(np.uint8), 3, 2048)
+    add("pull_misaligned_3", orc.DEBUG_PULL, np.concatenate([np.array([9, 8, 7], np.uint8), w2.view(np.uint8)]), 2, 2048)
+    add("push_misaligned_6", orc.DEBUG_PUSH, np.concatenate([rng.integers(0, 256, 6).astype(np.uint8), w2.view(np.uint8)]), 2, 2048)
+    add("push_nosync", orc.DEBUG_PUSH, np.zeros(nb, np.uint8), 1, 2048)
+    add("push_short_16", orc.DEBUG_PUSH, w.view(np.uint8)[:16], 1, 4)
+    res["names"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "smi_debug_cases.npz"), **res)
+    print("debug cases:", len(names))
+
+
 def design_taps():
     t = {}
     t["fir64_c2"] = sg.firwin(64, 1.0e6, window="hamming", fs=4e6)
@@ -230,7 +272,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     orc.build(ref=True)
     assert orc.have_ref(), "compiled reference missing: run in the build container"
-    gen_kat(); gen_rx(); gen_read(); gen_tx(); gen_dsp()
+    gen_kat(); gen_rx(); gen_read(); gen_tx(); gen_debug(); gen_dsp()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

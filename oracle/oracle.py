@@ -277,6 +277,50 @@ def rx_pipe_f32_mt(channel, b, fir_taps, rs_taps, L, M, n_threads, native_batch_
     return out[:no], bufs
 
 
+# ------------------------------------------------------- link-integrity modes
+DEBUG_NONE, DEBUG_LFSR, DEBUG_PUSH, DEBUG_PULL = 0, 1, 2, 3
+
+
+class _Dbg(C.Structure):
+    _fields_ = [("error_accum_counter", C.c_uint32), ("cur_err_cnt", C.c_uint32),
+                ("last_correct_byte", C.c_uint8), ("error_rate", C.c_double)]
+
+
+class DebugState:
+    """caribou_smi_debug_data_st without the wall-clock fields."""
+
+    def __init__(self):
+        self.s = _Dbg(0, 0, 0, 0.0)
+
+    def analyze(self, mode, buf):
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        return lib().orc_debug_analyze(C.byref(self.s), int(mode), _p(buf, C.c_uint8), C.c_size_t(buf.size))
+
+    def tuple(self):
+        return (self.s.error_accum_counter, self.s.cur_err_cnt, self.s.last_correct_byte, self.s.error_rate)
+
+
+def lfsr_stream(n, seed=0x56):
+    out = np.empty(n, dtype=np.uint8)
+    v = seed
+    lib().orc_lfsr.restype = C.c_uint8
+    for i in range(n):
+        v = lib().orc_lfsr(C.c_uint8(v))
+        out[i] = v
+    return out
+
+
+def ref_debug_read(mode, stream_bytes, length_samples, state, native_batch_len=NATIVE_BATCH_LEN):
+    """state = (accum, cur, last_byte, error_rate) -> (ret, new state) through the compiled reference."""
+    b = np.ascontiguousarray(stream_bytes, dtype=np.uint8)
+    a, c, l, r = C.c_uint32(state[0]), C.c_uint32(state[1]), C.c_uint8(state[2]), C.c_double(state[3])
+    with tempfile.NamedTemporaryFile(suffix=".smi") as f:
+        f.write(b.tobytes()); f.flush()
+        ret = ref().ref_debug_read_file(f.name.encode(), int(mode), C.c_size_t(length_samples),
+                                        C.c_size_t(native_batch_len), C.byref(a), C.byref(c), C.byref(l), C.byref(r))
+    return ret, (a.value, c.value, l.value, r.value)
+
+
 # ------------------------------------------------- compiled reference (_ref)
 def ref_find_buffer_offset(buf):
     buf = np.ascontiguousarray(buf, dtype=np.uint8).copy()

@@ -74,3 +74,30 @@ void ref_generate_data(const int16_t *iq, size_t n_samples, uint8_t *out)
     caribou_smi_generate_data(&dev, out, n_samples * CARIBOU_SMI_BYTES_PER_SAMPLE,
                               (caribou_smi_sample_complex_int16 *)iq);
 }
+
+/* caribou_smi_read() in a debug mode on a regular file: returns the reference's return code and
+ * hands back the debug counters it maintains (state carried in/out so calls can be chained). */
+int ref_debug_read_file(const char *path, int mode, size_t length_samples, size_t native_batch_len,
+                        uint32_t *accum, uint32_t *cur, uint8_t *last_byte, double *error_rate)
+{
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return -100;
+    caribou_smi_st dev;
+    ref_dev_init(&dev, fd, native_batch_len);
+    dev.debug_mode = (caribou_smi_debug_mode_en)mode;
+    dev.debug_data.error_accum_counter = *accum;
+    dev.debug_data.cur_err_cnt = *cur;
+    dev.debug_data.last_correct_byte = *last_byte;
+    dev.debug_data.error_rate = *error_rate;
+    gettimeofday(&dev.debug_data.last_time, NULL);
+    int16_t *iq = malloc(4 * (length_samples + 8));
+    int ret = caribou_smi_read(&dev, caribou_smi_channel_900, (caribou_smi_sample_complex_int16 *)iq, NULL, length_samples);
+    *accum = dev.debug_data.error_accum_counter;
+    *cur = dev.debug_data.cur_err_cnt;
+    *last_byte = dev.debug_data.last_correct_byte;
+    *error_rate = dev.debug_data.error_rate;
+    free(iq);
+    ref_dev_free(&dev);
+    close(fd);
+    return ret;
+}

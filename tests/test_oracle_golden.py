@@ -209,3 +209,28 @@ def test_iir_vs_scipy_butter(orc):
         wi = np.trunc(g[f"iir_{bw}k__y_i"]); wq = np.trunc(g[f"iir_{bw}k__y_q"])
         assert np.max(np.abs(out[:, 0] - wi)) <= 1 and np.max(np.abs(out[:, 1] - wq)) <= 1
         assert np.mean(out[:, 0] != wi) < 1e-3
+
+
+# ------------------------------------------------------- link-integrity modes
+def _dbg_names():
+    return [str(n) for n in load_golden("smi_debug_cases.npz")["names"]]
+
+
+@pytest.mark.parametrize("name", _dbg_names())
+def test_debug_modes_vs_reference_fixture(orc, name):
+    """caribou_smi_read in LFSR / push / pull mode (returns -2, caribou_smi.c:670-675): counters,
+    carried byte and error-rate EMA equal the compiled reference's, call after call."""
+    g = load_golden("smi_debug_cases.npz")
+    mode, n_calls, length_samples, nb = [int(v) for v in g[f"{name}__args"]]
+    stream = g[f"{name}__bytes"]
+    st = orc.DebugState()
+    pos = 0
+    for k in range(n_calls):
+        chunk = stream[pos:pos + min(nb, 4 * length_samples)]
+        offs = st.analyze(mode, chunk)
+        want_ret = int(g[f"{name}__rets"][k])
+        assert (-3 if offs < 0 else -2) == want_ret
+        assert list(st.tuple()[:3]) == g[f"{name}__states"][k].tolist()
+        # the EMA is one fp64 multiply-add: the oracle's -march build may fuse it (1 ulp)
+        assert st.tuple()[3] == pytest.approx(float(g[f"{name}__rates"][k]), rel=1e-14, abs=0)
+        pos += chunk.size
