@@ -73,9 +73,27 @@ def build_host(force=False, verbose=False):
     return HOST_LIB
 
 
+CPP_LIB = os.path.join(PKG, "libcariboulite_cpp.so")
+
+
+def build_cpp(force=False, verbose=False):
+    """The C++ API seam (CaribouLiteRadio) over the host C layer."""
+    cdir = os.path.join(CSRC, "cpp_api")
+    srcs = sorted(os.path.join(cdir, f) for f in os.listdir(cdir) if f.endswith(".cpp"))
+    deps = srcs + [os.path.join(cdir, f) for f in os.listdir(cdir) if f.endswith(".hpp")] + [HOST_LIB]
+    if force or _newer(CPP_LIB, deps):
+        cmd = ["g++", "-O2", "-g", "-std=c++14", "-Wall", "-Wextra", "-fPIC", "-shared", "-I", INC, "-I", cdir,
+               "-o", CPP_LIB] + srcs + ["-L", PKG, "-lcariboulite_host", "-lcariboulite_hip", "-Wl,-rpath,$ORIGIN", "-lpthread"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return CPP_LIB
+
+
 def build_all(force=False, verbose=False):
     build_hip(force, verbose)
     build_host(force, verbose)
+    build_cpp(force, verbose)
 
 
 if __name__ == "__main__":

@@ -91,3 +91,13 @@ def test_design_butter_matches_oracle_and_scipy(orc):
         for s in g[f"iir_{bw}k__sos"]:
             den_s = P.polymul(den_s, s[3:])
         assert np.allclose(den, den_s, rtol=1e-9, atol=0)
+
+
+def test_cpp_api_library_exports_the_reference_method_names():
+    from cariboulite_amd import _build
+    _build.build_all()
+    out = subprocess.run(["nm", "-DC", "--defined-only", _build.CPP_LIB], capture_output=True, text=True, check=True).stdout
+    for m in ("CaribouLiteRadio::ReadSamples(std::complex<float>*", "CaribouLiteRadio::ReadSamples(std::complex<short>*",
+              "CaribouLiteRadio::WriteSamples(std::complex<float>*", "CaribouLiteRadio::WriteSamples(std::complex<short>*",
+              "CaribouLiteRadio::StartReceiving(", "CaribouLiteRadio::StopReceiving()", "CaribouLiteRadio::GetNativeMtuSample()"):
+        assert m in out, m
