@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--settle", type=int, default=40, help="untimed steps before the warm-up (DVFS settle)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal on one GPU)")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c4"],
+                    help="c2 (default, the BASELINE.json metric) | c4: 256 streams x 2^24, FIR128 + 5/4, sharded (strong scaling)")
+    ap.add_argument("--fanout", action="store_true", help="c4 only: rank 0 holds all raw buffers and scatters them over xGMI first")
     return ap.parse_args()
 
 
@@ -79,6 +82,54 @@ def cpu_baseline(taps, d_words, budget_s):
                       f"orc_rx_pipe_f32_mt (unpack+sync -> /4096 -> FIR64 -> 3/2, fp32 AVX2, OpenMP)"}, out
 
 
+def bench_c4(a, world, rank, dev, dist, red_dev, arch, taps):
+    """Config 4 (secondary, not the BASELINE metric): 256 independent 4 MS/s streams, FIR128 + 5/4,
+    stream s on rank s mod N, no data-path collective; --fanout adds the one real exchange step
+    (root scatters the raw buffers with direct sends) and reports it separately."""
+    from cariboulite_amd import hip, synth, shard
+    n_streams = 256
+    n = 1 << (24 if a.log2_samples == 28 else a.log2_samples)
+    mine = shard.assign_streams(n_streams, world, rank)
+    fan_s = None
+    if a.fanout and dist is not None:
+        root_buf = None
+        if rank == 0:
+            root_buf = torch.stack([synth.torch_smi_words(n, dev, 0, 100 + s) for s in range(n_streams)])
+        torch.cuda.synchronize(); dist.barrier(); t0 = time.perf_counter()
+        words = shard.fanout_streams(root_buf, n_streams, dist, world, rank, 0, dev, torch.int32, n)
+        torch.cuda.synchronize(); dist.barrier(); fan_s = time.perf_counter() - t0
+        del root_buf
+    else:
+        words = torch.stack([synth.torch_smi_words(n, dev, 0, 100 + s) for s in mine])
+    pipe = hip.RxPipe(len(mine), hip.CHANNEL_S1G, taps["fir128_c4"], taps["rs_5_4"], 5, 4, hip.PIPE_OUT_IQ)
+    no = pipe.out_count(n)
+    out = torch.empty((len(mine), no, 2), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        pipe.run(hip.PIPE_IN_SMI_WORDS, words, n, n, out, no, stream)
+
+    for _ in range(a.settle + a.warmup):
+        step()
+    dt = shard.timed_steps(step, a.steps, sync_fn=torch.cuda.synchronize, dist=dist, device=red_dev)
+    if rank == 0:
+        value = n_streams * n * a.steps / dt / 1e6
+        print(json.dumps({
+            "metric": "Msamples/s through unpack+FIR(128)+resample(5/4) pipe, 256 streams", "value": round(value, 1),
+            "unit": "Msamples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"config 4: 256 streams x 2^{int(np.log2(n))} samples, FIR128 + 5/4, stream s on rank s mod N",
+                       "streams_per_gpu": len(mine), "arch": arch, "fanout_scatter_s": fan_s},
+            "roofline": {"bound": "hbm", "achieved": round(14.0 * n_streams * n * a.steps / dt / 1e9 / world, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s per GPU",
+                         "frac": round(14.0 * n_streams * n * a.steps / dt / 1e9 / world / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_frac_of_fp32_valu_peak": round(552.0 * n_streams * n * a.steps / dt / 1e12 / world / VALU_PEAK_TFLOPS, 4)}}),
+            flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -108,6 +159,8 @@ def main():
     from cariboulite_amd import hip, synth
     arch = hip.require_gpu()
     taps = np.load(os.path.join(ROOT, "tests", "golden", "taps.npz"))
+    if a.workload == "c4":
+        return bench_c4(a, world, rank, dev, dist, red_dev, arch, taps)
 
     n = 1 << a.log2_samples
     n_chunks = n // NATIVE_CHUNK_SAMPLES

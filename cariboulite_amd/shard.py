@@ -46,3 +46,36 @@ def timed_steps(step_fn, steps, sync_fn=None, dist=None, device=None):
 def job_throughput(units_per_rank_per_step, steps, dt_max, world):
     """Whole-job units per second: every rank processed the same per-step units (weak scaling)."""
     return world * units_per_rank_per_step * steps / dt_max
+
+
+def fanout_streams(root_buf, n_streams, dist, world, rank, root=0, device=None, dtype=None, n_elems=None):
+    """The one case with a real exchange step: `root` holds the raw SMI
+    buffers of ALL streams ([n_streams, n_elems]) and hands every rank the streams it owns.
+
+    xGMI is point-to-point (7 links per GPU), so this is a batch of direct sends -- one per
+    (peer, stream block), all posted at once so every link carries traffic concurrently -- not a
+    ring broadcast, which would be bound by a single link.  Returns this rank's [n_local, n_elems]
+    tensor (the root keeps a view of its own rows).
+    """
+    import torch
+    mine = assign_streams(n_streams, world, rank)
+    if rank == root:
+        n_elems, dtype, device = root_buf.shape[1], root_buf.dtype, root_buf.device
+    local = torch.empty((len(mine), n_elems), dtype=dtype, device=device)
+    ops = []
+    if rank == root:
+        for peer in range(world):
+            rows = assign_streams(n_streams, world, peer)
+            if not rows:
+                continue
+            block = root_buf[rows]                      # gather the peer's rows into one contiguous message
+            if peer == root:
+                local.copy_(block)
+            else:
+                ops.append(dist.P2POp(dist.isend, block, peer))
+    elif mine:
+        ops.append(dist.P2POp(dist.irecv, local, root))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return local

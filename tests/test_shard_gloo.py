@@ -79,3 +79,40 @@ def test_assign_streams_config4():
         assert sorted(sum(per, [])) == list(range(256))
     with pytest.raises(ValueError):
         shard.assign_streams(4, 2, 2)
+
+
+def _fanout_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch
+    import torch.distributed as dist
+    from cariboulite_amd import shard
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_streams, n = 5, 4096
+    root_buf = None
+    if rank == 0:
+        root_buf = (torch.arange(n_streams * n, dtype=torch.int32).reshape(n_streams, n) * 7 + 3)
+    local = shard.fanout_streams(root_buf, n_streams, dist, world, rank, root=0, device=torch.device("cpu"),
+                                 dtype=torch.int32, n_elems=n)
+    q.put((rank, shard.assign_streams(n_streams, world, rank), local.numpy().copy()))
+    dist.destroy_process_group()
+
+
+def test_fanout_streams_gloo():
+    """Root holds every stream's raw buffer; each rank ends up with exactly the rows it owns."""
+    import torch.multiprocessing as mp
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_fanout_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=180) for _ in ps]
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    full = (np.arange(5 * 4096, dtype=np.int64).reshape(5, 4096) * 7 + 3).astype(np.int32)
+    for rank, rows, local in res:
+        assert np.array_equal(local, full[rows])
