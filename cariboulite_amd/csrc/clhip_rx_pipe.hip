@@ -77,6 +77,9 @@ struct PipeCfg {
     static constexpr int HFA = HF == 0 ? 0 : round_up(HF, clcm(4, M));      // recomputed per tile
     static constexpr int NFIR = NT * R;             // FIR outputs per tile
     static constexpr int TILE_IN = NFIR - HFA;      // new inputs per tile
+    // FFA: y[0] of a lane needs B[-1] = the previous lane's B[R/2-1].  When the tile's very first FIR output
+    // is never consumed (HFA > HF) it can come by shuffle instead of being recomputed by every lane.
+    static constexpr bool BSHUF = FFA_ && (HFA > HF);
     static constexpr int HALO = T + HFA;            // local 0 <-> global S - HALO
     static constexpr int NLOAD = NFIR + T;          // staged samples
     static constexpr int NOUT = MODE == MODE_FM ? R : R * L / M;             // outputs per lane
@@ -301,8 +304,10 @@ __device__ __forceinline__ void fir_tile(const unsigned char *lds, int t, const 
 // lane instead of 1024 at T=64, R=16.  Same results to rounding (not bit-identical to the direct
 // form: the summation order differs), well inside the 1e-5 bar.  `ffa` = [H0 | H1 | HS], T/2 each.
 template <class C>
-__device__ __forceinline__ void fir_tile_ffa(const unsigned char *lds, int t, const float *ffa, f32x2 (&acc)[C::R])
+__device__ __forceinline__ void fir_tile_ffa(const unsigned char *lds, int t, const float *ffa, f32x2 (&acc)[C::R],
+                                             f32x2 &b_last)
 {
+    constexpr int U0 = C::BSHUF ? 0 : -1;           // first B output computed by this lane
     constexpr int T = C::T, R = C::R, TH = T / 2, RH = R / 2;      // decimated: TH taps, RH outputs, blocks of RH
     static_assert(TH % RH == 0 && R % 4 == 0, "FFA walks the decimated window in blocks of R/2");
     const unsigned char *win = lds + t * C::TSTRIDE;
@@ -324,7 +329,7 @@ __device__ __forceinline__ void fir_tile_ffa(const unsigned char *lds, int t, co
 #define FFA_BLOCK(TAPBASE, LO, HI)                                                          \
     _Pragma("unroll") for (int jj = 0; jj < RH; jj++) {                                     \
         const f32x2 xs = x0[jj] + x1[jj];                                                   \
-        _Pragma("unroll") for (int u = -1; u < RH; u++) {                                   \
+        _Pragma("unroll") for (int u = U0; u < RH; u++) {                                   \
             const int d = (TAPBASE) + u - jj;         /* relative to the block's tap window */ \
             if (d >= (LO) && d <= (HI)) {                                                   \
                 fma2<C::PK>(Bm[u + 1], x1[jj], t1[d - (LO)]);                               \
@@ -350,7 +355,7 @@ __device__ __forceinline__ void fir_tile_ffa(const unsigned char *lds, int t, co
         for (int jj = 0; jj < RH; jj++) {
             const f32x2 xs = x0[jj] + x1[jj];
 #pragma unroll
-            for (int u = -1; u < RH; u++) {
+            for (int u = U0; u < RH; u++) {
                 const int i = RH + u - jj;          // d - (base - RH), always in [0, 2RH-1]
                 fma2<C::PK>(Bm[u + 1], x1[jj], t1[i]);
                 if (u >= 0) { fma2<C::PK>(A[u], x0[jj], t0[i]); fma2<C::PK>(Cc[u], xs, ts[i]); }
@@ -368,9 +373,10 @@ __device__ __forceinline__ void fir_tile_ffa(const unsigned char *lds, int t, co
 #undef FFA_BLOCK
 #pragma unroll
     for (int u = 0; u < RH; u++) {
-        acc[2 * u] = A[u] + Bm[u];                  // A[u] + B[u-1]
+        acc[2 * u] = A[u] + Bm[u];                  // A[u] + B[u-1]   (u = 0 with BSHUF: B[-1] added later)
         acc[2 * u + 1] = Cc[u] - A[u] - Bm[u + 1];  // C[u] - A[u] - B[u]
     }
+    b_last = Bm[RH];
 }
 
 // Second stage: polyphase resampler / FM demod / pass-through from registers.  The HF FIR
@@ -379,7 +385,7 @@ __device__ __forceinline__ void fir_tile_ffa(const unsigned char *lds, int t, co
 // Result: the lane's NOUT output elements as PL 16-byte pieces.
 template <class C>
 __device__ __forceinline__ void second_stage(unsigned char *lds, int t, const float *rs, f32x2 (&acc)[C::R],
-                                             f32x4 (&pc)[C::NOUT * (C::MODE == MODE_FM ? 4 : 8) / 16])
+                                             f32x4 (&pc)[C::NOUT * (C::MODE == MODE_FM ? 4 : 8) / 16], const f32x2 b_last)
 {
     constexpr int R = C::R, L = C::L, M = C::M, KP = C::KP, HF = C::HF, NOUT = C::NOUT;
     constexpr int PL = NOUT * (C::MODE == MODE_FM ? 4 : 8) / 16;
@@ -390,6 +396,7 @@ __device__ __forceinline__ void second_stage(unsigned char *lds, int t, const fl
         if (lane == 63) {
 #pragma unroll
             for (int i = 0; i < HF; i++) tslot[wave * 8 + i] = acc[R - HF + i];
+            if constexpr (C::BSHUF) tslot[wave * 8 + 7] = b_last;      // HF <= 7: slot 7 is free
         }
     }
     __syncthreads();       // FIR reads of the staged tile are done (its LDS is reused below); tail slots visible
@@ -402,6 +409,15 @@ __device__ __forceinline__ void second_stage(unsigned char *lds, int t, const fl
             yh[i].y = __shfl_up(v.y, 1, 64);
             if (lane == 0) yh[i] = tslot[(wave > 0 ? wave - 1 : 0) * 8 + i];   // wave 0 / lane 0: history-only outputs
         }
+    }
+    if constexpr (C::BSHUF) {
+        // y[0] += B[-1]: the previous lane's last B output (the tile's first lane never uses its y[0])
+        static_assert(HF > 0 && HF <= 7, "B hand-off rides in the spare tail slot");
+        f32x2 bp;
+        bp.x = __shfl_up(b_last.x, 1, 64);
+        bp.y = __shfl_up(b_last.y, 1, 64);
+        if (lane == 0) bp = ((const f32x2 *)(lds + C::IN_BYTES))[(wave > 0 ? wave - 1 : 0) * 8 + 7];
+        acc[0] += bp;
     }
 #define YY(i) ((i) < 0 ? yh[HF + (i)] : acc[(i)])
     if constexpr (C::MODE == MODE_IQ) {
@@ -546,8 +562,9 @@ __device__ __forceinline__ void rx_pipe_edge_worker(const PipeArgs &a, unsigned 
     __syncthreads();
     f32x2 acc[C::R];
     f32x4 pc[PL];
-    if constexpr (C::FFA) fir_tile_ffa<C>(lds, t, a.fir, acc); else fir_tile<C>(lds, t, a.fir, acc);
-    second_stage<C>(lds, t, a.rs, acc, pc);
+    f32x2 b_last = {0.f, 0.f};
+    if constexpr (C::FFA) fir_tile_ffa<C>(lds, t, a.fir, acc, b_last); else fir_tile<C>(lds, t, a.fir, acc);
+    second_stage<C>(lds, t, a.rs, acc, pc, b_last);
     const long tile_e0 = C::MODE == MODE_FM ? (S - C::HFA) : (S - C::HFA) / C::M * C::L;
     const long lo = C::MODE == MODE_FM ? S : S / C::M * C::L;
     store_tile<C, true>(lds, t, (unsigned char *)a.out + (long)s * a.out_stride * OB, tile_e0, lo, bad ? 0 : a.n_out, pc);
@@ -613,13 +630,14 @@ void rx_pipe_fused_kernel(const PipeArgs a)
         }
         f32x2 acc[C::R];
         f32x4 pc[PL];
-        if constexpr (C::FFA) fir_tile_ffa<C>(lds, t, fir, acc); else fir_tile<C>(lds, t, fir, acc);
+        f32x2 b_last = {0.f, 0.f};
+        if constexpr (C::FFA) fir_tile_ffa<C>(lds, t, fir, acc, b_last); else fir_tile<C>(lds, t, fir, acc);
         if constexpr (DIAG) {                                // pin the phase's results before its stamp
 #pragma unroll
             for (int k = 0; k < C::R; k++) asm volatile("" : "+v"(acc[k]));
         }
         DIAG_STAMP(ts3);
-        second_stage<C>(lds, t, rs, acc, pc);
+        second_stage<C>(lds, t, rs, acc, pc, b_last);
         if constexpr (DIAG) {
 #pragma unroll
             for (int k = 0; k < PL; k++) asm volatile("" : "+v"(pc[k]));
