@@ -586,6 +586,8 @@ void rx_pipe_fused_kernel(const PipeArgs a)
 {
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0, ts6 = 0;
     unsigned long long d_stage = 0, d_bar0 = 0, d_fir = 0, d_second = 0, d_store = 0, d_bar2 = 0, d_tiles = 0;
+    unsigned long long k_t0 = 0, k_r0 = 0;
+    if constexpr (DIAG) { k_t0 = __builtin_amdgcn_s_memtime(); k_r0 = __builtin_amdgcn_s_memrealtime(); }
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int OB = C::MODE == MODE_FM ? 4 : 8, PL = C::NOUT * OB / 16;
     const int n_edge_wg = a.n_edge * a.n_streams;
@@ -658,7 +660,9 @@ void rx_pipe_fused_kernel(const PipeArgs a)
         if (a.diag && (threadIdx.x & 63) == 0) {
             unsigned long long *o = a.diag + ((size_t)blockIdx.x * (C::NT / 64) + (threadIdx.x >> 6)) * 8;
             o[0] = d_stage; o[1] = d_bar0; o[2] = d_fir; o[3] = d_second; o[4] = d_store; o[5] = d_bar2; o[6] = d_tiles;
-            o[7] = __builtin_amdgcn_s_memrealtime();
+            // shader clock of this wave's lifetime: d(s_memtime) / d(s_memrealtime) x 100 MHz, packed as two 32-bit deltas
+            const unsigned long long dt = __builtin_amdgcn_s_memtime() - k_t0, dr = __builtin_amdgcn_s_memrealtime() - k_r0;
+            o[7] = (dt << 32) | (dr & 0xffffffffull);
         }
     }
 }

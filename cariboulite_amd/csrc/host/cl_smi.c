@@ -144,6 +144,73 @@ static int cl_smi_read_debug(cl_smi *dev, size_t length_samples)
     return CL_SMI_ERR_DEBUGMODE;
 }
 
+/* ------------------------------------------------- file / wire replay front-end */
+/* a /dev/smi-shaped byte source.  Bytes are taken from any fd (regular
+ * file with a recorded capture, pipe, socket) with the reference's own read pattern -- read() of at most
+ * one native batch at a time (caribou_smi.c:466-492), short reads and lengths that are not a multiple of
+ * 4 included -- and queued exactly as the kernel kfifo would hand them on.  Returns bytes queued
+ * (0 at EOF / EAGAIN), -1 on a read error. */
+#include <errno.h>
+#include <fcntl.h>
+#include <unistd.h>
+
+long cl_smi_feed_fd(cl_smi *dev, int fd, size_t max_bytes)
+{
+    if (!dev || fd < 0) return -1;
+    uint8_t *tmp = (uint8_t *)malloc(dev->native_batch_len);
+    if (!tmp) return -1;
+    size_t total = 0;
+    while (total < max_bytes) {
+        size_t want = max_bytes - total < dev->native_batch_len ? max_bytes - total : dev->native_batch_len;
+        ssize_t r = read(fd, tmp, want);
+        if (r < 0) {
+            if (errno == EINTR) continue;
+            if (errno == EAGAIN || errno == EWOULDBLOCK) break;
+            free(tmp);
+            return -1;
+        }
+        if (r == 0) break;
+        if (cl_fifo_push(&dev->rx, tmp, (size_t)r)) { free(tmp); return -1; }
+        total += (size_t)r;
+    }
+    free(tmp);
+    return (long)total;
+}
+
+long cl_smi_feed_file(cl_smi *dev, const char *path, size_t offset_bytes, size_t max_bytes)
+{
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return -1;
+    if (offset_bytes && lseek(fd, (off_t)offset_bytes, SEEK_SET) < 0) { close(fd); return -1; }
+    long n = cl_smi_feed_fd(dev, fd, max_bytes);
+    close(fd);
+    return n;
+}
+
+/* the TX mirror: hand the packed bytes to an fd with write() of at most one native batch
+ * (caribou_smi.c:444-463,738-759) */
+long cl_smi_drain_to_fd(cl_smi *dev, int fd, size_t max_bytes)
+{
+    if (!dev || fd < 0) return -1;
+    uint8_t *tmp = (uint8_t *)malloc(dev->native_batch_len);
+    if (!tmp) return -1;
+    size_t total = 0;
+    while (total < max_bytes) {
+        size_t want = max_bytes - total < dev->native_batch_len ? max_bytes - total : dev->native_batch_len;
+        size_t got = cl_fifo_pop(&dev->tx, tmp, want);
+        if (!got) break;
+        size_t off = 0;
+        while (off < got) {
+            ssize_t w = write(fd, tmp + off, got - off);
+            if (w < 0) { if (errno == EINTR) continue; free(tmp); return -1; }
+            off += (size_t)w;
+        }
+        total += got;
+    }
+    free(tmp);
+    return (long)total;
+}
+
 /* --------------------------------------------------------------- RX path */
 int cl_smi_read_device(cl_smi *dev, int channel, size_t length_samples, int want_meta, int *all_aligned)
 {

@@ -30,6 +30,9 @@ _SIGS = {
     "cl_smi_close": (C.c_int, [C.c_void_p]),
     "cl_smi_feed_bytes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "cl_smi_pending_bytes": (C.c_size_t, [C.c_void_p]),
+    "cl_smi_feed_fd": (C.c_long, [C.c_void_p, C.c_int, C.c_size_t]),
+    "cl_smi_feed_file": (C.c_long, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_size_t]),
+    "cl_smi_drain_to_fd": (C.c_long, [C.c_void_p, C.c_int, C.c_size_t]),
     "cl_smi_set_max_read": (None, [C.c_void_p, C.c_size_t]),
     "cl_smi_drain_bytes": (C.c_size_t, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "cl_smi_set_tx_mode": (None, [C.c_void_p, C.c_int]),
@@ -139,6 +142,15 @@ class Device:
     def feedSmiBytes(self, b):
         b = np.ascontiguousarray(b, dtype=np.uint8)
         return lib().cl_smi_feed_bytes(self.smi, b.ctypes.data, b.size)
+
+    def feedSmiFile(self, path, offset=0, max_bytes=1 << 62):
+        return lib().cl_smi_feed_file(self.smi, str(path).encode(), offset, max_bytes)
+
+    def feedSmiFd(self, fd, max_bytes=1 << 62):
+        return lib().cl_smi_feed_fd(self.smi, fd, max_bytes)
+
+    def drainSmiToFd(self, fd, max_bytes=1 << 62):
+        return lib().cl_smi_drain_to_fd(self.smi, fd, max_bytes)
 
     def pendingSmiBytes(self):
         return lib().cl_smi_pending_bytes(self.smi)

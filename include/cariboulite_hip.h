@@ -248,6 +248,11 @@ int     cl_smi_close(cl_smi *dev);                     /* caribou_smi_close :584
 int     cl_smi_feed_bytes(cl_smi *dev, const uint8_t *h_bytes, size_t n_bytes);
 size_t  cl_smi_pending_bytes(const cl_smi *dev);
 void    cl_smi_set_max_read(cl_smi *dev, size_t max_bytes_per_read); /* model short reads */
+/* replay front-end: queue bytes from a file / pipe / socket fd with the
+ * reference's read pattern (<= one native batch per read(), short and ragged reads included) */
+long    cl_smi_feed_fd(cl_smi *dev, int fd, size_t max_bytes);
+long    cl_smi_feed_file(cl_smi *dev, const char *path, size_t offset_bytes, size_t max_bytes);
+long    cl_smi_drain_to_fd(cl_smi *dev, int fd, size_t max_bytes);     /* TX mirror: write() per native batch */
 /* bytes write() on the fd would have received */
 size_t  cl_smi_drain_bytes(cl_smi *dev, uint8_t *h_bytes, size_t max_bytes);
 void    cl_smi_set_tx_mode(cl_smi *dev, int cl_tx_mode);

@@ -242,3 +242,49 @@ def test_write_stream_all_formats(S, orc):
     dd = np.minimum(dd, 8192 - dd)
     assert dd.max() <= 1                                               # float->int boundary: +-1 LSB
     sdr.close()
+
+
+def test_file_and_pipe_replay_front_end(S, orc, tmp_path):
+    """recorded capture from a file, live feed through a pipe with short ragged
+    reads, and the TX mirror into a file -- all through the reference's chunk semantics."""
+    import os
+    n = 2 * MTU + 3000
+    b = words(n, 0, seed=33)
+    # a capture with 5 junk bytes in front: first chunk re-synchronises (extrapolated sample, untouched slot)
+    cap = np.concatenate([np.zeros(5, np.uint8), b])
+    f = tmp_path / "capture.smi"
+    cap.tofile(f)
+    sdr = S.Device(dict(driver="Cariboulite", channel="S1G"))
+    assert sdr.feedSmiFile(f) == cap.size
+    ret, iq, meta = sdr.smiRead(0, n)
+    wret, wiq, wmeta = orc.smi_read(0, cap, n, NB)
+    assert ret == wret and np.array_equal(iq, wiq) and np.array_equal(meta, wmeta)
+    sdr.smiRead(0, 1 << 20)                                            # flush the tail
+    # offset + length window of the same file
+    assert sdr.feedSmiFile(f, offset=5, max_bytes=4 * MTU) == 4 * MTU
+    ret, iq, _ = sdr.smiRead(0, MTU)
+    assert ret == MTU and np.array_equal(iq[:MTU], orc.rx_data_analyze(0, b[:NB])[1][:MTU])
+    # pipe: the writer hands over ragged pieces; whatever arrives is queued in order
+    r, w = os.pipe()
+    os.set_blocking(r, False)
+    pieces = [1001, 7, 4093, 65536 - 5101, 20000]
+    pos = 0
+    for p in pieces:
+        os.write(w, b[pos:pos + p].tobytes()); pos += p
+        assert sdr.feedSmiFd(r) == p                                   # EAGAIN ends the pump, nothing lost
+    os.close(w)
+    assert sdr.feedSmiFd(r) == 0                                       # EOF
+    os.close(r)
+    nn = pos // 4
+    ret, iq, _ = sdr.smiRead(0, nn)
+    assert ret == nn and np.array_equal(iq[:nn], orc.rx_data_analyze(0, b[:4 * nn])[1][:nn])
+    # TX mirror
+    rng = np.random.default_rng(2)
+    tx_iq = rng.integers(-4096, 4096, (MTU + 50, 2)).astype(np.int16)
+    assert sdr.smiWrite(0, tx_iq) == MTU + 50
+    out = tmp_path / "tx.smi"
+    fd = os.open(out, os.O_WRONLY | os.O_CREAT)
+    assert sdr.drainSmiToFd(fd) == 4 * (MTU + 50)
+    os.close(fd)
+    assert np.array_equal(np.fromfile(out, np.uint8), orc.generate_data(tx_iq))
+    sdr.close()

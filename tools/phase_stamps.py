@@ -26,3 +26,7 @@ tot = d[:, :6].sum()
 print("waves:", d.shape[0], "tiles/wave avg: %.1f" % d[:, 6].mean(), "cycles/tile/wave: %.0f" % (tot / d[:, 6].sum()))
 for i, nme in enumerate(names):
     print("%-26s %6.1f %%   %8.0f cycles/tile" % (nme, 100 * d[:, i].sum() / tot, d[:, i].sum() / d[:, 6].sum()))
+dt = (d[:, 7].astype(np.uint64) >> np.uint64(32)).astype(np.float64)
+dr = (d[:, 7].astype(np.uint64) & np.uint64(0xffffffff)).astype(np.float64)
+clk = dt / np.maximum(dr, 1) * 100e6
+print("in-kernel shader clock (median over waves): %.3f GHz   wave lifetime median %.1f us" % (np.median(clk) / 1e9, np.median(dr) / 100.0))
