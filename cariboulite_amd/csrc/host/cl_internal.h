@@ -4,6 +4,7 @@
 #ifndef CL_INTERNAL_H
 #define CL_INTERNAL_H
 
+#include <pthread.h>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -38,6 +39,7 @@ struct cl_smi {
     size_t native_batch_len;      /* caribou_smi.c:74-81 */
     uint32_t sample_rate;
     cl_fifo rx, tx;
+    pthread_mutex_t fifo_mu;      /* feeder thread vs reader thread (ASYNC mode) */
     size_t max_read;
     int tx_mode;
     /* device / pinned buffers, grown on demand */

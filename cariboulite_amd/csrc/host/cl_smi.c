@@ -86,6 +86,7 @@ cl_smi *cl_smi_init(int device)
     dev->tx_mode = CL_TX_DOCUMENTED;
     dev->stream = clhip_stream_create();
     if (!dev->stream) { free(dev); return NULL; }
+    pthread_mutex_init(&dev->fifo_mu, NULL);
     return dev;
 }
 
@@ -103,7 +104,13 @@ int cl_smi_close(cl_smi *dev)
     return 0;
 }
 
-int    cl_smi_feed_bytes(cl_smi *dev, const uint8_t *b, size_t n) { return cl_fifo_push(&dev->rx, b, n); }
+int cl_smi_feed_bytes(cl_smi *dev, const uint8_t *b, size_t n)
+{
+    pthread_mutex_lock(&dev->fifo_mu);
+    int rc = cl_fifo_push(&dev->rx, b, n);
+    pthread_mutex_unlock(&dev->fifo_mu);
+    return rc;
+}
 size_t cl_smi_pending_bytes(const cl_smi *dev) { return dev->rx.len; }
 void   cl_smi_set_max_read(cl_smi *dev, size_t m) { dev->max_read = m; }
 size_t cl_smi_drain_bytes(cl_smi *dev, uint8_t *b, size_t max) { return cl_fifo_pop(&dev->tx, b, max); }
@@ -125,7 +132,9 @@ static int cl_smi_read_debug(cl_smi *dev, size_t length_samples)
         return CL_SMI_ERR_IO;
     if (!dev->d_dbg) { dev->d_dbg = (int32_t *)clhip_malloc(16); dev->h_dbg = (int32_t *)clhip_host_alloc(16); }
     if (!dev->d_dbg || !dev->h_dbg) return CL_SMI_ERR_IO;
+    pthread_mutex_lock(&dev->fifo_mu);
     const size_t ret = cl_fifo_pop(&dev->rx, dev->h_stage, cur);
+    pthread_mutex_unlock(&dev->fifo_mu);
     if (ret == 0) return 0;                                   /* "Reading timed-out" */
     if (clhip_memcpy_h2d(dev->d_bytes, dev->h_stage, ret, dev->stream) ||
         clhip_smi_debug_analyze(dev->debug_mode, dev->d_bytes, ret, dev->debug_data.last_correct_byte, dev->d_dbg, dev->stream) ||
@@ -170,7 +179,7 @@ long cl_smi_feed_fd(cl_smi *dev, int fd, size_t max_bytes)
             return -1;
         }
         if (r == 0) break;
-        if (cl_fifo_push(&dev->rx, tmp, (size_t)r)) { free(tmp); return -1; }
+        if (cl_smi_feed_bytes(dev, tmp, (size_t)r)) { free(tmp); return -1; }
         total += (size_t)r;
     }
     free(tmp);
@@ -235,7 +244,9 @@ int cl_smi_read_device(cl_smi *dev, int channel, size_t length_samples, int want
         size_t cur = left > dev->native_batch_len ? dev->native_batch_len : left;
         size_t want = cur;
         if (dev->max_read && want > dev->max_read) want = dev->max_read;
+        pthread_mutex_lock(&dev->fifo_mu);
         size_t ret = cl_fifo_pop(&dev->rx, dev->h_stage + stage_off, want);
+        pthread_mutex_unlock(&dev->fifo_mu);
         if (ret == 0) break;                                   /* :657-661 "Reading timed-out" */
         cl_chunk *c = &dev->chunks[dev->n_chunks++];
         c->stage_off = stage_off; c->len = ret; c->slot0 = read_so_far; c->offs = 0;
@@ -270,8 +281,10 @@ int cl_smi_read_device(cl_smi *dev, int channel, size_t length_samples, int want
         if (dev->h_offs[i] < 0) {                               /* :665-668 -> -3 */
             dev->stat_sync_failures++;
             /* the reference returns at this chunk: what was read ahead of it goes back to the FIFO */
+            pthread_mutex_lock(&dev->fifo_mu);
             for (size_t k = dev->n_chunks; k-- > i + 1;)
-                if (cl_fifo_unpop(&dev->rx, dev->h_stage + dev->chunks[k].stage_off, dev->chunks[k].len)) return CL_SMI_ERR_IO;
+                if (cl_fifo_unpop(&dev->rx, dev->h_stage + dev->chunks[k].stage_off, dev->chunks[k].len)) { pthread_mutex_unlock(&dev->fifo_mu); return CL_SMI_ERR_IO; }
+            pthread_mutex_unlock(&dev->fifo_mu);
             dev->n_chunks = i;                                  /* chunks before the failure were delivered */
             return CL_SMI_ERR_SYNC;
         }

@@ -6,10 +6,13 @@
  * The data path (unpack, IIR, conversions, FIR / resample / FM, pack) runs
  * on the GPU through the clhip_* shim. */
 #include <math.h>
+#include <pthread.h>
+#include <unistd.h>
 
 #include "cl_internal.h"
 
 #define DIG_FILT_ORDER 6     /* CaribouliteStream.hpp:24 */
+#define NUM_NATIVE_MTUS_PER_QUEUE 10   /* CaribouliteStream.cpp:8 */
 
 typedef struct {
     int enabled;
@@ -34,6 +37,14 @@ struct cl_stream {
     cl_dsp_cfg dsp;
     clhip_rx_pipe *rx_pipe;
     clhip_tx_pipe *tx_pipe;
+    /* ASYNC mode: reader thread + ring (CaribouliteStream.cpp:16-49,70-75) */
+    int use_async;
+    cl_ring *rx_queue;
+    pthread_t reader_thread;
+    volatile int reader_thread_running;
+    cl_sample_complex_int16 *interm_native_buffer1;
+    void *astream;                       /* consumer-side HIP stream and CS16 device buffer: the reader */
+    int16_t *d_aiq; size_t aiq_cap;      /* thread owns the cl_smi ones */
 };
 
 struct cl_device {
@@ -95,10 +106,38 @@ static const char *kw(const char *const *keys, const char *const *vals, size_t n
     return NULL;
 }
 
+/* ReaderThread  CaribouliteStream.cpp:16-49 */
+static void *reader_thread_fn(void *arg)
+{
+    cl_stream *st = (cl_stream *)arg;
+    while (st->reader_thread_running) {
+        if (!st->stream_active) { usleep(10000); continue; }            /* :24-28 */
+        int ret = cl_radio_read_samples(st->dev->radio, st->interm_native_buffer1, NULL, st->mtu_size);
+        if (ret < 0) ret = 0;                                            /* :34-42 */
+        if (ret) cl_ring_put(st->rx_queue, st->interm_native_buffer1, (size_t)ret);
+        else usleep(500);                                                /* nothing pending: do not spin */
+    }
+    return NULL;
+}
+
+static void stream_stop_async(cl_stream *st)
+{
+    if (st->reader_thread_running) {
+        st->reader_thread_running = 0;
+        pthread_join(st->reader_thread, NULL);
+    }
+    if (st->rx_queue) { cl_ring_destroy(st->rx_queue); st->rx_queue = NULL; }
+    free(st->interm_native_buffer1); st->interm_native_buffer1 = NULL;
+    if (st->astream) { clhip_stream_sync(st->astream); clhip_stream_destroy(st->astream); st->astream = NULL; }
+    clhip_free(st->d_aiq); st->d_aiq = NULL; st->aiq_cap = 0;
+    st->use_async = 0;
+}
+
 /* ------------------------------------------------------------ device / stream */
 static void stream_free(cl_stream *st)
 {
     if (!st) return;
+    stream_stop_async(st);
     for (int i = 0; i < 3; i++) clhip_free(st->d_iir_state[i]);
     clhip_free(st->d_iir_ws); clhip_free(st->d_conv); clhip_host_free(st->h_conv);
     if (st->rx_pipe) clhip_rx_pipe_destroy(st->rx_pipe);
@@ -260,6 +299,18 @@ cl_stream *cl_setupStream(cl_device *dev, int direction, const char *format, con
         if (!st->tx_pipe) { cl_seterr(dev->err, sizeof dev->err, "setupStream: %s", clhip_last_error()); return NULL; }
     }
     st->stream_active = 0;                             /* :137 activate_channel(..., false) */
+    stream_stop_async(st);
+    const char *as = kw(keys, vals, n_kwargs, "ASYNC");
+    if (as && !strcmp(as, "1") && st->native_dir == CL_SOAPY_SDR_RX) {
+        /* rx_queue(mtu * NUM_NATIVE_MTUS_PER_QUEUE, override writes, blocking reads)  :70-75 */
+        st->rx_queue = cl_ring_create(st->mtu_size * NUM_NATIVE_MTUS_PER_QUEUE, sizeof(cl_sample_complex_int16), 1, 1);
+        st->interm_native_buffer1 = (cl_sample_complex_int16 *)malloc(sizeof(cl_sample_complex_int16) * st->mtu_size);
+        st->astream = clhip_stream_create();
+        if (!st->rx_queue || !st->interm_native_buffer1 || !st->astream) { cl_seterr(dev->err, sizeof dev->err, "setupStream: ASYNC allocation failed"); return NULL; }
+        st->use_async = 1;
+        st->reader_thread_running = 1;
+        if (pthread_create(&st->reader_thread, NULL, reader_thread_fn, st)) { st->reader_thread_running = 0; return NULL; }
+    }
     return st;
 }
 
@@ -298,9 +349,27 @@ static size_t fmt_bytes(int fmt) { return fmt == CL_FORMAT_CF32 ? 8 : fmt == CL_
 
 /* Stream::Read + Stream::ReadSamples(int16*)  CaribouliteStream.cpp:260-301:
  * native read (errors squashed to 0) then the optional IIR, result left on the device */
-static int read_native_device(cl_stream *st, size_t n, int *aligned)
+static int read_native_device(cl_stream *st, size_t n, int *aligned, long timeout_us)
 {
     cl_smi *smi = st->dev->smi;
+    if (st->use_async) {
+        /* Stream::Read with USE_ASYNC: rx_queue->get(buffer, num_samples, timeout_us)  :262-263.
+         * The reader thread owns the SMI path; the popped CS16 samples go back to the device only
+         * when an IIR / conversion / extension stage follows. */
+        if (cl_ensure((void **)&st->h_conv, &st->h_conv_cap, (n + 8) * 4, 1, 1) ||
+            cl_ensure((void **)&st->d_aiq, &st->aiq_cap, n + 8, 4, 0))
+            return 0;
+        const int got = (int)cl_ring_get(st->rx_queue, st->h_conv, n, (int)timeout_us);
+        if (aligned) *aligned = 0;
+        if (got > 0 && clhip_memcpy_h2d(st->d_aiq, st->h_conv, (size_t)got * 4, st->astream)) return 0;
+        if (got > 0 && st->filter_type != CL_DIGFILT_NONE) {
+            const int f = st->filter_type - 1;
+            const size_t need = clhip_iir_workspace_bytes((size_t)got, 3);
+            if (cl_ensure(&st->d_iir_ws, &st->iir_ws_cap, need, 1, 0)) return 0;
+            if (clhip_iir_cs16(st->sos[f], 3, st->d_iir_state[f], st->d_aiq, (size_t)got, st->d_iir_ws, st->iir_ws_cap, st->astream)) return 0;
+        }
+        return got;
+    }
     int ret = cl_smi_read_device(smi, st->dev->channel, n, 0, aligned);
     if (ret < 0) {
         if (ret == CL_SMI_ERR_IO) printf("reader thread failed to read SMI!\n");    /* :270 */
@@ -321,24 +390,31 @@ static int read_native_device(cl_stream *st, size_t n, int *aligned)
 /* Stream::ReadSamplesGen  CaribouliteStream.cpp:370-382 */
 int cl_readStream(cl_device *dev, cl_stream *st, void *const *buffs, size_t numElems, int *flags, long long *timeNs, long timeoutUs)
 {
-    (void)flags; (void)timeNs; (void)timeoutUs;        /* never written / ignored on the sync path */
+    (void)flags; (void)timeNs;                         /* never written; timeoutUs only matters in ASYNC mode */
     if (st->native_dir != CL_SOAPY_SDR_RX) return CL_SOAPY_SDR_NOT_SUPPORTED;       /* :248-251 */
     cl_smi *smi = dev->smi;
     clhip_set_device(smi->device);
     void *out = buffs[0];
     if (st->format == CL_FORMAT_CS16) {                /* :282-301, no MTU clamp */
         int aligned = 0;
-        int res = read_native_device(st, numElems, &aligned);
+        int res = read_native_device(st, numElems, &aligned, timeoutUs);
         if (res <= 0) return res;
+        if (st->use_async) {
+            if (st->filter_type == CL_DIGFILT_NONE) memcpy(out, st->h_conv, (size_t)res * 4);
+            else if (clhip_memcpy_d2h(out, st->d_aiq, (size_t)res * 4, st->astream) || clhip_stream_sync(st->astream)) return 0;
+            return res;
+        }
         if (st->filter_type == CL_DIGFILT_NONE) { if (cl_smi_copy_out(smi, (cl_sample_complex_int16 *)out, NULL, -1)) return 0; }
         else if (clhip_memcpy_d2h(out, smi->d_iq, (size_t)res * 4, smi->stream) || clhip_stream_sync(smi->stream)) return 0;
         return res;
     }
     if (numElems > st->mtu_size) numElems = st->mtu_size;                          /* :306,328,351 */
     int aligned = 0;
-    int res = read_native_device(st, numElems, &aligned);
+    int res = read_native_device(st, numElems, &aligned, timeoutUs);
     if (res <= 0) return res;
     const size_t n = (size_t)res;
+    int16_t *d_iq = st->use_async ? st->d_aiq : smi->d_iq;      /* the native samples of this call */
+    void *hs = st->use_async ? st->astream : smi->stream;
     if (st->rx_pipe) {
         /* extension stages where a client of readStream(CF32) would apply them */
         const size_t n_out = clhip_rx_pipe_out_count(st->rx_pipe, n);
@@ -346,17 +422,17 @@ int cl_readStream(cl_device *dev, cl_stream *st, void *const *buffs, size_t numE
         if (cl_ensure(&st->d_conv, &st->conv_cap, n_out * ob + 64, 1, 0)) return 0;
         long got;
         if (aligned)   /* every chunk in sync: one fused launch straight from the raw SMI words */
-            got = clhip_rx_pipe_run(st->rx_pipe, CL_PIPE_IN_SMI_WORDS, smi->d_bytes, 0, n, st->d_conv, 0, smi->stream);
-        else           /* re-synchronised or IIR-filtered: from the native int16 samples */
-            got = clhip_rx_pipe_run(st->rx_pipe, CL_PIPE_IN_CS16, smi->d_iq, 0, n, st->d_conv, 0, smi->stream);
+            got = clhip_rx_pipe_run(st->rx_pipe, CL_PIPE_IN_SMI_WORDS, smi->d_bytes, 0, n, st->d_conv, 0, hs);
+        else           /* re-synchronised, IIR-filtered or popped from the ring: from the native int16 samples */
+            got = clhip_rx_pipe_run(st->rx_pipe, CL_PIPE_IN_CS16, d_iq, 0, n, st->d_conv, 0, hs);
         if (got < 0) return 0;
-        if (got && (clhip_memcpy_d2h(out, st->d_conv, (size_t)got * ob, smi->stream) || clhip_stream_sync(smi->stream))) return 0;
+        if (got && (clhip_memcpy_d2h(out, st->d_conv, (size_t)got * ob, hs) || clhip_stream_sync(hs))) return 0;
         return (int)got;
     }
     /* :304-367: every one of the `res` slots is converted, stale ones included */
     if (cl_ensure(&st->d_conv, &st->conv_cap, n * 16 + 64, 1, 0)) return 0;
-    if (clhip_convert_from_cs16(smi->d_iq, n, st->format, st->d_conv, smi->stream) ||
-        clhip_memcpy_d2h(out, st->d_conv, n * fmt_bytes(st->format), smi->stream) || clhip_stream_sync(smi->stream))
+    if (clhip_convert_from_cs16(d_iq, n, st->format, st->d_conv, hs) ||
+        clhip_memcpy_d2h(out, st->d_conv, n * fmt_bytes(st->format), hs) || clhip_stream_sync(hs))
         return 0;
     return res;
 }

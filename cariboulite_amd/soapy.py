@@ -41,6 +41,13 @@ _SIGS = {
     "cl_smi_get_native_batch_samples": (C.c_size_t, [C.c_void_p]),
     "cl_smi_set_debug_mode": (None, [C.c_void_p, C.c_int]),
     "cl_smi_get_debug_data": (C.c_void_p, [C.c_void_p]),
+    "cl_ring_create": (C.c_void_p, [C.c_size_t, C.c_size_t, C.c_int, C.c_int]),
+    "cl_ring_destroy": (None, [C.c_void_p]),
+    "cl_ring_put": (C.c_size_t, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "cl_ring_get": (C.c_size_t, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
+    "cl_ring_reset": (None, [C.c_void_p]),
+    "cl_ring_size": (C.c_size_t, [C.c_void_p]),
+    "cl_ring_capacity": (C.c_size_t, [C.c_void_p]),
     "cl_radio_create": (C.c_void_p, [C.c_void_p, C.c_int]),
     "cl_radio_destroy": (None, [C.c_void_p]),
     "cl_radio_read_samples": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -113,6 +120,32 @@ def design_butter_lowpass(order, fs_hz, fc_hz):
 class SmiDebugData(C.Structure):
     _fields_ = [("error_accum_counter", C.c_uint32), ("cur_err_cnt", C.c_uint32),
                 ("last_correct_byte", C.c_uint8), ("error_rate", C.c_double)]
+
+
+class Ring:
+    """cl_ring over uint32 elements (the reference's circular_buffer<T>)."""
+
+    def __init__(self, size, override_write=True, block_read=True):
+        self.h = lib().cl_ring_create(size, 4, int(override_write), int(block_read))
+
+    def put(self, data):
+        d = np.ascontiguousarray(data, dtype=np.uint32)
+        return lib().cl_ring_put(self.h, d.ctypes.data, d.size)
+
+    def get(self, n, timeout_us=1000):
+        out = np.zeros(max(n, 1), dtype=np.uint32)
+        k = lib().cl_ring_get(self.h, out.ctypes.data, n, int(timeout_us))
+        return k, out[:k].copy()
+
+    def size(self):
+        return lib().cl_ring_size(self.h)
+
+    def capacity(self):
+        return lib().cl_ring_capacity(self.h)
+
+    def __del__(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.cl_ring_destroy(self.h); self.h = None
 
 
 class StreamResult:

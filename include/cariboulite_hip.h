@@ -274,6 +274,18 @@ const cl_smi_debug_data *cl_smi_get_debug_data(const cl_smi *dev);
 /* caribou_smi_get_native_batch_samples caribou_smi.c:765-769 */
 size_t  cl_smi_get_native_batch_samples(cl_smi *dev);
 
+/* --- circular_buffer<T> (datatypes/circular_buffer.h:16-164) ------------------------------------------
+ * power-of-two capacity; put() overwrites the oldest when override_write; get() blocks up to timeout_us and
+ * returns 0 unless all `length` elements are present (block_read), else min(length, size) at once. */
+typedef struct cl_ring cl_ring;
+cl_ring *cl_ring_create(size_t size_elems, size_t elem_bytes, int override_write, int block_read);
+void     cl_ring_destroy(cl_ring *r);
+size_t   cl_ring_put(cl_ring *r, const void *data, size_t length);
+size_t   cl_ring_get(cl_ring *r, void *data, size_t length, int timeout_us);
+void     cl_ring_reset(cl_ring *r);
+size_t   cl_ring_size(cl_ring *r);
+size_t   cl_ring_capacity(const cl_ring *r);
+
 /* --- radio pass-through trio: cariboulite_radio.h:592-619 ---------------- */
 typedef struct cl_radio cl_radio;   /* stands where cariboulite_radio_state_st stands */
 cl_radio *cl_radio_create(cl_smi *smi, int channel);
@@ -303,7 +315,8 @@ size_t cl_getStreamFormats(const cl_device *dev, int direction, size_t channel,
 const char *cl_getNativeStreamFormat(const cl_device *dev, int direction, size_t channel, double *fullScale);
 /* setupStream :100-139 -- NULL + cl_device_last_error() where the reference throws.
  * Extension kwargs (SURVEY.md section 5 "Config / flags"): FIR=<ntaps>:<cutoff_hz>,
- * RESAMP=<L>/<M>, DEMOD=FM, MOD=FM:<kf_hz>; defaults = reference behaviour. */
+ * RESAMP=<L>/<M>, DEMOD=FM, MOD=FM:<kf_hz>; ASYNC=1 enables the reader thread + ring of the reference's
+ * compiled-out USE_ASYNC path (CaribouliteStream.cpp:11,16-49,70-75); defaults = reference behaviour. */
 cl_stream *cl_setupStream(cl_device *dev, int direction, const char *format,
                           const size_t *channels, size_t n_channels,
                           const char *const *keys, const char *const *vals, size_t n_kwargs);

@@ -629,3 +629,46 @@ int orc_debug_analyze(orc_debug_data *d, int mode, const uint8_t *data, size_t l
     if (d->error_rate < 1e-8) d->error_rate = 0.0;
     return offs;
 }
+
+/* ======================================================================== */
+/* circular_buffer<T> (datatypes/circular_buffer.h:16-164), non-blocking     */
+/* semantics restated on 32-bit elements -- SURVEY.md section 8(f) rank 2    */
+/* ======================================================================== */
+void orc_ring_init(orc_ring *r, size_t size, int override_write, uint32_t *storage)
+{
+    size_t cap = 1;                       /* :21-25 next power of two */
+    while (cap < size) cap <<= 1;
+    r->buf = storage; r->max_size = cap; r->head = r->tail = 0; r->override_write = override_write;
+}
+size_t orc_ring_capacity_for(size_t size) { size_t cap = 1; while (cap < size) cap <<= 1; return cap; }
+size_t orc_ring_size(const orc_ring *r) { return r->head - r->tail; }
+
+/* :37-62 */
+size_t orc_ring_put(orc_ring *r, const uint32_t *data, size_t length)
+{
+    size_t sz = r->head - r->tail;
+    if ((r->max_size - sz) < length && r->override_write) r->tail += length - (r->max_size - sz);   /* drop the oldest */
+    size_t len = length < r->max_size - r->head + r->tail ? length : r->max_size - r->head + r->tail;
+    size_t hi = r->head & (r->max_size - 1);
+    size_t l = len < r->max_size - hi ? len : r->max_size - hi;
+    memcpy(r->buf + hi, data, l * sizeof(uint32_t));
+    memcpy(r->buf, data + l, (len - l) * sizeof(uint32_t));
+    r->head += len;
+    return len;
+}
+
+/* :64-93 with the wait already over: block_read returns 0 unless `length` items are present */
+size_t orc_ring_get(orc_ring *r, uint32_t *data, size_t length, int block_read)
+{
+    size_t sz = r->head - r->tail;
+    if (block_read && sz < length) return 0;
+    size_t len = length < sz ? length : sz;
+    size_t ti = r->tail & (r->max_size - 1);
+    size_t l = len < r->max_size - ti ? len : r->max_size - ti;
+    if (data) {
+        memcpy(data, r->buf + ti, l * sizeof(uint32_t));
+        memcpy(data + l, r->buf, (len - l) * sizeof(uint32_t));
+    }
+    r->tail += len;
+    return len;
+}

@@ -128,6 +128,18 @@ uint8_t orc_lfsr(uint8_t n);
 int orc_debug_find_offset(int mode, const uint8_t *buffer, size_t len);
 int orc_debug_analyze(orc_debug_data *d, int mode, const uint8_t *data, size_t len);
 
+/* ---- circular_buffer<T> semantics (datatypes/circular_buffer.h) on 32-bit elements ---- */
+typedef struct {
+    uint32_t *buf;
+    size_t max_size, head, tail;
+    int override_write;
+} orc_ring;
+void orc_ring_init(orc_ring *r, size_t size, int override_write, uint32_t *storage);
+size_t orc_ring_capacity_for(size_t size);
+size_t orc_ring_size(const orc_ring *r);
+size_t orc_ring_put(orc_ring *r, const uint32_t *data, size_t length);
+size_t orc_ring_get(orc_ring *r, uint32_t *data, size_t length, int block_read);
+
 size_t orc_rx_pipe_f32_mt(int channel, const uint8_t *bytes, size_t n_bytes, size_t native_batch_len,
                           const float *fir_taps, int fir_n, const float *rs_taps, int rs_n, int L, int M,
                           int16_t *iq_buf, float *x_buf, float *y_buf, float *out, int n_threads);

@@ -215,6 +215,36 @@ def gen_debug():
     print("debug cases:", len(names))
 
 
+def gen_ring():
+    """Op sequences through the reference's own circular_buffer<uint32_t> (compiled from
+    datatypes/circular_buffer.h): per op the returned count, the data popped and the fill level."""
+    rng = np.random.default_rng(0xB1F)
+    res = {}; names = []
+    for name, size, ov, blk in (("ov_block_100", 100, 1, 1), ("noov_block_64", 64, 0, 1), ("ov_noblock_33", 33, 1, 0),
+                                ("noov_noblock_256", 256, 0, 0)):
+        ring = orc.RefRing(size, ov, blk)
+        ops, rets, sizes, popped = [], [], [], []
+        ctr = 0
+        for _ in range(400):
+            if rng.random() < 0.55:
+                n = int(rng.integers(0, ring.capacity()))
+                d = np.arange(ctr, ctr + n, dtype=np.uint32); ctr += n
+                r = ring.put(d); ops.append((0, n)); rets.append(r)
+            else:
+                n = int(rng.integers(0, ring.capacity()))
+                k, d = ring.get(n, 100); ops.append((1, n)); rets.append(k); popped.append(d)
+            sizes.append(ring.size())
+        names.append(name)
+        res[f"{name}__cfg"] = np.array([size, ov, blk, ring.capacity()], dtype=np.int64)
+        res[f"{name}__ops"] = np.array(ops, dtype=np.int64)
+        res[f"{name}__rets"] = np.array(rets, dtype=np.int64)
+        res[f"{name}__sizes"] = np.array(sizes, dtype=np.int64)
+        res[f"{name}__popped"] = np.concatenate(popped) if popped else np.zeros(0, np.uint32)
+    res["names"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "ring_cases.npz"), **res)
+    print("ring cases:", len(names))
+
+
 def design_taps():
     t = {}
     t["fir64_c2"] = sg.firwin(64, 1.0e6, window="hamming", fs=4e6)
@@ -272,7 +302,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     orc.build(ref=True)
     assert orc.have_ref(), "compiled reference missing: run in the build container"
-    gen_kat(); gen_rx(); gen_read(); gen_tx(); gen_debug(); gen_dsp()
+    gen_kat(); gen_rx(); gen_read(); gen_tx(); gen_debug(); gen_ring(); gen_dsp()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -321,6 +321,81 @@ def ref_debug_read(mode, stream_bytes, length_samples, state, native_batch_len=N
     return ret, (a.value, c.value, l.value, r.value)
 
 
+# ------------------------------------------------------------ circular buffer
+class _Ring(C.Structure):
+    _fields_ = [("buf", C.POINTER(C.c_uint32)), ("max_size", C.c_size_t), ("head", C.c_size_t),
+                ("tail", C.c_size_t), ("override_write", C.c_int)]
+
+
+class Ring:
+    """circular_buffer<uint32_t> restated (no waiting: block_read only decides the short-read rule)."""
+
+    def __init__(self, size, override_write=True, block_read=True):
+        lib().orc_ring_capacity_for.restype = C.c_size_t
+        cap = lib().orc_ring_capacity_for(C.c_size_t(size))
+        self.store = np.zeros(cap, dtype=np.uint32)
+        self.r = _Ring()
+        self.block = int(block_read)
+        lib().orc_ring_init(C.byref(self.r), C.c_size_t(size), int(override_write), _p(self.store, C.c_uint32))
+        for f in ("orc_ring_put", "orc_ring_get", "orc_ring_size"):
+            getattr(lib(), f).restype = C.c_size_t
+
+    def put(self, data):
+        d = np.ascontiguousarray(data, dtype=np.uint32)
+        return lib().orc_ring_put(C.byref(self.r), _p(d, C.c_uint32), C.c_size_t(d.size))
+
+    def get(self, n):
+        out = np.zeros(max(n, 1), dtype=np.uint32)
+        k = lib().orc_ring_get(C.byref(self.r), _p(out, C.c_uint32), C.c_size_t(n), self.block)
+        return k, out[:k].copy()
+
+    def size(self):
+        return lib().orc_ring_size(C.byref(self.r))
+
+    def capacity(self):
+        return self.r.max_size
+
+
+REF_RING_PATH = os.path.join(HERE, "_ref", "libref_ring.so")
+_ref_ring = None
+
+
+def ref_ring_lib():
+    global _ref_ring
+    if _ref_ring is None:
+        _ref_ring = C.CDLL(REF_RING_PATH)
+        _ref_ring.ref_ring_new.restype = C.c_void_p
+        for f in ("ref_ring_put", "ref_ring_get", "ref_ring_size", "ref_ring_capacity"):
+            getattr(_ref_ring, f).restype = C.c_size_t
+    return _ref_ring
+
+
+class RefRing:
+    """The reference's own circular_buffer<uint32_t>, compiled from /root/reference."""
+
+    def __init__(self, size, override_write=True, block_read=True):
+        self.h = C.c_void_p(ref_ring_lib().ref_ring_new(C.c_size_t(size), int(override_write), int(block_read)))
+
+    def put(self, data):
+        d = np.ascontiguousarray(data, dtype=np.uint32)
+        return ref_ring_lib().ref_ring_put(self.h, _p(d, C.c_uint32), C.c_size_t(d.size))
+
+    def get(self, n, timeout_us=1000):
+        out = np.zeros(max(n, 1), dtype=np.uint32)
+        k = ref_ring_lib().ref_ring_get(self.h, _p(out, C.c_uint32), C.c_size_t(n), int(timeout_us))
+        return k, out[:k].copy()
+
+    def size(self):
+        return ref_ring_lib().ref_ring_size(self.h)
+
+    def capacity(self):
+        return ref_ring_lib().ref_ring_capacity(self.h)
+
+    def __del__(self):
+        if self.h:
+            ref_ring_lib().ref_ring_free(self.h); self.h = None
+
+
 # ------------------------------------------------- compiled reference (_ref)
 def ref_find_buffer_offset(buf):
     buf = np.ascontiguousarray(buf, dtype=np.uint8).copy()

@@ -288,3 +288,57 @@ def test_file_and_pipe_replay_front_end(S, orc, tmp_path):
     os.close(fd)
     assert np.array_equal(np.fromfile(out, np.uint8), orc.generate_data(tx_iq))
     sdr.close()
+
+
+def test_async_stream_reader_thread_and_ring(S, orc):
+    """ASYNC=1: the reference's compiled-out USE_ASYNC path (CaribouliteStream.cpp:16-49,70-75) --
+    a reader thread fills a 10-MTU overwrite-oldest ring, readStream pops whole requests with its timeout."""
+    import time
+    sdr = S.Device(dict(driver="Cariboulite", channel="S1G"))
+    rx = sdr.setupStream(S.SOAPY_SDR_RX, S.SOAPY_SDR_CS16, args={"ASYNC": "1"})
+    buf = np.zeros((MTU, 2), np.int16)
+    t0 = time.perf_counter()
+    assert sdr.readStream(rx, [buf], MTU, timeoutUs=30000).ret == 0        # inactive: nothing arrives, times out
+    assert time.perf_counter() - t0 >= 0.025
+    sdr.activateStream(rx)
+    b = words(4 * MTU, 0, seed=41)
+    sdr.feedSmiBytes(b)
+    want = orc.smi_read(0, b, 4 * MTU, NB)[1]
+    for k in range(4):
+        sr = sdr.readStream(rx, [buf], MTU, timeoutUs=2_000_000)
+        assert sr.ret == MTU and np.array_equal(buf, want[k * MTU:(k + 1) * MTU])
+    assert sdr.readStream(rx, [buf], MTU, timeoutUs=20000).ret == 0        # drained: whole-request rule
+    # partial request sizes pop across chunk boundaries in order
+    sdr.feedSmiBytes(b[: 4 * 2 * MTU])
+    time.sleep(0.3)
+    small = np.zeros((50000, 2), np.int16)
+    got = []
+    for _ in range(5):
+        assert sdr.readStream(rx, [small], 50000, timeoutUs=1_000_000).ret == 50000
+        got.append(small.copy())
+    assert np.array_equal(np.concatenate(got), want[:250000])
+    # CF32 + IIR on the consumer side of the ring
+    sdr.deactivateStream(rx)
+    rx = sdr.setupStream(S.SOAPY_SDR_RX, S.SOAPY_SDR_CF32, args={"ASYNC": "1"})
+    sdr.setBandwidth(S.SOAPY_SDR_RX, 0, 90e3)
+    sdr.activateStream(rx)
+    from cariboulite_amd import synth
+    b2, i2, q2 = synth.smi_stream_bytes(MTU, 0, stream=3)
+    sdr.feedSmiBytes(b2)
+    fb = np.zeros((MTU, 2), np.float32)
+    assert sdr.readStream(rx, [fb], MTU, timeoutUs=2_000_000).ret == MTU
+    wf = orc.cs16_to_cf32(orc.IIR(6, 4e6, 50e3).apply_cs16(np.stack([i2, q2], 1)))
+    assert np.max(np.abs(fb - wf)) <= 1.0 / 4096 + 1e-9 and np.mean(fb != wf) < 1e-4
+    # overwrite-oldest: feed 12 MTUs without reading; the ring keeps the newest 10 MTUs worth (capacity 2^21)
+    sdr.setBandwidth(S.SOAPY_SDR_RX, 0, 200e3)
+    rx = sdr.setupStream(S.SOAPY_SDR_RX, S.SOAPY_SDR_CS16, args={"ASYNC": "1"})
+    sdr.activateStream(rx)
+    big = words(12 * MTU, 0, seed=43)
+    for k in range(12):
+        sdr.feedSmiBytes(big[k * NB:(k + 1) * NB])
+    time.sleep(1.0)
+    wantb = orc.smi_read(0, big, 12 * MTU, NB)[1][:12 * MTU]
+    assert sdr.readStream(rx, [buf], MTU, timeoutUs=1_000_000).ret == MTU
+    # 12 MTU put into a 16-MTU ring (capacity = next power of two of 10 MTU): nothing dropped yet
+    assert np.array_equal(buf, wantb[:MTU])
+    sdr.close()
