@@ -65,6 +65,10 @@ struct PipeArgs {
     int chunk_shift;             // log2(samples per chunk): chunks are a power of two (native = 2^17)
     long chunks_per_stream;
     int32_t *bad_flag;           // set to 1 when a needed chunk has offs != 0 (tile writes nothing)
+    // dynamic tile queue of the persistent interior workers: queue[0] = items handed out beyond the
+    // first grid_int, queue[1] = workers that have left; the last one out zeroes both for the next launch
+    unsigned int *queue;
+    int queue_k;                 // items per grab; 0 = static striding
 };
 
 template <int T_, int L_, int M_, int KP_, int MODE_, int R_, int NT_, bool FFA_ = false, bool PK_ = true>
@@ -87,7 +91,7 @@ struct PipeCfg {
     static constexpr int TSTRIDE = (R * 8 + 16);    // bytes between lanes' windows in LDS
     static constexpr int IN_BYTES = (NLOAD * 8 + (NLOAD / R + 1) * 16 + 63) / 64 * 64;
     static constexpr int TAIL_BYTES = (NT / 64) * 8 * 8;   // one 8-sample tail slot per wave
-    static constexpr int LDS_BYTES = IN_BYTES + TAIL_BYTES;
+    static constexpr int LDS_BYTES = IN_BYTES + TAIL_BYTES + 16;   // + the workgroup's queue slot
     static_assert(T % 4 == 0 && R % 4 == 0, "T and R must be multiples of 4");
     static_assert((R * L) % M == 0 && (HFA * L) % M == 0, "lane outputs must be integral");
     static_assert(HF <= 8 && HF <= R, "history too long for the tail exchange");
@@ -597,17 +601,33 @@ void rx_pipe_fused_kernel(const PipeArgs a)
     }
     const int per_stream = a.n_int - 1;                      // interior tiles per stream: 1 .. n_int-1
     const int items = per_stream * a.n_streams;
-    const int step = a.grid_int;
+    // Work distribution: worker w starts on item w; after that it pulls chunks of queue_k consecutive
+    // items from an atomic counter, so every worker stays busy until the queue is dry: the kernel's tail
+    // is a few tiles, not one worker lifetime.  The grab for the chunk AFTER the next one is issued when a
+    // chunk is entered and travels through a VGPR of thread 0 and one LDS slot, a whole tile ahead of its
+    // use.  (Chunks, not single tiles: same-address device-scope atomics retire at ~12 ns each.)
+    // queue_k == 0: static striding by grid_int (A/B switch).
+    int *qslot = (int *)(lds + C::IN_BYTES + C::TAIL_BYTES);
+    const int K = a.queue_k;
+    unsigned int grabbed = 0;
+    int pos = 0, end = 0, nb_base = 0;           // current chunk [pos, end), base of the chunk after it
 
     TileRegs<C, KIND> regs;
     int item = (int)blockIdx.x - n_edge_wg;
-    if (item < items) {
+    {
+        if (K > 0) {
+            if (threadIdx.x == 0) *qslot = (int)atomicAdd(a.queue, 1u);
+            __syncthreads();
+            nb_base = a.grid_int + K * __builtin_amdgcn_readfirstlane(*qslot);
+            __syncthreads();                                 // everyone has read the slot before it is rewritten
+        }
         const int s0 = item / per_stream, tile0 = 1 + item % per_stream;
         const void *in0 = KIND == CL_PIPE_IN_CF32 ? (const void *)((const f32x2 *)a.in + (long)s0 * a.in_stride)
                                                  : (const void *)((const uint32_t *)a.in + (long)s0 * a.in_stride);
         tile_issue_loads<C, KIND>(regs, in0, (long)tile0 * C::TILE_IN - C::HALO, threadIdx.x);
+        if (K > 0 && threadIdx.x == 0) grabbed = atomicAdd(a.queue, 1u);
     }
-    for (; item < items; item += step) {
+    while (item < items) {
         // Keep per-iteration values per-iteration: without these the compiler hoists every tap load
         // (88 SGPRs -> spilled to VGPR lanes) and every lane address computation (50+ VGPRs) out of
         // the persistent loop, which costs two waves of occupancy.
@@ -621,11 +641,21 @@ void rx_pipe_fused_kernel(const PipeArgs a)
 
         DIAG_STAMP(ts0);
         tile_regs_to_lds<C, KIND, HIF>(regs, lds, t);
+        if (threadIdx.x == 0) *qslot = (int)grabbed;         // the latest grab arrived together with the prefetched words
         DIAG_STAMP(ts1);
         __syncthreads();
         DIAG_STAMP(ts2);
-        if (item + step < items) {                           // prefetch the next item's raw words
-            const int nx = item + step, sn = nx / per_stream, tn = 1 + nx % per_stream;
+        int next;
+        if (K == 0) next = item + a.grid_int;
+        else if (pos < end) next = pos++;
+        else {                                               // enter the next chunk; ask for the one after it
+            pos = nb_base; end = pos + K;
+            nb_base = a.grid_int + K * __builtin_amdgcn_readfirstlane(*qslot);
+            next = pos++;
+            if (next < items && threadIdx.x == 0) grabbed = atomicAdd(a.queue, 1u);
+        }
+        if (next < items) {                                  // prefetch the next item's raw words
+            const int sn = next / per_stream, tn = 1 + next % per_stream;
             const void *inn = KIND == CL_PIPE_IN_CF32 ? (const void *)((const f32x2 *)a.in + (long)sn * a.in_stride)
                                                      : (const void *)((const uint32_t *)a.in + (long)sn * a.in_stride);
             tile_issue_loads<C, KIND>(regs, inn, (long)tn * C::TILE_IN - C::HALO, t);
@@ -655,6 +685,12 @@ void rx_pipe_fused_kernel(const PipeArgs a)
             d_stage += ts1 - ts0; d_bar0 += ts2 - ts1; d_fir += ts3 - ts2; d_second += ts4 - ts3;
             d_store += ts5 - ts4; d_bar2 += ts6 - ts5; d_tiles += 1;
         }
+        item = next;
+    }
+    // every grab of this worker has returned; the last worker out re-arms the queue for the next launch
+    if (K > 0 && threadIdx.x == 0 && atomicAdd(a.queue + 1, 1u) == (unsigned)a.grid_int - 1u) {
+        __atomic_store_n(a.queue, 0u, __ATOMIC_RELAXED);
+        __atomic_store_n(a.queue + 1, 0u, __ATOMIC_RELEASE);
     }
     if constexpr (DIAG) {
         if (a.diag && (threadIdx.x & 63) == 0) {
@@ -801,6 +837,7 @@ struct clhip_rx_pipe {
     float *d_ffa, *d_ffa_int;          // [H0 | H1 | H0+H1] for the 2-parallel fast FIR, same two scalings
     bool ffa;                          // the selected fused instantiation uses them
     unsigned long long *diag;          // optional stamp buffer (diagnostic kernel build)
+    unsigned int *queue;               // tile queue of the fused kernel: {next item, workers done}, zero between launches
     f32x2 *X, *Y;
     size_t x_cap, y_cap;           // elements per stream
 };
@@ -853,7 +890,9 @@ extern "C" clhip_rx_pipe *clhip_rx_pipe_create(int n_streams, int channel, const
     p->d_fir = (float *)clhip_malloc(sizeof(float) * PIPE_MAX_FIR);
     p->d_fir_int = (float *)clhip_malloc(sizeof(float) * PIPE_MAX_FIR);
     p->d_rs = (float *)clhip_malloc(sizeof(float) * PIPE_MAX_RS);
-    if (!p->d_fir || !p->d_fir_int || !p->d_rs) { clhip_rx_pipe_destroy(p); return nullptr; }
+    p->queue = (unsigned int *)clhip_malloc(2 * sizeof(unsigned int));
+    if (!p->d_fir || !p->d_fir_int || !p->d_rs || !p->queue) { clhip_rx_pipe_destroy(p); return nullptr; }
+    (void)hipMemset(p->queue, 0, 2 * sizeof(unsigned int));
     float scaled[PIPE_MAX_FIR];
     for (int k = 0; k < PIPE_MAX_FIR; k++) scaled[k] = p->fir[k] / 4096.0f;   // exact: power of two
     (void)hipMemcpy(p->d_fir, p->fir, sizeof(float) * PIPE_MAX_FIR, hipMemcpyHostToDevice);
@@ -882,7 +921,7 @@ extern "C" void clhip_rx_pipe_destroy(clhip_rx_pipe *p)
     if (!p) return;
     clhip_free(p->hist[0]); clhip_free(p->hist[1]);
     clhip_free(p->d_fir); clhip_free(p->d_fir_int); clhip_free(p->d_rs); clhip_free(p->d_ffa); clhip_free(p->d_ffa_int);
-    clhip_free(p->X); clhip_free(p->Y);
+    clhip_free(p->X); clhip_free(p->Y); clhip_free(p->queue);
     delete p;
 }
 
@@ -928,8 +967,8 @@ template <class C, int KIND, bool HIF, bool DIAG = false>
 static int launch_pipe(PipeArgs &a, hipStream_t s)
 {
     const long items = (long)(a.n_int - 1) * a.n_streams;
-    // persistent interior grid: a multiple of what stays resident; each worker walks items
-    // blockIdx.x, +grid_int, ...; edge workers follow in the same launch
+    // persistent interior grid = what stays resident; worker w starts on item w and then pulls items
+    // from the pipe's tile queue; edge workers sit in front of them in the same launch
     static int resident = 0;
     if (!resident) {
         (void)hipFuncSetAttribute((const void *)rx_pipe_fused_kernel<C, KIND, HIF, DIAG>,
@@ -942,9 +981,12 @@ static int launch_pipe(PipeArgs &a, hipStream_t s)
             per_cu = 2;
         // the API under-reports here (LDS 4 x 37.5 KB and 4 waves/SIMD both fit); an oversubscribed
         // persistent grid is still correct (no inter-workgroup waits), so prefer the measured optimum
-        const int by_lds = (160 * 1024) / C::LDS_BYTES;
-        if (per_cu < 4 && by_lds >= 4) per_cu = 4;
-        per_cu *= 4;      // 4x oversubscribed: queued workgroups back-fill as residents finish (measured best)
+        const int by_lds = (160 * 1024) / C::LDS_BYTES, by_waves = 16 / (C::NT / 64);
+        const int want = by_lds < by_waves ? by_lds : by_waves;
+        if (per_cu < want && want >= 4) per_cu = want;
+        // queue mode: exactly what is resident (the tile queue keeps every worker busy to the end);
+        // static striding: 4x oversubscribed, queued workgroups back-fill as residents finish
+        if (a.queue_k == 0) per_cu *= 4;
         const char *e = getenv("CLHIP_WG_PER_CU");
         if (e && atoi(e) > 0) per_cu = atoi(e);
         resident = cus * per_cu;
@@ -1013,7 +1055,9 @@ extern "C" long clhip_rx_pipe_run(clhip_rx_pipe *p, int in_kind, const void *d_i
     a.out = d_out; a.out_stride = (long)out_stride;
     a.n_in = (long)n_in; a.n_out = (long)n_out;
     a.in_kind = in_kind; a.channel = p->channel; a.n_streams = p->n_streams;
-    a.halo = p->halo; a.hist_out = p->hist[p->cur ^ 1]; a.diag = p->diag;
+    a.halo = p->halo; a.hist_out = p->hist[p->cur ^ 1]; a.diag = p->diag; a.queue = p->queue;
+    static const int queue_k = getenv("CLHIP_QUEUE_K") ? atoi(getenv("CLHIP_QUEUE_K")) : 2;
+    a.queue_k = queue_k;
     a.in_scale = in_kind == CL_PIPE_IN_CF32 ? 1.0f : 4096.0f;
     a.fir = in_kind == CL_PIPE_IN_CF32 ? p->d_fir : p->d_fir_int;
     const float *ffa_taps = in_kind == CL_PIPE_IN_CF32 ? p->d_ffa : p->d_ffa_int;
