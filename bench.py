@@ -215,11 +215,11 @@ def main():
         # HBM traffic of the fused kernel from PMC counters: measured in separate rocprofv3 --pmc passes
         # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; tools/pmc_summ.py) and committed under profiles/
         traffic, traffic_src = None, None
-        pmc_file = os.path.join(ROOT, "profiles", "r01", "b_pmc.json")
+        pmc_file = os.path.join(ROOT, "profiles", "r01", "c_pmc.json")
         if a.log2_samples == 28 and os.path.exists(pmc_file):
             try:
                 traffic = round(json.load(open(pmc_file))["_derived"]["traffic_bytes_per_launch"])
-                traffic_src = "profiles/r01/b_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+                traffic_src = "profiles/r01/c_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
             except Exception:
                 traffic = None
         value = shard.job_throughput(n, a.steps, dt, world) / 1e6
