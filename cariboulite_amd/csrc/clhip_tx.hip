@@ -9,6 +9,7 @@
 // fp64 partial sums, a scan of the block sums, then a per-block scan that adds
 // the block offset, wraps to (-pi, pi] and evaluates sincos in fp32.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -287,6 +288,235 @@ __global__ __launch_bounds__(FM_BLOCK) void tx_fm_fused_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------
+// Config 5 fast path: FM message -> phasors -> L/M polyphase -> quantise -> pack, instantiated per
+// (L, M, KP) like the RX pipe's fused kernels; every other shape takes tx_fm_fused_kernel above.
+//
+// Phase is kept in TURNS (fp64): phi_t[n] = phi_t[n-1] + (kf/fs) m[n].  v_fract_f64 wraps it, and
+// v_sin_f32 / v_cos_f32 take turns directly, so a phasor costs fract + cvt + two transcendental ops.
+//   pass A  fm_super_sum_kernel : fp64 sum of one superblock (TXQ_SB messages) per workgroup
+//   pass B  fm_super_scan_kernel: exclusive scan of the superblock sums (one workgroup per stream)
+//   pass C  tx_fm_fast_kernel   : one workgroup per superblock walks it in sub-blocks of TXQ_SUB
+//           messages with a running fp64 offset; each lane owns PER consecutive messages (local
+//           fp64 prefix, wave scan by shuffles), writes its phasors to a padded LDS row, then computes
+//           PER*L/M outputs from an 8-row-sample-overlapping register window with the polyphase taps
+//           in SGPRs (compile-time phases), quantises, packs and stores 16-byte pieces.
+// LDS rows: PER samples (8 B each) + 16 B pad -> lane pitch 112 B at PER = 12: ds_write_b128 /
+// ds_read_b128 are conflict-free.  Row -1 holds the 8 samples before the sub-block.
+// ---------------------------------------------------------------------------
+#define TXQ_NT 256
+#define TXQ_NSUB 4
+typedef __attribute__((address_space(4))) float tx_cfloat_t;
+typedef f32x4 __attribute__((aligned(4))) f32x4_a4;      // 16-byte global access at dword alignment (unaligned mode)
+typedef u32x4 __attribute__((aligned(4))) u32x4_a4;
+
+template <int L_, int M_, int KP_> struct TxCfg {
+    static constexpr int L = L_, M = M_, KP = KP_;
+    static constexpr int PER = 4 * M_;                   // messages per lane per sub-block (float4 loads, whole output groups)
+    static constexpr int NOUT = PER * L_ / M_;           // outputs per lane per sub-block
+    static constexpr int SUB = TXQ_NT * PER, SB = SUB * TXQ_NSUB;
+    static constexpr int ROW = PER * 8 + 16;             // LDS bytes per lane row
+    static constexpr int HSLOT = 8;                      // samples kept before the sub-block (>= KP - 1)
+    static_assert(KP_ - 1 <= HSLOT && HSLOT <= PER, "history must fit the tail of one row");
+    static_assert(NOUT % 4 == 0, "16-byte stores of packed words");
+};
+
+__device__ __forceinline__ f32x2 phasor_turns(double t)
+{
+    const float r = (float)__builtin_amdgcn_fract(t);    // [0, 1): abs error 2^-25 turns = 1.9e-7 rad
+    f32x2 o = {__builtin_amdgcn_cosf(r), __builtin_amdgcn_sinf(r)};
+    return o;
+}
+
+// Index space of passes A and C: VIRTUAL message index i' = i + phi, phi = n0 mod M, so that i' = 0 sits on
+// polyphase phase 0 whatever the call's start; the phi virtual messages before the call carry no phase
+// increment (their phasors come from the history) and the outputs they own were emitted by the previous call.
+template <class C>
+__global__ __launch_bounds__(TXQ_NT) void fm_super_sum_kernel(const float *__restrict__ m, long m_stride, size_t nv, int phi,
+                                                              double wt, double *__restrict__ ssum, long n_super)
+{
+    __shared__ double sh[TXQ_NT / 64];
+    const float *mm = m + (long)blockIdx.y * m_stride - phi;          // indexed by i'
+    const size_t base = (size_t)blockIdx.x * C::SB;
+    double s = 0.0;
+    if (base >= (size_t)phi && base + C::SB <= nv) {
+#pragma unroll 4
+        for (int i = 0; i < C::SB / 4 / TXQ_NT; i++) {
+            const f32x4 v = *(const f32x4_a4 *)(mm + base + 4 * ((size_t)i * TXQ_NT + threadIdx.x));
+            s += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+        }
+    } else {
+        for (size_t j = base + threadIdx.x; j < nv && j < base + C::SB; j += TXQ_NT) s += j >= (size_t)phi ? (double)mm[j] : 0.0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int k = 0; k < TXQ_NT / 64; k++) t += sh[k];
+        ssum[(long)blockIdx.y * n_super + blockIdx.x] = t * wt;
+    }
+}
+
+// exclusive scan in turns, each offset wrapped to [0,1); phase_in / phase_new are radians in (-pi, pi]
+__global__ __launch_bounds__(256) void fm_super_scan_kernel(double *__restrict__ ssum, long n_super,
+                                                            const double *__restrict__ phase_in,
+                                                            double *__restrict__ phase_new)
+{
+    __shared__ double sh[256];
+    double *b = ssum + (long)blockIdx.x * n_super;
+    const int t = threadIdx.x;
+    const long per = (n_super + 255) / 256;
+    const long lo = (long)t * per, hi = lo + per < n_super ? lo + per : n_super;
+    double s = 0.0;
+    for (long k = lo; k < hi; k++) s += b[k];
+    sh[t] = s;
+    __syncthreads();
+    if (t == 0) {
+        double run = phase_in[blockIdx.x] * (1.0 / TWO_PI);
+        for (int k = 0; k < 256; k++) { const double v = sh[k]; sh[k] = run; run += v; }
+        phase_new[blockIdx.x] = wrap_pi(TWO_PI * (run - rint(run)));
+    }
+    __syncthreads();
+    double run = sh[t];
+    for (long k = lo; k < hi; k++) { const double v = b[k]; b[k] = run - floor(run); run += v; }
+}
+
+template <class C>
+__global__ __launch_bounds__(TXQ_NT, 2) void tx_fm_fast_kernel(
+    const float *__restrict__ m, long m_stride, size_t n, int phi, int skip, double wt, const double *__restrict__ soff,
+    long n_super, const f32x2 *__restrict__ hist_in, f32x2 *__restrict__ hist_out, const float *__restrict__ rs_dev,
+    long n_out, int pack_mode, uint32_t *__restrict__ words, long w_stride, f32x2 *__restrict__ tap, long tap_stride)
+{
+    constexpr int L = C::L, M = C::M, KP = C::KP, PER = C::PER, NOUT = C::NOUT, ROW = C::ROW, HS = C::HSLOT, H = KP - 1;
+    __shared__ __attribute__((aligned(16))) unsigned char rows[(TXQ_NT + 1) * ROW];   // row r at (r + 1) * ROW
+    __shared__ double sh[TXQ_NT / 64 + 1];
+    const int s = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const float *mm = m + (long)s * m_stride - phi;                   // indexed by the virtual message index; n = virtual count
+    const size_t sbase = (size_t)blockIdx.x * C::SB;
+    const tx_cfloat_t *__restrict__ rs = (const tx_cfloat_t *)rs_dev;
+    double off = soff[(long)s * n_super + blockIdx.x];           // phase (turns) after message sbase-1
+    unsigned char *myrow = rows + (t + 1) * ROW;
+
+    // the HS samples before the superblock -> tail of row -1
+    if (t < HS) {
+        const int k = t + 1;                                       // message sbase - k
+        f32x2 hv = {0.f, 0.f};
+        if (k <= H) {
+            if (sbase >= (size_t)k) {
+                double ph = off;
+                for (int i = 1; i < k; i++) ph -= wt * (double)mm[sbase - i];
+                hv = phasor_turns(ph);
+            } else {                                               // sbase == 0: real message -k - phi
+                const long idx = (long)H - k - phi;
+                if (idx >= 0) hv = hist_in[(long)s * H + idx];
+            }
+        }
+        *(f32x2 *)(rows + 8 * (PER - k)) = hv;
+    }
+    for (int sb = 0; sb < TXQ_NSUB; sb++) {
+        const size_t base = sbase + (size_t)sb * C::SUB;          // workgroup-uniform
+        if (base >= n) break;
+        const size_t tb = base + (size_t)t * PER;
+        // messages -> local fp64 prefix (turns)
+        float mv[PER];
+        if (tb >= (size_t)phi && tb + PER <= n) {
+#pragma unroll
+            for (int q = 0; q < PER / 4; q++) {
+                const f32x4 v = *(const f32x4_a4 *)(mm + tb + 4 * q);
+                mv[4 * q] = v.x; mv[4 * q + 1] = v.y; mv[4 * q + 2] = v.z; mv[4 * q + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < PER; k++) mv[k] = (tb + k >= (size_t)phi && tb + k < n) ? mm[tb + k] : 0.f;
+        }
+        double c[PER], run = 0.0;
+#pragma unroll
+        for (int k = 0; k < PER; k++) { run = __builtin_fma((double)mv[k], wt, run); c[k] = run; }
+        double incl = run;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const double up = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += up;
+        }
+        if (lane == 63) sh[wave] = incl;
+        __syncthreads();                                           // also: previous sub-block's window reads are done
+        double woff = off;
+#pragma unroll
+        for (int k = 0; k < TXQ_NT / 64; k++) { const double v = sh[k]; if (k < wave) woff += v; }
+        double total = 0.0;
+#pragma unroll
+        for (int k = 0; k < TXQ_NT / 64; k++) total += sh[k];
+        const double excl = woff + (incl - run);
+#pragma unroll
+        for (int k = 0; k < PER; k += 2) {
+            f32x2 a = tb + k < n ? phasor_turns(excl + c[k]) : f32x2{0.f, 0.f};
+            f32x2 b = tb + k + 1 < n ? phasor_turns(excl + c[k + 1]) : f32x2{0.f, 0.f};
+            if (tb == 0) {                                         // virtual messages before the call: carried history
+                if (k < phi) a = hist_in[(long)s * H + H - phi + k];
+                if (k + 1 < phi) b = hist_in[(long)s * H + H - phi + k + 1];
+            }
+            const f32x4 q = {a.x, a.y, b.x, b.y};
+            *(f32x4 *)(myrow + 8 * k) = q;
+        }
+        off += total; off -= floor(off);
+        __syncthreads();
+        // history for the next call: the last H phasors of the stream live in this sub-block's rows (or row -1)
+        if (H > 0 && base + C::SUB >= n && t < H) {
+            const long rel = (long)n - H + t - (long)base;         // >= -H
+            const long r = rel >= 0 ? rel / PER : -1, cidx = rel >= 0 ? rel % PER : PER + rel;
+            hist_out[(long)s * H + t] = *(const f32x2 *)(rows + (r + 1) * ROW + 8 * cidx);
+        }
+        // window: the HS samples before the lane's first message + its PER messages
+        f32x2 x[HS + PER];
+#pragma unroll
+        for (int k = 0; k < HS; k += 2) {
+            const f32x4 q = *(const f32x4 *)(myrow - ROW + 8 * (PER - HS + k));
+            x[k] = q.xy; x[k + 1] = q.zw;
+        }
+#pragma unroll
+        for (int k = 0; k < PER; k += 2) {
+            const f32x4 q = *(const f32x4 *)(myrow + 8 * k);
+            x[HS + k] = q.xy; x[HS + k + 1] = q.zw;
+        }
+        float tp[KP * L];
+#pragma unroll
+        for (int i = 0; i < KP * L; i++) tp[i] = rs[i];
+        uint32_t wd[NOUT];
+        f32x2 o[NOUT];
+#pragma unroll
+        for (int u = 0; u < NOUT; u++) {
+            const int bb = (u * M) / L, p = (u * M) % L;          // newest message (lane-relative), polyphase leg
+            f32x2 acc = {0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < KP; i++) acc += x[HS + bb - i] * tp[p + i * L];
+            o[u] = acc;
+            wd[u] = tx_pack_word(pack_mode, tx_f2i16(acc.x * 4096.0f), tx_f2i16(acc.y * 4096.0f));
+        }
+        const long j0 = (long)(tb / M) * L - skip;                 // tb is a multiple of M; the first `skip` outputs are not ours
+        uint32_t *wp = words + (long)s * w_stride + j0;
+        if (j0 >= 0 && j0 + NOUT <= n_out) {
+#pragma unroll
+            for (int q = 0; q < NOUT / 4; q++) { const u32x4 v = {wd[4 * q], wd[4 * q + 1], wd[4 * q + 2], wd[4 * q + 3]}; *(u32x4_a4 *)(wp + 4 * q) = v; }
+        } else {
+#pragma unroll
+            for (int u = 0; u < NOUT; u++) if (j0 + u >= 0 && j0 + u < n_out) wp[u] = wd[u];
+        }
+        if (tap) {
+#pragma unroll
+            for (int u = 0; u < NOUT; u++) if (j0 + u >= 0 && j0 + u < n_out) tap[(long)s * tap_stride + j0 + u] = o[u];
+        }
+        // the last HS samples of this sub-block become row -1 of the next one
+        f32x2 keep = {0.f, 0.f};
+        if (t < HS) keep = *(const f32x2 *)(rows + TXQ_NT * ROW + 8 * (PER - HS + t));
+        __syncthreads();
+        if (t < HS) *(f32x2 *)(rows + 8 * (PER - HS + t)) = keep;
+    }
+}
+
+typedef TxCfg<2, 3, 8> TxCfgC5;      // config 5: 2/3 resampler, 16 prototype taps
+
 extern "C" size_t clhip_fm_mod_workspace_bytes(size_t n) { return (clhip_div_up(n, FM_ELEMS) + 2) * sizeof(double); }
 
 static int fm_mod_launch(const float *d_msg, long m_stride, size_t n, int n_streams, double w, double *d_phase,
@@ -450,6 +680,36 @@ extern "C" long clhip_tx_pipe_run(clhip_tx_pipe *p, int in_kind, const void *d_i
     const int H = p->kp - 1;
     const f32x2 *x = (const f32x2 *)d_in;
     long x_stride = (long)in_stride;
+    static const int tx_fast = getenv("CLHIP_TX_FAST") ? atoi(getenv("CLHIP_TX_FAST")) : 1;
+    if (tx_fast && in_kind == CL_TXPIPE_IN_FM_MESSAGE && p->L == TxCfgC5::L && p->M == TxCfgC5::M &&
+        p->n_rs == TxCfgC5::KP * TxCfgC5::L && (((uintptr_t)d_in) & 3) == 0) {
+        // config 5 instantiation (see tx_fm_fast_kernel), in the virtual index space i' = i + phi
+        typedef TxCfgC5 C;
+        const int phi = (int)(p->n_total % (unsigned long long)p->M), skip = (phi * p->L + p->M - 1) / p->M;
+        const size_t nv = n_in + (size_t)phi;
+        const long n_super = (long)clhip_div_up(nv, (size_t)C::SB);
+        const size_t wsn = (size_t)(n_super + 2) * p->n_streams + 8;
+        if (wsn > p->ws_cap) {
+            clhip_free(p->ws);
+            p->ws = (double *)clhip_malloc(sizeof(double) * wsn);
+            p->ws_cap = p->ws ? wsn : 0;
+            if (!p->ws) return -1;
+        }
+        const double wt = p->w * (1.0 / TWO_PI);
+        dim3 grid((unsigned)n_super, p->n_streams);
+        double *phase_new = p->ws + (size_t)n_super * p->n_streams;
+        hipLaunchKernelGGL(fm_super_sum_kernel<C>, grid, dim3(TXQ_NT), 0, s, (const float *)d_in, (long)in_stride, nv, phi, wt,
+                           p->ws, n_super);
+        hipLaunchKernelGGL(fm_super_scan_kernel, dim3(p->n_streams), dim3(256), 0, s, p->ws, n_super, p->d_phase, phase_new);
+        hipLaunchKernelGGL(tx_fm_fast_kernel<C>, grid, dim3(TXQ_NT), 0, s, (const float *)d_in, (long)in_stride, nv, phi, skip, wt,
+                           p->ws, n_super, p->hist[p->cur], p->hist[p->cur ^ 1], p->d_rs, (long)n_out, p->pack_mode,
+                           (uint32_t *)d_bytes, (long)(out_stride_bytes / 4), (f32x2 *)d_iq_tap, (long)iq_tap_stride);
+        CLHIP_CHECK(hipMemcpyAsync(p->d_phase, phase_new, sizeof(double) * p->n_streams, hipMemcpyDeviceToDevice, s));
+        CLHIP_CHECK_LAUNCH();
+        p->cur ^= 1;
+        p->n_total += n_in;
+        return (long)n_out;
+    }
     if (in_kind == CL_TXPIPE_IN_FM_MESSAGE && H <= TXF_HMAX - 1) {
         // fused path: block sums -> block scan -> phasor + resample + quantise + pack in one kernel
         const long n_blocks = (long)clhip_div_up(n_in, FM_ELEMS);

@@ -197,3 +197,52 @@ def test_tx_pipe_config5(G, orc):
     b4 = torch.zeros(4 * 5000, dtype=torch.uint8, device=G.DEV)
     assert pipe4.run(hip.TXPIPE_IN_CF32, torch.from_numpy(x).to(G.DEV), 0, 5000, b4, 4 * 5000) == 5000
     assert np.array_equal(b4.cpu().numpy(), orc.generate_data(orc.cf32_to_cs16(x), orc.TX_DOCUMENTED))
+
+
+def test_tx_pipe_streaming_any_start_phase(G, orc):
+    """Config 5 in chunks of every residue mod 3 and across the fast kernel's sub-block (3072) and superblock
+    (12288) boundaries: float tap vs the fp64 oracle (FM mod -> upfirdn 2/3), words == quantise+pack of the tap."""
+    import torch
+    from cariboulite_amd import hip
+    t = load_golden("taps.npz")
+    rng = np.random.default_rng(77)
+    n = 200_003
+    msg = (0.4 * np.sin(2 * np.pi * 2e3 * np.arange(n) / 4e6) + 0.3 * rng.standard_normal(n)).astype(np.float32)
+    iq, _ = orc.fm_mod_f64(msg, 75e3, 4e6)
+    want = orc.Resampler(t["rs_2_3"], 2, 3).f64(iq)
+    d = torch.from_numpy(msg).to(G.DEV)
+    pipe = hip.TxPipe(1, 75e3, 4e6, t["rs_2_3"], 2, 3, hip.TX_DOCUMENTED)
+    sizes = [1, 1, 2, 5, 3071, 3072, 3073, 1, 12287, 12288, 12289, 4, 7, 40000, 2]
+    sizes.append(n - sum(sizes))
+    taps_out, words_out, pos = [], [], 0
+    for cn in sizes:
+        k = pipe.out_count(cn)
+        by = torch.zeros(4 * max(k, 1) + 16, dtype=torch.uint8, device=G.DEV)
+        tp = torch.zeros((max(k, 1) + 2, 2), dtype=torch.float32, device=G.DEV)
+        # odd element offsets: the kernel must not need 16-byte aligned buffers
+        assert pipe.run(hip.TXPIPE_IN_FM_MESSAGE, d[pos:], 0, cn, by[4:], 4 * max(k, 1), tp[1:], max(k, 1)) == k
+        taps_out.append(tp[1:1 + k].cpu().numpy()); words_out.append(by[4:4 + 4 * k].cpu().numpy()); pos += cn
+    assert pos == n
+    got = np.concatenate(taps_out)
+    assert got.shape == want.shape
+    assert np.max(np.abs(got - want)) <= TOL * np.max(np.abs(want))
+    assert np.array_equal(np.concatenate(words_out), orc.generate_data(orc.cf32_to_cs16(got), orc.TX_DOCUMENTED))
+    # one shot == chunked to rounding
+    pipe1 = hip.TxPipe(1, 75e3, 4e6, t["rs_2_3"], 2, 3, hip.TX_DOCUMENTED)
+    k = pipe1.out_count(n)
+    tp1 = torch.zeros((k, 2), dtype=torch.float32, device=G.DEV)
+    by1 = torch.zeros(4 * k, dtype=torch.uint8, device=G.DEV)
+    assert pipe1.run(hip.TXPIPE_IN_FM_MESSAGE, d, 0, n, by1, 4 * k, tp1, k) == k
+    assert np.max(np.abs(tp1.cpu().numpy() - got)) <= 2e-6
+    # two streams in one call (strided buffers)
+    pipe2 = hip.TxPipe(2, 75e3, 4e6, t["rs_2_3"], 2, 3, hip.TX_DOCUMENTED)
+    n2 = 30001
+    d2 = torch.stack([d[:n2], d[50000:50000 + n2]]).contiguous()
+    k2 = pipe2.out_count(n2)
+    tp2 = torch.zeros((2, k2, 2), dtype=torch.float32, device=G.DEV)
+    by2 = torch.zeros((2, 4 * k2), dtype=torch.uint8, device=G.DEV)
+    assert pipe2.run(hip.TXPIPE_IN_FM_MESSAGE, d2, n2, n2, by2, 4 * k2, tp2, k2) == k2
+    for si, off in ((0, 0), (1, 50000)):
+        iq2, _ = orc.fm_mod_f64(msg[off:off + n2], 75e3, 4e6)
+        w2 = orc.Resampler(t["rs_2_3"], 2, 3).f64(iq2)
+        assert np.max(np.abs(tp2[si].cpu().numpy() - w2)) <= TOL * np.max(np.abs(w2))
