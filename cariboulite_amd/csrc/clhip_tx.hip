@@ -359,28 +359,169 @@ __global__ __launch_bounds__(TXQ_NT) void fm_super_sum_kernel(const float *__res
     }
 }
 
-// exclusive scan in turns, each offset wrapped to [0,1); phase_in / phase_new are radians in (-pi, pi]
+// exclusive scan in turns, each offset wrapped to [0,1); phase_in / phase_new are radians in (-pi, pi].
+// One workgroup per stream walks the sums in tiles of 8192 staged through LDS (coalesced both ways): lane-local
+// serial scan of 32 entries from LDS, wave scan by shuffles, 4 wave totals, a running carry between tiles.
+#define SCAN_TILE 8192
 __global__ __launch_bounds__(256) void fm_super_scan_kernel(double *__restrict__ ssum, long n_super,
                                                             const double *__restrict__ phase_in,
                                                             double *__restrict__ phase_new)
 {
-    __shared__ double sh[256];
+    __shared__ double tile[SCAN_TILE + SCAN_TILE / 32];           // one pad per 32 entries: lane chunks on distinct banks
+    __shared__ double wsum[4];
     double *b = ssum + (long)blockIdx.x * n_super;
-    const int t = threadIdx.x;
-    const long per = (n_super + 255) / 256;
-    const long lo = (long)t * per, hi = lo + per < n_super ? lo + per : n_super;
-    double s = 0.0;
-    for (long k = lo; k < hi; k++) s += b[k];
-    sh[t] = s;
-    __syncthreads();
-    if (t == 0) {
-        double run = phase_in[blockIdx.x] * (1.0 / TWO_PI);
-        for (int k = 0; k < 256; k++) { const double v = sh[k]; sh[k] = run; run += v; }
-        phase_new[blockIdx.x] = wrap_pi(TWO_PI * (run - rint(run)));
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    double carry = phase_in[blockIdx.x] * (1.0 / TWO_PI);
+    for (long t0 = 0; t0 < n_super; t0 += SCAN_TILE) {
+        const int cnt = (int)(n_super - t0 < SCAN_TILE ? n_super - t0 : SCAN_TILE);
+#pragma unroll 8
+        for (int i = t; i < SCAN_TILE; i += 256) tile[i + i / 32] = i < cnt ? b[t0 + i] : 0.0;
+        __syncthreads();
+        double *mine = tile + t * 33;
+        double run = 0.0;
+#pragma unroll 8
+        for (int k = 0; k < 32; k++) { const double v = mine[k]; mine[k] = run; run += v; }      // exclusive within the lane
+        double incl = run;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const double up = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += up;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        double base = carry, total = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const double v = wsum[k]; total += v; if (k < wave) base += v; }
+        base += incl - run;
+#pragma unroll 8
+        for (int k = 0; k < 32; k++) { const double v = base + mine[k]; mine[k] = v - floor(v); }
+        __syncthreads();
+#pragma unroll 8
+        for (int i = t; i < SCAN_TILE; i += 256) if (i < cnt) b[t0 + i] = tile[i + i / 32];
+        carry += total; carry -= floor(carry);
+        __syncthreads();
     }
+    if (t == 0) phase_new[blockIdx.x] = wrap_pi(TWO_PI * (carry - rint(carry)));
+}
+
+// (int16_t)(f * 4096.0f) as the x86-64 reference build does it (cvttss2si, low 16 bits): v_cvt_i32_f32
+// saturates where cvttss2si returns 0x80000000, which only changes the low half for f >= 2^31; NaN gives 0 on both
+__device__ __forceinline__ uint32_t tx_f2i16_fast(float v)
+{
+    const int t = v < 2147483648.0f ? (int)v : 0;
+    return (uint32_t)t & 0xFFFFu;
+}
+
+// One sub-block of tx_fm_fast_kernel.  CHECKED = false: every message and every output of the sub-block is inside
+// the call (workgroup-uniform), so there is not a single bounds test or divergent branch in it.
+template <class C, bool CHECKED>
+__device__ __forceinline__ double tx_fast_subblock(const float *mm, size_t n, int phi, int skip, double wt, double off,
+                                                   size_t base, unsigned char *rows, double *sh, const f32x2 *hist_in_s,
+                                                   f32x2 *hist_out_s, const tx_cfloat_t *__restrict__ rs, long n_out,
+                                                   int pack_mode, uint32_t *words_s, f32x2 *tap_s)
+{
+    constexpr int L = C::L, M = C::M, KP = C::KP, PER = C::PER, NOUT = C::NOUT, ROW = C::ROW, HS = C::HSLOT, H = KP - 1;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    unsigned char *myrow = rows + (t + 1) * ROW;
+    const size_t tb = base + (size_t)t * PER;
+    // messages -> local fp64 prefix (turns)
+    float mv[PER];
+    if (!CHECKED || (tb >= (size_t)phi && tb + PER <= n)) {
+#pragma unroll
+        for (int q = 0; q < PER / 4; q++) {
+            const f32x4 v = *(const f32x4_a4 *)(mm + tb + 4 * q);
+            mv[4 * q] = v.x; mv[4 * q + 1] = v.y; mv[4 * q + 2] = v.z; mv[4 * q + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < PER; k++) mv[k] = (tb + k >= (size_t)phi && tb + k < n) ? mm[tb + k] : 0.f;
+    }
+    double c[PER], run = 0.0;
+#pragma unroll
+    for (int k = 0; k < PER; k++) { run = __builtin_fma((double)mv[k], wt, run); c[k] = run; }
+    double incl = run;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
+    }
+    if (lane == 63) sh[wave] = incl;
+    __syncthreads();                                           // also: the previous sub-block's window reads are done
+    double woff = off, total = 0.0;
+#pragma unroll
+    for (int k = 0; k < TXQ_NT / 64; k++) { const double v = sh[k]; total += v; if (k < wave) woff += v; }
+    const double excl = woff + (incl - run);
+#pragma unroll
+    for (int k = 0; k < PER; k += 2) {
+        f32x2 a = phasor_turns(excl + c[k]), b = phasor_turns(excl + c[k + 1]);
+        if (CHECKED) {
+            if (tb + k >= n) a = f32x2{0.f, 0.f};
+            if (tb + k + 1 >= n) b = f32x2{0.f, 0.f};
+            if (tb == 0) {                                     // virtual messages before the call: carried history
+                if (k < phi) a = hist_in_s[H - phi + k];
+                if (k + 1 < phi) b = hist_in_s[H - phi + k + 1];
+            }
+        }
+        const f32x4 q = {a.x, a.y, b.x, b.y};
+        *(f32x4 *)(myrow + 8 * k) = q;
+    }
+    off += total; off -= floor(off);
     __syncthreads();
-    double run = sh[t];
-    for (long k = lo; k < hi; k++) { const double v = b[k]; b[k] = run - floor(run); run += v; }
+    // history for the next call: the last H phasors of the stream live in this sub-block's rows (or row -1)
+    if (CHECKED && H > 0 && base + C::SUB >= n && t < H) {
+        const long rel = (long)n - H + t - (long)base;         // >= -H
+        const long r = rel >= 0 ? rel / PER : -1, cidx = rel >= 0 ? rel % PER : PER + rel;
+        hist_out_s[t] = *(const f32x2 *)(rows + (r + 1) * ROW + 8 * cidx);
+    }
+    // window: the HS samples before the lane's first message + its PER messages
+    f32x2 x[HS + PER];
+#pragma unroll
+    for (int k = 0; k < HS; k += 2) {
+        const f32x4 q = *(const f32x4 *)(myrow - ROW + 8 * (PER - HS + k));
+        x[k] = q.xy; x[k + 1] = q.zw;
+    }
+#pragma unroll
+    for (int k = 0; k < PER; k += 2) {
+        const f32x4 q = *(const f32x4 *)(myrow + 8 * k);
+        x[HS + k] = q.xy; x[HS + k + 1] = q.zw;
+    }
+    float tp[KP * L];
+#pragma unroll
+    for (int i = 0; i < KP * L; i++) tp[i] = rs[i];
+    uint32_t wd[NOUT];
+    f32x2 o[NOUT];
+#pragma unroll
+    for (int u = 0; u < NOUT; u++) {
+        const int bb = (u * M) / L, p = (u * M) % L;          // newest message (lane-relative), polyphase leg
+        f32x2 acc = {0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < KP; i++) acc += x[HS + bb - i] * tp[p + i * L];
+        o[u] = acc;
+        wd[u] = tx_pack_word(CL_TX_DOCUMENTED, tx_f2i16_fast(acc.x * 4096.0f), tx_f2i16_fast(acc.y * 4096.0f));
+    }
+    if (pack_mode == CL_TX_AS_WRITTEN) {                       // uniform: the shipped packer ignores its input
+#pragma unroll
+        for (int u = 0; u < NOUT; u++) wd[u] = tx_pack_word(CL_TX_AS_WRITTEN, 0, 0);
+    }
+    const long j0 = (long)(tb / M) * L - skip;                 // tb is a multiple of M; the first `skip` outputs are not ours
+    uint32_t *wp = words_s + j0;
+    if (!CHECKED || (j0 >= 0 && j0 + NOUT <= n_out)) {
+#pragma unroll
+        for (int q = 0; q < NOUT / 4; q++) { const u32x4 v = {wd[4 * q], wd[4 * q + 1], wd[4 * q + 2], wd[4 * q + 3]}; *(u32x4_a4 *)(wp + 4 * q) = v; }
+    } else {
+#pragma unroll
+        for (int u = 0; u < NOUT; u++) if (j0 + u >= 0 && j0 + u < n_out) wp[u] = wd[u];
+    }
+    if (tap_s) {
+#pragma unroll
+        for (int u = 0; u < NOUT; u++) if (!CHECKED || (j0 + u >= 0 && j0 + u < n_out)) tap_s[j0 + u] = o[u];
+    }
+    // the last HS samples of this sub-block become row -1 of the next one
+    f32x2 keep = {0.f, 0.f};
+    if (t < HS) keep = *(const f32x2 *)(rows + TXQ_NT * ROW + 8 * (PER - HS + t));
+    __syncthreads();
+    if (t < HS) *(f32x2 *)(rows + 8 * (PER - HS + t)) = keep;
+    return off;
 }
 
 template <class C>
@@ -389,15 +530,14 @@ __global__ __launch_bounds__(TXQ_NT, 2) void tx_fm_fast_kernel(
     long n_super, const f32x2 *__restrict__ hist_in, f32x2 *__restrict__ hist_out, const float *__restrict__ rs_dev,
     long n_out, int pack_mode, uint32_t *__restrict__ words, long w_stride, f32x2 *__restrict__ tap, long tap_stride)
 {
-    constexpr int L = C::L, M = C::M, KP = C::KP, PER = C::PER, NOUT = C::NOUT, ROW = C::ROW, HS = C::HSLOT, H = KP - 1;
+    constexpr int KP = C::KP, PER = C::PER, ROW = C::ROW, HS = C::HSLOT, H = KP - 1;
     __shared__ __attribute__((aligned(16))) unsigned char rows[(TXQ_NT + 1) * ROW];   // row r at (r + 1) * ROW
     __shared__ double sh[TXQ_NT / 64 + 1];
-    const int s = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int s = blockIdx.y, t = threadIdx.x;
     const float *mm = m + (long)s * m_stride - phi;                   // indexed by the virtual message index; n = virtual count
     const size_t sbase = (size_t)blockIdx.x * C::SB;
     const tx_cfloat_t *__restrict__ rs = (const tx_cfloat_t *)rs_dev;
     double off = soff[(long)s * n_super + blockIdx.x];           // phase (turns) after message sbase-1
-    unsigned char *myrow = rows + (t + 1) * ROW;
 
     // the HS samples before the superblock -> tail of row -1
     if (t < HS) {
@@ -415,103 +555,19 @@ __global__ __launch_bounds__(TXQ_NT, 2) void tx_fm_fast_kernel(
         }
         *(f32x2 *)(rows + 8 * (PER - k)) = hv;
     }
+    uint32_t *words_s = words + (long)s * w_stride;
+    f32x2 *tap_s = tap ? tap + (long)s * tap_stride : nullptr;
     for (int sb = 0; sb < TXQ_NSUB; sb++) {
         const size_t base = sbase + (size_t)sb * C::SUB;          // workgroup-uniform
         if (base >= n) break;
-        const size_t tb = base + (size_t)t * PER;
-        // messages -> local fp64 prefix (turns)
-        float mv[PER];
-        if (tb >= (size_t)phi && tb + PER <= n) {
-#pragma unroll
-            for (int q = 0; q < PER / 4; q++) {
-                const f32x4 v = *(const f32x4_a4 *)(mm + tb + 4 * q);
-                mv[4 * q] = v.x; mv[4 * q + 1] = v.y; mv[4 * q + 2] = v.z; mv[4 * q + 3] = v.w;
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < PER; k++) mv[k] = (tb + k >= (size_t)phi && tb + k < n) ? mm[tb + k] : 0.f;
-        }
-        double c[PER], run = 0.0;
-#pragma unroll
-        for (int k = 0; k < PER; k++) { run = __builtin_fma((double)mv[k], wt, run); c[k] = run; }
-        double incl = run;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const double up = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += up;
-        }
-        if (lane == 63) sh[wave] = incl;
-        __syncthreads();                                           // also: previous sub-block's window reads are done
-        double woff = off;
-#pragma unroll
-        for (int k = 0; k < TXQ_NT / 64; k++) { const double v = sh[k]; if (k < wave) woff += v; }
-        double total = 0.0;
-#pragma unroll
-        for (int k = 0; k < TXQ_NT / 64; k++) total += sh[k];
-        const double excl = woff + (incl - run);
-#pragma unroll
-        for (int k = 0; k < PER; k += 2) {
-            f32x2 a = tb + k < n ? phasor_turns(excl + c[k]) : f32x2{0.f, 0.f};
-            f32x2 b = tb + k + 1 < n ? phasor_turns(excl + c[k + 1]) : f32x2{0.f, 0.f};
-            if (tb == 0) {                                         // virtual messages before the call: carried history
-                if (k < phi) a = hist_in[(long)s * H + H - phi + k];
-                if (k + 1 < phi) b = hist_in[(long)s * H + H - phi + k + 1];
-            }
-            const f32x4 q = {a.x, a.y, b.x, b.y};
-            *(f32x4 *)(myrow + 8 * k) = q;
-        }
-        off += total; off -= floor(off);
-        __syncthreads();
-        // history for the next call: the last H phasors of the stream live in this sub-block's rows (or row -1)
-        if (H > 0 && base + C::SUB >= n && t < H) {
-            const long rel = (long)n - H + t - (long)base;         // >= -H
-            const long r = rel >= 0 ? rel / PER : -1, cidx = rel >= 0 ? rel % PER : PER + rel;
-            hist_out[(long)s * H + t] = *(const f32x2 *)(rows + (r + 1) * ROW + 8 * cidx);
-        }
-        // window: the HS samples before the lane's first message + its PER messages
-        f32x2 x[HS + PER];
-#pragma unroll
-        for (int k = 0; k < HS; k += 2) {
-            const f32x4 q = *(const f32x4 *)(myrow - ROW + 8 * (PER - HS + k));
-            x[k] = q.xy; x[k + 1] = q.zw;
-        }
-#pragma unroll
-        for (int k = 0; k < PER; k += 2) {
-            const f32x4 q = *(const f32x4 *)(myrow + 8 * k);
-            x[HS + k] = q.xy; x[HS + k + 1] = q.zw;
-        }
-        float tp[KP * L];
-#pragma unroll
-        for (int i = 0; i < KP * L; i++) tp[i] = rs[i];
-        uint32_t wd[NOUT];
-        f32x2 o[NOUT];
-#pragma unroll
-        for (int u = 0; u < NOUT; u++) {
-            const int bb = (u * M) / L, p = (u * M) % L;          // newest message (lane-relative), polyphase leg
-            f32x2 acc = {0.f, 0.f};
-#pragma unroll
-            for (int i = 0; i < KP; i++) acc += x[HS + bb - i] * tp[p + i * L];
-            o[u] = acc;
-            wd[u] = tx_pack_word(pack_mode, tx_f2i16(acc.x * 4096.0f), tx_f2i16(acc.y * 4096.0f));
-        }
-        const long j0 = (long)(tb / M) * L - skip;                 // tb is a multiple of M; the first `skip` outputs are not ours
-        uint32_t *wp = words + (long)s * w_stride + j0;
-        if (j0 >= 0 && j0 + NOUT <= n_out) {
-#pragma unroll
-            for (int q = 0; q < NOUT / 4; q++) { const u32x4 v = {wd[4 * q], wd[4 * q + 1], wd[4 * q + 2], wd[4 * q + 3]}; *(u32x4_a4 *)(wp + 4 * q) = v; }
-        } else {
-#pragma unroll
-            for (int u = 0; u < NOUT; u++) if (j0 + u >= 0 && j0 + u < n_out) wp[u] = wd[u];
-        }
-        if (tap) {
-#pragma unroll
-            for (int u = 0; u < NOUT; u++) if (j0 + u >= 0 && j0 + u < n_out) tap[(long)s * tap_stride + j0 + u] = o[u];
-        }
-        // the last HS samples of this sub-block become row -1 of the next one
-        f32x2 keep = {0.f, 0.f};
-        if (t < HS) keep = *(const f32x2 *)(rows + TXQ_NT * ROW + 8 * (PER - HS + t));
-        __syncthreads();
-        if (t < HS) *(f32x2 *)(rows + 8 * (PER - HS + t)) = keep;
+        // interior: all messages are real and inside the call, all outputs are ours, and the stream does not
+        // end here (the sub-block holding the last message also writes the history for the next call)
+        if (base > 0 && base + C::SUB < n)
+            off = tx_fast_subblock<C, false>(mm, n, phi, skip, wt, off, base, rows, sh, hist_in + (long)s * H,
+                                             hist_out + (long)s * H, rs, n_out, pack_mode, words_s, tap_s);
+        else
+            off = tx_fast_subblock<C, true>(mm, n, phi, skip, wt, off, base, rows, sh, hist_in + (long)s * H,
+                                            hist_out + (long)s * H, rs, n_out, pack_mode, words_s, tap_s);
     }
 }
 
