@@ -5,15 +5,22 @@
 // for the life of the stream.  fp32 state fails the 1e-5 bar at the reference's
 // narrow cut-offs, so everything here is fp64.
 //
-// The recursion is strictly sequential per rail; it is made parallel as a
-// blocked linear-recurrence scan over the cascade's 2*n_stages-dim state z:
+// The recursion is strictly sequential per rail; it is made parallel as a blocked
+// linear-recurrence scan over the cascade's D = 2*n_stages-dim state z:
 //     z[n] = F z[n-1] + g x[n]
-//   pass 1  every lane runs a SEG-sample segment from zero state  -> zero-state end vector
-//   pass 2a per tile of 256 segments: Kogge-Stone scan with P^(2^d), P = F^SEG  (LDS)
-//   pass 2b per stream: tiles chained sequentially with Q = P^256             (one lane)
-//   pass 3  every lane rebuilds its true start state (scan result + P^i * tile carry),
-//           re-runs its segment and writes the truncated int16 outputs in place
-// F, P^(2^d), P^i and Q are built on the host in fp64 by simulating the cascade.
+// A lane owns a SEG = 64-sample segment, a workgroup a tile of 256 segments.
+//   K1  zero-state end vector of every segment as a 64-tap "matrix FIR"
+//           zs = sum_k (F^(63-k) g) x[k]          (independent FMAs, taps by scalar loads)
+//       then a Kogge-Stone scan over the tile's 256 lanes with P^(2^d), P = F^64 (LDS exchange)
+//       -> E[seg] (state after the segment if the tile started from zero) and the tile's end vector
+//   K2  per stream: the tile end vectors are chained with Q = P^256: every lane runs 16 consecutive
+//       tiles serially, one Kogge-Stone scan with (Q^16)^(2^d) joins the 256 lanes, a second serial
+//       walk writes the state entering every tile.  4096 tiles (2^26 samples) per round.
+//   K3  every lane rebuilds its true start state  E[seg-1] + P^lane * (state entering the tile),
+//       runs the recursion over its segment and writes the truncated int16 outputs in place
+// Tiles travel through LDS (coalesced 16-byte global accesses on one side, one row of 64+4 dwords per
+// lane on the other: lane t reading 16 bytes of row t touches banks 4t..4t+3 -- conflict-free).
+// F, g, P^(2^d), P^i, Q and (Q^16)^(2^d) are built on the host in fp64 by simulating the cascade.
 #include <math.h>
 #include <string.h>
 
@@ -23,6 +30,10 @@
 #define IIR_MAX_DIM (2 * IIR_MAX_STAGES)
 #define IIR_SEG 64
 #define IIR_TILE 256
+#define IIR_K2_CHAIN 16                    // tiles walked serially by one lane of K2
+#define IIR_MSZ (IIR_MAX_DIM * IIR_MAX_DIM) // matrices are stored 8x8, row-major, zero outside DxD
+
+typedef __attribute__((address_space(4))) double cdouble_t;   // read-only tables: scalar (SMEM) loads when uniform
 
 struct IirCoef {
     int n_stages, dim;
@@ -30,63 +41,65 @@ struct IirCoef {
 };
 
 // one cascade step on a DF-II state (v1,v2 per stage); returns the output
+template <int NS>
 __host__ __device__ __forceinline__ double iir_step(const IirCoef &c, double *z, double in)
 {
     double out = in;
 #pragma unroll
-    for (int s = 0; s < IIR_MAX_STAGES; s++) {
-        if (s < c.n_stages) {
-            const double w = out - c.a1[s] * z[2 * s] - c.a2[s] * z[2 * s + 1];
-            out = c.b0[s] * w + c.b1[s] * z[2 * s] + c.b2[s] * z[2 * s + 1];
-            z[2 * s + 1] = z[2 * s];
-            z[2 * s] = w;
-        }
+    for (int s = 0; s < NS; s++) {
+        const double w = out - c.a1[s] * z[2 * s] - c.a2[s] * z[2 * s + 1];
+        out = c.b0[s] * w + c.b1[s] * z[2 * s] + c.b2[s] * z[2 * s + 1];
+        z[2 * s + 1] = z[2 * s];
+        z[2 * s] = w;
     }
     return out;
 }
 
-// (int16_t)(float)y with the x86 conversion semantics of the reference build
+// (int16_t)(float)y with the x86 conversion semantics of the reference build (cvttss2si, low half):
+// v_cvt_i32_f32 saturates where cvttss2si returns 0x80000000; the low 16 bits differ only for f >= 2^31
 __device__ __forceinline__ uint32_t iir_to_i16(double y)
 {
     const float f = (float)y;
-    const int t = (f >= -2147483648.0f && f < 2147483648.0f) ? (int)f : (int)0x80000000;
+    const int t = f < 2147483648.0f ? (int)f : 0;
     return (uint32_t)t & 0xFFFFu;
 }
 
-// 8x8 mat-vec; rows/columns beyond the filter's dimension are zero in the tables
-__device__ __forceinline__ void matvec(const double *__restrict__ m, const double *v, double *out)
+// out[r] (+)= sum_c m[r][c] v[c] over the DxD corner of an 8x8 table
+template <int D, bool ACC, class MP>
+__device__ __forceinline__ void matvec(MP m, const double *v, double *out)
 {
 #pragma unroll
-    for (int r = 0; r < IIR_MAX_DIM; r++) {
-        double s = 0.0;
+    for (int r = 0; r < D; r++) {
+        double s = ACC ? out[r] : 0.0;
 #pragma unroll
-        for (int c = 0; c < IIR_MAX_DIM; c++) s += m[r * IIR_MAX_DIM + c] * v[c];
+        for (int c = 0; c < D; c++) s = __builtin_fma(m[r * IIR_MAX_DIM + c], v[c], s);
         out[r] = s;
     }
 }
 
-// A tile is IIR_TILE segments x IIR_SEG samples = 16384 int16 pairs (64 KiB).  Lanes walk their own
-// segment sequentially, so direct global access would touch 64 cache lines per load instruction;
-// instead the tile is copied through LDS: coalesced 16-byte global accesses on one side, a
-// (IIR_SEG+1)-dword row pitch on the other so that lane t reading word k of row t hits bank (t+k)%32.
-#define IIR_PITCH (IIR_SEG + 1)
+// ---------------------------------------------------------------------------
+// tile staging
+// ---------------------------------------------------------------------------
+#define IIR_PITCH (IIR_SEG + 4)             // dwords per lane row: 16-byte aligned rows, bank = 4 * lane
 #define IIR_LDS_WORDS (IIR_TILE * IIR_PITCH)
 
 __device__ __forceinline__ void iir_tile_load(const uint32_t *__restrict__ x, long n_left, uint32_t *sm, int t)
 {
-    // n_left = samples of this stream from the tile start (>= 1); words beyond it are not read
+    // n_left = samples of this stream from the tile start (>= 1); words beyond it read as zero
     constexpr int TOTAL = IIR_TILE * IIR_SEG;
     const bool vec = ((uintptr_t)x & 15) == 0;
+#pragma unroll 4
     for (int i = t * 4; i < TOTAL; i += IIR_TILE * 4) {
-        uint32_t w[4] = {0, 0, 0, 0};
-        if (vec && i + 4 <= n_left) {
-            const u32x4 v = *(const u32x4 *)(x + i);
-            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-        } else {
-            for (int k = 0; k < 4; k++) if (i + k < n_left) w[k] = x[i + k];
+        u32x4 v = {0, 0, 0, 0};
+        if (vec && i + 4 <= n_left) v = *(const u32x4 *)(x + i);
+        else {
+            if (i < n_left) v.x = x[i];
+            if (i + 1 < n_left) v.y = x[i + 1];
+            if (i + 2 < n_left) v.z = x[i + 2];
+            if (i + 3 < n_left) v.w = x[i + 3];
         }
         const int row = i / IIR_SEG, col = i % IIR_SEG;          // 4 consecutive words stay in one row
-        for (int k = 0; k < 4; k++) sm[row * IIR_PITCH + col + k] = w[k];
+        *(u32x4 *)(sm + row * IIR_PITCH + col) = v;
     }
 }
 
@@ -94,151 +107,194 @@ __device__ __forceinline__ void iir_tile_store(uint32_t *__restrict__ x, long n_
 {
     constexpr int TOTAL = IIR_TILE * IIR_SEG;
     const bool vec = ((uintptr_t)x & 15) == 0;
+#pragma unroll 4
     for (int i = t * 4; i < TOTAL; i += IIR_TILE * 4) {
         const int row = i / IIR_SEG, col = i % IIR_SEG;
-        uint32_t w[4];
-        for (int k = 0; k < 4; k++) w[k] = sm[row * IIR_PITCH + col + k];
-        if (vec && i + 4 <= n_left) {
-            u32x4 v = {w[0], w[1], w[2], w[3]};
-            *(u32x4 *)(x + i) = v;
-        } else {
-            for (int k = 0; k < 4; k++) if (i + k < n_left) x[i + k] = w[k];
+        const u32x4 v = *(const u32x4 *)(sm + row * IIR_PITCH + col);
+        if (vec && i + 4 <= n_left) *(u32x4 *)(x + i) = v;
+        else {
+            if (i < n_left) x[i] = v.x;
+            if (i + 1 < n_left) x[i + 1] = v.y;
+            if (i + 2 < n_left) x[i + 2] = v.z;
+            if (i + 3 < n_left) x[i + 3] = v.w;
         }
     }
-}
-
-// pass 1: zero-state response of every segment.  ws_seg[stream][seg][rail][dim]
-__global__ __launch_bounds__(IIR_TILE) void iir_pass1_kernel(IirCoef c, const uint32_t *__restrict__ iq, long stride,
-                                                           long n, long n_seg, double *__restrict__ ws_seg)
-{
-    extern __shared__ uint32_t iir_sm[];
-    const int t = threadIdx.x;
-    const long tile0 = (long)blockIdx.x * IIR_TILE * IIR_SEG;
-    iir_tile_load(iq + (long)blockIdx.y * stride + tile0, n - tile0, iir_sm, t);
-    __syncthreads();
-    const long seg = (long)blockIdx.x * IIR_TILE + t;
-    if (seg >= n_seg) return;
-    const uint32_t *x = iir_sm + t * IIR_PITCH;
-    const long cnt = n - seg * IIR_SEG < IIR_SEG ? n - seg * IIR_SEG : IIR_SEG;
-    double zi[IIR_MAX_DIM], zq[IIR_MAX_DIM];
-#pragma unroll
-    for (int k = 0; k < IIR_MAX_DIM; k++) { zi[k] = 0.0; zq[k] = 0.0; }
-    for (long k = 0; k < cnt; k++) {
-        const uint32_t w = x[k];
-        (void)iir_step(c, zi, (double)(int16_t)(w & 0xFFFF));
-        (void)iir_step(c, zq, (double)(int16_t)(w >> 16));
-    }
-    double *o = ws_seg + ((long)blockIdx.y * n_seg + seg) * 2 * IIR_MAX_DIM;
-#pragma unroll
-    for (int k = 0; k < IIR_MAX_DIM; k++) { o[k] = zi[k]; o[IIR_MAX_DIM + k] = zq[k]; }
 }
 
 // Kogge-Stone inclusive scan over the 256 lanes of a workgroup for the recurrence
 //   v_i <- v_i + M^(2^d) v_(i - 2^d),   pow2[d] = M^(2^d)
-// leaving v_i = sum_{j<=i} M^(i-j) v_j (both rails).  sh: [IIR_TILE][2*IIR_MAX_DIM+1] doubles.
-__device__ __forceinline__ void ks_scan(double (&v)[2 * IIR_MAX_DIM], const double *__restrict__ pow2,
-                                        double (*sh)[2 * IIR_MAX_DIM + 1], int t)
+// leaving v_i = sum_{j<=i} M^(i-j) v_j (both rails: v = [I rail D | Q rail D]).  sh: 256 rows of 2D+1 doubles.
+template <int D>
+__device__ __forceinline__ void ks_scan(double (&v)[2 * D], const cdouble_t *__restrict__ pow2, double *sh, int t)
 {
+    constexpr int RS = 2 * D + 1;
+#pragma unroll 1
     for (int d = 0; d < 8; d++) {
 #pragma unroll
-        for (int k = 0; k < 2 * IIR_MAX_DIM; k++) sh[t][k] = v[k];
+        for (int k = 0; k < 2 * D; k++) sh[t * RS + k] = v[k];
         __syncthreads();
         const int src = t - (1 << d);
         if (src >= 0) {
-            double pv[2 * IIR_MAX_DIM], add[IIR_MAX_DIM];
+            double pv[2 * D];
 #pragma unroll
-            for (int k = 0; k < 2 * IIR_MAX_DIM; k++) pv[k] = sh[src][k];
-            const double *m = pow2 + d * IIR_MAX_DIM * IIR_MAX_DIM;
-            matvec(m, pv, add);
-#pragma unroll
-            for (int k = 0; k < IIR_MAX_DIM; k++) v[k] += add[k];
-            matvec(m, pv + IIR_MAX_DIM, add);
-#pragma unroll
-            for (int k = 0; k < IIR_MAX_DIM; k++) v[IIR_MAX_DIM + k] += add[k];
+            for (int k = 0; k < 2 * D; k++) pv[k] = sh[src * RS + k];
+            const cdouble_t *m = pow2 + d * IIR_MSZ;
+            matvec<D, true>(m, pv, v);
+            matvec<D, true>(m, pv + D, v + D);
         }
         __syncthreads();
     }
 }
 
-// pass 2a: inclusive scan inside each tile (zero carry), in place:
-//   E[i] = sum_{j<=i} P^(i-j) zs[j]     pow2[d] = P^(2^d)
-__global__ __launch_bounds__(IIR_TILE) void iir_pass2a_kernel(const double *__restrict__ pow2, long n_seg,
-                                                            double *__restrict__ ws_seg)
+struct IirPlan {
+    IirCoef coef;
+    double G[IIR_SEG][IIR_MAX_DIM];         // G[j] = F^j g
+    double pow2[8][IIR_MSZ];                // P^(2^d), P = F^SEG
+    double ppow[IIR_TILE][IIR_MSZ];         // P^i
+    double Q[IIR_MSZ];                      // P^TILE
+    double qspow2[8][IIR_MSZ];              // (Q^CHAIN)^(2^d)
+};
+
+// K1: zero-state end vector per segment + scan inside the tile.
+//   E[stream][seg][2D], tend[stream][tile][2D]
+template <int NS>
+__global__ __launch_bounds__(IIR_TILE) void iir_k1_kernel(const IirPlan *__restrict__ plan, const uint32_t *__restrict__ iq,
+                                                         long stride, long n, long n_seg, long n_tiles,
+                                                         double *__restrict__ E, double *__restrict__ tend)
 {
-    __shared__ double sh[IIR_TILE][2 * IIR_MAX_DIM + 1];
+    constexpr int D = 2 * NS;
+    extern __shared__ __attribute__((aligned(16))) uint32_t iir_sm[];
     const int t = threadIdx.x;
+    const long tile0 = (long)blockIdx.x * IIR_TILE * IIR_SEG;
+    iir_tile_load(iq + (long)blockIdx.y * stride + tile0, n - tile0, iir_sm, t);
+    __syncthreads();
+    const cdouble_t *__restrict__ G = (const cdouble_t *)&plan->G[0][0];
+    const uint32_t *x = iir_sm + t * IIR_PITCH;
+    double v[2 * D];
+#pragma unroll
+    for (int k = 0; k < 2 * D; k++) v[k] = 0.0;
+#pragma unroll 2
+    for (int k = 0; k < IIR_SEG; k += 4) {
+        const u32x4 w = *(const u32x4 *)(x + k);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const double xi = (double)(int16_t)(w[j] & 0xFFFF), xq = (double)(int16_t)(w[j] >> 16);
+            const cdouble_t *g = G + (IIR_SEG - 1 - (k + j)) * IIR_MAX_DIM;
+#pragma unroll
+            for (int r = 0; r < D; r++) {
+                const double gr = g[r];
+                v[r] = __builtin_fma(gr, xi, v[r]);
+                v[D + r] = __builtin_fma(gr, xq, v[D + r]);
+            }
+        }
+    }
+    __syncthreads();                         // the staged tile is dead: its LDS carries the scan exchange
+    ks_scan<D>(v, (const cdouble_t *)&plan->pow2[0][0], (double *)iir_sm, t);
     const long seg = (long)blockIdx.x * IIR_TILE + t;
-    double *o = ws_seg + ((long)blockIdx.y * n_seg + seg) * 2 * IIR_MAX_DIM;
-    double v[2 * IIR_MAX_DIM];
-#pragma unroll
-    for (int k = 0; k < 2 * IIR_MAX_DIM; k++) v[k] = seg < n_seg ? o[k] : 0.0;
-    ks_scan(v, pow2, sh, t);
     if (seg < n_seg) {
+        double *o = E + ((long)blockIdx.y * n_seg + seg) * 2 * D;
 #pragma unroll
-        for (int k = 0; k < 2 * IIR_MAX_DIM; k++) o[k] = v[k];
+        for (int k = 0; k < 2 * D; k++) o[k] = v[k];
+    }
+    if (t == IIR_TILE - 1) {
+        double *o = tend + ((long)blockIdx.y * n_tiles + blockIdx.x) * 2 * D;
+#pragma unroll
+        for (int k = 0; k < 2 * D; k++) o[k] = v[k];
     }
 }
 
-// pass 2b: chain the tiles of one stream.  carry[k] = state entering tile k:
-//   carry[0] = state_in,  carry[k+1] = Q carry[k] + E[last segment of tile k],  Q = P^TILE
-// The same scan one level up: 256 tiles per step with Q^(2^d), then Q^(i+1) times the step's
-// carry-in.  One workgroup per stream; a 2^26-sample stream is 16 steps.
-__global__ __launch_bounds__(IIR_TILE) void iir_pass2b_kernel(const double *__restrict__ qpow2 /* Q^(2^d) */,
-                                                            const double *__restrict__ qpow /* Q^i, i<=TILE */,
-                                                            long n_seg, long n_tiles, const double *__restrict__ ws_seg,
-                                                            double *__restrict__ carry, const double *__restrict__ state)
+// K2: state entering every tile.  carry[stream][tile][2D], tile = 0 .. n_tiles-1
+template <int NS>
+__global__ __launch_bounds__(IIR_TILE) void iir_k2_kernel(const IirPlan *__restrict__ plan, long n_tiles,
+                                                         const double *__restrict__ tend, double *__restrict__ carry,
+                                                         const double *__restrict__ state)
 {
-    __shared__ double sh[IIR_TILE][2 * IIR_MAX_DIM + 1];
-    __shared__ double cc[2 * IIR_MAX_DIM];
+    constexpr int D = 2 * NS, RS = 2 * D + 1;
+    __shared__ double sh[IIR_TILE * RS];
+    __shared__ double cc[2 * D];
     const int s = blockIdx.x, t = threadIdx.x;
-    if (t < 2 * IIR_MAX_DIM) cc[t] = state[(long)s * 2 * IIR_MAX_DIM + t];
+    const cdouble_t *__restrict__ Q = (const cdouble_t *)&plan->Q[0];
+    const double *te = tend + (long)s * n_tiles * 2 * D;
+    double *cr = carry + (long)s * n_tiles * 2 * D;
+    if (t < 2 * D) cc[t] = state[(long)s * 2 * IIR_MAX_DIM + (t / D) * IIR_MAX_DIM + (t % D)];
     __syncthreads();
-    for (long base = 0; base < n_tiles; base += IIR_TILE) {
-        const long tile = base + t;
-        double v[2 * IIR_MAX_DIM];
-        // E of the tile's last segment (a ragged last tile only feeds the unused carry after the stream)
-        const long last = (tile + 1) * IIR_TILE - 1 < n_seg ? (tile + 1) * IIR_TILE - 1 : n_seg - 1;
+    for (long base = 0; base < n_tiles; base += (long)IIR_TILE * IIR_K2_CHAIN) {
+        const long T0 = base + (long)t * IIR_K2_CHAIN;
+        double cin[2 * D], v[2 * D];
 #pragma unroll
-        for (int k = 0; k < 2 * IIR_MAX_DIM; k++)
-            v[k] = tile < n_tiles ? ws_seg[((long)s * n_seg + last) * 2 * IIR_MAX_DIM + k] : 0.0;
-        ks_scan(v, qpow2, sh, t);
-        // state entering tile+1 = v + Q^(t+1) * carry-in of this step
-        double c[2 * IIR_MAX_DIM], add[IIR_MAX_DIM];
+        for (int k = 0; k < 2 * D; k++) { cin[k] = cc[k]; v[k] = t == 0 ? cin[k] : 0.0; }
+        // zero-carry end of the lane's chain (lane 0 starts from the round's carry-in)
+        if (T0 < n_tiles) {
+#pragma unroll 1
+            for (int i = 0; i < IIR_K2_CHAIN; i++) {
+                double nv[2 * D];
 #pragma unroll
-        for (int k = 0; k < 2 * IIR_MAX_DIM; k++) c[k] = cc[k];
-        const double *m = qpow + (long)(t + 1) * IIR_MAX_DIM * IIR_MAX_DIM;
-        matvec(m, c, add);
+                for (int k = 0; k < 2 * D; k++) nv[k] = T0 + i < n_tiles ? te[(T0 + i) * 2 * D + k] : 0.0;
+                matvec<D, true>(Q, v, nv);
+                matvec<D, true>(Q, v + D, nv + D);
 #pragma unroll
-        for (int k = 0; k < IIR_MAX_DIM; k++) v[k] += add[k];
-        matvec(m, c + IIR_MAX_DIM, add);
-#pragma unroll
-        for (int k = 0; k < IIR_MAX_DIM; k++) v[IIR_MAX_DIM + k] += add[k];
-        double *cr = carry + ((long)s * (n_tiles + 1)) * 2 * IIR_MAX_DIM;
-        if (t == 0) {
-#pragma unroll
-            for (int k = 0; k < 2 * IIR_MAX_DIM; k++) cr[base * 2 * IIR_MAX_DIM + k] = c[k];
+                for (int k = 0; k < 2 * D; k++) v[k] = nv[k];
+            }
         }
-        if (tile + 1 <= n_tiles && tile < n_tiles) {
+        ks_scan<D>(v, (const cdouble_t *)&plan->qspow2[0][0], sh, t);
+        // exclusive: the state entering the lane's first tile
 #pragma unroll
-            for (int k = 0; k < 2 * IIR_MAX_DIM; k++) cr[(tile + 1) * 2 * IIR_MAX_DIM + k] = v[k];
-        }
+        for (int k = 0; k < 2 * D; k++) sh[t * RS + k] = v[k];
         __syncthreads();
+        double c[2 * D];
+#pragma unroll
+        for (int k = 0; k < 2 * D; k++) c[k] = t == 0 ? cin[k] : sh[(t - 1) * RS + k];
+        if (T0 < n_tiles) {
+#pragma unroll 1
+            for (int i = 0; i < IIR_K2_CHAIN; i++) {
+                if (T0 + i >= n_tiles) break;
+                double nv[2 * D];
+#pragma unroll
+                for (int k = 0; k < 2 * D; k++) { cr[(T0 + i) * 2 * D + k] = c[k]; nv[k] = te[(T0 + i) * 2 * D + k]; }
+                matvec<D, true>(Q, c, nv);
+                matvec<D, true>(Q, c + D, nv + D);
+#pragma unroll
+                for (int k = 0; k < 2 * D; k++) c[k] = nv[k];
+            }
+        }
         if (t == IIR_TILE - 1) {
 #pragma unroll
-            for (int k = 0; k < 2 * IIR_MAX_DIM; k++) cc[k] = v[k];
+            for (int k = 0; k < 2 * D; k++) cc[k] = v[k];          // inclusive result of the last lane = end of the round
         }
         __syncthreads();
     }
 }
 
-// pass 3: true start state per segment, re-run, write int16 in place; the lane
-// owning the last segment also writes the stream's new carried state.
-__global__ __launch_bounds__(IIR_TILE) void iir_pass3_kernel(IirCoef c, uint32_t *__restrict__ iq, long stride, long n,
-                                                           long n_seg, long n_tiles, const double *__restrict__ ppow,
-                                                           const double *__restrict__ ws_seg,
-                                                           const double *__restrict__ carry, double *__restrict__ state)
+// K3: true start state per segment, recursion, int16 in place; the lane owning the last segment also
+// writes the stream's new carried state.  FULL: every segment of the tile is complete.
+template <int NS, bool FULL>
+__device__ __forceinline__ void iir_k3_segment(const IirCoef &c, uint32_t *x, long cnt, double *zi, double *zq)
 {
-    extern __shared__ uint32_t iir_sm[];
+#pragma unroll 2
+    for (int k = 0; k < IIR_SEG; k += 4) {
+        if (!FULL && k >= cnt) break;
+        u32x4 w = *(const u32x4 *)(x + k);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (FULL || k + j < cnt) {
+                // filter((float)x): int16 -> float -> double is exact
+                const double yi = iir_step<NS>(c, zi, (double)(int16_t)(w[j] & 0xFFFF));
+                const double yq = iir_step<NS>(c, zq, (double)(int16_t)(w[j] >> 16));
+                w[j] = iir_to_i16(yi) | (iir_to_i16(yq) << 16);
+            }
+        }
+        *(u32x4 *)(x + k) = w;
+    }
+}
+
+template <int NS>
+__global__ __launch_bounds__(IIR_TILE) void iir_k3_kernel(const IirPlan *__restrict__ plan, IirCoef c, uint32_t *__restrict__ iq,
+                                                         long stride, long n, long n_seg, long n_tiles,
+                                                         const double *__restrict__ E, const double *__restrict__ carry,
+                                                         double *__restrict__ state)
+{
+    constexpr int D = 2 * NS;
+    extern __shared__ __attribute__((aligned(16))) uint32_t iir_sm[];
     const int t = threadIdx.x;
     const long tile0 = (long)blockIdx.x * IIR_TILE * IIR_SEG;
     uint32_t *xt = iq + (long)blockIdx.y * stride + tile0;
@@ -246,35 +302,31 @@ __global__ __launch_bounds__(IIR_TILE) void iir_pass3_kernel(IirCoef c, uint32_t
     __syncthreads();
     const long seg = (long)blockIdx.x * IIR_TILE + t;
     if (seg < n_seg) {
-        const double *cr = carry + ((long)blockIdx.y * (n_tiles + 1) + blockIdx.x) * 2 * IIR_MAX_DIM;
-        const double *m = ppow + (long)t * IIR_MAX_DIM * IIR_MAX_DIM;          // P^t
-        double zi[IIR_MAX_DIM], zq[IIR_MAX_DIM], cv[IIR_MAX_DIM];
+        const double *cr = carry + ((long)blockIdx.y * n_tiles + blockIdx.x) * 2 * D;
+        const double *m = &plan->ppow[t][0];                                 // P^t
+        double zi[D], zq[D], cv[2 * D];
 #pragma unroll
-        for (int k = 0; k < IIR_MAX_DIM; k++) { zi[k] = 0.0; zq[k] = 0.0; }
-#pragma unroll
-        for (int k = 0; k < IIR_MAX_DIM; k++) cv[k] = cr[k];
-        matvec(m, cv, zi);
-#pragma unroll
-        for (int k = 0; k < IIR_MAX_DIM; k++) cv[k] = cr[IIR_MAX_DIM + k];
-        matvec(m, cv, zq);
+        for (int k = 0; k < 2 * D; k++) cv[k] = cr[k];
         if (t > 0) {
-            const double *e = ws_seg + ((long)blockIdx.y * n_seg + seg - 1) * 2 * IIR_MAX_DIM;
+            const double *e = E + ((long)blockIdx.y * n_seg + seg - 1) * 2 * D;
 #pragma unroll
-            for (int k = 0; k < IIR_MAX_DIM; k++) { zi[k] += e[k]; zq[k] += e[IIR_MAX_DIM + k]; }
+            for (int k = 0; k < D; k++) { zi[k] = e[k]; zq[k] = e[D + k]; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < D; k++) { zi[k] = 0.0; zq[k] = 0.0; }
         }
+        matvec<D, true>(m, cv, zi);
+        matvec<D, true>(m, cv + D, zq);
         uint32_t *x = iir_sm + t * IIR_PITCH;
-        const long cnt = n - seg * IIR_SEG < IIR_SEG ? n - seg * IIR_SEG : IIR_SEG;
-        for (long k = 0; k < cnt; k++) {
-            const uint32_t w = x[k];
-            // filter((float)x): int16 -> float -> double is exact
-            const double yi = iir_step(c, zi, (double)(int16_t)(w & 0xFFFF));
-            const double yq = iir_step(c, zq, (double)(int16_t)(w >> 16));
-            x[k] = iir_to_i16(yi) | (iir_to_i16(yq) << 16);
+        if (tile0 + (long)IIR_TILE * IIR_SEG <= n) iir_k3_segment<NS, true>(c, x, IIR_SEG, zi, zq);
+        else {
+            const long cnt = n - seg * IIR_SEG < IIR_SEG ? n - seg * IIR_SEG : IIR_SEG;
+            iir_k3_segment<NS, false>(c, x, cnt, zi, zq);
         }
         if (seg == n_seg - 1) {
             double *st = state + (long)blockIdx.y * 2 * IIR_MAX_DIM;
 #pragma unroll
-            for (int k = 0; k < IIR_MAX_DIM; k++) { st[k] = zi[k]; st[IIR_MAX_DIM + k] = zq[k]; }
+            for (int k = 0; k < D; k++) { st[k] = zi[k]; st[IIR_MAX_DIM + k] = zq[k]; }
         }
     }
     __syncthreads();
@@ -286,7 +338,7 @@ __global__ __launch_bounds__(IIR_TILE) void iir_pass3_kernel(IirCoef c, uint32_t
 // ---------------------------------------------------------------------------
 static void mat_mul(int dim, const double *a, const double *b, double *o)
 {
-    double t[IIR_MAX_DIM * IIR_MAX_DIM] = {0};
+    double t[IIR_MSZ] = {0};
     for (int r = 0; r < dim; r++)
         for (int c = 0; c < dim; c++) {
             double s = 0;
@@ -296,13 +348,15 @@ static void mat_mul(int dim, const double *a, const double *b, double *o)
     memcpy(o, t, sizeof t);
 }
 
-struct IirPlan {
-    IirCoef coef;
-    double pow2[8][IIR_MAX_DIM * IIR_MAX_DIM];              // P^(2^d)
-    double ppow[IIR_TILE + 1][IIR_MAX_DIM * IIR_MAX_DIM];   // P^i
-    double qpow2[8][IIR_MAX_DIM * IIR_MAX_DIM];             // Q^(2^d), Q = P^TILE
-    double qpow[IIR_TILE + 1][IIR_MAX_DIM * IIR_MAX_DIM];   // Q^i
-};
+static double host_step(const IirCoef &c, double *z, double in)
+{
+    switch (c.n_stages) {
+    case 1: return iir_step<1>(c, z, in);
+    case 2: return iir_step<2>(c, z, in);
+    case 3: return iir_step<3>(c, z, in);
+    default: return iir_step<4>(c, z, in);
+    }
+}
 
 static void iir_plan_build(const double *sos, int n_stages, IirPlan *pl)
 {
@@ -314,33 +368,67 @@ static void iir_plan_build(const double *sos, int n_stages, IirPlan *pl)
         c.a1[s] = sos[5 * s + 3]; c.a2[s] = sos[5 * s + 4];
     }
     const int dim = c.dim;
-    double F[IIR_MAX_DIM * IIR_MAX_DIM] = {0};
+    double F[IIR_MSZ] = {0};
     for (int j = 0; j < dim; j++) {          // column j = one zero-input step from e_j
         double z[IIR_MAX_DIM] = {0};
         z[j] = 1.0;
-        (void)iir_step(c, z, 0.0);
+        (void)host_step(c, z, 0.0);
         for (int r = 0; r < dim; r++) F[r * IIR_MAX_DIM + j] = z[r];
     }
-    double P[IIR_MAX_DIM * IIR_MAX_DIM];
+    {   // G[j] = F^j g: the state j steps after a unit input into a resting filter
+        double z[IIR_MAX_DIM] = {0};
+        (void)host_step(c, z, 1.0);
+        for (int j = 0; j < IIR_SEG; j++) {
+            for (int r = 0; r < dim; r++) pl->G[j][r] = z[r];
+            (void)host_step(c, z, 0.0);
+        }
+    }
+    double P[IIR_MSZ];
     memcpy(P, F, sizeof P);
     for (int k = 0; k < 6; k++) mat_mul(dim, P, P, P);     // F^64 (IIR_SEG = 64)
     static_assert(IIR_SEG == 64, "P = F^SEG is built by six squarings");
     memcpy(pl->pow2[0], P, sizeof P);
     for (int d = 1; d < 8; d++) mat_mul(dim, pl->pow2[d - 1], pl->pow2[d - 1], pl->pow2[d]);
     for (int r = 0; r < dim; r++) pl->ppow[0][r * IIR_MAX_DIM + r] = 1.0;
-    for (int i = 1; i <= IIR_TILE; i++) mat_mul(dim, pl->ppow[i - 1], P, pl->ppow[i]);
-    const double *Q = pl->ppow[IIR_TILE];
-    memcpy(pl->qpow2[0], Q, sizeof pl->qpow2[0]);
-    for (int d = 1; d < 8; d++) mat_mul(dim, pl->qpow2[d - 1], pl->qpow2[d - 1], pl->qpow2[d]);
-    for (int r = 0; r < dim; r++) pl->qpow[0][r * IIR_MAX_DIM + r] = 1.0;
-    for (int i = 1; i <= IIR_TILE; i++) mat_mul(dim, pl->qpow[i - 1], Q, pl->qpow[i]);
+    for (int i = 1; i < IIR_TILE; i++) mat_mul(dim, pl->ppow[i - 1], P, pl->ppow[i]);
+    mat_mul(dim, pl->ppow[IIR_TILE - 1], P, pl->Q);
+    static_assert(IIR_K2_CHAIN == 16, "Q^CHAIN is built by four squarings");
+    memcpy(pl->qspow2[0], pl->Q, sizeof pl->Q);
+    for (int k = 0; k < 4; k++) mat_mul(dim, pl->qspow2[0], pl->qspow2[0], pl->qspow2[0]);
+    for (int d = 1; d < 8; d++) mat_mul(dim, pl->qspow2[d - 1], pl->qspow2[d - 1], pl->qspow2[d]);
+}
+
+static size_t iir_var_bytes(size_t n_samples)
+{
+    const size_t n_seg = clhip_div_up(n_samples, IIR_SEG), n_tiles = clhip_div_up(n_seg, IIR_TILE);
+    return (n_seg + 2 * n_tiles + 4) * 2 * IIR_MAX_DIM * sizeof(double);
 }
 
 extern "C" size_t clhip_iir_workspace_bytes(size_t n_samples, int n_stages)
 {
     (void)n_stages;
-    const size_t n_seg = clhip_div_up(n_samples, IIR_SEG), n_tiles = clhip_div_up(n_seg, IIR_TILE);
-    return sizeof(IirPlan) + 256 + (n_seg + n_tiles + 2) * 2 * IIR_MAX_DIM * sizeof(double);
+    return sizeof(IirPlan) + 256 + iir_var_bytes(n_samples);
+}
+
+template <int NS>
+static void iir_launch(const IirPlan *d_plan, const IirCoef &coef, double *d_state, uint32_t *d_iq, long stride, long n,
+                       int n_streams, double *E, double *tend, double *carry, hipStream_t s)
+{
+    const long n_seg = (long)clhip_div_up((size_t)n, IIR_SEG), n_tiles = (long)clhip_div_up((size_t)n_seg, IIR_TILE);
+    dim3 grid((unsigned)n_tiles, n_streams), block(IIR_TILE);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void *)iir_k1_kernel<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, IIR_LDS_WORDS * 4);
+        (void)hipFuncSetAttribute((const void *)iir_k3_kernel<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, IIR_LDS_WORDS * 4);
+        attr = true;
+    }
+    static_assert(IIR_LDS_WORDS * 4 >= IIR_TILE * (2 * IIR_MAX_DIM + 1) * 8, "the scan exchange reuses the tile's LDS");
+    hipLaunchKernelGGL(iir_k1_kernel<NS>, grid, block, IIR_LDS_WORDS * 4, s, d_plan, (const uint32_t *)d_iq, stride, n, n_seg,
+                       n_tiles, E, tend);
+    hipLaunchKernelGGL(iir_k2_kernel<NS>, dim3(n_streams), block, 0, s, d_plan, n_tiles, (const double *)tend, carry,
+                       (const double *)d_state);
+    hipLaunchKernelGGL(iir_k3_kernel<NS>, grid, block, IIR_LDS_WORDS * 4, s, d_plan, coef, d_iq, stride, n, n_seg, n_tiles,
+                       (const double *)E, (const double *)carry, d_state);
 }
 
 // d_state: 2*IIR_MAX_DIM doubles per stream, layout [rail][2*stage + {0:v1,1:v2}]
@@ -354,7 +442,7 @@ extern "C" int clhip_iir_cs16_batch(const double *h_sos, int n_stages, double *d
         return -1;
     }
     const size_t n_seg = clhip_div_up(n_samples, IIR_SEG), n_tiles = clhip_div_up(n_seg, IIR_TILE);
-    const size_t need = sizeof(IirPlan) + 256 + (n_seg + n_tiles + 2) * 2 * IIR_MAX_DIM * sizeof(double) * n_streams;
+    const size_t need = sizeof(IirPlan) + 256 + iir_var_bytes(n_samples) * n_streams;
     if (ws_bytes < need) {
         clhip_set_error("clhip_iir_cs16: workspace too small (%zu < %zu)", ws_bytes, need);
         return -1;
@@ -378,26 +466,16 @@ extern "C" int clhip_iir_cs16_batch(const double *h_sos, int n_stages, double *d
         CLHIP_CHECK(hipMemcpyAsync(d_plan, &plan, sizeof plan, hipMemcpyHostToDevice, s));
         last_ws = d_ws;
     }
-    double *ws_seg = (double *)(ws + ((sizeof(IirPlan) + 255) & ~(size_t)255));
-    double *carry = ws_seg + n_seg * n_streams * 2 * IIR_MAX_DIM;
-    const double *d_pow2 = &d_plan->pow2[0][0];
-    const double *d_ppow = &d_plan->ppow[0][0];
-    const double *d_qpow2 = &d_plan->qpow2[0][0];
-    const double *d_qpow = &d_plan->qpow[0][0];
-    dim3 grid((unsigned)n_tiles, n_streams), block(IIR_TILE);
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void *)iir_pass1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, IIR_LDS_WORDS * 4);
-        (void)hipFuncSetAttribute((const void *)iir_pass3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, IIR_LDS_WORDS * 4);
-        attr = true;
+    const int D2 = 4 * n_stages;             // doubles per state pair
+    double *E = (double *)(ws + ((sizeof(IirPlan) + 255) & ~(size_t)255));
+    double *tend = E + n_seg * n_streams * D2;
+    double *carry = tend + n_tiles * n_streams * D2;
+    switch (n_stages) {
+    case 1: iir_launch<1>(d_plan, plan.coef, d_state, (uint32_t *)d_iq, (long)stride_samples, (long)n_samples, n_streams, E, tend, carry, s); break;
+    case 2: iir_launch<2>(d_plan, plan.coef, d_state, (uint32_t *)d_iq, (long)stride_samples, (long)n_samples, n_streams, E, tend, carry, s); break;
+    case 3: iir_launch<3>(d_plan, plan.coef, d_state, (uint32_t *)d_iq, (long)stride_samples, (long)n_samples, n_streams, E, tend, carry, s); break;
+    default: iir_launch<4>(d_plan, plan.coef, d_state, (uint32_t *)d_iq, (long)stride_samples, (long)n_samples, n_streams, E, tend, carry, s); break;
     }
-    hipLaunchKernelGGL(iir_pass1_kernel, grid, block, IIR_LDS_WORDS * 4, s, plan.coef, (const uint32_t *)d_iq, (long)stride_samples,
-                       (long)n_samples, (long)n_seg, ws_seg);
-    hipLaunchKernelGGL(iir_pass2a_kernel, grid, block, 0, s, d_pow2, (long)n_seg, ws_seg);
-    hipLaunchKernelGGL(iir_pass2b_kernel, dim3(n_streams), dim3(IIR_TILE), 0, s, d_qpow2, d_qpow, (long)n_seg,
-                       (long)n_tiles, ws_seg, carry, (const double *)d_state);
-    hipLaunchKernelGGL(iir_pass3_kernel, grid, block, IIR_LDS_WORDS * 4, s, plan.coef, (uint32_t *)d_iq, (long)stride_samples,
-                       (long)n_samples, (long)n_seg, (long)n_tiles, d_ppow, ws_seg, carry, d_state);
     CLHIP_CHECK_LAUNCH();
     return 0;
 }
