@@ -8,19 +8,21 @@
 // The recursion is strictly sequential per rail; it is made parallel as a blocked
 // linear-recurrence scan over the cascade's D = 2*n_stages-dim state z:
 //     z[n] = F z[n-1] + g x[n]
-// A lane owns a SEG = 64-sample segment, a workgroup a tile of 256 segments.
+// A lane owns a SEG = 64-sample segment, a workgroup (2 waves) a tile of 128 segments.
 //   K1  zero-state end vector of every segment as a 64-tap "matrix FIR"
 //           zs = sum_k (F^(63-k) g) x[k]          (independent FMAs, taps by scalar loads)
-//       then a Kogge-Stone scan over the tile's 256 lanes with P^(2^d), P = F^64 (LDS exchange)
-//       -> E[seg] (state after the segment if the tile started from zero) and the tile's end vector
-//   K2  per stream: the tile end vectors are chained with Q = P^256: every lane runs 16 consecutive
+//       written out, then reduced over the tile: Kogge-Stone inside each wave by shuffles with P^(2^d),
+//       P = F^64, waves joined through LDS -> the tile's zero-carry end vector
+//   K2  per stream: the tile end vectors are chained with Q = P^128: every lane runs 16 consecutive
 //       tiles serially, one Kogge-Stone scan with (Q^16)^(2^d) joins the 256 lanes, a second serial
-//       walk writes the state entering every tile.  4096 tiles (2^26 samples) per round.
-//   K3  every lane rebuilds its true start state  E[seg-1] + P^lane * (state entering the tile),
-//       runs the recursion over its segment and writes the truncated int16 outputs in place
+//       walk writes the state entering every tile.  4096 tiles (2^25 samples) per round.
+//   K3  the same scan over u = zs (+ P * tile carry on the first lane) gives the state after every
+//       segment; shifted by one lane it is every lane's true start state.  The lane then runs the
+//       recursion over its segment and writes the truncated int16 outputs in place.
+//       The tile's global loads are in flight while the scan runs.
 // Tiles travel through LDS (coalesced 16-byte global accesses on one side, one row of 64+4 dwords per
 // lane on the other: lane t reading 16 bytes of row t touches banks 4t..4t+3 -- conflict-free).
-// F, g, P^(2^d), P^i, Q and (Q^16)^(2^d) are built on the host in fp64 by simulating the cascade.
+// F, g, P^(2^d), Q and (Q^16)^(2^d) are built on the host in fp64 by simulating the cascade.
 #include <math.h>
 #include <string.h>
 
@@ -29,7 +31,8 @@
 #define IIR_MAX_STAGES 4
 #define IIR_MAX_DIM (2 * IIR_MAX_STAGES)
 #define IIR_SEG 64
-#define IIR_TILE 256
+#define IIR_TILE 128
+#define IIR_K2_LANES 256
 #define IIR_K2_CHAIN 16                    // tiles walked serially by one lane of K2
 #define IIR_MSZ (IIR_MAX_DIM * IIR_MAX_DIM) // matrices are stored 8x8, row-major, zero outside DxD
 
@@ -83,13 +86,16 @@ __device__ __forceinline__ void matvec(MP m, const double *v, double *out)
 #define IIR_PITCH (IIR_SEG + 4)             // dwords per lane row: 16-byte aligned rows, bank = 4 * lane
 #define IIR_LDS_WORDS (IIR_TILE * IIR_PITCH)
 
-__device__ __forceinline__ void iir_tile_load(const uint32_t *__restrict__ x, long n_left, uint32_t *sm, int t)
+#define IIR_NLD (IIR_SEG / 4)                // 16-byte pieces per lane per tile
+
+// issue every global load of the tile first (IIR_NLD x 16 bytes in flight per lane), commit to LDS later
+__device__ __forceinline__ void iir_tile_issue(const uint32_t *__restrict__ x, long n_left, u32x4 (&r)[IIR_NLD], int t)
 {
     // n_left = samples of this stream from the tile start (>= 1); words beyond it read as zero
-    constexpr int TOTAL = IIR_TILE * IIR_SEG;
     const bool vec = ((uintptr_t)x & 15) == 0;
-#pragma unroll 4
-    for (int i = t * 4; i < TOTAL; i += IIR_TILE * 4) {
+#pragma unroll
+    for (int q = 0; q < IIR_NLD; q++) {
+        const int i = (q * IIR_TILE + t) * 4;
         u32x4 v = {0, 0, 0, 0};
         if (vec && i + 4 <= n_left) v = *(const u32x4 *)(x + i);
         else {
@@ -98,17 +104,26 @@ __device__ __forceinline__ void iir_tile_load(const uint32_t *__restrict__ x, lo
             if (i + 2 < n_left) v.z = x[i + 2];
             if (i + 3 < n_left) v.w = x[i + 3];
         }
+        r[q] = v;
+    }
+}
+
+__device__ __forceinline__ void iir_tile_commit(const u32x4 (&r)[IIR_NLD], uint32_t *sm, int t)
+{
+#pragma unroll
+    for (int q = 0; q < IIR_NLD; q++) {
+        const int i = (q * IIR_TILE + t) * 4;
         const int row = i / IIR_SEG, col = i % IIR_SEG;          // 4 consecutive words stay in one row
-        *(u32x4 *)(sm + row * IIR_PITCH + col) = v;
+        *(u32x4 *)(sm + row * IIR_PITCH + col) = r[q];
     }
 }
 
 __device__ __forceinline__ void iir_tile_store(uint32_t *__restrict__ x, long n_left, const uint32_t *sm, int t)
 {
-    constexpr int TOTAL = IIR_TILE * IIR_SEG;
     const bool vec = ((uintptr_t)x & 15) == 0;
-#pragma unroll 4
-    for (int i = t * 4; i < TOTAL; i += IIR_TILE * 4) {
+#pragma unroll
+    for (int q = 0; q < IIR_NLD; q++) {
+        const int i = (q * IIR_TILE + t) * 4;
         const int row = i / IIR_SEG, col = i % IIR_SEG;
         const u32x4 v = *(const u32x4 *)(sm + row * IIR_PITCH + col);
         if (vec && i + 4 <= n_left) *(u32x4 *)(x + i) = v;
@@ -121,11 +136,67 @@ __device__ __forceinline__ void iir_tile_store(uint32_t *__restrict__ x, long n_
     }
 }
 
-// Kogge-Stone inclusive scan over the 256 lanes of a workgroup for the recurrence
-//   v_i <- v_i + M^(2^d) v_(i - 2^d),   pow2[d] = M^(2^d)
-// leaving v_i = sum_{j<=i} M^(i-j) v_j (both rails: v = [I rail D | Q rail D]).  sh: 256 rows of 2D+1 doubles.
+// Kogge-Stone inclusive scan for the recurrence  v_i <- v_i + M^(2^d) v_(i - 2^d),  pow2[d] = M^(2^d),
+// leaving v_i = sum_{j<=i} M^(i-j) v_j (both rails: v = [I rail D | Q rail D]).
+// wave_scan: the 64 lanes of a wave by shuffles (no LDS storage, no barrier).
 template <int D>
-__device__ __forceinline__ void ks_scan(double (&v)[2 * D], const cdouble_t *__restrict__ pow2, double *sh, int t)
+__device__ __forceinline__ void wave_scan(double (&v)[2 * D], const cdouble_t *__restrict__ pow2, int lane)
+{
+#pragma unroll 1
+    for (int d = 0; d < 6; d++) {
+        double pv[2 * D];
+#pragma unroll
+        for (int k = 0; k < 2 * D; k++) pv[k] = __shfl_up(v[k], 1 << d, 64);
+        if (lane >= (1 << d)) {
+            const cdouble_t *m = pow2 + d * IIR_MSZ;
+            matvec<D, true>(m, pv, v);
+            matvec<D, true>(m, pv + D, v + D);
+        }
+    }
+}
+
+// tile_scan: the IIR_TILE = 128 lanes of a workgroup: wave_scan in both waves, then the second wave adds
+// P^(lane+1) times the first wave's total (ppow[i] = P^i, one matrix per lane).  `sh` = IIR_TILE rows of
+// 2D+1 doubles; on return sh[t] holds lane t's result.  LAST_ONLY: only lane IIR_TILE-1 needs to be right
+// (the tile total): its power is P^64 = pow2[6], no table.
+template <int D, bool LAST_ONLY>
+__device__ __forceinline__ void tile_scan(double (&v)[2 * D], const cdouble_t *__restrict__ pow2,
+                                          const double *__restrict__ ppow, double *sh, int t)
+{
+    static_assert(IIR_TILE == 128, "two waves per tile");
+    constexpr int RS = 2 * D + 1;
+    wave_scan<D>(v, pow2, t & 63);
+    if (t == 63) {
+#pragma unroll
+        for (int k = 0; k < 2 * D; k++) sh[63 * RS + k] = v[k];
+    }
+    __syncthreads();
+    if (LAST_ONLY ? t == IIR_TILE - 1 : t >= 64) {
+        double s0[2 * D];
+#pragma unroll
+        for (int k = 0; k < 2 * D; k++) s0[k] = sh[63 * RS + k];
+        if (LAST_ONLY) {
+            const cdouble_t *m = pow2 + 6 * IIR_MSZ;
+            matvec<D, true>(m, s0, v);
+            matvec<D, true>(m, s0 + D, v + D);
+        } else {
+            const double *m = ppow + (long)(t - 63) * IIR_MSZ;       // P^(lane + 1)
+            matvec<D, true>(m, s0, v);
+            matvec<D, true>(m, s0 + D, v + D);
+        }
+    }
+    if (!LAST_ONLY) {
+        if (t != 63) {
+#pragma unroll
+            for (int k = 0; k < 2 * D; k++) sh[t * RS + k] = v[k];
+        }
+        __syncthreads();
+    }
+}
+
+// the 256 lanes of K2 (one workgroup): plain LDS exchange every round
+template <int D>
+__device__ __forceinline__ void ks_scan256(double (&v)[2 * D], const cdouble_t *__restrict__ pow2, double *sh, int t)
 {
     constexpr int RS = 2 * D + 1;
 #pragma unroll 1
@@ -150,23 +221,27 @@ struct IirPlan {
     IirCoef coef;
     double G[IIR_SEG][IIR_MAX_DIM];         // G[j] = F^j g
     double pow2[8][IIR_MSZ];                // P^(2^d), P = F^SEG
-    double ppow[IIR_TILE][IIR_MSZ];         // P^i
+    double ppow[IIR_SEG + 1][IIR_MSZ];      // P^i, i <= 64
     double Q[IIR_MSZ];                      // P^TILE
     double qspow2[8][IIR_MSZ];              // (Q^CHAIN)^(2^d)
 };
 
-// K1: zero-state end vector per segment + scan inside the tile.
-//   E[stream][seg][2D], tend[stream][tile][2D]
+// K1: zero-state end vector per segment (written to ZS) and the tile's zero-carry end vector.
+//   ZS[stream][seg][2D], tend[stream][tile][2D]
 template <int NS>
 __global__ __launch_bounds__(IIR_TILE) void iir_k1_kernel(const IirPlan *__restrict__ plan, const uint32_t *__restrict__ iq,
                                                          long stride, long n, long n_seg, long n_tiles,
-                                                         double *__restrict__ E, double *__restrict__ tend)
+                                                         double *__restrict__ ZS, double *__restrict__ tend)
 {
-    constexpr int D = 2 * NS;
+    constexpr int D = 2 * NS, RS = 2 * D + 1;
     extern __shared__ __attribute__((aligned(16))) uint32_t iir_sm[];
     const int t = threadIdx.x;
     const long tile0 = (long)blockIdx.x * IIR_TILE * IIR_SEG;
-    iir_tile_load(iq + (long)blockIdx.y * stride + tile0, n - tile0, iir_sm, t);
+    {
+        u32x4 r[IIR_NLD];
+        iir_tile_issue(iq + (long)blockIdx.y * stride + tile0, n - tile0, r, t);
+        iir_tile_commit(r, iir_sm, t);
+    }
     __syncthreads();
     const cdouble_t *__restrict__ G = (const cdouble_t *)&plan->G[0][0];
     const uint32_t *x = iir_sm + t * IIR_PITCH;
@@ -188,29 +263,30 @@ __global__ __launch_bounds__(IIR_TILE) void iir_k1_kernel(const IirPlan *__restr
             }
         }
     }
-    __syncthreads();                         // the staged tile is dead: its LDS carries the scan exchange
-    ks_scan<D>(v, (const cdouble_t *)&plan->pow2[0][0], (double *)iir_sm, t);
     const long seg = (long)blockIdx.x * IIR_TILE + t;
     if (seg < n_seg) {
-        double *o = E + ((long)blockIdx.y * n_seg + seg) * 2 * D;
+        double *o = ZS + ((long)blockIdx.y * n_seg + seg) * 2 * D;
 #pragma unroll
         for (int k = 0; k < 2 * D; k++) o[k] = v[k];
     }
+    __syncthreads();                         // the staged tile is dead: its LDS carries the scan exchange
+    tile_scan<D, true>(v, (const cdouble_t *)&plan->pow2[0][0], nullptr, (double *)iir_sm, t);
     if (t == IIR_TILE - 1) {
         double *o = tend + ((long)blockIdx.y * n_tiles + blockIdx.x) * 2 * D;
 #pragma unroll
         for (int k = 0; k < 2 * D; k++) o[k] = v[k];
     }
+    (void)RS;
 }
 
 // K2: state entering every tile.  carry[stream][tile][2D], tile = 0 .. n_tiles-1
 template <int NS>
-__global__ __launch_bounds__(IIR_TILE) void iir_k2_kernel(const IirPlan *__restrict__ plan, long n_tiles,
-                                                         const double *__restrict__ tend, double *__restrict__ carry,
-                                                         const double *__restrict__ state)
+__global__ __launch_bounds__(IIR_K2_LANES) void iir_k2_kernel(const IirPlan *__restrict__ plan, long n_tiles,
+                                                             const double *__restrict__ tend, double *__restrict__ carry,
+                                                             const double *__restrict__ state)
 {
     constexpr int D = 2 * NS, RS = 2 * D + 1;
-    __shared__ double sh[IIR_TILE * RS];
+    __shared__ double sh[IIR_K2_LANES * RS];
     __shared__ double cc[2 * D];
     const int s = blockIdx.x, t = threadIdx.x;
     const cdouble_t *__restrict__ Q = (const cdouble_t *)&plan->Q[0];
@@ -218,25 +294,31 @@ __global__ __launch_bounds__(IIR_TILE) void iir_k2_kernel(const IirPlan *__restr
     double *cr = carry + (long)s * n_tiles * 2 * D;
     if (t < 2 * D) cc[t] = state[(long)s * 2 * IIR_MAX_DIM + (t / D) * IIR_MAX_DIM + (t % D)];
     __syncthreads();
-    for (long base = 0; base < n_tiles; base += (long)IIR_TILE * IIR_K2_CHAIN) {
+    for (long base = 0; base < n_tiles; base += (long)IIR_K2_LANES * IIR_K2_CHAIN) {
         const long T0 = base + (long)t * IIR_K2_CHAIN;
-        double cin[2 * D], v[2 * D];
+        double cin[2 * D], v[2 * D], nx[2 * D];
 #pragma unroll
         for (int k = 0; k < 2 * D; k++) { cin[k] = cc[k]; v[k] = t == 0 ? cin[k] : 0.0; }
-        // zero-carry end of the lane's chain (lane 0 starts from the round's carry-in)
+        // zero-carry end of the lane's chain (lane 0 starts from the round's carry-in); the next tile's
+        // end vector is loaded while the current one is multiplied
         if (T0 < n_tiles) {
+#pragma unroll
+            for (int k = 0; k < 2 * D; k++) nx[k] = te[T0 * 2 * D + k];
 #pragma unroll 1
             for (int i = 0; i < IIR_K2_CHAIN; i++) {
                 double nv[2 * D];
 #pragma unroll
-                for (int k = 0; k < 2 * D; k++) nv[k] = T0 + i < n_tiles ? te[(T0 + i) * 2 * D + k] : 0.0;
+                for (int k = 0; k < 2 * D; k++) nv[k] = nx[k];
+                const long tn = T0 + i + 1;
+#pragma unroll
+                for (int k = 0; k < 2 * D; k++) nx[k] = (i + 1 < IIR_K2_CHAIN && tn < n_tiles) ? te[tn * 2 * D + k] : 0.0;
                 matvec<D, true>(Q, v, nv);
                 matvec<D, true>(Q, v + D, nv + D);
 #pragma unroll
                 for (int k = 0; k < 2 * D; k++) v[k] = nv[k];
             }
         }
-        ks_scan<D>(v, (const cdouble_t *)&plan->qspow2[0][0], sh, t);
+        ks_scan256<D>(v, (const cdouble_t *)&plan->qspow2[0][0], sh, t);
         // exclusive: the state entering the lane's first tile
 #pragma unroll
         for (int k = 0; k < 2 * D; k++) sh[t * RS + k] = v[k];
@@ -245,19 +327,24 @@ __global__ __launch_bounds__(IIR_TILE) void iir_k2_kernel(const IirPlan *__restr
 #pragma unroll
         for (int k = 0; k < 2 * D; k++) c[k] = t == 0 ? cin[k] : sh[(t - 1) * RS + k];
         if (T0 < n_tiles) {
+#pragma unroll
+            for (int k = 0; k < 2 * D; k++) nx[k] = te[T0 * 2 * D + k];
 #pragma unroll 1
             for (int i = 0; i < IIR_K2_CHAIN; i++) {
                 if (T0 + i >= n_tiles) break;
                 double nv[2 * D];
 #pragma unroll
-                for (int k = 0; k < 2 * D; k++) { cr[(T0 + i) * 2 * D + k] = c[k]; nv[k] = te[(T0 + i) * 2 * D + k]; }
+                for (int k = 0; k < 2 * D; k++) { cr[(T0 + i) * 2 * D + k] = c[k]; nv[k] = nx[k]; }
+                const long tn = T0 + i + 1;
+#pragma unroll
+                for (int k = 0; k < 2 * D; k++) nx[k] = (i + 1 < IIR_K2_CHAIN && tn < n_tiles) ? te[tn * 2 * D + k] : 0.0;
                 matvec<D, true>(Q, c, nv);
                 matvec<D, true>(Q, c + D, nv + D);
 #pragma unroll
                 for (int k = 0; k < 2 * D; k++) c[k] = nv[k];
             }
         }
-        if (t == IIR_TILE - 1) {
+        if (t == IIR_K2_LANES - 1) {
 #pragma unroll
             for (int k = 0; k < 2 * D; k++) cc[k] = v[k];          // inclusive result of the last lane = end of the round
         }
@@ -290,33 +377,43 @@ __device__ __forceinline__ void iir_k3_segment(const IirCoef &c, uint32_t *x, lo
 template <int NS>
 __global__ __launch_bounds__(IIR_TILE) void iir_k3_kernel(const IirPlan *__restrict__ plan, IirCoef c, uint32_t *__restrict__ iq,
                                                          long stride, long n, long n_seg, long n_tiles,
-                                                         const double *__restrict__ E, const double *__restrict__ carry,
+                                                         const double *__restrict__ ZS, const double *__restrict__ carry,
                                                          double *__restrict__ state)
 {
-    constexpr int D = 2 * NS;
+    constexpr int D = 2 * NS, RS = 2 * D + 1;
     extern __shared__ __attribute__((aligned(16))) uint32_t iir_sm[];
     const int t = threadIdx.x;
     const long tile0 = (long)blockIdx.x * IIR_TILE * IIR_SEG;
     uint32_t *xt = iq + (long)blockIdx.y * stride + tile0;
-    iir_tile_load(xt, n - tile0, iir_sm, t);
-    __syncthreads();
+    u32x4 raw[IIR_NLD];
+    iir_tile_issue(xt, n - tile0, raw, t);                   // in flight while the start states are computed
     const long seg = (long)blockIdx.x * IIR_TILE + t;
+    const cdouble_t *cr = (const cdouble_t *)(carry + ((long)blockIdx.y * n_tiles + blockIdx.x) * 2 * D);
+    const cdouble_t *pow2 = (const cdouble_t *)&plan->pow2[0][0];
+    double u[2 * D], cv[2 * D];
+#pragma unroll
+    for (int k = 0; k < 2 * D; k++) cv[k] = cr[k];
+    {
+        const double *z = ZS + ((long)blockIdx.y * n_seg + (seg < n_seg ? seg : n_seg - 1)) * 2 * D;
+#pragma unroll
+        for (int k = 0; k < 2 * D; k++) u[k] = seg < n_seg ? z[k] : 0.0;
+    }
+    if (t == 0) {                                            // the tile's carry enters through the first segment
+        matvec<D, true>(pow2, cv, u);
+        matvec<D, true>(pow2, cv + D, u + D);
+    }
+    double *sh = (double *)iir_sm;                           // the tile region is still empty
+    tile_scan<D, false>(u, pow2, &plan->ppow[0][0], sh, t);  // u = state after the lane's segment; sh[t] = the same
+    double zi[D], zq[D];
+#pragma unroll
+    for (int k = 0; k < D; k++) {
+        zi[k] = t == 0 ? cv[k] : sh[(t - 1) * RS + k];
+        zq[k] = t == 0 ? cv[D + k] : sh[(t - 1) * RS + D + k];
+    }
+    __syncthreads();                                         // exchange rows are read: the tile may land
+    iir_tile_commit(raw, iir_sm, t);
+    __syncthreads();
     if (seg < n_seg) {
-        const double *cr = carry + ((long)blockIdx.y * n_tiles + blockIdx.x) * 2 * D;
-        const double *m = &plan->ppow[t][0];                                 // P^t
-        double zi[D], zq[D], cv[2 * D];
-#pragma unroll
-        for (int k = 0; k < 2 * D; k++) cv[k] = cr[k];
-        if (t > 0) {
-            const double *e = E + ((long)blockIdx.y * n_seg + seg - 1) * 2 * D;
-#pragma unroll
-            for (int k = 0; k < D; k++) { zi[k] = e[k]; zq[k] = e[D + k]; }
-        } else {
-#pragma unroll
-            for (int k = 0; k < D; k++) { zi[k] = 0.0; zq[k] = 0.0; }
-        }
-        matvec<D, true>(m, cv, zi);
-        matvec<D, true>(m, cv + D, zq);
         uint32_t *x = iir_sm + t * IIR_PITCH;
         if (tile0 + (long)IIR_TILE * IIR_SEG <= n) iir_k3_segment<NS, true>(c, x, IIR_SEG, zi, zq);
         else {
@@ -390,8 +487,9 @@ static void iir_plan_build(const double *sos, int n_stages, IirPlan *pl)
     memcpy(pl->pow2[0], P, sizeof P);
     for (int d = 1; d < 8; d++) mat_mul(dim, pl->pow2[d - 1], pl->pow2[d - 1], pl->pow2[d]);
     for (int r = 0; r < dim; r++) pl->ppow[0][r * IIR_MAX_DIM + r] = 1.0;
-    for (int i = 1; i < IIR_TILE; i++) mat_mul(dim, pl->ppow[i - 1], P, pl->ppow[i]);
-    mat_mul(dim, pl->ppow[IIR_TILE - 1], P, pl->Q);
+    for (int i = 1; i <= 64; i++) mat_mul(dim, pl->ppow[i - 1], P, pl->ppow[i]);
+    static_assert(IIR_TILE == 128, "Q = P^TILE = P^(2^7)");
+    memcpy(pl->Q, pl->pow2[7], sizeof pl->Q);
     static_assert(IIR_K2_CHAIN == 16, "Q^CHAIN is built by four squarings");
     memcpy(pl->qspow2[0], pl->Q, sizeof pl->Q);
     for (int k = 0; k < 4; k++) mat_mul(dim, pl->qspow2[0], pl->qspow2[0], pl->qspow2[0]);
@@ -416,16 +514,16 @@ static void iir_launch(const IirPlan *d_plan, const IirCoef &coef, double *d_sta
 {
     const long n_seg = (long)clhip_div_up((size_t)n, IIR_SEG), n_tiles = (long)clhip_div_up((size_t)n_seg, IIR_TILE);
     dim3 grid((unsigned)n_tiles, n_streams), block(IIR_TILE);
+    static_assert(IIR_TILE * (2 * IIR_MAX_DIM + 1) * 8 <= IIR_LDS_WORDS * 4, "the scan exchange fits the tile's LDS");
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void *)iir_k1_kernel<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, IIR_LDS_WORDS * 4);
         (void)hipFuncSetAttribute((const void *)iir_k3_kernel<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, IIR_LDS_WORDS * 4);
         attr = true;
     }
-    static_assert(IIR_LDS_WORDS * 4 >= IIR_TILE * (2 * IIR_MAX_DIM + 1) * 8, "the scan exchange reuses the tile's LDS");
     hipLaunchKernelGGL(iir_k1_kernel<NS>, grid, block, IIR_LDS_WORDS * 4, s, d_plan, (const uint32_t *)d_iq, stride, n, n_seg,
                        n_tiles, E, tend);
-    hipLaunchKernelGGL(iir_k2_kernel<NS>, dim3(n_streams), block, 0, s, d_plan, n_tiles, (const double *)tend, carry,
+    hipLaunchKernelGGL(iir_k2_kernel<NS>, dim3(n_streams), dim3(IIR_K2_LANES), 0, s, d_plan, n_tiles, (const double *)tend, carry,
                        (const double *)d_state);
     hipLaunchKernelGGL(iir_k3_kernel<NS>, grid, block, IIR_LDS_WORDS * 4, s, d_plan, coef, d_iq, stride, n, n_seg, n_tiles,
                        (const double *)E, (const double *)carry, d_state);
