@@ -13,9 +13,10 @@
 //           zs = sum_k (F^(63-k) g) x[k]          (independent FMAs, taps by scalar loads)
 //       written out, then reduced over the tile: Kogge-Stone inside each wave by shuffles with P^(2^d),
 //       P = F^64, waves joined through LDS -> the tile's zero-carry end vector
-//   K2  per stream: the tile end vectors are chained with Q = P^128: every lane runs 16 consecutive
-//       tiles serially, one Kogge-Stone scan with (Q^16)^(2^d) joins the 256 lanes, a second serial
-//       walk writes the state entering every tile.  4096 tiles (2^25 samples) per round.
+//   K2a groups of 256 tiles (one per lane) are scanned in parallel with Q^(2^d), Q = P^128 (Kogge-Stone
+//       through LDS): X[tile] = state entering the tile if its group started from rest; group end vectors
+//   K2b one lane per stream chains the group ends with Q^256: gc[g] = state entering group g
+//       (32 steps for 2^26 samples); K3 rebuilds its tile carry as X[tile] + Q^i gc[g]
 //   K3  the same scan over u = zs (+ P * tile carry on the first lane) gives the state after every
 //       segment; shifted by one lane it is every lane's true start state.  The lane then runs the
 //       recursion over its segment and writes the truncated int16 outputs in place.
@@ -33,7 +34,7 @@
 #define IIR_SEG 64
 #define IIR_TILE 128
 #define IIR_K2_LANES 256
-#define IIR_K2_CHAIN 16                    // tiles walked serially by one lane of K2
+#define IIR_GROUP 256                      // tiles per K2a workgroup
 #define IIR_MSZ (IIR_MAX_DIM * IIR_MAX_DIM) // matrices are stored 8x8, row-major, zero outside DxD
 
 typedef __attribute__((address_space(4))) double cdouble_t;   // read-only tables: scalar (SMEM) loads when uniform
@@ -223,7 +224,8 @@ struct IirPlan {
     double pow2[8][IIR_MSZ];                // P^(2^d), P = F^SEG
     double ppow[IIR_SEG + 1][IIR_MSZ];      // P^i, i <= 64
     double Q[IIR_MSZ];                      // P^TILE
-    double qspow2[8][IIR_MSZ];              // (Q^CHAIN)^(2^d)
+    double qpow2[9][IIR_MSZ];               // Q^(2^d); [8] = Q^256 chains the groups
+    double qpow[IIR_GROUP][IIR_MSZ];        // Q^i
 };
 
 // K1: zero-state end vector per segment (written to ZS) and the tile's zero-carry end vector.
@@ -279,76 +281,66 @@ __global__ __launch_bounds__(IIR_TILE) void iir_k1_kernel(const IirPlan *__restr
     (void)RS;
 }
 
-// K2: state entering every tile.  carry[stream][tile][2D], tile = 0 .. n_tiles-1
+// K2a: scan inside each group of 256 tiles.  X[stream][tile][2D] (exclusive, zero carry-in),
+// gend[stream][group][2D] (inclusive result of the group's last tile)
 template <int NS>
-__global__ __launch_bounds__(IIR_K2_LANES) void iir_k2_kernel(const IirPlan *__restrict__ plan, long n_tiles,
-                                                             const double *__restrict__ tend, double *__restrict__ carry,
-                                                             const double *__restrict__ state)
+__global__ __launch_bounds__(IIR_GROUP) void iir_k2a_kernel(const IirPlan *__restrict__ plan, long n_tiles, long n_groups,
+                                                           const double *__restrict__ tend, double *__restrict__ X,
+                                                           double *__restrict__ gend)
 {
     constexpr int D = 2 * NS, RS = 2 * D + 1;
-    __shared__ double sh[IIR_K2_LANES * RS];
-    __shared__ double cc[2 * D];
-    const int s = blockIdx.x, t = threadIdx.x;
-    const cdouble_t *__restrict__ Q = (const cdouble_t *)&plan->Q[0];
-    const double *te = tend + (long)s * n_tiles * 2 * D;
-    double *cr = carry + (long)s * n_tiles * 2 * D;
-    if (t < 2 * D) cc[t] = state[(long)s * 2 * IIR_MAX_DIM + (t / D) * IIR_MAX_DIM + (t % D)];
+    __shared__ double sh[IIR_GROUP * RS];
+    const int t = threadIdx.x;
+    const long tile = (long)blockIdx.x * IIR_GROUP + t;
+    const double *te = tend + ((long)blockIdx.y * n_tiles + tile) * 2 * D;
+    double v[2 * D];
+#pragma unroll
+    for (int k = 0; k < 2 * D; k++) v[k] = tile < n_tiles ? te[k] : 0.0;
+    ks_scan256<D>(v, (const cdouble_t *)&plan->qpow2[0][0], sh, t);
+#pragma unroll
+    for (int k = 0; k < 2 * D; k++) sh[t * RS + k] = v[k];
     __syncthreads();
-    for (long base = 0; base < n_tiles; base += (long)IIR_K2_LANES * IIR_K2_CHAIN) {
-        const long T0 = base + (long)t * IIR_K2_CHAIN;
-        double cin[2 * D], v[2 * D], nx[2 * D];
+    if (tile < n_tiles) {
+        double *o = X + ((long)blockIdx.y * n_tiles + tile) * 2 * D;
 #pragma unroll
-        for (int k = 0; k < 2 * D; k++) { cin[k] = cc[k]; v[k] = t == 0 ? cin[k] : 0.0; }
-        // zero-carry end of the lane's chain (lane 0 starts from the round's carry-in); the next tile's
-        // end vector is loaded while the current one is multiplied
-        if (T0 < n_tiles) {
+        for (int k = 0; k < 2 * D; k++) o[k] = t == 0 ? 0.0 : sh[(t - 1) * RS + k];
+    }
+    if (t == IIR_GROUP - 1) {
+        double *o = gend + ((long)blockIdx.y * n_groups + blockIdx.x) * 2 * D;
 #pragma unroll
-            for (int k = 0; k < 2 * D; k++) nx[k] = te[T0 * 2 * D + k];
-#pragma unroll 1
-            for (int i = 0; i < IIR_K2_CHAIN; i++) {
-                double nv[2 * D];
+        for (int k = 0; k < 2 * D; k++) o[k] = v[k];
+    }
+}
+
+// K2b: gc[stream][group][2D] = state entering the group; one lane per stream
+template <int NS>
+__global__ void iir_k2b_kernel(const IirPlan *__restrict__ plan, int n_streams, long n_groups,
+                               const double *__restrict__ gend, double *__restrict__ gc, const double *__restrict__ state)
+{
+    constexpr int D = 2 * NS;
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_streams) return;
+    const cdouble_t *__restrict__ QG = (const cdouble_t *)&plan->qpow2[8][0];
+    double c[2 * D];
 #pragma unroll
-                for (int k = 0; k < 2 * D; k++) nv[k] = nx[k];
-                const long tn = T0 + i + 1;
+    for (int k = 0; k < 2 * D; k++) c[k] = state[(long)s * 2 * IIR_MAX_DIM + (k / D) * IIR_MAX_DIM + (k % D)];
+    const double *ge = gend + (long)s * n_groups * 2 * D;
+    double *o = gc + (long)s * n_groups * 2 * D;
+    double nx[2 * D];
 #pragma unroll
-                for (int k = 0; k < 2 * D; k++) nx[k] = (i + 1 < IIR_K2_CHAIN && tn < n_tiles) ? te[tn * 2 * D + k] : 0.0;
-                matvec<D, true>(Q, v, nv);
-                matvec<D, true>(Q, v + D, nv + D);
+    for (int k = 0; k < 2 * D; k++) nx[k] = ge[k];
+    for (long g = 0; g < n_groups; g++) {
+        double nv[2 * D];
 #pragma unroll
-                for (int k = 0; k < 2 * D; k++) v[k] = nv[k];
-            }
+        for (int k = 0; k < 2 * D; k++) { o[g * 2 * D + k] = c[k]; nv[k] = nx[k]; }
+        if (g + 1 < n_groups) {
+#pragma unroll
+            for (int k = 0; k < 2 * D; k++) nx[k] = ge[(g + 1) * 2 * D + k];
         }
-        ks_scan256<D>(v, (const cdouble_t *)&plan->qspow2[0][0], sh, t);
-        // exclusive: the state entering the lane's first tile
+        matvec<D, true>(QG, c, nv);
+        matvec<D, true>(QG, c + D, nv + D);
 #pragma unroll
-        for (int k = 0; k < 2 * D; k++) sh[t * RS + k] = v[k];
-        __syncthreads();
-        double c[2 * D];
-#pragma unroll
-        for (int k = 0; k < 2 * D; k++) c[k] = t == 0 ? cin[k] : sh[(t - 1) * RS + k];
-        if (T0 < n_tiles) {
-#pragma unroll
-            for (int k = 0; k < 2 * D; k++) nx[k] = te[T0 * 2 * D + k];
-#pragma unroll 1
-            for (int i = 0; i < IIR_K2_CHAIN; i++) {
-                if (T0 + i >= n_tiles) break;
-                double nv[2 * D];
-#pragma unroll
-                for (int k = 0; k < 2 * D; k++) { cr[(T0 + i) * 2 * D + k] = c[k]; nv[k] = nx[k]; }
-                const long tn = T0 + i + 1;
-#pragma unroll
-                for (int k = 0; k < 2 * D; k++) nx[k] = (i + 1 < IIR_K2_CHAIN && tn < n_tiles) ? te[tn * 2 * D + k] : 0.0;
-                matvec<D, true>(Q, c, nv);
-                matvec<D, true>(Q, c + D, nv + D);
-#pragma unroll
-                for (int k = 0; k < 2 * D; k++) c[k] = nv[k];
-            }
-        }
-        if (t == IIR_K2_LANES - 1) {
-#pragma unroll
-            for (int k = 0; k < 2 * D; k++) cc[k] = v[k];          // inclusive result of the last lane = end of the round
-        }
-        __syncthreads();
+        for (int k = 0; k < 2 * D; k++) c[k] = nv[k];
     }
 }
 
@@ -376,9 +368,9 @@ __device__ __forceinline__ void iir_k3_segment(const IirCoef &c, uint32_t *x, lo
 
 template <int NS>
 __global__ __launch_bounds__(IIR_TILE) void iir_k3_kernel(const IirPlan *__restrict__ plan, IirCoef c, uint32_t *__restrict__ iq,
-                                                         long stride, long n, long n_seg, long n_tiles,
-                                                         const double *__restrict__ ZS, const double *__restrict__ carry,
-                                                         double *__restrict__ state)
+                                                         long stride, long n, long n_seg, long n_tiles, long n_groups,
+                                                         const double *__restrict__ ZS, const double *__restrict__ X,
+                                                         const double *__restrict__ gc, double *__restrict__ state)
 {
     constexpr int D = 2 * NS, RS = 2 * D + 1;
     extern __shared__ __attribute__((aligned(16))) uint32_t iir_sm[];
@@ -388,11 +380,19 @@ __global__ __launch_bounds__(IIR_TILE) void iir_k3_kernel(const IirPlan *__restr
     u32x4 raw[IIR_NLD];
     iir_tile_issue(xt, n - tile0, raw, t);                   // in flight while the start states are computed
     const long seg = (long)blockIdx.x * IIR_TILE + t;
-    const cdouble_t *cr = (const cdouble_t *)(carry + ((long)blockIdx.y * n_tiles + blockIdx.x) * 2 * D);
     const cdouble_t *pow2 = (const cdouble_t *)&plan->pow2[0][0];
     double u[2 * D], cv[2 * D];
+    {   // state entering the tile = X[tile] + Q^i gc[group], i = tile index inside its group (all uniform)
+        const int g = (int)(blockIdx.x / IIR_GROUP), gi = (int)(blockIdx.x % IIR_GROUP);
+        const cdouble_t *xx = (const cdouble_t *)(X + ((long)blockIdx.y * n_tiles + blockIdx.x) * 2 * D);
+        const cdouble_t *gg = (const cdouble_t *)(gc + ((long)blockIdx.y * n_groups + g) * 2 * D);
+        const cdouble_t *qi = (const cdouble_t *)&plan->qpow[gi][0];
+        double gv[2 * D];
 #pragma unroll
-    for (int k = 0; k < 2 * D; k++) cv[k] = cr[k];
+        for (int k = 0; k < 2 * D; k++) { cv[k] = xx[k]; gv[k] = gg[k]; }
+        matvec<D, true>(qi, gv, cv);
+        matvec<D, true>(qi, gv + D, cv + D);
+    }
     {
         const double *z = ZS + ((long)blockIdx.y * n_seg + (seg < n_seg ? seg : n_seg - 1)) * 2 * D;
 #pragma unroll
@@ -490,16 +490,17 @@ static void iir_plan_build(const double *sos, int n_stages, IirPlan *pl)
     for (int i = 1; i <= 64; i++) mat_mul(dim, pl->ppow[i - 1], P, pl->ppow[i]);
     static_assert(IIR_TILE == 128, "Q = P^TILE = P^(2^7)");
     memcpy(pl->Q, pl->pow2[7], sizeof pl->Q);
-    static_assert(IIR_K2_CHAIN == 16, "Q^CHAIN is built by four squarings");
-    memcpy(pl->qspow2[0], pl->Q, sizeof pl->Q);
-    for (int k = 0; k < 4; k++) mat_mul(dim, pl->qspow2[0], pl->qspow2[0], pl->qspow2[0]);
-    for (int d = 1; d < 8; d++) mat_mul(dim, pl->qspow2[d - 1], pl->qspow2[d - 1], pl->qspow2[d]);
+    static_assert(IIR_GROUP == 256, "Q^GROUP = Q^(2^8)");
+    memcpy(pl->qpow2[0], pl->Q, sizeof pl->Q);
+    for (int d = 1; d <= 8; d++) mat_mul(dim, pl->qpow2[d - 1], pl->qpow2[d - 1], pl->qpow2[d]);
+    for (int r = 0; r < dim; r++) pl->qpow[0][r * IIR_MAX_DIM + r] = 1.0;
+    for (int i = 1; i < IIR_GROUP; i++) mat_mul(dim, pl->qpow[i - 1], pl->Q, pl->qpow[i]);
 }
 
 static size_t iir_var_bytes(size_t n_samples)
 {
     const size_t n_seg = clhip_div_up(n_samples, IIR_SEG), n_tiles = clhip_div_up(n_seg, IIR_TILE);
-    return (n_seg + 2 * n_tiles + 4) * 2 * IIR_MAX_DIM * sizeof(double);
+    return (n_seg + 2 * n_tiles + 2 * clhip_div_up(n_tiles, IIR_GROUP) + 4) * 2 * IIR_MAX_DIM * sizeof(double);
 }
 
 extern "C" size_t clhip_iir_workspace_bytes(size_t n_samples, int n_stages)
@@ -510,23 +511,23 @@ extern "C" size_t clhip_iir_workspace_bytes(size_t n_samples, int n_stages)
 
 template <int NS>
 static void iir_launch(const IirPlan *d_plan, const IirCoef &coef, double *d_state, uint32_t *d_iq, long stride, long n,
-                       int n_streams, double *E, double *tend, double *carry, hipStream_t s)
+                       int n_streams, double *ws, hipStream_t s)
 {
+    constexpr int D2 = 4 * NS;               // doubles per state pair
     const long n_seg = (long)clhip_div_up((size_t)n, IIR_SEG), n_tiles = (long)clhip_div_up((size_t)n_seg, IIR_TILE);
+    const long n_groups = (long)clhip_div_up((size_t)n_tiles, IIR_GROUP);
+    double *ZS = ws, *tend = ZS + n_seg * n_streams * D2, *X = tend + n_tiles * n_streams * D2;
+    double *gend = X + n_tiles * n_streams * D2, *gc = gend + n_groups * n_streams * D2;
     dim3 grid((unsigned)n_tiles, n_streams), block(IIR_TILE);
     static_assert(IIR_TILE * (2 * IIR_MAX_DIM + 1) * 8 <= IIR_LDS_WORDS * 4, "the scan exchange fits the tile's LDS");
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void *)iir_k1_kernel<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, IIR_LDS_WORDS * 4);
-        (void)hipFuncSetAttribute((const void *)iir_k3_kernel<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, IIR_LDS_WORDS * 4);
-        attr = true;
-    }
     hipLaunchKernelGGL(iir_k1_kernel<NS>, grid, block, IIR_LDS_WORDS * 4, s, d_plan, (const uint32_t *)d_iq, stride, n, n_seg,
-                       n_tiles, E, tend);
-    hipLaunchKernelGGL(iir_k2_kernel<NS>, dim3(n_streams), dim3(IIR_K2_LANES), 0, s, d_plan, n_tiles, (const double *)tend, carry,
-                       (const double *)d_state);
+                       n_tiles, ZS, tend);
+    hipLaunchKernelGGL(iir_k2a_kernel<NS>, dim3((unsigned)n_groups, n_streams), dim3(IIR_GROUP), 0, s, d_plan, n_tiles, n_groups,
+                       (const double *)tend, X, gend);
+    hipLaunchKernelGGL(iir_k2b_kernel<NS>, dim3((unsigned)clhip_div_up((size_t)n_streams, 64)), dim3(64), 0, s, d_plan, n_streams,
+                       n_groups, (const double *)gend, gc, (const double *)d_state);
     hipLaunchKernelGGL(iir_k3_kernel<NS>, grid, block, IIR_LDS_WORDS * 4, s, d_plan, coef, d_iq, stride, n, n_seg, n_tiles,
-                       (const double *)E, (const double *)carry, d_state);
+                       n_groups, (const double *)ZS, (const double *)X, (const double *)gc, d_state);
 }
 
 // d_state: 2*IIR_MAX_DIM doubles per stream, layout [rail][2*stage + {0:v1,1:v2}]
@@ -539,7 +540,6 @@ extern "C" int clhip_iir_cs16_batch(const double *h_sos, int n_stages, double *d
         clhip_set_error("clhip_iir_cs16: bad arguments (1..%d biquads)", IIR_MAX_STAGES);
         return -1;
     }
-    const size_t n_seg = clhip_div_up(n_samples, IIR_SEG), n_tiles = clhip_div_up(n_seg, IIR_TILE);
     const size_t need = sizeof(IirPlan) + 256 + iir_var_bytes(n_samples) * n_streams;
     if (ws_bytes < need) {
         clhip_set_error("clhip_iir_cs16: workspace too small (%zu < %zu)", ws_bytes, need);
@@ -564,15 +564,12 @@ extern "C" int clhip_iir_cs16_batch(const double *h_sos, int n_stages, double *d
         CLHIP_CHECK(hipMemcpyAsync(d_plan, &plan, sizeof plan, hipMemcpyHostToDevice, s));
         last_ws = d_ws;
     }
-    const int D2 = 4 * n_stages;             // doubles per state pair
-    double *E = (double *)(ws + ((sizeof(IirPlan) + 255) & ~(size_t)255));
-    double *tend = E + n_seg * n_streams * D2;
-    double *carry = tend + n_tiles * n_streams * D2;
+    double *wsv = (double *)(ws + ((sizeof(IirPlan) + 255) & ~(size_t)255));
     switch (n_stages) {
-    case 1: iir_launch<1>(d_plan, plan.coef, d_state, (uint32_t *)d_iq, (long)stride_samples, (long)n_samples, n_streams, E, tend, carry, s); break;
-    case 2: iir_launch<2>(d_plan, plan.coef, d_state, (uint32_t *)d_iq, (long)stride_samples, (long)n_samples, n_streams, E, tend, carry, s); break;
-    case 3: iir_launch<3>(d_plan, plan.coef, d_state, (uint32_t *)d_iq, (long)stride_samples, (long)n_samples, n_streams, E, tend, carry, s); break;
-    default: iir_launch<4>(d_plan, plan.coef, d_state, (uint32_t *)d_iq, (long)stride_samples, (long)n_samples, n_streams, E, tend, carry, s); break;
+    case 1: iir_launch<1>(d_plan, plan.coef, d_state, (uint32_t *)d_iq, (long)stride_samples, (long)n_samples, n_streams, wsv, s); break;
+    case 2: iir_launch<2>(d_plan, plan.coef, d_state, (uint32_t *)d_iq, (long)stride_samples, (long)n_samples, n_streams, wsv, s); break;
+    case 3: iir_launch<3>(d_plan, plan.coef, d_state, (uint32_t *)d_iq, (long)stride_samples, (long)n_samples, n_streams, wsv, s); break;
+    default: iir_launch<4>(d_plan, plan.coef, d_state, (uint32_t *)d_iq, (long)stride_samples, (long)n_samples, n_streams, wsv, s); break;
     }
     CLHIP_CHECK_LAUNCH();
     return 0;
