@@ -93,18 +93,19 @@ __device__ __forceinline__ void matvec(MP m, const double *v, double *out)
 __device__ __forceinline__ void iir_tile_issue(const uint32_t *__restrict__ x, long n_left, u32x4 (&r)[IIR_NLD], int t)
 {
     // n_left = samples of this stream from the tile start (>= 1); words beyond it read as zero
-    const bool vec = ((uintptr_t)x & 15) == 0;
+    if ((((uintptr_t)x & 15) == 0) && n_left >= (long)IIR_TILE * IIR_SEG) {      // workgroup-uniform: 16 straight loads
 #pragma unroll
+        for (int q = 0; q < IIR_NLD; q++) r[q] = *(const u32x4 *)(x + (q * IIR_TILE + t) * 4);
+        return;
+    }
+#pragma unroll                                                   // (unrolled: r[] must stay in registers)
     for (int q = 0; q < IIR_NLD; q++) {
         const int i = (q * IIR_TILE + t) * 4;
         u32x4 v = {0, 0, 0, 0};
-        if (vec && i + 4 <= n_left) v = *(const u32x4 *)(x + i);
-        else {
-            if (i < n_left) v.x = x[i];
-            if (i + 1 < n_left) v.y = x[i + 1];
-            if (i + 2 < n_left) v.z = x[i + 2];
-            if (i + 3 < n_left) v.w = x[i + 3];
-        }
+        if (i < n_left) v.x = x[i];
+        if (i + 1 < n_left) v.y = x[i + 1];
+        if (i + 2 < n_left) v.z = x[i + 2];
+        if (i + 3 < n_left) v.w = x[i + 3];
         r[q] = v;
     }
 }
@@ -121,19 +122,22 @@ __device__ __forceinline__ void iir_tile_commit(const u32x4 (&r)[IIR_NLD], uint3
 
 __device__ __forceinline__ void iir_tile_store(uint32_t *__restrict__ x, long n_left, const uint32_t *sm, int t)
 {
-    const bool vec = ((uintptr_t)x & 15) == 0;
+    if ((((uintptr_t)x & 15) == 0) && n_left >= (long)IIR_TILE * IIR_SEG) {
 #pragma unroll
+        for (int q = 0; q < IIR_NLD; q++) {
+            const int i = (q * IIR_TILE + t) * 4;
+            *(u32x4 *)(x + i) = *(const u32x4 *)(sm + (i / IIR_SEG) * IIR_PITCH + i % IIR_SEG);
+        }
+        return;
+    }
+#pragma unroll 1
     for (int q = 0; q < IIR_NLD; q++) {
         const int i = (q * IIR_TILE + t) * 4;
-        const int row = i / IIR_SEG, col = i % IIR_SEG;
-        const u32x4 v = *(const u32x4 *)(sm + row * IIR_PITCH + col);
-        if (vec && i + 4 <= n_left) *(u32x4 *)(x + i) = v;
-        else {
-            if (i < n_left) x[i] = v.x;
-            if (i + 1 < n_left) x[i + 1] = v.y;
-            if (i + 2 < n_left) x[i + 2] = v.z;
-            if (i + 3 < n_left) x[i + 3] = v.w;
-        }
+        const u32x4 v = *(const u32x4 *)(sm + (i / IIR_SEG) * IIR_PITCH + i % IIR_SEG);
+        if (i < n_left) x[i] = v.x;
+        if (i + 1 < n_left) x[i + 1] = v.y;
+        if (i + 2 < n_left) x[i + 2] = v.z;
+        if (i + 3 < n_left) x[i + 3] = v.w;
     }
 }
 
