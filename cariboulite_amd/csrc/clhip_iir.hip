@@ -51,8 +51,10 @@ __host__ __device__ __forceinline__ double iir_step(const IirCoef &c, double *z,
     double out = in;
 #pragma unroll
     for (int s = 0; s < NS; s++) {
-        const double w = out - c.a1[s] * z[2 * s] - c.a2[s] * z[2 * s + 1];
-        out = c.b0[s] * w + c.b1[s] * z[2 * s] + c.b2[s] * z[2 * s + 1];
+        // the feed-forward part of the old state does not wait for w: three dependent FMAs per stage, not five
+        const double ff = __builtin_fma(c.b1[s], z[2 * s], c.b2[s] * z[2 * s + 1]);
+        const double w = __builtin_fma(-c.a2[s], z[2 * s + 1], __builtin_fma(-c.a1[s], z[2 * s], out));
+        out = __builtin_fma(c.b0[s], w, ff);
         z[2 * s + 1] = z[2 * s];
         z[2 * s] = w;
     }
