@@ -450,7 +450,7 @@ __device__ __forceinline__ void second_stage(unsigned char *lds, int t, const fl
 #pragma unroll
         for (int i = 0; i < R; i++) {
             const f32x2 c = YY(i), p = YY(i - 1);
-            o[i] = atan2f(c.y * p.x - c.x * p.y, c.x * p.x + c.y * p.y);
+            o[i] = clhip_atan2f(c.y * p.x - c.x * p.y, c.x * p.x + c.y * p.y);
         }
 #pragma unroll
         for (int k = 0; k < PL; k++) { pc[k].x = o[4 * k]; pc[k].y = o[4 * k + 1]; pc[k].z = o[4 * k + 2]; pc[k].w = o[4 * k + 3]; }
@@ -794,7 +794,7 @@ __global__ __launch_bounds__(256) void gen_fm_kernel(const f32x2 *__restrict__ Y
     float *o = out + (long)s * out_stride;
     for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (long)gridDim.x * blockDim.x) {
         const f32x2 c = y[j], p = y[j - 1];
-        o[j] = atan2f(c.y * p.x - c.x * p.y, c.x * p.x + c.y * p.y);
+        o[j] = clhip_atan2f(c.y * p.x - c.x * p.y, c.x * p.x + c.y * p.y);
     }
 }
 

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void fm_demod_kernel(const f32x2 *__restrict__
         f32x2 p;
         if (j > 0) p = x[j - 1];
         else { p.x = prev[0]; p.y = prev[1]; }
-        out[j] = atan2f(c.y * p.x - c.x * p.y, c.x * p.x + c.y * p.y);
+        out[j] = clhip_atan2f(c.y * p.x - c.x * p.y, c.x * p.x + c.y * p.y);
     }
 }
 __global__ void fm_demod_carry_kernel(const f32x2 *__restrict__ x, size_t n, float *__restrict__ prev)
