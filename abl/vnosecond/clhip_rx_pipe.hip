@@ -435,7 +435,7 @@ __device__ __forceinline__ void second_stage(unsigned char *lds, int t, const fl
                 const int tp = m * M, b = tp / L, p = tp % L;
                 f32x2 sacc = {0.f, 0.f};
 #pragma unroll
-                for (int i = 0; i < KP; i++) fma2<C::PK>(sacc, YY(b - i), rsv[p + i * L]);
+                for (int i = 0; i < 1; i++) fma2<C::PK>(sacc, YY(b - i), rsv[p + i * L]);
                 o[m] = sacc;
             }
         } else {
@@ -538,10 +538,7 @@ __device__ __forceinline__ bool tile_sync_bad(const PipeArgs &a, int s, long S)
     if (a.chunk_offs) {
         const long first = S - C::HALO > 0 ? S - C::HALO : 0;
         const long last = (S + C::TILE_IN < a.n_in ? S + C::TILE_IN : a.n_in) - 1;
-        // written by clhip_smi_find_offsets before this launch, read-only here: scalar loads (SMEM).  A vector
-        // load would put an s_waitcnt vmcnt(0) at the top of every tile and drain the previous tile's stores.
-        typedef __attribute__((address_space(4))) int32_t cint_t;
-        const cint_t *o = (const cint_t *)(a.chunk_offs + (long)s * a.chunks_per_stream);
+        const int32_t *o = a.chunk_offs + (long)s * a.chunks_per_stream;
         for (int c = (int)(first >> a.chunk_shift); c <= (int)(last >> a.chunk_shift); c++) bad |= o[c] != 0;
         if (bad && threadIdx.x == 0) atomicOr(a.bad_flag, 1);          // the tile writes nothing
     }
@@ -629,10 +626,6 @@ void rx_pipe_fused_kernel(const PipeArgs a)
                                                  : (const void *)((const uint32_t *)a.in + (long)s0 * a.in_stride);
         tile_issue_loads<C, KIND>(regs, in0, (long)tile0 * C::TILE_IN - C::HALO, threadIdx.x);
         if (K > 0 && threadIdx.x == 0) grabbed = atomicAdd(a.queue, 1u);
-        // the first tile's words are waited for here (once per worker), so that no path into the loop carries
-        // pending loads: the staging at the loop top then needs no vmcnt wait at all (see the note after the FIR)
-#pragma unroll
-        for (int k = 0; k < TileRegs<C, KIND>::NV; k++) asm volatile("" : "+v"(regs.w[k]));
     }
     while (item < items) {
         // Keep per-iteration values per-iteration: without these the compiler hoists every tap load
@@ -671,11 +664,6 @@ void rx_pipe_fused_kernel(const PipeArgs a)
         f32x4 pc[PL];
         f32x2 b_last = {0.f, 0.f};
         if constexpr (C::FFA) fir_tile_ffa<C>(lds, t, fir, acc, b_last); else fir_tile<C>(lds, t, fir, acc);
-        // Retire the prefetch here, where only loads are outstanding and they have long landed.  vmcnt counts
-        // loads and stores together: waiting for these registers at the top of the next tile would also wait
-        // for this tile's 12 output stores to reach memory.
-#pragma unroll
-        for (int k = 0; k < TileRegs<C, KIND>::NV; k++) asm volatile("" : "+v"(regs.w[k]));
         if constexpr (DIAG) {                                // pin the phase's results before its stamp
 #pragma unroll
             for (int k = 0; k < C::R; k++) asm volatile("" : "+v"(acc[k]));

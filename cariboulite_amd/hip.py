@@ -82,11 +82,12 @@ def exported_symbols():
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        path = os.environ.get("CLHIP_LIB", LIB_PATH)      # an alternative build of the shim (diagnostic / ablation builds)
+        if not os.path.exists(path):
             raise ImportError(
-                f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(the HIP extension is required; there is no CPU fallback)")
-        _lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        _lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
         for name, (res, args) in _SIGS.items():
             fn = getattr(_lib, name)          # AttributeError if the .so lacks a declared symbol
             fn.restype, fn.argtypes = res, args

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive rate of the SoapySDR-shaped boundary: host SMI bytes in (cl_smi_feed_bytes), host samples out
+(readStream, one MTU = 131072 samples per call), one stream.  Never bench.py's `value`."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from cariboulite_amd import soapy as S, synth
+
+MTU, NB = 131072, 524288
+K = 64
+b, _, _ = synth.smi_stream_bytes(K * MTU, 0, stream=1)
+res = {}
+for name, fmt, dt, width, args, bw in (
+        ("cs16", S.SOAPY_SDR_CS16, np.int16, 2, None, None),
+        ("cf32", S.SOAPY_SDR_CF32, np.float32, 2, None, None),
+        ("cs16_iir", S.SOAPY_SDR_CS16, np.int16, 2, None, 100e3),
+        ("cf32_fir64_rs_3_2", S.SOAPY_SDR_CF32, np.float32, 2, {"FIR": "64:1000000", "RESAMP": "3/2"}, None)):
+    sdr = S.Device(dict(driver="Cariboulite", channel="S1G"))
+    rx = sdr.setupStream(S.SOAPY_SDR_RX, fmt, args=args)
+    if bw:
+        sdr.setBandwidth(S.SOAPY_SDR_RX, 0, bw)
+    sdr.activateStream(rx)
+    buf = np.zeros((2 * MTU, width), dt)
+    t_feed = t_read = 0.0
+    got = 0
+    for rep in range(3):
+        t0 = time.perf_counter()
+        sdr.feedSmiBytes(b)
+        t1 = time.perf_counter()
+        n = 0
+        while True:
+            r = sdr.readStream(rx, [buf], MTU).ret
+            if r <= 0:
+                break
+            n += r
+        t2 = time.perf_counter()
+        if rep:                       # first repetition warms up
+            t_feed += t1 - t0; t_read += t2 - t1; got += n
+    res[name] = dict(msps_in=2 * K * MTU / t_read / 1e6, ms_per_mtu_call=t_read / (2 * K) * 1e3,
+                     feed_gbps=2 * b.size / t_feed / 1e9, out_elems=got)
+    sdr.close()
+print(json.dumps(res, indent=1))
