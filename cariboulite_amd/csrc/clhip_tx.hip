@@ -415,17 +415,9 @@ __device__ __forceinline__ uint32_t tx_f2i16_fast(float v)
 // One sub-block of tx_fm_fast_kernel.  CHECKED = false: every message and every output of the sub-block is inside
 // the call (workgroup-uniform), so there is not a single bounds test or divergent branch in it.
 template <class C, bool CHECKED>
-__device__ __forceinline__ double tx_fast_subblock(const float *mm, size_t n, int phi, int skip, double wt, double off,
-                                                   size_t base, unsigned char *rows, double *sh, const f32x2 *hist_in_s,
-                                                   f32x2 *hist_out_s, const tx_cfloat_t *__restrict__ rs, long n_out,
-                                                   int pack_mode, uint32_t *words_s, f32x2 *tap_s)
+__device__ __forceinline__ void tx_load_msgs(const float *mm, size_t n, int phi, size_t tb, float (&mv)[C::PER])
 {
-    constexpr int L = C::L, M = C::M, KP = C::KP, PER = C::PER, NOUT = C::NOUT, ROW = C::ROW, HS = C::HSLOT, H = KP - 1;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    unsigned char *myrow = rows + (t + 1) * ROW;
-    const size_t tb = base + (size_t)t * PER;
-    // messages -> local fp64 prefix (turns)
-    float mv[PER];
+    constexpr int PER = C::PER;
     if (!CHECKED || (tb >= (size_t)phi && tb + PER <= n)) {
 #pragma unroll
         for (int q = 0; q < PER / 4; q++) {
@@ -436,6 +428,19 @@ __device__ __forceinline__ double tx_fast_subblock(const float *mm, size_t n, in
 #pragma unroll
         for (int k = 0; k < PER; k++) mv[k] = (tb + k >= (size_t)phi && tb + k < n) ? mm[tb + k] : 0.f;
     }
+}
+
+template <class C, bool CHECKED>
+__device__ __forceinline__ double tx_fast_subblock(const float (&mv)[C::PER], size_t n, int phi, int skip, double wt, double off,
+                                                   size_t base, unsigned char *rows, double *sh, const f32x2 *hist_in_s,
+                                                   f32x2 *hist_out_s, const tx_cfloat_t *__restrict__ rs, long n_out,
+                                                   int pack_mode, uint32_t *words_s, f32x2 *tap_s)
+{
+    constexpr int L = C::L, M = C::M, KP = C::KP, PER = C::PER, NOUT = C::NOUT, ROW = C::ROW, HS = C::HSLOT, H = KP - 1;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    unsigned char *myrow = rows + (t + 1) * ROW;
+    const size_t tb = base + (size_t)t * PER;
+    // local fp64 prefix (turns)
     double c[PER], run = 0.0;
 #pragma unroll
     for (int k = 0; k < PER; k++) { run = __builtin_fma((double)mv[k], wt, run); c[k] = run; }
@@ -562,12 +567,164 @@ __global__ __launch_bounds__(TXQ_NT, 2) void tx_fm_fast_kernel(
         if (base >= n) break;
         // interior: all messages are real and inside the call, all outputs are ours, and the stream does not
         // end here (the sub-block holding the last message also writes the history for the next call)
-        if (base > 0 && base + C::SUB < n)
-            off = tx_fast_subblock<C, false>(mm, n, phi, skip, wt, off, base, rows, sh, hist_in + (long)s * H,
+        float mv[PER];
+        if (base > 0 && base + C::SUB < n) {
+            tx_load_msgs<C, false>(mm, n, phi, base + (size_t)t * PER, mv);
+            off = tx_fast_subblock<C, false>(mv, n, phi, skip, wt, off, base, rows, sh, hist_in + (long)s * H,
                                              hist_out + (long)s * H, rs, n_out, pack_mode, words_s, tap_s);
-        else
-            off = tx_fast_subblock<C, true>(mm, n, phi, skip, wt, off, base, rows, sh, hist_in + (long)s * H,
+        } else {
+            tx_load_msgs<C, true>(mm, n, phi, base + (size_t)t * PER, mv);
+            off = tx_fast_subblock<C, true>(mv, n, phi, skip, wt, off, base, rows, sh, hist_in + (long)s * H,
                                             hist_out + (long)s * H, rs, n_out, pack_mode, words_s, tap_s);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Single-pass variant: the message is read ONCE.  Each workgroup takes a ticket (so that every superblock
+// before it is owned by a workgroup that is already running), sums its 12288 messages, publishes
+// its fp64 aggregate, and finds its phase offset by decoupled look-back over its predecessors' aggregates /
+// inclusive prefixes (flags carry the launch epoch: no reset between launches).  The poll loop is bounded: on
+// overrun it raises *err and carries on with a wrong phase instead of hanging the GPU.
+// ---------------------------------------------------------------------------
+// One 64-bit word per superblock, written and polled with relaxed agent-scope atomics (no fences, hence no
+// L2 write-back / invalidate traffic): [63:62] state {1: aggregate, 2: inclusive prefix} | [61:48] launch epoch |
+// [47:0] phase in turns mod 1 as 48-bit fixed point.  Integer sums mod 2^48 are exact and associative, so the
+// offset a workgroup finds does not depend on how far back it had to look.
+struct TxLookBack {
+    unsigned long long *st;          // [n_streams][n_super]
+    unsigned int *ticket;            // monotonically increasing across launches
+    unsigned int ticket_base, epoch; // epoch in 1 .. 16383
+    int *err;
+};
+#define TXLB_MASK 0xFFFFFFFFFFFFull
+__device__ __forceinline__ unsigned long long txlb_fix(double turns)
+{
+    const double f = turns - floor(turns);
+    return (unsigned long long)(f * 281474976710656.0) & TXLB_MASK;       // 2^48
+}
+
+template <class C>
+__global__ __launch_bounds__(TXQ_NT, 2) void tx_fm_chain_kernel(
+    const float *__restrict__ m, long m_stride, size_t n, int phi, int skip, double wt, TxLookBack lb, long n_super,
+    int n_streams, const double *__restrict__ phase_in, double *__restrict__ phase_new,
+    const f32x2 *__restrict__ hist_in, f32x2 *__restrict__ hist_out, const float *__restrict__ rs_dev,
+    long n_out, int pack_mode, uint32_t *__restrict__ words, long w_stride, f32x2 *__restrict__ tap, long tap_stride)
+{
+    constexpr int KP = C::KP, PER = C::PER, ROW = C::ROW, HS = C::HSLOT, H = KP - 1;
+    __shared__ __attribute__((aligned(16))) unsigned char rows[(TXQ_NT + 1) * ROW];
+    __shared__ double sh[TXQ_NT / 64 + 1];
+    __shared__ double sh_off;
+    __shared__ unsigned int sh_ticket;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    // Order: workgroups are dispatched in index order, so every superblock before this one belongs to a
+    // workgroup that has at least been dispatched and does not wait for us.  lb.ticket != NULL: take a ticket
+    // instead (same-address atomics retire at ~12 ns each, which throttles the start of 10^4 workgroups).
+    if (lb.ticket) {
+        if (t == 0) sh_ticket = atomicAdd(lb.ticket, 1u) - lb.ticket_base;
+        __syncthreads();
+    }
+    const unsigned int T = lb.ticket ? sh_ticket : blockIdx.x;
+    const int s = (int)(T % (unsigned)n_streams);
+    const long b = (long)(T / (unsigned)n_streams);
+    const float *mm = m + (long)s * m_stride - phi;
+    const size_t sbase = (size_t)b * C::SB;
+    const tx_cfloat_t *__restrict__ rs = (const tx_cfloat_t *)rs_dev;
+    const bool interior = sbase > 0 && sbase + C::SB < n;         // workgroup-uniform: all four sub-blocks unchecked
+
+    // aggregate of the superblock; the messages are read again from L2 / Infinity Cache by the sub-block loop
+    // (keeping 48 of them per lane in registers would cost two waves of occupancy, and occupancy hides the look-back)
+    double part = 0.0;
+#pragma unroll
+    for (int sb = 0; sb < TXQ_NSUB; sb++) {
+        const size_t tb = sbase + (size_t)sb * C::SUB + (size_t)t * PER;
+        float mv[PER];
+        if (interior) tx_load_msgs<C, false>(mm, n, phi, tb, mv);
+        else tx_load_msgs<C, true>(mm, n, phi, tb, mv);
+        double r = 0.0;
+#pragma unroll
+        for (int k = 0; k < PER; k++) r = __builtin_fma((double)mv[k], wt, r);
+        part += r;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);
+    if (lane == 0) sh[wave] = part;
+    __syncthreads();
+    if (wave == 0) {
+        double total = 0.0;
+#pragma unroll
+        for (int k = 0; k < TXQ_NT / 64; k++) total += sh[k];
+        unsigned long long *st = lb.st + (long)s * n_super;
+        const unsigned long long e = (unsigned long long)lb.epoch << 48;
+        const unsigned long long mine = txlb_fix(total);
+        if (lane == 0) __hip_atomic_store(st + b, (1ull << 62) | e | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long pin = txlb_fix(phase_in[s] * (1.0 / TWO_PI));
+        unsigned long long acc = 0;
+        long j0 = b - 1;
+        bool done = false;
+        int guard = 0;
+        while (!done) {
+            const long j = j0 - lane;
+            unsigned long long w = (3ull << 62) | pin;             // state 3 = before the stream's first superblock
+            if (j >= 0) {
+                do {
+                    w = __hip_atomic_load(st + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (++guard > (1 << 22)) { *lb.err = 1; w = (2ull << 62) | e; }
+                } while (((w >> 48) & 0x3FFF) != lb.epoch || (w >> 62) == 0);
+            }
+            const unsigned long long have = __ballot((w >> 62) >= 2);
+            const int first = have ? __builtin_ctzll(have) : 64;
+            unsigned long long v = lane <= first ? (w & TXLB_MASK) : 0ull;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            acc += v;
+            if (first < 64) done = true; else j0 -= 64;
+        }
+        acc &= TXLB_MASK;
+        if (lane == 0) {
+            const unsigned long long inc = (acc + mine) & TXLB_MASK;
+            __hip_atomic_store(st + b, (2ull << 62) | e | inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sh_off = (double)acc * (1.0 / 281474976710656.0);
+            if (b == n_super - 1) {
+                const double it = (double)inc * (1.0 / 281474976710656.0);
+                phase_new[s] = wrap_pi(TWO_PI * (it - rint(it)));
+            }
+        }
+    }
+    __syncthreads();
+    double off = sh_off;                                           // phase (turns) after message sbase-1
+
+    // the HS samples before the superblock -> tail of row -1
+    if (t < HS) {
+        const int k = t + 1;                                       // message sbase - k
+        f32x2 hv = {0.f, 0.f};
+        if (k <= H) {
+            if (sbase >= (size_t)k) {
+                double ph = off;
+                for (int i = 1; i < k; i++) ph -= wt * (double)mm[sbase - i];
+                hv = phasor_turns(ph);
+            } else {                                               // sbase == 0: real message -k - phi
+                const long idx = (long)H - k - phi;
+                if (idx >= 0) hv = hist_in[(long)s * H + idx];
+            }
+        }
+        *(f32x2 *)(rows + 8 * (PER - k)) = hv;
+    }
+    uint32_t *words_s = words + (long)s * w_stride;
+    f32x2 *tap_s = tap ? tap + (long)s * tap_stride : nullptr;
+    for (int sb = 0; sb < TXQ_NSUB; sb++) {
+        const size_t base = sbase + (size_t)sb * C::SUB;          // workgroup-uniform
+        if (base >= n) break;
+        float mv[PER];
+        if (base > 0 && base + C::SUB < n) {
+            tx_load_msgs<C, false>(mm, n, phi, base + (size_t)t * PER, mv);
+            off = tx_fast_subblock<C, false>(mv, n, phi, skip, wt, off, base, rows, sh, hist_in + (long)s * H,
+                                             hist_out + (long)s * H, rs, n_out, pack_mode, words_s, tap_s);
+        } else {
+            tx_load_msgs<C, true>(mm, n, phi, base + (size_t)t * PER, mv);
+            off = tx_fast_subblock<C, true>(mv, n, phi, skip, wt, off, base, rows, sh, hist_in + (long)s * H,
+                                            hist_out + (long)s * H, rs, n_out, pack_mode, words_s, tap_s);
+        }
     }
 }
 
@@ -619,6 +776,9 @@ struct clhip_tx_pipe {
     unsigned long long n_total;
     f32x2 *Y; size_t y_cap;          // modulated signal workspace (per stream)
     double *ws; size_t ws_cap;
+    // single-pass (look-back) state of the config-5 path
+    unsigned long long *lb_st; size_t lb_cap;                            // per stream x superblock
+    unsigned int *lb_ticket; int *lb_err, *lb_err_dev; unsigned int ticket_total, epoch;   // lb_err: pinned host word the kernel can raise
 };
 
 // one output per lane: upfirdn polyphase leg -> quantise -> pack
@@ -700,6 +860,8 @@ extern "C" void clhip_tx_pipe_destroy(clhip_tx_pipe *p)
     if (!p) return;
     clhip_free(p->d_rs); clhip_free(p->d_phase); clhip_free(p->hist[0]); clhip_free(p->hist[1]);
     clhip_free(p->Y); clhip_free(p->ws);
+    clhip_free(p->lb_st); clhip_free(p->lb_ticket);
+    if (p->lb_err) (void)hipHostFree(p->lb_err);
     delete p;
 }
 
@@ -753,6 +915,54 @@ extern "C" long clhip_tx_pipe_run(clhip_tx_pipe *p, int in_kind, const void *d_i
         }
         const double wt = p->w * (1.0 / TWO_PI);
         dim3 grid((unsigned)n_super, p->n_streams);
+        static const int tx_chain = getenv("CLHIP_TX_CHAIN") ? atoi(getenv("CLHIP_TX_CHAIN")) : 1;
+        if (tx_chain) {
+            // single pass: tickets + decoupled look-back (tx_fm_chain_kernel)
+            const size_t need = (size_t)n_super * p->n_streams;
+            if (need > p->lb_cap || !p->lb_ticket) {
+                clhip_free(p->lb_st);
+                p->lb_st = (unsigned long long *)clhip_malloc(sizeof(unsigned long long) * need);
+                if (!p->lb_ticket) {
+                    p->lb_ticket = (unsigned int *)clhip_malloc(sizeof(unsigned int));
+                    if (p->lb_ticket) CLHIP_CHECK(hipMemsetAsync(p->lb_ticket, 0, sizeof(unsigned int), s));
+                    if (hipHostMalloc((void **)&p->lb_err, sizeof(int), hipHostMallocMapped) != hipSuccess) p->lb_err = nullptr;
+                    if (p->lb_err) {
+                        *p->lb_err = 0;
+                        if (hipHostGetDevicePointer((void **)&p->lb_err_dev, p->lb_err, 0) != hipSuccess) p->lb_err_dev = nullptr;
+                    }
+                }
+                p->lb_cap = p->lb_st ? need : 0;
+                if (!p->lb_cap || !p->lb_ticket || !p->lb_err || !p->lb_err_dev) {
+                    clhip_set_error("clhip_tx_pipe_run: look-back state allocation failed");
+                    return -1;
+                }
+                CLHIP_CHECK(hipMemsetAsync(p->lb_st, 0, sizeof(unsigned long long) * need, s));   // epoch 0 is never used
+            }
+            if (++p->epoch > 0x3FFF) {                              // 14-bit epoch wrapped: forget every old entry
+                p->epoch = 1;
+                CLHIP_CHECK(hipMemsetAsync(p->lb_st, 0, sizeof(unsigned long long) * p->lb_cap, s));
+            }
+            static const int use_ticket = getenv("CLHIP_TX_TICKET") ? atoi(getenv("CLHIP_TX_TICKET")) : 0;
+            if (*(volatile int *)p->lb_err) {                       // raised by an earlier launch of this pipe
+                clhip_set_error("clhip_tx_pipe_run: a look-back poll overran in an earlier call; output of that call is invalid "
+                                "(set CLHIP_TX_CHAIN=0 for the three-pass path)");
+                *p->lb_err = 0;
+                return -1;
+            }
+            TxLookBack lb = {p->lb_st, use_ticket ? p->lb_ticket : nullptr, p->ticket_total, p->epoch, p->lb_err_dev};
+            const unsigned n_wg = (unsigned)(n_super * p->n_streams);
+            double *phase_new = p->ws;                             // scratch: d_phase is read by late workgroups
+            hipLaunchKernelGGL(tx_fm_chain_kernel<C>, dim3(n_wg), dim3(TXQ_NT), 0, s, (const float *)d_in, (long)in_stride, nv, phi,
+                               skip, wt, lb, n_super, p->n_streams, (const double *)p->d_phase, phase_new, p->hist[p->cur],
+                               p->hist[p->cur ^ 1], p->d_rs, (long)n_out, p->pack_mode, (uint32_t *)d_bytes,
+                               (long)(out_stride_bytes / 4), (f32x2 *)d_iq_tap, (long)iq_tap_stride);
+            p->ticket_total += n_wg;
+            CLHIP_CHECK(hipMemcpyAsync(p->d_phase, phase_new, sizeof(double) * p->n_streams, hipMemcpyDeviceToDevice, s));
+            CLHIP_CHECK_LAUNCH();
+            p->cur ^= 1;
+            p->n_total += n_in;
+            return (long)n_out;
+        }
         double *phase_new = p->ws + (size_t)n_super * p->n_streams;
         hipLaunchKernelGGL(fm_super_sum_kernel<C>, grid, dim3(TXQ_NT), 0, s, (const float *)d_in, (long)in_stride, nv, phi, wt,
                            p->ws, n_super);
