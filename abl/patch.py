@@ -19,6 +19,17 @@ elif v == "fir1":       # FFA middle blocks: 1 of 3
 elif v == "noload":     # no HBM reads of the next tile
     rep("            tile_issue_loads<C, KIND>(regs, inn, (long)tn * C::TILE_IN - C::HALO, t);\n        }",
         "            if (a.n_in < 0) tile_issue_loads<C, KIND>(regs, inn, (long)tn * C::TILE_IN - C::HALO, t);\n        }")
+elif v == "fakestore":  # same store instructions and addresses, no LDS transposes (data lands in the wrong place)
+    a = s.index("#pragma unroll\n    for (int h = 0; h < 2; h++) {\n        if ((lane >> 5) == h) {")
+    b = s.index("// wave-uniform: do the chunks this tile reads all have sync offset 0?")
+    body = """    if (!CHECKED) {
+        unsigned char *hb0 = outb + (tile_e0 + (long)NOUT * (wave * 64)) * OB + lane * 16;
+#pragma unroll
+        for (int k = 0; k < PL; k++) *(f32x4 *)(hb0 + k * 1024) = pc[k];
+        return;
+    }
+"""
+    s = s[:a] + body + s[a:]
 elif v == "base":
     pass
 open(path, "w").write(s)
