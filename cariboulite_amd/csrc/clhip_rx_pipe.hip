@@ -759,19 +759,45 @@ __global__ __launch_bounds__(256) void gen_stage_kernel(PipeArgs a, int halo, f3
         x[j] = j < halo ? a.hist_in[(long)s * halo + j] : load_sample(a, in, j - halo) * inv;
 }
 
+// Generic FIR (any T <= PIPE_MAX_FIR): a workgroup stages 2048 + T - 1 samples in LDS, a lane owns 8 consecutive
+// outputs and walks its window once; window position d meets output r through tap (T-1) + r - d, read with scalar
+// loads from a zero-padded copy of the taps (8 zeros on both sides: no bounds tests).  Every accumulator sees its
+// taps in descending k order, like the fused direct form (bit-identical results).
+#define GEN_PER 8
+#define GEN_TILE (256 * GEN_PER)
+#define GEN_PAD 8
 __global__ __launch_bounds__(256) void gen_fir_kernel(const f32x2 *__restrict__ X, long x_stride, int halo,
-                                                      const float *__restrict__ taps, int T, int hfg,
+                                                      const float *__restrict__ taps_pad, int T, int hfg,
                                                       long n_in, f32x2 *__restrict__ Y, long y_stride)
 {
-    const int s = blockIdx.y;
+    __shared__ f32x2 xs[(GEN_TILE + PIPE_MAX_FIR) / 8 * 9 + 9];      // one pad per 8 samples: lane stride 18 dwords, conflict-free
+    const int s = blockIdx.y, t = threadIdx.x;
     const f32x2 *x = X + (long)s * x_stride + halo;      // x[0] = first new input; negative = history
     f32x2 *y = Y + (long)s * y_stride;
     const long total = hfg + n_in;
-    for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += (long)gridDim.x * blockDim.x) {
-        const long n = j - hfg;
-        f32x2 accv = {0.f, 0.f};
-        for (int k = T - 1; k >= 0; k--) accv += x[n - k] * taps[k];   // same order as the fused kernel
-        y[j] = accv;
+    const cfloat_t *__restrict__ tp = (const cfloat_t *)taps_pad + GEN_PAD;      // tp[k], k in [-8, T+8)
+    for (long j0 = (long)blockIdx.x * GEN_TILE; j0 < total; j0 += (long)gridDim.x * GEN_TILE) {
+        const long n0 = j0 - hfg;                        // input index of the tile's first output
+        __syncthreads();                                 // the previous tile's windows are done
+        for (int i = t; i < GEN_TILE + T - 1; i += 256) {
+            const long g = n0 - (T - 1) + i;
+            f32x2 z = {0.f, 0.f};
+            xs[i + (i >> 3)] = g < n_in ? x[g] : z;
+        }
+        __syncthreads();
+        f32x2 acc[GEN_PER];
+#pragma unroll
+        for (int r = 0; r < GEN_PER; r++) { acc[r].x = 0.f; acc[r].y = 0.f; }
+        const f32x2 *w = xs + t * (GEN_PER + 1);         // w[d + d/8] = x[n0 + 8t - (T-1) + d]
+        for (int d = 0; d < T - 1 + GEN_PER; d++) {
+            const f32x2 xv = w[d + (d >> 3)];
+            const cfloat_t *q = tp + (T - 1 - d);       // tap for output r: q[r]
+#pragma unroll
+            for (int r = 0; r < GEN_PER; r++) acc[r] += xv * q[r];
+        }
+#pragma unroll
+        for (int r = 0; r < GEN_PER; r++)
+            if (j0 + t * GEN_PER + r < total) y[j0 + t * GEN_PER + r] = acc[r];
     }
 }
 
@@ -846,6 +872,7 @@ struct clhip_rx_pipe {
     // generic workspaces
     const int32_t *chk_offs; size_t chk_chunk_samples; int32_t *chk_flag;   // optional sync validation
     float *d_fir, *d_fir_int, *d_rs;   // taps; d_fir_int = taps/4096 for integer inputs
+    float *d_fir_pad;                  // [8 zeros | taps | zeros] for the generic FIR kernel
     float *d_ffa, *d_ffa_int;          // [H0 | H1 | H0+H1] for the 2-parallel fast FIR, same two scalings
     bool ffa;                          // the selected fused instantiation uses them
     unsigned long long *diag;          // optional stamp buffer (diagnostic kernel build)
@@ -908,6 +935,14 @@ extern "C" clhip_rx_pipe *clhip_rx_pipe_create(int n_streams, int channel, const
     float scaled[PIPE_MAX_FIR];
     for (int k = 0; k < PIPE_MAX_FIR; k++) scaled[k] = p->fir[k] / 4096.0f;   // exact: power of two
     (void)hipMemcpy(p->d_fir, p->fir, sizeof(float) * PIPE_MAX_FIR, hipMemcpyHostToDevice);
+    {
+        float padded[PIPE_MAX_FIR + 2 * GEN_PAD + GEN_PER];
+        memset(padded, 0, sizeof padded);
+        memcpy(padded + GEN_PAD, p->fir, sizeof(float) * n_fir);
+        p->d_fir_pad = (float *)clhip_malloc(sizeof padded);
+        if (!p->d_fir_pad) { clhip_rx_pipe_destroy(p); return nullptr; }
+        (void)hipMemcpy(p->d_fir_pad, padded, sizeof padded, hipMemcpyHostToDevice);
+    }
     (void)hipMemcpy(p->d_fir_int, scaled, sizeof(float) * PIPE_MAX_FIR, hipMemcpyHostToDevice);
     if ((n_fir & 1) == 0) {
         const int th = n_fir / 2;
@@ -932,7 +967,7 @@ extern "C" void clhip_rx_pipe_destroy(clhip_rx_pipe *p)
 {
     if (!p) return;
     clhip_free(p->hist[0]); clhip_free(p->hist[1]);
-    clhip_free(p->d_fir); clhip_free(p->d_fir_int); clhip_free(p->d_rs); clhip_free(p->d_ffa); clhip_free(p->d_ffa_int);
+    clhip_free(p->d_fir); clhip_free(p->d_fir_int); clhip_free(p->d_rs); clhip_free(p->d_fir_pad); clhip_free(p->d_ffa); clhip_free(p->d_ffa_int);
     clhip_free(p->X); clhip_free(p->Y); clhip_free(p->queue);
     delete p;
 }
@@ -1105,8 +1140,9 @@ extern "C" long clhip_rx_pipe_run(clhip_rx_pipe *p, int in_kind, const void *d_i
         const unsigned gx = (unsigned)(clhip_div_up(p->halo + n_in, 256) > 4096 ? 4096 : clhip_div_up(p->halo + n_in, 256));
         dim3 grid(gx, p->n_streams), block(256);
         hipLaunchKernelGGL(gen_stage_kernel, grid, block, 0, s, a, p->halo, p->X, (long)p->x_cap);
-        hipLaunchKernelGGL(gen_fir_kernel, grid, block, 0, s, p->X, (long)p->x_cap, p->halo, p->d_fir, p->T, p->hfg,
-                           (long)n_in, p->Y, (long)p->y_cap);
+        const unsigned gf = (unsigned)(clhip_div_up(p->hfg + n_in, GEN_TILE) > 8192 ? 8192 : clhip_div_up(p->hfg + n_in, GEN_TILE));
+        hipLaunchKernelGGL(gen_fir_kernel, dim3(gf, p->n_streams), block, 0, s, p->X, (long)p->x_cap, p->halo, p->d_fir_pad, p->T,
+                           p->hfg, (long)n_in, p->Y, (long)p->y_cap);
         if (p->mode == CL_PIPE_OUT_FM_DEMOD)
             hipLaunchKernelGGL(gen_fm_kernel, grid, block, 0, s, p->Y, (long)p->y_cap, p->hfg, (long)n_in,
                                (float *)d_out, (long)out_stride);
