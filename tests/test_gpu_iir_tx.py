@@ -246,3 +246,62 @@ def test_tx_pipe_streaming_any_start_phase(G, orc):
         iq2, _ = orc.fm_mod_f64(msg[off:off + n2], 75e3, 4e6)
         w2 = orc.Resampler(t["rs_2_3"], 2, 3).f64(iq2)
         assert np.max(np.abs(tp2[si].cpu().numpy() - w2)) <= TOL * np.max(np.abs(w2))
+
+
+@pytest.mark.parametrize("order", [2, 4, 6, 8])
+def test_iir_orders_and_long_streams(G, orc, order):
+    """1..4 biquads; a stream long enough for several tile groups (256 tiles of 8192 samples per group), a ragged
+    tail, then a second call that continues from the carried state; two streams with an odd stride."""
+    import torch
+    from cariboulite_amd import hip
+    rng = np.random.default_rng(100 + order)
+    n1, n2 = 2 * 256 * 8192 + 8192 * 3 + 77, 300_001
+    x = rng.integers(-4096, 4096, size=(n1 + n2, 2), dtype=np.int16)
+    ref = orc.IIR(order, 4e6, 60e3)
+    want = ref.apply_cs16(x.copy())
+    f = hip.IIR(_sos5(orc.IIR(order, 4e6, 60e3)))
+    d = torch.from_numpy(x.copy()).to(G.DEV)
+    f.run(d, n1)
+    f.run(d[n1:], n2)
+    got = d.cpu().numpy()
+    diff = np.abs(got.astype(np.int32) - want.astype(np.int32))
+    assert diff.max() <= 1 and np.mean(diff != 0) < 1e-4, (diff.max(), np.mean(diff != 0))
+    # two streams, stride larger than the length, unaligned start (falls back to scalar staging)
+    ns, n, stride = 2, 100_003, 100_100
+    buf = rng.integers(-4096, 4096, size=(ns * stride + 1, 2), dtype=np.int16)
+    d2 = torch.from_numpy(buf.copy()).to(G.DEV)
+    f2 = hip.IIR(_sos5(orc.IIR(order, 4e6, 60e3)), ns)
+    f2.run(d2[1:], n, stride=stride)
+    got2 = d2.cpu().numpy()
+    for s in range(ns):
+        lo = 1 + s * stride
+        w = orc.IIR(order, 4e6, 60e3).apply_cs16(buf[lo:lo + n].copy())
+        dd = np.abs(got2[lo:lo + n].astype(np.int32) - w.astype(np.int32))
+        assert dd.max() <= 1 and np.mean(dd != 0) < 1e-4
+        assert np.array_equal(got2[lo + n:lo + stride], buf[lo + n:lo + stride])      # the gap is untouched
+    assert np.array_equal(got2[0], buf[0])
+
+
+def test_tx_pipe_long_message_lookback(G, orc):
+    """3.2 M messages = 261 superblocks per stream: the single-launch look-back runs many workgroups deep;
+    two consecutive calls (epochs) on the same pipe, both against the fp64 oracle."""
+    import torch
+    from cariboulite_amd import hip
+    t = load_golden("taps.npz")
+    rng = np.random.default_rng(5)
+    n = 3_200_017
+    msg = (0.5 * np.sin(2 * np.pi * 1.5e3 * np.arange(2 * n) / 4e6) + 0.25 * rng.standard_normal(2 * n)).astype(np.float32)
+    iq, _ = orc.fm_mod_f64(msg, 75e3, 4e6)
+    want = orc.Resampler(t["rs_2_3"], 2, 3).f64(iq)
+    d = torch.from_numpy(msg).to(G.DEV)
+    pipe = hip.TxPipe(1, 75e3, 4e6, t["rs_2_3"], 2, 3, hip.TX_DOCUMENTED)
+    got, pos = [], 0
+    for cn in (n, n):
+        k = pipe.out_count(cn)
+        by = torch.zeros(4 * k, dtype=torch.uint8, device=G.DEV)
+        tp = torch.zeros((k, 2), dtype=torch.float32, device=G.DEV)
+        assert pipe.run(hip.TXPIPE_IN_FM_MESSAGE, d[pos:], 0, cn, by, 4 * k, tp, k) == k
+        got.append(tp.cpu().numpy()); pos += cn
+    got = np.concatenate(got)
+    assert got.shape == want.shape
+    assert np.max(np.abs(got - want)) <= TOL * np.max(np.abs(want))
