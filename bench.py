@@ -76,8 +76,18 @@ def cpu_baseline(taps, d_words, budget_s):
             if dt > budget_s * (0.6 if label == "all" else 0.4):
                 break
         res[label] = reps * n / dt / 1e6
+    # (i) of SURVEY.md 8(d): the reference-semantics plumbing alone (chunked sync search + unpack + /4096), one thread
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        _, iq, _ = orc.smi_read(0, b, n, 524288)
+        _ = orc.cs16_to_cf32(iq)
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt > 1.5:
+            break
+    res["unpack_1t"] = reps * n / dt / 1e6
     return {"value": round(res["all"], 1), "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "value_1_thread": round(res["1t"], 1),
+            "value_1_thread": round(res["1t"], 1), "unpack_scale_only_1_thread": round(res["unpack_1t"], 1),
             "sample": f"first 2^24 samples (128 native chunks) of the GPU input, oracle/cl_oracle.c "
                       f"orc_rx_pipe_f32_mt (unpack+sync -> /4096 -> FIR64 -> 3/2, fp32 AVX2, OpenMP)"}, out
 
@@ -241,6 +251,7 @@ def main():
                          "kernel_ms_avg": round(kern_avg_s * 1e3, 4), "kernel_ms_min": round(float(np.min(kern_ms)), 4),
                          "kernel_ms_each": [round(float(v), 3) for v in kern_ms],
                          "algorithmic_bytes_per_sample": ALGO_BYTES_PER_SAMPLE,
+                         "read_only_frac": round(4.0 * n / kern_avg_s / 1e9 / HBM_PEAK_GBS, 4),   # 4 B read per sample alone
                          "algorithmic_tflops": round(FLOP_PER_SAMPLE * n / kern_avg_s / 1e12, 2),
                          "algorithmic_frac_of_fp32_valu_peak": round(FLOP_PER_SAMPLE * n / kern_avg_s / 1e12 / VALU_PEAK_TFLOPS, 4)},
         }

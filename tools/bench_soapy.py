@@ -15,7 +15,8 @@ for name, fmt, dt, width, args, bw in (
         ("cs16", S.SOAPY_SDR_CS16, np.int16, 2, None, None),
         ("cf32", S.SOAPY_SDR_CF32, np.float32, 2, None, None),
         ("cs16_iir", S.SOAPY_SDR_CS16, np.int16, 2, None, 100e3),
-        ("cf32_fir64_rs_3_2", S.SOAPY_SDR_CF32, np.float32, 2, {"FIR": "64:1000000", "RESAMP": "3/2"}, None)):
+        ("cf32_fir64_rs_3_2", S.SOAPY_SDR_CF32, np.float32, 2, {"FIR": "64:1000000", "RESAMP": "3/2"}, None),
+        ("cs16_async_ring", S.SOAPY_SDR_CS16, np.int16, 2, {"ASYNC": "1"}, None)):
     sdr = S.Device(dict(driver="Cariboulite", channel="S1G"))
     rx = sdr.setupStream(S.SOAPY_SDR_RX, fmt, args=args)
     if bw:
@@ -26,18 +27,31 @@ for name, fmt, dt, width, args, bw in (
     got = 0
     for rep in range(3):
         t0 = time.perf_counter()
-        sdr.feedSmiBytes(b)
+        if args and "ASYNC" in args:
+            sdr.feedSmiBytes(b[: 8 * NB])          # stay inside the ring: 8 of its 16 MTUs
+        else:
+            sdr.feedSmiBytes(b)
         t1 = time.perf_counter()
         n = 0
-        while True:
-            r = sdr.readStream(rx, [buf], MTU).ret
-            if r <= 0:
-                break
-            n += r
+        if args and "ASYNC" in args:
+            # the reader thread drains the FIFO into the ring (10 MTUs, overwrite-oldest): feed and read in lock step
+            n = 0
+            for k in range(8):
+                r = sdr.readStream(rx, [buf], MTU, timeoutUs=2_000_000).ret
+                if r <= 0:
+                    break
+                n += r
+        else:
+            while True:
+                r = sdr.readStream(rx, [buf], MTU).ret
+                if r <= 0:
+                    break
+                n += r
         t2 = time.perf_counter()
         if rep:                       # first repetition warms up
             t_feed += t1 - t0; t_read += t2 - t1; got += n
-    res[name] = dict(msps_in=2 * K * MTU / t_read / 1e6, ms_per_mtu_call=t_read / (2 * K) * 1e3,
+    res[name] = dict(msps_in=got / t_read / 1e6 if (args and "ASYNC" in args) else 2 * K * MTU / t_read / 1e6,
+                     ms_per_mtu_call=t_read / max(got // MTU, 1) * 1e3 if (args and "ASYNC" in args) else t_read / (2 * K) * 1e3,
                      feed_gbps=2 * b.size / t_feed / 1e9, out_elems=got)
     sdr.close()
 print(json.dumps(res, indent=1))
