@@ -6,12 +6,16 @@
 // reference registers (soapy_api/SoapyCariboulite.cpp:119) and forwards every
 // stream virtual of soapy_api/Cariboulite.hpp:65-93 to include/cariboulite_hip.h:
 //
-//   g++ -std=c++11 -fPIC -shared SoapyCaribouliteHip.cpp -I../../../include \
-//       -L../.. -lcariboulite_host -lcariboulite_hip -lSoapySDR -o libSoapyCaribouliteHip.so
+//   g++ -std=c++11 -fPIC -shared SoapyCaribouliteHip.cpp -I../../../include -L../.. -lcariboulite_host
+//       -lcariboulite_hip -lSoapySDR -o libSoapyCaribouliteHip.so
+//
+// tests/test_soapy_module.py compiles it against a compile-check stub of the API slice used here
+// (tests/cpp/soapy_api_stub) and drives it through the Device virtuals on the GPU box.
 #include <SoapySDR/Device.hpp>
 #include <SoapySDR/Formats.hpp>
 #include <SoapySDR/Registry.hpp>
 
+#include <cstdio>
 #include <stdexcept>
 #include <string>
 #include <vector>
