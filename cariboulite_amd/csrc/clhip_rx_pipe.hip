@@ -980,6 +980,9 @@ extern "C" void clhip_rx_pipe_reset(clhip_rx_pipe *p)
     p->cur = 0; p->n_total = 0;
 }
 
+extern "C" void clhip_rx_pipe_seek(clhip_rx_pipe *p, unsigned long long n_total) { p->n_total = n_total; }
+extern "C" size_t clhip_rx_pipe_halo(const clhip_rx_pipe *p) { return (size_t)p->halo; }
+
 extern "C" void clhip_rx_pipe_force_generic(clhip_rx_pipe *p, int on) { p->force_generic = on != 0; }
 
 // Diagnostic only (tools/phase_stamps.py): run config 2 through the s_memtime-stamped build of the fused

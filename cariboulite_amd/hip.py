@@ -55,6 +55,8 @@ _SIGS = {
     "clhip_rx_pipe_create": (C.c_void_p, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "clhip_rx_pipe_destroy": (None, [C.c_void_p]),
     "clhip_rx_pipe_reset": (None, [C.c_void_p]),
+    "clhip_rx_pipe_seek": (None, [C.c_void_p, C.c_ulonglong]),
+    "clhip_rx_pipe_halo": (C.c_size_t, [C.c_void_p]),
     "clhip_rx_pipe_out_count": (C.c_size_t, [C.c_void_p, C.c_size_t]),
     "clhip_rx_pipe_uses_fused": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int]),
     "clhip_rx_pipe_run": (C.c_long, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -176,6 +178,12 @@ class RxPipe:
 
     def reset(self):
         lib().clhip_rx_pipe_reset(self.h)
+
+    def seek(self, n_total):
+        lib().clhip_rx_pipe_seek(self.h, n_total)
+
+    def halo(self):
+        return lib().clhip_rx_pipe_halo(self.h)
 
     def out_count(self, n_in):
         return lib().clhip_rx_pipe_out_count(self.h, n_in)

@@ -16,6 +16,36 @@ def assign_streams(n_streams, world, rank):
     return list(range(rank, n_streams, world))
 
 
+def time_slices(n, world, align):
+    """Cut ONE stream of n input samples into `world` contiguous slices whose starts are multiples of `align`
+    (lcm of the decimation M and 2, so that every slice starts on polyphase phase 0 and on an even index);
+    returns [(start, stop)] per rank.  Slice owners prime their pipe with the halo before `start`
+    (RxPipe.seek + one discarded run), see clhip_rx_pipe_seek."""
+    if world < 1 or align < 1:
+        raise ValueError("world and align must be positive")
+    per = -(-n // world)
+    per = -(-per // align) * align
+    out = []
+    for r in range(world):
+        a, b = min(r * per, n), min((r + 1) * per, n)
+        out.append((a, b))
+    return out
+
+
+def run_time_slice(pipe, in_kind, d_in, start, stop, d_out, out_count_fn, scratch_out):
+    """Process input samples [start, stop) of one long device-resident stream `d_in` with `pipe` as if the pipe
+    had seen everything before `start`: reset, seek, run the halo (outputs discarded into scratch_out), run the slice
+    into d_out.  Returns the number of outputs written."""
+    halo = pipe.halo()
+    pipe.reset()
+    h0 = max(start - halo, 0)
+    # a stream start inside the halo keeps the zero history of a fresh pipe for the missing part
+    pipe.seek(h0)
+    if start > h0:
+        pipe.run(in_kind, d_in[h0:], 0, start - h0, scratch_out, 0)
+    return pipe.run(in_kind, d_in[start:], 0, stop - start, d_out, 0)
+
+
 def owner_of(stream, world):
     return stream % world
 

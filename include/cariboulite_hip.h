@@ -188,6 +188,12 @@ clhip_rx_pipe *clhip_rx_pipe_create(int n_streams, int channel,
                                     int out_mode);
 void   clhip_rx_pipe_destroy(clhip_rx_pipe *p);
 void   clhip_rx_pipe_reset(clhip_rx_pipe *p);                    /* zero history, phase 0      */
+/* Time slicing of ONE long stream over several GPUs: place the pipe at absolute input index
+ * n_total (sets the polyphase phase; history is left as it is).  A slice owner resets, seeks to (slice start - halo),
+ * runs the halo samples before its slice once (outputs discarded) and then its slice: its outputs equal the
+ * single-pipe outputs bit for bit.  halo = clhip_rx_pipe_halo(). */
+void   clhip_rx_pipe_seek(clhip_rx_pipe *p, unsigned long long n_total);
+size_t clhip_rx_pipe_halo(const clhip_rx_pipe *p);               /* pre-FIR samples of history kept per stream */
 size_t clhip_rx_pipe_out_count(const clhip_rx_pipe *p, size_t n_in); /* outputs the next run yields */
 int    clhip_rx_pipe_uses_fused(const clhip_rx_pipe *p, size_t n_in, int in_kind);
 /* d_in: stream s at d_in + s*in_stride_elems (elements of in_kind);

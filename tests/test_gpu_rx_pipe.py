@@ -249,3 +249,29 @@ def test_linearity_and_impulse_full_size(G, orc):
     assert np.max(np.abs(got[2_000_000:2_000_064, 0] - h * 0.5)) < 1e-6
     nz = np.zeros(n, bool); nz[1000:1064] = True; nz[2_000_000:2_000_064] = True
     assert np.all(got[~nz] == 0)
+
+
+def test_time_sliced_single_stream_equals_one_pipe(G, orc):
+    """one long stream cut into contiguous time slices, each processed by its own pipe
+    (its own GPU in production) after priming with the halo before the slice: bit-identical to one pipe."""
+    import torch
+    from cariboulite_amd import hip, shard, synth
+    t = load_golden("taps.npz")
+    n = 1_000_000
+    words = synth.torch_smi_words(n, G.DEV, 0, 9)
+    one = hip.RxPipe(1, 0, t["fir64_c2"], t["rs_3_2"], 3, 2, hip.PIPE_OUT_IQ)
+    n_out = one.out_count(n)
+    ref = torch.empty((n_out, 2), dtype=torch.float32, device=G.DEV)
+    assert one.run(hip.PIPE_IN_SMI_WORDS, words, 0, n, ref, 0) == n_out
+    for world in (2, 3, 8):
+        got = torch.zeros_like(ref)
+        scratch = torch.empty((1024, 2), dtype=torch.float32, device=G.DEV)
+        pos = 0
+        for (a, b) in shard.time_slices(n, world, 2):        # lcm(M = 2, 2)
+            p = hip.RxPipe(1, 0, t["fir64_c2"], t["rs_3_2"], 3, 2, hip.PIPE_OUT_IQ)
+            assert a * 3 % 2 == 0 and pos == a * 3 // 2
+            k = shard.run_time_slice(p, hip.PIPE_IN_SMI_WORDS, words, a, b, got[pos:], None, scratch)
+            pos += k
+        assert pos == n_out
+        torch.cuda.synchronize()
+        assert torch.equal(got, ref), world

@@ -116,3 +116,13 @@ def test_fanout_streams_gloo():
     full = (np.arange(5 * 4096, dtype=np.int64).reshape(5, 4096) * 7 + 3).astype(np.int32)
     for rank, rows, local in res:
         assert np.array_equal(local, full[rows])
+
+
+def test_time_slices_cover_the_stream():
+    from cariboulite_amd import shard
+    for n, world, align in ((1_000_000, 3, 2), (131072, 8, 4), (10, 4, 4), (7, 1, 2)):
+        sl = shard.time_slices(n, world, align)
+        assert len(sl) == world and sl[0][0] == 0 and sl[-1][1] == n
+        for (a, b), (c, d) in zip(sl, sl[1:]):
+            assert b == c and a <= b
+        assert all(a % align == 0 for a, _ in sl if a < n)
