@@ -23,9 +23,14 @@
 //       The tile's global loads are in flight while the scan runs.
 // Tiles travel through LDS (coalesced 16-byte global accesses on one side, one row of 64+4 dwords per
 // lane on the other: lane t reading 16 bytes of row t touches banks 4t..4t+3 -- conflict-free).
-// F, g, P^(2^d), Q and (Q^16)^(2^d) are built on the host in fp64 by simulating the cascade.
+// F, g, P^(2^d), P^i, Q^(2^d) and Q^i are built on the host in fp64 by simulating the cascade, once per filter
+// (iir_plan_for keeps them on the device in a buffer the shim owns).
 #include <math.h>
 #include <string.h>
+
+#include <mutex>
+#include <new>
+#include <vector>
 
 #include "clhip_common.h"
 
@@ -503,6 +508,45 @@ static void iir_plan_build(const double *sos, int n_stages, IirPlan *pl)
     for (int i = 1; i < IIR_GROUP; i++) mat_mul(dim, pl->qpow[i - 1], pl->Q, pl->qpow[i]);
 }
 
+// Transition tables per (device, filter): built once, uploaded once into a buffer the shim owns, kept for the life
+// of the process (a filter's tables are 175 KB; an SDR session uses a handful).  Nothing about a plan lives in the
+// caller's workspace, so a workspace freed and reallocated at the same address cannot resurrect a stale table.
+struct IirPlanEntry {
+    int device, n_stages;
+    double sos[5 * IIR_MAX_STAGES];
+    IirPlan host;                  // coef goes to K3 by value
+    IirPlan *dev;                  // device copy
+};
+
+static const IirPlanEntry *iir_plan_for(const double *sos, int n_stages)
+{
+    static std::mutex mu;
+    static std::vector<IirPlanEntry *> cache;
+    int device = 0;
+    (void)hipGetDevice(&device);
+    std::lock_guard<std::mutex> lock(mu);
+    for (const IirPlanEntry *e : cache)
+        if (e->device == device && e->n_stages == n_stages && !memcmp(e->sos, sos, sizeof(double) * 5 * n_stages)) return e;
+    if (cache.size() >= 256) {                  // pathological filter churn: start over once nothing is in flight
+        (void)hipDeviceSynchronize();
+        for (IirPlanEntry *e : cache) { clhip_free(e->dev); delete e; }
+        cache.clear();
+    }
+    IirPlanEntry *e = new (std::nothrow) IirPlanEntry();
+    if (!e) { clhip_set_error("clhip_iir_cs16: out of memory"); return nullptr; }
+    e->device = device; e->n_stages = n_stages;
+    memcpy(e->sos, sos, sizeof(double) * 5 * n_stages);
+    iir_plan_build(sos, n_stages, &e->host);
+    e->dev = (IirPlan *)clhip_malloc(sizeof(IirPlan));
+    if (!e->dev || hipMemcpy(e->dev, &e->host, sizeof(IirPlan), hipMemcpyHostToDevice) != hipSuccess) {
+        clhip_set_error("clhip_iir_cs16: cannot place the filter tables on the device");
+        clhip_free(e->dev); delete e;
+        return nullptr;
+    }
+    cache.push_back(e);
+    return e;
+}
+
 static size_t iir_var_bytes(size_t n_samples)
 {
     const size_t n_seg = clhip_div_up(n_samples, IIR_SEG), n_tiles = clhip_div_up(n_seg, IIR_TILE);
@@ -512,7 +556,7 @@ static size_t iir_var_bytes(size_t n_samples)
 extern "C" size_t clhip_iir_workspace_bytes(size_t n_samples, int n_stages)
 {
     (void)n_stages;
-    return sizeof(IirPlan) + 256 + iir_var_bytes(n_samples);
+    return 256 + iir_var_bytes(n_samples);
 }
 
 template <int NS>
@@ -546,31 +590,17 @@ extern "C" int clhip_iir_cs16_batch(const double *h_sos, int n_stages, double *d
         clhip_set_error("clhip_iir_cs16: bad arguments (1..%d biquads)", IIR_MAX_STAGES);
         return -1;
     }
-    const size_t need = sizeof(IirPlan) + 256 + iir_var_bytes(n_samples) * n_streams;
+    const size_t need = 256 + iir_var_bytes(n_samples) * n_streams;
     if (ws_bytes < need) {
         clhip_set_error("clhip_iir_cs16: workspace too small (%zu < %zu)", ws_bytes, need);
         return -1;
     }
     hipStream_t s = (hipStream_t)stream;
-    static thread_local IirPlan plan;        // stays valid until the async copy below has been enqueued+run
-    static thread_local double last_sos[5 * IIR_MAX_STAGES];
-    static thread_local int last_n = 0;
-    static thread_local void *last_ws = nullptr;
-    unsigned char *ws = (unsigned char *)d_ws;
-    IirPlan *d_plan = (IirPlan *)ws;
-    const bool changed = last_n != n_stages || memcmp(last_sos, h_sos, sizeof(double) * 5 * n_stages);
-    if (changed) {
-        iir_plan_build(h_sos, n_stages, &plan);
-        memcpy(last_sos, h_sos, sizeof(double) * 5 * n_stages);
-        last_n = n_stages;
-    }
-    if (changed || last_ws != d_ws) {
-        // tables live at the head of the workspace; re-sent only when the filter or the workspace changes
-        // (a pageable-source copy is staged by the runtime before the call returns)
-        CLHIP_CHECK(hipMemcpyAsync(d_plan, &plan, sizeof plan, hipMemcpyHostToDevice, s));
-        last_ws = d_ws;
-    }
-    double *wsv = (double *)(ws + ((sizeof(IirPlan) + 255) & ~(size_t)255));
+    const IirPlanEntry *pe = iir_plan_for(h_sos, n_stages);
+    if (!pe) return -1;
+    const IirPlan &plan = pe->host;
+    const IirPlan *d_plan = pe->dev;
+    double *wsv = (double *)d_ws;
     switch (n_stages) {
     case 1: iir_launch<1>(d_plan, plan.coef, d_state, (uint32_t *)d_iq, (long)stride_samples, (long)n_samples, n_streams, wsv, s); break;
     case 2: iir_launch<2>(d_plan, plan.coef, d_state, (uint32_t *)d_iq, (long)stride_samples, (long)n_samples, n_streams, wsv, s); break;
