@@ -187,10 +187,11 @@ __device__ __forceinline__ uint32_t tx_f2i16(float v)
 __device__ __forceinline__ uint32_t tx_pack_word(int mode, uint32_t ii, uint32_t qq)
 {
     if (mode == CL_TX_AS_WRITTEN) { ii = 0xFFFFu; qq = 0; }       // caribou_smi.c:700-701
-    ii &= 0x1FFFu; qq &= 0x1FFFu;
-    const uint32_t s = (0x7u << 29) | ((ii >> 8) << 24) | (((ii >> 1) & 0x7Fu) << 16) | ((ii & 1u) << 14) |
-                       ((qq >> 7) << 8) | (qq & 0x7Fu);
-    return __builtin_bswap32(s);
+    // caribou_smi.c:693-711 builds s = 111 | I12..I8 | 0 I7..I1 | 0 I0 Q12..Q7 | 0 Q6..Q0 MSB-first and byte-swaps it;
+    // the same word assembled directly in memory (little-endian) order, reading only the 13 low bits of ii / qq:
+    //   byte0 = 0xE0 | I12..I8   byte1 = I7..I1   byte2 = I0<<6 | Q12..Q7   byte3 = Q6..Q0
+    return 0xE0u | ((ii >> 8) & 0x1Fu) | ((ii << 7) & 0x7F00u) | ((ii & 1u) << 22) | ((qq << 9) & 0x3F0000u) |
+           ((qq << 24) & 0x7F000000u);
 }
 
 // pass 3 fused with the TX tail (config 5): per 1024-message block
