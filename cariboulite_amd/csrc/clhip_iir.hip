@@ -357,6 +357,27 @@ __global__ void iir_k2b_kernel(const IirPlan *__restrict__ plan, int n_streams, 
 
 // K3: true start state per segment, recursion, int16 in place; the lane owning the last segment also
 // writes the stream's new carried state.  FULL: every segment of the tile is complete.
+// two consecutive samples through the cascade, stage by stage: the state is written once per pair
+// ((v1, v2) <- (w_B, w_A)), so nothing is shifted between samples
+template <int NS>
+__device__ __forceinline__ void iir_step2(const IirCoef &c, double *z, double in0, double in1, double &out0, double &out1)
+{
+    double o0 = in0, o1 = in1;
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        const double z0 = z[2 * s], z1 = z[2 * s + 1];
+        const double ffa = __builtin_fma(c.b1[s], z0, c.b2[s] * z1);
+        const double wa = __builtin_fma(-c.a2[s], z1, __builtin_fma(-c.a1[s], z0, o0));
+        o0 = __builtin_fma(c.b0[s], wa, ffa);
+        const double ffb = __builtin_fma(c.b1[s], wa, c.b2[s] * z0);
+        const double wb = __builtin_fma(-c.a2[s], z0, __builtin_fma(-c.a1[s], wa, o1));
+        o1 = __builtin_fma(c.b0[s], wb, ffb);
+        z[2 * s] = wb;
+        z[2 * s + 1] = wa;
+    }
+    out0 = o0; out1 = o1;
+}
+
 template <int NS, bool FULL>
 __device__ __forceinline__ void iir_k3_segment(const IirCoef &c, uint32_t *x, long cnt, double *zi, double *zq)
 {
@@ -364,13 +385,24 @@ __device__ __forceinline__ void iir_k3_segment(const IirCoef &c, uint32_t *x, lo
     for (int k = 0; k < IIR_SEG; k += 4) {
         if (!FULL && k >= cnt) break;
         u32x4 w = *(const u32x4 *)(x + k);
+        if (FULL || k + 4 <= cnt) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            if (FULL || k + j < cnt) {
+            for (int j = 0; j < 4; j += 2) {
                 // filter((float)x): int16 -> float -> double is exact
-                const double yi = iir_step<NS>(c, zi, (double)(int16_t)(w[j] & 0xFFFF));
-                const double yq = iir_step<NS>(c, zq, (double)(int16_t)(w[j] >> 16));
-                w[j] = iir_to_i16(yi) | (iir_to_i16(yq) << 16);
+                double yi0, yi1, yq0, yq1;
+                iir_step2<NS>(c, zi, (double)(int16_t)(w[j] & 0xFFFF), (double)(int16_t)(w[j + 1] & 0xFFFF), yi0, yi1);
+                iir_step2<NS>(c, zq, (double)(int16_t)(w[j] >> 16), (double)(int16_t)(w[j + 1] >> 16), yq0, yq1);
+                w[j] = iir_to_i16(yi0) | (iir_to_i16(yq0) << 16);
+                w[j + 1] = iir_to_i16(yi1) | (iir_to_i16(yq1) << 16);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (k + j < cnt) {
+                    const double yi = iir_step<NS>(c, zi, (double)(int16_t)(w[j] & 0xFFFF));
+                    const double yq = iir_step<NS>(c, zq, (double)(int16_t)(w[j] >> 16));
+                    w[j] = iir_to_i16(yi) | (iir_to_i16(yq) << 16);
+                }
             }
         }
         *(u32x4 *)(x + k) = w;
