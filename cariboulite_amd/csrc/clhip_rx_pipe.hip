@@ -505,7 +505,8 @@ __device__ __forceinline__ void store_tile(unsigned char *lds, int t, unsigned c
         if (plain) {
 #pragma unroll
             for (int j = 0; j < NJ; j++)
-                if (HALF_PIECES % 64 == 0 || lane + 64 * j < HALF_PIECES) *(f32x4 *)(hb + j * 1024) = v[j];
+                if (HALF_PIECES % 64 == 0 || lane + 64 * j < HALF_PIECES)
+                    __builtin_nontemporal_store(v[j], (f32x4 *)(hb + j * 1024));     // streamed out, never read back here
         } else {
 #pragma unroll
             for (int j = 0; j < NJ; j++) {
