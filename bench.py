@@ -13,6 +13,9 @@ Infinity Cache).  Streams are independent, so N GPUs run N such streams with
 no data-path collective (weak scaling); the only collectives are the timing
 barrier and the max-over-ranks reduction.
 
+--workload c1|c3|c4|c5|iir times the other configs of BASELINE.json (and the a6 IIR) through the same contract;
+the default (c2) is the headline metric.
+
 One JSON line on rank 0.  `roofline` prices the fused kernel against HBM
 (16 algorithmic bytes per input sample: 4 read + 12 written); `cpu_baseline`
 is the oracle's fp32 CPU pipe (oracle/cl_oracle.c, "port") on this host's cores.
@@ -47,8 +50,10 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--settle", type=int, default=40, help="untimed steps before the warm-up (DVFS settle)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal on one GPU)")
-    ap.add_argument("--workload", default="c2", choices=["c2", "c4"],
-                    help="c2 (default, the BASELINE.json metric) | c4: 256 streams x 2^24, FIR128 + 5/4, sharded (strong scaling)")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c4", "c1", "c3", "c5", "iir"],
+                    help="c2 (default, the BASELINE.json metric) | c4: 256 streams x 2^24, FIR128 + 5/4, sharded (strong "
+                         "scaling) | c1 / c3 / c5 / iir: the other BASELINE.json configs and the a6 filter, one stream set "
+                         "per GPU (weak scaling), same JSON shape with their own algorithmic bytes")
     ap.add_argument("--fanout", action="store_true", help="c4 only: rank 0 holds all raw buffers and scatters them over xGMI first")
     return ap.parse_args()
 
@@ -140,6 +145,75 @@ def bench_c4(a, world, rank, dev, dist, red_dev, arch, taps):
         dist.destroy_process_group()
 
 
+def bench_secondary(a, world, rank, dev, dist, red_dev, arch, taps):
+    """The other configs of BASELINE.json (parity-test cases, not the headline metric) through the same timing
+    contract: one independent copy of the workload per GPU, no data-path collective."""
+    from cariboulite_amd import hip, synth, shard
+    stream = torch.cuda.current_stream().cuda_stream
+    if a.workload == "c1":
+        n = 1 << a.log2_samples
+        nch = max(n // NATIVE_CHUNK_SAMPLES, 1)
+        words = synth.torch_smi_words(n, dev, 0, rank)
+        offs = torch.zeros(nch, dtype=torch.int32, device=dev)
+        out = torch.empty((n, 2), dtype=torch.float32, device=dev)
+        def step():
+            hip.smi_find_offsets(words, 4 * n, 524288, 524288, nch, offs, stream)
+            hip.smi_unpack(0, words, 4 * n, 524288, 524288, nch, offs, hip.FORMAT_CF32, out, None, stream)
+        units, bytes_per, metric = n, 12.0, "Msamples/s through sync check + int13 unpack + /4096 (CF32 out)"
+        desc = f"config 1 on the GPU: one 2^{a.log2_samples}-sample SMI buffer, chunked sync check + unpack -> CF32"
+        kern = "smi_find_offsets_kernel + smi_unpack_kernel<CF32>"
+    elif a.workload == "c3":
+        n = 1 << (a.log2_samples - 1)
+        w2 = [synth.torch_smi_words(n, dev, ch, 2 * rank + ch) for ch in (0, 1)]
+        pipes = [hip.RxPipe(1, ch, taps["fir64_c3"], None, 1, 1, hip.PIPE_OUT_FM_DEMOD) for ch in (0, 1)]
+        outs = [torch.empty(n, dtype=torch.float32, device=dev) for _ in (0, 1)]
+        def step():
+            for ch in (0, 1):
+                pipes[ch].run(hip.PIPE_IN_SMI_WORDS, w2[ch], 0, n, outs[ch], 0, stream)
+        units, bytes_per, metric = 2 * n, 8.0, "Msamples/s through unpack+FIR(64)+FM demod, S1G + HiF"
+        desc = f"config 3: two channels (S1G, HiF) x 2^{a.log2_samples - 1} samples, FIR64 + phase-difference FM demod, fp32 out"
+        kern = "rx_pipe_fused_kernel<PipeCfg<64,1,1,1,MODE_FM,16,256,FFA>> x2"
+    elif a.workload == "c5":
+        n = 1 << (a.log2_samples - 1)
+        msg = torch.randn(n, device=dev) * 0.3
+        pipe = hip.TxPipe(1, 75e3, 4e6, taps["rs_2_3"], 2, 3, hip.TX_DOCUMENTED)
+        no = pipe.out_count(n) + 4
+        by = torch.empty(4 * no, dtype=torch.uint8, device=dev)
+        def step():
+            pipe.run(hip.TXPIPE_IN_FM_MESSAGE, msg, 0, n, by, 4 * no, None, 0, stream)
+        units, bytes_per, metric = n, 4.0 + 8.0 / 3.0, "Msamples/s through FM mod + 2/3 resample + int13 pack (TX)"
+        desc = f"config 5: 2^{a.log2_samples - 1} fp32 messages -> FM modulate -> 2/3 polyphase -> (int16)(f*4096) -> SMI TX words"
+        kern = "tx_fm_chain_kernel<TxCfg<2,3,8>>"
+    else:
+        n = 1 << (a.log2_samples - 2)
+        iq = torch.randint(-4096, 4096, (n, 2), dtype=torch.int16, device=dev)
+        from cariboulite_amd import soapy as S
+        f = hip.IIR(S.design_butter_lowpass(6, 4e6, 50e3))        # the reference's 100 kHz-bandwidth filter (fc = bw / 2)
+        def step():
+            f.run(iq, n, None, stream)
+        units, bytes_per, metric = n, 12.0, "Msamples/s through the Butterworth-6 IIR on CS16 (fp64, in place)"
+        desc = f"a6: 2^{a.log2_samples - 2} CS16 samples filtered in place, both rails, state carried"
+        kern = "iir_k1 + iir_k2a + iir_k2b + iir_k3"
+    for _ in range(a.settle + a.warmup):
+        step()
+    dt = shard.timed_steps(step, a.steps, sync_fn=torch.cuda.synchronize, dist=dist, device=red_dev)
+    if rank == 0:
+        value = world * units * a.steps / dt / 1e6
+        ach = bytes_per * units * a.steps / dt / 1e9
+        print(json.dumps({
+            "metric": metric, "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64" if a.workload == "iir" else "f32", "data": "synthetic",
+            "config": {"workload": desc, "arch": arch, "parallelism": f"{world} independent copy(ies), no data-path collective"},
+            "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s per GPU",
+                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "kernel": kern,
+                         "algorithmic_bytes_per_sample": round(bytes_per, 3),
+                         "note": "whole step (all launches of the workload), HIP-event free: wall clock of the timed region"}}),
+            flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -171,6 +245,8 @@ def main():
     taps = np.load(os.path.join(ROOT, "tests", "golden", "taps.npz"))
     if a.workload == "c4":
         return bench_c4(a, world, rank, dev, dist, red_dev, arch, taps)
+    if a.workload != "c2":
+        return bench_secondary(a, world, rank, dev, dist, red_dev, arch, taps)
 
     n = 1 << a.log2_samples
     n_chunks = n // NATIVE_CHUNK_SAMPLES
