@@ -8,16 +8,17 @@
 // The recursion is strictly sequential per rail; it is made parallel as a blocked
 // linear-recurrence scan over the cascade's D = 2*n_stages-dim state z:
 //     z[n] = F z[n-1] + g x[n]
-// A lane owns a SEG = 64-sample segment, a workgroup (2 waves) a tile of 128 segments.
+// A lane owns a SEG = 64-sample segment, a workgroup is ONE wave and owns a tile of 64 segments: no workgroup
+// barrier anywhere in K1 / K3, every scan over a tile is a shuffle scan.
 //   K1  zero-state end vector of every segment as a 64-tap "matrix FIR"
 //           zs = sum_k (F^(63-k) g) x[k]          (independent FMAs, taps by scalar loads)
-//       written out, then reduced over the tile: Kogge-Stone inside each wave by shuffles with P^(2^d),
-//       P = F^64, waves joined through LDS -> the tile's zero-carry end vector
-//   K2a groups of 256 tiles (one per lane) are scanned in parallel with Q^(2^d), Q = P^128 (Kogge-Stone
+//       written out, then reduced over the tile by a Kogge-Stone shuffle scan with P^(2^d), P = F^64
+//       -> the tile's zero-carry end vector
+//   K2a groups of 256 tiles (one per lane) are scanned in parallel with Q^(2^d), Q = P^64 (Kogge-Stone
 //       through LDS): X[tile] = state entering the tile if its group started from rest; group end vectors
-//   K2b one lane per stream chains the group ends with Q^256: gc[g] = state entering group g
-//       (32 steps for 2^26 samples); K3 rebuilds its tile carry as X[tile] + Q^i gc[g]
-//   K3  the same scan over u = zs (+ P * tile carry on the first lane) gives the state after every
+//   K2b one wave per stream scans the group ends with (Q^256)^(2^d): gc[g] = state entering group g;
+//       K3 rebuilds its tile carry as X[tile] + Q^i gc[g]
+//   K3  the same shuffle scan over u = zs (+ P * tile carry on the first lane) gives the state after every
 //       segment; shifted by one lane it is every lane's true start state.  The lane then runs the
 //       recursion over its segment and writes the truncated int16 outputs in place.
 //       The tile's global loads are in flight while the scan runs.
@@ -37,7 +38,7 @@
 #define IIR_MAX_STAGES 4
 #define IIR_MAX_DIM (2 * IIR_MAX_STAGES)
 #define IIR_SEG 64
-#define IIR_TILE 128
+#define IIR_TILE 64                        // one wave per workgroup: no workgroup barrier anywhere in K1 / K3
 #define IIR_K2_LANES 256
 #define IIR_GROUP 256                      // tiles per K2a workgroup
 #define IIR_MSZ (IIR_MAX_DIM * IIR_MAX_DIM) // matrices are stored 8x8, row-major, zero outside DxD
@@ -167,42 +168,18 @@ __device__ __forceinline__ void wave_scan(double (&v)[2 * D], const cdouble_t *_
     }
 }
 
-// tile_scan: the IIR_TILE = 128 lanes of a workgroup: wave_scan in both waves, then the second wave adds
-// P^(lane+1) times the first wave's total (ppow[i] = P^i, one matrix per lane).  `sh` = IIR_TILE rows of
-// 2D+1 doubles; on return sh[t] holds lane t's result.  LAST_ONLY: only lane IIR_TILE-1 needs to be right
-// (the tile total): its power is P^64 = pow2[6], no table.
+// tile_scan: a tile is one wave (IIR_TILE = 64): the shuffle scan is the whole scan.  `sh` = IIR_TILE rows of 2D+1
+// doubles; unless LAST_ONLY (only lane 63's value is wanted) sh[t] receives lane t's result for its neighbour.
 template <int D, bool LAST_ONLY>
-__device__ __forceinline__ void tile_scan(double (&v)[2 * D], const cdouble_t *__restrict__ pow2,
-                                          const double *__restrict__ ppow, double *sh, int t)
+__device__ __forceinline__ void tile_scan(double (&v)[2 * D], const cdouble_t *__restrict__ pow2, double *sh, int t)
 {
-    static_assert(IIR_TILE == 128, "two waves per tile");
+    static_assert(IIR_TILE == 64, "one wave per tile");
     constexpr int RS = 2 * D + 1;
-    wave_scan<D>(v, pow2, t & 63);
-    if (t == 63) {
-#pragma unroll
-        for (int k = 0; k < 2 * D; k++) sh[63 * RS + k] = v[k];
-    }
-    __syncthreads();
-    if (LAST_ONLY ? t == IIR_TILE - 1 : t >= 64) {
-        double s0[2 * D];
-#pragma unroll
-        for (int k = 0; k < 2 * D; k++) s0[k] = sh[63 * RS + k];
-        if (LAST_ONLY) {
-            const cdouble_t *m = pow2 + 6 * IIR_MSZ;
-            matvec<D, true>(m, s0, v);
-            matvec<D, true>(m, s0 + D, v + D);
-        } else {
-            const double *m = ppow + (long)(t - 63) * IIR_MSZ;       // P^(lane + 1)
-            matvec<D, true>(m, s0, v);
-            matvec<D, true>(m, s0 + D, v + D);
-        }
-    }
+    wave_scan<D>(v, pow2, t);
     if (!LAST_ONLY) {
-        if (t != 63) {
 #pragma unroll
-            for (int k = 0; k < 2 * D; k++) sh[t * RS + k] = v[k];
-        }
-        __syncthreads();
+        for (int k = 0; k < 2 * D; k++) sh[t * RS + k] = v[k];
+        __syncthreads();                     // single wave: orders the LDS writes before the neighbour's reads
     }
 }
 
@@ -233,9 +210,8 @@ struct IirPlan {
     IirCoef coef;
     double G[IIR_SEG][IIR_MAX_DIM];         // G[j] = F^j g
     double pow2[8][IIR_MSZ];                // P^(2^d), P = F^SEG
-    double ppow[IIR_SEG + 1][IIR_MSZ];      // P^i, i <= 64
     double Q[IIR_MSZ];                      // P^TILE
-    double qpow2[9][IIR_MSZ];               // Q^(2^d); [8] = Q^256 chains the groups
+    double qpow2[14][IIR_MSZ];              // Q^(2^d); [8 + d] = (Q^256)^(2^d) chains the groups
     double qpow[IIR_GROUP][IIR_MSZ];        // Q^i
 };
 
@@ -283,7 +259,7 @@ __global__ __launch_bounds__(IIR_TILE) void iir_k1_kernel(const IirPlan *__restr
         for (int k = 0; k < 2 * D; k++) o[k] = v[k];
     }
     __syncthreads();                         // the staged tile is dead: its LDS carries the scan exchange
-    tile_scan<D, true>(v, (const cdouble_t *)&plan->pow2[0][0], nullptr, (double *)iir_sm, t);
+    tile_scan<D, true>(v, (const cdouble_t *)&plan->pow2[0][0], (double *)iir_sm, t);
     if (t == IIR_TILE - 1) {
         double *o = tend + ((long)blockIdx.y * n_tiles + blockIdx.x) * 2 * D;
 #pragma unroll
@@ -323,40 +299,41 @@ __global__ __launch_bounds__(IIR_GROUP) void iir_k2a_kernel(const IirPlan *__res
     }
 }
 
-// K2b: gc[stream][group][2D] = state entering the group; one lane per stream
+// K2b: gc[stream][group][2D] = state entering the group.  One wave per stream: lane g holds the end vector of group
+// base + g (lane 0 also takes QG * carry-in), one shuffle scan with QG^(2^d), QG = Q^256, and the exclusive
+// shift is the answer; 64 groups (2^26 samples) per round.
 template <int NS>
-__global__ void iir_k2b_kernel(const IirPlan *__restrict__ plan, int n_streams, long n_groups,
-                               const double *__restrict__ gend, double *__restrict__ gc, const double *__restrict__ state)
+__global__ __launch_bounds__(64) void iir_k2b_kernel(const IirPlan *__restrict__ plan, long n_groups,
+                                                    const double *__restrict__ gend, double *__restrict__ gc,
+                                                    const double *__restrict__ state)
 {
     constexpr int D = 2 * NS;
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_streams) return;
-    const cdouble_t *__restrict__ QG = (const cdouble_t *)&plan->qpow2[8][0];
-    double c[2 * D];
-#pragma unroll
-    for (int k = 0; k < 2 * D; k++) c[k] = state[(long)s * 2 * IIR_MAX_DIM + (k / D) * IIR_MAX_DIM + (k % D)];
+    const int s = blockIdx.x, lane = threadIdx.x;
+    const cdouble_t *__restrict__ qg = (const cdouble_t *)&plan->qpow2[8][0];          // QG^(2^d) = qpow2[8 + d]
     const double *ge = gend + (long)s * n_groups * 2 * D;
     double *o = gc + (long)s * n_groups * 2 * D;
-    double nx[2 * D];
+    double carry[2 * D];
 #pragma unroll
-    for (int k = 0; k < 2 * D; k++) nx[k] = ge[k];
-    for (long g = 0; g < n_groups; g++) {
-        double nv[2 * D];
+    for (int k = 0; k < 2 * D; k++) carry[k] = state[(long)s * 2 * IIR_MAX_DIM + (k / D) * IIR_MAX_DIM + (k % D)];
+    for (long base = 0; base < n_groups; base += 64) {
+        const long g = base + lane;
+        double v[2 * D];
 #pragma unroll
-        for (int k = 0; k < 2 * D; k++) { o[g * 2 * D + k] = c[k]; nv[k] = nx[k]; }
-        if (g + 1 < n_groups) {
-#pragma unroll
-            for (int k = 0; k < 2 * D; k++) nx[k] = ge[(g + 1) * 2 * D + k];
+        for (int k = 0; k < 2 * D; k++) v[k] = g < n_groups ? ge[g * 2 * D + k] : 0.0;
+        if (lane == 0) {
+            matvec<D, true>(qg, carry, v);
+            matvec<D, true>(qg, carry + D, v + D);
         }
-        matvec<D, true>(QG, c, nv);
-        matvec<D, true>(QG, c + D, nv + D);
+        wave_scan<D>(v, qg, lane);
 #pragma unroll
-        for (int k = 0; k < 2 * D; k++) c[k] = nv[k];
+        for (int k = 0; k < 2 * D; k++) {
+            const double prev = __shfl_up(v[k], 1, 64);
+            if (g < n_groups) o[g * 2 * D + k] = lane == 0 ? carry[k] : prev;
+            carry[k] = __shfl(v[k], 63, 64);
+        }
     }
 }
 
-// K3: true start state per segment, recursion, int16 in place; the lane owning the last segment also
-// writes the stream's new carried state.  FULL: every segment of the tile is complete.
 // two consecutive samples through the cascade, stage by stage: the state is written once per pair
 // ((v1, v2) <- (w_B, w_A)), so nothing is shifted between samples
 template <int NS>
@@ -446,7 +423,7 @@ __global__ __launch_bounds__(IIR_TILE) void iir_k3_kernel(const IirPlan *__restr
         matvec<D, true>(pow2, cv + D, u + D);
     }
     double *sh = (double *)iir_sm;                           // the tile region is still empty
-    tile_scan<D, false>(u, pow2, &plan->ppow[0][0], sh, t);  // u = state after the lane's segment; sh[t] = the same
+    tile_scan<D, false>(u, pow2, sh, t);                     // u = state after the lane's segment; sh[t] = the same
     double zi[D], zq[D];
 #pragma unroll
     for (int k = 0; k < D; k++) {
@@ -529,13 +506,11 @@ static void iir_plan_build(const double *sos, int n_stages, IirPlan *pl)
     static_assert(IIR_SEG == 64, "P = F^SEG is built by six squarings");
     memcpy(pl->pow2[0], P, sizeof P);
     for (int d = 1; d < 8; d++) mat_mul(dim, pl->pow2[d - 1], pl->pow2[d - 1], pl->pow2[d]);
-    for (int r = 0; r < dim; r++) pl->ppow[0][r * IIR_MAX_DIM + r] = 1.0;
-    for (int i = 1; i <= 64; i++) mat_mul(dim, pl->ppow[i - 1], P, pl->ppow[i]);
-    static_assert(IIR_TILE == 128, "Q = P^TILE = P^(2^7)");
-    memcpy(pl->Q, pl->pow2[7], sizeof pl->Q);
+    static_assert(IIR_TILE == 64, "Q = P^TILE = P^(2^6)");
+    memcpy(pl->Q, pl->pow2[6], sizeof pl->Q);
     static_assert(IIR_GROUP == 256, "Q^GROUP = Q^(2^8)");
     memcpy(pl->qpow2[0], pl->Q, sizeof pl->Q);
-    for (int d = 1; d <= 8; d++) mat_mul(dim, pl->qpow2[d - 1], pl->qpow2[d - 1], pl->qpow2[d]);
+    for (int d = 1; d < 14; d++) mat_mul(dim, pl->qpow2[d - 1], pl->qpow2[d - 1], pl->qpow2[d]);
     for (int r = 0; r < dim; r++) pl->qpow[0][r * IIR_MAX_DIM + r] = 1.0;
     for (int i = 1; i < IIR_GROUP; i++) mat_mul(dim, pl->qpow[i - 1], pl->Q, pl->qpow[i]);
 }
@@ -606,8 +581,8 @@ static void iir_launch(const IirPlan *d_plan, const IirCoef &coef, double *d_sta
                        n_tiles, ZS, tend);
     hipLaunchKernelGGL(iir_k2a_kernel<NS>, dim3((unsigned)n_groups, n_streams), dim3(IIR_GROUP), 0, s, d_plan, n_tiles, n_groups,
                        (const double *)tend, X, gend);
-    hipLaunchKernelGGL(iir_k2b_kernel<NS>, dim3((unsigned)clhip_div_up((size_t)n_streams, 64)), dim3(64), 0, s, d_plan, n_streams,
-                       n_groups, (const double *)gend, gc, (const double *)d_state);
+    hipLaunchKernelGGL(iir_k2b_kernel<NS>, dim3((unsigned)n_streams), dim3(64), 0, s, d_plan, n_groups, (const double *)gend, gc,
+                       (const double *)d_state);
     hipLaunchKernelGGL(iir_k3_kernel<NS>, grid, block, IIR_LDS_WORDS * 4, s, d_plan, coef, d_iq, stride, n, n_seg, n_tiles,
                        n_groups, (const double *)ZS, (const double *)X, (const double *)gc, d_state);
 }

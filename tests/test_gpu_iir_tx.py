@@ -305,3 +305,22 @@ def test_tx_pipe_long_message_lookback(G, orc):
     got = np.concatenate(got)
     assert got.shape == want.shape
     assert np.max(np.abs(got - want)) <= TOL * np.max(np.abs(want))
+
+
+def test_iir_second_round_of_tile_groups(G, orc):
+    """71 M samples = 68 tile groups: K2b's group scan takes a second 64-group round.  Bit-for-bit check of the int16
+    outputs against the sequential fp64 oracle (about 10 s of host time)."""
+    import torch
+    from cariboulite_amd import hip
+    n = (1 << 26) + (1 << 22) + 12345
+    x = np.random.default_rng(3).integers(-4096, 4096, size=(n, 2), dtype=np.int16)
+    ref = orc.IIR(6, 4e6, 25e3)
+    want = ref.apply_cs16(x.copy())
+    f = hip.IIR(_sos5(orc.IIR(6, 4e6, 25e3)))
+    d = torch.from_numpy(x).to(G.DEV)
+    f.run(d, n)
+    got = d.cpu().numpy()
+    del d
+    diff = np.abs(got[-(1 << 23):].astype(np.int32) - want[-(1 << 23):].astype(np.int32))      # the part behind group 64
+    assert diff.max() <= 1 and np.mean(diff != 0) < 1e-4
+    assert np.mean(got[: 1 << 23] != want[: 1 << 23]) < 1e-4
