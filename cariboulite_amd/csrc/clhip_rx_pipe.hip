@@ -857,6 +857,12 @@ typedef PipeCfg<64, 1, 1, 1, MODE_FM, 16, 256, true> CfgC3f;
 typedef PipeCfg<128, 5, 4, 8, MODE_IQ, 16, 256, true> CfgC4f;
 typedef PipeCfg<64, 1, 1, 1, MODE_IQ, 16, 256, true> CfgF64f;
 typedef PipeCfg<128, 1, 1, 1, MODE_IQ, 16, 256, true> CfgF128f;
+typedef PipeCfg<64, 1, 2, 8, MODE_IQ, 16, 256> CfgD2;      // decimators after FIR64: 1/2, 1/4, 3/4 (8 taps per phase)
+typedef PipeCfg<64, 1, 2, 8, MODE_IQ, 16, 256, true> CfgD2f;
+typedef PipeCfg<64, 1, 4, 8, MODE_IQ, 16, 256> CfgD4;
+typedef PipeCfg<64, 1, 4, 8, MODE_IQ, 16, 256, true> CfgD4f;
+typedef PipeCfg<64, 3, 4, 8, MODE_IQ, 16, 256> CfgD34;
+typedef PipeCfg<64, 3, 4, 8, MODE_IQ, 16, 256, true> CfgD34f;
 typedef PipeCfg<64, 1, 1, 1, MODE_IQ, 16, 256> CfgF64;    // FIR64 only
 typedef PipeCfg<128, 1, 1, 1, MODE_IQ, 16, 256> CfgF128;  // FIR128 only
 
@@ -890,6 +896,9 @@ static int fused_lookup(int T, int L, int M, int n_rs, int mode, int *halo)
     if (mode == CL_PIPE_OUT_IQ && T == 128 && L == 5 && M == 4 && n_rs == 40) { *halo = CfgC4::HALO; return 2; }
     if (mode == CL_PIPE_OUT_IQ && T == 64 && !rs) { *halo = CfgF64::HALO; return 3; }
     if (mode == CL_PIPE_OUT_IQ && T == 128 && !rs) { *halo = CfgF128::HALO; return 4; }
+    if (mode == CL_PIPE_OUT_IQ && T == 64 && L == 1 && M == 2 && n_rs == 8) { *halo = CfgD2::HALO; return 5; }
+    if (mode == CL_PIPE_OUT_IQ && T == 64 && L == 1 && M == 4 && n_rs == 8) { *halo = CfgD4::HALO; return 6; }
+    if (mode == CL_PIPE_OUT_IQ && T == 64 && L == 3 && M == 4 && n_rs == 24) { *halo = CfgD34::HALO; return 7; }
     return -1;
 }
 
@@ -1137,6 +1146,9 @@ extern "C" long clhip_rx_pipe_run(clhip_rx_pipe *p, int in_kind, const void *d_i
         case 2: rc = ffa ? launch_fused<CfgC4f>(a, s) : launch_fused<CfgC4>(a, s); break;
         case 3: rc = ffa ? launch_fused<CfgF64f>(a, s) : launch_fused<CfgF64>(a, s); break;
         case 4: rc = ffa ? launch_fused<CfgF128f>(a, s) : launch_fused<CfgF128>(a, s); break;
+        case 5: rc = ffa ? launch_fused<CfgD2f>(a, s) : launch_fused<CfgD2>(a, s); break;
+        case 6: rc = ffa ? launch_fused<CfgD4f>(a, s) : launch_fused<CfgD4>(a, s); break;
+        case 7: rc = ffa ? launch_fused<CfgD34f>(a, s) : launch_fused<CfgD34>(a, s); break;
         }
         if (rc) return -1;
     } else {

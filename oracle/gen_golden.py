@@ -250,7 +250,7 @@ def design_taps():
     t["fir64_c2"] = sg.firwin(64, 1.0e6, window="hamming", fs=4e6)
     t["fir64_c3"] = sg.firwin(64, 100e3, window="hamming", fs=4e6)
     t["fir128_c4"] = sg.firwin(128, 1.2e6, window="hamming", fs=4e6)
-    for L, M in ((3, 2), (5, 4), (2, 3)):
+    for L, M in ((3, 2), (5, 4), (2, 3), (1, 2), (1, 4), (3, 4)):     # the last three: decimating shapes of the fused pipe
         t[f"rs_{L}_{M}"] = L * sg.firwin(8 * L, 1.0 / max(L, M), window="hamming")
     return {k: v.astype(np.float32) for k, v in t.items()}, t
 

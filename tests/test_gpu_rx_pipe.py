@@ -25,6 +25,9 @@ CONFIGS = {
     "c4": dict(fir="fir128_c4", rs="rs_5_4", L=5, M=4, mode=0),
     "f64": dict(fir="fir64_c2", rs=None, L=1, M=1, mode=0),
     "f128": dict(fir="fir128_c4", rs=None, L=1, M=1, mode=0),
+    "d2": dict(fir="fir64_c2", rs="rs_1_2", L=1, M=2, mode=0),       # decimating shapes
+    "d4": dict(fir="fir64_c2", rs="rs_1_4", L=1, M=4, mode=0),
+    "d34": dict(fir="fir64_c2", rs="rs_3_4", L=3, M=4, mode=0),
 }
 
 
@@ -154,7 +157,7 @@ def test_fused_vs_generic_second_implementation(G, orc, cfg, monkeypatch):
         assert np.max(np.abs(a - g)) <= 2e-6 * np.max(np.abs(g))
 
 
-@pytest.mark.parametrize("cfg", ["c2", "c3", "c4"])
+@pytest.mark.parametrize("cfg", ["c2", "c3", "c4", "d2", "d4", "d34"])
 def test_streaming_chunks_equal_one_shot(G, orc, cfg):
     """History carried across calls: chunked == one big call (SURVEY.md section 5 checkpoint row)."""
     from cariboulite_amd import hip, synth
