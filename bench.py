@@ -191,7 +191,7 @@ def bench_secondary(a, world, rank, dev, dist, red_dev, arch, taps):
         f = hip.IIR(S.design_butter_lowpass(6, 4e6, 50e3))        # the reference's 100 kHz-bandwidth filter (fc = bw / 2)
         def step():
             f.run(iq, n, None, stream)
-        units, bytes_per, metric = n, 12.0, "Msamples/s through the Butterworth-6 IIR on CS16 (fp64, in place)"
+        units, bytes_per, metric = n, 8.0, "Msamples/s through the Butterworth-6 IIR on CS16 (fp64, in place)"   # in place: R 4 + W 4
         desc = f"a6: 2^{a.log2_samples - 2} CS16 samples filtered in place, both rails, state carried"
         kern = "iir_k1 + iir_k2a + iir_k2b + iir_k3"
     for _ in range(a.settle + a.warmup):
@@ -321,7 +321,10 @@ def main():
                        "samples_per_gpu_per_step": n, "fir_taps": 64, "resample": "3/2", "arch": arch,
                        "parallelism": f"{world} independent stream(s), no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         # the same algorithmic bytes priced on the WALL step (sync search + launch + gaps), the clock `value` uses
+                         "frac_on_step_clock": round(ALGO_BYTES_PER_SAMPLE * n / (dt / a.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                         "traffic": traffic, "traffic_unit": "HBM bytes per launch",
                          "traffic_source": traffic_src,
                          "kernel": "rx_pipe_fused_kernel<PipeCfg<64,3,2,8,MODE_IQ,16,256,FFA>, SMI_WORDS, S1G>",
                          "kernel_ms_avg": round(kern_avg_s * 1e3, 4), "kernel_ms_min": round(float(np.min(kern_ms)), 4),

@@ -597,6 +597,7 @@ struct TxLookBack {
     unsigned int *ticket;            // monotonically increasing across launches
     unsigned int ticket_base, epoch; // epoch in 1 .. 16383
     int *err;
+    int poll_bound;                  // polls of one predecessor word before giving up
 };
 #define TXLB_MASK 0xFFFFFFFFFFFFull
 __device__ __forceinline__ unsigned long long txlb_fix(double turns)
@@ -670,7 +671,7 @@ __global__ __launch_bounds__(TXQ_NT, 2) void tx_fm_chain_kernel(
             if (j >= 0) {
                 do {
                     w = __hip_atomic_load(st + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (++guard > (1 << 22)) { *lb.err = 1; w = (2ull << 62) | e; }
+                    if (++guard > lb.poll_bound) { *lb.err = 1; w = (2ull << 62) | e; }
                 } while (((w >> 48) & 0x3FFF) != lb.epoch || (w >> 62) == 0);
             }
             const unsigned long long have = __ballot((w >> 62) >= 2);
@@ -773,7 +774,10 @@ struct clhip_tx_pipe {
     float rs[TX_MAX_RS];
     float *d_rs;
     f32x2 *hist[2]; int cur;         // [n_streams][kp-1] modulated samples preceding the call
-    double *d_phase;                 // [n_streams]
+    double *d_phase2; int pcur;      // [2][n_streams] ping-pong: the single-launch path writes the other half directly
+    double *d_phase;                 // = d_phase2 + pcur * n_streams: the current phase of every stream
+    unsigned long long undo_n_total; int undo_cur, undo_pcur; bool can_undo;   // pre-call state of the last run
+    int poll_bound;                  // look-back poll bound (diagnostic knob, default 2^22)
     unsigned long long n_total;
     f32x2 *Y; size_t y_cap;          // modulated signal workspace (per stream)
     double *ws; size_t ws_cap;
@@ -848,7 +852,9 @@ extern "C" clhip_tx_pipe *clhip_tx_pipe_create(int n_streams, double fm_kf_hz, d
     p->kp = (p->n_rs + up - 1) / up;
     const int H = p->kp - 1 > 0 ? p->kp - 1 : 1;
     p->d_rs = (float *)clhip_malloc(sizeof p->rs);
-    p->d_phase = (double *)clhip_malloc(sizeof(double) * n_streams);
+    p->d_phase2 = (double *)clhip_malloc(sizeof(double) * 2 * n_streams);
+    p->d_phase = p->d_phase2; p->pcur = 0;
+    p->poll_bound = getenv("CLHIP_TX_POLL_BOUND") ? atoi(getenv("CLHIP_TX_POLL_BOUND")) : 1 << 22;   // diagnostic knob
     for (int i = 0; i < 2; i++) p->hist[i] = (f32x2 *)clhip_malloc(sizeof(f32x2) * H * n_streams);
     if (!p->d_rs || !p->d_phase || !p->hist[0] || !p->hist[1]) { clhip_tx_pipe_destroy(p); return nullptr; }
     (void)hipMemcpy(p->d_rs, p->rs, sizeof p->rs, hipMemcpyHostToDevice);
@@ -859,7 +865,7 @@ extern "C" clhip_tx_pipe *clhip_tx_pipe_create(int n_streams, double fm_kf_hz, d
 extern "C" void clhip_tx_pipe_destroy(clhip_tx_pipe *p)
 {
     if (!p) return;
-    clhip_free(p->d_rs); clhip_free(p->d_phase); clhip_free(p->hist[0]); clhip_free(p->hist[1]);
+    clhip_free(p->d_rs); clhip_free(p->d_phase2); clhip_free(p->hist[0]); clhip_free(p->hist[1]);
     clhip_free(p->Y); clhip_free(p->ws);
     clhip_free(p->lb_st); clhip_free(p->lb_ticket);
     if (p->lb_err) (void)hipHostFree(p->lb_err);
@@ -869,11 +875,33 @@ extern "C" void clhip_tx_pipe_destroy(clhip_tx_pipe *p)
 extern "C" void clhip_tx_pipe_reset(clhip_tx_pipe *p)
 {
     const int H = p->kp - 1 > 0 ? p->kp - 1 : 1;
-    (void)hipMemset(p->d_phase, 0, sizeof(double) * p->n_streams);
+    (void)hipMemset(p->d_phase2, 0, sizeof(double) * 2 * p->n_streams);
+    p->pcur = 0; p->d_phase = p->d_phase2; p->can_undo = false;
+    if (p->lb_err) *p->lb_err = 0;
     (void)hipMemset(p->hist[0], 0, sizeof(f32x2) * H * p->n_streams);
     (void)hipMemset(p->hist[1], 0, sizeof(f32x2) * H * p->n_streams);
     p->cur = 0; p->n_total = 0;
 }
+
+// After the caller has synchronised the stream of the last clhip_tx_pipe_run: 0 = its output is valid.  -1 = the
+// look-back guard fired (a workgroup gave up waiting for a predecessor's phase and carried on with a made-up one):
+// the bytes of that call must not be used; the pipe is put back to its pre-call state (phase, resampler history,
+// polyphase phase are ping-pong / host state the failed launch did not overwrite), so the call can be repeated.
+extern "C" int clhip_tx_pipe_status(clhip_tx_pipe *p)
+{
+    if (!p) return -1;
+    if (!p->lb_err || !*(volatile int *)p->lb_err) return 0;
+    *p->lb_err = 0;
+    if (p->can_undo) {
+        p->cur = p->undo_cur; p->pcur = p->undo_pcur; p->n_total = p->undo_n_total;
+        p->d_phase = p->d_phase2 + (size_t)p->pcur * p->n_streams;
+        p->can_undo = false;
+    }
+    clhip_set_error("clhip_tx_pipe_status: look-back poll overran; the output of the last call is invalid, pipe state restored");
+    return -1;
+}
+
+extern "C" void clhip_tx_pipe_set_poll_bound(clhip_tx_pipe *p, int polls) { if (p) p->poll_bound = polls < 0 ? (1 << 22) : polls; }
 
 extern "C" size_t clhip_tx_pipe_out_count(const clhip_tx_pipe *p, size_t n_in)
 {
@@ -897,6 +925,7 @@ extern "C" long clhip_tx_pipe_run(clhip_tx_pipe *p, int in_kind, const void *d_i
     hipStream_t s = (hipStream_t)stream;
     const size_t n_out = clhip_tx_pipe_out_count(p, n_in);
     const int H = p->kp - 1;
+    p->undo_n_total = p->n_total; p->undo_cur = p->cur; p->undo_pcur = p->pcur; p->can_undo = true;
     const f32x2 *x = (const f32x2 *)d_in;
     long x_stride = (long)in_stride;
     static const int tx_fast = getenv("CLHIP_TX_FAST") ? atoi(getenv("CLHIP_TX_FAST")) : 1;
@@ -943,23 +972,27 @@ extern "C" long clhip_tx_pipe_run(clhip_tx_pipe *p, int in_kind, const void *d_i
                 p->epoch = 1;
                 CLHIP_CHECK(hipMemsetAsync(p->lb_st, 0, sizeof(unsigned long long) * p->lb_cap, s));
             }
-            static const int use_ticket = getenv("CLHIP_TX_TICKET") ? atoi(getenv("CLHIP_TX_TICKET")) : 0;
-            if (*(volatile int *)p->lb_err) {                       // raised by an earlier launch of this pipe
-                clhip_set_error("clhip_tx_pipe_run: a look-back poll overran in an earlier call; output of that call is invalid "
-                                "(set CLHIP_TX_CHAIN=0 for the three-pass path)");
+            // Forward progress: with a ticket every superblock before ours belongs to a workgroup that is already
+            // running and waits only for ITS predecessors, so the look-back always ends.  CLHIP_TX_TICKET=0 orders by
+            // blockIdx instead (workgroups are dispatched in index order on this hardware, not by contract).
+            static const int use_ticket = getenv("CLHIP_TX_TICKET") ? atoi(getenv("CLHIP_TX_TICKET")) : 1;
+            if (*(volatile int *)p->lb_err) {                       // raised by an earlier launch nobody asked about
+                clhip_set_error("clhip_tx_pipe_run: a look-back poll overran in an earlier call and clhip_tx_pipe_status() "
+                                "was not consulted; output of that call is invalid");
                 *p->lb_err = 0;
+                p->can_undo = false;
                 return -1;
             }
-            TxLookBack lb = {p->lb_st, use_ticket ? p->lb_ticket : nullptr, p->ticket_total, p->epoch, p->lb_err_dev};
+            TxLookBack lb = {p->lb_st, use_ticket ? p->lb_ticket : nullptr, p->ticket_total, p->epoch, p->lb_err_dev, p->poll_bound};
             const unsigned n_wg = (unsigned)(n_super * p->n_streams);
-            double *phase_new = p->ws;                             // scratch: d_phase is read by late workgroups
+            double *phase_new = p->d_phase2 + (size_t)(p->pcur ^ 1) * p->n_streams;   // the other half: late workgroups still read d_phase
             hipLaunchKernelGGL(tx_fm_chain_kernel<C>, dim3(n_wg), dim3(TXQ_NT), 0, s, (const float *)d_in, (long)in_stride, nv, phi,
                                skip, wt, lb, n_super, p->n_streams, (const double *)p->d_phase, phase_new, p->hist[p->cur],
                                p->hist[p->cur ^ 1], p->d_rs, (long)n_out, p->pack_mode, (uint32_t *)d_bytes,
                                (long)(out_stride_bytes / 4), (f32x2 *)d_iq_tap, (long)iq_tap_stride);
             p->ticket_total += n_wg;
-            CLHIP_CHECK(hipMemcpyAsync(p->d_phase, phase_new, sizeof(double) * p->n_streams, hipMemcpyDeviceToDevice, s));
             CLHIP_CHECK_LAUNCH();
+            p->pcur ^= 1; p->d_phase = phase_new;
             p->cur ^= 1;
             p->n_total += n_in;
             return (long)n_out;

@@ -485,6 +485,9 @@ int cl_writeStream(cl_device *dev, cl_stream *st, const void *const *buffs, size
             return 0;
     }
     if (n_packed && (clhip_memcpy_d2h(smi->h_stage, smi->d_bytes, 4 * n_packed, smi->stream) || clhip_stream_sync(smi->stream))) return 0;
+    /* the modulator's verdict on this very call: invalid words never reach the fd (squashed to 0 like every
+     * write error, CaribouliteStream.cpp:185-194); the pipe is back where it was, the client may write again */
+    if (st->tx_pipe && clhip_tx_pipe_status(st->tx_pipe)) { cl_seterr(dev->err, sizeof dev->err, "writeStream: %s", clhip_last_error()); return 0; }
     /* caribou_smi_write's chunk loop (caribou_smi.c:738-759) over the packed bytes */
     size_t left = 4 * n_packed, done = 0;
     while (left) {

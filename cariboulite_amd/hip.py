@@ -63,12 +63,17 @@ _SIGS = {
     "clhip_rx_pipe_force_generic": (None, [C.c_void_p, C.c_int]),
     "clhip_rx_pipe_set_diag": (None, [C.c_void_p, C.c_void_p]),
     "clhip_rx_pipe_set_sync_check": (None, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "clhip_rx_pipe_rollback": (C.c_int, [C.c_void_p]),
+    "clhip_rx_pipe_run_smi": (C.c_long, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "clhip_tx_pipe_create": (C.c_void_p, [C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "clhip_tx_pipe_destroy": (None, [C.c_void_p]),
     "clhip_tx_pipe_reset": (None, [C.c_void_p]),
     "clhip_tx_pipe_out_count": (C.c_size_t, [C.c_void_p, C.c_size_t]),
     "clhip_tx_pipe_run": (C.c_long, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
                                      C.c_void_p, C.c_size_t, C.c_void_p]),
+    "clhip_tx_pipe_status": (C.c_int, [C.c_void_p]),
+    "clhip_tx_pipe_set_poll_bound": (None, [C.c_void_p, C.c_int]),
     "clhip_fm_demod": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "clhip_fm_mod": (C.c_int, [C.c_void_p, C.c_size_t, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "clhip_fm_mod_workspace_bytes": (C.c_size_t, [C.c_size_t]),
@@ -207,6 +212,19 @@ class RxPipe:
                                               stream if stream is not None else current_stream()),
                       "clhip_rx_pipe_run")
 
+    def rollback(self):
+        return lib().clhip_rx_pipe_rollback(self.h)
+
+    def run_smi(self, d_bytes, stream_stride_bytes, n_bytes, chunk_len_bytes, d_offs, d_cs16, d_out, out_stride,
+                h_offs=None, stream=None):
+        """caribou_smi_read-shaped call; returns outputs per stream or CL_SMI_ERR_SYNC (-3) (other errors raise)."""
+        rc = lib().clhip_rx_pipe_run_smi(self.h, ptr(d_bytes), stream_stride_bytes, n_bytes, chunk_len_bytes, ptr(d_offs),
+                                         h_offs.ctypes.data if h_offs is not None else None, ptr(d_cs16), ptr(d_out),
+                                         out_stride, stream if stream is not None else current_stream())
+        if rc < 0 and rc != -3:
+            raise RuntimeError("clhip_rx_pipe_run_smi failed: " + last_error())
+        return rc
+
 
 class IIR:
     """clhip_iir_cs16: in-place fp64 biquad cascade on CS16 streams (state carried on device)."""
@@ -255,6 +273,13 @@ class TxPipe:
 
     def out_count(self, n_in):
         return lib().clhip_tx_pipe_out_count(self.h, n_in)
+
+    def status(self):
+        """0 = the last run's bytes are valid (ask after synchronising its stream), -1 = look-back overrun."""
+        return lib().clhip_tx_pipe_status(self.h)
+
+    def set_poll_bound(self, polls):
+        lib().clhip_tx_pipe_set_poll_bound(self.h, polls)
 
     def run(self, in_kind, d_in, in_stride, n_in, d_bytes, out_stride_bytes, d_tap=None, tap_stride=0, stream=None):
         return _check(lib().clhip_tx_pipe_run(self.h, in_kind, ptr(d_in), in_stride, n_in, ptr(d_bytes),

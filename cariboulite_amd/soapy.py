@@ -236,6 +236,9 @@ class Device:
             raise RuntimeError(lib().cl_device_last_error(self.h).decode())     # std::runtime_error in the reference
         return st
 
+    def lastError(self):
+        return lib().cl_device_last_error(self.h).decode()
+
     def closeStream(self, st):
         lib().cl_closeStream(self.h, st)
 

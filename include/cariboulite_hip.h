@@ -208,10 +208,29 @@ void   clhip_rx_pipe_force_generic(clhip_rx_pipe *p, int on);
 /* Device-side sync validation for CL_PIPE_IN_SMI_WORDS runs: d_offs holds the
  * per-chunk results of clhip_smi_find_offsets ([n_streams][ceil(n_in/chunk_samples)]).
  * A tile that needs a chunk with offs != 0 writes nothing and sets *d_bad_flag = 1;
- * the caller then re-runs that call through clhip_smi_unpack + CL_PIPE_IN_CS16.
- * Pass NULL to disable. */
+ * the caller then synchronises, calls clhip_rx_pipe_rollback() and re-runs that call through
+ * clhip_smi_unpack + CL_PIPE_IN_CS16 (clhip_rx_pipe_run_smi does all of this).  Pass NULL to disable. */
 void   clhip_rx_pipe_set_sync_check(clhip_rx_pipe *p, const int32_t *d_offs, size_t chunk_samples,
                                     int32_t *d_bad_flag);
+/* Undo the most recent clhip_rx_pipe_run (one level): history and polyphase phase are again what they were
+ * before that call -- a run never overwrites the history it read.  The stream of that run must have been
+ * synchronised.  0, or -1 when there is no run to undo (fresh / reset / seeked pipe, or already undone). */
+int    clhip_rx_pipe_rollback(clhip_rx_pipe *p);
+/*
+ * One caribou_smi_read-shaped call (caribou_smi/caribou_smi.c:632-682) feeding the pipe, with the bytes of the
+ * call resident on the device: stream s at d_bytes + s*stream_stride_bytes, n_bytes each, analysed in chunks
+ * of chunk_len_bytes exactly like the reference's native batches.
+ *   every chunk in sync  -> per-chunk sync search + ONE fused launch from the raw words, verdict checked on the device;
+ *   a chunk with offs > 0 -> the raw-word run is rolled back and the call is redone with the reference's re-sync
+ *                           semantics (:319-325,382-389: skipped bytes, one extrapolated sample, untouched slots)
+ *                           through clhip_smi_unpack into d_cs16 ([n_streams][n_bytes/4 + 2] int16 pairs; it stands
+ *                           where the Stream's interm_native_buffer stands, so "untouched" slots keep what it held);
+ *   a chunk without sync -> CL_SMI_ERR_SYNC (:665-668) and the pipe keeps its pre-call state.
+ * d_offs: [n_streams][ceil(n_bytes/chunk_len_bytes)] device scratch, holds the search results afterwards; h_offs
+ * (optional, host) receives a copy.  Synchronises `stream`.  Returns outputs per stream, or a negative error. */
+long   clhip_rx_pipe_run_smi(clhip_rx_pipe *p, const uint8_t *d_bytes, size_t stream_stride_bytes, size_t n_bytes,
+                             size_t chunk_len_bytes, int32_t *d_offs, int32_t *h_offs, int16_t *d_cs16,
+                             void *d_out, size_t out_stride_elems, void *stream);
 
 /*
  * The TX pipe: fp32 message -> FM modulate (fp64 phase) -> L/M resample ->
@@ -230,6 +249,14 @@ size_t clhip_tx_pipe_out_count(const clhip_tx_pipe *p, size_t n_in);
 long   clhip_tx_pipe_run(clhip_tx_pipe *p, int in_kind, const void *d_in, size_t in_stride_elems,
                          size_t n_in, uint8_t *d_bytes, size_t out_stride_bytes,
                          float *d_iq_tap, size_t iq_tap_stride, void *stream);
+/* Verdict on the LAST clhip_tx_pipe_run, to be asked after synchronising its stream and before the bytes are
+ * handed on (cl_writeStream does: nothing reaches the TX FIFO otherwise, caribou_smi.c:738-759).  0 = valid.
+ * -1 = the single-launch FM path's bounded look-back gave up on a predecessor: the bytes are invalid and the pipe
+ * is back in its pre-call state, so the same call can be repeated.  With the default ticket ordering every
+ * predecessor is already running and the bound (2^22 polls) is never reached. */
+int    clhip_tx_pipe_status(clhip_tx_pipe *p);
+/* diagnostic knob: polls of a predecessor before the look-back gives up (tests force the failure with 0); < 0 = default */
+void   clhip_tx_pipe_set_poll_bound(clhip_tx_pipe *p, int polls);
 
 /* standalone FM / CW stages on device buffers */
 int clhip_fm_demod(const float *d_iq, size_t n, float *d_prev_iq /*2 floats, in/out*/, float *d_out, void *stream);

@@ -307,6 +307,39 @@ def test_tx_pipe_long_message_lookback(G, orc):
     assert np.max(np.abs(got - want)) <= TOL * np.max(np.abs(want))
 
 
+def test_tx_lookback_overrun_is_reported_by_the_same_call(G, orc):
+    """The look-back's bounded poll: forced to give up (poll bound 0), the call's verdict is -1 right after its own
+    stream sync, the pipe is back in its pre-call state, and repeating the call gives a fresh pipe's bytes."""
+    import torch
+    from cariboulite_amd import hip
+    t = load_golden("taps.npz")
+    rng = np.random.default_rng(9)
+    n0, n = 30_000, 60_000                                      # 3 and 5 superblocks of 12288 messages
+    msg = (0.4 * rng.standard_normal(n0 + n)).astype(np.float32)
+    d = torch.from_numpy(msg).to(G.DEV)
+
+    def run(pipe, lo, cn):
+        k = pipe.out_count(cn)
+        by = torch.zeros(4 * k, dtype=torch.uint8, device=G.DEV)
+        assert pipe.run(hip.TXPIPE_IN_FM_MESSAGE, d[lo:], 0, cn, by, 4 * k) == k
+        torch.cuda.synchronize()
+        return by.cpu().numpy()
+
+    good = hip.TxPipe(1, 75e3, 4e6, t["rs_2_3"], 2, 3, hip.TX_DOCUMENTED)
+    w0 = run(good, 0, n0); assert good.status() == 0
+    w1 = run(good, n0, n); assert good.status() == 0
+    p = hip.TxPipe(1, 75e3, 4e6, t["rs_2_3"], 2, 3, hip.TX_DOCUMENTED)
+    assert np.array_equal(run(p, 0, n0), w0) and p.status() == 0
+    before = p.out_count(n)
+    p.set_poll_bound(0)
+    run(p, n0, n)
+    assert p.status() == -1 and "look-back" in hip.last_error()
+    assert p.status() == 0                                      # reported once
+    assert p.out_count(n) == before                             # polyphase phase restored
+    p.set_poll_bound(-1)
+    assert np.array_equal(run(p, n0, n), w1) and p.status() == 0   # FM phase and resampler history restored
+
+
 def test_iir_second_round_of_tile_groups(G, orc):
     """71 M samples = 68 tile groups: K2b's group scan takes a second 64-group round.  Bit-for-bit check of the int16
     outputs against the sequential fp64 oracle (about 10 s of host time)."""

@@ -233,6 +233,38 @@ def test_multi_stream_and_input_kinds(G, orc):
     assert np.max(np.abs(b - single[0])) <= 1e-6 * np.max(np.abs(single[0]))
 
 
+@pytest.mark.parametrize("channel", [0, 1])
+def test_c4_share_of_one_gpu_32_streams(G, orc, channel):
+    """Config 4 as a workload: the 32 streams one GPU owns (256 streams / 8 GPUs), FIR128 + 5/4, ONE pipe and one
+    launch per call, ragged tail, two calls (carried history) -- every stream against the fp64 oracle."""
+    import torch
+    from cariboulite_amd import hip, synth
+    t = load_golden("taps.npz")
+    ns = 32
+    calls = [3 * 4088 + 1000, 2 * 4088 + 604]                  # multiples of M = 4: both calls start on phase 0
+    n = sum(calls)
+    words = np.stack([synth.smi_stream_bytes(n, channel, stream=200 + s)[0].view(np.uint32) for s in range(ns)])
+    d_in = torch.from_numpy(words.view(np.int32)).to(G.DEV)
+    pipe = hip.RxPipe(ns, channel, t["fir128_c4"], t["rs_5_4"], 5, 4, hip.PIPE_OUT_IQ)
+    got, pos = [], 0
+    for cn in calls:
+        assert pipe.uses_fused(cn)
+        no = pipe.out_count(cn)
+        out = torch.full((ns, no + 4, 2), float("nan"), dtype=torch.float32, device=G.DEV)
+        assert pipe.run(hip.PIPE_IN_SMI_WORDS, d_in.data_ptr() + 4 * pos, n, cn, out, no + 4) == no
+        torch.cuda.synchronize()
+        o = out.cpu().numpy()
+        assert np.all(np.isnan(o[:, no:]))
+        got.append(o[:, :no])
+        pos += cn
+    got = np.concatenate(got, axis=1)
+    for s in range(ns):
+        _, iq, _ = orc.rx_data_analyze(channel, words[s].view(np.uint8))
+        want = oracle_chain(orc, "c4", orc.cs16_to_cf32(iq[:n]))
+        assert got[s].shape == want.shape
+        assert np.max(np.abs(got[s] - want)) <= TOL * np.max(np.abs(want)), s
+
+
 def test_linearity_and_impulse_full_size(G, orc):
     """Size-independent properties at a bench-like size: an impulse returns the taps;
     response to a constant settles at the DC gain."""

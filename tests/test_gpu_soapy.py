@@ -244,6 +244,28 @@ def test_write_stream_all_formats(S, orc):
     sdr.close()
 
 
+def test_write_stream_refuses_bytes_of_an_overrun_lookback(S, orc, monkeypatch):
+    """cl_writeStream asks the modulator for its verdict before anything reaches the TX FIFO: with the look-back
+    forced to give up, the same call returns 0 (errors are squashed, CaribouliteStream.cpp:185-194) and the FIFO
+    stays empty; the stream then works normally again."""
+    g = load_golden("dsp_float.npz")
+    m = np.tile(g["fm_msg"], 8)[:60000]
+    msg_iq = np.stack([m, np.zeros_like(m)], 1)
+    sdr = S.Device(dict(driver="Cariboulite", channel="S1G"))
+    monkeypatch.setenv("CLHIP_TX_POLL_BOUND", "0")              # read when the TX pipe is created
+    tx = sdr.setupStream(S.SOAPY_SDR_TX, S.SOAPY_SDR_CF32, args={"MOD": "FM:75000", "RESAMP": "2/3"})
+    monkeypatch.delenv("CLHIP_TX_POLL_BOUND")
+    assert sdr.writeStream(tx, [msg_iq], m.size).ret == 0
+    assert sdr.drainSmiBytes().size == 0
+    assert "look-back" in sdr.lastError()
+    assert sdr.writeStream(tx, [msg_iq], m.size).ret == 0       # still refused: same pipe, same bound
+    assert sdr.drainSmiBytes().size == 0
+    tx = sdr.setupStream(S.SOAPY_SDR_TX, S.SOAPY_SDR_CF32, args={"MOD": "FM:75000", "RESAMP": "2/3"})
+    assert sdr.writeStream(tx, [msg_iq], m.size).ret == m.size
+    assert sdr.drainSmiBytes().size == 4 * (-(-m.size * 2 // 3))
+    sdr.close()
+
+
 def test_file_and_pipe_replay_front_end(S, orc, tmp_path):
     """recorded capture from a file, live feed through a pipe with short ragged
     reads, and the TX mirror into a file -- all through the reference's chunk semantics."""
