@@ -117,6 +117,11 @@ extern "C" int clhip_event_record(void *e, void *s)
     CLHIP_CHECK(hipEventRecord((hipEvent_t)e, (hipStream_t)s));
     return 0;
 }
+extern "C" int clhip_stream_wait_event(void *s, void *e)
+{
+    CLHIP_CHECK(hipStreamWaitEvent((hipStream_t)s, (hipEvent_t)e, 0));
+    return 0;
+}
 extern "C" float clhip_event_elapsed_ms(void *a, void *b)
 {
     float ms = -1.0f;

@@ -1263,7 +1263,7 @@ extern "C" long clhip_rx_pipe_run_smi(clhip_rx_pipe *p, const uint8_t *d_bytes, 
     if (dev_check && !any_bad && (n_bytes & 3) == 0) return got;      // generic-path pipe, everything in sync: done
     if (dev_check && clhip_rx_pipe_rollback(p)) return -1;            // undo the raw-word run
     if (any_lost) { clhip_set_error("SMI data synchronization failed"); return CL_SMI_ERR_SYNC; }
-    if (!d_cs16) { clhip_set_error("clhip_rx_pipe_run_smi: re-sync needs the CS16 scratch buffer"); return -1; }
+    if (!d_cs16) { clhip_set_error("clhip_rx_pipe_run_smi: chunks out of sync; redo from re-synchronised int16 samples"); return CL_PIPE_ERR_RESYNC; }
     const size_t cs_stride = n_in + 2;                       // int16 pairs per stream (one spare slot for the extrapolated sample)
     for (int st = 0; st < p->n_streams; st++)
         if (clhip_smi_unpack(p->channel, d_bytes + (size_t)st * stream_stride_bytes, n_bytes, chunk_len_bytes, chunk_len_bytes,

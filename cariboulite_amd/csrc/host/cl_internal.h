@@ -44,6 +44,11 @@ struct cl_smi {
     int tx_mode;
     /* device / pinned buffers, grown on demand */
     uint8_t *d_bytes; size_t bytes_cap;
+    /* cl_smi_read_pipe_device: the raw words of the previous call when it took the fused route (which never
+     * materialises int16 samples), kept so that a re-sync in THIS call finds in d_iq what the reference's
+     * persistent intermediate buffer would hold in the slots it leaves untouched */
+    uint8_t *d_bytes_prev; size_t bytes_prev_cap, prev_fused_bytes;
+    int32_t *d_zoffs; size_t zoffs_cap;      /* all-zero sync offsets for that catch-up unpack */
     int16_t *d_iq; size_t iq_cap;         /* samples */
     uint8_t *d_meta; size_t meta_cap;
     uint8_t *h_stage; size_t h_stage_cap; /* pinned host staging */
@@ -52,6 +57,12 @@ struct cl_smi {
     int debug_mode;               /* caribou_smi_debug_mode_en */
     cl_smi_debug_data debug_data;
     int32_t *d_dbg; int32_t *h_dbg; /* 4 ints each */
+    /* read-ahead reader (cl_smi_read_device_ra): the NEXT read() is popped into the other pinned slot and its
+     * host-to-device copy runs on `cstream` while the current chunk is analysed on `stream` */
+    void *cstream; void *ev_copied[2];
+    uint8_t *h_slot[2], *d_slot[2]; size_t slot_cap;
+    struct { int valid, slot; size_t len; } ahead;
+    int next_slot;
     /* statistics (SURVEY.md section 5 "Metrics"): */
     uint64_t stat_samples, stat_resyncs, stat_sync_failures;
     char err[256];
@@ -61,6 +72,13 @@ struct cl_smi {
  * dev->d_meta, fills dev->chunks.  Returns read_so_far, or CL_SMI_ERR_*;
  * *all_aligned = 1 when every chunk had offs == 0 and a whole number of samples. */
 int cl_smi_read_device(cl_smi *dev, int channel, size_t length_samples, int want_meta, int *all_aligned);
+/* the same chunk loop with results in caller-owned DEVICE buffers (NULL = the seam's own / no metadata) */
+int cl_smi_read_device_to(cl_smi *dev, int channel, size_t length_samples, int16_t *d_iq, uint8_t *d_meta, int *all_aligned);
+/* the same chunk loop feeding an RX pipe straight from the staged raw words (fused launch + device-side sync verdict) */
+int cl_smi_read_pipe_device(cl_smi *dev, int channel, size_t length_samples, clhip_rx_pipe *pipe, void *d_out, long *n_out);
+/* the same chunk loop, one chunk at a time, with the next read() staged and copied ahead (reader threads) */
+int cl_smi_read_device_ra(cl_smi *dev, int channel, size_t length_samples, int16_t *d_iq);
+void cl_smi_readahead_cancel(cl_smi *dev);     /* bytes staged ahead go back to the front of the FIFO */
 /* copy the slots the reference writes from the device results to host buffers */
 int cl_smi_copy_out(cl_smi *dev, cl_sample_complex_int16 *buffer, cl_sample_meta *metadata, int upto_chunk);
 int cl_ensure(void **p, size_t *cap, size_t need, size_t elem, int pinned);

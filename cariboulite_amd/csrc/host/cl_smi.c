@@ -95,7 +95,10 @@ int cl_smi_close(cl_smi *dev)
     if (!dev) return -1;
     clhip_set_device(dev->device);
     clhip_stream_sync(dev->stream);
-    clhip_free(dev->d_bytes); clhip_free(dev->d_iq); clhip_free(dev->d_meta); clhip_free(dev->d_offs);
+    cl_smi_readahead_cancel(dev);
+    if (dev->cstream) { clhip_stream_sync(dev->cstream); clhip_stream_destroy(dev->cstream); }
+    for (int k = 0; k < 2; k++) { clhip_event_destroy(dev->ev_copied[k]); clhip_host_free(dev->h_slot[k]); clhip_free(dev->d_slot[k]); }
+    clhip_free(dev->d_bytes); clhip_free(dev->d_bytes_prev); clhip_free(dev->d_zoffs); clhip_free(dev->d_iq); clhip_free(dev->d_meta); clhip_free(dev->d_offs);
     clhip_host_free(dev->h_stage); clhip_host_free(dev->h_offs); clhip_free(dev->d_dbg); clhip_host_free(dev->h_dbg);
     free(dev->chunks);
     cl_fifo_free(&dev->rx); cl_fifo_free(&dev->tx);
@@ -223,26 +226,32 @@ long cl_smi_drain_to_fd(cl_smi *dev, int fd, size_t max_bytes)
 /* --------------------------------------------------------------- RX path */
 int cl_smi_read_device(cl_smi *dev, int channel, size_t length_samples, int want_meta, int *all_aligned)
 {
-    clhip_set_device(dev->device);
+    if (cl_ensure((void **)&dev->d_iq, &dev->iq_cap, length_samples + 8, 4, 0) ||
+        (want_meta && cl_ensure((void **)&dev->d_meta, &dev->meta_cap, length_samples + 8, 1, 0)))
+        return CL_SMI_ERR_IO;
+    return cl_smi_read_device_to(dev, channel, length_samples, dev->d_iq, want_meta ? dev->d_meta : NULL, all_aligned);
+}
+
+/* The reference's chunk loop (caribou_smi.c:643-679; read() = FIFO pop) up to the point where bytes are analysed:
+ * every read() of the call is popped into the pinned staging buffer and the lot goes to the device in one copy.
+ * Fills dev->chunks; *contiguous = the staged bytes are the call's word sequence back to back (whole samples, no
+ * staging gaps).  Returns read_so_far (0: nothing pending) or CL_SMI_ERR_IO. */
+static long smi_stage_call(cl_smi *dev, size_t length_samples, int *contiguous)
+{
     size_t left = length_samples * CL_BYTES_PER_SAMPLE, read_so_far = 0, stage_off = 0;
     dev->n_chunks = 0;
-    if (all_aligned) *all_aligned = 1;
+    *contiguous = 1;
     /* worst-case staging: every chunk rounded up to 256 B */
     const size_t max_chunks = left / (dev->max_read && dev->max_read < dev->native_batch_len ? dev->max_read : dev->native_batch_len) + 2;
     if (cl_ensure((void **)&dev->chunks, &dev->chunks_cap, max_chunks, sizeof(cl_chunk), 2)) return CL_SMI_ERR_IO;
     const size_t need_bytes = left + 256 * max_chunks + 256;
     if (cl_ensure((void **)&dev->h_stage, &dev->h_stage_cap, need_bytes, 1, 1) ||
         cl_ensure((void **)&dev->d_bytes, &dev->bytes_cap, need_bytes, 1, 0) ||
-        cl_ensure((void **)&dev->d_iq, &dev->iq_cap, length_samples + 8, 4, 0) ||
-        (want_meta && cl_ensure((void **)&dev->d_meta, &dev->meta_cap, length_samples + 8, 1, 0)) ||
-        cl_ensure((void **)&dev->d_offs, &dev->offs_cap, max_chunks, 4, 0))
+        cl_ensure((void **)&dev->d_offs, &dev->offs_cap, max_chunks, 4, 0) ||
+        cl_ensure((void **)&dev->h_offs, &dev->h_offs_cap, max_chunks, 4, 1))
         return CL_SMI_ERR_IO;
-    if (cl_ensure((void **)&dev->h_offs, &dev->h_offs_cap, max_chunks, 4, 1)) return CL_SMI_ERR_IO;
-
-    /* the reference's chunk loop, caribou_smi.c:643-679; read() = FIFO pop */
     while (left) {
-        size_t cur = left > dev->native_batch_len ? dev->native_batch_len : left;
-        size_t want = cur;
+        size_t want = left > dev->native_batch_len ? dev->native_batch_len : left;
         if (dev->max_read && want > dev->max_read) want = dev->max_read;
         pthread_mutex_lock(&dev->fifo_mu);
         size_t ret = cl_fifo_pop(&dev->rx, dev->h_stage + stage_off, want);
@@ -250,12 +259,47 @@ int cl_smi_read_device(cl_smi *dev, int channel, size_t length_samples, int want
         if (ret == 0) break;                                   /* :657-661 "Reading timed-out" */
         cl_chunk *c = &dev->chunks[dev->n_chunks++];
         c->stage_off = stage_off; c->len = ret; c->slot0 = read_so_far; c->offs = 0;
+        if ((ret & 3) || stage_off != 4 * read_so_far || (left > ret && ret != dev->native_batch_len)) *contiguous = 0;
         stage_off += (ret + 255) & ~(size_t)255;
         read_so_far += ret / CL_BYTES_PER_SAMPLE;              /* :677 */
         left -= ret;                                           /* :678 */
     }
+    if (dev->n_chunks && clhip_memcpy_h2d(dev->d_bytes, dev->h_stage, stage_off, dev->stream)) return CL_SMI_ERR_IO;
+    return (long)read_so_far;
+}
+
+/* The sync-search results of a staged call are on the host (dev->h_offs): statistics, and the reference's exit
+ * at the first chunk without sync (:665-668 -> -3) -- what was read after that chunk goes back to the FIFO. */
+static int smi_call_verdict(cl_smi *dev, int *all_aligned)
+{
+    for (size_t i = 0; i < dev->n_chunks; i++) {
+        dev->chunks[i].offs = dev->h_offs[i];
+        /* "aligned" = the staged bytes ARE the sample sequence: in sync, whole samples, no staging gaps */
+        if (dev->h_offs[i] != 0 || (dev->chunks[i].len & 3) || dev->chunks[i].stage_off != 4 * dev->chunks[i].slot0) { if (all_aligned) *all_aligned = 0; }
+        if (dev->h_offs[i] > 0) dev->stat_resyncs++;
+        if (dev->h_offs[i] < 0) {
+            dev->stat_sync_failures++;
+            pthread_mutex_lock(&dev->fifo_mu);
+            for (size_t k = dev->n_chunks; k-- > i + 1;)
+                if (cl_fifo_unpop(&dev->rx, dev->h_stage + dev->chunks[k].stage_off, dev->chunks[k].len)) { pthread_mutex_unlock(&dev->fifo_mu); return CL_SMI_ERR_IO; }
+            pthread_mutex_unlock(&dev->fifo_mu);
+            dev->n_chunks = i;                                  /* chunks before the failure were delivered */
+            return CL_SMI_ERR_SYNC;
+        }
+    }
+    return 0;
+}
+
+int cl_smi_read_device_to(cl_smi *dev, int channel, size_t length_samples, int16_t *d_iq, uint8_t *d_meta, int *all_aligned)
+{
+    clhip_set_device(dev->device);
+    cl_smi_readahead_cancel(dev);
+    if (d_iq == dev->d_iq) dev->prev_fused_bytes = 0;          /* the seam's int16 buffer is brought up to date here */
+    if (all_aligned) *all_aligned = 1;
+    int contiguous;
+    const long read_so_far = smi_stage_call(dev, length_samples, &contiguous);
+    if (read_so_far < 0) return (int)read_so_far;
     if (dev->n_chunks == 0) return 0;
-    if (clhip_memcpy_h2d(dev->d_bytes, dev->h_stage, stage_off, dev->stream)) return CL_SMI_ERR_IO;
 
     /* runs of full native chunks go out as ONE batched launch each */
     size_t i = 0;
@@ -267,27 +311,169 @@ int cl_smi_read_device(cl_smi *dev, int channel, size_t length_samples, int want
         const size_t stride = dev->native_batch_len, total = (j - i - 1) * stride + dev->chunks[j - 1].len;
         if (clhip_smi_find_offsets(dev->d_bytes + c->stage_off, total, stride, stride, (int)(j - i), dev->d_offs + i, dev->stream) ||
             clhip_smi_unpack(channel, dev->d_bytes + c->stage_off, total, stride, stride, (int)(j - i), dev->d_offs + i,
-                             CL_FORMAT_CS16, dev->d_iq + 2 * c->slot0, want_meta ? dev->d_meta + c->slot0 : NULL, dev->stream))
+                             CL_FORMAT_CS16, d_iq + 2 * c->slot0, d_meta ? d_meta + c->slot0 : NULL, dev->stream))
             return CL_SMI_ERR_IO;
         i = j;
     }
     if (clhip_memcpy_d2h(dev->h_offs, dev->d_offs, dev->n_chunks * 4, dev->stream) || clhip_stream_sync(dev->stream))
         return CL_SMI_ERR_IO;
-    for (i = 0; i < dev->n_chunks; i++) {
-        dev->chunks[i].offs = dev->h_offs[i];
-        /* "aligned" = the staged bytes ARE the sample sequence: in sync, whole samples, no staging gaps */
-        if (dev->h_offs[i] != 0 || (dev->chunks[i].len & 3) || dev->chunks[i].stage_off != 4 * dev->chunks[i].slot0) { if (all_aligned) *all_aligned = 0; }
-        if (dev->h_offs[i] > 0) dev->stat_resyncs++;
-        if (dev->h_offs[i] < 0) {                               /* :665-668 -> -3 */
+    const int v = smi_call_verdict(dev, all_aligned);
+    if (v) return v;
+    dev->stat_samples += (uint64_t)read_so_far;
+    return (int)read_so_far;
+}
+
+/* caribou_smi_read feeding an RX pipe without materialising the int16 samples: the call's reads are staged as
+ * above; when they form one contiguous word sequence the pipe runs straight from the raw bytes
+ * (clhip_rx_pipe_run_smi: per-chunk sync search + ONE fused launch, verdict checked on the device, re-sync and "-3"
+ * handled with the reference's semantics); otherwise the chunks are unpacked first and the pipe runs from int16.
+ * *n_out = outputs the pipe produced (left in d_out, complete).  Returns samples consumed, 0, or CL_SMI_ERR_*. */
+int cl_smi_read_pipe_device(cl_smi *dev, int channel, size_t length_samples, clhip_rx_pipe *pipe, void *d_out, long *n_out)
+{
+    clhip_set_device(dev->device);
+    cl_smi_readahead_cancel(dev);
+    *n_out = 0;
+    if (cl_ensure((void **)&dev->d_iq, &dev->iq_cap, length_samples + 8, 4, 0)) return CL_SMI_ERR_IO;
+    int contiguous;
+    const long read_so_far = smi_stage_call(dev, length_samples, &contiguous);
+    if (read_so_far < 0) return (int)read_so_far;
+    if (dev->n_chunks == 0) return 0;
+    if (!contiguous) {                                         /* short / ragged reads: analyse chunk by chunk first */
+        /* the bytes are staged already: give them back and take the ordinary route (rare; keeps one code path) */
+        pthread_mutex_lock(&dev->fifo_mu);
+        for (size_t k = dev->n_chunks; k-- > 0;)
+            if (cl_fifo_unpop(&dev->rx, dev->h_stage + dev->chunks[k].stage_off, dev->chunks[k].len)) { pthread_mutex_unlock(&dev->fifo_mu); return CL_SMI_ERR_IO; }
+        pthread_mutex_unlock(&dev->fifo_mu);
+        clhip_stream_sync(dev->stream);
+        const int ret = cl_smi_read_device_to(dev, channel, length_samples, dev->d_iq, NULL, NULL);
+        if (ret <= 0) return ret;
+        *n_out = clhip_rx_pipe_run(pipe, CL_PIPE_IN_CS16, dev->d_iq, 0, (size_t)ret, d_out, 0, dev->stream);
+        if (*n_out < 0 || clhip_stream_sync(dev->stream)) return CL_SMI_ERR_IO;
+        return ret;
+    }
+    const cl_chunk *last = &dev->chunks[dev->n_chunks - 1];
+    const size_t total = last->stage_off + last->len, nb = dev->native_batch_len;
+    long got = clhip_rx_pipe_run_smi(pipe, dev->d_bytes, 0, total, nb, dev->d_offs, dev->h_offs, NULL, d_out, 0, dev->stream);
+    if (got < 0 && got != CL_SMI_ERR_SYNC && got != CL_PIPE_ERR_RESYNC) return CL_SMI_ERR_IO;
+    const int v = smi_call_verdict(dev, NULL);
+    if (v) return v;                                           /* -3: pipe and FIFO as the reference leaves them */
+    if (got == CL_SMI_ERR_SYNC) return CL_SMI_ERR_IO;          /* the pipe saw a lost chunk the table does not show */
+    if (got == CL_PIPE_ERR_RESYNC) {
+        /* the reference's way: int16 samples in the persistent intermediate buffer, untouched slots keeping what
+         * the previous call left there.  That call's samples were never materialised if it took the fused route:
+         * unpack its raw words (all in sync, or it would not have) first, then this call's over them. */
+        const int nc = (int)dev->n_chunks;
+        if (dev->prev_fused_bytes) {
+            const int pc = (int)((dev->prev_fused_bytes + nb - 1) / nb);
+            if (cl_ensure((void **)&dev->d_zoffs, &dev->zoffs_cap, (size_t)pc, 4, 0)) return CL_SMI_ERR_IO;
+            if (clhip_memset(dev->d_zoffs, 0, 4 * (size_t)pc, dev->stream) ||
+                clhip_smi_unpack(channel, dev->d_bytes_prev, dev->prev_fused_bytes, nb, nb, pc, dev->d_zoffs, CL_FORMAT_CS16,
+                                 dev->d_iq, NULL, dev->stream))
+                return CL_SMI_ERR_IO;
+            dev->prev_fused_bytes = 0;
+        }
+        if (clhip_smi_unpack(channel, dev->d_bytes, total, nb, nb, nc, dev->d_offs, CL_FORMAT_CS16, dev->d_iq, NULL, dev->stream))
+            return CL_SMI_ERR_IO;
+        got = clhip_rx_pipe_run(pipe, CL_PIPE_IN_CS16, dev->d_iq, 0, (size_t)read_so_far, d_out, 0, dev->stream);
+        if (got < 0 || clhip_stream_sync(dev->stream)) return CL_SMI_ERR_IO;
+    } else {
+        /* fused route: keep these raw words until the next call has been through */
+        uint8_t *tb = dev->d_bytes; dev->d_bytes = dev->d_bytes_prev; dev->d_bytes_prev = tb;
+        size_t tc = dev->bytes_cap; dev->bytes_cap = dev->bytes_prev_cap; dev->bytes_prev_cap = tc;
+        dev->prev_fused_bytes = total;
+    }
+    *n_out = got;
+    dev->stat_samples += (uint64_t)read_so_far;
+    return (int)read_so_far;
+}
+
+/* ------------------------------------------------------------- read-ahead reader */
+/* pop the next read() into pinned slot `slot` and start its host-to-device copy on the copy stream */
+static size_t ra_stage(cl_smi *dev, int slot, size_t want)
+{
+    pthread_mutex_lock(&dev->fifo_mu);
+    const size_t got = cl_fifo_pop(&dev->rx, dev->h_slot[slot], want);
+    pthread_mutex_unlock(&dev->fifo_mu);
+    if (got && (clhip_memcpy_h2d(dev->d_slot[slot], dev->h_slot[slot], got, dev->cstream) ||
+                clhip_event_record(dev->ev_copied[slot], dev->cstream)))
+        return 0;
+    return got;
+}
+
+void cl_smi_readahead_cancel(cl_smi *dev)
+{
+    if (!dev->ahead.valid) return;
+    clhip_stream_sync(dev->cstream);
+    pthread_mutex_lock(&dev->fifo_mu);
+    cl_fifo_unpop(&dev->rx, dev->h_slot[dev->ahead.slot], dev->ahead.len);
+    pthread_mutex_unlock(&dev->fifo_mu);
+    dev->ahead.valid = 0;
+}
+
+/* caribou_smi_read's chunk loop (caribou_smi.c:643-679) for a reader thread: chunk k is analysed on the seam's
+ * stream while the bytes of read() k+1 -- also the first read() of the NEXT call -- are already popped into the
+ * other pinned slot and on their way to the device on a second HIP stream.  Same chunks, slots and return codes
+ * as cl_smi_read_device; a read() staged ahead that the loop turns out not to want goes back to the FIFO. */
+int cl_smi_read_device_ra(cl_smi *dev, int channel, size_t length_samples, int16_t *d_iq)
+{
+    clhip_set_device(dev->device);
+    const size_t nb = dev->native_batch_len;
+    if (!dev->cstream) {
+        dev->cstream = clhip_stream_create();
+        for (int k = 0; k < 2; k++) {
+            dev->ev_copied[k] = clhip_event_create();
+            dev->h_slot[k] = (uint8_t *)clhip_host_alloc(nb + 256);
+            dev->d_slot[k] = (uint8_t *)clhip_malloc(nb + 256);
+        }
+        dev->slot_cap = nb + 256;
+        if (!dev->cstream || !dev->ev_copied[0] || !dev->ev_copied[1] || !dev->h_slot[0] || !dev->h_slot[1] || !dev->d_slot[0] || !dev->d_slot[1])
+            return CL_SMI_ERR_IO;
+    }
+    if (!d_iq) {
+        if (cl_ensure((void **)&dev->d_iq, &dev->iq_cap, length_samples + 8, 4, 0)) return CL_SMI_ERR_IO;
+        d_iq = dev->d_iq;
+    }
+    if (cl_ensure((void **)&dev->d_offs, &dev->offs_cap, 4, 4, 0) || cl_ensure((void **)&dev->h_offs, &dev->h_offs_cap, 4, 4, 1))
+        return CL_SMI_ERR_IO;
+    const size_t cap_read = dev->max_read && dev->max_read < nb ? dev->max_read : nb;
+    size_t left = length_samples * CL_BYTES_PER_SAMPLE, read_so_far = 0;
+    dev->n_chunks = 0;
+    while (left) {
+        const size_t want = left < cap_read ? left : cap_read;
+        size_t got; int slot;
+        if (dev->ahead.valid) {
+            slot = dev->ahead.slot; got = dev->ahead.len; dev->ahead.valid = 0;
+            if (got > want) {                                  /* staged for a longer read than this one */
+                clhip_stream_sync(dev->cstream);
+                pthread_mutex_lock(&dev->fifo_mu);
+                cl_fifo_unpop(&dev->rx, dev->h_slot[slot] + want, got - want);
+                pthread_mutex_unlock(&dev->fifo_mu);
+                got = want;
+            }
+        } else {
+            slot = dev->next_slot;
+            got = ra_stage(dev, slot, want);
+            if (!got) break;                                   /* :657-661 "Reading timed-out" */
+        }
+        dev->next_slot = slot ^ 1;
+        /* the read() after this one: the rest of this call, or the head of the next call */
+        const size_t rest = left - got, want_next = rest ? (rest < cap_read ? rest : cap_read) : cap_read;
+        const size_t a = ra_stage(dev, slot ^ 1, want_next);
+        if (a) { dev->ahead.valid = 1; dev->ahead.slot = slot ^ 1; dev->ahead.len = a; }
+        if (clhip_stream_wait_event(dev->stream, dev->ev_copied[slot]) ||
+            clhip_smi_find_offsets(dev->d_slot[slot], got, nb, nb, 1, dev->d_offs, dev->stream) ||
+            clhip_smi_unpack(channel, dev->d_slot[slot], got, nb, nb, 1, dev->d_offs, CL_FORMAT_CS16, d_iq + 2 * read_so_far, NULL, dev->stream) ||
+            clhip_memcpy_d2h(dev->h_offs, dev->d_offs, 4, dev->stream) || clhip_stream_sync(dev->stream))
+            return CL_SMI_ERR_IO;
+        const int32_t offs = dev->h_offs[0];
+        if (offs > 0) dev->stat_resyncs++;
+        if (offs < 0) {                                        /* :665-668 -> -3; nothing after this read() is consumed */
             dev->stat_sync_failures++;
-            /* the reference returns at this chunk: what was read ahead of it goes back to the FIFO */
-            pthread_mutex_lock(&dev->fifo_mu);
-            for (size_t k = dev->n_chunks; k-- > i + 1;)
-                if (cl_fifo_unpop(&dev->rx, dev->h_stage + dev->chunks[k].stage_off, dev->chunks[k].len)) { pthread_mutex_unlock(&dev->fifo_mu); return CL_SMI_ERR_IO; }
-            pthread_mutex_unlock(&dev->fifo_mu);
-            dev->n_chunks = i;                                  /* chunks before the failure were delivered */
+            cl_smi_readahead_cancel(dev);
             return CL_SMI_ERR_SYNC;
         }
+        read_so_far += got / CL_BYTES_PER_SAMPLE;              /* :677 */
+        left -= got;                                           /* :678 */
     }
     dev->stat_samples += read_so_far;
     return (int)read_so_far;
@@ -332,23 +518,46 @@ int cl_smi_read(cl_smi *dev, int channel, cl_sample_complex_int16 *buffer, cl_sa
     return ret;
 }
 
-/* --------------------------------------------------------------- TX path */
-/* caribou_smi_write caribou_smi.c:720-762 */
-int cl_smi_write(cl_smi *dev, int channel, cl_sample_complex_int16 *buffer, size_t length_samples)
+/* caribou_smi_read with the caller's buffers in DEVICE memory (length_samples + 1 slots each; metadata may be
+ * NULL): same chunk loop, slots and return codes; the results are complete when the call returns */
+int cl_smi_read_to_device(cl_smi *dev, int channel, int16_t *d_iq, uint8_t *d_meta, size_t length_samples)
 {
-    (void)channel;
-    if (!dev) return CL_SMI_ERR_IO;
+    if (!dev || !d_iq) return CL_SMI_ERR_IO;
+    if (dev->debug_mode != CL_SMI_DEBUG_NONE) return cl_smi_read_debug(dev, length_samples);
+    return cl_smi_read_device_to(dev, channel, length_samples, d_iq, d_meta, NULL);
+}
+
+/* caribou_smi_flush_fifo caribou_smi.c:772-783: drop what the driver FIFO holds (and what was staged ahead of it) */
+int cl_smi_flush_fifo(cl_smi *dev)
+{
+    if (!dev) return -1;
+    cl_smi_readahead_cancel(dev);
+    pthread_mutex_lock(&dev->fifo_mu);
+    cl_fifo_pop(&dev->rx, NULL, dev->rx.len);
+    pthread_mutex_unlock(&dev->fifo_mu);
+    return 0;
+}
+
+void *cl_smi_stream(cl_smi *dev) { return dev ? dev->stream : NULL; }
+int   cl_smi_device(const cl_smi *dev) { return dev ? dev->device : -1; }
+
+/* --------------------------------------------------------------- TX path */
+static int smi_write_core(cl_smi *dev, const cl_sample_complex_int16 *h_buffer, const int16_t *d_src, size_t length_samples)
+{
     clhip_set_device(dev->device);
     size_t left = length_samples * CL_BYTES_PER_SAMPLE, written_so_far = 0;
     if (length_samples == 0) return 0;
-    if (cl_ensure((void **)&dev->d_iq, &dev->iq_cap, length_samples + 8, 4, 0) ||
+    if ((h_buffer && cl_ensure((void **)&dev->d_iq, &dev->iq_cap, length_samples + 8, 4, 0)) ||
         cl_ensure((void **)&dev->d_bytes, &dev->bytes_cap, left + 256, 1, 0) ||
         cl_ensure((void **)&dev->h_stage, &dev->h_stage_cap, left + 256, 1, 1))
         return CL_SMI_ERR_IO;
     /* the chunk loop only slices the same contiguous arrays (len &= ~3 never bites: 4 B/sample), so
      * the whole call is one pack launch; the FIFO then receives it in native-batch writes */
-    if (clhip_memcpy_h2d(dev->d_iq, buffer, left, dev->stream) ||
-        clhip_smi_pack(dev->tx_mode, dev->d_iq, length_samples, dev->d_bytes, dev->stream) ||
+    if (h_buffer) {
+        if (clhip_memcpy_h2d(dev->d_iq, h_buffer, left, dev->stream)) return CL_SMI_ERR_IO;
+        d_src = dev->d_iq;
+    }
+    if (clhip_smi_pack(dev->tx_mode, d_src, length_samples, dev->d_bytes, dev->stream) ||
         clhip_memcpy_d2h(dev->h_stage, dev->d_bytes, left, dev->stream) || clhip_stream_sync(dev->stream))
         return CL_SMI_ERR_IO;
     while (left) {
@@ -360,6 +569,22 @@ int cl_smi_write(cl_smi *dev, int channel, cl_sample_complex_int16 *buffer, size
         left -= cur;                                            /* :758 (ret == len) */
     }
     return (int)written_so_far;
+}
+
+/* caribou_smi_write caribou_smi.c:720-762 */
+int cl_smi_write(cl_smi *dev, int channel, cl_sample_complex_int16 *buffer, size_t length_samples)
+{
+    (void)channel;
+    if (!dev || (!buffer && length_samples)) return CL_SMI_ERR_IO;
+    return smi_write_core(dev, buffer, NULL, length_samples);
+}
+
+/* the same with the samples already in DEVICE memory (on the seam's stream, or complete) */
+int cl_smi_write_from_device(cl_smi *dev, int channel, const int16_t *d_iq, size_t length_samples)
+{
+    (void)channel;
+    if (!dev || (!d_iq && length_samples)) return CL_SMI_ERR_IO;
+    return smi_write_core(dev, NULL, d_iq, length_samples);
 }
 
 /* ----------------------------------------------------- radio pass-through */
@@ -387,5 +612,20 @@ int cl_radio_write_samples(cl_radio *radio, cl_sample_complex_int16 *buffer, siz
     if (ret < 0) fprintf(stderr, "SMI writing operation failed\n");
     return ret;
 }
+/* the trio's device-resident forms: the C++ API and the stream object keep their samples on the GPU */
+int cl_radio_read_samples_device(cl_radio *radio, int16_t *d_iq, uint8_t *d_meta, size_t length)
+{
+    int ret = cl_smi_read_to_device(radio->smi, radio->channel, d_iq, d_meta, length);
+    if (ret == CL_SMI_ERR_IO) fprintf(stderr, "SMI reading operation failed\n");
+    else if (ret == CL_SMI_ERR_SYNC) fprintf(stderr, "SMI data synchronization failed\n");
+    return ret;
+}
+int cl_radio_write_samples_device(cl_radio *radio, const int16_t *d_iq, size_t length)
+{
+    int ret = cl_smi_write_from_device(radio->smi, radio->channel, d_iq, length);
+    if (ret < 0) fprintf(stderr, "SMI writing operation failed\n");
+    return ret;
+}
+cl_smi *cl_radio_smi(cl_radio *radio) { return radio ? radio->smi : NULL; }
 /* cariboulite_radio.c:1310-1315 */
 size_t cl_radio_get_native_mtu_size_samples(cl_radio *radio) { return cl_smi_get_native_batch_samples(radio->smi); }

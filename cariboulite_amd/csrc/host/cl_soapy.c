@@ -37,13 +37,16 @@ struct cl_stream {
     cl_dsp_cfg dsp;
     clhip_rx_pipe *rx_pipe;
     clhip_tx_pipe *tx_pipe;
-    /* ASYNC mode: reader thread + ring (CaribouliteStream.cpp:16-49,70-75) */
+    /* ASYNC mode: reader thread + ring (CaribouliteStream.cpp:16-49,70-75).  The ring's storage is DEVICE memory:
+     * the reader thread's unpacked samples go device-to-device into it while the next native batch is already
+     * being copied host-to-device on a second HIP stream (cl_smi_read_device_ra); the consumer's stages read
+     * them from there, so a sample crosses PCIe once as raw bytes and once as the client's output format. */
     int use_async;
     cl_ring *rx_queue;
     pthread_t reader_thread;
     volatile int reader_thread_running;
-    cl_sample_complex_int16 *interm_native_buffer1;
-    void *astream;                       /* consumer-side HIP stream and CS16 device buffer: the reader */
+    int16_t *d_native1;                  /* interm_native_buffer1 of the reference, on the device (reader thread's) */
+    void *astream;                       /* consumer-side HIP stream and linear CS16 device buffer: the reader */
     int16_t *d_aiq; size_t aiq_cap;      /* thread owns the cl_smi ones */
 };
 
@@ -106,17 +109,40 @@ static const char *kw(const char *const *keys, const char *const *vals, size_t n
     return NULL;
 }
 
+/* device-to-device between a linear buffer and a span of the ring (elements = CS16 samples, 4 bytes) */
+static int ring_span_copy(cl_ring *q, const cl_ring_span *sp, int16_t *d_linear, int to_ring, void *hs)
+{
+    uint8_t *base = (uint8_t *)cl_ring_storage(q), *lin = (uint8_t *)d_linear;
+    for (int k = 0; k < 2; k++) {
+        if (!sp->len[k]) continue;
+        uint8_t *slot = base + 4 * sp->pos[k];
+        if (to_ring ? clhip_memcpy_d2d(slot, lin, 4 * sp->len[k], hs) : clhip_memcpy_d2d(lin, slot, 4 * sp->len[k], hs)) return -1;
+        lin += 4 * sp->len[k];
+    }
+    return 0;
+}
+
 /* ReaderThread  CaribouliteStream.cpp:16-49 */
 static void *reader_thread_fn(void *arg)
 {
     cl_stream *st = (cl_stream *)arg;
+    cl_smi *smi = st->dev->smi;
     while (st->reader_thread_running) {
-        if (!st->stream_active) { usleep(10000); continue; }            /* :24-28 */
-        int ret = cl_radio_read_samples(st->dev->radio, st->interm_native_buffer1, NULL, st->mtu_size);
+        if (!st->stream_active) { cl_smi_readahead_cancel(smi); usleep(10000); continue; }   /* :24-28 */
+        /* cariboulite_radio_read_samples(radio, interm_native_buffer1, ..., mtu_size)  :30-33 */
+        int ret = cl_smi_read_device_ra(smi, st->dev->channel, st->mtu_size, st->d_native1);
+        if (ret == CL_SMI_ERR_IO) fprintf(stderr, "SMI reading operation failed\n");
+        else if (ret == CL_SMI_ERR_SYNC) fprintf(stderr, "SMI data synchronization failed\n");
         if (ret < 0) ret = 0;                                            /* :34-42 */
-        if (ret) cl_ring_put(st->rx_queue, st->interm_native_buffer1, (size_t)ret);
-        else usleep(500);                                                /* nothing pending: do not spin */
+        if (ret) {                                                       /* rx_queue->put(interm_native_buffer1, ret)  :44 */
+            cl_ring_span sp;
+            size_t n = cl_ring_put_begin(st->rx_queue, (size_t)ret, &sp);
+            if (n && (ring_span_copy(st->rx_queue, &sp, st->d_native1, 1, smi->stream) || clhip_stream_sync(smi->stream))) n = 0;
+            cl_ring_put_end(st->rx_queue, n);
+        } else
+            usleep(500);                                                 /* nothing pending: do not spin */
     }
+    cl_smi_readahead_cancel(smi);
     return NULL;
 }
 
@@ -127,7 +153,7 @@ static void stream_stop_async(cl_stream *st)
         pthread_join(st->reader_thread, NULL);
     }
     if (st->rx_queue) { cl_ring_destroy(st->rx_queue); st->rx_queue = NULL; }
-    free(st->interm_native_buffer1); st->interm_native_buffer1 = NULL;
+    clhip_free(st->d_native1); st->d_native1 = NULL;
     if (st->astream) { clhip_stream_sync(st->astream); clhip_stream_destroy(st->astream); st->astream = NULL; }
     clhip_free(st->d_aiq); st->d_aiq = NULL; st->aiq_cap = 0;
     st->use_async = 0;
@@ -303,10 +329,10 @@ cl_stream *cl_setupStream(cl_device *dev, int direction, const char *format, con
     const char *as = kw(keys, vals, n_kwargs, "ASYNC");
     if (as && !strcmp(as, "1") && st->native_dir == CL_SOAPY_SDR_RX) {
         /* rx_queue(mtu * NUM_NATIVE_MTUS_PER_QUEUE, override writes, blocking reads)  :70-75 */
-        st->rx_queue = cl_ring_create(st->mtu_size * NUM_NATIVE_MTUS_PER_QUEUE, sizeof(cl_sample_complex_int16), 1, 1);
-        st->interm_native_buffer1 = (cl_sample_complex_int16 *)malloc(sizeof(cl_sample_complex_int16) * st->mtu_size);
+        st->rx_queue = cl_ring_create_device(dev->smi->device, st->mtu_size * NUM_NATIVE_MTUS_PER_QUEUE, sizeof(cl_sample_complex_int16), 1, 1);
+        st->d_native1 = (int16_t *)clhip_malloc(sizeof(cl_sample_complex_int16) * (st->mtu_size + 8));
         st->astream = clhip_stream_create();
-        if (!st->rx_queue || !st->interm_native_buffer1 || !st->astream) { cl_seterr(dev->err, sizeof dev->err, "setupStream: ASYNC allocation failed"); return NULL; }
+        if (!st->rx_queue || !st->d_native1 || !st->astream) { cl_seterr(dev->err, sizeof dev->err, "setupStream: ASYNC allocation failed"); return NULL; }
         st->use_async = 1;
         st->reader_thread_running = 1;
         if (pthread_create(&st->reader_thread, NULL, reader_thread_fn, st)) { st->reader_thread_running = 0; return NULL; }
@@ -353,16 +379,19 @@ static int read_native_device(cl_stream *st, size_t n, int *aligned, long timeou
 {
     cl_smi *smi = st->dev->smi;
     if (st->use_async) {
-        /* Stream::Read with USE_ASYNC: rx_queue->get(buffer, num_samples, timeout_us)  :262-263.
-         * The reader thread owns the SMI path; the popped CS16 samples go back to the device only
-         * when an IIR / conversion / extension stage follows. */
-        if (cl_ensure((void **)&st->h_conv, &st->h_conv_cap, (n + 8) * 4, 1, 1) ||
-            cl_ensure((void **)&st->d_aiq, &st->aiq_cap, n + 8, 4, 0))
-            return 0;
-        const int got = (int)cl_ring_get(st->rx_queue, st->h_conv, n, (int)timeout_us);
+        /* Stream::Read with USE_ASYNC: rx_queue->get(buffer, num_samples, timeout_us)  :262-263.  The popped samples
+         * move device-to-device into the consumer's linear buffer (the ring stays locked until the copy is done:
+         * the reader thread may overwrite the oldest slots), and every later stage reads them there. */
+        if (cl_ensure((void **)&st->d_aiq, &st->aiq_cap, n + 8, 4, 0)) return 0;
+        cl_ring_span sp;
+        const size_t claimed = cl_ring_get_begin(st->rx_queue, n, (int)timeout_us, &sp);
         if (aligned) *aligned = 0;
-        if (got > 0 && clhip_memcpy_h2d(st->d_aiq, st->h_conv, (size_t)got * 4, st->astream)) return 0;
-        if (got > 0 && st->filter_type != CL_DIGFILT_NONE) {
+        if (!claimed) return 0;
+        const int bad = ring_span_copy(st->rx_queue, &sp, st->d_aiq, 0, st->astream) || clhip_stream_sync(st->astream);
+        cl_ring_get_end(st->rx_queue, claimed);
+        if (bad) return 0;
+        const int got = (int)claimed;
+        if (st->filter_type != CL_DIGFILT_NONE) {
             const int f = st->filter_type - 1;
             const size_t need = clhip_iir_workspace_bytes((size_t)got, 3);
             if (cl_ensure(&st->d_iir_ws, &st->iir_ws_cap, need, 1, 0)) return 0;
@@ -399,9 +428,10 @@ int cl_readStream(cl_device *dev, cl_stream *st, void *const *buffs, size_t numE
         int aligned = 0;
         int res = read_native_device(st, numElems, &aligned, timeoutUs);
         if (res <= 0) return res;
-        if (st->use_async) {
-            if (st->filter_type == CL_DIGFILT_NONE) memcpy(out, st->h_conv, (size_t)res * 4);
-            else if (clhip_memcpy_d2h(out, st->d_aiq, (size_t)res * 4, st->astream) || clhip_stream_sync(st->astream)) return 0;
+        if (st->use_async) {            /* one PCIe crossing: device -> pinned mirror -> the client's buffer */
+            if (cl_ensure((void **)&st->h_conv, &st->h_conv_cap, (size_t)res * 4 + 64, 1, 1) ||
+                clhip_memcpy_d2h(st->h_conv, st->d_aiq, (size_t)res * 4, st->astream) || clhip_stream_sync(st->astream)) return 0;
+            memcpy(out, st->h_conv, (size_t)res * 4);
             return res;
         }
         if (st->filter_type == CL_DIGFILT_NONE) { if (cl_smi_copy_out(smi, (cl_sample_complex_int16 *)out, NULL, -1)) return 0; }
@@ -409,6 +439,18 @@ int cl_readStream(cl_device *dev, cl_stream *st, void *const *buffs, size_t numE
         return res;
     }
     if (numElems > st->mtu_size) numElems = st->mtu_size;                          /* :306,328,351 */
+    if (st->rx_pipe && !st->use_async && st->filter_type == CL_DIGFILT_NONE) {
+        /* extension stages straight from the staged raw words: no int16 intermediate, one fused launch, the sync
+         * verdict checked on the device; re-sync / "-3" as caribou_smi_read has them (clhip_rx_pipe_run_smi) */
+        const size_t ob = st->dsp.demod_fm ? 4 : 8;
+        if (cl_ensure(&st->d_conv, &st->conv_cap, clhip_rx_pipe_out_count(st->rx_pipe, numElems) * ob + 64, 1, 0)) return 0;
+        long got = 0;
+        const int ret = cl_smi_read_pipe_device(smi, dev->channel, numElems, st->rx_pipe, st->d_conv, &got);
+        if (ret == CL_SMI_ERR_IO) printf("reader thread failed to read SMI!\n");    /* :270 */
+        if (ret <= 0 || got <= 0) return 0;                                         /* :266-276 */
+        if (clhip_memcpy_d2h(out, st->d_conv, (size_t)got * ob, smi->stream) || clhip_stream_sync(smi->stream)) return 0;
+        return (int)got;
+    }
     int aligned = 0;
     int res = read_native_device(st, numElems, &aligned, timeoutUs);
     if (res <= 0) return res;

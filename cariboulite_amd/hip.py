@@ -41,6 +41,7 @@ _SIGS = {
     "clhip_event_destroy": (None, [C.c_void_p]),
     "clhip_event_record": (C.c_int, [C.c_void_p, C.c_void_p]),
     "clhip_event_elapsed_ms": (C.c_float, [C.c_void_p, C.c_void_p]),
+    "clhip_stream_wait_event": (C.c_int, [C.c_void_p, C.c_void_p]),
     "clhip_smi_find_offsets": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]),
     "clhip_smi_unpack": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p,
                                    C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -221,7 +222,7 @@ class RxPipe:
         rc = lib().clhip_rx_pipe_run_smi(self.h, ptr(d_bytes), stream_stride_bytes, n_bytes, chunk_len_bytes, ptr(d_offs),
                                          h_offs.ctypes.data if h_offs is not None else None, ptr(d_cs16), ptr(d_out),
                                          out_stride, stream if stream is not None else current_stream())
-        if rc < 0 and rc != -3:
+        if rc < 0 and rc not in (-3, -4):
             raise RuntimeError("clhip_rx_pipe_run_smi failed: " + last_error())
         return rc
 

@@ -41,7 +41,22 @@ _SIGS = {
     "cl_smi_get_native_batch_samples": (C.c_size_t, [C.c_void_p]),
     "cl_smi_set_debug_mode": (None, [C.c_void_p, C.c_int]),
     "cl_smi_get_debug_data": (C.c_void_p, [C.c_void_p]),
+    "cl_smi_read_to_device": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "cl_smi_write_from_device": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
+    "cl_smi_flush_fifo": (C.c_int, [C.c_void_p]),
+    "cl_smi_stream": (C.c_void_p, [C.c_void_p]),
+    "cl_smi_device": (C.c_int, [C.c_void_p]),
+    "cl_radio_read_samples_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "cl_radio_write_samples_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "cl_radio_smi": (C.c_void_p, [C.c_void_p]),
     "cl_ring_create": (C.c_void_p, [C.c_size_t, C.c_size_t, C.c_int, C.c_int]),
+    "cl_ring_create_device": (C.c_void_p, [C.c_int, C.c_size_t, C.c_size_t, C.c_int, C.c_int]),
+    "cl_ring_storage": (C.c_void_p, [C.c_void_p]),
+    "cl_ring_on_device": (C.c_int, [C.c_void_p]),
+    "cl_ring_put_begin": (C.c_size_t, [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "cl_ring_put_end": (None, [C.c_void_p, C.c_size_t]),
+    "cl_ring_get_begin": (C.c_size_t, [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
+    "cl_ring_get_end": (None, [C.c_void_p, C.c_size_t]),
     "cl_ring_destroy": (None, [C.c_void_p]),
     "cl_ring_put": (C.c_size_t, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "cl_ring_get": (C.c_size_t, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
@@ -125,8 +140,13 @@ class SmiDebugData(C.Structure):
 class Ring:
     """cl_ring over uint32 elements (the reference's circular_buffer<T>)."""
 
-    def __init__(self, size, override_write=True, block_read=True):
-        self.h = lib().cl_ring_create(size, 4, int(override_write), int(block_read))
+    def __init__(self, size, override_write=True, block_read=True, device=None):
+        if device is None:
+            self.h = lib().cl_ring_create(size, 4, int(override_write), int(block_read))
+        else:                                        # storage in device memory
+            self.h = lib().cl_ring_create_device(device, size, 4, int(override_write), int(block_read))
+        if not self.h:
+            raise RuntimeError("cl_ring_create failed")
 
     def put(self, data):
         d = np.ascontiguousarray(data, dtype=np.uint32)

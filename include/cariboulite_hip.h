@@ -101,6 +101,7 @@ void       *clhip_event_create(void);
 void        clhip_event_destroy(void *event);
 int         clhip_event_record(void *event, void *stream);
 float       clhip_event_elapsed_ms(void *start, void *stop); /* synchronises on stop */
+int         clhip_stream_wait_event(void *stream, void *event); /* later work on `stream` waits for `event` */
 
 /*
  * Sync search -- replaces caribou_smi_find_buffer_offset
@@ -227,7 +228,10 @@ int    clhip_rx_pipe_rollback(clhip_rx_pipe *p);
  *                           where the Stream's interm_native_buffer stands, so "untouched" slots keep what it held);
  *   a chunk without sync -> CL_SMI_ERR_SYNC (:665-668) and the pipe keeps its pre-call state.
  * d_offs: [n_streams][ceil(n_bytes/chunk_len_bytes)] device scratch, holds the search results afterwards; h_offs
- * (optional, host) receives a copy.  Synchronises `stream`.  Returns outputs per stream, or a negative error. */
+ * (optional, host) receives a copy.  Synchronises `stream`.  Returns outputs per stream, or a negative error.
+ * d_cs16 == NULL: a call that needs the re-sync route returns CL_PIPE_ERR_RESYNC with the pipe rolled back and the
+ * offsets in d_offs / h_offs, and the caller runs clhip_smi_unpack + clhip_rx_pipe_run(CL_PIPE_IN_CS16) itself. */
+#define CL_PIPE_ERR_RESYNC (-4)
 long   clhip_rx_pipe_run_smi(clhip_rx_pipe *p, const uint8_t *d_bytes, size_t stream_stride_bytes, size_t n_bytes,
                              size_t chunk_len_bytes, int32_t *d_offs, int32_t *h_offs, int16_t *d_cs16,
                              void *d_out, size_t out_stride_elems, void *stream);
@@ -306,14 +310,36 @@ void    cl_smi_set_debug_mode(cl_smi *dev, int cl_smi_debug_mode);
 const cl_smi_debug_data *cl_smi_get_debug_data(const cl_smi *dev);
 /* caribou_smi_get_native_batch_samples caribou_smi.c:765-769 */
 size_t  cl_smi_get_native_batch_samples(cl_smi *dev);
+int     cl_smi_flush_fifo(cl_smi *dev);                /* caribou_smi_flush_fifo :772-783: drop the pending RX bytes */
+/* Device-resident forms of the seam for callers whose next stage runs on the GPU (the C++ API, the stream
+ * object): same chunk loop, slots, untouched-slot behaviour and return codes as cl_smi_read / cl_smi_write,
+ * with `d_iq` (length + 1 slots) / `d_meta` (may be NULL) in DEVICE memory.  A read is complete on return; a
+ * write consumes samples that are complete or were produced on cl_smi_stream(). */
+int     cl_smi_read_to_device(cl_smi *dev, int channel, int16_t *d_iq, uint8_t *d_meta, size_t length_samples);
+int     cl_smi_write_from_device(cl_smi *dev, int channel, const int16_t *d_iq, size_t length_samples);
+void   *cl_smi_stream(cl_smi *dev);        /* the hipStream_t the seam launches on */
+int     cl_smi_device(const cl_smi *dev);  /* its HIP device */
 
-/* --- circular_buffer<T> (datatypes/circular_buffer.h:16-164) ------------------------------------------
- * power-of-two capacity; put() overwrites the oldest when override_write; get() blocks up to timeout_us and
- * returns 0 unless all `length` elements are present (block_read), else min(length, size) at once. */
+/* --- the ASYNC mode's sample ring: circular_buffer<T> (datatypes/circular_buffer.h:16-164) re-imagined ------
+ * Power-of-two capacity; put() discards the oldest elements when override_write (else it is cut to what fits);
+ * get() waits up to timeout_us and yields nothing unless all `length` elements are present (block_read), else
+ * min(length, held) at once -- the observable behaviour of the reference's template.  The STORAGE is one array in
+ * device memory (cl_ring_create_device) or host memory (cl_ring_create); the bookkeeping is on the host.  Producers
+ * and consumers that own a GPU stream use the span calls: _begin locks the ring and names at most two linear
+ * pieces of the storage (element positions), the caller moves the data itself (hipMemcpyAsync D2D, a kernel), makes
+ * sure the move is complete, and calls _end, which publishes / releases and unlocks. */
 typedef struct cl_ring cl_ring;
+typedef struct { size_t pos[2], len[2]; } cl_ring_span;      /* elements; piece 1 is the wrapped part (pos 0) */
 cl_ring *cl_ring_create(size_t size_elems, size_t elem_bytes, int override_write, int block_read);
+cl_ring *cl_ring_create_device(int device, size_t size_elems, size_t elem_bytes, int override_write, int block_read);
 void     cl_ring_destroy(cl_ring *r);
-size_t   cl_ring_put(cl_ring *r, const void *data, size_t length);
+void    *cl_ring_storage(const cl_ring *r);                  /* base of the array (device or host pointer) */
+int      cl_ring_on_device(const cl_ring *r);
+size_t   cl_ring_put_begin(cl_ring *r, size_t length, cl_ring_span *span);              /* returns elements accepted */
+void     cl_ring_put_end(cl_ring *r, size_t accepted);
+size_t   cl_ring_get_begin(cl_ring *r, size_t length, int timeout_us, cl_ring_span *span); /* 0: nothing claimed, not locked */
+void     cl_ring_get_end(cl_ring *r, size_t claimed);
+size_t   cl_ring_put(cl_ring *r, const void *data, size_t length);                      /* host data, either storage */
 size_t   cl_ring_get(cl_ring *r, void *data, size_t length, int timeout_us);
 void     cl_ring_reset(cl_ring *r);
 size_t   cl_ring_size(cl_ring *r);
@@ -328,6 +354,10 @@ int    cl_radio_read_samples(cl_radio *radio, cl_sample_complex_int16 *buffer,
 int    cl_radio_write_samples(cl_radio *radio, cl_sample_complex_int16 *buffer,
                               size_t length);                             /* :1288-1307 */
 size_t cl_radio_get_native_mtu_size_samples(cl_radio *radio);             /* :1310-1315 */
+/* the read / write pair with DEVICE buffers (see cl_smi_read_to_device / cl_smi_write_from_device) */
+int    cl_radio_read_samples_device(cl_radio *radio, int16_t *d_iq, uint8_t *d_meta, size_t length);
+int    cl_radio_write_samples_device(cl_radio *radio, const int16_t *d_iq, size_t length);
+cl_smi *cl_radio_smi(cl_radio *radio);
 
 /* --- SoapySDR device/stream calls: soapy_api/Cariboulite.hpp:65-93 ------- */
 typedef struct cl_device cl_device;   /* stands where class Cariboulite stands        */

@@ -195,6 +195,40 @@ def test_rx_extension_stages_via_kwargs(S, orc):
     sdr.close()
 
 
+def test_rx_pipe_stream_resync_and_sync_loss(S, orc):
+    """readStream(CF32, FIR + 3/2) over a byte stream with a slipped batch and a batch without sync: the slipped one is
+    redone with the reference's re-sync semantics (its untouched slot keeps the previous batch's sample, as the
+    Stream's persistent interm_native_buffer does), the lost one yields 0 elements (Stream::Read squashes -3,
+    CaribouliteStream.cpp:266-276) and leaves the float stages where they were -- the batches after it continue the
+    oracle's smi_read -> FIR -> 3/2 chain."""
+    from cariboulite_amd import synth
+    t = load_golden("taps.npz")
+    SENT = -21846
+    sdr = S.Device(dict(driver="Cariboulite", channel="HiF"))
+    rx = sdr.setupStream(S.SOAPY_SDR_RX, S.SOAPY_SDR_CF32, args={"FIR": "64:1000000", "RESAMP": "3/2"})
+    b = synth.smi_stream_bytes(5 * MTU, 1, stream=31)[0].copy()
+    b[NB:2 * NB] = np.concatenate([np.full(6, 0x11, np.uint8), b[NB:2 * NB - 6]])      # batch 1: 6 bytes late
+    b[3 * NB:4 * NB] = 0                                                               # batch 3: no sync
+    sdr.feedSmiBytes(b)
+    fir, rs = orc.FIR(t["fir64_c2"]), orc.Resampler(t["rs_3_2"], 3, 2)
+    interm = np.zeros((MTU + 2, 2), np.int16)            # the Stream's interm_native_buffer2: untouched slots persist
+    for k in range(5):
+        out = np.zeros((MTU * 3 // 2 + 8, 2), np.float32)
+        sr = sdr.readStream(rx, [out], MTU)
+        ret, iq, _ = orc.smi_read(1, b[k * NB:(k + 1) * NB], MTU, NB, fill=SENT)
+        if k == 3:
+            assert ret == -3 and sr.ret == 0
+            continue
+        assert ret == MTU
+        touched = (iq != SENT).any(axis=1)
+        assert touched[:MTU].sum() == (MTU - 1 if k == 1 else MTU)          # offs 6: slot MTU-1 untouched
+        interm[touched] = iq[touched]
+        want = rs.f64(fir.f64(orc.cs16_to_cf32(interm[:MTU])))
+        assert sr.ret == want.shape[0]
+        assert np.max(np.abs(out[:sr.ret] - want)) <= 1e-5 * np.max(np.abs(want)), k
+    sdr.close()
+
+
 def test_write_stream_all_formats(S, orc):
     from cariboulite_amd import hip
     sdr = S.Device(dict(driver="Cariboulite", channel="S1G"))
@@ -364,3 +398,79 @@ def test_async_stream_reader_thread_and_ring(S, orc):
     # 12 MTU put into a 16-MTU ring (capacity = next power of two of 10 MTU): nothing dropped yet
     assert np.array_equal(buf, wantb[:MTU])
     sdr.close()
+
+
+@pytest.mark.parametrize("name", [str(n) for n in load_golden("ring_cases.npz")["names"]])
+def test_device_ring_replays_the_reference_fixtures(S, name):
+    """The ASYNC mode's ring with its storage in DEVICE memory: counts, order and fill level of the op sequences
+    recorded from the reference's circular_buffer<uint32_t> (tests/golden/ring_cases.npz)."""
+    g = load_golden("ring_cases.npz")
+    size, ov, blk, cap = [int(v) for v in g[f"{name}__cfg"]]
+    r = S.Ring(size, ov, blk, device=0)
+    assert r.capacity() == cap and S.lib().cl_ring_on_device(r.h) == 1
+    ops, rets, sizes, popped = g[f"{name}__ops"], g[f"{name}__rets"], g[f"{name}__sizes"], g[f"{name}__popped"]
+    ctr, pp = 0, 0
+    for (kind, n), want, sz in zip(ops.tolist(), rets.tolist(), sizes.tolist()):
+        if kind == 0:
+            d = np.arange(ctr, ctr + n, dtype=np.uint32); ctr += n
+            assert r.put(d) == want
+        else:
+            k, d = r.get(n, timeout_us=100)
+            assert k == want and np.array_equal(d, popped[pp:pp + k])
+            pp += k
+        assert r.size() == sz
+    assert pp == popped.size
+
+
+def test_device_ring_spans_move_data_device_to_device(S):
+    """Span calls: the caller moves the data itself (here torch D2D copies) between _begin and _end; wrap-around gives
+    two pieces; overwrite-oldest releases exactly what the new elements need."""
+    import ctypes as C
+    import torch
+    r = S.Ring(1000, True, True, device=0)                    # capacity 1024 uint32
+    base = S.lib().cl_ring_storage(r.h)
+
+    class Span(C.Structure):
+        _fields_ = [("pos", C.c_size_t * 2), ("len", C.c_size_t * 2)]
+
+    from cariboulite_amd import hip
+    sp = Span()
+
+    def put(src):              # src: device int32 tensor
+        n = S.lib().cl_ring_put_begin(r.h, src.numel(), C.byref(sp))
+        off = 0
+        for k in range(2):
+            if sp.len[k]:
+                hip.lib().clhip_memcpy_d2d(base + 4 * sp.pos[k], src.data_ptr() + 4 * off, 4 * sp.len[k], None)
+                off += sp.len[k]
+        torch.cuda.synchronize(); hip.lib().clhip_stream_sync(None)
+        S.lib().cl_ring_put_end(r.h, n)
+        return n, [(sp.pos[k], sp.len[k]) for k in range(2)]
+
+    def get(n):
+        dst = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+        k = S.lib().cl_ring_get_begin(r.h, n, 1000, C.byref(sp))
+        if not k:
+            return 0, dst, None
+        off = 0
+        for j in range(2):
+            if sp.len[j]:
+                hip.lib().clhip_memcpy_d2d(dst.data_ptr() + 4 * off, base + 4 * sp.pos[j], 4 * sp.len[j], None)
+                off += sp.len[j]
+        hip.lib().clhip_stream_sync(None)
+        S.lib().cl_ring_get_end(r.h, k)
+        return k, dst, [(sp.pos[j], sp.len[j]) for j in range(2)]
+
+    a = torch.arange(0, 700, dtype=torch.int32, device="cuda:0")
+    assert put(a)[0] == 700
+    k, d, _ = get(600)
+    assert k == 600 and torch.equal(d, a[:600])
+    b = torch.arange(700, 1300, dtype=torch.int32, device="cuda:0")
+    n, pieces = put(b)                                         # 100 held; 600 more wrap past slot 1023
+    assert n == 600 and pieces == [(700, 324), (0, 276)]
+    c = torch.arange(1300, 1800, dtype=torch.int32, device="cuda:0")
+    assert put(c)[0] == 500 and r.size() == 1024              # 700 + 500 > 1024: the oldest 176 are released
+    k, d, pieces = get(1024)
+    assert k == 1024 and d[0].item() == 1800 - 1024 and d[-1].item() == 1799
+    assert torch.equal(d, torch.arange(776, 1800, dtype=torch.int32, device="cuda:0"))
+    assert get(1)[0] == 0                                      # empty: whole-request rule, times out
