@@ -63,6 +63,7 @@ struct cl_smi {
     uint8_t *h_slot[2], *d_slot[2]; size_t slot_cap;
     struct { int valid, slot; size_t len; } ahead;
     int next_slot;
+    int ra_pending; size_t ra_samples;     /* between cl_smi_ra_launch and cl_smi_ra_finish */
     /* statistics (SURVEY.md section 5 "Metrics"): */
     uint64_t stat_samples, stat_resyncs, stat_sync_failures;
     char err[256];
@@ -78,6 +79,8 @@ int cl_smi_read_device_to(cl_smi *dev, int channel, size_t length_samples, int16
 int cl_smi_read_pipe_device(cl_smi *dev, int channel, size_t length_samples, clhip_rx_pipe *pipe, void *d_out, long *n_out);
 /* the same chunk loop, one chunk at a time, with the next read() staged and copied ahead (reader threads) */
 int cl_smi_read_device_ra(cl_smi *dev, int channel, size_t length_samples, int16_t *d_iq);
+long cl_smi_ra_launch(cl_smi *dev, int channel, size_t length_samples, int16_t *d_iq);   /* its two halves: the caller may queue */
+int cl_smi_ra_finish(cl_smi *dev);                                                      /* work on the seam's stream in between */
 void cl_smi_readahead_cancel(cl_smi *dev);     /* bytes staged ahead go back to the front of the FIFO */
 /* copy the slots the reference writes from the device results to host buffers */
 int cl_smi_copy_out(cl_smi *dev, cl_sample_complex_int16 *buffer, cl_sample_meta *metadata, int upto_chunk);

@@ -29,6 +29,7 @@ struct cl_ring {
     int on_device, device;
     size_t elem, cap;            /* cap is a power of two */
     uint64_t written, released;  /* written - released = elements held, never more than cap */
+    uint64_t released_before_put;/* what `released` was when the open cl_ring_put_begin took the lock */
     int drop_oldest;             /* a put that does not fit discards the oldest elements instead of being cut */
     int whole_requests;          /* a get waits for its full length and yields nothing otherwise */
     void *xfer;                  /* HIP stream of the host-data convenience calls on device storage */
@@ -104,6 +105,7 @@ static void ring_span(const cl_ring *r, uint64_t at, size_t count, cl_ring_span 
 size_t cl_ring_put_begin(cl_ring *r, size_t length, cl_ring_span *sp)
 {
     pthread_mutex_lock(&r->mu);
+    r->released_before_put = r->released;
     size_t held = (size_t)(r->written - r->released);
     if (r->drop_oldest && length > r->cap - held) {
         size_t drop = length - (r->cap - held);
@@ -120,6 +122,14 @@ void cl_ring_put_end(cl_ring *r, size_t accepted)
 {
     r->written += accepted;
     if (r->whole_requests) pthread_cond_signal(&r->grown);
+    pthread_mutex_unlock(&r->mu);
+}
+
+/* Give up an open put: nothing is published and the elements it would have displaced are held again (nobody
+ * saw them released: the ring was locked throughout). */
+void cl_ring_put_cancel(cl_ring *r)
+{
+    r->released = r->released_before_put;
     pthread_mutex_unlock(&r->mu);
 }
 

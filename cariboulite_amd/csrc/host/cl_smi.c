@@ -114,7 +114,7 @@ int cl_smi_feed_bytes(cl_smi *dev, const uint8_t *b, size_t n)
     pthread_mutex_unlock(&dev->fifo_mu);
     return rc;
 }
-size_t cl_smi_pending_bytes(const cl_smi *dev) { return dev->rx.len; }
+size_t cl_smi_pending_bytes(const cl_smi *dev) { return dev->rx.len + (dev->ahead.valid ? dev->ahead.len : 0); }   /* staged ahead = still pending */
 void   cl_smi_set_max_read(cl_smi *dev, size_t m) { dev->max_read = m; }
 size_t cl_smi_drain_bytes(cl_smi *dev, uint8_t *b, size_t max) { return cl_fifo_pop(&dev->tx, b, max); }
 void   cl_smi_set_tx_mode(cl_smi *dev, int mode) { dev->tx_mode = mode; }
@@ -413,11 +413,32 @@ void cl_smi_readahead_cancel(cl_smi *dev)
 /* caribou_smi_read's chunk loop (caribou_smi.c:643-679) for a reader thread: chunk k is analysed on the seam's
  * stream while the bytes of read() k+1 -- also the first read() of the NEXT call -- are already popped into the
  * other pinned slot and on their way to the device on a second HIP stream.  Same chunks, slots and return codes
- * as cl_smi_read_device; a read() staged ahead that the loop turns out not to want goes back to the FIFO. */
-int cl_smi_read_device_ra(cl_smi *dev, int channel, size_t length_samples, int16_t *d_iq)
+ * as cl_smi_read_device; a read() staged ahead that the loop turns out not to want goes back to the FIFO.
+ *
+ * Two halves, so that the caller can queue its own work on the seam's stream (the ring's device-to-device copy,
+ * a conversion) behind the analysis and pay for ONE synchronisation per call:
+ *   cl_smi_ra_launch  runs the loop; the analysis of the call's LAST read() is launched but not waited for.
+ *                     Returns the samples the call yields if that last chunk is in sync (0: nothing pending).
+ *   cl_smi_ra_finish  synchronises, applies the last chunk's verdict, returns what caribou_smi_read returns. */
+static int ra_chunk_verdict(cl_smi *dev)
+{
+    const int32_t offs = dev->h_offs[0];
+    dev->chunks[dev->n_chunks].offs = offs;
+    if (offs >= 0) dev->n_chunks++;                            /* chunks before a failure were delivered */
+    if (offs > 0) dev->stat_resyncs++;
+    if (offs < 0) {                                            /* :665-668 -> -3; nothing after this read() is consumed */
+        dev->stat_sync_failures++;
+        cl_smi_readahead_cancel(dev);
+        return CL_SMI_ERR_SYNC;
+    }
+    return 0;
+}
+
+long cl_smi_ra_launch(cl_smi *dev, int channel, size_t length_samples, int16_t *d_iq)
 {
     clhip_set_device(dev->device);
     const size_t nb = dev->native_batch_len;
+    dev->ra_pending = 0;
     if (!dev->cstream) {
         dev->cstream = clhip_stream_create();
         for (int k = 0; k < 2; k++) {
@@ -432,11 +453,13 @@ int cl_smi_read_device_ra(cl_smi *dev, int channel, size_t length_samples, int16
     if (!d_iq) {
         if (cl_ensure((void **)&dev->d_iq, &dev->iq_cap, length_samples + 8, 4, 0)) return CL_SMI_ERR_IO;
         d_iq = dev->d_iq;
+        dev->prev_fused_bytes = 0;
     }
     if (cl_ensure((void **)&dev->d_offs, &dev->offs_cap, 4, 4, 0) || cl_ensure((void **)&dev->h_offs, &dev->h_offs_cap, 4, 4, 1))
         return CL_SMI_ERR_IO;
     const size_t cap_read = dev->max_read && dev->max_read < nb ? dev->max_read : nb;
     size_t left = length_samples * CL_BYTES_PER_SAMPLE, read_so_far = 0;
+    if (cl_ensure((void **)&dev->chunks, &dev->chunks_cap, left / cap_read + 2, sizeof(cl_chunk), 2)) return CL_SMI_ERR_IO;
     dev->n_chunks = 0;
     while (left) {
         const size_t want = left < cap_read ? left : cap_read;
@@ -463,20 +486,40 @@ int cl_smi_read_device_ra(cl_smi *dev, int channel, size_t length_samples, int16
         if (clhip_stream_wait_event(dev->stream, dev->ev_copied[slot]) ||
             clhip_smi_find_offsets(dev->d_slot[slot], got, nb, nb, 1, dev->d_offs, dev->stream) ||
             clhip_smi_unpack(channel, dev->d_slot[slot], got, nb, nb, 1, dev->d_offs, CL_FORMAT_CS16, d_iq + 2 * read_so_far, NULL, dev->stream) ||
-            clhip_memcpy_d2h(dev->h_offs, dev->d_offs, 4, dev->stream) || clhip_stream_sync(dev->stream))
+            clhip_memcpy_d2h(dev->h_offs, dev->d_offs, 4, dev->stream))
             return CL_SMI_ERR_IO;
-        const int32_t offs = dev->h_offs[0];
-        if (offs > 0) dev->stat_resyncs++;
-        if (offs < 0) {                                        /* :665-668 -> -3; nothing after this read() is consumed */
-            dev->stat_sync_failures++;
-            cl_smi_readahead_cancel(dev);
-            return CL_SMI_ERR_SYNC;
-        }
+        cl_chunk *c = &dev->chunks[dev->n_chunks];             /* published (n_chunks++) once its verdict is in */
+        c->stage_off = 0; c->len = got; c->slot0 = read_so_far; c->offs = 0;
         read_so_far += got / CL_BYTES_PER_SAMPLE;              /* :677 */
         left -= got;                                           /* :678 */
+        if (left == 0 || !a) {                                 /* the call's last read(): a further one would time out */
+            dev->ra_pending = 1; dev->ra_samples = read_so_far;
+            return (long)read_so_far;
+        }
+        if (clhip_stream_sync(dev->stream)) return CL_SMI_ERR_IO;
+        const int v = ra_chunk_verdict(dev);
+        if (v) return v;
     }
     dev->stat_samples += read_so_far;
-    return (int)read_so_far;
+    return (long)read_so_far;
+}
+
+int cl_smi_ra_finish(cl_smi *dev)
+{
+    if (!dev->ra_pending) return 0;
+    dev->ra_pending = 0;
+    if (clhip_stream_sync(dev->stream)) return CL_SMI_ERR_IO;
+    const int v = ra_chunk_verdict(dev);
+    if (v) return v;
+    dev->stat_samples += dev->ra_samples;
+    return (int)dev->ra_samples;
+}
+
+int cl_smi_read_device_ra(cl_smi *dev, int channel, size_t length_samples, int16_t *d_iq)
+{
+    const long exp = cl_smi_ra_launch(dev, channel, length_samples, d_iq);
+    if (exp < 0 || !dev->ra_pending) return (int)exp;
+    return cl_smi_ra_finish(dev);
 }
 
 /* Copy exactly the slots the reference writes (caribou_smi.c:344-389): n unpacked

@@ -129,18 +129,32 @@ static void *reader_thread_fn(void *arg)
     cl_smi *smi = st->dev->smi;
     while (st->reader_thread_running) {
         if (!st->stream_active) { cl_smi_readahead_cancel(smi); usleep(10000); continue; }   /* :24-28 */
-        /* cariboulite_radio_read_samples(radio, interm_native_buffer1, ..., mtu_size)  :30-33 */
-        int ret = cl_smi_read_device_ra(smi, st->dev->channel, st->mtu_size, st->d_native1);
+        /* cariboulite_radio_read_samples(radio, interm_native_buffer1, ..., mtu_size)  :30-33, then
+         * rx_queue->put(interm_native_buffer1, ret)  :44 -- the put's device-to-device copy is queued behind the
+         * analysis on the seam's stream, so the two cost one synchronisation; a read that then turns out to have
+         * failed (-3) cancels the put, which nobody has seen */
+        const long expect = cl_smi_ra_launch(smi, st->dev->channel, st->mtu_size, st->d_native1);
+        cl_ring_span sp;
+        size_t room = 0;
+        int put_open = 0;
+        if (expect > 0 && smi->ra_pending) {
+            room = cl_ring_put_begin(st->rx_queue, (size_t)expect, &sp);
+            put_open = 1;
+            if (room && ring_span_copy(st->rx_queue, &sp, st->d_native1, 1, smi->stream)) room = 0;
+        }
+        int ret = expect < 0 ? (int)expect : (smi->ra_pending ? cl_smi_ra_finish(smi) : (int)expect);
         if (ret == CL_SMI_ERR_IO) fprintf(stderr, "SMI reading operation failed\n");
         else if (ret == CL_SMI_ERR_SYNC) fprintf(stderr, "SMI data synchronization failed\n");
         if (ret < 0) ret = 0;                                            /* :34-42 */
-        if (ret) {                                                       /* rx_queue->put(interm_native_buffer1, ret)  :44 */
-            cl_ring_span sp;
+        if (put_open) {
+            if (ret == expect && room) cl_ring_put_end(st->rx_queue, room);
+            else cl_ring_put_cancel(st->rx_queue);
+        } else if (ret > 0) {                                            /* (a call whose last read() was already waited for) */
             size_t n = cl_ring_put_begin(st->rx_queue, (size_t)ret, &sp);
             if (n && (ring_span_copy(st->rx_queue, &sp, st->d_native1, 1, smi->stream) || clhip_stream_sync(smi->stream))) n = 0;
             cl_ring_put_end(st->rx_queue, n);
-        } else
-            usleep(500);                                                 /* nothing pending: do not spin */
+        }
+        if (!ret) usleep(500);                                           /* nothing pending: do not spin */
     }
     cl_smi_readahead_cancel(smi);
     return NULL;
@@ -387,7 +401,20 @@ static int read_native_device(cl_stream *st, size_t n, int *aligned, long timeou
         const size_t claimed = cl_ring_get_begin(st->rx_queue, n, (int)timeout_us, &sp);
         if (aligned) *aligned = 0;
         if (!claimed) return 0;
-        const int bad = ring_span_copy(st->rx_queue, &sp, st->d_aiq, 0, st->astream) || clhip_stream_sync(st->astream);
+        int bad;
+        if (st->format == CL_FORMAT_CS16 && st->filter_type == CL_DIGFILT_NONE) {
+            /* no device stage follows: the ring's slots go straight to the pinned mirror (*aligned = 2 tells the caller) */
+            bad = cl_ensure((void **)&st->h_conv, &st->h_conv_cap, claimed * 4 + 64, 1, 1);
+            uint8_t *base = (uint8_t *)cl_ring_storage(st->rx_queue), *dst = (uint8_t *)st->h_conv;
+            for (int k = 0; k < 2 && !bad; k++) {
+                if (!sp.len[k]) continue;
+                bad = clhip_memcpy_d2h(dst, base + 4 * sp.pos[k], 4 * sp.len[k], st->astream);
+                dst += 4 * sp.len[k];
+            }
+            if (aligned) *aligned = 2;
+        } else
+            bad = ring_span_copy(st->rx_queue, &sp, st->d_aiq, 0, st->astream);
+        bad = bad || clhip_stream_sync(st->astream);
         cl_ring_get_end(st->rx_queue, claimed);
         if (bad) return 0;
         const int got = (int)claimed;
@@ -399,7 +426,11 @@ static int read_native_device(cl_stream *st, size_t n, int *aligned, long timeou
         }
         return got;
     }
-    int ret = cl_smi_read_device(smi, st->dev->channel, n, 0, aligned);
+    /* up to one native batch per call (what every client of the reference asks for): the chunk-at-a-time reader,
+     * which has the NEXT batch's bytes on their way to the device while this one is analysed and copied out */
+    int ret;
+    if (n <= st->mtu_size) { ret = cl_smi_read_device_ra(smi, st->dev->channel, n, NULL); if (aligned) *aligned = 0; }
+    else ret = cl_smi_read_device(smi, st->dev->channel, n, 0, aligned);
     if (ret < 0) {
         if (ret == CL_SMI_ERR_IO) printf("reader thread failed to read SMI!\n");    /* :270 */
         ret = 0;                                                                    /* :266-276 */
@@ -429,8 +460,9 @@ int cl_readStream(cl_device *dev, cl_stream *st, void *const *buffs, size_t numE
         int res = read_native_device(st, numElems, &aligned, timeoutUs);
         if (res <= 0) return res;
         if (st->use_async) {            /* one PCIe crossing: device -> pinned mirror -> the client's buffer */
-            if (cl_ensure((void **)&st->h_conv, &st->h_conv_cap, (size_t)res * 4 + 64, 1, 1) ||
-                clhip_memcpy_d2h(st->h_conv, st->d_aiq, (size_t)res * 4, st->astream) || clhip_stream_sync(st->astream)) return 0;
+            if (aligned != 2 &&
+                (cl_ensure((void **)&st->h_conv, &st->h_conv_cap, (size_t)res * 4 + 64, 1, 1) ||
+                 clhip_memcpy_d2h(st->h_conv, st->d_aiq, (size_t)res * 4, st->astream) || clhip_stream_sync(st->astream))) return 0;
             memcpy(out, st->h_conv, (size_t)res * 4);
             return res;
         }

@@ -55,6 +55,7 @@ _SIGS = {
     "cl_ring_on_device": (C.c_int, [C.c_void_p]),
     "cl_ring_put_begin": (C.c_size_t, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "cl_ring_put_end": (None, [C.c_void_p, C.c_size_t]),
+    "cl_ring_put_cancel": (None, [C.c_void_p]),
     "cl_ring_get_begin": (C.c_size_t, [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "cl_ring_get_end": (None, [C.c_void_p, C.c_size_t]),
     "cl_ring_destroy": (None, [C.c_void_p]),

@@ -337,6 +337,7 @@ void    *cl_ring_storage(const cl_ring *r);                  /* base of the arra
 int      cl_ring_on_device(const cl_ring *r);
 size_t   cl_ring_put_begin(cl_ring *r, size_t length, cl_ring_span *span);              /* returns elements accepted */
 void     cl_ring_put_end(cl_ring *r, size_t accepted);
+void     cl_ring_put_cancel(cl_ring *r);                       /* instead of _end: the put never happened */
 size_t   cl_ring_get_begin(cl_ring *r, size_t length, int timeout_us, cl_ring_span *span); /* 0: nothing claimed, not locked */
 void     cl_ring_get_end(cl_ring *r, size_t claimed);
 size_t   cl_ring_put(cl_ring *r, const void *data, size_t length);                      /* host data, either storage */
