@@ -54,6 +54,7 @@ def parse():
                     help="c2 (default, the BASELINE.json metric) | c4: 256 streams x 2^24, FIR128 + 5/4, sharded (strong "
                          "scaling) | c1 / c3 / c5 / iir: the other BASELINE.json configs and the a6 filter, one stream set "
                          "per GPU (weak scaling), same JSON shape with their own algorithmic bytes")
+    ap.add_argument("--streams", type=int, default=256, help="c4 only: total streams (32 = the share of one GPU of the 8-GPU job)")
     ap.add_argument("--fanout", action="store_true", help="c4 only: rank 0 holds all raw buffers and scatters them over xGMI first")
     return ap.parse_args()
 
@@ -97,12 +98,26 @@ def cpu_baseline(taps, d_words, budget_s):
                       f"orc_rx_pipe_f32_mt (unpack+sync -> /4096 -> FIR64 -> 3/2, fp32 AVX2, OpenMP)"}, out
 
 
+def pmc_traffic(workload):
+    """HBM bytes per step measured with rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections;
+    tools/collect_workload_profiles.sh) and committed under profiles/: (bytes, source) or (None, None)."""
+    for rnd in ("r02", "r01"):
+        f = os.path.join(ROOT, "profiles", rnd, f"{workload}_pmc.json")
+        if os.path.exists(f):
+            try:
+                d = json.load(open(f))["_derived"]
+                return round(d.get("traffic_bytes_per_step", d.get("traffic_bytes_per_launch"))), f"profiles/{rnd}/{workload}_pmc.json"
+            except Exception:
+                pass
+    return None, None
+
+
 def bench_c4(a, world, rank, dev, dist, red_dev, arch, taps):
     """Config 4 (secondary, not the BASELINE metric): 256 independent 4 MS/s streams, FIR128 + 5/4,
     stream s on rank s mod N, no data-path collective; --fanout adds the one real exchange step
     (root scatters the raw buffers with direct sends) and reports it separately."""
     from cariboulite_amd import hip, synth, shard
-    n_streams = 256
+    n_streams = a.streams
     n = 1 << (24 if a.log2_samples == 28 else a.log2_samples)
     mine = shard.assign_streams(n_streams, world, rank)
     fan_s = None
@@ -130,15 +145,17 @@ def bench_c4(a, world, rank, dev, dist, red_dev, arch, taps):
     if rank == 0:
         value = n_streams * n * a.steps / dt / 1e6
         print(json.dumps({
-            "metric": "Msamples/s through unpack+FIR(128)+resample(5/4) pipe, 256 streams", "value": round(value, 1),
+            "metric": f"Msamples/s through unpack+FIR(128)+resample(5/4) pipe, {n_streams} streams", "value": round(value, 1),
             "unit": "Msamples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"config 4: 256 streams x 2^{int(np.log2(n))} samples, FIR128 + 5/4, stream s on rank s mod N",
+            "config": {"workload": f"config 4: {n_streams} streams x 2^{int(np.log2(n))} samples, FIR128 + 5/4, stream s on rank s mod N",
                        "streams_per_gpu": len(mine), "arch": arch, "fanout_scatter_s": fan_s},
             "roofline": {"bound": "hbm", "achieved": round(14.0 * n_streams * n * a.steps / dt / 1e9 / world, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s per GPU",
-                         "frac": round(14.0 * n_streams * n * a.steps / dt / 1e9 / world / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(14.0 * n_streams * n * a.steps / dt / 1e9 / world / HBM_PEAK_GBS, 4),
+                         "traffic": pmc_traffic("c4")[0] if (n_streams == 32 * world and n == 1 << 24) else None,
+                         "traffic_source": pmc_traffic("c4")[1], "kernel": "rx_pipe_fused_kernel<PipeCfg<128,5,4,8,MODE_IQ,16,256,FFA>>",
                          "algorithmic_frac_of_fp32_valu_peak": round(552.0 * n_streams * n * a.steps / dt / 1e12 / world / VALU_PEAK_TFLOPS, 4)}}),
             flush=True)
     if dist is not None:
@@ -206,7 +223,9 @@ def bench_secondary(a, world, rank, dev, dist, red_dev, arch, taps):
             "vs_baseline": None, "dtype": "f64" if a.workload == "iir" else "f32", "data": "synthetic",
             "config": {"workload": desc, "arch": arch, "parallelism": f"{world} independent copy(ies), no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s per GPU",
-                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "kernel": kern,
+                         "frac": round(ach / HBM_PEAK_GBS, 4),
+                         "traffic": pmc_traffic(a.workload)[0] if a.log2_samples == 28 else None, "traffic_unit": "HBM bytes per step",
+                         "traffic_source": pmc_traffic(a.workload)[1], "kernel": kern,
                          "algorithmic_bytes_per_sample": round(bytes_per, 3),
                          "note": "whole step (all launches of the workload), HIP-event free: wall clock of the timed region"}}),
             flush=True)
@@ -300,14 +319,9 @@ def main():
     if rank == 0:
         # HBM traffic of the fused kernel from PMC counters: measured in separate rocprofv3 --pmc passes
         # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; tools/pmc_summ.py) and committed under profiles/
-        traffic, traffic_src = None, None
-        pmc_file = os.path.join(ROOT, "profiles", "r01", "c_pmc.json")
-        if a.log2_samples == 28 and os.path.exists(pmc_file):
-            try:
-                traffic = round(json.load(open(pmc_file))["_derived"]["traffic_bytes_per_launch"])
-                traffic_src = "profiles/r01/c_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
-            except Exception:
-                traffic = None
+        traffic, traffic_src = pmc_traffic("c2") if a.log2_samples == 28 else (None, None)
+        if traffic is None and a.log2_samples == 28:
+            traffic, traffic_src = pmc_traffic("c")            # round 1 named its files c_*
         value = shard.job_throughput(n, a.steps, dt, world) / 1e6
         achieved = ALGO_BYTES_PER_SAMPLE * n / kern_avg_s / 1e9
         res = {

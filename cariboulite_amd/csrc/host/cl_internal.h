@@ -40,6 +40,7 @@ struct cl_smi {
     uint32_t sample_rate;
     cl_fifo rx, tx;
     pthread_mutex_t fifo_mu;      /* feeder thread vs reader thread (ASYNC mode) */
+    pthread_cond_t fifo_fed;      /* signalled by every feed: poll(POLLIN) of the reference's timeout read */
     size_t max_read;
     int tx_mode;
     /* device / pinned buffers, grown on demand */
@@ -81,7 +82,9 @@ int cl_smi_read_pipe_device(cl_smi *dev, int channel, size_t length_samples, clh
 int cl_smi_read_device_ra(cl_smi *dev, int channel, size_t length_samples, int16_t *d_iq);
 long cl_smi_ra_launch(cl_smi *dev, int channel, size_t length_samples, int16_t *d_iq);   /* its two halves: the caller may queue */
 int cl_smi_ra_finish(cl_smi *dev);                                                      /* work on the seam's stream in between */
-void cl_smi_readahead_cancel(cl_smi *dev);     /* bytes staged ahead go back to the front of the FIFO */
+void cl_smi_readahead_cancel(cl_smi *dev);
+/* poll(POLLIN, timeout) on the injected byte stream: returns 1 when bytes are pending (at once or within timeout_us) */
+int cl_smi_wait_bytes(cl_smi *dev, long timeout_us);     /* bytes staged ahead go back to the front of the FIFO */
 /* copy the slots the reference writes from the device results to host buffers */
 int cl_smi_copy_out(cl_smi *dev, cl_sample_complex_int16 *buffer, cl_sample_meta *metadata, int upto_chunk);
 int cl_ensure(void **p, size_t *cap, size_t need, size_t elem, int pinned);

@@ -3,6 +3,8 @@
  * behaviour as caribou_smi_read / caribou_smi_write, with the /dev/smi fd
  * replaced by an injected byte FIFO and the per-chunk analysis
  * (caribou_smi.c:235-393) / packing (:684-717) done by HIP kernels. */
+#include <time.h>
+
 #include "cl_internal.h"
 
 void cl_seterr(char *dst, size_t n, const char *fmt, ...)
@@ -87,6 +89,7 @@ cl_smi *cl_smi_init(int device)
     dev->stream = clhip_stream_create();
     if (!dev->stream) { free(dev); return NULL; }
     pthread_mutex_init(&dev->fifo_mu, NULL);
+    pthread_cond_init(&dev->fifo_fed, NULL);
     return dev;
 }
 
@@ -111,8 +114,26 @@ int cl_smi_feed_bytes(cl_smi *dev, const uint8_t *b, size_t n)
 {
     pthread_mutex_lock(&dev->fifo_mu);
     int rc = cl_fifo_push(&dev->rx, b, n);
+    pthread_cond_broadcast(&dev->fifo_fed);
     pthread_mutex_unlock(&dev->fifo_mu);
     return rc;
+}
+
+/* caribou_smi_timeout_read's poll(POLLIN, timeout) (caribou_smi.c:466-492) on the injected stream */
+int cl_smi_wait_bytes(cl_smi *dev, long timeout_us)
+{
+    struct timespec until;
+    clock_gettime(CLOCK_REALTIME, &until);
+    until.tv_sec += timeout_us / 1000000;
+    until.tv_nsec += (timeout_us % 1000000) * 1000L;
+    if (until.tv_nsec >= 1000000000L) { until.tv_sec++; until.tv_nsec -= 1000000000L; }
+    pthread_mutex_lock(&dev->fifo_mu);
+    int expired = 0;
+    while (dev->rx.len == 0 && !dev->ahead.valid && !expired)
+        expired = pthread_cond_timedwait(&dev->fifo_fed, &dev->fifo_mu, &until) != 0;
+    const int ready = dev->rx.len != 0 || dev->ahead.valid;
+    pthread_mutex_unlock(&dev->fifo_mu);
+    return ready;
 }
 size_t cl_smi_pending_bytes(const cl_smi *dev) { return dev->rx.len + (dev->ahead.valid ? dev->ahead.len : 0); }   /* staged ahead = still pending */
 void   cl_smi_set_max_read(cl_smi *dev, size_t m) { dev->max_read = m; }

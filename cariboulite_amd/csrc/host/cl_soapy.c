@@ -154,7 +154,7 @@ static void *reader_thread_fn(void *arg)
             if (n && (ring_span_copy(st->rx_queue, &sp, st->d_native1, 1, smi->stream) || clhip_stream_sync(smi->stream))) n = 0;
             cl_ring_put_end(st->rx_queue, n);
         }
-        if (!ret) usleep(500);                                           /* nothing pending: do not spin */
+        if (!ret) cl_smi_wait_bytes(smi, 2000);                          /* nothing pending: poll(POLLIN) with a timeout, do not spin */
     }
     cl_smi_readahead_cancel(smi);
     return NULL;

@@ -25,7 +25,7 @@ for name, fmt, dt, width, args, bw in (
     buf = np.zeros((2 * MTU, width), dt)
     t_feed = t_read = 0.0
     got = 0
-    for rep in range(3):
+    for rep in range(9 if (args and "ASYNC" in args) else 3):
         t0 = time.perf_counter()
         if args and "ASYNC" in args:
             sdr.feedSmiBytes(b[: 8 * NB])          # stay inside the ring: 8 of its 16 MTUs
