@@ -27,6 +27,7 @@
 // F, g, P^(2^d), P^i, Q^(2^d) and Q^i are built on the host in fp64 by simulating the cascade, once per filter
 // (iir_plan_for keeps them on the device in a buffer the shim owns).
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -213,6 +214,7 @@ struct IirPlan {
     double Q[IIR_MSZ];                      // P^TILE
     double qpow2[14][IIR_MSZ];              // Q^(2^d); [8 + d] = (Q^256)^(2^d) chains the groups
     double qpow[IIR_GROUP][IIR_MSZ];        // Q^i
+    int horizon;                            // tiles after which a carried state has decayed below 1e-18 (0: unknown / too long)
 };
 
 // K1: zero-state end vector per segment (written to ZS) and the tile's zero-carry end vector.
@@ -450,6 +452,187 @@ __global__ __launch_bounds__(IIR_TILE) void iir_k3_kernel(const IirPlan *__restr
     iir_tile_store(xt, n - tile0, iir_sm, t);
 }
 
+
+// ---------------------------------------------------------------------------
+// Single pass (default).  The stream is read ONCE and written once: a persistent wave takes tiles by ticket,
+// stages a tile in LDS, forms every segment's zero-state end vector (the K1 matrix FIR), scans them over the tile
+// (zero carry) and publishes the tile's zero-carry end vector -- its AGGREGATE.  The state entering the tile is then
+//     cv = sum_{k=1..H} Q^(k-1) aggregate(tile - k)            (+ Q^tile * carried state for the first H tiles)
+// where H = plan->horizon is the number of tiles after which ANY reachable state has decayed below 1e-18 in absolute
+// terms (int16 inputs bound the state; the bound is evaluated on the host from |Q^H| and the filter's l1 gains, far
+// below the 1e-8 rounding noise the fp64 sums carry anyway).  So a tile waits for H predecessors' aggregates -- not
+// for their prefixes: there is no chain through the launch, every tile is done a fixed time after it starts, and a
+// filter too narrow for H <= IIR_HMAX takes the four-kernel scan instead.  Lane t's start state is the exclusive
+// scan value + P^t cv; it runs the recursion over its LDS row in place and the tile leaves with coalesced stores
+// while the next tile's loads (issued a whole tile earlier) are already in registers.
+//   Publication: an aggregate is 2D doubles written with relaxed agent-scope 64-bit atomic stores into slots the
+// host pre-set to all-ones (a NaN no aggregate can be): a reader polls until none of the 2D words is the sentinel,
+// so no flag, no fence and no store ordering is needed.  Tickets make every predecessor a wave that is already
+// running and waits for nothing younger: the poll always ends (it is bounded all the same).
+// ---------------------------------------------------------------------------
+#define IIR_HMAX 8
+#define IIR_SENTINEL 0xFFFFFFFFFFFFFFFFull
+
+template <int NS>
+__global__ __launch_bounds__(IIR_TILE, 2) void iir_onepass_kernel(const IirPlan *__restrict__ plan, IirCoef c, uint32_t *__restrict__ iq,
+                                                                  long stride, long n, long n_seg, long n_tiles, int n_streams,
+                                                                  unsigned int *ticket, unsigned long long *agg,
+                                                                  const double *__restrict__ state_in, double *__restrict__ state_out,
+                                                                  int horizon, int *err)
+{
+    constexpr int D = 2 * NS, D2 = 2 * D;
+    extern __shared__ __attribute__((aligned(16))) uint32_t iir_sm[];
+    const int t0 = threadIdx.x;
+    const long total = n_tiles * n_streams;
+
+    unsigned int tk = 0;
+    if (t0 == 0) tk = atomicAdd(ticket, 1u) + 1u;                      // the counter starts at all-ones
+    long T = (long)(unsigned)__builtin_amdgcn_readfirstlane((int)tk);
+    u32x4 raw[IIR_NLD];
+    if (T < total) {
+        const long b = T / n_streams, s = T % n_streams;
+        iir_tile_issue(iq + s * stride + b * IIR_TILE * IIR_SEG, n - b * IIR_TILE * IIR_SEG, raw, t0);
+    }
+    while (T < total) {
+        // per-iteration values stay per-iteration: otherwise the compiler hoists every lane address of the staging
+        // code and every scalar table load out of the persistent loop and spills them
+        int t = t0;
+        const IirPlan *pl = plan;
+        asm volatile("" : "+v"(t));
+        asm volatile("" : "+s"(pl));
+        const cdouble_t *pow2 = (const cdouble_t *)&pl->pow2[0][0];
+        const cdouble_t *__restrict__ G = (const cdouble_t *)&pl->G[0][0];
+        const long b = T / n_streams, s = T % n_streams;
+        const long tile0 = b * IIR_TILE * IIR_SEG;
+        uint32_t *xt = iq + s * stride + tile0;
+        if (t == 0) tk = atomicAdd(ticket, 1u) + 1u;                   // the next tile's ticket: its loads go out early
+        iir_tile_commit(raw, iir_sm, t);
+        __syncthreads();
+        const long Tn = (long)(unsigned)__builtin_amdgcn_readfirstlane((int)tk);
+        // zero-state end vector of the lane's segment: zs = sum_k (F^(63-k) g) x[k]
+        uint32_t *x = iir_sm + t * IIR_PITCH;
+        double v[D2];
+#pragma unroll
+        for (int k = 0; k < D2; k++) v[k] = 0.0;
+#pragma unroll 2
+        for (int k = 0; k < IIR_SEG; k += 4) {
+            const u32x4 w = *(const u32x4 *)(x + k);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const double xi = (double)(int16_t)(w[j] & 0xFFFF), xq = (double)(int16_t)(w[j] >> 16);
+                const cdouble_t *g = G + (IIR_SEG - 1 - (k + j)) * IIR_MAX_DIM;
+#pragma unroll
+                for (int r = 0; r < D; r++) {
+                    const double gr = g[r];
+                    v[r] = __builtin_fma(gr, xi, v[r]);
+                    v[D + r] = __builtin_fma(gr, xq, v[D + r]);
+                }
+            }
+        }
+        wave_scan<D>(v, pow2, t);                                      // v = state after the lane's segment, zero carry-in
+        unsigned long long *mine = agg + (s * n_tiles + b) * D2;
+        if (t == IIR_TILE - 1) {
+#pragma unroll
+            for (int k = 0; k < D2; k++)
+                __hip_atomic_store(mine + k, (unsigned long long)__builtin_bit_cast(unsigned long long, v[k]), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // state entering the tile
+        double cv[D2];
+        {
+            const long j = b - 1 - t;                                  // lane t looks at tile b-1-t; tile -1 = the carried state
+            const bool want = t < horizon && j >= -1;
+            double a[D2];
+#pragma unroll
+            for (int k = 0; k < D2; k++) a[k] = 0.0;
+            if (want && j == -1) {
+                const double *st = state_in + s * 2 * IIR_MAX_DIM;
+#pragma unroll
+                for (int k = 0; k < D2; k++) a[k] = st[(k / D) * IIR_MAX_DIM + (k % D)];
+            }
+            bool pending = want && j >= 0;
+            const unsigned long long *theirs = agg + (s * n_tiles + (j >= 0 ? j : 0)) * D2;
+            int guard = 0;
+            while (__any(pending)) {
+                if (pending) {
+                    bool ok = true;
+#pragma unroll
+                    for (int k = 0; k < D2; k++) {
+                        const unsigned long long w = __hip_atomic_load(theirs + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok &= w != IIR_SENTINEL;
+                        a[k] = __builtin_bit_cast(double, w);
+                    }
+                    if (ok) pending = false;
+                    else if (++guard > (1 << 22)) { *err = 1; pending = false; }   // never reached: predecessors run and wait for nothing younger
+                }
+            }
+            // cv = a_0 + Q (a_1 + Q (a_2 + ...)): Horner over the lanes that looked, the lane's vector broadcast by
+            // v_readlane, the one matrix Q by scalar loads -- no per-lane tables, nothing to reduce
+            const cdouble_t *qm = (const cdouble_t *)&pl->Q[0];
+#pragma unroll
+            for (int k = 0; k < D2; k++) cv[k] = 0.0;
+            for (int h = horizon - 1; h >= 0; h--) {                   // uniform
+                double nx[D2];
+#pragma unroll
+                for (int k = 0; k < D2; k++) {
+                    const unsigned long long bits = __builtin_bit_cast(unsigned long long, a[k]);
+                    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)bits, h);
+                    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(bits >> 32), h);
+                    nx[k] = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+                }
+                matvec<D, true>(qm, cv, nx);
+                matvec<D, true>(qm, cv + D, nx + D);
+#pragma unroll
+                for (int k = 0; k < D2; k++) cv[k] = nx[k];
+            }
+        }
+        // the lane's true start state: what the lanes before it left (zero carry) + P^t cv, P^t built from the
+        // bits of t with the scan's own P^(2^d) tables (scalar loads; a per-lane table would cost 72 VGPRs)
+        double zi[D], zq[D];
+        {
+#pragma unroll 1
+            for (int d = 0; d < 6; d++) {
+                if (t & (1 << d)) {
+                    const cdouble_t *m = pow2 + d * IIR_MSZ;
+                    double nx[D2];
+                    matvec<D, false>(m, cv, nx);
+                    matvec<D, false>(m, cv + D, nx + D);
+#pragma unroll
+                    for (int k = 0; k < D2; k++) cv[k] = nx[k];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < D2; k++) {
+                const double p = __shfl_up(v[k], 1, 64);
+                const double st = (t == 0 ? 0.0 : p) + cv[k];
+                if (k < D) zi[k] = st; else zq[k - D] = st;
+            }
+        }
+        // the next tile's words go out now and land while the recursion (the longest phase) runs
+        if (Tn < total) {
+            const long bn = Tn / n_streams, sn = Tn % n_streams;
+            iir_tile_issue(iq + sn * stride + bn * IIR_TILE * IIR_SEG, n - bn * IIR_TILE * IIR_SEG, raw, t);
+        }
+        const long seg = b * IIR_TILE + t;
+        if (seg < n_seg) {
+            if (tile0 + (long)IIR_TILE * IIR_SEG <= n) iir_k3_segment<NS, true>(c, x, IIR_SEG, zi, zq);
+            else {
+                const long cnt = n - seg * IIR_SEG < IIR_SEG ? n - seg * IIR_SEG : IIR_SEG;
+                iir_k3_segment<NS, false>(c, x, cnt, zi, zq);
+            }
+            if (seg == n_seg - 1) {
+                double *so = state_out + s * 2 * IIR_MAX_DIM;
+#pragma unroll
+                for (int k = 0; k < D; k++) { so[k] = zi[k]; so[IIR_MAX_DIM + k] = zq[k]; }
+            }
+        }
+        __syncthreads();
+        iir_tile_store(xt, n - tile0, iir_sm, t);
+        __syncthreads();                                               // the rows are free for the next tile
+        T = Tn;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // host: transition matrices by simulating the cascade
 // ---------------------------------------------------------------------------
@@ -513,6 +696,37 @@ static void iir_plan_build(const double *sos, int n_stages, IirPlan *pl)
     for (int d = 1; d < 14; d++) mat_mul(dim, pl->qpow2[d - 1], pl->qpow2[d - 1], pl->qpow2[d]);
     for (int r = 0; r < dim; r++) pl->qpow[0][r * IIR_MAX_DIM + r] = 1.0;
     for (int i = 1; i < IIR_GROUP; i++) mat_mul(dim, pl->qpow[i - 1], pl->Q, pl->qpow[i]);
+    // Horizon of the single-pass kernel.  int16 inputs bound every reachable state component c by
+    // 32768 * sum_n |h_c[n]| (h_c = impulse response of that component); a state entering tile b-H reaches tile b
+    // as Q^H s, so max_r sum_c |Q^H[r][c]| smax[c] bounds what dropping it costs.  Below 1e-18 (absolute; the
+    // outputs are integers and the fp64 sums themselves carry ~1e-8 of rounding) the tile may ignore it.
+    pl->horizon = 0;
+    {
+        double smax[IIR_MAX_DIM] = {0}, z[IIR_MAX_DIM] = {0};
+        (void)host_step(c, z, 1.0);
+        bool settled = false;
+        for (long i = 0; i < 8000000 && !settled; i++) {
+            double m = 0;
+            for (int r = 0; r < dim; r++) { smax[r] += fabs(z[r]); m = fmax(m, fabs(z[r])); }
+            if (!(m < 1e300)) break;                             // diverging: not a filter this path can bound
+            if (i > 64 && m < 1e-40) settled = true;
+            (void)host_step(c, z, 0.0);
+        }
+        if (settled) {
+            double Qk[IIR_MSZ];
+            memcpy(Qk, pl->Q, sizeof Qk);
+            for (int k = 1; k <= IIR_HMAX; k++) {
+                double worst = 0;
+                for (int r = 0; r < dim; r++) {
+                    double acc = 0;
+                    for (int cc = 0; cc < dim; cc++) acc += fabs(Qk[r * IIR_MAX_DIM + cc]) * 65536.0 * smax[cc];
+                    worst = fmax(worst, acc);
+                }
+                if (worst < 1e-18) { pl->horizon = k; break; }
+                mat_mul(dim, Qk, pl->Q, Qk);
+            }
+        }
+    }
 }
 
 // Transition tables per (device, filter): built once, uploaded once into a buffer the shim owns, kept for the life
@@ -534,10 +748,14 @@ static const IirPlanEntry *iir_plan_for(const double *sos, int n_stages)
     std::lock_guard<std::mutex> lock(mu);
     for (const IirPlanEntry *e : cache)
         if (e->device == device && e->n_stages == n_stages && !memcmp(e->sos, sos, sizeof(double) * 5 * n_stages)) return e;
-    if (cache.size() >= 256) {                  // pathological filter churn: start over once nothing is in flight
-        (void)hipDeviceSynchronize();
-        for (IirPlanEntry *e : cache) { clhip_free(e->dev); delete e; }
-        cache.clear();
+    if (cache.size() >= 256) {                  // pathological filter churn: drop THIS device's tables once nothing is in
+        (void)hipDeviceSynchronize();           // flight on it (entries of other devices may be in use by other threads)
+        std::vector<IirPlanEntry *> keep;
+        for (IirPlanEntry *e : cache) {
+            if (e->device == device) { clhip_free(e->dev); delete e; }
+            else keep.push_back(e);
+        }
+        cache.swap(keep);
     }
     IirPlanEntry *e = new (std::nothrow) IirPlanEntry();
     if (!e) { clhip_set_error("clhip_iir_cs16: out of memory"); return nullptr; }
@@ -564,6 +782,45 @@ extern "C" size_t clhip_iir_workspace_bytes(size_t n_samples, int n_stages)
 {
     (void)n_stages;
     return 256 + iir_var_bytes(n_samples);
+}
+
+// workgroups (= waves) the single-pass kernel keeps resident: 8 per CU (17 KB of LDS each, 2 per SIMD), per device
+static int iir_resident_waves(void)
+{
+    static std::mutex mu;
+    static int cached[64];
+    int device = 0, cus = 256;
+    (void)hipGetDevice(&device);
+    std::lock_guard<std::mutex> lock(mu);
+    if (device >= 0 && device < 64 && cached[device]) return cached[device];
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+    const char *e = getenv("CLHIP_IIR_WG_PER_CU");
+    const int per_cu = e && atoi(e) > 0 ? atoi(e) : 8;
+    if (device >= 0 && device < 64) cached[device] = cus * per_cu;
+    return cus * per_cu;
+}
+
+template <int NS>
+static int iir_launch_onepass(const IirPlan *d_plan, const IirPlan &plan, double *d_state, uint32_t *d_iq, long stride, long n,
+                              int n_streams, double *ws, hipStream_t s)
+{
+    constexpr int D2 = 4 * NS;
+    const long n_seg = (long)clhip_div_up((size_t)n, IIR_SEG), n_tiles = (long)clhip_div_up((size_t)n_seg, IIR_TILE);
+    // workspace: [ticket, error word | pad to 16 B][aggregates: n_streams x n_tiles x 2D][copy of the carried states]
+    unsigned int *ticket = (unsigned int *)ws;
+    unsigned long long *agg = (unsigned long long *)(ws + 2);
+    double *state_copy = (double *)(agg + (size_t)n_tiles * n_streams * D2);
+    int *err = (int *)(state_copy + (size_t)n_streams * 2 * IIR_MAX_DIM);
+    CLHIP_CHECK(hipMemsetAsync(ws, 0xFF, 16 + sizeof(unsigned long long) * (size_t)n_tiles * n_streams * D2, s));
+    CLHIP_CHECK(hipMemsetAsync(err, 0, sizeof(int), s));
+    // the kernel writes the new carried state while early tiles may still read the old one: they read a copy
+    CLHIP_CHECK(hipMemcpyAsync(state_copy, d_state, sizeof(double) * 2 * IIR_MAX_DIM * n_streams, hipMemcpyDeviceToDevice, s));
+    const long total = n_tiles * n_streams;
+    const int resident = iir_resident_waves();
+    const unsigned grid = (unsigned)(total < resident ? total : resident);
+    hipLaunchKernelGGL(iir_onepass_kernel<NS>, dim3(grid), dim3(IIR_TILE), IIR_LDS_WORDS * 4, s, d_plan, plan.coef, d_iq, stride, n,
+                       n_seg, n_tiles, n_streams, ticket, agg, (const double *)state_copy, d_state, plan.horizon, err);
+    return 0;
 }
 
 template <int NS>
@@ -608,6 +865,20 @@ extern "C" int clhip_iir_cs16_batch(const double *h_sos, int n_stages, double *d
     const IirPlan &plan = pe->host;
     const IirPlan *d_plan = pe->dev;
     double *wsv = (double *)d_ws;
+    // single pass unless the filter's memory is too long for it (or CLHIP_IIR_ONEPASS=0: the four-kernel scan, A/B)
+    static const int onepass_env = getenv("CLHIP_IIR_ONEPASS") ? atoi(getenv("CLHIP_IIR_ONEPASS")) : 1;
+    if (onepass_env && plan.horizon >= 1 && plan.horizon <= IIR_HMAX) {
+        int rc;
+        switch (n_stages) {
+        case 1: rc = iir_launch_onepass<1>(d_plan, plan, d_state, (uint32_t *)d_iq, (long)stride_samples, (long)n_samples, n_streams, wsv, s); break;
+        case 2: rc = iir_launch_onepass<2>(d_plan, plan, d_state, (uint32_t *)d_iq, (long)stride_samples, (long)n_samples, n_streams, wsv, s); break;
+        case 3: rc = iir_launch_onepass<3>(d_plan, plan, d_state, (uint32_t *)d_iq, (long)stride_samples, (long)n_samples, n_streams, wsv, s); break;
+        default: rc = iir_launch_onepass<4>(d_plan, plan, d_state, (uint32_t *)d_iq, (long)stride_samples, (long)n_samples, n_streams, wsv, s); break;
+        }
+        if (rc) return -1;
+        CLHIP_CHECK_LAUNCH();
+        return 0;
+    }
     switch (n_stages) {
     case 1: iir_launch<1>(d_plan, plan.coef, d_state, (uint32_t *)d_iq, (long)stride_samples, (long)n_samples, n_streams, wsv, s); break;
     case 2: iir_launch<2>(d_plan, plan.coef, d_state, (uint32_t *)d_iq, (long)stride_samples, (long)n_samples, n_streams, wsv, s); break;

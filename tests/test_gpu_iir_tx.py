@@ -357,3 +357,52 @@ def test_iir_second_round_of_tile_groups(G, orc):
     diff = np.abs(got[-(1 << 23):].astype(np.int32) - want[-(1 << 23):].astype(np.int32))      # the part behind group 64
     assert diff.max() <= 1 and np.mean(diff != 0) < 1e-4
     assert np.mean(got[: 1 << 23] != want[: 1 << 23]) < 1e-4
+
+
+def test_iir_four_kernel_scan_still_agrees(G, orc):
+    """CLHIP_IIR_ONEPASS=0: the four-kernel blocked scan (the path of filters whose memory is too long for the
+    single-pass kernel's horizon) against the same oracle.  Child process: the switch is latched at first use."""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys, numpy as np, torch
+        sys.path.insert(0, %r)
+        from cariboulite_amd import hip, soapy
+        from oracle import oracle as orc
+        rng = np.random.default_rng(5)
+        n = 3 * 256 * 4096 + 4096 * 7 + 123
+        x = rng.integers(-4096, 4096, size=(n, 2), dtype=np.int16)
+        ref = orc.IIR(6, 4e6, 10e3)
+        want = ref.apply_cs16(x.copy())
+        s = ref.sos()
+        sos5 = np.concatenate([s[:, :3], s[:, 4:]], 1)
+        f = hip.IIR(sos5)
+        d = torch.from_numpy(x.copy()).to("cuda:0")
+        f.run(d, 2 * 256 * 4096 + 11)
+        f.run(d[2 * 256 * 4096 + 11:], n - (2 * 256 * 4096 + 11))
+        diff = np.abs(d.cpu().numpy().astype(np.int32) - want.astype(np.int32))
+        assert diff.max() <= 1 and np.mean(diff != 0) < 1e-4, (diff.max(), np.mean(diff != 0))
+        print("legacy ok")
+    """) % root
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CLHIP_IIR_ONEPASS="0"), capture_output=True, text=True)
+    assert r.returncode == 0 and "legacy ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+def test_iir_narrowest_reference_filter_many_tiles(G, orc):
+    """fc = 10 kHz (the reference's 20 kHz-bandwidth filter: the longest memory of the three, horizon of several
+    tiles in the single-pass kernel), 32 streams of 40 tiles + a ragged tail, two calls: carried state + look-back
+    near the stream start (the carried state enters through the first `horizon` tiles)."""
+    import torch
+    from cariboulite_amd import hip
+    rng = np.random.default_rng(11)
+    ns, n1, n2 = 6, 40 * 4096 + 1000, 9 * 4096 + 17
+    x = rng.integers(-4096, 4096, size=(ns, n1 + n2, 2), dtype=np.int16)
+    f = hip.IIR(_sos5(orc.IIR(6, 4e6, 10e3)), ns)
+    d = torch.from_numpy(x.copy()).to(G.DEV)
+    f.run(d, n1, stride=n1 + n2)
+    f.run(d[:, n1:], n2, stride=n1 + n2)
+    got = d.cpu().numpy()
+    for s in range(ns):
+        want = orc.IIR(6, 4e6, 10e3).apply_cs16(x[s].copy())
+        diff = np.abs(got[s].astype(np.int32) - want.astype(np.int32))
+        assert diff.max() <= 1 and np.mean(diff != 0) < 1e-4, (s, diff.max(), np.mean(diff != 0))
