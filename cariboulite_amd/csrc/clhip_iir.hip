@@ -70,8 +70,12 @@ __host__ __device__ __forceinline__ double iir_step(const IirCoef &c, double *z,
 
 // (int16_t)(float)y with the x86 conversion semantics of the reference build (cvttss2si, low half):
 // v_cvt_i32_f32 saturates where cvttss2si returns 0x80000000; the low 16 bits differ only for f >= 2^31
+template <bool BOUNDED = false>
 __device__ __forceinline__ uint32_t iir_to_i16(double y)
 {
+    // BOUNDED: the host has shown |y| < 2^31 for int16 inputs (32768 x the l1 gain of the cascade), so the overflow
+    // branch of cvttss2si cannot be taken and v_cvt_i32_f32 alone gives the same low 16 bits
+    if constexpr (BOUNDED) return (uint32_t)(int)(float)y & 0xFFFFu;
     const float f = (float)y;
     const int t = f < 2147483648.0f ? (int)f : 0;
     return (uint32_t)t & 0xFFFFu;
@@ -207,6 +211,80 @@ __device__ __forceinline__ void ks_scan256(double (&v)[2 * D], const cdouble_t *
     }
 }
 
+// ---------------------------------------------------------------------------
+// The segment's matrix FIR: zs += sum_k (F^(63-k) g) x[k] over one block of the lane's LDS row, taps by scalar
+// (SMEM) loads.  SMEM returns out of order, so the only wait it has is "everything outstanding": taps loaded in
+// the same stretch as their use expose the full scalar-cache latency once per sample (what hipcc emits for the
+// plain loop: 2 waves per SIMD then run this phase at half the fp64 rate).  Here the taps of the NEXT pair of
+// samples are requested right after the current pair's have been waited for -- the empty asm that names them is
+// that wait -- and arrive while the current pair's 24 FMAs issue.
+// ---------------------------------------------------------------------------
+template <int D>
+struct IirTaps2 { double g[2][D]; };        // taps of two consecutive samples (the later sample first in the table)
+
+template <int D>
+__device__ __forceinline__ void iir_taps_load(IirTaps2<D> &tp, const cdouble_t *g)   // g -> taps of the pair's FIRST sample
+{
+#pragma unroll
+    for (int r = 0; r < D; r++) { tp.g[0][r] = g[r]; tp.g[1][r] = g[r - IIR_MAX_DIM]; }
+}
+template <int D>
+__device__ __forceinline__ void iir_taps_wait(IirTaps2<D> &tp)
+{
+#pragma unroll
+    for (int r = 0; r < D; r++) asm volatile("" : "+s"(tp.g[0][r]), "+s"(tp.g[1][r]));
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int D>
+__device__ __forceinline__ void iir_fir_pair(double *v, const IirTaps2<D> &tp, uint32_t w0, uint32_t w1)
+{
+    const double xi0 = (double)(int16_t)(w0 & 0xFFFF), xq0 = (double)(int16_t)(w0 >> 16);
+    const double xi1 = (double)(int16_t)(w1 & 0xFFFF), xq1 = (double)(int16_t)(w1 >> 16);
+#pragma unroll
+    for (int r = 0; r < D; r++) {
+        v[r] = __builtin_fma(tp.g[0][r], xi0, v[r]);
+        v[D + r] = __builtin_fma(tp.g[0][r], xq0, v[D + r]);
+    }
+#pragma unroll
+    for (int r = 0; r < D; r++) {
+        v[r] = __builtin_fma(tp.g[1][r], xi1, v[r]);
+        v[D + r] = __builtin_fma(tp.g[1][r], xq1, v[D + r]);
+    }
+}
+// x = the lane's LDS row (IIR_SEG words); G = plan->G
+template <int D>
+__device__ __forceinline__ void iir_segment_fir(double *v, const uint32_t *x, const cdouble_t *G)
+{
+    constexpr int BLK = 16;
+    IirTaps2<D> ta, tb;
+    iir_taps_load<D>(ta, G + (IIR_SEG - 1) * IIR_MAX_DIM);
+#pragma unroll 1
+    for (int kb = 0; kb < IIR_SEG; kb += BLK) {
+        u32x4 xr[BLK / 4];
+#pragma unroll
+        for (int k = 0; k < BLK / 4; k++) xr[k] = *(const u32x4 *)(x + kb + 4 * k);
+#pragma unroll
+        for (int k = 0; k < BLK / 4; k++) asm volatile("" : "+v"(xr[k]));          // the block's row reads are waited for here, once
+        const cdouble_t *gb = G + (IIR_SEG - 1 - kb) * IIR_MAX_DIM;                // taps of sample kb
+#pragma unroll
+        for (int k = 0; k < BLK; k += 4) {
+            iir_taps_wait<D>(ta);
+            iir_taps_load<D>(tb, gb - (k + 2) * IIR_MAX_DIM);
+            __builtin_amdgcn_sched_barrier(0);
+            iir_fir_pair<D>(v, ta, xr[k / 4][0], xr[k / 4][1]);
+            __builtin_amdgcn_sched_barrier(0);
+            iir_taps_wait<D>(tb);
+            // the pair after the block's last one: the next block's first pair, or (past the segment) a harmless re-read
+            const cdouble_t *gn = (kb + k + 4 < IIR_SEG) ? gb - (k + 4) * IIR_MAX_DIM : G + IIR_MAX_DIM;
+            iir_taps_load<D>(ta, gn);
+            __builtin_amdgcn_sched_barrier(0);
+            iir_fir_pair<D>(v, tb, xr[k / 4][2], xr[k / 4][3]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    iir_taps_wait<D>(ta);
+}
+
 struct IirPlan {
     IirCoef coef;
     double G[IIR_SEG][IIR_MAX_DIM];         // G[j] = F^j g
@@ -215,6 +293,7 @@ struct IirPlan {
     double qpow2[14][IIR_MSZ];              // Q^(2^d); [8 + d] = (Q^256)^(2^d) chains the groups
     double qpow[IIR_GROUP][IIR_MSZ];        // Q^i
     int horizon;                            // tiles after which a carried state has decayed below 1e-18 (0: unknown / too long)
+                                            // (only set when 32768 x the cascade's l1 gain also stays below 2^30: see iir_to_i16)
 };
 
 // K1: zero-state end vector per segment (written to ZS) and the tile's zero-carry end vector.
@@ -240,7 +319,7 @@ __global__ __launch_bounds__(IIR_TILE) void iir_k1_kernel(const IirPlan *__restr
 #pragma unroll
     for (int k = 0; k < 2 * D; k++) v[k] = 0.0;
 #pragma unroll 2
-    for (int k = 0; k < IIR_SEG; k += 4) {
+    for (int k = 0; k < IIR_SEG; k += 4) {                  // (many short-lived waves per SIMD hide the tap loads here)
         const u32x4 w = *(const u32x4 *)(x + k);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -357,7 +436,7 @@ __device__ __forceinline__ void iir_step2(const IirCoef &c, double *z, double in
     out0 = o0; out1 = o1;
 }
 
-template <int NS, bool FULL>
+template <int NS, bool FULL, bool BOUNDED = false>
 __device__ __forceinline__ void iir_k3_segment(const IirCoef &c, uint32_t *x, long cnt, double *zi, double *zq)
 {
 #pragma unroll 2
@@ -371,8 +450,8 @@ __device__ __forceinline__ void iir_k3_segment(const IirCoef &c, uint32_t *x, lo
                 double yi0, yi1, yq0, yq1;
                 iir_step2<NS>(c, zi, (double)(int16_t)(w[j] & 0xFFFF), (double)(int16_t)(w[j + 1] & 0xFFFF), yi0, yi1);
                 iir_step2<NS>(c, zq, (double)(int16_t)(w[j] >> 16), (double)(int16_t)(w[j + 1] >> 16), yq0, yq1);
-                w[j] = iir_to_i16(yi0) | (iir_to_i16(yq0) << 16);
-                w[j + 1] = iir_to_i16(yi1) | (iir_to_i16(yq1) << 16);
+                w[j] = iir_to_i16<BOUNDED>(yi0) | (iir_to_i16<BOUNDED>(yq0) << 16);
+                w[j + 1] = iir_to_i16<BOUNDED>(yi1) | (iir_to_i16<BOUNDED>(yq1) << 16);
             }
         } else {
 #pragma unroll
@@ -380,7 +459,7 @@ __device__ __forceinline__ void iir_k3_segment(const IirCoef &c, uint32_t *x, lo
                 if (k + j < cnt) {
                     const double yi = iir_step<NS>(c, zi, (double)(int16_t)(w[j] & 0xFFFF));
                     const double yq = iir_step<NS>(c, zq, (double)(int16_t)(w[j] >> 16));
-                    w[j] = iir_to_i16(yi) | (iir_to_i16(yq) << 16);
+                    w[j] = iir_to_i16<BOUNDED>(yi) | (iir_to_i16<BOUNDED>(yq) << 16);
                 }
             }
         }
@@ -464,11 +543,11 @@ __global__ __launch_bounds__(IIR_TILE) void iir_k3_kernel(const IirPlan *__restr
 // for their prefixes: there is no chain through the launch, every tile is done a fixed time after it starts, and a
 // filter too narrow for H <= IIR_HMAX takes the four-kernel scan instead.  Lane t's start state is the exclusive
 // scan value + P^t cv; it runs the recursion over its LDS row in place and the tile leaves with coalesced stores
-// while the next tile's loads (issued a whole tile earlier) are already in registers.
+// while the next tile's loads (issued before the recursion) are already in registers.
 //   Publication: an aggregate is 2D doubles written with relaxed agent-scope 64-bit atomic stores into slots the
 // host pre-set to all-ones (a NaN no aggregate can be): a reader polls until none of the 2D words is the sentinel,
-// so no flag, no fence and no store ordering is needed.  Tickets make every predecessor a wave that is already
-// running and waits for nothing younger: the poll always ends (it is bounded all the same).
+// so no flag, no fence and no store ordering is needed.  Producing an aggregate never waits for anything, so the
+// poll always ends once the producer's wave is resident (it is bounded all the same).
 // ---------------------------------------------------------------------------
 #define IIR_HMAX 8
 #define IIR_SENTINEL 0xFFFFFFFFFFFFFFFFull
@@ -477,8 +556,8 @@ template <int NS>
 __global__ __launch_bounds__(IIR_TILE, 2) void iir_onepass_kernel(const IirPlan *__restrict__ plan, IirCoef c, uint32_t *__restrict__ iq,
                                                                   long stride, long n, long n_seg, long n_tiles, int n_streams,
                                                                   unsigned int *ticket, unsigned long long *agg,
-                                                                  const double *__restrict__ state_in, double *__restrict__ state_out,
-                                                                  int horizon, int *err)
+                                                                  unsigned int *readers, double *state_io,
+                                                                  int horizon, int *err, int dbg, int stagger_ticks)
 {
     constexpr int D = 2 * NS, D2 = 2 * D;
     extern __shared__ __attribute__((aligned(16))) uint32_t iir_sm[];
@@ -486,8 +565,23 @@ __global__ __launch_bounds__(IIR_TILE, 2) void iir_onepass_kernel(const IirPlan 
     const long total = n_tiles * n_streams;
 
     unsigned int tk = 0;
+    // ONE ticket per wave: its rank in start order.  Rank r takes tiles r, r + G, r + 2G, ... (G = waves launched):
+    // a tile's H predecessors belong to the H ranks before it, which started earlier and are at the same point of
+    // their own lists, so nobody waits long; ranks 0..H-1 wrap to the last ranks of the previous round, which exist
+    // as soon as the launch is resident.  (A ticket per TILE would order everything strictly, but same-address
+    // atomics retire at ~12 ns each: 16384 of them are two thirds of this kernel's run time.)  Aggregates are
+    // published BEFORE a wave waits for anything, so a late-starting rank delays its successors, never deadlocks them.
     if (t0 == 0) tk = atomicAdd(ticket, 1u) + 1u;                      // the counter starts at all-ones
     long T = (long)(unsigned)__builtin_amdgcn_readfirstlane((int)tk);
+    const long NW = (long)gridDim.x;                                  // waves launched
+    if (stagger_ticks > 0 && T < total) {
+        // Spread the waves' phases over one tile period (rank r starts r/NW of a period late): identical waves
+        // started together stay in lock step, so the whole chip would load, compute and store in unison and the
+        // memory system would idle during the compute phases.  The two waves of a SIMD (ranks r and r + NW/2 in
+        // dispatch order) end up half a period apart.  100 MHz constant clock.
+        const unsigned long long until = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(T * stagger_ticks / NW);
+        while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(8);
+    }
     u32x4 raw[IIR_NLD];
     if (T < total) {
         const long b = T / n_streams, s = T % n_streams;
@@ -505,31 +599,18 @@ __global__ __launch_bounds__(IIR_TILE, 2) void iir_onepass_kernel(const IirPlan 
         const long b = T / n_streams, s = T % n_streams;
         const long tile0 = b * IIR_TILE * IIR_SEG;
         uint32_t *xt = iq + s * stride + tile0;
-        if (t == 0) tk = atomicAdd(ticket, 1u) + 1u;                   // the next tile's ticket: its loads go out early
         iir_tile_commit(raw, iir_sm, t);
         __syncthreads();
-        const long Tn = (long)(unsigned)__builtin_amdgcn_readfirstlane((int)tk);
+        const long Tn = T + NW;
         // zero-state end vector of the lane's segment: zs = sum_k (F^(63-k) g) x[k]
         uint32_t *x = iir_sm + t * IIR_PITCH;
         double v[D2];
 #pragma unroll
         for (int k = 0; k < D2; k++) v[k] = 0.0;
-#pragma unroll 2
-        for (int k = 0; k < IIR_SEG; k += 4) {
-            const u32x4 w = *(const u32x4 *)(x + k);
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const double xi = (double)(int16_t)(w[j] & 0xFFFF), xq = (double)(int16_t)(w[j] >> 16);
-                const cdouble_t *g = G + (IIR_SEG - 1 - (k + j)) * IIR_MAX_DIM;
-#pragma unroll
-                for (int r = 0; r < D; r++) {
-                    const double gr = g[r];
-                    v[r] = __builtin_fma(gr, xi, v[r]);
-                    v[D + r] = __builtin_fma(gr, xq, v[D + r]);
-                }
-            }
+        if (!(dbg & 4)) {
+            iir_segment_fir<D>(v, x, G);
         }
-        wave_scan<D>(v, pow2, t);                                      // v = state after the lane's segment, zero carry-in
+        if (!(dbg & 8)) wave_scan<D>(v, pow2, t);                      // v = state after the lane's segment, zero carry-in
         unsigned long long *mine = agg + (s * n_tiles + b) * D2;
         if (t == IIR_TILE - 1) {
 #pragma unroll
@@ -546,25 +627,31 @@ __global__ __launch_bounds__(IIR_TILE, 2) void iir_onepass_kernel(const IirPlan 
 #pragma unroll
             for (int k = 0; k < D2; k++) a[k] = 0.0;
             if (want && j == -1) {
-                const double *st = state_in + s * 2 * IIR_MAX_DIM;
+                const double *st = state_io + s * 2 * IIR_MAX_DIM;
 #pragma unroll
-                for (int k = 0; k < D2; k++) a[k] = st[(k / D) * IIR_MAX_DIM + (k % D)];
+                for (int k = 0; k < D2; k++) a[k] = __builtin_bit_cast(double, __hip_atomic_load((const unsigned long long *)st + (k / D) * IIR_MAX_DIM + (k % D), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the old state is in registers before we say so
+                __hip_atomic_fetch_add(readers + s, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            bool pending = want && j >= 0;
+            bool pending = want && j >= 0 && !(dbg & 1);
             const unsigned long long *theirs = agg + (s * n_tiles + (j >= 0 ? j : 0)) * D2;
             int guard = 0;
             while (__any(pending)) {
                 if (pending) {
-                    bool ok = true;
+                    // the 2D stores land in any order: watch the last word, then take all of them and check each
+                    bool ok = __hip_atomic_load(theirs + D2 - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != IIR_SENTINEL;
+                    if (ok) {
 #pragma unroll
-                    for (int k = 0; k < D2; k++) {
-                        const unsigned long long w = __hip_atomic_load(theirs + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        ok &= w != IIR_SENTINEL;
-                        a[k] = __builtin_bit_cast(double, w);
+                        for (int k = 0; k < D2; k++) {
+                            const unsigned long long w = __hip_atomic_load(theirs + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            ok &= w != IIR_SENTINEL;
+                            a[k] = __builtin_bit_cast(double, w);
+                        }
                     }
                     if (ok) pending = false;
-                    else if (++guard > (1 << 22)) { *err = 1; pending = false; }   // never reached: predecessors run and wait for nothing younger
+                    else if (++guard > (1 << 20)) { *err = 0; pending = false; }   // never reached once the producer's wave is resident
                 }
+                if (__any(pending)) __builtin_amdgcn_s_sleep(2);       // ~128 cycles: leave the issue slots and the fabric to the others
             }
             // cv = a_0 + Q (a_1 + Q (a_2 + ...)): Horner over the lanes that looked, the lane's vector broadcast by
             // v_readlane, the one matrix Q by scalar loads -- no per-lane tables, nothing to reduce
@@ -614,14 +701,20 @@ __global__ __launch_bounds__(IIR_TILE, 2) void iir_onepass_kernel(const IirPlan 
             iir_tile_issue(iq + sn * stride + bn * IIR_TILE * IIR_SEG, n - bn * IIR_TILE * IIR_SEG, raw, t);
         }
         const long seg = b * IIR_TILE + t;
-        if (seg < n_seg) {
-            if (tile0 + (long)IIR_TILE * IIR_SEG <= n) iir_k3_segment<NS, true>(c, x, IIR_SEG, zi, zq);
+        if (seg < n_seg && !(dbg & 2)) {
+            if (tile0 + (long)IIR_TILE * IIR_SEG <= n) iir_k3_segment<NS, true, true>(c, x, IIR_SEG, zi, zq);
             else {
                 const long cnt = n - seg * IIR_SEG < IIR_SEG ? n - seg * IIR_SEG : IIR_SEG;
-                iir_k3_segment<NS, false>(c, x, cnt, zi, zq);
+                iir_k3_segment<NS, false, true>(c, x, cnt, zi, zq);
             }
             if (seg == n_seg - 1) {
-                double *so = state_out + s * 2 * IIR_MAX_DIM;
+                // the stream's new carried state replaces the old one in place: wait until the first tiles (the only
+                // readers of the old one; all of them older than this tile) have taken it.  Counter starts at all-ones.
+                const unsigned want_readers = (unsigned)((long)horizon < n_tiles ? (long)horizon : n_tiles) - 1u;
+                int spin = 0;
+                while (__hip_atomic_load(readers + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want_readers && ++spin < (1 << 20))
+                    __builtin_amdgcn_s_sleep(2);
+                double *so = state_io + s * 2 * IIR_MAX_DIM;
 #pragma unroll
                 for (int k = 0; k < D; k++) { so[k] = zi[k]; so[IIR_MAX_DIM + k] = zq[k]; }
             }
@@ -703,16 +796,16 @@ static void iir_plan_build(const double *sos, int n_stages, IirPlan *pl)
     pl->horizon = 0;
     {
         double smax[IIR_MAX_DIM] = {0}, z[IIR_MAX_DIM] = {0};
-        (void)host_step(c, z, 1.0);
+        double ygain = fabs(host_step(c, z, 1.0));
         bool settled = false;
         for (long i = 0; i < 8000000 && !settled; i++) {
             double m = 0;
             for (int r = 0; r < dim; r++) { smax[r] += fabs(z[r]); m = fmax(m, fabs(z[r])); }
             if (!(m < 1e300)) break;                             // diverging: not a filter this path can bound
             if (i > 64 && m < 1e-40) settled = true;
-            (void)host_step(c, z, 0.0);
+            ygain += fabs(host_step(c, z, 0.0));
         }
-        if (settled) {
+        if (settled && 32768.0 * ygain < 1073741824.0) {
             double Qk[IIR_MSZ];
             memcpy(Qk, pl->Q, sizeof Qk);
             for (int k = 1; k <= IIR_HMAX; k++) {
@@ -806,20 +899,21 @@ static int iir_launch_onepass(const IirPlan *d_plan, const IirPlan &plan, double
 {
     constexpr int D2 = 4 * NS;
     const long n_seg = (long)clhip_div_up((size_t)n, IIR_SEG), n_tiles = (long)clhip_div_up((size_t)n_seg, IIR_TILE);
-    // workspace: [ticket, error word | pad to 16 B][aggregates: n_streams x n_tiles x 2D][copy of the carried states]
+    // workspace, all of it pre-set to all-ones by ONE memset: [rank counter, error word (0 = poll overran) | 8 B pad]
+    // [per stream: readers of the old carried state][aggregates: n_streams x n_tiles x 2D]
     unsigned int *ticket = (unsigned int *)ws;
-    unsigned long long *agg = (unsigned long long *)(ws + 2);
-    double *state_copy = (double *)(agg + (size_t)n_tiles * n_streams * D2);
-    int *err = (int *)(state_copy + (size_t)n_streams * 2 * IIR_MAX_DIM);
-    CLHIP_CHECK(hipMemsetAsync(ws, 0xFF, 16 + sizeof(unsigned long long) * (size_t)n_tiles * n_streams * D2, s));
-    CLHIP_CHECK(hipMemsetAsync(err, 0, sizeof(int), s));
-    // the kernel writes the new carried state while early tiles may still read the old one: they read a copy
-    CLHIP_CHECK(hipMemcpyAsync(state_copy, d_state, sizeof(double) * 2 * IIR_MAX_DIM * n_streams, hipMemcpyDeviceToDevice, s));
+    int *err = (int *)ws + 1;
+    unsigned int *readers = (unsigned int *)(ws + 2);
+    const size_t rd_doubles = ((size_t)n_streams + 1) / 2;
+    unsigned long long *agg = (unsigned long long *)(ws + 2 + rd_doubles);
+    CLHIP_CHECK(hipMemsetAsync(ws, 0xFF, sizeof(double) * (2 + rd_doubles + (size_t)n_tiles * n_streams * D2), s));
     const long total = n_tiles * n_streams;
     const int resident = iir_resident_waves();
     const unsigned grid = (unsigned)(total < resident ? total : resident);
     hipLaunchKernelGGL(iir_onepass_kernel<NS>, dim3(grid), dim3(IIR_TILE), IIR_LDS_WORDS * 4, s, d_plan, plan.coef, d_iq, stride, n,
-                       n_seg, n_tiles, n_streams, ticket, agg, (const double *)state_copy, d_state, plan.horizon, err);
+                       n_seg, n_tiles, n_streams, ticket, agg, readers, d_state, plan.horizon, err,
+                       getenv("CLHIP_IIR_DBG") ? atoi(getenv("CLHIP_IIR_DBG")) : 0,
+                       total >= 2L * grid ? (getenv("CLHIP_IIR_STAGGER_US") ? atoi(getenv("CLHIP_IIR_STAGGER_US")) : 16) * 100 : 0);    // timing ablations only (results invalid)
     return 0;
 }
 
