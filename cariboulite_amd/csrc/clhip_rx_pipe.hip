@@ -532,18 +532,35 @@ __device__ __forceinline__ void store_tile(unsigned char *lds, int t, unsigned c
 }
 
 // wave-uniform: do the chunks this tile reads all have sync offset 0?  (device-side validation)
+// Two sources: the per-chunk results of clhip_smi_find_offsets (a.chunk_offs), or -- a.chunk_offs == NULL with the
+// check armed -- the chunk's own first four words: caribou_smi_find_buffer_offset (caribou_smi.c:235-292) returns 0
+// exactly when the words at byte offsets 0, 4, 8, 12 all carry the sync pattern (0 is the smallest candidate), or when
+// the chunk is at most 16 bytes long.  Four scalar loads per tile replace a kernel launch per call.
 template <class C>
 __device__ __forceinline__ bool tile_sync_bad(const PipeArgs &a, int s, long S)
 {
     bool bad = false;
-    if (a.chunk_offs) {
+    if (a.bad_flag) {
         const long first = S - C::HALO > 0 ? S - C::HALO : 0;
         const long last = (S + C::TILE_IN < a.n_in ? S + C::TILE_IN : a.n_in) - 1;
-        // written by clhip_smi_find_offsets before this launch, read-only here: scalar loads (SMEM).  A vector
-        // load would put an s_waitcnt vmcnt(0) at the top of every tile and drain the previous tile's stores.
-        typedef __attribute__((address_space(4))) int32_t cint_t;
-        const cint_t *o = (const cint_t *)(a.chunk_offs + (long)s * a.chunks_per_stream);
-        for (int c = (int)(first >> a.chunk_shift); c <= (int)(last >> a.chunk_shift); c++) bad |= o[c] != 0;
+        if (a.chunk_offs) {
+            // written by clhip_smi_find_offsets before this launch, read-only here: scalar loads (SMEM).  A vector
+            // load would put an s_waitcnt vmcnt(0) at the top of every tile and drain the previous tile's stores.
+            typedef __attribute__((address_space(4))) int32_t cint_t;
+            const cint_t *o = (const cint_t *)(a.chunk_offs + (long)s * a.chunks_per_stream);
+            for (int c = (int)(first >> a.chunk_shift); c <= (int)(last >> a.chunk_shift); c++) bad |= o[c] != 0;
+        } else {
+            typedef __attribute__((address_space(4))) uint32_t cu32_t;
+            const cu32_t *w = (const cu32_t *)((const uint32_t *)a.in + (long)s * a.in_stride);
+            for (long c = first >> a.chunk_shift; c <= (last >> a.chunk_shift); c++) {
+                const long c0 = c << a.chunk_shift;
+                if (a.n_in - c0 > 4) {                              // len <= 16 bytes: offset 0 by definition (:249-252)
+                    const uint32_t m = (w[c0] & w[c0 + 1] & w[c0 + 2] & w[c0 + 3]) & 0xC001C000u;
+                    const uint32_t z = (w[c0] | w[c0 + 1] | w[c0 + 2] | w[c0 + 3]) & 0xC001C000u;
+                    bad |= m != 0x80004000u || z != 0x80004000u;    // every word: (w & 0xC001C000) == 0x80004000
+                }
+            }
+        }
         if (bad && threadIdx.x == 0) atomicOr(a.bad_flag, 1);          // the tile writes nothing
     }
     return bad;
@@ -1017,7 +1034,7 @@ extern "C" void clhip_rx_pipe_set_diag(clhip_rx_pipe *p, unsigned long long *d_b
 extern "C" void clhip_rx_pipe_set_sync_check(clhip_rx_pipe *p, const int32_t *d_offs, size_t chunk_samples,
                                              int32_t *d_bad_flag)
 {
-    if (chunk_samples & (chunk_samples - 1)) { d_offs = nullptr; clhip_set_error("sync check needs a power-of-two chunk size"); }
+    if (chunk_samples & (chunk_samples - 1)) { d_offs = nullptr; d_bad_flag = nullptr; clhip_set_error("sync check needs a power-of-two chunk size"); }
     p->chk_offs = d_offs; p->chk_chunk_samples = chunk_samples; p->chk_flag = d_bad_flag;
 }
 
@@ -1137,7 +1154,7 @@ extern "C" long clhip_rx_pipe_run(clhip_rx_pipe *p, int in_kind, const void *d_i
     a.fir = in_kind == CL_PIPE_IN_CF32 ? p->d_fir : p->d_fir_int;
     const float *ffa_taps = in_kind == CL_PIPE_IN_CF32 ? p->d_ffa : p->d_ffa_int;
     a.rs = p->d_rs;
-    if (in_kind == CL_PIPE_IN_SMI_WORDS && p->chk_offs && p->chk_flag && p->chk_chunk_samples) {
+    if (in_kind == CL_PIPE_IN_SMI_WORDS && p->chk_flag && p->chk_chunk_samples) {
         int sh = 0;
         while (((size_t)1 << sh) < p->chk_chunk_samples) sh++;
         a.chunk_offs = p->chk_offs; a.chunk_shift = sh;
@@ -1222,12 +1239,18 @@ extern "C" long clhip_rx_pipe_run_smi(clhip_rx_pipe *p, const uint8_t *d_bytes, 
         p->h_flag = (int32_t *)clhip_host_alloc(sizeof(int32_t));
         if (!p->d_flag || !p->h_flag) return -1;
     }
-    for (int st = 0; st < p->n_streams; st++)
-        if (clhip_smi_find_offsets(d_bytes + (size_t)st * stream_stride_bytes, n_bytes, chunk_len_bytes, chunk_len_bytes,
-                                   n_chunks, d_offs + (size_t)st * n_chunks, s))
-            return -1;
     const size_t chunk_samples = chunk_len_bytes / 4;
     const bool dev_check = (chunk_samples & (chunk_samples - 1)) == 0 && (n_bytes & 3) == 0 && ((uintptr_t)d_bytes & 15) == 0;
+    // the fused kernel verifies each chunk's sync words itself; the byte-granular search only runs when that fails
+    const bool in_kernel = dev_check && clhip_rx_pipe_uses_fused(p, n_in, CL_PIPE_IN_SMI_WORDS) != 0;
+    auto search = [&]() -> int {
+        for (int st = 0; st < p->n_streams; st++)
+            if (clhip_smi_find_offsets(d_bytes + (size_t)st * stream_stride_bytes, n_bytes, chunk_len_bytes, chunk_len_bytes,
+                                       n_chunks, d_offs + (size_t)st * n_chunks, s))
+                return -1;
+        return 0;
+    };
+    if (!in_kernel && search()) return -1;
     // saved so that a caller-armed check (bench.py) survives this call
     const int32_t *keep_offs = p->chk_offs; const size_t keep_cs = p->chk_chunk_samples; int32_t *keep_flag = p->chk_flag;
     long got = -1;
@@ -1236,7 +1259,7 @@ extern "C" long clhip_rx_pipe_run_smi(clhip_rx_pipe *p, const uint8_t *d_bytes, 
         // the generic kernels do not look at the chunk table: a call that takes them is judged from the table itself
         const bool flag_valid = clhip_rx_pipe_uses_fused(p, n_in, CL_PIPE_IN_SMI_WORDS) != 0;
         CLHIP_CHECK(hipMemsetAsync(p->d_flag, 0, sizeof(int32_t), s));
-        clhip_rx_pipe_set_sync_check(p, d_offs, chunk_samples, p->d_flag);
+        clhip_rx_pipe_set_sync_check(p, in_kernel ? nullptr : d_offs, chunk_samples, p->d_flag);
         got = clhip_rx_pipe_run(p, CL_PIPE_IN_SMI_WORDS, d_bytes, stream_stride_bytes / 4, n_in, d_out, out_stride, stream);
         p->chk_offs = keep_offs; p->chk_chunk_samples = keep_cs; p->chk_flag = keep_flag;
         if (got < 0) return -1;
@@ -1246,8 +1269,10 @@ extern "C" long clhip_rx_pipe_run_smi(clhip_rx_pipe *p, const uint8_t *d_bytes, 
     }
     if (!redo) {
         if (h_offs) memset(h_offs, 0, sizeof(int32_t) * (size_t)n_chunks * p->n_streams);
+        if (in_kernel) CLHIP_CHECK(hipMemsetAsync(d_offs, 0, sizeof(int32_t) * (size_t)n_chunks * p->n_streams, s));   // what the search would have written
         return got;
     }
+    if (in_kernel && search()) return -1;                   // now the byte-granular search
     // slow path: what did the search find?
     const size_t n_offs = (size_t)n_chunks * p->n_streams;
     int32_t stack_offs[64];

@@ -208,6 +208,8 @@ void   clhip_rx_pipe_set_diag(clhip_rx_pipe *p, unsigned long long *d_buf);
 void   clhip_rx_pipe_force_generic(clhip_rx_pipe *p, int on);
 /* Device-side sync validation for CL_PIPE_IN_SMI_WORDS runs: d_offs holds the
  * per-chunk results of clhip_smi_find_offsets ([n_streams][ceil(n_in/chunk_samples)]).
+ * d_offs == NULL with a flag: every tile verifies the sync words at the head of the chunks it reads itself
+ * (offset 0 <=> the first four words carry the pattern, caribou_smi.c:235-292) -- no search launch at all.
  * A tile that needs a chunk with offs != 0 writes nothing and sets *d_bad_flag = 1;
  * the caller then synchronises, calls clhip_rx_pipe_rollback() and re-runs that call through
  * clhip_smi_unpack + CL_PIPE_IN_CS16 (clhip_rx_pipe_run_smi does all of this).  Pass NULL to disable. */

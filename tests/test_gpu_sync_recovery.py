@@ -132,7 +132,8 @@ def test_c2_misaligned_and_lost_chunks_equal_smi_read_chain(G, orc, channel, chu
     assert kinds[-1] == "aligned"        # the call after the failures: carried history and phase are the oracle's
 
 
-def test_rollback_restores_the_pre_call_state(G, orc):
+@pytest.mark.parametrize("source", ["search_results", "in_kernel"])
+def test_rollback_restores_the_pre_call_state(G, orc, source):
     """The armed check on its own: a bad launch writes nothing for the affected tiles, raises the flag, and
     rollback() puts the pipe back so that re-running the same (repaired) call gives a clean pipe's outputs."""
     import torch
@@ -151,7 +152,7 @@ def test_rollback_restores_the_pre_call_state(G, orc):
         flag = torch.zeros(1, dtype=torch.int32, device=G.DEV)
         hip.smi_find_offsets(d, b.size, 4 * per, 4 * per, nch, offs)
         if armed:
-            pipe.set_sync_check(offs, per, flag)
+            pipe.set_sync_check(offs if source == "search_results" else None, per, flag)   # None: tiles test the chunk heads themselves
         no = pipe.out_count(n)
         out = torch.full((no, 2), float("nan"), dtype=torch.float32, device=G.DEV)
         assert pipe.run(hip.PIPE_IN_SMI_WORDS, d, 0, n, out, 0) == no
