@@ -23,6 +23,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <new>
 
 #include "clhip_common.h"
@@ -893,6 +894,7 @@ struct clhip_rx_pipe {
     unsigned long long n_total;    // inputs consumed so far (per stream)
     unsigned long long undo_n_total; bool can_undo;   // pre-call state of the last run (clhip_rx_pipe_rollback)
     int32_t *d_flag, *h_flag;      // clhip_rx_pipe_run_smi: device-side sync verdict and its pinned host mirror
+    hipStream_t last_stream; bool last_stream_valid;   // where the last run was queued (reset waits for it)
     bool force_generic;
     int fused_id;                  // -1 = none
     // generic workspaces
@@ -989,6 +991,8 @@ extern "C" clhip_rx_pipe *clhip_rx_pipe_create(int n_streams, int channel, const
         (void)hipMemcpy(p->d_ffa_int, f[1], sizeof f[1], hipMemcpyHostToDevice);
     }
     (void)hipMemcpy(p->d_rs, p->rs, sizeof(float) * PIPE_MAX_RS, hipMemcpyHostToDevice);
+    // the fills above ran on the null stream, which the shim's non-blocking streams do not wait for
+    (void)hipStreamSynchronize(nullptr);
     return p;
 }
 
@@ -1005,8 +1009,11 @@ extern "C" void clhip_rx_pipe_destroy(clhip_rx_pipe *p)
 extern "C" void clhip_rx_pipe_reset(clhip_rx_pipe *p)
 {
     const size_t hb = sizeof(f32x2) * (size_t)p->n_streams * p->halo;
+    // a run of this pipe may still be reading / writing the history on its (non-blocking) stream
+    if (p->last_stream_valid) (void)hipStreamSynchronize(p->last_stream);
     (void)hipMemset(p->hist[0], 0, hb);
     (void)hipMemset(p->hist[1], 0, hb);
+    (void)hipStreamSynchronize(nullptr);
     p->cur = 0; p->n_total = 0; p->can_undo = false;
 }
 
@@ -1061,27 +1068,39 @@ static int launch_pipe(PipeArgs &a, hipStream_t s)
     const long items = (long)(a.n_int - 1) * a.n_streams;
     // persistent interior grid = what stays resident; worker w starts on item w and then pulls items
     // from the pipe's tile queue; edge workers sit in front of them in the same launch
-    static int resident = 0;
-    if (!resident) {
-        (void)hipFuncSetAttribute((const void *)rx_pipe_fused_kernel<C, KIND, HIF, DIAG>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-        int dev = 0, cus = 256, per_cu = 0;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)rx_pipe_fused_kernel<C, KIND, HIF, DIAG>,
-                                                         C::NT, C::LDS_BYTES) != hipSuccess || per_cu < 1)
-            per_cu = 2;
-        // the API under-reports here (LDS 4 x 37.5 KB and 4 waves/SIMD both fit); an oversubscribed
-        // persistent grid is still correct (no inter-workgroup waits), so prefer the measured optimum
-        const int by_lds = (160 * 1024) / C::LDS_BYTES, by_waves = 16 / (C::NT / 64);
-        const int want = by_lds < by_waves ? by_lds : by_waves;
-        if (per_cu < want && want >= 4) per_cu = want;
-        // queue mode: exactly what is resident (the tile queue keeps every worker busy to the end);
-        // static striding: 4x oversubscribed, queued workgroups back-fill as residents finish
-        if (a.queue_k == 0) per_cu *= 4;
-        const char *e = getenv("CLHIP_WG_PER_CU");
-        if (e && atoi(e) > 0) per_cu = atoi(e);
-        resident = cus * per_cu;
+    // per (instantiation, device): one process may drive several GPUs, from several threads
+    static std::mutex mu;
+    static int resident_on[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int resident;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        const int slot = dev >= 0 && dev < 64 ? dev : 0;
+        if (!resident_on[slot]) {
+            (void)hipFuncSetAttribute((const void *)rx_pipe_fused_kernel<C, KIND, HIF, DIAG>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+            int cus = 256, per_cu = 0;
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)rx_pipe_fused_kernel<C, KIND, HIF, DIAG>,
+                                                             C::NT, C::LDS_BYTES) != hipSuccess || per_cu < 1)
+                per_cu = 2;
+            // The occupancy API under-reports this kernel (4 x 37.5 KB of LDS and 4 waves per SIMD at 128 VGPRs both
+            // fit a CU; profiles/r01/c_pmc.json shows 3.8 resident waves per SIMD with the grid below).  A persistent
+            // grid larger than what is resident is still correct -- workers never wait for each other, the surplus
+            // workgroups simply start when a slot frees up and find the queue (nearly) dry -- so the measured
+            // optimum is preferred over the API's answer.
+            const int by_lds = (160 * 1024) / C::LDS_BYTES, by_waves = 16 / (C::NT / 64);
+            const int want = by_lds < by_waves ? by_lds : by_waves;
+            if (per_cu < want && want >= 4) per_cu = want;
+            // queue mode: exactly what is resident (the tile queue keeps every worker busy to the end);
+            // static striding: 4x oversubscribed, queued workgroups back-fill as residents finish
+            if (a.queue_k == 0) per_cu *= 4;
+            const char *e = getenv("CLHIP_WG_PER_CU");
+            if (e && atoi(e) > 0) per_cu = atoi(e);
+            resident_on[slot] = cus * per_cu;
+        }
+        resident = resident_on[slot];
     }
     a.grid_int = (int)(items < resident ? items : resident);
     const unsigned grid = (unsigned)a.grid_int + (unsigned)a.n_edge * a.n_streams;
@@ -1138,6 +1157,7 @@ extern "C" long clhip_rx_pipe_run(clhip_rx_pipe *p, int in_kind, const void *d_i
     if (n_in == 0) return 0;
     if (!d_in || !d_out) { clhip_set_error("clhip_rx_pipe_run: null buffer"); return -1; }
     hipStream_t s = (hipStream_t)stream;
+    p->last_stream = s; p->last_stream_valid = true;
     const size_t n_out = clhip_rx_pipe_out_count(p, n_in);
 
     PipeArgs a;

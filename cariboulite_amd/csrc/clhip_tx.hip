@@ -778,6 +778,7 @@ struct clhip_tx_pipe {
     double *d_phase;                 // = d_phase2 + pcur * n_streams: the current phase of every stream
     unsigned long long undo_n_total; int undo_cur, undo_pcur; bool can_undo;   // pre-call state of the last run
     int poll_bound;                  // look-back poll bound (diagnostic knob, default 2^22)
+    hipStream_t last_stream; bool last_stream_valid;
     unsigned long long n_total;
     f32x2 *Y; size_t y_cap;          // modulated signal workspace (per stream)
     double *ws; size_t ws_cap;
@@ -875,12 +876,14 @@ extern "C" void clhip_tx_pipe_destroy(clhip_tx_pipe *p)
 extern "C" void clhip_tx_pipe_reset(clhip_tx_pipe *p)
 {
     const int H = p->kp - 1 > 0 ? p->kp - 1 : 1;
+    if (p->last_stream_valid) (void)hipStreamSynchronize(p->last_stream);      // a run may still be using the state
     (void)hipMemset(p->d_phase2, 0, sizeof(double) * 2 * p->n_streams);
     p->pcur = 0; p->d_phase = p->d_phase2; p->can_undo = false;
     if (p->lb_err) *p->lb_err = 0;
     (void)hipMemset(p->hist[0], 0, sizeof(f32x2) * H * p->n_streams);
     (void)hipMemset(p->hist[1], 0, sizeof(f32x2) * H * p->n_streams);
     p->cur = 0; p->n_total = 0;
+    (void)hipStreamSynchronize(nullptr);       // the fills ran on the null stream; non-blocking streams do not wait for it
 }
 
 // After the caller has synchronised the stream of the last clhip_tx_pipe_run: 0 = its output is valid.  -1 = the
@@ -926,6 +929,7 @@ extern "C" long clhip_tx_pipe_run(clhip_tx_pipe *p, int in_kind, const void *d_i
     const size_t n_out = clhip_tx_pipe_out_count(p, n_in);
     const int H = p->kp - 1;
     p->undo_n_total = p->n_total; p->undo_cur = p->cur; p->undo_pcur = p->pcur; p->can_undo = true;
+    p->last_stream = s; p->last_stream_valid = true;
     const f32x2 *x = (const f32x2 *)d_in;
     long x_stride = (long)in_stride;
     static const int tx_fast = getenv("CLHIP_TX_FAST") ? atoi(getenv("CLHIP_TX_FAST")) : 1;
