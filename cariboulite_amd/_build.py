@@ -90,10 +90,26 @@ def build_cpp(force=False, verbose=False):
     return CPP_LIB
 
 
+FANOUT_LIB = os.path.join(PKG, "libcariboulite_fanout.so")
+
+
+def build_fanout(force=False, verbose=False):
+    """The multi-GPU fan-out / fan-in of raw stream buffers over RCCL point-to-point (include/cariboulite_fanout.h)."""
+    src = os.path.join(CSRC, "fanout", "clfan.cpp")
+    deps = [src, os.path.join(INC, "cariboulite_fanout.h")]
+    if force or _newer(FANOUT_LIB, deps):
+        cmd = [_hipcc(), "-O2", "-fPIC", "-shared", "-std=c++17", "-Wall", src, "-o", FANOUT_LIB, "-lrccl"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return FANOUT_LIB
+
+
 def build_all(force=False, verbose=False):
     build_hip(force, verbose)
     build_host(force, verbose)
     build_cpp(force, verbose)
+    build_fanout(force, verbose)
 
 
 if __name__ == "__main__":

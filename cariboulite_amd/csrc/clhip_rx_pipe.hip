@@ -881,6 +881,12 @@ typedef PipeCfg<64, 1, 4, 8, MODE_IQ, 16, 256> CfgD4;
 typedef PipeCfg<64, 1, 4, 8, MODE_IQ, 16, 256, true> CfgD4f;
 typedef PipeCfg<64, 3, 4, 8, MODE_IQ, 16, 256> CfgD34;
 typedef PipeCfg<64, 3, 4, 8, MODE_IQ, 16, 256, true> CfgD34f;
+typedef PipeCfg<128, 3, 2, 8, MODE_IQ, 16, 256> CfgL32;     // longer FIRs with the other second stages: any FIR=<ntaps>
+typedef PipeCfg<128, 3, 2, 8, MODE_IQ, 16, 256, true> CfgL32f;   // kwarg of 65..128 taps (zero-padded) stays fused
+typedef PipeCfg<128, 1, 1, 1, MODE_FM, 16, 256> CfgLFM;
+typedef PipeCfg<128, 1, 1, 1, MODE_FM, 16, 256, true> CfgLFMf;
+typedef PipeCfg<64, 5, 4, 8, MODE_IQ, 16, 256> CfgS54;      // FIR <= 64 taps + 5/4
+typedef PipeCfg<64, 5, 4, 8, MODE_IQ, 16, 256, true> CfgS54f;
 typedef PipeCfg<64, 1, 1, 1, MODE_IQ, 16, 256> CfgF64;    // FIR64 only
 typedef PipeCfg<128, 1, 1, 1, MODE_IQ, 16, 256> CfgF128;  // FIR128 only
 
@@ -909,9 +915,15 @@ struct clhip_rx_pipe {
     size_t x_cap, y_cap;           // elements per stream
 };
 
-static int fused_lookup(int T, int L, int M, int n_rs, int mode, int *halo)
+// Fused instantiations exist for T = 64 and T = 128.  A FIR of any other length up to 128 taps runs through the next
+// one up with its taps zero-padded at the END (k >= n_fir): y[n] = sum_k h[k] x[n-k] is unchanged, the extra products
+// are exact zeros added to the accumulators first (taps are walked in descending k), so the direct form stays
+// bit-identical to the generic kernels' result for the unpadded filter; the pipe simply keeps a longer history.
+static int fused_lookup(int n_fir, int L, int M, int n_rs, int mode, int *halo, int *T_fused)
 {
     const bool rs = !(L == 1 && M == 1);
+    const int T = n_fir <= 64 ? 64 : 128;
+    *T_fused = T;
     if (mode == CL_PIPE_OUT_IQ && T == 64 && L == 3 && M == 2 && n_rs == 24) { *halo = CfgC2::HALO; return 0; }
     if (mode == CL_PIPE_OUT_FM_DEMOD && T == 64 && !rs) { *halo = CfgC3::HALO; return 1; }
     if (mode == CL_PIPE_OUT_IQ && T == 128 && L == 5 && M == 4 && n_rs == 40) { *halo = CfgC4::HALO; return 2; }
@@ -920,6 +932,9 @@ static int fused_lookup(int T, int L, int M, int n_rs, int mode, int *halo)
     if (mode == CL_PIPE_OUT_IQ && T == 64 && L == 1 && M == 2 && n_rs == 8) { *halo = CfgD2::HALO; return 5; }
     if (mode == CL_PIPE_OUT_IQ && T == 64 && L == 1 && M == 4 && n_rs == 8) { *halo = CfgD4::HALO; return 6; }
     if (mode == CL_PIPE_OUT_IQ && T == 64 && L == 3 && M == 4 && n_rs == 24) { *halo = CfgD34::HALO; return 7; }
+    if (mode == CL_PIPE_OUT_IQ && T == 128 && L == 3 && M == 2 && n_rs == 24) { *halo = CfgL32::HALO; return 8; }
+    if (mode == CL_PIPE_OUT_FM_DEMOD && T == 128 && !rs) { *halo = CfgLFM::HALO; return 9; }
+    if (mode == CL_PIPE_OUT_IQ && T == 64 && L == 5 && M == 4 && n_rs == 40) { *halo = CfgS54::HALO; return 10; }
     return -1;
 }
 
@@ -948,8 +963,8 @@ extern "C" clhip_rx_pipe *clhip_rx_pipe_create(int n_streams, int channel, const
     if (resamp) memcpy(p->rs, h_rs, sizeof(float) * n_rs);
     const int kp = resamp ? (n_rs + up - 1) / up : 1;
     p->hfg = out_mode == CL_PIPE_OUT_FM_DEMOD ? 1 : (resamp ? kp - 1 : 0);
-    int halo = 0;
-    p->fused_id = fused_lookup(n_fir, up, down, p->n_rs, out_mode, &halo);
+    int halo = 0, t_fused = n_fir;
+    p->fused_id = fused_lookup(n_fir, up, down, p->n_rs, out_mode, &halo, &t_fused);
     p->halo = p->fused_id >= 0 ? halo : round_up(n_fir - 1 + p->hfg, 4) + 4;
     const size_t hb = sizeof(f32x2) * (size_t)n_streams * p->halo;
     for (int i = 0; i < 2; i++) {
@@ -975,8 +990,9 @@ extern "C" clhip_rx_pipe *clhip_rx_pipe_create(int n_streams, int channel, const
         (void)hipMemcpy(p->d_fir_pad, padded, sizeof padded, hipMemcpyHostToDevice);
     }
     (void)hipMemcpy(p->d_fir_int, scaled, sizeof(float) * PIPE_MAX_FIR, hipMemcpyHostToDevice);
-    if ((n_fir & 1) == 0) {
-        const int th = n_fir / 2;
+    if (p->fused_id >= 0 || (n_fir & 1) == 0) {
+        // [H0 | H1 | H0+H1] of the filter as the fused kernel sees it (zero-padded to its T: p->fir is zero past n_fir)
+        const int th = (p->fused_id >= 0 ? t_fused : n_fir) / 2;
         float f[2][3 * PIPE_MAX_FIR / 2];
         for (int v = 0; v < th; v++) {
             for (int k = 0; k < 2; k++) {
@@ -1201,6 +1217,9 @@ extern "C" long clhip_rx_pipe_run(clhip_rx_pipe *p, int in_kind, const void *d_i
         case 5: rc = ffa ? launch_fused<CfgD2f>(a, s) : launch_fused<CfgD2>(a, s); break;
         case 6: rc = ffa ? launch_fused<CfgD4f>(a, s) : launch_fused<CfgD4>(a, s); break;
         case 7: rc = ffa ? launch_fused<CfgD34f>(a, s) : launch_fused<CfgD34>(a, s); break;
+        case 8: rc = ffa ? launch_fused<CfgL32f>(a, s) : launch_fused<CfgL32>(a, s); break;
+        case 9: rc = ffa ? launch_fused<CfgLFMf>(a, s) : launch_fused<CfgLFM>(a, s); break;
+        case 10: rc = ffa ? launch_fused<CfgS54f>(a, s) : launch_fused<CfgS54>(a, s); break;
         }
         if (rc) return -1;
     } else {

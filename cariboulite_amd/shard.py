@@ -78,20 +78,45 @@ def job_throughput(units_per_rank_per_step, steps, dt_max, world):
     return world * units_per_rank_per_step * steps / dt_max
 
 
+_fan_comm = None
+
+
+def _fanout_comm(dist, world, rank, device):
+    """The process's RCCL point-to-point communicator behind the C ABI (clfan_*): rank 0 makes the id,
+    torch.distributed only carries its 128 bytes to the other ranks."""
+    global _fan_comm
+    if _fan_comm is None:
+        import torch
+        from . import fanout
+        ident = torch.tensor(fanout.Comm.unique_id() if rank == 0 else [0] * fanout.ID_BYTES, dtype=torch.uint8, device=device)
+        if world > 1:
+            dist.broadcast(ident, 0)
+        _fan_comm = fanout.Comm(world, rank, ident.cpu().tolist())
+    return _fan_comm
+
+
 def fanout_streams(root_buf, n_streams, dist, world, rank, root=0, device=None, dtype=None, n_elems=None):
     """The one case with a real exchange step: `root` holds the raw SMI
     buffers of ALL streams ([n_streams, n_elems]) and hands every rank the streams it owns.
 
-    xGMI is point-to-point (7 links per GPU), so this is a batch of direct sends -- one per
-    (peer, stream block), all posted at once so every link carries traffic concurrently -- not a
-    ring broadcast, which would be bound by a single link.  Returns this rank's [n_local, n_elems]
-    tensor (the root keeps a view of its own rows).
+    xGMI is point-to-point (7 links per GPU), so this is a set of direct sends -- one per (peer, stream), all in
+    one group so every link carries traffic concurrently -- not a ring broadcast, which would be bound by a single
+    link.  On GPUs the exchange is the C ABI's (include/cariboulite_fanout.h: grouped ncclSend / ncclRecv, this
+    module is only a caller); with a CPU backend (the gloo rehearsal of the logic) the same schedule is posted through
+    torch.distributed.  Returns this rank's [n_local, n_elems] tensor.
     """
     import torch
     mine = assign_streams(n_streams, world, rank)
     if rank == root:
         n_elems, dtype, device = root_buf.shape[1], root_buf.dtype, root_buf.device
     local = torch.empty((len(mine), n_elems), dtype=dtype, device=device)
+    on_gpu = torch.device(device).type == "cuda"
+    if on_gpu and (dist is None or dist.get_backend() == "nccl"):
+        comm = _fanout_comm(dist, world, rank, device)
+        row = n_elems * local.element_size()
+        comm.scatter(root, root_buf.data_ptr() if rank == root else None, row, row, n_streams,
+                     local.data_ptr() if len(mine) else None, row, torch.cuda.current_stream().cuda_stream)
+        return local
     ops = []
     if rank == root:
         for peer in range(world):
@@ -109,3 +134,37 @@ def fanout_streams(root_buf, n_streams, dist, world, rank, root=0, device=None, 
         for req in dist.batch_isend_irecv(ops):
             req.wait()
     return local
+
+
+def gather_streams(local, n_streams, dist, world, rank, root=0):
+    """Fan-in: every rank's per-stream results ([n_local, n_elems], same n_elems everywhere) back to `root` as
+    [n_streams, n_elems] (None elsewhere).  GPU path = clfan_gather_streams (grouped ncclSend / ncclRecv)."""
+    import torch
+    n_elems = local.shape[1]
+    out = torch.empty((n_streams, n_elems), dtype=local.dtype, device=local.device) if rank == root else None
+    mine = assign_streams(n_streams, world, rank)
+    if local.device.type == "cuda" and (dist is None or dist.get_backend() == "nccl"):
+        comm = _fanout_comm(dist, world, rank, local.device)
+        row = n_elems * local.element_size()
+        comm.gather(root, local.data_ptr() if len(mine) else None, row, row, n_streams,
+                    out.data_ptr() if rank == root else None, row, torch.cuda.current_stream().cuda_stream)
+        return out
+    ops, parts = [], {}
+    if rank == root:
+        for peer in range(world):
+            rows = assign_streams(n_streams, world, peer)
+            if not rows:
+                continue
+            if peer == root:
+                out[rows] = local
+            else:
+                parts[peer] = torch.empty((len(rows), n_elems), dtype=local.dtype, device=local.device)
+                ops.append(dist.P2POp(dist.irecv, parts[peer], peer))
+    elif mine:
+        ops.append(dist.P2POp(dist.isend, local.contiguous(), root))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    for peer, blk in parts.items():
+        out[assign_streams(n_streams, world, peer)] = blk
+    return out

@@ -36,6 +36,24 @@ def test_every_declared_symbol_is_exported_and_bound():
     assert all(s in _exports(soapy.LIB_PATH) for s in decl if not s.startswith("clhip_"))
 
 
+def test_fanout_library_exports_what_its_header_declares():
+    """include/cariboulite_fanout.h (the RCCL point-to-point fan-out): every declared clfan_* symbol is exported by
+    libcariboulite_fanout.so, bound by the ctypes face, and the stream -> rank rule matches shard.assign_streams."""
+    from cariboulite_amd import fanout, shard, _build
+    _build.build_fanout()
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "cariboulite_fanout.h")).read(), flags=re.S)
+    decl = sorted(set(re.findall(r"\b(clfan_[A-Za-z0-9_]+)\s*\(", src)))
+    assert len(decl) >= 9
+    exp = _exports(fanout.LIB_PATH)
+    assert not [s for s in decl if s not in exp]
+    assert sorted(decl) == fanout.exported_symbols()
+    dyn = subprocess.run(["ldd", fanout.LIB_PATH], capture_output=True, text=True).stdout
+    assert "librccl" in dyn                                           # the transfers are RCCL's
+    for n, w in ((256, 8), (5, 2), (3, 4), (0, 2)):
+        for r in range(w):
+            assert fanout.lib().clfan_local_count(n, w, r) == len(shard.assign_streams(n, w, r))
+
+
 def test_product_does_not_link_or_import_the_oracle():
     from cariboulite_amd import hip, soapy
     for lib in (hip.LIB_PATH, soapy.LIB_PATH):

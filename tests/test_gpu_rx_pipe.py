@@ -265,6 +265,35 @@ def test_c4_share_of_one_gpu_32_streams(G, orc, channel):
         assert np.max(np.abs(got[s] - want)) <= TOL * np.max(np.abs(want)), s
 
 
+@pytest.mark.parametrize("ntaps,rs,L,M,mode", [(33, "rs_3_2", 3, 2, 0), (48, None, 1, 1, 1), (100, "rs_3_2", 3, 2, 0),
+                                                (97, None, 1, 1, 1), (20, "rs_5_4", 5, 4, 0), (1, "rs_3_4", 3, 4, 0),
+                                                (127, "rs_5_4", 5, 4, 0), (65, None, 1, 1, 0)])
+def test_arbitrary_tap_counts_stay_fused(G, orc, ntaps, rs, L, M, mode):
+    """Any FIR=<ntaps> stream kwarg up to 128 taps (odd lengths included) runs the fused kernel: the taps are
+    zero-padded to the next instantiated length.  Against the fp64 oracle of the UNPADDED filter, chunked."""
+    from cariboulite_amd import hip, soapy, synth
+    t = load_golden("taps.npz")
+    h = soapy.design_lowpass(ntaps, 100e3 if mode == 1 else 900e3, 4e6) if ntaps > 1 else np.ones(1, np.float32)
+    n = 3 * 4088 + 1236
+    b, _, _ = synth.smi_stream_bytes(n, 0, stream=21)
+    pipe = hip.RxPipe(1, 0, h, t[rs] if rs else None, L, M, mode)
+    assert pipe.uses_fused(n)
+    got = run_pipe(G, pipe, b, n, chunks=[2 * 4088, n - 2 * 4088])          # second call: carried (longer) history
+    _, iq, _ = orc.rx_data_analyze(0, b)
+    y = orc.FIR(h).f64(orc.cs16_to_cf32(iq[:n]))
+    if mode == 1:
+        # demod stage in isolation on the GPU's own FIR outputs + the magnitude-weighted end-to-end bound (see check_fm)
+        fir_only = hip.RxPipe(1, 0, h, None, 1, 1, hip.PIPE_OUT_IQ)
+        y_gpu = run_pipe(G, fir_only, b, n)
+        assert np.max(np.abs(y_gpu - y)) <= TOL * np.max(np.abs(y))
+        d = np.abs(got[:, 0] - orc.fm_demod_f64(y_gpu.astype(np.float64))[0]); d = np.minimum(d, 2 * np.pi - d)
+        assert np.max(d) <= TOL * np.pi
+        return
+    want = orc.Resampler(t[rs], L, M).f64(y) if rs else y
+    assert got.shape == want.shape
+    assert np.max(np.abs(got - want)) <= TOL * np.max(np.abs(want))
+
+
 def test_linearity_and_impulse_full_size(G, orc):
     """Size-independent properties at a bench-like size: an impulse returns the taps;
     response to a constant settles at the DC gain."""

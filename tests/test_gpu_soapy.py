@@ -474,3 +474,28 @@ def test_device_ring_spans_move_data_device_to_device(S):
     assert k == 1024 and d[0].item() == 1800 - 1024 and d[-1].item() == 1799
     assert torch.equal(d, torch.arange(776, 1800, dtype=torch.int32, device="cuda:0"))
     assert get(1)[0] == 0                                      # empty: whole-request rule, times out
+
+
+def test_fanout_c_abi_single_rank_and_strides(S):
+    """clfan_* (include/cariboulite_fanout.h) on the one GPU of this box: world 1 -- every stream is the root's own,
+    so scatter / gather are the device-to-device legs of the same code that posts ncclSend / ncclRecv for peers --
+    with row strides larger than the rows; and through shard.fanout_streams / gather_streams (dist=None)."""
+    import torch
+    from cariboulite_amd import fanout, shard
+    c = fanout.Comm(1, 0)
+    assert fanout.lib().clfan_world(c.h) == 1 and fanout.lib().clfan_rank(c.h) == 0
+    ns, n, pad = 5, 3000, 40
+    root = torch.arange(ns * (n + pad), dtype=torch.int32, device="cuda:0").reshape(ns, n + pad)
+    mine = torch.full((ns, n + 8), -1, dtype=torch.int32, device="cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    c.scatter(0, root.data_ptr(), 4 * (n + pad), 4 * n, ns, mine.data_ptr(), 4 * (n + 8), st)
+    torch.cuda.synchronize()
+    assert torch.equal(mine[:, :n], root[:, :n]) and bool((mine[:, n:] == -1).all())
+    back = torch.zeros_like(root)
+    c.gather(0, mine.data_ptr(), 4 * (n + 8), 4 * n, ns, back.data_ptr(), 4 * (n + pad), st)
+    torch.cuda.synchronize()
+    assert torch.equal(back[:, :n], root[:, :n]) and bool((back[:, n:] == 0).all())
+    loc = shard.fanout_streams(root[:, :n].contiguous(), ns, None, 1, 0, root=0)
+    assert torch.equal(loc, root[:, :n])
+    assert torch.equal(shard.gather_streams(loc, ns, None, 1, 0), root[:, :n])
+    c.close()

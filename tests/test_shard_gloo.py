@@ -95,7 +95,8 @@ def _fanout_worker(rank, world, port, q):
         root_buf = (torch.arange(n_streams * n, dtype=torch.int32).reshape(n_streams, n) * 7 + 3)
     local = shard.fanout_streams(root_buf, n_streams, dist, world, rank, root=0, device=torch.device("cpu"),
                                  dtype=torch.int32, n_elems=n)
-    q.put((rank, shard.assign_streams(n_streams, world, rank), local.numpy().copy()))
+    back = shard.gather_streams(local * 2, n_streams, dist, world, rank, root=0)        # fan-in of per-stream results
+    q.put((rank, shard.assign_streams(n_streams, world, rank), local.numpy().copy(), back.numpy().copy() if rank == 0 else None))
     dist.destroy_process_group()
 
 
@@ -114,8 +115,10 @@ def test_fanout_streams_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     full = (np.arange(5 * 4096, dtype=np.int64).reshape(5, 4096) * 7 + 3).astype(np.int32)
-    for rank, rows, local in res:
+    for rank, rows, local, back in res:
         assert np.array_equal(local, full[rows])
+        if rank == 0:
+            assert np.array_equal(back, full * 2)
 
 
 def test_time_slices_cover_the_stream():
