@@ -467,7 +467,8 @@ void orc_fm_demod_f64(double prev[2], const double *x, size_t n, double *y)
     for (size_t i = 0; i < n; i++) {
         double a = x[2 * i], b = x[2 * i + 1];
         double re = a * pr + b * pi_, im = b * pr - a * pi_;
-        y[i] = atan2(im, re);
+        /* a13: z = 0 (e.g. x[-1] = 0) demodulates to 0 whatever the signs of its zeros (np.angle(0) = 0) */
+        y[i] = (re == 0.0 && im == 0.0) ? 0.0 : atan2(im, re);
         pr = a; pi_ = b;
     }
     prev[0] = pr; prev[1] = pi_;
@@ -478,7 +479,7 @@ void orc_fm_demod_f32(float prev[2], const float *x, size_t n, float *y)
     for (size_t i = 0; i < n; i++) {
         float a = x[2 * i], b = x[2 * i + 1];
         float re = a * pr + b * pi_, im = b * pr - a * pi_;
-        y[i] = atan2f(im, re);
+        y[i] = (re == 0.0f && im == 0.0f) ? 0.0f : atan2f(im, re);
         pr = a; pi_ = b;
     }
     prev[0] = pr; prev[1] = pi_;
