@@ -779,6 +779,7 @@ struct clhip_tx_pipe {
     unsigned long long undo_n_total; int undo_cur, undo_pcur; bool can_undo;   // pre-call state of the last run
     int poll_bound;                  // look-back poll bound (diagnostic knob, default 2^22)
     hipStream_t last_stream; bool last_stream_valid;
+    bool force_ticket;               // a look-back poll overran once in dispatch order: this pipe orders by ticket from now on
     unsigned long long n_total;
     f32x2 *Y; size_t y_cap;          // modulated signal workspace (per stream)
     double *ws; size_t ws_cap;
@@ -855,7 +856,7 @@ extern "C" clhip_tx_pipe *clhip_tx_pipe_create(int n_streams, double fm_kf_hz, d
     p->d_rs = (float *)clhip_malloc(sizeof p->rs);
     p->d_phase2 = (double *)clhip_malloc(sizeof(double) * 2 * n_streams);
     p->d_phase = p->d_phase2; p->pcur = 0;
-    p->poll_bound = getenv("CLHIP_TX_POLL_BOUND") ? atoi(getenv("CLHIP_TX_POLL_BOUND")) : 1 << 22;   // diagnostic knob
+    p->poll_bound = getenv("CLHIP_TX_POLL_BOUND") ? atoi(getenv("CLHIP_TX_POLL_BOUND")) : -1;   // diagnostic knob; -1 = by ordering mode
     for (int i = 0; i < 2; i++) p->hist[i] = (f32x2 *)clhip_malloc(sizeof(f32x2) * H * n_streams);
     if (!p->d_rs || !p->d_phase || !p->hist[0] || !p->hist[1]) { clhip_tx_pipe_destroy(p); return nullptr; }
     (void)hipMemcpy(p->d_rs, p->rs, sizeof p->rs, hipMemcpyHostToDevice);
@@ -895,6 +896,7 @@ extern "C" int clhip_tx_pipe_status(clhip_tx_pipe *p)
     if (!p) return -1;
     if (!p->lb_err || !*(volatile int *)p->lb_err) return 0;
     *p->lb_err = 0;
+    p->force_ticket = true;
     if (p->can_undo) {
         p->cur = p->undo_cur; p->pcur = p->undo_pcur; p->n_total = p->undo_n_total;
         p->d_phase = p->d_phase2 + (size_t)p->pcur * p->n_streams;
@@ -904,7 +906,7 @@ extern "C" int clhip_tx_pipe_status(clhip_tx_pipe *p)
     return -1;
 }
 
-extern "C" void clhip_tx_pipe_set_poll_bound(clhip_tx_pipe *p, int polls) { if (p) p->poll_bound = polls < 0 ? (1 << 22) : polls; }
+extern "C" void clhip_tx_pipe_set_poll_bound(clhip_tx_pipe *p, int polls) { if (p) p->poll_bound = polls < 0 ? -1 : polls; }
 
 extern "C" size_t clhip_tx_pipe_out_count(const clhip_tx_pipe *p, size_t n_in)
 {
@@ -976,10 +978,15 @@ extern "C" long clhip_tx_pipe_run(clhip_tx_pipe *p, int in_kind, const void *d_i
                 p->epoch = 1;
                 CLHIP_CHECK(hipMemsetAsync(p->lb_st, 0, sizeof(unsigned long long) * p->lb_cap, s));
             }
-            // Forward progress: with a ticket every superblock before ours belongs to a workgroup that is already
-            // running and waits only for ITS predecessors, so the look-back always ends.  CLHIP_TX_TICKET=0 orders by
-            // blockIdx instead (workgroups are dispatched in index order on this hardware, not by contract).
-            static const int use_ticket = getenv("CLHIP_TX_TICKET") ? atoi(getenv("CLHIP_TX_TICKET")) : 1;
+            // Forward progress.  Default: superblocks are ordered by blockIdx -- workgroups are dispatched in index order on
+            // this hardware (not by contract), so a predecessor is always at least dispatched; 7 % faster than a ticket
+            // per workgroup (profiles/r02/c5_lookback_*_bench.json: the ticket's atomic round trip sits in front of
+            // every workgroup's first load).  Correctness does not rest on that order: the poll is bounded, an
+            // overrun is reported by clhip_tx_pipe_status() for the SAME call with the pipe rolled back, and from
+            // then on this pipe takes tickets (every predecessor then belongs to a running workgroup that waits only
+            // for ITS predecessors: the look-back ends whatever the dispatch order).  CLHIP_TX_TICKET=1 / 0 force either.
+            static const int ticket_env = getenv("CLHIP_TX_TICKET") ? atoi(getenv("CLHIP_TX_TICKET")) : -1;
+            const int use_ticket = ticket_env >= 0 ? ticket_env : (p->force_ticket ? 1 : 0);
             if (*(volatile int *)p->lb_err) {                       // raised by an earlier launch nobody asked about
                 clhip_set_error("clhip_tx_pipe_run: a look-back poll overran in an earlier call and clhip_tx_pipe_status() "
                                 "was not consulted; output of that call is invalid");
@@ -987,7 +994,9 @@ extern "C" long clhip_tx_pipe_run(clhip_tx_pipe *p, int in_kind, const void *d_i
                 p->can_undo = false;
                 return -1;
             }
-            TxLookBack lb = {p->lb_st, use_ticket ? p->lb_ticket : nullptr, p->ticket_total, p->epoch, p->lb_err_dev, p->poll_bound};
+            // dispatch order: give up after ~0.2 s of polling and let the ticket order take over; tickets: the wait is always finite
+            const int bound = p->poll_bound >= 0 ? p->poll_bound : (use_ticket ? 1 << 22 : 1 << 18);
+            TxLookBack lb = {p->lb_st, use_ticket ? p->lb_ticket : nullptr, p->ticket_total, p->epoch, p->lb_err_dev, bound};
             const unsigned n_wg = (unsigned)(n_super * p->n_streams);
             double *phase_new = p->d_phase2 + (size_t)(p->pcur ^ 1) * p->n_streams;   // the other half: late workgroups still read d_phase
             hipLaunchKernelGGL(tx_fm_chain_kernel<C>, dim3(n_wg), dim3(TXQ_NT), 0, s, (const float *)d_in, (long)in_stride, nv, phi,

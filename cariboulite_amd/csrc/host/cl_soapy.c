@@ -535,33 +535,36 @@ int cl_writeStream(cl_device *dev, cl_stream *st, const void *const *buffs, size
         return 0;
     if (!(st->tx_pipe && st->dsp.mod_fm) && clhip_memcpy_h2d(st->d_conv, in, n * ib, smi->stream)) return 0;
     size_t n_packed = n;
-    if (st->tx_pipe) {
-        /* MOD=FM: the I component carries the real message (SURVEY.md a13 "if given I/Q, use I");
-         * stride 2 floats walks the I rail of the CF32 buffer */
-        long got;
-        if (st->dsp.mod_fm) {
-            /* gather I into a dense message: reuse the upper half of d_conv via a strided D2D is not
-             * available in the C-ABI, so the message is compacted on the host side of the copy */
-            float *tmp = (float *)malloc(sizeof(float) * n);
-            if (!tmp) return 0;
-            for (size_t k = 0; k < n; k++) tmp[k] = ((const float *)in)[2 * k];
-            int bad = clhip_memcpy_h2d(st->d_conv, tmp, n * 4, smi->stream) || clhip_stream_sync(smi->stream);
-            free(tmp);
-            if (bad) return 0;
-            got = clhip_tx_pipe_run(st->tx_pipe, CL_TXPIPE_IN_FM_MESSAGE, st->d_conv, 0, n, smi->d_bytes, 0, NULL, 0, smi->stream);
-        } else
-            got = clhip_tx_pipe_run(st->tx_pipe, CL_TXPIPE_IN_CF32, st->d_conv, 0, n, smi->d_bytes, 0, NULL, 0, smi->stream);
-        if (got < 0) return 0;
-        n_packed = (size_t)got;
-    } else {
-        if (clhip_convert_to_cs16(st->d_conv, st->format, n, smi->d_iq, smi->stream) ||      /* :199-244 */
-            clhip_smi_pack(smi->tx_mode, smi->d_iq, n, smi->d_bytes, smi->stream))            /* caribou_smi.c:684-717 */
-            return 0;
+    /* a modulator call whose look-back gave up (dispatch-order mode) has put the pipe back where it was and switched it
+     * to ticket order: the call is simply made again, once */
+    for (int attempt = 0;; attempt++) {
+        n_packed = n;
+        if (st->tx_pipe) {
+            /* MOD=FM: the I component carries the real message (SURVEY.md a13 "if given I/Q, use I") */
+            long got;
+            if (st->dsp.mod_fm) {
+                /* compact the I rail into a dense message on the host side of the copy (pinned staging, no allocation) */
+                if (cl_ensure((void **)&st->h_conv, &st->h_conv_cap, n * 4 + 64, 1, 1)) return 0;
+                float *msg = (float *)st->h_conv;
+                for (size_t k = 0; k < n; k++) msg[k] = ((const float *)in)[2 * k];
+                if (clhip_memcpy_h2d(st->d_conv, msg, n * 4, smi->stream)) return 0;
+                got = clhip_tx_pipe_run(st->tx_pipe, CL_TXPIPE_IN_FM_MESSAGE, st->d_conv, 0, n, smi->d_bytes, 0, NULL, 0, smi->stream);
+            } else
+                got = clhip_tx_pipe_run(st->tx_pipe, CL_TXPIPE_IN_CF32, st->d_conv, 0, n, smi->d_bytes, 0, NULL, 0, smi->stream);
+            if (got < 0) return 0;
+            n_packed = (size_t)got;
+        } else {
+            if (clhip_convert_to_cs16(st->d_conv, st->format, n, smi->d_iq, smi->stream) ||      /* :199-244 */
+                clhip_smi_pack(smi->tx_mode, smi->d_iq, n, smi->d_bytes, smi->stream))            /* caribou_smi.c:684-717 */
+                return 0;
+        }
+        if (n_packed && (clhip_memcpy_d2h(smi->h_stage, smi->d_bytes, 4 * n_packed, smi->stream) || clhip_stream_sync(smi->stream))) return 0;
+        /* the modulator's verdict on this very call: invalid words never reach the fd (squashed to 0 like every
+         * write error, CaribouliteStream.cpp:185-194) */
+        if (!st->tx_pipe || clhip_tx_pipe_status(st->tx_pipe) == 0) break;
+        cl_seterr(dev->err, sizeof dev->err, "writeStream: %s", clhip_last_error());
+        if (attempt) return 0;
     }
-    if (n_packed && (clhip_memcpy_d2h(smi->h_stage, smi->d_bytes, 4 * n_packed, smi->stream) || clhip_stream_sync(smi->stream))) return 0;
-    /* the modulator's verdict on this very call: invalid words never reach the fd (squashed to 0 like every
-     * write error, CaribouliteStream.cpp:185-194); the pipe is back where it was, the client may write again */
-    if (st->tx_pipe && clhip_tx_pipe_status(st->tx_pipe)) { cl_seterr(dev->err, sizeof dev->err, "writeStream: %s", clhip_last_error()); return 0; }
     /* caribou_smi_write's chunk loop (caribou_smi.c:738-759) over the packed bytes */
     size_t left = 4 * n_packed, done = 0;
     while (left) {

@@ -257,10 +257,11 @@ long   clhip_tx_pipe_run(clhip_tx_pipe *p, int in_kind, const void *d_in, size_t
                          float *d_iq_tap, size_t iq_tap_stride, void *stream);
 /* Verdict on the LAST clhip_tx_pipe_run, to be asked after synchronising its stream and before the bytes are
  * handed on (cl_writeStream does: nothing reaches the TX FIFO otherwise, caribou_smi.c:738-759).  0 = valid.
- * -1 = the single-launch FM path's bounded look-back gave up on a predecessor: the bytes are invalid and the pipe
- * is back in its pre-call state, so the same call can be repeated.  With the default ticket ordering every
- * predecessor is already running and the bound (2^22 polls) is never reached. */
-int    clhip_tx_pipe_status(clhip_tx_pipe *p);
+ * -1 = the single-launch FM path's bounded look-back gave up on a predecessor: the bytes are invalid, the pipe is
+ * back in its pre-call state and from now on orders its superblocks by an atomic ticket instead of by dispatch
+ * order -- every predecessor then belongs to a running workgroup and the wait is always finite -- so the caller
+ * simply repeats the call (cl_writeStream does, once).  Dispatch order is the default because it is 7 % faster
+ * (profiles/r02/c5_lookback_*_bench.json) and has never been observed to fail; correctness does not depend on it. */
 /* diagnostic knob: polls of a predecessor before the look-back gives up (tests force the failure with 0); < 0 = default */
 void   clhip_tx_pipe_set_poll_bound(clhip_tx_pipe *p, int polls);
 
