@@ -627,6 +627,7 @@ __global__ __launch_bounds__(TXQ_NT, 2) void tx_fm_chain_kernel(
         __syncthreads();
     }
     const unsigned int T = lb.ticket ? sh_ticket : blockIdx.x;
+    if (T >= (unsigned)(n_super * n_streams)) return;              // (workgroup-uniform) never index past the launch's superblocks
     const int s = (int)(T % (unsigned)n_streams);
     const long b = (long)(T / (unsigned)n_streams);
     const float *mm = m + (long)s * m_stride - phi;
@@ -1003,7 +1004,7 @@ extern "C" long clhip_tx_pipe_run(clhip_tx_pipe *p, int in_kind, const void *d_i
                                skip, wt, lb, n_super, p->n_streams, (const double *)p->d_phase, phase_new, p->hist[p->cur],
                                p->hist[p->cur ^ 1], p->d_rs, (long)n_out, p->pack_mode, (uint32_t *)d_bytes,
                                (long)(out_stride_bytes / 4), (f32x2 *)d_iq_tap, (long)iq_tap_stride);
-            p->ticket_total += n_wg;
+            if (use_ticket) p->ticket_total += n_wg;               // the device counter moves only when tickets are taken
             CLHIP_CHECK_LAUNCH();
             p->pcur ^= 1; p->d_phase = phase_new;
             p->cur ^= 1;
