@@ -306,7 +306,7 @@ __global__ __launch_bounds__(FM_BLOCK) void tx_fm_fused_kernel(
 // ds_read_b128 are conflict-free.  Row -1 holds the 8 samples before the sub-block.
 // ---------------------------------------------------------------------------
 #define TXQ_NT 256
-#define TXQ_NSUB 4
+#define TXQ_NSUB 6      // sub-blocks per superblock: 4 -> 0.290 ms, 5 -> 0.276, 6 -> 0.268, 7 -> 0.276, 8 -> 0.274 (config 5, 2^27 messages)
 typedef __attribute__((address_space(4))) float tx_cfloat_t;
 typedef f32x4 __attribute__((aligned(4))) f32x4_a4;      // 16-byte global access at dword alignment (unaligned mode)
 typedef u32x4 __attribute__((aligned(4))) u32x4_a4;
@@ -583,7 +583,7 @@ __global__ __launch_bounds__(TXQ_NT, 2) void tx_fm_fast_kernel(
 
 // ---------------------------------------------------------------------------
 // Single-pass variant: the message is read ONCE.  Each workgroup takes a ticket (so that every superblock
-// before it is owned by a workgroup that is already running), sums its 12288 messages, publishes
+// before it is owned by a workgroup that is already running), sums its 18432 messages, publishes
 // its fp64 aggregate, and finds its phase offset by decoupled look-back over its predecessors' aggregates /
 // inclusive prefixes (flags carry the launch epoch: no reset between launches).  The poll loop is bounded: on
 // overrun it raises *err and carries on with a wrong phase instead of hanging the GPU.

@@ -201,7 +201,7 @@ def test_tx_pipe_config5(G, orc):
 
 def test_tx_pipe_streaming_any_start_phase(G, orc):
     """Config 5 in chunks of every residue mod 3 and across the fast kernel's sub-block (3072) and superblock
-    (12288) boundaries: float tap vs the fp64 oracle (FM mod -> upfirdn 2/3), words == quantise+pack of the tap."""
+    (18432; 12288 in round 1) boundaries: float tap vs the fp64 oracle (FM mod -> upfirdn 2/3), words == quantise+pack of the tap."""
     import torch
     from cariboulite_amd import hip
     t = load_golden("taps.npz")
@@ -212,7 +212,7 @@ def test_tx_pipe_streaming_any_start_phase(G, orc):
     want = orc.Resampler(t["rs_2_3"], 2, 3).f64(iq)
     d = torch.from_numpy(msg).to(G.DEV)
     pipe = hip.TxPipe(1, 75e3, 4e6, t["rs_2_3"], 2, 3, hip.TX_DOCUMENTED)
-    sizes = [1, 1, 2, 5, 3071, 3072, 3073, 1, 12287, 12288, 12289, 4, 7, 40000, 2]
+    sizes = [1, 1, 2, 5, 3071, 3072, 3073, 1, 12287, 12288, 12289, 4, 7, 40000, 2, 18431, 18432, 18433]
     sizes.append(n - sum(sizes))
     taps_out, words_out, pos = [], [], 0
     for cn in sizes:
@@ -283,7 +283,7 @@ def test_iir_orders_and_long_streams(G, orc, order):
 
 
 def test_tx_pipe_long_message_lookback(G, orc):
-    """3.2 M messages = 261 superblocks per stream: the single-launch look-back runs many workgroups deep;
+    """3.2 M messages = 174 superblocks per stream: the single-launch look-back runs many workgroups deep;
     two consecutive calls (epochs) on the same pipe, both against the fp64 oracle."""
     import torch
     from cariboulite_amd import hip
@@ -314,7 +314,7 @@ def test_tx_lookback_overrun_is_reported_by_the_same_call(G, orc):
     from cariboulite_amd import hip
     t = load_golden("taps.npz")
     rng = np.random.default_rng(9)
-    n0, n = 30_000, 60_000                                      # 3 and 5 superblocks of 12288 messages
+    n0, n = 40_000, 80_000                                      # 3 and 5 superblocks of 18432 messages
     msg = (0.4 * rng.standard_normal(n0 + n)).astype(np.float32)
     d = torch.from_numpy(msg).to(G.DEV)
 
