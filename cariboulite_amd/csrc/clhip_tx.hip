@@ -306,6 +306,12 @@ __global__ __launch_bounds__(FM_BLOCK) void tx_fm_fused_kernel(
 // ds_read_b128 are conflict-free.  Row -1 holds the 8 samples before the sub-block.
 // ---------------------------------------------------------------------------
 #define TXQ_NT 256
+// TXQ_KEEP=1 (compile-time experiment): the superblock's messages stay in registers between the sum pass and the
+// sub-block loop, so the stream is read once -- 147 / 179 / 234 VGPRs at 3 / 4 / 6 sub-blocks instead of 85, and
+// 0.295 / 0.318 / 0.284 ms on config 5 against 0.268 with the re-read: occupancy, which hides the look-back, is worth more
+#ifndef TXQ_KEEP
+#define TXQ_KEEP 0
+#endif
 #define TXQ_NSUB 6      // sub-blocks per superblock: 4 -> 0.290 ms, 5 -> 0.276, 6 -> 0.268, 7 -> 0.276, 8 -> 0.274 (config 5, 2^27 messages)
 typedef __attribute__((address_space(4))) float tx_cfloat_t;
 typedef f32x4 __attribute__((aligned(4))) f32x4_a4;      // 16-byte global access at dword alignment (unaligned mode)
@@ -638,6 +644,7 @@ __global__ __launch_bounds__(TXQ_NT, 2) void tx_fm_chain_kernel(
     // aggregate of the superblock; the messages are read again from L2 / Infinity Cache by the sub-block loop
     // (keeping 48 of them per lane in registers would cost two waves of occupancy, and occupancy hides the look-back)
     double part = 0.0;
+    float kept[TXQ_KEEP ? TXQ_NSUB : 1][PER];                     // TXQ_KEEP: the superblock's messages stay in registers
 #pragma unroll
     for (int sb = 0; sb < TXQ_NSUB; sb++) {
         const size_t tb = sbase + (size_t)sb * C::SUB + (size_t)t * PER;
@@ -646,7 +653,7 @@ __global__ __launch_bounds__(TXQ_NT, 2) void tx_fm_chain_kernel(
         else tx_load_msgs<C, true>(mm, n, phi, tb, mv);
         double r = 0.0;
 #pragma unroll
-        for (int k = 0; k < PER; k++) r = __builtin_fma((double)mv[k], wt, r);
+        for (int k = 0; k < PER; k++) { r = __builtin_fma((double)mv[k], wt, r); if (TXQ_KEEP) kept[sb][k] = mv[k]; }
         part += r;
     }
 #pragma unroll
@@ -715,16 +722,21 @@ __global__ __launch_bounds__(TXQ_NT, 2) void tx_fm_chain_kernel(
     }
     uint32_t *words_s = words + (long)s * w_stride;
     f32x2 *tap_s = tap ? tap + (long)s * tap_stride : nullptr;
+#pragma unroll
     for (int sb = 0; sb < TXQ_NSUB; sb++) {
         const size_t base = sbase + (size_t)sb * C::SUB;          // workgroup-uniform
         if (base >= n) break;
         float mv[PER];
+        if (TXQ_KEEP) {
+#pragma unroll
+            for (int k = 0; k < PER; k++) mv[k] = kept[sb][k];
+        }
         if (base > 0 && base + C::SUB < n) {
-            tx_load_msgs<C, false>(mm, n, phi, base + (size_t)t * PER, mv);
+            if (!TXQ_KEEP) tx_load_msgs<C, false>(mm, n, phi, base + (size_t)t * PER, mv);
             off = tx_fast_subblock<C, false>(mv, n, phi, skip, wt, off, base, rows, sh, hist_in + (long)s * H,
                                              hist_out + (long)s * H, rs, n_out, pack_mode, words_s, tap_s);
         } else {
-            tx_load_msgs<C, true>(mm, n, phi, base + (size_t)t * PER, mv);
+            if (!TXQ_KEEP) tx_load_msgs<C, true>(mm, n, phi, base + (size_t)t * PER, mv);
             off = tx_fast_subblock<C, true>(mv, n, phi, skip, wt, off, base, rows, sh, hist_in + (long)s * H,
                                             hist_out + (long)s * H, rs, n_out, pack_mode, words_s, tap_s);
         }
