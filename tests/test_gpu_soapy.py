@@ -195,6 +195,35 @@ def test_rx_extension_stages_via_kwargs(S, orc):
     sdr.close()
 
 
+def test_read_stream_cs16_batches_with_a_lost_and_a_slipped_batch(S, orc):
+    """readStream(CS16), one MTU per call (the read-ahead reader: the next batch is staged while this one is analysed):
+    a batch without sync yields 0 (Stream::Read squashes -3) and consumes exactly that batch -- what had been staged
+    ahead goes back to the FIFO --, a slipped batch is re-synchronised, the batches around them are untouched; then
+    flush drops what is pending (caribou_smi_flush_fifo)."""
+    sdr = S.Device(dict(driver="Cariboulite", channel="S1G"))
+    rx = sdr.setupStream(S.SOAPY_SDR_RX, S.SOAPY_SDR_CS16)
+    b = words(5 * MTU, 0, seed=71).copy()
+    b[NB:2 * NB] = 0                                                             # batch 1: no sync
+    b[3 * NB:4 * NB] = np.concatenate([np.full(3, 0x15, np.uint8), b[3 * NB:4 * NB - 3]])   # batch 3: 3 bytes late
+    sdr.feedSmiBytes(b)
+    buf = np.full((MTU, 2), -21846, np.int16)
+    for k in range(5):
+        buf[:] = -21846
+        sr = sdr.readStream(rx, [buf], MTU)
+        ret, iq, _ = orc.smi_read(0, b[k * NB:(k + 1) * NB], MTU, NB)
+        if k == 1:
+            assert ret == -3 and sr.ret == 0
+            assert sdr.pendingSmiBytes() == 3 * NB                               # batches 2..4 still queued (staged-ahead bytes count)
+            continue
+        assert sr.ret == ret == MTU
+        assert np.array_equal(buf, iq[:MTU]), k                                  # slot for slot (sentinel where the reference writes nothing)
+    assert sdr.readStream(rx, [buf], MTU).ret == 0
+    sdr.feedSmiBytes(b[:2 * NB])
+    assert S.lib().cl_smi_flush_fifo(sdr.smi) == 0 and sdr.pendingSmiBytes() == 0
+    assert sdr.readStream(rx, [buf], MTU).ret == 0
+    sdr.close()
+
+
 def test_rx_pipe_stream_resync_and_sync_loss(S, orc):
     """readStream(CF32, FIR + 3/2) over a byte stream with a slipped batch and a batch without sync: the slipped one is
     redone with the reference's re-sync semantics (its untouched slot keeps the previous batch's sample, as the

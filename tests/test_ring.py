@@ -66,3 +66,41 @@ def test_product_ring_blocking_get():
     assert r.size() == 1024
     k, d = r.get(1024, timeout_us=1000)
     assert d[-1] == 1899 and d[0] == 1900 - 1024
+
+
+def test_span_calls_on_host_storage_and_put_cancel():
+    """The two-phase calls: _begin names at most two linear pieces of the storage, the caller moves the data, _end
+    publishes / releases; put_cancel undoes a put nobody has seen, including the elements it would have displaced."""
+    import ctypes as C
+    from cariboulite_amd import soapy
+    L = soapy.lib()
+
+    class Span(C.Structure):
+        _fields_ = [("pos", C.c_size_t * 2), ("len", C.c_size_t * 2)]
+
+    r = soapy.Ring(100, True, True)                     # capacity 128 uint32, host storage
+    assert L.cl_ring_on_device(r.h) == 0
+    base = L.cl_ring_storage(r.h)
+    store = (C.c_uint32 * 128).from_address(base)
+    sp = Span()
+    assert r.put(np.arange(100, dtype=np.uint32)) == 100 and r.get(90, timeout_us=100)[0] == 90       # written 100, released 90
+    n = L.cl_ring_put_begin(r.h, 60, C.byref(sp))
+    assert n == 60 and (sp.pos[0], sp.len[0], sp.pos[1], sp.len[1]) == (100, 28, 0, 32)             # wraps at 128
+    for k in range(28):
+        store[100 + k] = 1000 + k
+    for k in range(32):
+        store[k] = 1028 + k
+    L.cl_ring_put_end(r.h, n)
+    assert r.size() == 70
+    # a put that must displace the oldest elements, then thinks better of it: nothing changed
+    n = L.cl_ring_put_begin(r.h, 100, C.byref(sp))
+    assert n == 100
+    L.cl_ring_put_cancel(r.h)
+    assert r.size() == 70
+    k = L.cl_ring_get_begin(r.h, 70, 1000, C.byref(sp))
+    assert k == 70 and (sp.pos[0], sp.len[0], sp.pos[1], sp.len[1]) == (90, 38, 0, 32)
+    got = [store[90 + i] for i in range(38)] + [store[i] for i in range(32)]
+    L.cl_ring_get_end(r.h, k)
+    assert got == list(range(90, 100)) + list(range(1000, 1060))
+    assert r.size() == 0 and L.cl_ring_get_begin(r.h, 1, 1000, C.byref(sp)) == 0                   # whole-request rule: times out unlocked
+    assert r.put(np.arange(5, dtype=np.uint32)) == 5                                               # (so the ring is not left locked)
