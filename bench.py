@@ -313,10 +313,9 @@ def main():
 
     # barrier + synchronize on both sides, EXACTLY `steps` steps, max over ranks
     dt = shard.timed_steps(timed_step, a.steps, sync_fn=torch.cuda.synchronize, dist=dist, device=red_dev)
-    hip.smi_find_offsets(words, 4 * n, 4 * NATIVE_CHUNK_SAMPLES, 4 * NATIVE_CHUNK_SAMPLES, max(n_chunks, 1), offs, stream)
-    assert int(bad.item()) == 0 and int(offs.abs().max().item()) == 0, "synthetic stream lost sync?"
     kern_avg_s = float(L.clhip_event_elapsed_ms(ev0, ev1)) / a.steps / 1e3
-    # per-launch durations (min, spread) from a second, untimed pass with an event pair around every launch
+    # per-launch durations (min, spread) from a second, untimed pass with an event pair around every launch, queued
+    # right behind the timed region (a host-side pause in between would restart the DVFS transient)
     evs = [(L.clhip_event_create(), L.clhip_event_create()) for _ in range(min(a.steps, 50))]
     for e0, e1 in evs:
         L.clhip_event_record(e0, stream)
@@ -326,6 +325,9 @@ def main():
     kern_ms = [L.clhip_event_elapsed_ms(e0, e1) for e0, e1 in evs]
     for e0, e1 in evs + [(ev0, ev1)]:
         L.clhip_event_destroy(e0); L.clhip_event_destroy(e1)
+    # every launch verified its chunks' sync words on the device; the byte-granular search agrees
+    hip.smi_find_offsets(words, 4 * n, 4 * NATIVE_CHUNK_SAMPLES, 4 * NATIVE_CHUNK_SAMPLES, max(n_chunks, 1), offs, stream)
+    assert int(bad.item()) == 0 and int(offs.abs().max().item()) == 0, "synthetic stream lost sync?"
 
     if rank == 0:
         # HBM traffic of the fused kernel from PMC counters: measured in separate rocprofv3 --pmc passes
