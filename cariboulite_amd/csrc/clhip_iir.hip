@@ -574,12 +574,14 @@ __global__ __launch_bounds__(IIR_TILE, 2) void iir_onepass_kernel(const IirPlan 
     if (t0 == 0) tk = atomicAdd(ticket, 1u) + 1u;                      // the counter starts at all-ones
     long T = (long)(unsigned)__builtin_amdgcn_readfirstlane((int)tk);
     const long NW = (long)gridDim.x;                                  // waves launched
-    if (stagger_ticks > 0 && T < total) {
+    if (stagger_ticks != 0 && T < total) {
         // Spread the waves' phases over one tile period (rank r starts r/NW of a period late): identical waves
         // started together stay in lock step, so the whole chip would load, compute and store in unison and the
         // memory system would idle during the compute phases.  The two waves of a SIMD (ranks r and r + NW/2 in
         // dispatch order) end up half a period apart.  100 MHz constant clock.
-        const unsigned long long until = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(T * stagger_ticks / NW);
+        // stagger_ticks > 0: by rank over the launch; < 0: by ring (= stream of the rank's first tile), |stagger_ticks| apart per ring
+        const unsigned long long until = __builtin_amdgcn_s_memrealtime() +
+            (stagger_ticks > 0 ? (unsigned long long)(T * stagger_ticks / NW) : (unsigned long long)((T % n_streams) * (long)(-stagger_ticks)));
         while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(8);
     }
     u32x4 raw[IIR_NLD];
