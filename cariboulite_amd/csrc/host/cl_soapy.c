@@ -455,6 +455,46 @@ int cl_readStream(cl_device *dev, cl_stream *st, void *const *buffs, size_t numE
     cl_smi *smi = dev->smi;
     clhip_set_device(smi->device);
     void *out = buffs[0];
+    if (!st->use_async && !st->rx_pipe && st->filter_type == CL_DIGFILT_NONE && numElems && numElems <= st->mtu_size) {
+        /* One native batch, no state-carrying stage behind the read: everything the call needs is queued on the seam's
+         * stream behind the chunk analysis -- the conversion kernel (every slot, stale ones included, :304-367) and
+         * the device-to-host copy into the pinned mirror -- so the call pays ONE synchronisation; the verdict of the
+         * last read() arrives with it and a failed read simply discards what was queued.  Host side: CS16 copies
+         * exactly the slots the reference writes (caribou_smi.c:344-389), the other formats all of them. */
+        const size_t eb = fmt_bytes(st->format);
+        if (cl_ensure((void **)&st->h_conv, &st->h_conv_cap, numElems * eb + 64, 1, 1) ||
+            (st->format != CL_FORMAT_CS16 && cl_ensure(&st->d_conv, &st->conv_cap, numElems * 16 + 64, 1, 0)))
+            return 0;
+        const long expect = cl_smi_ra_launch(smi, dev->channel, numElems, NULL);
+        int ret;
+        if (expect > 0 && smi->ra_pending) {
+            int bad;
+            if (st->format == CL_FORMAT_CS16) bad = clhip_memcpy_d2h(st->h_conv, smi->d_iq, (size_t)expect * 4, smi->stream);
+            else bad = clhip_convert_from_cs16(smi->d_iq, (size_t)expect, st->format, st->d_conv, smi->stream) ||
+                       clhip_memcpy_d2h(st->h_conv, st->d_conv, (size_t)expect * eb, smi->stream);
+            ret = cl_smi_ra_finish(smi);
+            if (bad) ret = CL_SMI_ERR_IO;
+        } else {                                           /* nothing pending, or the loop ended on an earlier read() */
+            ret = expect < 0 ? (int)expect : (smi->ra_pending ? cl_smi_ra_finish(smi) : (int)expect);
+            if (ret > 0) {
+                int bad;
+                if (st->format == CL_FORMAT_CS16) bad = clhip_memcpy_d2h(st->h_conv, smi->d_iq, (size_t)ret * 4, smi->stream);
+                else bad = clhip_convert_from_cs16(smi->d_iq, (size_t)ret, st->format, st->d_conv, smi->stream) ||
+                           clhip_memcpy_d2h(st->h_conv, st->d_conv, (size_t)ret * eb, smi->stream);
+                if (bad || clhip_stream_sync(smi->stream)) ret = CL_SMI_ERR_IO;
+            }
+        }
+        if (ret == CL_SMI_ERR_IO) printf("reader thread failed to read SMI!\n");    /* :270 */
+        if (ret <= 0) return 0;                                                     /* :266-276 */
+        if (st->format != CL_FORMAT_CS16) { memcpy(out, st->h_conv, (size_t)ret * eb); return ret; }
+        for (size_t i = 0; i < smi->n_chunks; i++) {
+            const cl_chunk *c = &smi->chunks[i];
+            const size_t shortening = c->offs > 0 ? (size_t)(c->offs / 4 + 1) : 0;
+            const size_t nn = (c->len - 4 * shortening) / 4, n_iq = nn + (shortening > 0 && nn >= 2 ? 1 : 0);
+            memcpy((uint8_t *)out + 4 * c->slot0, (const uint8_t *)st->h_conv + 4 * c->slot0, 4 * n_iq);
+        }
+        return ret;
+    }
     if (st->format == CL_FORMAT_CS16) {                /* :282-301, no MTU clamp */
         int aligned = 0;
         int res = read_native_device(st, numElems, &aligned, timeoutUs);
