@@ -262,6 +262,7 @@ long   clhip_tx_pipe_run(clhip_tx_pipe *p, int in_kind, const void *d_in, size_t
  * order -- every predecessor then belongs to a running workgroup and the wait is always finite -- so the caller
  * simply repeats the call (cl_writeStream does, once).  Dispatch order is the default because it is 7 % faster
  * (profiles/r02/c5_lookback_*_bench.json) and has never been observed to fail; correctness does not depend on it. */
+int    clhip_tx_pipe_status(clhip_tx_pipe *p);
 /* diagnostic knob: polls of a predecessor before the look-back gives up (tests force the failure with 0); < 0 = default */
 void   clhip_tx_pipe_set_poll_bound(clhip_tx_pipe *p, int polls);
 
