@@ -900,6 +900,7 @@ struct clhip_rx_pipe {
     unsigned long long n_total;    // inputs consumed so far (per stream)
     unsigned long long undo_n_total; bool can_undo;   // pre-call state of the last run (clhip_rx_pipe_rollback)
     int32_t *d_flag, *h_flag;      // clhip_rx_pipe_run_smi: device-side sync verdict and its pinned host mirror
+    void *h_sink;                  // one-shot: the next run_smi also copies its outputs here (before its synchronisation)
     hipStream_t last_stream; bool last_stream_valid;   // where the last run was queued (reset waits for it)
     bool force_generic;
     int fused_id;                  // -1 = none
@@ -1038,6 +1039,9 @@ extern "C" void clhip_rx_pipe_seek(clhip_rx_pipe *p, unsigned long long n_total)
 // A run never touches the history it read (ping-pong buffers) and the polyphase phase is a host counter, so the
 // pre-call state of the LAST run is still complete: undoing it is a pointer flip.  The caller must have synchronised
 // the stream of that run (its kernels may still be writing the other history buffer).
+extern "C" size_t clhip_rx_pipe_out_elem_bytes(const clhip_rx_pipe *p) { return p->mode == CL_PIPE_OUT_FM_DEMOD ? sizeof(float) : sizeof(f32x2); }
+extern "C" void clhip_rx_pipe_set_host_sink(clhip_rx_pipe *p, void *h_out) { if (p) p->h_sink = h_out; }
+
 extern "C" int clhip_rx_pipe_rollback(clhip_rx_pipe *p)
 {
     if (!p || !p->can_undo) { clhip_set_error("clhip_rx_pipe_rollback: no run to undo"); return -1; }
@@ -1269,6 +1273,9 @@ extern "C" long clhip_rx_pipe_run_smi(clhip_rx_pipe *p, const uint8_t *d_bytes, 
         return -1;
     }
     const size_t n_in = n_bytes / 4;                        // read_so_far += ret / 4 (:677)
+    void *sink = p->n_streams == 1 ? p->h_sink : nullptr;   // (one stream: the outputs are one contiguous run)
+    p->h_sink = nullptr;
+    const size_t ob = p->mode == CL_PIPE_OUT_FM_DEMOD ? sizeof(float) : sizeof(f32x2);
     if (n_in == 0) return 0;
     if (p->n_streams > 1 && (stream_stride_bytes & 3)) { clhip_set_error("clhip_rx_pipe_run_smi: stream stride must be whole words"); return -1; }
     hipStream_t s = (hipStream_t)stream;
@@ -1303,6 +1310,8 @@ extern "C" long clhip_rx_pipe_run_smi(clhip_rx_pipe *p, const uint8_t *d_bytes, 
         p->chk_offs = keep_offs; p->chk_chunk_samples = keep_cs; p->chk_flag = keep_flag;
         if (got < 0) return -1;
         CLHIP_CHECK(hipMemcpyAsync(p->h_flag, p->d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        // the outputs ride out under the same synchronisation (speculatively: a redo below overwrites all of them)
+        if (sink && got > 0) CLHIP_CHECK(hipMemcpyAsync(sink, d_out, (size_t)got * ob, hipMemcpyDeviceToHost, s));
         CLHIP_CHECK(hipStreamSynchronize(s));
         redo = !flag_valid || *p->h_flag != 0;
     }
@@ -1324,7 +1333,7 @@ extern "C" long clhip_rx_pipe_run_smi(clhip_rx_pipe *p, const uint8_t *d_bytes, 
         for (size_t i = 0; i < n_offs; i++) { any_bad |= ho[i] != 0; any_lost |= ho[i] < 0; }
     if (ho != h_offs && ho != stack_offs) free(ho);
     if (e != hipSuccess) { clhip_set_error("clhip_rx_pipe_run_smi: %s", hipGetErrorString(e)); return -1; }
-    if (dev_check && !any_bad && (n_bytes & 3) == 0) return got;      // generic-path pipe, everything in sync: done
+    if (dev_check && !any_bad && (n_bytes & 3) == 0) return got;      // generic-path pipe, everything in sync: done (sink filled above)
     if (dev_check && clhip_rx_pipe_rollback(p)) return -1;            // undo the raw-word run
     if (any_lost) { clhip_set_error("SMI data synchronization failed"); return CL_SMI_ERR_SYNC; }
     if (!d_cs16) { clhip_set_error("clhip_rx_pipe_run_smi: chunks out of sync; redo from re-synchronised int16 samples"); return CL_PIPE_ERR_RESYNC; }
@@ -1335,6 +1344,7 @@ extern "C" long clhip_rx_pipe_run_smi(clhip_rx_pipe *p, const uint8_t *d_bytes, 
             return -1;
     got = clhip_rx_pipe_run(p, CL_PIPE_IN_CS16, d_cs16, cs_stride, n_in, d_out, out_stride, stream);
     if (got < 0) return -1;
+    if (sink && got > 0) CLHIP_CHECK(hipMemcpyAsync(sink, d_out, (size_t)got * ob, hipMemcpyDeviceToHost, s));
     CLHIP_CHECK(hipStreamSynchronize(s));
     return got;
 }

@@ -65,6 +65,7 @@ struct cl_smi {
     struct { int valid, slot; size_t len; } ahead;
     int next_slot;
     int ra_pending; size_t ra_samples;     /* between cl_smi_ra_launch and cl_smi_ra_finish */
+    int ra_certain, stage_certain;         /* the host has seen the sync pattern at the head of every chunk of the call */
     /* statistics (SURVEY.md section 5 "Metrics"): */
     uint64_t stat_samples, stat_resyncs, stat_sync_failures;
     char err[256];
@@ -77,12 +78,13 @@ int cl_smi_read_device(cl_smi *dev, int channel, size_t length_samples, int want
 /* the same chunk loop with results in caller-owned DEVICE buffers (NULL = the seam's own / no metadata) */
 int cl_smi_read_device_to(cl_smi *dev, int channel, size_t length_samples, int16_t *d_iq, uint8_t *d_meta, int *all_aligned);
 /* the same chunk loop feeding an RX pipe straight from the staged raw words (fused launch + device-side sync verdict) */
-int cl_smi_read_pipe_device(cl_smi *dev, int channel, size_t length_samples, clhip_rx_pipe *pipe, void *d_out, long *n_out);
+int cl_smi_read_pipe_device(cl_smi *dev, int channel, size_t length_samples, clhip_rx_pipe *pipe, void *d_out, long *n_out, void *h_out);
 /* the same chunk loop, one chunk at a time, with the next read() staged and copied ahead (reader threads) */
 int cl_smi_read_device_ra(cl_smi *dev, int channel, size_t length_samples, int16_t *d_iq);
 long cl_smi_ra_launch(cl_smi *dev, int channel, size_t length_samples, int16_t *d_iq);   /* its two halves: the caller may queue */
 int cl_smi_ra_finish(cl_smi *dev);                                                      /* work on the seam's stream in between */
 void cl_smi_readahead_cancel(cl_smi *dev);
+int cl_smi_head_in_sync(const uint8_t *chunk, size_t len);   /* offs == 0 decided on the host from the staged bytes */
 /* poll(POLLIN, timeout) on the injected byte stream: returns 1 when bytes are pending (at once or within timeout_us) */
 int cl_smi_wait_bytes(cl_smi *dev, long timeout_us);     /* bytes staged ahead go back to the front of the FIFO */
 /* copy the slots the reference writes from the device results to host buffers */

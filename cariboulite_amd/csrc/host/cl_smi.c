@@ -262,6 +262,7 @@ static long smi_stage_call(cl_smi *dev, size_t length_samples, int *contiguous)
     size_t left = length_samples * CL_BYTES_PER_SAMPLE, read_so_far = 0, stage_off = 0;
     dev->n_chunks = 0;
     *contiguous = 1;
+    dev->stage_certain = 1;                                    /* every staged chunk's head carries the sync pattern */
     /* worst-case staging: every chunk rounded up to 256 B */
     const size_t max_chunks = left / (dev->max_read && dev->max_read < dev->native_batch_len ? dev->max_read : dev->native_batch_len) + 2;
     if (cl_ensure((void **)&dev->chunks, &dev->chunks_cap, max_chunks, sizeof(cl_chunk), 2)) return CL_SMI_ERR_IO;
@@ -281,6 +282,7 @@ static long smi_stage_call(cl_smi *dev, size_t length_samples, int *contiguous)
         cl_chunk *c = &dev->chunks[dev->n_chunks++];
         c->stage_off = stage_off; c->len = ret; c->slot0 = read_so_far; c->offs = 0;
         if ((ret & 3) || stage_off != 4 * read_so_far || (left > ret && ret != dev->native_batch_len)) *contiguous = 0;
+        if (!cl_smi_head_in_sync(dev->h_stage + stage_off, ret)) dev->stage_certain = 0;
         stage_off += (ret + 255) & ~(size_t)255;
         read_so_far += ret / CL_BYTES_PER_SAMPLE;              /* :677 */
         left -= ret;                                           /* :678 */
@@ -349,8 +351,9 @@ int cl_smi_read_device_to(cl_smi *dev, int channel, size_t length_samples, int16
  * (clhip_rx_pipe_run_smi: per-chunk sync search + ONE fused launch, verdict checked on the device, re-sync and "-3"
  * handled with the reference's semantics); otherwise the chunks are unpacked first and the pipe runs from int16.
  * *n_out = outputs the pipe produced (left in d_out, complete).  Returns samples consumed, 0, or CL_SMI_ERR_*. */
-int cl_smi_read_pipe_device(cl_smi *dev, int channel, size_t length_samples, clhip_rx_pipe *pipe, void *d_out, long *n_out)
+int cl_smi_read_pipe_device(cl_smi *dev, int channel, size_t length_samples, clhip_rx_pipe *pipe, void *d_out, long *n_out, void *h_out)
 {
+    const size_t out_bytes = clhip_rx_pipe_out_elem_bytes(pipe);
     clhip_set_device(dev->device);
     cl_smi_readahead_cancel(dev);
     *n_out = 0;
@@ -369,11 +372,17 @@ int cl_smi_read_pipe_device(cl_smi *dev, int channel, size_t length_samples, clh
         const int ret = cl_smi_read_device_to(dev, channel, length_samples, dev->d_iq, NULL, NULL);
         if (ret <= 0) return ret;
         *n_out = clhip_rx_pipe_run(pipe, CL_PIPE_IN_CS16, dev->d_iq, 0, (size_t)ret, d_out, 0, dev->stream);
-        if (*n_out < 0 || clhip_stream_sync(dev->stream)) return CL_SMI_ERR_IO;
+        if (*n_out < 0) return CL_SMI_ERR_IO;
+        if (h_out && *n_out > 0 && clhip_memcpy_d2h(h_out, d_out, (size_t)*n_out * out_bytes, dev->stream)) return CL_SMI_ERR_IO;
+        if (clhip_stream_sync(dev->stream)) return CL_SMI_ERR_IO;
         return ret;
     }
     const cl_chunk *last = &dev->chunks[dev->n_chunks - 1];
     const size_t total = last->stage_off + last->len, nb = dev->native_batch_len;
+    /* every chunk known to be in sync: the outputs leave for the client's buffer under run_smi's own synchronisation;
+     * otherwise the client's buffer is only written once the call is known to deliver (a lost chunk delivers nothing) */
+    const int direct = h_out && dev->stage_certain;
+    clhip_rx_pipe_set_host_sink(pipe, direct ? h_out : NULL);
     long got = clhip_rx_pipe_run_smi(pipe, dev->d_bytes, 0, total, nb, dev->d_offs, dev->h_offs, NULL, d_out, 0, dev->stream);
     if (got < 0 && got != CL_SMI_ERR_SYNC && got != CL_PIPE_ERR_RESYNC) return CL_SMI_ERR_IO;
     const int v = smi_call_verdict(dev, NULL);
@@ -396,8 +405,12 @@ int cl_smi_read_pipe_device(cl_smi *dev, int channel, size_t length_samples, clh
         if (clhip_smi_unpack(channel, dev->d_bytes, total, nb, nb, nc, dev->d_offs, CL_FORMAT_CS16, dev->d_iq, NULL, dev->stream))
             return CL_SMI_ERR_IO;
         got = clhip_rx_pipe_run(pipe, CL_PIPE_IN_CS16, dev->d_iq, 0, (size_t)read_so_far, d_out, 0, dev->stream);
-        if (got < 0 || clhip_stream_sync(dev->stream)) return CL_SMI_ERR_IO;
+        if (got < 0) return CL_SMI_ERR_IO;
+        if (h_out && got > 0 && clhip_memcpy_d2h(h_out, d_out, (size_t)got * out_bytes, dev->stream)) return CL_SMI_ERR_IO;
+        if (clhip_stream_sync(dev->stream)) return CL_SMI_ERR_IO;
     } else {
+        if (h_out && !direct && got > 0 &&
+            (clhip_memcpy_d2h(h_out, d_out, (size_t)got * out_bytes, dev->stream) || clhip_stream_sync(dev->stream))) return CL_SMI_ERR_IO;
         /* fused route: keep these raw words until the next call has been through */
         uint8_t *tb = dev->d_bytes; dev->d_bytes = dev->d_bytes_prev; dev->d_bytes_prev = tb;
         size_t tc = dev->bytes_cap; dev->bytes_cap = dev->bytes_prev_cap; dev->bytes_prev_cap = tc;
@@ -406,6 +419,21 @@ int cl_smi_read_pipe_device(cl_smi *dev, int channel, size_t length_samples, clh
     *n_out = got;
     dev->stat_samples += (uint64_t)read_so_far;
     return (int)read_so_far;
+}
+
+/* caribou_smi_find_buffer_offset (caribou_smi.c:235-292) returns 0 exactly when the chunk is at most 16 bytes long or its
+ * words at byte offsets 0, 4, 8, 12 all carry the sync pattern (0 is the smallest candidate offset).  The staged bytes
+ * are in pinned host memory, so the host knows BEFORE the device has looked whether a chunk will come back in sync --
+ * and may then let results flow straight into the client's buffer, every slot of which such a chunk writes. */
+int cl_smi_head_in_sync(const uint8_t *chunk, size_t len)
+{
+    if (len <= 16) return 1;
+    for (int k = 0; k < 4; k++) {
+        uint32_t w;
+        memcpy(&w, chunk + 4 * k, 4);
+        if ((w & 0xC001C000u) != 0x80004000u) return 0;
+    }
+    return 1;
 }
 
 /* ------------------------------------------------------------- read-ahead reader */
@@ -460,6 +488,7 @@ long cl_smi_ra_launch(cl_smi *dev, int channel, size_t length_samples, int16_t *
     clhip_set_device(dev->device);
     const size_t nb = dev->native_batch_len;
     dev->ra_pending = 0;
+    dev->ra_certain = 1;                                       /* every read() of the call known to be in sync, whole samples */
     if (!dev->cstream) {
         dev->cstream = clhip_stream_create();
         for (int k = 0; k < 2; k++) {
@@ -509,6 +538,7 @@ long cl_smi_ra_launch(cl_smi *dev, int channel, size_t length_samples, int16_t *
             clhip_smi_unpack(channel, dev->d_slot[slot], got, nb, nb, 1, dev->d_offs, CL_FORMAT_CS16, d_iq + 2 * read_so_far, NULL, dev->stream) ||
             clhip_memcpy_d2h(dev->h_offs, dev->d_offs, 4, dev->stream))
             return CL_SMI_ERR_IO;
+        if ((got & 3) || !cl_smi_head_in_sync(dev->h_slot[slot], got)) dev->ra_certain = 0;
         cl_chunk *c = &dev->chunks[dev->n_chunks];             /* published (n_chunks++) once its verdict is in */
         c->stage_off = 0; c->len = got; c->slot0 = read_so_far; c->offs = 0;
         read_so_far += got / CL_BYTES_PER_SAMPLE;              /* :677 */

@@ -472,27 +472,35 @@ int cl_readStream(cl_device *dev, cl_stream *st, void *const *buffs, size_t numE
             (st->format != CL_FORMAT_CS16 && cl_ensure(&st->d_conv, &st->conv_cap, numElems * 16 + 64, 1, 0)))
             return 0;
         const long expect = cl_smi_ra_launch(smi, dev->channel, numElems, NULL);
+        /* the staged bytes are in pinned host memory: when every chunk of the call starts with the sync pattern the
+         * call WILL deliver `expect` samples into every slot (offset 0 <=> those four words), so the device-to-host
+         * copy may target the client's buffer itself.  Otherwise it goes to the pinned mirror and the client's
+         * buffer is written after the verdict: nothing on a failed read, for CS16 only the slots the reference writes. */
+        const int direct = single_sync == 2 && smi->ra_certain;
+        void *dst = direct ? out : st->h_conv;
         int ret;
         if (expect > 0 && smi->ra_pending) {
             int bad;
-            if (st->format == CL_FORMAT_CS16) bad = clhip_memcpy_d2h(st->h_conv, smi->d_iq, (size_t)expect * 4, smi->stream);
+            if (st->format == CL_FORMAT_CS16) bad = clhip_memcpy_d2h(dst, smi->d_iq, (size_t)expect * 4, smi->stream);
             else bad = clhip_convert_from_cs16(smi->d_iq, (size_t)expect, st->format, st->d_conv, smi->stream) ||
-                       clhip_memcpy_d2h(single_sync == 2 ? out : st->h_conv, st->d_conv, (size_t)expect * eb, smi->stream);
+                       clhip_memcpy_d2h(dst, st->d_conv, (size_t)expect * eb, smi->stream);
             ret = cl_smi_ra_finish(smi);
             if (bad) ret = CL_SMI_ERR_IO;
         } else {                                           /* nothing pending, or the loop ended on an earlier read() */
             ret = expect < 0 ? (int)expect : (smi->ra_pending ? cl_smi_ra_finish(smi) : (int)expect);
+            dst = st->h_conv;
             if (ret > 0) {
                 int bad;
-                if (st->format == CL_FORMAT_CS16) bad = clhip_memcpy_d2h(st->h_conv, smi->d_iq, (size_t)ret * 4, smi->stream);
+                if (st->format == CL_FORMAT_CS16) bad = clhip_memcpy_d2h(dst, smi->d_iq, (size_t)ret * 4, smi->stream);
                 else bad = clhip_convert_from_cs16(smi->d_iq, (size_t)ret, st->format, st->d_conv, smi->stream) ||
-                           clhip_memcpy_d2h(st->h_conv, st->d_conv, (size_t)ret * eb, smi->stream);
+                           clhip_memcpy_d2h(dst, st->d_conv, (size_t)ret * eb, smi->stream);
                 if (bad || clhip_stream_sync(smi->stream)) ret = CL_SMI_ERR_IO;
             }
         }
         if (ret == CL_SMI_ERR_IO) printf("reader thread failed to read SMI!\n");    /* :270 */
         if (ret <= 0) return 0;                                                     /* :266-276 */
-        if (st->format != CL_FORMAT_CS16) { if (single_sync != 2 || ret != expect) memcpy(out, st->h_conv, (size_t)ret * eb); return ret; }
+        if (dst == out) return ret;
+        if (st->format != CL_FORMAT_CS16) { memcpy(out, st->h_conv, (size_t)ret * eb); return ret; }
         for (size_t i = 0; i < smi->n_chunks; i++) {
             const cl_chunk *c = &smi->chunks[i];
             const size_t shortening = c->offs > 0 ? (size_t)(c->offs / 4 + 1) : 0;
@@ -523,10 +531,10 @@ int cl_readStream(cl_device *dev, cl_stream *st, void *const *buffs, size_t numE
         const size_t ob = st->dsp.demod_fm ? 4 : 8;
         if (cl_ensure(&st->d_conv, &st->conv_cap, clhip_rx_pipe_out_count(st->rx_pipe, numElems) * ob + 64, 1, 0)) return 0;
         long got = 0;
-        const int ret = cl_smi_read_pipe_device(smi, dev->channel, numElems, st->rx_pipe, st->d_conv, &got);
+        /* the outputs are copied into the client's buffer under the pipe call's own synchronisation */
+        const int ret = cl_smi_read_pipe_device(smi, dev->channel, numElems, st->rx_pipe, st->d_conv, &got, out);
         if (ret == CL_SMI_ERR_IO) printf("reader thread failed to read SMI!\n");    /* :270 */
         if (ret <= 0 || got <= 0) return 0;                                         /* :266-276 */
-        if (clhip_memcpy_d2h(out, st->d_conv, (size_t)got * ob, smi->stream) || clhip_stream_sync(smi->stream)) return 0;
         return (int)got;
     }
     int aligned = 0;

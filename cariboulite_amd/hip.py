@@ -65,6 +65,8 @@ _SIGS = {
     "clhip_rx_pipe_set_diag": (None, [C.c_void_p, C.c_void_p]),
     "clhip_rx_pipe_set_sync_check": (None, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "clhip_rx_pipe_rollback": (C.c_int, [C.c_void_p]),
+    "clhip_rx_pipe_set_host_sink": (None, [C.c_void_p, C.c_void_p]),
+    "clhip_rx_pipe_out_elem_bytes": (C.c_size_t, [C.c_void_p]),
     "clhip_rx_pipe_run_smi": (C.c_long, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "clhip_tx_pipe_create": (C.c_void_p, [C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),

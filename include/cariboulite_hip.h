@@ -234,6 +234,10 @@ int    clhip_rx_pipe_rollback(clhip_rx_pipe *p);
  * d_cs16 == NULL: a call that needs the re-sync route returns CL_PIPE_ERR_RESYNC with the pipe rolled back and the
  * offsets in d_offs / h_offs, and the caller runs clhip_smi_unpack + clhip_rx_pipe_run(CL_PIPE_IN_CS16) itself. */
 #define CL_PIPE_ERR_RESYNC (-4)
+/* One-shot, single-stream pipes: the NEXT clhip_rx_pipe_run_smi also copies its outputs to h_out (host memory) before its
+ * synchronisation, so a host caller pays one synchronisation per call (cl_readStream does this). */
+void   clhip_rx_pipe_set_host_sink(clhip_rx_pipe *p, void *h_out);
+size_t clhip_rx_pipe_out_elem_bytes(const clhip_rx_pipe *p);       /* 8 (complex float) or 4 (FM demod) */
 long   clhip_rx_pipe_run_smi(clhip_rx_pipe *p, const uint8_t *d_bytes, size_t stream_stride_bytes, size_t n_bytes,
                              size_t chunk_len_bytes, int32_t *d_offs, int32_t *h_offs, int16_t *d_cs16,
                              void *d_out, size_t out_stride_elems, void *stream);

@@ -213,6 +213,7 @@ def test_read_stream_cs16_batches_with_a_lost_and_a_slipped_batch(S, orc):
         ret, iq, _ = orc.smi_read(0, b[k * NB:(k + 1) * NB], MTU, NB)
         if k == 1:
             assert ret == -3 and sr.ret == 0
+            assert (buf == -21846).all()                                         # a failed read leaves the client's buffer alone
             assert sdr.pendingSmiBytes() == 3 * NB                               # batches 2..4 still queued (staged-ahead bytes count)
             continue
         assert sr.ret == ret == MTU
@@ -247,6 +248,7 @@ def test_rx_pipe_stream_resync_and_sync_loss(S, orc):
         ret, iq, _ = orc.smi_read(1, b[k * NB:(k + 1) * NB], MTU, NB, fill=SENT)
         if k == 3:
             assert ret == -3 and sr.ret == 0
+            assert not out.any()                              # nothing delivered, nothing written
             continue
         assert ret == MTU
         touched = (iq != SENT).any(axis=1)
