@@ -13,15 +13,28 @@
 
 #include "cariboulite_hip.h"
 
-/* growable byte FIFO standing where the /dev/smi kernel kfifo stands */
+/* Growable byte FIFO standing where the /dev/smi kernel kfifo stands.  One linear buffer, three cursors:
+ *     [keep, head)        bytes a reader has STAGED to the device (host-to-device copies read them in place) but whose
+ *                         read() has not been confirmed yet -- they still belong to the FIFO and can be taken back;
+ *     [head, head + len)  bytes pending;
+ * The RX FIFO lives in pinned host memory: the feeder (or read(fd, ...) itself, cl_smi_feed_reserve / _commit) writes
+ * where the DMA engine reads, no staging copy in between.  A move of the buffer (compaction, growth) first waits for
+ * the copies in flight (`dma_stream`). */
 typedef struct {
     uint8_t *data;
-    size_t cap, head, len;       /* bytes [head, head+len) are pending (linear, compacted on demand) */
+    size_t cap, keep, head, len;
+    int pinned;                  /* hipHostMalloc'ed */
+    void *dma_stream;            /* stream whose copies read [keep, head) in place (NULL: none) */
 } cl_fifo;
 
 void   cl_fifo_free(cl_fifo *f);
+uint8_t *cl_fifo_reserve(cl_fifo *f, size_t n);              /* room for n more bytes at the tail (may move the buffer) */
+void   cl_fifo_commit(cl_fifo *f, size_t n);
 int    cl_fifo_push(cl_fifo *f, const uint8_t *src, size_t n);
-size_t cl_fifo_pop(cl_fifo *f, uint8_t *dst, size_t n);      /* dst may be NULL (discard) */
+size_t cl_fifo_pop(cl_fifo *f, uint8_t *dst, size_t n);      /* consume with a copy; dst may be NULL (discard) */
+size_t cl_fifo_stage(cl_fifo *f, size_t n, uint8_t **where); /* take up to n bytes IN PLACE: they stay owned until confirmed */
+void   cl_fifo_confirm(cl_fifo *f, size_t n);                /* the oldest n staged bytes are consumed for good */
+void   cl_fifo_unstage(cl_fifo *f, size_t n);                /* the NEWEST n staged bytes are pending again */
 
 #define CL_MAX_CHUNKS_INLINE 64
 
@@ -59,10 +72,11 @@ struct cl_smi {
     cl_smi_debug_data debug_data;
     int32_t *d_dbg; int32_t *h_dbg; /* 4 ints each */
     /* read-ahead reader (cl_smi_read_device_ra): the NEXT read() is popped into the other pinned slot and its
-     * host-to-device copy runs on `cstream` while the current chunk is analysed on `stream` */
+     * host-to-device copy runs on `cstream` while the current chunk is analysed on `stream`.  The bytes are taken IN
+     * PLACE from the pinned RX FIFO (cl_fifo_stage): what the feeder wrote is what the DMA engine reads */
     void *cstream; void *ev_copied[2];
-    uint8_t *h_slot[2], *d_slot[2]; size_t slot_cap;
-    struct { int valid, slot; size_t len; } ahead;
+    uint8_t *d_slot[2]; size_t slot_cap;   /* device side of the double buffer; the host side is the pinned RX FIFO itself */
+    struct { int valid, slot, head_ok; size_t len; } ahead;
     int next_slot;
     int ra_pending; size_t ra_samples;     /* between cl_smi_ra_launch and cl_smi_ra_finish */
     int ra_certain, stage_certain;         /* the host has seen the sync pattern at the head of every chunk of the call */

@@ -16,22 +16,42 @@ void cl_seterr(char *dst, size_t n, const char *fmt, ...)
 }
 
 /* ------------------------------------------------------------------ FIFO */
-void cl_fifo_free(cl_fifo *f) { free(f->data); memset(f, 0, sizeof *f); }
+void cl_fifo_free(cl_fifo *f)
+{
+    if (f->pinned) clhip_host_free(f->data); else free(f->data);
+    memset(f, 0, sizeof *f);
+}
+
+/* make room for n more bytes behind the pending ones; the bytes from `keep` on survive a move */
+uint8_t *cl_fifo_reserve(cl_fifo *f, size_t n)
+{
+    if (f->len == 0 && f->keep == f->head) f->keep = f->head = 0;          /* empty: start over at the front */
+    if (f->head + f->len + n > f->cap) {
+        const size_t live = f->head - f->keep + f->len;                      /* staged-unconfirmed + pending */
+        if (f->dma_stream && f->head > f->keep) clhip_stream_sync(f->dma_stream);   /* copies read [keep, head) in place */
+        if (live + n <= f->cap && f->keep) {                                /* compact */
+            memmove(f->data, f->data + f->keep, live);
+        } else {                                                            /* grow */
+            size_t cap = f->cap ? f->cap : (size_t)1 << 20;
+            while (cap < live + n) cap *= 2;
+            uint8_t *p = f->pinned ? (uint8_t *)clhip_host_alloc(cap) : (uint8_t *)malloc(cap);
+            if (!p) return NULL;
+            if (live) memcpy(p, f->data + f->keep, live);
+            if (f->pinned) clhip_host_free(f->data); else free(f->data);
+            f->data = p; f->cap = cap;
+        }
+        f->head -= f->keep; f->keep = 0;
+    }
+    return f->data + f->head + f->len;
+}
+
+void cl_fifo_commit(cl_fifo *f, size_t n) { f->len += n; }
 
 int cl_fifo_push(cl_fifo *f, const uint8_t *src, size_t n)
 {
-    if (f->head && f->head + f->len + n > f->cap) {          /* compact */
-        memmove(f->data, f->data + f->head, f->len);
-        f->head = 0;
-    }
-    if (f->head + f->len + n > f->cap) {
-        size_t cap = f->cap ? f->cap : 1 << 16;
-        while (cap < f->head + f->len + n) cap *= 2;
-        uint8_t *p = (uint8_t *)realloc(f->data, cap);
-        if (!p) return -1;
-        f->data = p; f->cap = cap;
-    }
-    memcpy(f->data + f->head + f->len, src, n);
+    uint8_t *dst = cl_fifo_reserve(f, n);
+    if (!dst) return -1;
+    memcpy(dst, src, n);
     f->len += n;
     return 0;
 }
@@ -40,26 +60,46 @@ size_t cl_fifo_pop(cl_fifo *f, uint8_t *dst, size_t n)
 {
     if (n > f->len) n = f->len;
     if (dst && n) memcpy(dst, f->data + f->head, n);
+    if (f->keep == f->head) f->keep += n;               /* nothing staged in front: consumed for good */
     f->head += n; f->len -= n;
-    if (f->len == 0) f->head = 0;
     return n;
 }
 
-/* put bytes back at the FRONT of the FIFO (bytes read ahead but not consumed) */
+size_t cl_fifo_stage(cl_fifo *f, size_t n, uint8_t **where)
+{
+    if (n > f->len) n = f->len;
+    *where = f->data + f->head;
+    f->head += n; f->len -= n;
+    return n;
+}
+
+void cl_fifo_confirm(cl_fifo *f, size_t n) { f->keep += n; if (f->keep > f->head) f->keep = f->head; }
+
+void cl_fifo_unstage(cl_fifo *f, size_t n)
+{
+    if (n > f->head - f->keep) n = f->head - f->keep;
+    f->head -= n; f->len += n;
+}
+
+/* put bytes back at the FRONT of the pending ones (a batched call read them with a copy and did not consume them) */
 static int cl_fifo_unpop(cl_fifo *f, const uint8_t *src, size_t n)
 {
     if (n == 0) return 0;
-    if (f->head >= n) {
-        f->head -= n; f->len += n;
+    if (f->keep == f->head && f->head >= n) {           /* room in front, nothing staged there */
+        f->head -= n; f->keep = f->head; f->len += n;
         memcpy(f->data + f->head, src, n);
         return 0;
     }
-    uint8_t *p = (uint8_t *)malloc(f->len + n + (1 << 16));
+    /* rebuild: [staged-unconfirmed | src | pending] */
+    const size_t staged = f->head - f->keep, cap = staged + n + f->len + ((size_t)1 << 16);
+    if (f->dma_stream && staged) clhip_stream_sync(f->dma_stream);
+    uint8_t *p = f->pinned ? (uint8_t *)clhip_host_alloc(cap) : (uint8_t *)malloc(cap);
     if (!p) return -1;
-    memcpy(p, src, n);
-    if (f->len) memcpy(p + n, f->data + f->head, f->len);
-    free(f->data);
-    f->data = p; f->cap = f->len + n + (1 << 16); f->head = 0; f->len += n;
+    if (staged) memcpy(p, f->data + f->keep, staged);
+    memcpy(p + staged, src, n);
+    if (f->len) memcpy(p + staged + n, f->data + f->head, f->len);
+    if (f->pinned) clhip_host_free(f->data); else free(f->data);
+    f->data = p; f->cap = cap; f->keep = 0; f->head = staged; f->len += n;
     return 0;
 }
 
@@ -90,6 +130,7 @@ cl_smi *cl_smi_init(int device)
     if (!dev->stream) { free(dev); return NULL; }
     pthread_mutex_init(&dev->fifo_mu, NULL);
     pthread_cond_init(&dev->fifo_fed, NULL);
+    dev->rx.pinned = 1;                                /* the feeder writes where the DMA engine reads */
     return dev;
 }
 
@@ -100,7 +141,7 @@ int cl_smi_close(cl_smi *dev)
     clhip_stream_sync(dev->stream);
     cl_smi_readahead_cancel(dev);
     if (dev->cstream) { clhip_stream_sync(dev->cstream); clhip_stream_destroy(dev->cstream); }
-    for (int k = 0; k < 2; k++) { clhip_event_destroy(dev->ev_copied[k]); clhip_host_free(dev->h_slot[k]); clhip_free(dev->d_slot[k]); }
+    for (int k = 0; k < 2; k++) { clhip_event_destroy(dev->ev_copied[k]); clhip_free(dev->d_slot[k]); }
     clhip_free(dev->d_bytes); clhip_free(dev->d_bytes_prev); clhip_free(dev->d_zoffs); clhip_free(dev->d_iq); clhip_free(dev->d_meta); clhip_free(dev->d_offs);
     clhip_host_free(dev->h_stage); clhip_host_free(dev->h_offs); clhip_free(dev->d_dbg); clhip_host_free(dev->h_dbg);
     free(dev->chunks);
@@ -110,8 +151,29 @@ int cl_smi_close(cl_smi *dev)
     return 0;
 }
 
+/* Zero-copy feed: a pointer into the pinned RX FIFO with room for n bytes -- read(fd, p, n) straight into it -- and the
+ * commit of what actually arrived.  One producer at a time; the pointer is valid until the commit. */
+uint8_t *cl_smi_feed_reserve(cl_smi *dev, size_t n)
+{
+    clhip_set_device(dev->device);
+    pthread_mutex_lock(&dev->fifo_mu);
+    uint8_t *p = cl_fifo_reserve(&dev->rx, n);
+    pthread_mutex_unlock(&dev->fifo_mu);
+    return p;
+}
+
+int cl_smi_feed_commit(cl_smi *dev, size_t n)
+{
+    pthread_mutex_lock(&dev->fifo_mu);
+    cl_fifo_commit(&dev->rx, n);
+    pthread_cond_broadcast(&dev->fifo_fed);
+    pthread_mutex_unlock(&dev->fifo_mu);
+    return 0;
+}
+
 int cl_smi_feed_bytes(cl_smi *dev, const uint8_t *b, size_t n)
 {
+    clhip_set_device(dev->device);
     pthread_mutex_lock(&dev->fifo_mu);
     int rc = cl_fifo_push(&dev->rx, b, n);
     pthread_cond_broadcast(&dev->fifo_fed);
@@ -147,6 +209,7 @@ const cl_smi_debug_data *cl_smi_get_debug_data(const cl_smi *dev) { return &dev-
 static int cl_smi_read_debug(cl_smi *dev, size_t length_samples)
 {
     clhip_set_device(dev->device);
+    cl_smi_readahead_cancel(dev);
     size_t left = length_samples * CL_BYTES_PER_SAMPLE;
     if (!left) return 0;
     size_t cur = left > dev->native_batch_len ? dev->native_batch_len : left;
@@ -190,23 +253,21 @@ static int cl_smi_read_debug(cl_smi *dev, size_t length_samples)
 long cl_smi_feed_fd(cl_smi *dev, int fd, size_t max_bytes)
 {
     if (!dev || fd < 0) return -1;
-    uint8_t *tmp = (uint8_t *)malloc(dev->native_batch_len);
-    if (!tmp) return -1;
     size_t total = 0;
     while (total < max_bytes) {
-        size_t want = max_bytes - total < dev->native_batch_len ? max_bytes - total : dev->native_batch_len;
-        ssize_t r = read(fd, tmp, want);
+        const size_t want = max_bytes - total < dev->native_batch_len ? max_bytes - total : dev->native_batch_len;
+        uint8_t *slot = cl_smi_feed_reserve(dev, want);        /* read() lands in pinned memory the DMA engine reads from */
+        if (!slot) return -1;
+        ssize_t r = read(fd, slot, want);
         if (r < 0) {
             if (errno == EINTR) continue;
             if (errno == EAGAIN || errno == EWOULDBLOCK) break;
-            free(tmp);
             return -1;
         }
         if (r == 0) break;
-        if (cl_smi_feed_bytes(dev, tmp, (size_t)r)) { free(tmp); return -1; }
+        cl_smi_feed_commit(dev, (size_t)r);
         total += (size_t)r;
     }
-    free(tmp);
     return (long)total;
 }
 
@@ -437,24 +498,30 @@ int cl_smi_head_in_sync(const uint8_t *chunk, size_t len)
 }
 
 /* ------------------------------------------------------------- read-ahead reader */
-/* pop the next read() into pinned slot `slot` and start its host-to-device copy on the copy stream */
-static size_t ra_stage(cl_smi *dev, int slot, size_t want)
+/* Take the next read() IN PLACE from the pinned FIFO and start its host-to-device copy on the copy stream (enqueued
+ * under the FIFO lock: a feeder that has to move the buffer waits for that stream first).  *in_sync = the host's
+ * verdict on the chunk head (cl_smi_head_in_sync), taken while the bytes cannot move. */
+static size_t ra_stage(cl_smi *dev, int slot, size_t want, int *in_sync)
 {
+    uint8_t *src = NULL;
     pthread_mutex_lock(&dev->fifo_mu);
-    const size_t got = cl_fifo_pop(&dev->rx, dev->h_slot[slot], want);
+    dev->rx.dma_stream = dev->cstream;
+    const size_t got = cl_fifo_stage(&dev->rx, want, &src);
+    int bad = 0;
+    if (got) {
+        *in_sync = !(got & 3) && cl_smi_head_in_sync(src, got);
+        bad = clhip_memcpy_h2d(dev->d_slot[slot], src, got, dev->cstream) || clhip_event_record(dev->ev_copied[slot], dev->cstream);
+        if (bad) cl_fifo_unstage(&dev->rx, got);
+    }
     pthread_mutex_unlock(&dev->fifo_mu);
-    if (got && (clhip_memcpy_h2d(dev->d_slot[slot], dev->h_slot[slot], got, dev->cstream) ||
-                clhip_event_record(dev->ev_copied[slot], dev->cstream)))
-        return 0;
-    return got;
+    return bad ? 0 : got;
 }
 
 void cl_smi_readahead_cancel(cl_smi *dev)
 {
     if (!dev->ahead.valid) return;
-    clhip_stream_sync(dev->cstream);
     pthread_mutex_lock(&dev->fifo_mu);
-    cl_fifo_unpop(&dev->rx, dev->h_slot[dev->ahead.slot], dev->ahead.len);
+    cl_fifo_unstage(&dev->rx, dev->ahead.len);                 /* still in place: pending again */
     pthread_mutex_unlock(&dev->fifo_mu);
     dev->ahead.valid = 0;
 }
@@ -473,6 +540,9 @@ static int ra_chunk_verdict(cl_smi *dev)
 {
     const int32_t offs = dev->h_offs[0];
     dev->chunks[dev->n_chunks].offs = offs;
+    pthread_mutex_lock(&dev->fifo_mu);                         /* this read() is consumed for good, whatever it held */
+    cl_fifo_confirm(&dev->rx, dev->chunks[dev->n_chunks].len);
+    pthread_mutex_unlock(&dev->fifo_mu);
     if (offs >= 0) dev->n_chunks++;                            /* chunks before a failure were delivered */
     if (offs > 0) dev->stat_resyncs++;
     if (offs < 0) {                                            /* :665-668 -> -3; nothing after this read() is consumed */
@@ -493,11 +563,10 @@ long cl_smi_ra_launch(cl_smi *dev, int channel, size_t length_samples, int16_t *
         dev->cstream = clhip_stream_create();
         for (int k = 0; k < 2; k++) {
             dev->ev_copied[k] = clhip_event_create();
-            dev->h_slot[k] = (uint8_t *)clhip_host_alloc(nb + 256);
             dev->d_slot[k] = (uint8_t *)clhip_malloc(nb + 256);
         }
         dev->slot_cap = nb + 256;
-        if (!dev->cstream || !dev->ev_copied[0] || !dev->ev_copied[1] || !dev->h_slot[0] || !dev->h_slot[1] || !dev->d_slot[0] || !dev->d_slot[1])
+        if (!dev->cstream || !dev->ev_copied[0] || !dev->ev_copied[1] || !dev->d_slot[0] || !dev->d_slot[1])
             return CL_SMI_ERR_IO;
     }
     if (!d_iq) {
@@ -513,32 +582,33 @@ long cl_smi_ra_launch(cl_smi *dev, int channel, size_t length_samples, int16_t *
     dev->n_chunks = 0;
     while (left) {
         const size_t want = left < cap_read ? left : cap_read;
-        size_t got; int slot;
+        size_t got; int slot, head_ok = 0;
         if (dev->ahead.valid) {
-            slot = dev->ahead.slot; got = dev->ahead.len; dev->ahead.valid = 0;
-            if (got > want) {                                  /* staged for a longer read than this one */
-                clhip_stream_sync(dev->cstream);
+            slot = dev->ahead.slot; got = dev->ahead.len; head_ok = dev->ahead.head_ok; dev->ahead.valid = 0;
+            if (got > want) {                                  /* staged for a longer read than this one: the tail is pending again */
                 pthread_mutex_lock(&dev->fifo_mu);
-                cl_fifo_unpop(&dev->rx, dev->h_slot[slot] + want, got - want);
+                cl_fifo_unstage(&dev->rx, got - want);         /* (the newest staged bytes: nothing was staged behind them) */
                 pthread_mutex_unlock(&dev->fifo_mu);
                 got = want;
+                head_ok = head_ok && want > 16;                /* a chunk of <= 16 bytes is in sync by definition, but keep it simple */
             }
         } else {
             slot = dev->next_slot;
-            got = ra_stage(dev, slot, want);
+            got = ra_stage(dev, slot, want, &head_ok);
             if (!got) break;                                   /* :657-661 "Reading timed-out" */
         }
         dev->next_slot = slot ^ 1;
         /* the read() after this one: the rest of this call, or the head of the next call */
         const size_t rest = left - got, want_next = rest ? (rest < cap_read ? rest : cap_read) : cap_read;
-        const size_t a = ra_stage(dev, slot ^ 1, want_next);
-        if (a) { dev->ahead.valid = 1; dev->ahead.slot = slot ^ 1; dev->ahead.len = a; }
+        int ahead_ok = 0;
+        const size_t a = ra_stage(dev, slot ^ 1, want_next, &ahead_ok);
+        if (a) { dev->ahead.valid = 1; dev->ahead.slot = slot ^ 1; dev->ahead.len = a; dev->ahead.head_ok = ahead_ok; }
         if (clhip_stream_wait_event(dev->stream, dev->ev_copied[slot]) ||
             clhip_smi_find_offsets(dev->d_slot[slot], got, nb, nb, 1, dev->d_offs, dev->stream) ||
             clhip_smi_unpack(channel, dev->d_slot[slot], got, nb, nb, 1, dev->d_offs, CL_FORMAT_CS16, d_iq + 2 * read_so_far, NULL, dev->stream) ||
             clhip_memcpy_d2h(dev->h_offs, dev->d_offs, 4, dev->stream))
             return CL_SMI_ERR_IO;
-        if ((got & 3) || !cl_smi_head_in_sync(dev->h_slot[slot], got)) dev->ra_certain = 0;
+        if ((got & 3) || !head_ok) dev->ra_certain = 0;
         cl_chunk *c = &dev->chunks[dev->n_chunks];             /* published (n_chunks++) once its verdict is in */
         c->stage_off = 0; c->len = got; c->slot0 = read_so_far; c->offs = 0;
         read_so_far += got / CL_BYTES_PER_SAMPLE;              /* :677 */

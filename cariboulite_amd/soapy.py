@@ -29,6 +29,8 @@ _SIGS = {
     "cl_smi_init": (C.c_void_p, [C.c_int]),
     "cl_smi_close": (C.c_int, [C.c_void_p]),
     "cl_smi_feed_bytes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "cl_smi_feed_reserve": (C.c_void_p, [C.c_void_p, C.c_size_t]),
+    "cl_smi_feed_commit": (C.c_int, [C.c_void_p, C.c_size_t]),
     "cl_smi_pending_bytes": (C.c_size_t, [C.c_void_p]),
     "cl_smi_feed_fd": (C.c_long, [C.c_void_p, C.c_int, C.c_size_t]),
     "cl_smi_feed_file": (C.c_long, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_size_t]),

@@ -291,6 +291,10 @@ int     cl_smi_close(cl_smi *dev);                     /* caribou_smi_close :584
 /* injection points replacing the /dev/smi fd: bytes
  * queued here are what read() on the fd would have returned, in order */
 int     cl_smi_feed_bytes(cl_smi *dev, const uint8_t *h_bytes, size_t n_bytes);
+/* zero-copy form: a pointer into the seam's pinned byte FIFO with room for n_bytes -- read(fd, p, n) straight into
+ * it -- and the commit of what arrived; the host-to-device copies of the read-ahead reader start from that memory */
+uint8_t *cl_smi_feed_reserve(cl_smi *dev, size_t n_bytes);
+int     cl_smi_feed_commit(cl_smi *dev, size_t n_bytes);
 size_t  cl_smi_pending_bytes(const cl_smi *dev);
 void    cl_smi_set_max_read(cl_smi *dev, size_t max_bytes_per_read); /* model short reads */
 /* replay front-end: queue bytes from a file / pipe / socket fd with the
