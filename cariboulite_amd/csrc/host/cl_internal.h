@@ -24,7 +24,7 @@ typedef struct {
     uint8_t *data;
     size_t cap, keep, head, len;
     int pinned;                  /* hipHostMalloc'ed */
-    void *dma_stream;            /* stream whose copies read [keep, head) in place (NULL: none) */
+    void *dma_stream[2];         /* streams whose copies read FIFO memory in place (waited for before the buffer moves) */
 } cl_fifo;
 
 void   cl_fifo_free(cl_fifo *f);

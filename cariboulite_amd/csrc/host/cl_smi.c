@@ -28,7 +28,8 @@ uint8_t *cl_fifo_reserve(cl_fifo *f, size_t n)
     if (f->len == 0 && f->keep == f->head) f->keep = f->head = 0;          /* empty: start over at the front */
     if (f->head + f->len + n > f->cap) {
         const size_t live = f->head - f->keep + f->len;                      /* staged-unconfirmed + pending */
-        if (f->dma_stream && f->head > f->keep) clhip_stream_sync(f->dma_stream);   /* copies read [keep, head) in place */
+        for (int k = 0; k < 2; k++)                                          /* copies may still be reading this memory in place */
+            if (f->dma_stream[k]) clhip_stream_sync(f->dma_stream[k]);
         if (live + n <= f->cap && f->keep) {                                /* compact */
             memmove(f->data, f->data + f->keep, live);
         } else {                                                            /* grow */
@@ -92,7 +93,8 @@ static int cl_fifo_unpop(cl_fifo *f, const uint8_t *src, size_t n)
     }
     /* rebuild: [staged-unconfirmed | src | pending] */
     const size_t staged = f->head - f->keep, cap = staged + n + f->len + ((size_t)1 << 16);
-    if (f->dma_stream && staged) clhip_stream_sync(f->dma_stream);
+    for (int k = 0; k < 2; k++)
+        if (f->dma_stream[k]) clhip_stream_sync(f->dma_stream[k]);
     uint8_t *p = f->pinned ? (uint8_t *)clhip_host_alloc(cap) : (uint8_t *)malloc(cap);
     if (!p) return -1;
     if (staged) memcpy(p, f->data + f->keep, staged);
@@ -333,6 +335,31 @@ static long smi_stage_call(cl_smi *dev, size_t length_samples, int *contiguous)
         cl_ensure((void **)&dev->d_offs, &dev->offs_cap, max_chunks, 4, 0) ||
         cl_ensure((void **)&dev->h_offs, &dev->h_offs_cap, max_chunks, 4, 1))
         return CL_SMI_ERR_IO;
+    if (left <= dev->native_batch_len && !(dev->max_read && dev->max_read < left)) {
+        /* the call is ONE read(): its bytes go to the device straight from the pinned FIFO (no staging copy).  They are
+         * consumed whatever the analysis says (a failed chunk is consumed too, :665-668), and the copy is enqueued
+         * under the FIFO lock: a feeder that must move the buffer waits for this stream first. */
+        uint8_t *src = NULL;
+        int bad = 0;
+        pthread_mutex_lock(&dev->fifo_mu);
+        dev->rx.dma_stream[1] = dev->stream;
+        size_t got = cl_fifo_stage(&dev->rx, left, &src);
+        if (got & 3) { cl_fifo_unstage(&dev->rx, got); got = 0; bad = 2; }          /* ragged: the copying loop below */
+        else if (got) {
+            dev->stage_certain = cl_smi_head_in_sync(src, got);
+            bad = clhip_memcpy_h2d(dev->d_bytes, src, got, dev->stream);
+            if (bad) cl_fifo_unstage(&dev->rx, got); else cl_fifo_confirm(&dev->rx, got);
+        }
+        pthread_mutex_unlock(&dev->fifo_mu);
+        if (bad == 1) return CL_SMI_ERR_IO;
+        if (bad == 0) {
+            if (got) {
+                cl_chunk *c = &dev->chunks[dev->n_chunks++];
+                c->stage_off = 0; c->len = got; c->slot0 = 0; c->offs = 0;
+            }
+            return (long)(got / CL_BYTES_PER_SAMPLE);
+        }
+    }
     while (left) {
         size_t want = left > dev->native_batch_len ? dev->native_batch_len : left;
         if (dev->max_read && want > dev->max_read) want = dev->max_read;
@@ -505,7 +532,7 @@ static size_t ra_stage(cl_smi *dev, int slot, size_t want, int *in_sync)
 {
     uint8_t *src = NULL;
     pthread_mutex_lock(&dev->fifo_mu);
-    dev->rx.dma_stream = dev->cstream;
+    dev->rx.dma_stream[0] = dev->cstream;
     const size_t got = cl_fifo_stage(&dev->rx, want, &src);
     int bad = 0;
     if (got) {
