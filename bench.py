@@ -316,7 +316,7 @@ def main():
     kern_avg_s = float(L.clhip_event_elapsed_ms(ev0, ev1)) / a.steps / 1e3
     # per-launch durations (min, spread) from a second, untimed pass with an event pair around every launch, queued
     # right behind the timed region (a host-side pause in between would restart the DVFS transient)
-    evs = [(L.clhip_event_create(), L.clhip_event_create()) for _ in range(min(a.steps, 50))]
+    evs = [(L.clhip_event_create(), L.clhip_event_create()) for _ in range(min(a.steps, 10))]
     for e0, e1 in evs:
         L.clhip_event_record(e0, stream)
         pipe.run(hip.PIPE_IN_SMI_WORDS, words, 0, n, out, 0, stream)

@@ -19,7 +19,7 @@ for WL in "$@"; do
   find $OUT/${WL}_prof -name "*kernel_stats.csv" -exec cp {} $OUT/${WL}_kernel_stats.csv \;
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/$OUT/${WL}_pmc_fetch -o run -- python3 bench.py --workload $WL $EXTRA --steps $PS --warmup $PW --settle $PSETTLE --no-cpu > /dev/null 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/$OUT/${WL}_pmc_write -o run -- python3 bench.py --workload $WL $EXTRA --steps $PS --warmup $PW --settle $PSETTLE --no-cpu > /dev/null 2>&1
-  T=$TOTAL; if [ "$WL" = "c2" ]; then T=$((TOTAL+PS)); fi   # c2 adds an untimed pass of min(steps, 50) launches with per-launch events
+  T=$TOTAL; if [ "$WL" = "c2" ]; then T=$((TOTAL+10)); fi   # c2 adds an untimed pass of min(steps, 10) launches with per-launch events
   python3 tools/pmc_workload_json.py $OUT/${WL}_pmc.json $WL ${ALG[$WL]} $T $OUT/${WL}_pmc_fetch $OUT/${WL}_pmc_write $OUT/${WL}_kernel_stats.csv > $OUT/${WL}_pmc.txt
   rm -rf $OUT/${WL}_prof $OUT/${WL}_pmc_fetch $OUT/${WL}_pmc_write
   echo "$WL done"; tail -3 $OUT/${WL}_pmc.txt
