@@ -513,7 +513,9 @@ def test_fanout_c_abi_single_rank_and_strides(S):
     with row strides larger than the rows; and through shard.fanout_streams / gather_streams (dist=None)."""
     import torch
     from cariboulite_amd import fanout, shard
-    c = fanout.Comm(1, 0)
+    ident = fanout.Comm.unique_id()                              # ncclGetUniqueId through the C ABI, torch's RCCL in the same process
+    assert len(ident) == fanout.ID_BYTES and any(ident)
+    c = fanout.Comm(1, 0, ident)
     assert fanout.lib().clfan_world(c.h) == 1 and fanout.lib().clfan_rank(c.h) == 0
     ns, n, pad = 5, 3000, 40
     root = torch.arange(ns * (n + pad), dtype=torch.int32, device="cuda:0").reshape(ns, n + pad)
