@@ -16,4 +16,4 @@ e0.record()
 for _ in range(10): f.run(iq, n)
 e1.record(); torch.cuda.synchronize()
 t = e0.elapsed_time(e1) / 10 * 1e-3
-print(json.dumps(dict(ms=t * 1e3, gsps=n / t / 1e9, hbm_frac=12 * n / t / 8e12)))
+print(json.dumps(dict(ms=t * 1e3, gsps=n / t / 1e9, hbm_frac=8 * n / t / 8e12)))
