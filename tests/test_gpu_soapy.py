@@ -532,3 +532,54 @@ def test_fanout_c_abi_single_rank_and_strides(S):
     assert torch.equal(loc, root[:, :n])
     assert torch.equal(shard.gather_streams(loc, ns, None, 1, 0), root[:, :n])
     c.close()
+
+
+def test_two_devices_two_threads_concurrently(S, orc):
+    """SURVEY 8(b) threading: one thread per stream, many streams at once.  The board's two channels are two Soapy
+    devices (SoapyCariboulite.cpp:46-69); here each has its own SMI seam, HIP streams and pipes, and two client threads
+    drive them at the same time: S1G reads CF32 through FIR64 + 3/2 with the IIR-free fused pipe, HiF reads CS16
+    with the 100 kHz IIR selected.  Every batch must equal what the same calls give single-threaded (the oracle chain)."""
+    import threading
+    from cariboulite_amd import synth
+    t = load_golden("taps.npz")
+    n_batches = 6
+    devs = {ch: S.Device(dict(driver="Cariboulite", channel=name)) for ch, name in ((0, "S1G"), (1, "HiF"))}
+    data = {ch: synth.smi_stream_bytes(n_batches * MTU, ch, stream=90 + ch) for ch in (0, 1)}
+    rx0 = devs[0].setupStream(S.SOAPY_SDR_RX, S.SOAPY_SDR_CF32, args={"FIR": "64:1000000", "RESAMP": "3/2"})
+    rx1 = devs[1].setupStream(S.SOAPY_SDR_RX, S.SOAPY_SDR_CS16)
+    devs[1].setBandwidth(S.SOAPY_SDR_RX, 0, 90e3)
+    for ch in (0, 1):
+        devs[ch].feedSmiBytes(data[ch][0])
+    got = {0: [], 1: []}
+    errs = []
+
+    def reader(ch):
+        try:
+            for _ in range(n_batches):
+                if ch == 0:
+                    buf = np.zeros((MTU * 3 // 2 + 8, 2), np.float32)
+                    r = devs[0].readStream(rx0, [buf], MTU).ret
+                else:
+                    buf = np.zeros((MTU, 2), np.int16)
+                    r = devs[1].readStream(rx1, [buf], MTU).ret
+                got[ch].append(buf[:r].copy())
+        except Exception as e:                                   # pragma: no cover
+            errs.append(e)
+
+    th = [threading.Thread(target=reader, args=(ch,)) for ch in (0, 1)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join(timeout=120)
+    assert not errs and all(len(got[ch]) == n_batches for ch in (0, 1))
+    x0 = orc.cs16_to_cf32(np.stack([data[0][1], data[0][2]], 1))
+    fir, rs = orc.FIR(t["fir64_c2"]), orc.Resampler(t["rs_3_2"], 3, 2)
+    want0 = rs.f64(fir.f64(x0))
+    g0 = np.concatenate(got[0])
+    assert g0.shape == want0.shape and np.max(np.abs(g0 - want0)) <= 1e-5 * np.max(np.abs(want0))
+    want1 = orc.IIR(6, 4e6, 50e3).apply_cs16(np.stack([data[1][1], data[1][2]], 1))
+    g1 = np.concatenate(got[1])
+    d = np.abs(g1.astype(np.int32) - want1.astype(np.int32))
+    assert g1.shape == want1.shape and d.max() <= 1 and np.mean(d != 0) < 1e-4
+    for ch in (0, 1):
+        devs[ch].close()
