@@ -1,0 +1,22 @@
+"""not-gpu: the host-side bookkeeping of the ingest path (three-cursor byte FIFO, sample ring span calls) under
+AddressSanitizer + UBSan on the CPU build, driven by random op sequences against a plain model
+(tests/cpp/test_fifo_ring_asan.c).  Sanitizers are a CPU-build affair on this pool."""
+import os
+import subprocess
+
+from conftest import ROOT
+
+
+def test_fifo_and_ring_bookkeeping_under_asan(tmp_path):
+    from cariboulite_amd import _build
+    _build.build_all()
+    pkg = os.path.join(ROOT, "cariboulite_amd")
+    host = os.path.join(pkg, "csrc", "host")
+    exe = str(tmp_path / "fifo_ring_asan")
+    cmd = ["gcc", "-std=gnu11", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
+           os.path.join(ROOT, "tests", "cpp", "test_fifo_ring_asan.c"), os.path.join(host, "cl_ring.c"), os.path.join(host, "cl_smi.c"),
+           "-I", host, "-I", os.path.join(ROOT, "include"), "-L", pkg, "-lcariboulite_hip", f"-Wl,-rpath,{pkg}", "-lpthread", "-lm", "-o", exe]
+    subprocess.run(cmd, check=True)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "harness ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
