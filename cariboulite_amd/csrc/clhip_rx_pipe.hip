@@ -30,6 +30,16 @@
 
 typedef __attribute__((address_space(4))) float cfloat_t;   // constant address space (scalar-loadable)
 
+#ifndef CLHIP_FFA_DPP
+#define CLHIP_FFA_DPP 0
+#endif
+// dst[lane] = src[lane + 1] across the whole wave (DPP wave_shl:1, ctrl 0x130); lane 63 keeps its own value
+__device__ __forceinline__ float clhip_wave_shl1(float v)
+{
+    const int i = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, 0x130, 0xF, 0xF, false));
+}
+
 #define MODE_IQ 0
 #define MODE_FM 1
 
@@ -325,12 +335,30 @@ __device__ __forceinline__ void fir_tile_ffa(const unsigned char *lds, int t, co
     f32x2 x0[RH], x1[RH];
     // decimated block b holds j = RH*b + jj (window samples 2j, 2j+1 = one ds_read_b128);
     // sample jj meets output u through tap d = (TH - RH*b) + (u - jj)
-#define LOAD_DBLOCK(B)                                                                      \
+#define LOAD_DBLOCK_LDS(B)                                                                  \
     _Pragma("unroll") for (int jj = 0; jj < RH; jj++) {                                     \
         const int w = 2 * (RH * (B) + jj);                                                  \
         const f32x4 xx = *(const f32x4 *)(win + w * 8 + (w / R) * 16);                      \
         x0[jj] = xx.xy; x1[jj] = xx.zw;                                                     \
     }
+#if CLHIP_FFA_DPP
+    // Window block B of lane t is block 0 of lane t + B (lanes own R consecutive outputs and a block is R samples): after
+    // block 0 has been read from LDS, every later block arrives from the next lane by a one-lane wave shift
+    // (v_mov_b32_dpp wave_shl:1) of the registers that hold the previous block; only the lanes whose source lies
+    // in the next wave (the last B lanes) read LDS.  32 moves replace 8 ds_read_b128 per block.
+    const int lane_w = t & 63;
+#define LOAD_DBLOCK(B)                                                                      \
+    if ((B) == 0) { LOAD_DBLOCK_LDS(0) }                                                    \
+    else {                                                                                  \
+        _Pragma("unroll") for (int jj = 0; jj < RH; jj++) {                                 \
+            x0[jj].x = clhip_wave_shl1(x0[jj].x); x0[jj].y = clhip_wave_shl1(x0[jj].y);     \
+            x1[jj].x = clhip_wave_shl1(x1[jj].x); x1[jj].y = clhip_wave_shl1(x1[jj].y);     \
+        }                                                                                   \
+        if (lane_w >= 64 - (B)) { LOAD_DBLOCK_LDS(B) }                                      \
+    }
+#else
+#define LOAD_DBLOCK(B) LOAD_DBLOCK_LDS(B)
+#endif
 #define FFA_BLOCK(TAPBASE, LO, HI)                                                          \
     _Pragma("unroll") for (int jj = 0; jj < RH; jj++) {                                     \
         const f32x2 xs = x0[jj] + x1[jj];                                                   \
@@ -375,6 +403,7 @@ __device__ __forceinline__ void fir_tile_ffa(const unsigned char *lds, int t, co
         FFA_BLOCK(0, 0, RH - 1)
     }
 #undef LOAD_DBLOCK
+#undef LOAD_DBLOCK_LDS
 #undef FFA_BLOCK
 #pragma unroll
     for (int u = 0; u < RH; u++) {
