@@ -38,9 +38,11 @@ int cariboulite_radio_read_samples(cariboulite_radio_state_st *radio, cariboulit
     size_t want = length * CARIBOU_SMI_BYTES_PER_SAMPLE;
     while (want) {
         const size_t cur = want > smi->native_batch_len ? smi->native_batch_len : want;
-        const ssize_t ret = read(smi->filedesc, smi->read_temp_buffer, cur);
+        uint8_t *slot = cl_smi_feed_reserve(g_smi, cur);       /* pinned memory the GPU's copy engine reads from: no staging copy */
+        if (!slot) return -1;
+        const ssize_t ret = read(smi->filedesc, slot, cur);
         if (ret <= 0) break;
-        cl_smi_feed_bytes(g_smi, smi->read_temp_buffer, (size_t)ret);
+        cl_smi_feed_commit(g_smi, (size_t)ret);
         want -= (size_t)ret;
     }
     return cl_radio_read_samples(r, (cl_sample_complex_int16 *)buffer, (cl_sample_meta *)metadata, length);
