@@ -81,7 +81,13 @@ __device__ __forceinline__ uint32_t iir_to_i16(double y)
     return (uint32_t)t & 0xFFFFu;
 }
 
-// out[r] (+)= sum_c m[r][c] v[c] over the DxD corner of an 8x8 table
+// out[r] (+)= sum_c m[r][c] v[c] over the DxD corner of an 8x8 table.  Every table is a power of the cascade's
+// one-sample transition F, and F is block lower triangular in the state order [stage 0 | stage 1 | ...]: a stage sees
+// its own two state words and, through its input, those of the stages before it, never a later one.  Entries with
+// c > (r | 1) are exact zeros in every power (the host builds them by products of such matrices), so they are skipped:
+// 24 FMAs instead of 36 for three biquads.
+__host__ __device__ constexpr bool iir_mat_nonzero(int r, int c) { return c <= (r | 1); }
+
 template <int D, bool ACC, class MP>
 __device__ __forceinline__ void matvec(MP m, const double *v, double *out)
 {
@@ -89,7 +95,8 @@ __device__ __forceinline__ void matvec(MP m, const double *v, double *out)
     for (int r = 0; r < D; r++) {
         double s = ACC ? out[r] : 0.0;
 #pragma unroll
-        for (int c = 0; c < D; c++) s = __builtin_fma(m[r * IIR_MAX_DIM + c], v[c], s);
+        for (int c = 0; c < D; c++)
+            if (iir_mat_nonzero(r, c)) s = __builtin_fma(m[r * IIR_MAX_DIM + c], v[c], s);
         out[r] = s;
     }
 }
@@ -292,6 +299,7 @@ struct IirPlan {
     double Q[IIR_MSZ];                      // P^TILE
     double qpow2[14][IIR_MSZ];              // Q^(2^d); [8 + d] = (Q^256)^(2^d) chains the groups
     double qpow[IIR_GROUP][IIR_MSZ];        // Q^i
+    double ptab[IIR_MSZ][IIR_TILE];         // ptab[8 r + c][t] = (P^t)[r][c]: entry-major, so the 64 lanes of one load read 512 contiguous bytes
     int horizon;                            // tiles after which a carried state has decayed below 1e-18 (0: unknown / too long)
                                             // (only set when 32768 x the cascade's l1 gain also stays below 2^30: see iir_to_i16)
 };
@@ -417,26 +425,30 @@ __global__ __launch_bounds__(64) void iir_k2b_kernel(const IirPlan *__restrict__
 
 // two consecutive samples through the cascade, stage by stage: the state is written once per pair
 // ((v1, v2) <- (w_B, w_A)), so nothing is shifted between samples
-template <int NS>
+// B121: the host has seen b = (1, 2, 1) exactly in every stage after the first (what a Butterworth / Chebyshev low-pass
+// design puts there; the gain sits in stage 0).  fma(2, z0, 1 * z1) and fma(1, w, ff) round exactly like 2 z0 + z1 and
+// w + ff, so those stages take four operations instead of five with bit-identical results.
+template <int NS, bool B121 = false>
 __device__ __forceinline__ void iir_step2(const IirCoef &c, double *z, double in0, double in1, double &out0, double &out1)
 {
     double o0 = in0, o1 = in1;
 #pragma unroll
     for (int s = 0; s < NS; s++) {
         const double z0 = z[2 * s], z1 = z[2 * s + 1];
-        const double ffa = __builtin_fma(c.b1[s], z0, c.b2[s] * z1);
+        const bool unit = B121 && s > 0;
+        const double ffa = unit ? __builtin_fma(2.0, z0, z1) : __builtin_fma(c.b1[s], z0, c.b2[s] * z1);
         const double wa = __builtin_fma(-c.a2[s], z1, __builtin_fma(-c.a1[s], z0, o0));
-        o0 = __builtin_fma(c.b0[s], wa, ffa);
-        const double ffb = __builtin_fma(c.b1[s], wa, c.b2[s] * z0);
+        o0 = unit ? wa + ffa : __builtin_fma(c.b0[s], wa, ffa);
+        const double ffb = unit ? __builtin_fma(2.0, wa, z0) : __builtin_fma(c.b1[s], wa, c.b2[s] * z0);
         const double wb = __builtin_fma(-c.a2[s], z0, __builtin_fma(-c.a1[s], wa, o1));
-        o1 = __builtin_fma(c.b0[s], wb, ffb);
+        o1 = unit ? wb + ffb : __builtin_fma(c.b0[s], wb, ffb);
         z[2 * s] = wb;
         z[2 * s + 1] = wa;
     }
     out0 = o0; out1 = o1;
 }
 
-template <int NS, bool FULL, bool BOUNDED = false>
+template <int NS, bool FULL, bool BOUNDED = false, bool B121 = false>
 __device__ __forceinline__ void iir_k3_segment(const IirCoef &c, uint32_t *x, long cnt, double *zi, double *zq)
 {
 #pragma unroll 2
@@ -448,8 +460,8 @@ __device__ __forceinline__ void iir_k3_segment(const IirCoef &c, uint32_t *x, lo
             for (int j = 0; j < 4; j += 2) {
                 // filter((float)x): int16 -> float -> double is exact
                 double yi0, yi1, yq0, yq1;
-                iir_step2<NS>(c, zi, (double)(int16_t)(w[j] & 0xFFFF), (double)(int16_t)(w[j + 1] & 0xFFFF), yi0, yi1);
-                iir_step2<NS>(c, zq, (double)(int16_t)(w[j] >> 16), (double)(int16_t)(w[j + 1] >> 16), yq0, yq1);
+                iir_step2<NS, B121>(c, zi, (double)(int16_t)(w[j] & 0xFFFF), (double)(int16_t)(w[j + 1] & 0xFFFF), yi0, yi1);
+                iir_step2<NS, B121>(c, zq, (double)(int16_t)(w[j] >> 16), (double)(int16_t)(w[j + 1] >> 16), yq0, yq1);
                 w[j] = iir_to_i16<BOUNDED>(yi0) | (iir_to_i16<BOUNDED>(yq0) << 16);
                 w[j + 1] = iir_to_i16<BOUNDED>(yi1) | (iir_to_i16<BOUNDED>(yq1) << 16);
             }
@@ -552,7 +564,7 @@ __global__ __launch_bounds__(IIR_TILE) void iir_k3_kernel(const IirPlan *__restr
 #define IIR_HMAX 8
 #define IIR_SENTINEL 0xFFFFFFFFFFFFFFFFull
 
-template <int NS>
+template <int NS, bool B121>
 __global__ __launch_bounds__(IIR_TILE, 2) void iir_onepass_kernel(const IirPlan *__restrict__ plan, IirCoef c, uint32_t *__restrict__ iq,
                                                                   long stride, long n, long n_seg, long n_tiles, int n_streams,
                                                                   unsigned int *ticket, unsigned long long *agg,
@@ -675,10 +687,12 @@ __global__ __launch_bounds__(IIR_TILE, 2) void iir_onepass_kernel(const IirPlan 
                 for (int k = 0; k < D2; k++) cv[k] = nx[k];
             }
         }
-        // the lane's true start state: what the lanes before it left (zero carry) + P^t cv, P^t built from the
-        // bits of t with the scan's own P^(2^d) tables (scalar loads; a per-lane table would cost 72 VGPRs)
+        // the lane's true start state: what the lanes before it left (zero carry) + P^t cv.  P^t comes from the plan's
+        // per-lane table (its non-zero entries: D (D + 2) / 2 coalesced 8-byte loads from a 12 KB table that stays in
+        // L2) and is used once -- one product instead of the six a P^(2^d) ladder over the bits of t costs the wave.
+        // (Four biquads: 40 entries in flight would spill; they keep the ladder, on the scan's scalar tables.)
         double zi[D], zq[D];
-        {
+        if constexpr (NS > 3) {
 #pragma unroll 1
             for (int d = 0; d < 6; d++) {
                 if (t & (1 << d)) {
@@ -696,6 +710,21 @@ __global__ __launch_bounds__(IIR_TILE, 2) void iir_onepass_kernel(const IirPlan 
                 const double st = (t == 0 ? 0.0 : p) + cv[k];
                 if (k < D) zi[k] = st; else zq[k - D] = st;
             }
+        } else {
+            const double *ptab = &pl->ptab[0][0] + t;
+#pragma unroll
+            for (int r = 0; r < D; r++) {
+                const double pi = __shfl_up(v[r], 1, 64), pq = __shfl_up(v[D + r], 1, 64);
+                double si = t == 0 ? 0.0 : pi, sq = t == 0 ? 0.0 : pq;
+#pragma unroll
+                for (int cc = 0; cc < D; cc++)
+                    if (iir_mat_nonzero(r, cc)) {
+                        const double p = ptab[(r * IIR_MAX_DIM + cc) * IIR_TILE];
+                        si = __builtin_fma(p, cv[cc], si);
+                        sq = __builtin_fma(p, cv[D + cc], sq);
+                    }
+                zi[r] = si; zq[r] = sq;
+            }
         }
         // the next tile's words go out now and land while the recursion (the longest phase) runs
         if (Tn < total) {
@@ -704,10 +733,10 @@ __global__ __launch_bounds__(IIR_TILE, 2) void iir_onepass_kernel(const IirPlan 
         }
         const long seg = b * IIR_TILE + t;
         if (seg < n_seg && !(dbg & 2)) {
-            if (tile0 + (long)IIR_TILE * IIR_SEG <= n) iir_k3_segment<NS, true, true>(c, x, IIR_SEG, zi, zq);
+            if (tile0 + (long)IIR_TILE * IIR_SEG <= n) iir_k3_segment<NS, true, true, B121>(c, x, IIR_SEG, zi, zq);
             else {
                 const long cnt = n - seg * IIR_SEG < IIR_SEG ? n - seg * IIR_SEG : IIR_SEG;
-                iir_k3_segment<NS, false, true>(c, x, cnt, zi, zq);
+                iir_k3_segment<NS, false, true, B121>(c, x, cnt, zi, zq);
             }
             if (seg == n_seg - 1) {
                 // the stream's new carried state replaces the old one in place: wait until the first tiles (the only
@@ -786,6 +815,14 @@ static void iir_plan_build(const double *sos, int n_stages, IirPlan *pl)
     for (int d = 1; d < 8; d++) mat_mul(dim, pl->pow2[d - 1], pl->pow2[d - 1], pl->pow2[d]);
     static_assert(IIR_TILE == 64, "Q = P^TILE = P^(2^6)");
     memcpy(pl->Q, pl->pow2[6], sizeof pl->Q);
+    {   // P^t per lane, entry-major
+        double Pt[IIR_MSZ] = {0};
+        for (int r = 0; r < dim; r++) Pt[r * IIR_MAX_DIM + r] = 1.0;
+        for (int t = 0; t < IIR_TILE; t++) {
+            for (int e = 0; e < IIR_MSZ; e++) pl->ptab[e][t] = Pt[e];
+            mat_mul(dim, Pt, P, Pt);
+        }
+    }
     static_assert(IIR_GROUP == 256, "Q^GROUP = Q^(2^8)");
     memcpy(pl->qpow2[0], pl->Q, sizeof pl->Q);
     for (int d = 1; d < 14; d++) mat_mul(dim, pl->qpow2[d - 1], pl->qpow2[d - 1], pl->qpow2[d]);
@@ -912,10 +949,16 @@ static int iir_launch_onepass(const IirPlan *d_plan, const IirPlan &plan, double
     const long total = n_tiles * n_streams;
     const int resident = iir_resident_waves();
     const unsigned grid = (unsigned)(total < resident ? total : resident);
-    hipLaunchKernelGGL(iir_onepass_kernel<NS>, dim3(grid), dim3(IIR_TILE), IIR_LDS_WORDS * 4, s, d_plan, plan.coef, d_iq, stride, n,
-                       n_seg, n_tiles, n_streams, ticket, agg, readers, d_state, plan.horizon, err,
-                       getenv("CLHIP_IIR_DBG") ? atoi(getenv("CLHIP_IIR_DBG")) : 0,
-                       total >= 2L * grid ? (getenv("CLHIP_IIR_STAGGER_US") ? atoi(getenv("CLHIP_IIR_STAGGER_US")) : 0) * 100 : 0);   // experiment knob: measured neutral to slightly negative    // timing ablations only (results invalid)
+    bool b121 = true;                       // b = (1, 2, 1) exactly in every stage after the first: the four-operation stage form
+    for (int k = 1; k < NS; k++) b121 = b121 && plan.coef.b0[k] == 1.0 && plan.coef.b1[k] == 2.0 && plan.coef.b2[k] == 1.0;
+    const int dbg = getenv("CLHIP_IIR_DBG") ? atoi(getenv("CLHIP_IIR_DBG")) : 0;                       // timing ablations only (results invalid)
+    const int stagger = total >= 2L * grid ? (getenv("CLHIP_IIR_STAGGER_US") ? atoi(getenv("CLHIP_IIR_STAGGER_US")) : 0) * 100 : 0;   // experiment knob: measured neutral
+    if (b121 && NS > 1 && !(dbg & 16))
+        hipLaunchKernelGGL((iir_onepass_kernel<NS, true>), dim3(grid), dim3(IIR_TILE), IIR_LDS_WORDS * 4, s, d_plan, plan.coef, d_iq,
+                           stride, n, n_seg, n_tiles, n_streams, ticket, agg, readers, d_state, plan.horizon, err, dbg, stagger);
+    else
+        hipLaunchKernelGGL((iir_onepass_kernel<NS, false>), dim3(grid), dim3(IIR_TILE), IIR_LDS_WORDS * 4, s, d_plan, plan.coef, d_iq,
+                           stride, n, n_seg, n_tiles, n_streams, ticket, agg, readers, d_state, plan.horizon, err, dbg, stagger);
     return 0;
 }
 
