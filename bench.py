@@ -210,7 +210,7 @@ def bench_secondary(a, world, rank, dev, dist, red_dev, arch, taps):
             f.run(iq, n, None, stream)
         units, bytes_per, metric = n, 8.0, "Msamples/s through the Butterworth-6 IIR on CS16 (fp64, in place)"   # in place: R 4 + W 4
         desc = f"a6: 2^{a.log2_samples - 2} CS16 samples filtered in place, both rails, state carried"
-        kern = "iir_k1 + iir_k2a + iir_k2b + iir_k3"
+        kern = "iir_onepass_kernel<3, true> (one memset + one launch per step)"
     for _ in range(a.settle + a.warmup):
         step()
     dt = shard.timed_steps(step, a.steps, sync_fn=torch.cuda.synchronize, dist=dist, device=red_dev)

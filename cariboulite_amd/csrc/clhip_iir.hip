@@ -38,7 +38,18 @@
 
 #define IIR_MAX_STAGES 4
 #define IIR_MAX_DIM (2 * IIR_MAX_STAGES)
+// Compile-time shape of the single-pass kernel (defaults = the measured optimum; the others are kept buildable because
+// they were measured): samples per lane segment (a multiple of 16), waves per SIMD the register
+// budget is cut for, and whether the next tile's words wait in registers during the recursion.
+#ifndef IIR_SEG
 #define IIR_SEG 64
+#endif
+#ifndef IIR_WAVES_PER_SIMD
+#define IIR_WAVES_PER_SIMD 2
+#endif
+#ifndef IIR_PREFETCH
+#define IIR_PREFETCH 1                     // the single-pass kernel keeps the next tile's words in registers during the recursion
+#endif
 #define IIR_TILE 64                        // one wave per workgroup: no workgroup barrier anywhere in K1 / K3
 #define IIR_K2_LANES 256
 #define IIR_GROUP 256                      // tiles per K2a workgroup
@@ -109,16 +120,34 @@ __device__ __forceinline__ void matvec(MP m, const double *v, double *out)
 
 #define IIR_NLD (IIR_SEG / 4)                // 16-byte pieces per lane per tile
 
-// issue every global load of the tile first (IIR_NLD x 16 bytes in flight per lane), commit to LDS later
+// A whole, 16-byte aligned tile travels through registers: every global load is issued first (IIR_NLD x 16 bytes in
+// flight per lane) and committed to LDS later.  A ragged or unaligned tile (the last one of a stream, or a stream
+// that starts on an odd sample) is read word by word at commit time by a rolled loop that needs no registers to speak
+// of; words beyond the stream read as zero.  n_left = samples of this stream from the tile start (>= 1).
+__device__ __forceinline__ bool iir_tile_whole(const uint32_t *x, long n_left)      // workgroup-uniform
+{
+    return (((uintptr_t)x & 15) == 0) && n_left >= (long)IIR_TILE * IIR_SEG;
+}
+
 __device__ __forceinline__ void iir_tile_issue(const uint32_t *__restrict__ x, long n_left, u32x4 (&r)[IIR_NLD], int t)
 {
-    // n_left = samples of this stream from the tile start (>= 1); words beyond it read as zero
-    if ((((uintptr_t)x & 15) == 0) && n_left >= (long)IIR_TILE * IIR_SEG) {      // workgroup-uniform: 16 straight loads
+    if (!iir_tile_whole(x, n_left)) return;
 #pragma unroll
-        for (int q = 0; q < IIR_NLD; q++) r[q] = *(const u32x4 *)(x + (q * IIR_TILE + t) * 4);
+    for (int q = 0; q < IIR_NLD; q++) r[q] = *(const u32x4 *)(x + (q * IIR_TILE + t) * 4);
+}
+
+__device__ __forceinline__ void iir_tile_commit(const uint32_t *__restrict__ x, long n_left, const u32x4 (&r)[IIR_NLD], uint32_t *sm, int t)
+{
+    if (iir_tile_whole(x, n_left)) {
+#pragma unroll
+        for (int q = 0; q < IIR_NLD; q++) {
+            const int i = (q * IIR_TILE + t) * 4;
+            const int row = i / IIR_SEG, col = i % IIR_SEG;      // 4 consecutive words stay in one row
+            *(u32x4 *)(sm + row * IIR_PITCH + col) = r[q];
+        }
         return;
     }
-#pragma unroll                                                   // (unrolled: r[] must stay in registers)
+#pragma unroll 1
     for (int q = 0; q < IIR_NLD; q++) {
         const int i = (q * IIR_TILE + t) * 4;
         u32x4 v = {0, 0, 0, 0};
@@ -126,17 +155,7 @@ __device__ __forceinline__ void iir_tile_issue(const uint32_t *__restrict__ x, l
         if (i + 1 < n_left) v.y = x[i + 1];
         if (i + 2 < n_left) v.z = x[i + 2];
         if (i + 3 < n_left) v.w = x[i + 3];
-        r[q] = v;
-    }
-}
-
-__device__ __forceinline__ void iir_tile_commit(const u32x4 (&r)[IIR_NLD], uint32_t *sm, int t)
-{
-#pragma unroll
-    for (int q = 0; q < IIR_NLD; q++) {
-        const int i = (q * IIR_TILE + t) * 4;
-        const int row = i / IIR_SEG, col = i % IIR_SEG;          // 4 consecutive words stay in one row
-        *(u32x4 *)(sm + row * IIR_PITCH + col) = r[q];
+        *(u32x4 *)(sm + (i / IIR_SEG) * IIR_PITCH + i % IIR_SEG) = v;
     }
 }
 
@@ -318,7 +337,7 @@ __global__ __launch_bounds__(IIR_TILE) void iir_k1_kernel(const IirPlan *__restr
     {
         u32x4 r[IIR_NLD];
         iir_tile_issue(iq + (long)blockIdx.y * stride + tile0, n - tile0, r, t);
-        iir_tile_commit(r, iir_sm, t);
+        iir_tile_commit(iq + (long)blockIdx.y * stride + tile0, n - tile0, r, iir_sm, t);
     }
     __syncthreads();
     const cdouble_t *__restrict__ G = (const cdouble_t *)&plan->G[0][0];
@@ -524,7 +543,7 @@ __global__ __launch_bounds__(IIR_TILE) void iir_k3_kernel(const IirPlan *__restr
         zq[k] = t == 0 ? cv[D + k] : sh[(t - 1) * RS + D + k];
     }
     __syncthreads();                                         // exchange rows are read: the tile may land
-    iir_tile_commit(raw, iir_sm, t);
+    iir_tile_commit(xt, n - tile0, raw, iir_sm, t);
     __syncthreads();
     if (seg < n_seg) {
         uint32_t *x = iir_sm + t * IIR_PITCH;
@@ -565,7 +584,7 @@ __global__ __launch_bounds__(IIR_TILE) void iir_k3_kernel(const IirPlan *__restr
 #define IIR_SENTINEL 0xFFFFFFFFFFFFFFFFull
 
 template <int NS, bool B121>
-__global__ __launch_bounds__(IIR_TILE, 2) void iir_onepass_kernel(const IirPlan *__restrict__ plan, IirCoef c, uint32_t *__restrict__ iq,
+__global__ __launch_bounds__(IIR_TILE, IIR_WAVES_PER_SIMD) void iir_onepass_kernel(const IirPlan *__restrict__ plan, IirCoef c, uint32_t *__restrict__ iq,
                                                                   long stride, long n, long n_seg, long n_tiles, int n_streams,
                                                                   unsigned int *ticket, unsigned long long *agg,
                                                                   unsigned int *readers, double *state_io,
@@ -596,11 +615,13 @@ __global__ __launch_bounds__(IIR_TILE, 2) void iir_onepass_kernel(const IirPlan 
             (stagger_ticks > 0 ? (unsigned long long)(T * stagger_ticks / NW) : (unsigned long long)((T % n_streams) * (long)(-stagger_ticks)));
         while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(8);
     }
+#if IIR_PREFETCH
     u32x4 raw[IIR_NLD];
     if (T < total) {
         const long b = T / n_streams, s = T % n_streams;
         iir_tile_issue(iq + s * stride + b * IIR_TILE * IIR_SEG, n - b * IIR_TILE * IIR_SEG, raw, t0);
     }
+#endif
     while (T < total) {
         // per-iteration values stay per-iteration: otherwise the compiler hoists every lane address of the staging
         // code and every scalar table load out of the persistent loop and spills them
@@ -613,7 +634,23 @@ __global__ __launch_bounds__(IIR_TILE, 2) void iir_onepass_kernel(const IirPlan 
         const long b = T / n_streams, s = T % n_streams;
         const long tile0 = b * IIR_TILE * IIR_SEG;
         uint32_t *xt = iq + s * stride + tile0;
-        iir_tile_commit(raw, iir_sm, t);
+#if !IIR_PREFETCH
+        if (iir_tile_whole(xt, n - tile0)) {
+            u32x4 raw[IIR_NLD];
+#pragma unroll
+            for (int q = 0; q < IIR_NLD; q++) raw[q] = *(const u32x4 *)(xt + (q * IIR_TILE + t) * 4);
+#pragma unroll
+            for (int q = 0; q < IIR_NLD; q++) {
+                const int i = (q * IIR_TILE + t) * 4;
+                *(u32x4 *)(iir_sm + (i / IIR_SEG) * IIR_PITCH + i % IIR_SEG) = raw[q];
+            }
+        } else {
+            u32x4 none[IIR_NLD];
+            iir_tile_commit(xt, n - tile0, none, iir_sm, t);
+        }
+#else
+        iir_tile_commit(xt, n - tile0, raw, iir_sm, t);
+#endif
         __syncthreads();
         const long Tn = T + NW;
         // zero-state end vector of the lane's segment: zs = sum_k (F^(63-k) g) x[k]
@@ -727,10 +764,12 @@ __global__ __launch_bounds__(IIR_TILE, 2) void iir_onepass_kernel(const IirPlan 
             }
         }
         // the next tile's words go out now and land while the recursion (the longest phase) runs
+#if IIR_PREFETCH
         if (Tn < total) {
             const long bn = Tn / n_streams, sn = Tn % n_streams;
             iir_tile_issue(iq + sn * stride + bn * IIR_TILE * IIR_SEG, n - bn * IIR_TILE * IIR_SEG, raw, t);
         }
+#endif
         const long seg = b * IIR_TILE + t;
         if (seg < n_seg && !(dbg & 2)) {
             if (tile0 + (long)IIR_TILE * IIR_SEG <= n) iir_k3_segment<NS, true, true, B121>(c, x, IIR_SEG, zi, zq);
@@ -809,8 +848,7 @@ static void iir_plan_build(const double *sos, int n_stages, IirPlan *pl)
     }
     double P[IIR_MSZ];
     memcpy(P, F, sizeof P);
-    for (int k = 0; k < 6; k++) mat_mul(dim, P, P, P);     // F^64 (IIR_SEG = 64)
-    static_assert(IIR_SEG == 64, "P = F^SEG is built by six squarings");
+    for (int k = 1; k < IIR_SEG; k++) mat_mul(dim, P, F, P);     // F^SEG
     memcpy(pl->pow2[0], P, sizeof P);
     for (int d = 1; d < 8; d++) mat_mul(dim, pl->pow2[d - 1], pl->pow2[d - 1], pl->pow2[d]);
     static_assert(IIR_TILE == 64, "Q = P^TILE = P^(2^6)");
@@ -916,19 +954,23 @@ extern "C" size_t clhip_iir_workspace_bytes(size_t n_samples, int n_stages)
     return 256 + iir_var_bytes(n_samples);
 }
 
-// workgroups (= waves) the single-pass kernel keeps resident: 8 per CU (17 KB of LDS each, 2 per SIMD), per device
-static int iir_resident_waves(void)
+// Workgroups (= waves) the single-pass kernel launches: as many as the device keeps resident at once, per kernel
+// instantiation and device.  Never more: a rank's first tiles wait for the aggregates of the ranks before it, so every
+// launched wave must be running (a wave that waits for a slot would be waited for by the waves that hold the slots).
+template <class K>
+static int iir_resident_waves(K kernel, int slot)
 {
     static std::mutex mu;
-    static int cached[64];
-    int device = 0, cus = 256;
+    static int cached[16][64];
+    int device = 0, cus = 256, per_cu = 0;
     (void)hipGetDevice(&device);
     std::lock_guard<std::mutex> lock(mu);
-    if (device >= 0 && device < 64 && cached[device]) return cached[device];
+    if (device >= 0 && device < 64 && cached[slot][device]) return cached[slot][device];
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
-    const char *e = getenv("CLHIP_IIR_WG_PER_CU");
-    const int per_cu = e && atoi(e) > 0 ? atoi(e) : 8;
-    if (device >= 0 && device < 64) cached[device] = cus * per_cu;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, IIR_TILE, IIR_LDS_WORDS * 4) != hipSuccess || per_cu < 1) per_cu = 1;
+    const char *e = getenv("CLHIP_IIR_WG_PER_CU");               // experiment knob: fewer than the device would hold
+    if (e && atoi(e) > 0 && atoi(e) < per_cu) per_cu = atoi(e);
+    if (device >= 0 && device < 64) cached[slot][device] = cus * per_cu;
     return cus * per_cu;
 }
 
@@ -947,13 +989,14 @@ static int iir_launch_onepass(const IirPlan *d_plan, const IirPlan &plan, double
     unsigned long long *agg = (unsigned long long *)(ws + 2 + rd_doubles);
     CLHIP_CHECK(hipMemsetAsync(ws, 0xFF, sizeof(double) * (2 + rd_doubles + (size_t)n_tiles * n_streams * D2), s));
     const long total = n_tiles * n_streams;
-    const int resident = iir_resident_waves();
-    const unsigned grid = (unsigned)(total < resident ? total : resident);
     bool b121 = true;                       // b = (1, 2, 1) exactly in every stage after the first: the four-operation stage form
     for (int k = 1; k < NS; k++) b121 = b121 && plan.coef.b0[k] == 1.0 && plan.coef.b1[k] == 2.0 && plan.coef.b2[k] == 1.0;
     const int dbg = getenv("CLHIP_IIR_DBG") ? atoi(getenv("CLHIP_IIR_DBG")) : 0;                       // timing ablations only (results invalid)
+    const bool unit_b = b121 && NS > 1 && !(dbg & 16);
+    const int resident = unit_b ? iir_resident_waves(iir_onepass_kernel<NS, true>, 2 * NS) : iir_resident_waves(iir_onepass_kernel<NS, false>, 2 * NS + 1);
+    const unsigned grid = (unsigned)(total < resident ? total : resident);
     const int stagger = total >= 2L * grid ? (getenv("CLHIP_IIR_STAGGER_US") ? atoi(getenv("CLHIP_IIR_STAGGER_US")) : 0) * 100 : 0;   // experiment knob: measured neutral
-    if (b121 && NS > 1 && !(dbg & 16))
+    if (unit_b)
         hipLaunchKernelGGL((iir_onepass_kernel<NS, true>), dim3(grid), dim3(IIR_TILE), IIR_LDS_WORDS * 4, s, d_plan, plan.coef, d_iq,
                            stride, n, n_seg, n_tiles, n_streams, ticket, agg, readers, d_state, plan.horizon, err, dbg, stagger);
     else
