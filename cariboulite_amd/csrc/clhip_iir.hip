@@ -588,7 +588,7 @@ __global__ __launch_bounds__(IIR_TILE, IIR_WAVES_PER_SIMD) void iir_onepass_kern
                                                                   long stride, long n, long n_seg, long n_tiles, int n_streams,
                                                                   unsigned int *ticket, unsigned long long *agg,
                                                                   unsigned int *readers, double *state_io,
-                                                                  int horizon, int *err, int dbg, int stagger_ticks)
+                                                                  int horizon, unsigned int *overruns, int poll_bound, int dbg, int stagger_ticks)
 {
     constexpr int D = 2 * NS, D2 = 2 * D;
     extern __shared__ __attribute__((aligned(16))) uint32_t iir_sm[];
@@ -700,7 +700,10 @@ __global__ __launch_bounds__(IIR_TILE, IIR_WAVES_PER_SIMD) void iir_onepass_kern
                         }
                     }
                     if (ok) pending = false;
-                    else if (++guard > (1 << 20)) { *err = 0; pending = false; }   // never reached once the producer's wave is resident
+                    else if (++guard > poll_bound) {                      // never reached once the producer's wave is resident
+                        __hip_atomic_fetch_add(overruns, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // pinned host word: clhip_iir_overruns()
+                        pending = false;
+                    }
                 }
                 if (__any(pending)) __builtin_amdgcn_s_sleep(2);       // ~128 cycles: leave the issue slots and the fabric to the others
             }
@@ -782,8 +785,10 @@ __global__ __launch_bounds__(IIR_TILE, IIR_WAVES_PER_SIMD) void iir_onepass_kern
                 // readers of the old one; all of them older than this tile) have taken it.  Counter starts at all-ones.
                 const unsigned want_readers = (unsigned)((long)horizon < n_tiles ? (long)horizon : n_tiles) - 1u;
                 int spin = 0;
-                while (__hip_atomic_load(readers + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want_readers && ++spin < (1 << 20))
+                while (__hip_atomic_load(readers + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want_readers) {
+                    if (++spin > poll_bound) { __hip_atomic_fetch_add(overruns, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
                     __builtin_amdgcn_s_sleep(2);
+                }
                 double *so = state_io + s * 2 * IIR_MAX_DIM;
 #pragma unroll
                 for (int k = 0; k < D; k++) { so[k] = zi[k]; so[IIR_MAX_DIM + k] = zq[k]; }
@@ -974,16 +979,50 @@ static int iir_resident_waves(K kernel, int slot)
     return cus * per_cu;
 }
 
+// The single-pass kernel's polls are bounded (a wave waits only for waves that are running, so the bound is never
+// reached on a GPU the launch has to itself; a launch squeezed to a handful of resident waves by other work could reach
+// it).  A poll that gives up counts itself in one word of pinned, device-mapped host memory per device; the results of
+// that call are then wrong and clhip_iir_overruns() says so once the stream has been synchronised.
+static unsigned int *iir_overrun_word(unsigned int **dev_ptr)
+{
+    static std::mutex mu;
+    static unsigned int *host[64], *dev[64];
+    int device = 0;
+    (void)hipGetDevice(&device);
+    if (device < 0 || device >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!host[device]) {
+        unsigned int *h = nullptr, *d = nullptr;
+        if (hipHostMalloc((void **)&h, 64, hipHostMallocMapped) != hipSuccess) return nullptr;
+        *h = 0;
+        if (hipHostGetDevicePointer((void **)&d, h, 0) != hipSuccess) { (void)hipHostFree(h); return nullptr; }
+        host[device] = h; dev[device] = d;
+    }
+    if (dev_ptr) *dev_ptr = dev[device];
+    return host[device];
+}
+
+extern "C" int clhip_iir_overruns(void)
+{
+    unsigned int *h = iir_overrun_word(nullptr);
+    if (!h) return 0;
+    const unsigned int n = __atomic_exchange_n(h, 0u, __ATOMIC_RELAXED);
+    return n > 0x7fffffffu ? 0x7fffffff : (int)n;
+}
+
 template <int NS>
 static int iir_launch_onepass(const IirPlan *d_plan, const IirPlan &plan, double *d_state, uint32_t *d_iq, long stride, long n,
                               int n_streams, double *ws, hipStream_t s)
 {
     constexpr int D2 = 4 * NS;
     const long n_seg = (long)clhip_div_up((size_t)n, IIR_SEG), n_tiles = (long)clhip_div_up((size_t)n_seg, IIR_TILE);
-    // workspace, all of it pre-set to all-ones by ONE memset: [rank counter, error word (0 = poll overran) | 8 B pad]
+    // workspace, all of it pre-set to all-ones by ONE memset: [rank counter, spare word | 8 B pad]
     // [per stream: readers of the old carried state][aggregates: n_streams x n_tiles x 2D]
     unsigned int *ticket = (unsigned int *)ws;
-    int *err = (int *)ws + 1;
+    unsigned int *d_overruns = nullptr;
+    if (!iir_overrun_word(&d_overruns)) { clhip_set_error("clhip_iir_cs16: cannot map the overrun counter"); return -1; }
+    const char *pb = getenv("CLHIP_IIR_POLL_BOUND");                  // tests force the failure with 0
+    const int poll_bound = pb ? atoi(pb) : (1 << 20);
     unsigned int *readers = (unsigned int *)(ws + 2);
     const size_t rd_doubles = ((size_t)n_streams + 1) / 2;
     unsigned long long *agg = (unsigned long long *)(ws + 2 + rd_doubles);
@@ -998,10 +1037,10 @@ static int iir_launch_onepass(const IirPlan *d_plan, const IirPlan &plan, double
     const int stagger = total >= 2L * grid ? (getenv("CLHIP_IIR_STAGGER_US") ? atoi(getenv("CLHIP_IIR_STAGGER_US")) : 0) * 100 : 0;   // experiment knob: measured neutral
     if (unit_b)
         hipLaunchKernelGGL((iir_onepass_kernel<NS, true>), dim3(grid), dim3(IIR_TILE), IIR_LDS_WORDS * 4, s, d_plan, plan.coef, d_iq,
-                           stride, n, n_seg, n_tiles, n_streams, ticket, agg, readers, d_state, plan.horizon, err, dbg, stagger);
+                           stride, n, n_seg, n_tiles, n_streams, ticket, agg, readers, d_state, plan.horizon, d_overruns, poll_bound, dbg, stagger);
     else
         hipLaunchKernelGGL((iir_onepass_kernel<NS, false>), dim3(grid), dim3(IIR_TILE), IIR_LDS_WORDS * 4, s, d_plan, plan.coef, d_iq,
-                           stride, n, n_seg, n_tiles, n_streams, ticket, agg, readers, d_state, plan.horizon, err, dbg, stagger);
+                           stride, n, n_seg, n_tiles, n_streams, ticket, agg, readers, d_state, plan.horizon, d_overruns, poll_bound, dbg, stagger);
     return 0;
 }
 

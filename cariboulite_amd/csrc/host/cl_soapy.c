@@ -447,10 +447,24 @@ static int read_native_device(cl_stream *st, size_t n, int *aligned, long timeou
     return ret;
 }
 
+static int read_stream(cl_device *dev, cl_stream *st, void *const *buffs, size_t numElems, long timeoutUs);
+
 /* Stream::ReadSamplesGen  CaribouliteStream.cpp:370-382 */
 int cl_readStream(cl_device *dev, cl_stream *st, void *const *buffs, size_t numElems, int *flags, long long *timeNs, long timeoutUs)
 {
     (void)flags; (void)timeNs;                         /* never written; timeoutUs only matters in ASYNC mode */
+    const int ret = read_stream(dev, st, buffs, numElems, timeoutUs);
+    /* every successful return has synchronised the stream the IIR ran on: a bounded poll of the single-pass kernel
+     * that gave up (clhip_iir_overruns) means wrong samples -- they are not handed out as good ones */
+    if (ret > 0 && st->filter_type != CL_DIGFILT_NONE && clhip_iir_overruns() > 0) {
+        cl_seterr(dev->err, sizeof dev->err, "readStream: the IIR kernel could not order its tiles (GPU shared with other work?); samples dropped, filter state is undefined");
+        return 0;                                                                   /* :266-276: errors read as 0 */
+    }
+    return ret;
+}
+
+static int read_stream(cl_device *dev, cl_stream *st, void *const *buffs, size_t numElems, long timeoutUs)
+{
     if (st->native_dir != CL_SOAPY_SDR_RX) return CL_SOAPY_SDR_NOT_SUPPORTED;       /* :248-251 */
     cl_smi *smi = dev->smi;
     clhip_set_device(smi->device);

@@ -51,6 +51,7 @@ _SIGS = {
     "clhip_smi_pack": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "clhip_iir_cs16": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
     "clhip_iir_workspace_bytes": (C.c_size_t, [C.c_size_t, C.c_int]),
+    "clhip_iir_overruns": (C.c_int, []),
     "clhip_iir_cs16_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int,
                                        C.c_void_p, C.c_size_t, C.c_void_p]),
     "clhip_rx_pipe_create": (C.c_void_p, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -252,6 +253,11 @@ class IIR:
                                           n if stride is None else stride, n, self.n_streams, ptr(self.ws),
                                           self.ws.numel(), stream if stream is not None else current_stream()),
                "clhip_iir_cs16_batch")
+
+    @staticmethod
+    def overruns():
+        """polls of the single-pass kernel that gave up on this device since the last call (after a synchronise)"""
+        return lib().clhip_iir_overruns()
 
 
 class TxPipe:

@@ -167,6 +167,12 @@ size_t clhip_iir_workspace_bytes(size_t n_samples, int n_stages);   /* per strea
 int clhip_iir_cs16_batch(const double *h_sos, int n_stages, double *d_state, int16_t *d_iq,
                          size_t stride_samples, size_t n_samples, int n_streams,
                          void *d_workspace, size_t workspace_bytes, void *stream);
+/* The single-pass kernel orders its tiles by waiting for the waves before it, with bounded polls.  Number of polls
+ * that gave up on the current device since the last call of this function (and reset to 0): non-zero means the IIR
+ * calls that have completed since then produced wrong samples and left a wrong carried state (only a launch squeezed
+ * to a handful of resident waves by other work on the GPU can get there).  Valid once the streams those calls ran on
+ * have been synchronised; costs one read of pinned host memory. */
+int clhip_iir_overruns(void);
 
 /*
  * The RX pipe: raw SMI words -> int13 I/Q -> x/4096 -> FIR(T) -> [L/M polyphase

@@ -406,3 +406,31 @@ def test_iir_narrowest_reference_filter_many_tiles(G, orc):
         want = orc.IIR(6, 4e6, 10e3).apply_cs16(x[s].copy())
         diff = np.abs(got[s].astype(np.int32) - want.astype(np.int32))
         assert diff.max() <= 1 and np.mean(diff != 0) < 1e-4, (s, diff.max(), np.mean(diff != 0))
+
+
+def test_iir_poll_overrun_is_counted_and_reported(G, orc, monkeypatch):
+    """The single-pass kernel's polls are bounded.  With the bound forced to 0 every tile that finds a predecessor's
+    aggregate not yet published gives up: the call must say so through clhip_iir_overruns() (the Soapy layer turns that
+    into a failed read), the counter resets when read, and a normal call afterwards is clean and exact again."""
+    import torch
+    from cariboulite_amd import hip
+    rng = np.random.default_rng(5)
+    n = 600 * 4096 + 123
+    x = rng.integers(-4096, 4096, size=(n, 2), dtype=np.int16)
+    hip.IIR.overruns()                                   # whatever earlier tests left
+    monkeypatch.setenv("CLHIP_IIR_POLL_BOUND", "0")
+    f = hip.IIR(_sos5(orc.IIR(6, 4e6, 50e3)), 1)
+    d = torch.from_numpy(x.copy()).to(G.DEV)
+    f.run(d, n)
+    torch.cuda.synchronize()
+    assert hip.IIR.overruns() > 0
+    assert hip.IIR.overruns() == 0                       # read-and-reset
+    monkeypatch.delenv("CLHIP_IIR_POLL_BOUND")
+    f = hip.IIR(_sos5(orc.IIR(6, 4e6, 50e3)), 1)
+    d = torch.from_numpy(x.copy()).to(G.DEV)
+    f.run(d, n)
+    torch.cuda.synchronize()
+    assert hip.IIR.overruns() == 0
+    want = orc.IIR(6, 4e6, 50e3).apply_cs16(x.copy())
+    diff = np.abs(d.cpu().numpy().astype(np.int32) - want.astype(np.int32))
+    assert diff.max() <= 1 and np.mean(diff != 0) < 1e-4, (diff.max(), np.mean(diff != 0))

@@ -157,6 +157,26 @@ def test_iir_via_set_bandwidth_state_persists(S, orc):
     sdr.close()
 
 
+def test_iir_overrun_fails_the_read_instead_of_handing_out_samples(S, orc, monkeypatch):
+    """A bounded poll of the single-pass IIR kernel that gives up (forced here with a bound of 0) must not reach the
+    client as samples: readStream squashes it to 0 like every other read error (CaribouliteStream.cpp:266-276) and the
+    device says why."""
+    from cariboulite_amd import synth
+    sdr = S.Device(dict(driver="Cariboulite", channel="S1G"))
+    rx = sdr.setupStream(S.SOAPY_SDR_RX, S.SOAPY_SDR_CS16)
+    sdr.setBandwidth(S.SOAPY_SDR_RX, 0, 90e3)
+    K = 16                                                        # CS16 reads are not clamped to the MTU: 512 tiles in one launch
+    b, _, _ = synth.smi_stream_bytes((K + 1) * MTU, 0, stream=12)
+    sdr.feedSmiBytes(b)
+    buf = np.zeros((K * MTU, 2), np.int16)
+    monkeypatch.setenv("CLHIP_IIR_POLL_BOUND", "0")
+    assert sdr.readStream(rx, [buf], K * MTU).ret == 0
+    assert "IIR" in sdr.lastError()
+    monkeypatch.delenv("CLHIP_IIR_POLL_BOUND")
+    assert sdr.readStream(rx, [buf], MTU).ret == MTU              # the next batch is read normally
+    sdr.close()
+
+
 def test_rx_extension_stages_via_kwargs(S, orc):
     """FIR / RESAMP / DEMOD kwargs (SURVEY.md section 5 'Config / flags'), default = reference behaviour."""
     from cariboulite_amd import synth
