@@ -583,6 +583,22 @@ __global__ __launch_bounds__(IIR_TILE) void iir_k3_kernel(const IirPlan *__restr
 #define IIR_HMAX 8
 #define IIR_SENTINEL 0xFFFFFFFFFFFFFFFFull
 
+// A wave's rank: start order within its class (block index mod 64), classes interleaved -- rank = class + 64 * (how many
+// waves of the class started before it).  Workgroups are dispatched in index order, so this is the start order of the
+// launch to within a few waves, and a wave that is running still only ever waits for waves that started before it or
+// are starting now, which is what keeps a launch that is only partly resident moving.  One counter for all waves would
+// give the exact order, but same-address atomics retire at ~12 ns each: 2 048 of them delay the last wave by 25 us, a
+// tenth of this kernel's run time (and a ticket per TILE, 16 384 of them, two thirds of it).  The 64 counters start at
+// all-ones.
+#define IIR_RANK_CLASSES 64
+__device__ __forceinline__ long iir_take_rank(unsigned int *ticket, int t0)
+{
+    const unsigned int cls = blockIdx.x & (IIR_RANK_CLASSES - 1);
+    unsigned int tk = 0;
+    if (t0 == 0) tk = atomicAdd(ticket + cls, 1u) + 1u;
+    return (long)cls + (long)IIR_RANK_CLASSES * (long)(unsigned)__builtin_amdgcn_readfirstlane((int)tk);
+}
+
 template <int NS, bool B121>
 __global__ __launch_bounds__(IIR_TILE, IIR_WAVES_PER_SIMD) void iir_onepass_kernel(const IirPlan *__restrict__ plan, IirCoef c, uint32_t *__restrict__ iq,
                                                                   long stride, long n, long n_seg, long n_tiles, int n_streams,
@@ -595,15 +611,11 @@ __global__ __launch_bounds__(IIR_TILE, IIR_WAVES_PER_SIMD) void iir_onepass_kern
     const int t0 = threadIdx.x;
     const long total = n_tiles * n_streams;
 
-    unsigned int tk = 0;
-    // ONE ticket per wave: its rank in start order.  Rank r takes tiles r, r + G, r + 2G, ... (G = waves launched):
-    // a tile's H predecessors belong to the H ranks before it, which started earlier and are at the same point of
-    // their own lists, so nobody waits long; ranks 0..H-1 wrap to the last ranks of the previous round, which exist
-    // as soon as the launch is resident.  (A ticket per TILE would order everything strictly, but same-address
-    // atomics retire at ~12 ns each: 16384 of them are two thirds of this kernel's run time.)  Aggregates are
-    // published BEFORE a wave waits for anything, so a late-starting rank delays its successors, never deadlocks them.
-    if (t0 == 0) tk = atomicAdd(ticket, 1u) + 1u;                      // the counter starts at all-ones
-    long T = (long)(unsigned)__builtin_amdgcn_readfirstlane((int)tk);
+    // ONE ticket per wave: its rank.  Rank r takes tiles r, r + G, r + 2G, ... (G = waves launched): a tile's H
+    // predecessors belong to the H ranks before it, which are at the same point of their own lists, so nobody waits
+    // long; ranks 0..H-1 wrap to the last ranks of the previous round.  Aggregates are published BEFORE a wave waits
+    // for anything, so a late-starting rank delays its successors, never deadlocks them.
+    long T = iir_take_rank(ticket, t0);
     const long NW = (long)gridDim.x;                                  // waves launched
     if (stagger_ticks != 0 && T < total) {
         // Spread the waves' phases over one tile period (rank r starts r/NW of a period late): identical waves
@@ -689,17 +701,16 @@ __global__ __launch_bounds__(IIR_TILE, IIR_WAVES_PER_SIMD) void iir_onepass_kern
             int guard = 0;
             while (__any(pending)) {
                 if (pending) {
-                    // the 2D stores land in any order: watch the last word, then take all of them and check each
-                    bool ok = __hip_atomic_load(theirs + D2 - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != IIR_SENTINEL;
-                    if (ok) {
+                    // the 2D stores land in any order: take all of them every time and check each (one round trip through
+                    // the fabric per poll; watching one word first would add a second trip to the poll that succeeds)
+                    bool ok = true;
 #pragma unroll
-                        for (int k = 0; k < D2; k++) {
-                            const unsigned long long w = __hip_atomic_load(theirs + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            ok &= w != IIR_SENTINEL;
-                            a[k] = __builtin_bit_cast(double, w);
-                        }
+                    for (int k = 0; k < D2; k++) {
+                        const unsigned long long w = __hip_atomic_load(theirs + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok &= w != IIR_SENTINEL;
+                        a[k] = __builtin_bit_cast(double, w);
                     }
-                    if (ok) pending = false;
+                    if (ok && poll_bound >= 0) pending = false;
                     else if (++guard > poll_bound) {                      // never reached once the producer's wave is resident
                         __hip_atomic_fetch_add(overruns, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // pinned host word: clhip_iir_overruns()
                         pending = false;
@@ -966,13 +977,16 @@ template <class K>
 static int iir_resident_waves(K kernel, int slot)
 {
     static std::mutex mu;
-    static int cached[16][64];
+    static int cached[32][64];
     int device = 0, cus = 256, per_cu = 0;
     (void)hipGetDevice(&device);
     std::lock_guard<std::mutex> lock(mu);
     if (device >= 0 && device < 64 && cached[slot][device]) return cached[slot][device];
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, IIR_TILE, IIR_LDS_WORDS * 4) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (per_cu > 4) per_cu -= per_cu % 4;                        // the same number of waves on each of the CU's four SIMDs: the ring
+                                                                 // advances at the pace of its slowest wave, and a SIMD with one
+                                                                 // wave more than the others sets that pace for everybody
     const char *e = getenv("CLHIP_IIR_WG_PER_CU");               // experiment knob: fewer than the device would hold
     if (e && atoi(e) > 0 && atoi(e) < per_cu) per_cu = atoi(e);
     if (device >= 0 && device < 64) cached[slot][device] = cus * per_cu;
@@ -1016,17 +1030,18 @@ static int iir_launch_onepass(const IirPlan *d_plan, const IirPlan &plan, double
 {
     constexpr int D2 = 4 * NS;
     const long n_seg = (long)clhip_div_up((size_t)n, IIR_SEG), n_tiles = (long)clhip_div_up((size_t)n_seg, IIR_TILE);
-    // workspace, all of it pre-set to all-ones by ONE memset: [rank counter, spare word | 8 B pad]
+    // workspace, all of it pre-set to all-ones by ONE memset: [64 rank counters]
     // [per stream: readers of the old carried state][aggregates: n_streams x n_tiles x 2D]
     unsigned int *ticket = (unsigned int *)ws;
     unsigned int *d_overruns = nullptr;
     if (!iir_overrun_word(&d_overruns)) { clhip_set_error("clhip_iir_cs16: cannot map the overrun counter"); return -1; }
-    const char *pb = getenv("CLHIP_IIR_POLL_BOUND");                  // tests force the failure with 0
+    const char *pb = getenv("CLHIP_IIR_POLL_BOUND");                  // tests force the give-up path with -1
     const int poll_bound = pb ? atoi(pb) : (1 << 20);
-    unsigned int *readers = (unsigned int *)(ws + 2);
+    constexpr size_t TK = IIR_RANK_CLASSES * sizeof(unsigned int) / sizeof(double);
+    unsigned int *readers = (unsigned int *)(ws + TK);
     const size_t rd_doubles = ((size_t)n_streams + 1) / 2;
-    unsigned long long *agg = (unsigned long long *)(ws + 2 + rd_doubles);
-    CLHIP_CHECK(hipMemsetAsync(ws, 0xFF, sizeof(double) * (2 + rd_doubles + (size_t)n_tiles * n_streams * D2), s));
+    unsigned long long *agg = (unsigned long long *)(ws + TK + rd_doubles);
+    CLHIP_CHECK(hipMemsetAsync(ws, 0xFF, sizeof(double) * (TK + rd_doubles + (size_t)n_tiles * n_streams * D2), s));
     const long total = n_tiles * n_streams;
     bool b121 = true;                       // b = (1, 2, 1) exactly in every stage after the first: the four-operation stage form
     for (int k = 1; k < NS; k++) b121 = b121 && plan.coef.b0[k] == 1.0 && plan.coef.b1[k] == 2.0 && plan.coef.b2[k] == 1.0;

@@ -409,8 +409,8 @@ def test_iir_narrowest_reference_filter_many_tiles(G, orc):
 
 
 def test_iir_poll_overrun_is_counted_and_reported(G, orc, monkeypatch):
-    """The single-pass kernel's polls are bounded.  With the bound forced to 0 every tile that finds a predecessor's
-    aggregate not yet published gives up: the call must say so through clhip_iir_overruns() (the Soapy layer turns that
+    """The single-pass kernel's polls are bounded.  With the bound forced below 0 every tile that looks at a predecessor's
+    aggregate gives up: the call must say so through clhip_iir_overruns() (the Soapy layer turns that
     into a failed read), the counter resets when read, and a normal call afterwards is clean and exact again."""
     import torch
     from cariboulite_amd import hip
@@ -418,7 +418,7 @@ def test_iir_poll_overrun_is_counted_and_reported(G, orc, monkeypatch):
     n = 600 * 4096 + 123
     x = rng.integers(-4096, 4096, size=(n, 2), dtype=np.int16)
     hip.IIR.overruns()                                   # whatever earlier tests left
-    monkeypatch.setenv("CLHIP_IIR_POLL_BOUND", "0")
+    monkeypatch.setenv("CLHIP_IIR_POLL_BOUND", "-1")
     f = hip.IIR(_sos5(orc.IIR(6, 4e6, 50e3)), 1)
     d = torch.from_numpy(x.copy()).to(G.DEV)
     f.run(d, n)

@@ -158,7 +158,7 @@ def test_iir_via_set_bandwidth_state_persists(S, orc):
 
 
 def test_iir_overrun_fails_the_read_instead_of_handing_out_samples(S, orc, monkeypatch):
-    """A bounded poll of the single-pass IIR kernel that gives up (forced here with a bound of 0) must not reach the
+    """A bounded poll of the single-pass IIR kernel that gives up (forced here with a negative bound) must not reach the
     client as samples: readStream squashes it to 0 like every other read error (CaribouliteStream.cpp:266-276) and the
     device says why."""
     from cariboulite_amd import synth
@@ -169,7 +169,7 @@ def test_iir_overrun_fails_the_read_instead_of_handing_out_samples(S, orc, monke
     b, _, _ = synth.smi_stream_bytes((K + 1) * MTU, 0, stream=12)
     sdr.feedSmiBytes(b)
     buf = np.zeros((K * MTU, 2), np.int16)
-    monkeypatch.setenv("CLHIP_IIR_POLL_BOUND", "0")
+    monkeypatch.setenv("CLHIP_IIR_POLL_BOUND", "-1")
     assert sdr.readStream(rx, [buf], K * MTU).ret == 0
     assert "IIR" in sdr.lastError()
     monkeypatch.delenv("CLHIP_IIR_POLL_BOUND")
