@@ -434,3 +434,38 @@ def test_iir_poll_overrun_is_counted_and_reported(G, orc, monkeypatch):
     want = orc.IIR(6, 4e6, 50e3).apply_cs16(x.copy())
     diff = np.abs(d.cpu().numpy().astype(np.int32) - want.astype(np.int32))
     assert diff.max() <= 1 and np.mean(diff != 0) < 1e-4, (diff.max(), np.mean(diff != 0))
+
+
+@pytest.mark.parametrize("order", [4, 6, 8])
+def test_iir_sections_with_general_numerators(G, orc, order):
+    """The C ABI takes any biquad cascade.  A Chebyshev-II low-pass has its zeros off z = -1, so no section is
+    b = (1, 2, 1): the single-pass kernel takes its five-operation stage form (the Butterworth designs of the other tests
+    all take the four-operation one).  Oracle: the same DF-II cascade (orc_iir_step) with these coefficients."""
+    import ctypes as C
+    import torch
+    from scipy import signal
+    from cariboulite_amd import hip
+    sos = signal.cheby2(order, 40, 120e3, "low", fs=4e6, output="sos")
+    assert not any(np.array_equal(s[:3], [1.0, 2.0, 1.0]) for s in sos[1:])
+    sos5 = np.concatenate([sos[:, :3] / sos[:, 3:4], sos[:, 4:] / sos[:, 3:4]], 1)
+
+    def oracle_filter():
+        f = orc.IIR(order, 4e6, 50e3)                    # any design of the same order: only the struct is reused
+        for rail in (f.fi, f.fq):
+            for s in range(order // 2):
+                rail.b0[s], rail.b1[s], rail.b2[s], rail.a1[s], rail.a2[s] = sos5[s]
+                rail.v1[s] = rail.v2[s] = 0.0
+        return f
+
+    rng = np.random.default_rng(order)
+    n1, n2 = 70 * 4096 + 333, 5 * 4096 + 1
+    x = rng.integers(-4096, 4096, size=(n1 + n2, 2), dtype=np.int16)
+    f = hip.IIR(sos5, 1)
+    d = torch.from_numpy(x.copy()).to(G.DEV)
+    f.run(d, n1)
+    f.run(d[n1:], n2)                                    # carried state, ragged tails
+    torch.cuda.synchronize()
+    assert hip.IIR.overruns() == 0
+    want = oracle_filter().apply_cs16(x.copy())
+    diff = np.abs(d.cpu().numpy().astype(np.int32) - want.astype(np.int32))
+    assert diff.max() <= 1 and np.mean(diff != 0) < 1e-4, (diff.max(), np.mean(diff != 0))
