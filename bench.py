@@ -101,7 +101,7 @@ def cpu_baseline(taps, d_words, budget_s):
 def pmc_traffic(workload):
     """HBM bytes per step measured with rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections;
     tools/collect_workload_profiles.sh) and committed under profiles/: (bytes, source) or (None, None)."""
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         f = os.path.join(ROOT, "profiles", rnd, f"{workload}_pmc.json")
         if os.path.exists(f):
             try:
@@ -167,6 +167,7 @@ def bench_secondary(a, world, rank, dev, dist, red_dev, arch, taps):
     contract: one independent copy of the workload per GPU, no data-path collective."""
     from cariboulite_amd import hip, synth, shard
     stream = torch.cuda.current_stream().cuda_stream
+    checks = []                                   # verdicts asked after the timed region (a failed one voids the line)
     if a.workload == "c1":
         n = 1 << a.log2_samples
         nch = max(n // NATIVE_CHUNK_SAMPLES, 1)
@@ -210,10 +211,13 @@ def bench_secondary(a, world, rank, dev, dist, red_dev, arch, taps):
             f.run(iq, n, None, stream)
         units, bytes_per, metric = n, 8.0, "Msamples/s through the Butterworth-6 IIR on CS16 (fp64, in place)"   # in place: R 4 + W 4
         desc = f"a6: 2^{a.log2_samples - 2} CS16 samples filtered in place, both rails, state carried"
-        kern = "iir_onepass_kernel<3, true> (one memset + one launch per step)"
+        kern = "iir_rail_kernel<3, 64, true> (one launch per step)"
+        checks.append(lambda: f.status() == 0 and not f.on_scan_path())
     for _ in range(a.settle + a.warmup):
         step()
     dt = shard.timed_steps(step, a.steps, sync_fn=torch.cuda.synchronize, dist=dist, device=red_dev)
+    if not all(c() for c in checks):
+        raise SystemExit(f"bench.py --workload {a.workload}: a timed step reported an overrun; the line would be invalid")
     if rank == 0:
         value = world * units * a.steps / dt / 1e6
         ach = bytes_per * units * a.steps / dt / 1e9

@@ -20,8 +20,10 @@
 //       K3 rebuilds its tile carry as X[tile] + Q^i gc[g]
 //   K3  the same shuffle scan over u = zs (+ P * tile carry on the first lane) gives the state after every
 //       segment; shifted by one lane it is every lane's true start state.  The lane then runs the
-//       recursion over its segment and writes the truncated int16 outputs in place.
+//       recursion over its segment and writes the truncated int16 outputs.
 //       The tile's global loads are in flight while the scan runs.
+// That four-kernel scan has no communication between workgroups; it is the path of filters whose memory is too long
+// for the single-pass kernel below (the default), and the one a call is repeated on when a single-pass launch gave up.
 // Tiles travel through LDS (coalesced 16-byte global accesses on one side, one row of 64+4 dwords per
 // lane on the other: lane t reading 16 bytes of row t touches banks 4t..4t+3 -- conflict-free).
 // F, g, P^(2^d), P^i, Q^(2^d) and Q^i are built on the host in fp64 by simulating the cascade, once per filter
@@ -38,24 +40,14 @@
 
 #define IIR_MAX_STAGES 4
 #define IIR_MAX_DIM (2 * IIR_MAX_STAGES)
-// Compile-time shape of the single-pass kernel (defaults = the measured optimum; the others are kept buildable because
-// they were measured): samples per lane segment (a multiple of 16), waves per SIMD the register
-// budget is cut for, and whether the next tile's words wait in registers during the recursion.
-#ifndef IIR_SEG
-#define IIR_SEG 64
-#endif
-#ifndef IIR_WAVES_PER_SIMD
-#define IIR_WAVES_PER_SIMD 2
-#endif
-#ifndef IIR_PREFETCH
-#define IIR_PREFETCH 1                     // the single-pass kernel keeps the next tile's words in registers during the recursion
-#endif
+#define IIR_SEG 64                         // the four-kernel scan: samples per lane segment (both rails per lane)
 #define IIR_TILE 64                        // one wave per workgroup: no workgroup barrier anywhere in K1 / K3
 #define IIR_K2_LANES 256
 #define IIR_GROUP 256                      // tiles per K2a workgroup
 #define IIR_MSZ (IIR_MAX_DIM * IIR_MAX_DIM) // matrices are stored 8x8, row-major, zero outside DxD
 
 typedef __attribute__((address_space(4))) double cdouble_t;   // read-only tables: scalar (SMEM) loads when uniform
+typedef __attribute__((address_space(1))) double gdouble_t;   // per-lane table reads: global (not flat) loads
 
 struct IirCoef {
     int n_stages, dim;
@@ -311,17 +303,23 @@ __device__ __forceinline__ void iir_segment_fir(double *v, const uint32_t *x, co
     iir_taps_wait<D>(ta);
 }
 
+#define RL_SEGS 32                         // the single-pass kernel: segments (lane pairs) per tile
+struct IirRailTab {                        // per (filter, segment length)
+    double pow2[10][IIR_MSZ];              // P^(2^d), P = F^SEG; [5] = Q = P^32; [5 + d] = Q^(2^d)
+    double ptab[IIR_MSZ][RL_SEGS];         // ptab[8 r + c][m] = (P^m)[r][c]: entry-major, one load = 32 x 8 contiguous bytes
+    int seg, horizon;                      // horizon in tiles of 32 x seg samples; 0 = none within RL_HMAX (or the output gain is unbounded)
+};
+
 struct IirPlan {
     IirCoef coef;
     double G[IIR_SEG][IIR_MAX_DIM];         // G[j] = F^j g
-    double pow2[8][IIR_MSZ];                // P^(2^d), P = F^SEG
-    double Q[IIR_MSZ];                      // P^TILE
-    double qpow2[14][IIR_MSZ];              // Q^(2^d); [8 + d] = (Q^256)^(2^d) chains the groups
-    double qpow[IIR_GROUP][IIR_MSZ];        // Q^i
-    double ptab[IIR_MSZ][IIR_TILE];         // ptab[8 r + c][t] = (P^t)[r][c]: entry-major, so the 64 lanes of one load read 512 contiguous bytes
-    int horizon;                            // tiles after which a carried state has decayed below 1e-18 (0: unknown / too long)
-                                            // (only set when 32768 x the cascade's l1 gain also stays below 2^30: see iir_to_i16)
+    double pow2[8][IIR_MSZ];                // P^(2^d), P = F^SEG                         } the four-kernel scan's
+    double Q[IIR_MSZ];                      // P^TILE                                     } tables (64 x 64-sample
+    double qpow2[14][IIR_MSZ];              // Q^(2^d); [8 + d] = (Q^256)^(2^d)           } tiles, both rails per
+    double qpow[IIR_GROUP][IIR_MSZ];        // Q^i                                        } lane)
+    IirRailTab rail[3];                     // the single-pass kernel's, per segment length (kRailSegs)
 };
+
 
 // K1: zero-state end vector per segment (written to ZS) and the tile's zero-carry end vector.
 //   ZS[stream][seg][2D], tend[stream][tile][2D]
@@ -499,7 +497,7 @@ __device__ __forceinline__ void iir_k3_segment(const IirCoef &c, uint32_t *x, lo
 }
 
 template <int NS>
-__global__ __launch_bounds__(IIR_TILE) void iir_k3_kernel(const IirPlan *__restrict__ plan, IirCoef c, uint32_t *__restrict__ iq,
+__global__ __launch_bounds__(IIR_TILE) void iir_k3_kernel(const IirPlan *__restrict__ plan, IirCoef c, const uint32_t *in, uint32_t *out,
                                                          long stride, long n, long n_seg, long n_tiles, long n_groups,
                                                          const double *__restrict__ ZS, const double *__restrict__ X,
                                                          const double *__restrict__ gc, double *__restrict__ state)
@@ -508,7 +506,8 @@ __global__ __launch_bounds__(IIR_TILE) void iir_k3_kernel(const IirPlan *__restr
     extern __shared__ __attribute__((aligned(16))) uint32_t iir_sm[];
     const int t = threadIdx.x;
     const long tile0 = (long)blockIdx.x * IIR_TILE * IIR_SEG;
-    uint32_t *xt = iq + (long)blockIdx.y * stride + tile0;
+    const uint32_t *xt = in + (long)blockIdx.y * stride + tile0;
+    uint32_t *xo = out + (long)blockIdx.y * stride + tile0;
     u32x4 raw[IIR_NLD];
     iir_tile_issue(xt, n - tile0, raw, t);                   // in flight while the start states are computed
     const long seg = (long)blockIdx.x * IIR_TILE + t;
@@ -559,256 +558,476 @@ __global__ __launch_bounds__(IIR_TILE) void iir_k3_kernel(const IirPlan *__restr
         }
     }
     __syncthreads();
-    iir_tile_store(xt, n - tile0, iir_sm, t);
+    iir_tile_store(xo, n - tile0, iir_sm, t);
 }
 
-
 // ---------------------------------------------------------------------------
-// Single pass (default).  The stream is read ONCE and written once: a persistent wave takes tiles by ticket,
-// stages a tile in LDS, forms every segment's zero-state end vector (the K1 matrix FIR), scans them over the tile
-// (zero carry) and publishes the tile's zero-carry end vector -- its AGGREGATE.  The state entering the tile is then
-//     cv = sum_{k=1..H} Q^(k-1) aggregate(tile - k)            (+ Q^tile * carried state for the first H tiles)
-// where H = plan->horizon is the number of tiles after which ANY reachable state has decayed below 1e-18 in absolute
-// terms (int16 inputs bound the state; the bound is evaluated on the host from |Q^H| and the filter's l1 gains, far
-// below the 1e-8 rounding noise the fp64 sums carry anyway).  So a tile waits for H predecessors' aggregates -- not
-// for their prefixes: there is no chain through the launch, every tile is done a fixed time after it starts, and a
-// filter too narrow for H <= IIR_HMAX takes the four-kernel scan instead.  Lane t's start state is the exclusive
-// scan value + P^t cv; it runs the recursion over its LDS row in place and the tile leaves with coalesced stores
-// while the next tile's loads (issued before the recursion) are already in registers.
-//   Publication: an aggregate is 2D doubles written with relaxed agent-scope 64-bit atomic stores into slots the
-// host pre-set to all-ones (a NaN no aggregate can be): a reader polls until none of the 2D words is the sentinel,
-// so no flag, no fence and no store ordering is needed.  Producing an aggregate never waits for anything, so the
-// poll always ends once the producer's wave is resident (it is bounded all the same).
+// Single pass (default).  The stream is read ONCE and written once.
+//
+// Shape: the two rails of a segment sit on NEIGHBOURING LANES -- lane t = (segment t >> 1, rail t & 1) -- so a lane
+// carries D doubles of state where a lane that owns both rails carries 2D, a tile is 32 segments x SEG samples
+// (8.5 KB of LDS at SEG = 64) and the kernel fits four waves per SIMD at full-length segments: fp64 issue needs
+// that many waves to approach its rate (tools/microbench/fir64_phase.hip: 15 T DFMA-lanes/s at one wave per SIMD, 20 at
+// two, 25-31 at four to eight).  Both lanes of a pair read the same LDS words (a broadcast), each takes its half;
+// the (int16)(float) results of a pair meet again through one DPP quad swap + one v_perm_b32 per sample.
+//
+// Per tile: coalesced load -> LDS rows -> every segment's zero-state end vector as a SEG-tap matrix FIR (taps by
+// scalar loads, double-buffered in SGPRs) -> Kogge-Stone shuffle scan over the 32 segments with P^(2^d), P = F^SEG ->
+// the tile's zero-carry end vector, its AGGREGATE, published by the last lane pair.  The state entering the tile is
+//     cv = sum_{k=1..H} Q^(k-1) aggregate(tile - k)     (the carried state stands in for tile -1),   Q = P^32
+// where H = the horizon: the number of tiles after which ANY reachable state has decayed below 1e-18 absolute (host:
+// iir_horizon).  So a tile waits for H predecessors' aggregates, never for their prefixes: no chain through the
+// launch.  Lane pair h fetches aggregate(tile-1-h); H <= 6 folds them by Horner, longer horizons (short tiles of a
+// narrow filter) by a log-step tree with Q^(2^d).  Lane start state = exclusive scan value + P^m cv (P^m from a per-
+// segment table), DF-II recursion two samples per cascade pass over the LDS row, coalesced store.
+//
+// Order and progress: a wave takes its tiles by atomic ticket from one of 64 counters (its class = block index mod
+// 64): tile = class + 64 * ticket.  Same-address atomics retire at ~12 ns each, so one counter would serialise the
+// launch; 64 counters hand out tiles in start order to within a few tiles.  The ticket of the NEXT tile is requested
+// at the top of the current one, so its round trip is never waited for.  A tile's predecessors have smaller indices;
+// the smallest tile nobody has taken is taken as soon as a wave of its class finishes what it holds, and that wave
+// only waits for tiles that HAVE been taken (whose aggregates are published before their owners wait for anything):
+// the launch moves as long as one wave of every class is running -- the first 64 workgroups dispatched -- whatever
+// else shares the GPU, and however many of the launched waves are resident.  Polls are bounded all the same: one
+// that gives up zeroes what it did not get (no NaN reaches the state), raises the object's pinned overrun word and a
+// device-side abort flag that ends every other poll of the launch at once; the host rolls the call back.
+//
+// Publication: an aggregate is D doubles per rail written with relaxed agent-scope 64-bit atomic stores into slots
+// pre-set to all-ones (a NaN no aggregate can be): a reader polls until none of its D words is the sentinel, so no
+// flag, no fence and no store ordering is needed.  Two aggregate buffers alternate between launches and every launch
+// re-arms the one it does not use (each wave a share), so a call is ONE launch: no memset.  The counters are put
+// back to zero by the last wave out.  The carried state is ping-pong (read from one half, written to the other).
 // ---------------------------------------------------------------------------
-#define IIR_HMAX 8
 #define IIR_SENTINEL 0xFFFFFFFFFFFFFFFFull
+#define RL_HMAX 32                         // a lane pair per predecessor
+#define RL_HORNER_MAX 6                    // longer horizons fold by the log-step tree
+#define RL_CLASSES 64
+#ifndef RL_CTL_STRIDE
+#define RL_CTL_STRIDE 1024                 // words between control words: 4 KB apart, each in a memory channel of its own (atomics to
+#endif                                     // ONE 256-byte block retire one at a time whatever their addresses: 32 768 of them, 0.19 ms)
+#define RL_CTL_EXIT (64 * RL_CTL_STRIDE)   // ctl[c * stride]: class counters; then: waves that have left, abort flag
+#define RL_CTL_ABORT (65 * RL_CTL_STRIDE)
+#define RL_CTL_WORDS (66 * RL_CTL_STRIDE)
+#ifndef RL_WAVES
+#define RL_WAVES 4                         // waves per SIMD the register budget is cut for
+#endif
+#ifndef RL_PREFETCH
+#define RL_PREFETCH 1                      // the next tile's words wait in registers during the recursion
+#endif
 
-// A wave's rank: start order within its class (block index mod 64), classes interleaved -- rank = class + 64 * (how many
-// waves of the class started before it).  Workgroups are dispatched in index order, so this is the start order of the
-// launch to within a few waves, and a wave that is running still only ever waits for waves that started before it or
-// are starting now, which is what keeps a launch that is only partly resident moving.  One counter for all waves would
-// give the exact order, but same-address atomics retire at ~12 ns each: 2 048 of them delay the last wave by 25 us, a
-// tenth of this kernel's run time (and a ticket per TILE, 16 384 of them, two thirds of it).  The 64 counters start at
-// all-ones.
-#define IIR_RANK_CLASSES 64
-__device__ __forceinline__ long iir_take_rank(unsigned int *ticket, int t0)
+struct IirRailArgs {
+    const double *G;                       // [64][8]: G[j] = F^j g
+    const IirRailTab *tab;
+    IirCoef c;
+    const uint32_t *in;
+    uint32_t *out;
+    long stride, n, n_seg, n_tiles;
+    int n_streams, horizon;
+    unsigned int *ctl;
+    unsigned long long *agg;               // this launch's aggregates: [stream][tile][rail][D], all-ones on entry
+    unsigned long long *agg_other;         // the other buffer and how much of it the launches before this one used
+    long other_words;
+    const double *state_in;
+    double *state_out;
+    unsigned int *overrun;                 // the object's pinned host word (device address)
+    int poll_bound, dbg, n_classes, dynamic;
+    unsigned long long *stamps;            // diagnostics (CLHIP_IIR_STAMPS=1): [RL_STAMP_WAVES][RL_STAMP_TILES][RL_STAMP_PHASES] of s_memrealtime
+};
+#define RL_STAMP_WAVES 64
+#define RL_STAMP_TILES 16
+#define RL_STAMP_PHASES 12
+#define RL_STAMP_ALLWAVES 8192             // behind the phase table: [wave][start, end, tiles done]
+#define RL_STAMP(p) do { if (A.stamps && blockIdx.x < RL_STAMP_WAVES && it < RL_STAMP_TILES && t0 == 0) \
+        A.stamps[((size_t)blockIdx.x * RL_STAMP_TILES + it) * RL_STAMP_PHASES + (p)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+
+// zs += sum_k (F^(SEG-1-k) g) x[k] for the lane's rail over its LDS row; taps as in iir_segment_fir
+template <int D>
+__device__ __forceinline__ void rail_fir_pair(double *v, const IirTaps2<D> &tp, uint32_t w0, uint32_t w1, int sh)
 {
-    const unsigned int cls = blockIdx.x & (IIR_RANK_CLASSES - 1);
-    unsigned int tk = 0;
-    if (t0 == 0) tk = atomicAdd(ticket + cls, 1u) + 1u;
-    return (long)cls + (long)IIR_RANK_CLASSES * (long)(unsigned)__builtin_amdgcn_readfirstlane((int)tk);
+    const double x0 = (double)(int)__builtin_amdgcn_sbfe((int)w0, sh, 16), x1 = (double)(int)__builtin_amdgcn_sbfe((int)w1, sh, 16);
+#pragma unroll
+    for (int r = 0; r < D; r++) v[r] = __builtin_fma(tp.g[0][r], x0, v[r]);
+#pragma unroll
+    for (int r = 0; r < D; r++) v[r] = __builtin_fma(tp.g[1][r], x1, v[r]);
 }
 
-template <int NS, bool B121>
-__global__ __launch_bounds__(IIR_TILE, IIR_WAVES_PER_SIMD) void iir_onepass_kernel(const IirPlan *__restrict__ plan, IirCoef c, uint32_t *__restrict__ iq,
-                                                                  long stride, long n, long n_seg, long n_tiles, int n_streams,
-                                                                  unsigned int *ticket, unsigned long long *agg,
-                                                                  unsigned int *readers, double *state_io,
-                                                                  int horizon, unsigned int *overruns, int poll_bound, int dbg, int stagger_ticks)
+template <int D, int SEG>
+__device__ __forceinline__ void rail_segment_fir(double *v, const uint32_t *x, const cdouble_t *G, int sh)
 {
-    constexpr int D = 2 * NS, D2 = 2 * D;
+    constexpr int BLK = 16;
+    static_assert(SEG % BLK == 0, "segments are whole blocks");
+    IirTaps2<D> ta, tb;
+    iir_taps_load<D>(ta, G + (SEG - 1) * IIR_MAX_DIM);
+#pragma unroll 1
+    for (int kb = 0; kb < SEG; kb += BLK) {
+        u32x4 xr[BLK / 4];
+#pragma unroll
+        for (int k = 0; k < BLK / 4; k++) xr[k] = *(const u32x4 *)(x + kb + 4 * k);
+#pragma unroll
+        for (int k = 0; k < BLK / 4; k++) asm volatile("" : "+v"(xr[k]));
+        const cdouble_t *gb = G + (SEG - 1 - kb) * IIR_MAX_DIM;
+#pragma unroll
+        for (int k = 0; k < BLK; k += 4) {
+            iir_taps_wait<D>(ta);
+            iir_taps_load<D>(tb, gb - (k + 2) * IIR_MAX_DIM);
+            __builtin_amdgcn_sched_barrier(0);
+            rail_fir_pair<D>(v, ta, xr[k / 4][0], xr[k / 4][1], sh);
+            __builtin_amdgcn_sched_barrier(0);
+            iir_taps_wait<D>(tb);
+            const cdouble_t *gn = (kb + k + 4 < SEG) ? gb - (k + 4) * IIR_MAX_DIM : G + IIR_MAX_DIM;
+            iir_taps_load<D>(ta, gn);
+            __builtin_amdgcn_sched_barrier(0);
+            rail_fir_pair<D>(v, tb, xr[k / 4][2], xr[k / 4][3], sh);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    iir_taps_wait<D>(ta);
+}
+
+// the other lane of the pair's value (DPP quad_perm [1,0,3,2]: a full-rate VALU move, no LDS)
+__device__ __forceinline__ uint32_t rail_partner(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
+}
+
+// The recursion of one rail over the lane's row, in place: both lanes of a pair end up with the packed (i, q) words
+// (sel: the lane's byte selector for v_perm_b32), the I lane writes them back.
+template <int NS, int SEG, bool FULL, bool B121>
+__device__ __forceinline__ void rail_recursion(const IirCoef &c, uint32_t *x, long cnt, double *z, int sh, uint32_t sel, int rail)
+{
+#pragma unroll 2
+    for (int k = 0; k < SEG; k += 4) {
+        if (!FULL && k >= cnt) break;
+        u32x4 w = *(const u32x4 *)(x + k);
+        if (FULL || k + 4 <= cnt) {
+#pragma unroll
+            for (int j = 0; j < 4; j += 2) {
+                double y0, y1;
+                iir_step2<NS, B121>(c, z, (double)(int)__builtin_amdgcn_sbfe((int)w[j], sh, 16), (double)(int)__builtin_amdgcn_sbfe((int)w[j + 1], sh, 16), y0, y1);
+                const uint32_t r0 = (uint32_t)(int)(float)y0, r1 = (uint32_t)(int)(float)y1;   // v_perm_b32 takes the low halves
+                w[j] = __builtin_amdgcn_perm(rail_partner(r0), r0, sel);
+                w[j + 1] = __builtin_amdgcn_perm(rail_partner(r1), r1, sel);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (k + j < cnt) {                                  // uniform over the pair
+                    const uint32_t r = (uint32_t)(int)(float)iir_step<NS>(c, z, (double)(int)__builtin_amdgcn_sbfe((int)w[j], sh, 16));
+                    w[j] = __builtin_amdgcn_perm(rail_partner(r), r, sel);
+                }
+            }
+        }
+        if (rail == 0) *(u32x4 *)(x + k) = w;
+    }
+}
+
+template <int SEG>
+__device__ __forceinline__ bool rail_tile_whole(const uint32_t *in, const uint32_t *out, long n_left)      // wave-uniform
+{
+    return ((((uintptr_t)in | (uintptr_t)out) & 15) == 0) && n_left >= (long)RL_SEGS * SEG;
+}
+
+// (a tile that is not whole is read word by word at commit time; its registers are DEFINED all the same, so that the
+// compiler does not see last tile's values flow round the persistent loop and keep 4 x SEG / 8 registers live through it)
+template <int SEG>
+__device__ __forceinline__ void rail_tile_issue(const uint32_t *__restrict__ x, bool whole, u32x4 (&r)[SEG / 8], int t)
+{
+    if (whole) {
+#pragma unroll
+        for (int q = 0; q < SEG / 8; q++) r[q] = *(const u32x4 *)(x + (q * 64 + t) * 4);
+    } else {
+#pragma unroll
+        for (int q = 0; q < SEG / 8; q++) r[q] = u32x4{0, 0, 0, 0};
+    }
+}
+
+template <int SEG>
+__device__ __forceinline__ void rail_tile_commit(const uint32_t *__restrict__ x, bool whole, long n_left, const u32x4 (&r)[SEG / 8], uint32_t *sm, int t)
+{
+    constexpr int PITCH = SEG + 4;
+    if (whole) {
+#pragma unroll
+        for (int q = 0; q < SEG / 8; q++) {
+            const int i = (q * 64 + t) * 4;
+            *(u32x4 *)(sm + (i / SEG) * PITCH + i % SEG) = r[q];
+        }
+        return;
+    }
+#pragma unroll 1
+    for (int q = 0; q < SEG / 8; q++) {                          // ragged or unaligned: word by word, zeros past the end
+        const int i = (q * 64 + t) * 4;
+        u32x4 v = {0, 0, 0, 0};
+        if (i < n_left) v.x = x[i];
+        if (i + 1 < n_left) v.y = x[i + 1];
+        if (i + 2 < n_left) v.z = x[i + 2];
+        if (i + 3 < n_left) v.w = x[i + 3];
+        *(u32x4 *)(sm + (i / SEG) * PITCH + i % SEG) = v;
+    }
+}
+
+template <int SEG>
+__device__ __forceinline__ void rail_tile_store(uint32_t *__restrict__ x, bool whole, long n_left, const uint32_t *sm, int t)
+{
+    constexpr int PITCH = SEG + 4;
+    if (whole) {
+#pragma unroll
+        for (int q = 0; q < SEG / 8; q++) {
+            const int i = (q * 64 + t) * 4;
+            *(u32x4 *)(x + i) = *(const u32x4 *)(sm + (i / SEG) * PITCH + i % SEG);
+        }
+        return;
+    }
+#pragma unroll 1
+    for (int q = 0; q < SEG / 8; q++) {
+        const int i = (q * 64 + t) * 4;
+        const u32x4 v = *(const u32x4 *)(sm + (i / SEG) * PITCH + i % SEG);
+        if (i < n_left) x[i] = v.x;
+        if (i + 1 < n_left) x[i + 1] = v.y;
+        if (i + 2 < n_left) x[i + 2] = v.z;
+        if (i + 3 < n_left) x[i + 3] = v.w;
+    }
+}
+
+__device__ __forceinline__ unsigned rail_tile_of(unsigned cls, unsigned nc, unsigned ticket, unsigned total)
+{
+    const unsigned long long t = (unsigned long long)cls + (unsigned long long)nc * ticket;
+    return t < total ? (unsigned)t : total;
+}
+
+template <int NS, int SEG, bool B121>
+__global__ __launch_bounds__(64, RL_WAVES) void iir_rail_kernel(const IirRailArgs A)
+{
+    constexpr int D = 2 * NS, PITCH = SEG + 4, NLD = SEG / 8;
+    constexpr long TILE = (long)RL_SEGS * SEG;
     extern __shared__ __attribute__((aligned(16))) uint32_t iir_sm[];
     const int t0 = threadIdx.x;
-    const long total = n_tiles * n_streams;
+    const unsigned total = (unsigned)(A.n_tiles * A.n_streams), ns = (unsigned)A.n_streams;    // < 2^31 tiles (host-checked)
+    const unsigned NC = (unsigned)A.n_classes;
+    const unsigned cls = blockIdx.x & (NC - 1);
 
-    // ONE ticket per wave: its rank.  Rank r takes tiles r, r + G, r + 2G, ... (G = waves launched): a tile's H
-    // predecessors belong to the H ranks before it, which are at the same point of their own lists, so nobody waits
-    // long; ranks 0..H-1 wrap to the last ranks of the previous round.  Aggregates are published BEFORE a wave waits
-    // for anything, so a late-starting rank delays its successors, never deadlocks them.
-    long T = iir_take_rank(ticket, t0);
-    const long NW = (long)gridDim.x;                                  // waves launched
-    if (stagger_ticks != 0 && T < total) {
-        // Spread the waves' phases over one tile period (rank r starts r/NW of a period late): identical waves
-        // started together stay in lock step, so the whole chip would load, compute and store in unison and the
-        // memory system would idle during the compute phases.  The two waves of a SIMD (ranks r and r + NW/2 in
-        // dispatch order) end up half a period apart.  100 MHz constant clock.
-        // stagger_ticks > 0: by rank over the launch; < 0: by ring (= stream of the rank's first tile), |stagger_ticks| apart per ring
-        const unsigned long long until = __builtin_amdgcn_s_memrealtime() +
-            (stagger_ticks > 0 ? (unsigned long long)(T * stagger_ticks / NW) : (unsigned long long)((T % n_streams) * (long)(-stagger_ticks)));
-        while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(8);
+    // re-arm the aggregate buffer the NEXT launch will use (this launch does not touch it otherwise)
+    for (long i = (long)blockIdx.x * 64 + t0; i < A.other_words; i += (long)gridDim.x * 64) A.agg_other[i] = IIR_SENTINEL;
+
+    if (A.stamps && t0 == 0 && blockIdx.x < RL_STAMP_ALLWAVES)
+        A.stamps[(size_t)RL_STAMP_WAVES * RL_STAMP_TILES * RL_STAMP_PHASES + 3 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+    unsigned int tk = 0;
+    if (t0 == 0) tk = atomicAdd(A.ctl + cls * RL_CTL_STRIDE, 1u);
+    // (a ticket beyond the launch's tiles saturates: more tickets than tiles are only ever taken by waves on their way out)
+    unsigned T = rail_tile_of(cls, NC, (unsigned)__builtin_amdgcn_readfirstlane((int)tk), total);
+    const unsigned NW = gridDim.x;
+    constexpr bool PF = RL_PREFETCH && NS < 4;      // (four biquads: the start-state phase needs the registers)
+    u32x4 raw[NLD];
+    if constexpr (PF) {
+        const long b = T / ns, s = T % ns;
+        const uint32_t *xin = A.in + s * A.stride + b * TILE;
+        rail_tile_issue<SEG>(xin, T < total && rail_tile_whole<SEG>(xin, A.out + s * A.stride + b * TILE, A.n - b * TILE), raw, t0);
     }
-#if IIR_PREFETCH
-    u32x4 raw[IIR_NLD];
-    if (T < total) {
-        const long b = T / n_streams, s = T % n_streams;
-        iir_tile_issue(iq + s * stride + b * IIR_TILE * IIR_SEG, n - b * IIR_TILE * IIR_SEG, raw, t0);
-    }
-#endif
+    int it = -1;
     while (T < total) {
+        it++;
+        RL_STAMP(0);
         // per-iteration values stay per-iteration: otherwise the compiler hoists every lane address of the staging
         // code and every scalar table load out of the persistent loop and spills them
         int t = t0;
-        const IirPlan *pl = plan;
+        const IirRailTab *tab = A.tab;
+        const double *Gp = A.G;
         asm volatile("" : "+v"(t));
-        asm volatile("" : "+s"(pl));
-        const cdouble_t *pow2 = (const cdouble_t *)&pl->pow2[0][0];
-        const cdouble_t *__restrict__ G = (const cdouble_t *)&pl->G[0][0];
-        const long b = T / n_streams, s = T % n_streams;
-        const long tile0 = b * IIR_TILE * IIR_SEG;
-        uint32_t *xt = iq + s * stride + tile0;
-#if !IIR_PREFETCH
-        if (iir_tile_whole(xt, n - tile0)) {
-            u32x4 raw[IIR_NLD];
-#pragma unroll
-            for (int q = 0; q < IIR_NLD; q++) raw[q] = *(const u32x4 *)(xt + (q * IIR_TILE + t) * 4);
-#pragma unroll
-            for (int q = 0; q < IIR_NLD; q++) {
-                const int i = (q * IIR_TILE + t) * 4;
-                *(u32x4 *)(iir_sm + (i / IIR_SEG) * IIR_PITCH + i % IIR_SEG) = raw[q];
-            }
-        } else {
-            u32x4 none[IIR_NLD];
-            iir_tile_commit(xt, n - tile0, none, iir_sm, t);
-        }
-#else
-        iir_tile_commit(xt, n - tile0, raw, iir_sm, t);
-#endif
-        __syncthreads();
-        const long Tn = T + NW;
-        // zero-state end vector of the lane's segment: zs = sum_k (F^(63-k) g) x[k]
-        uint32_t *x = iir_sm + t * IIR_PITCH;
-        double v[D2];
-#pragma unroll
-        for (int k = 0; k < D2; k++) v[k] = 0.0;
-        if (!(dbg & 4)) {
-            iir_segment_fir<D>(v, x, G);
-        }
-        if (!(dbg & 8)) wave_scan<D>(v, pow2, t);                      // v = state after the lane's segment, zero carry-in
-        unsigned long long *mine = agg + (s * n_tiles + b) * D2;
-        if (t == IIR_TILE - 1) {
-#pragma unroll
-            for (int k = 0; k < D2; k++)
-                __hip_atomic_store(mine + k, (unsigned long long)__builtin_bit_cast(unsigned long long, v[k]), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-        }
-        // state entering the tile
-        double cv[D2];
+        asm volatile("" : "+s"(tab), "+s"(Gp));
+        const cdouble_t *pow2 = (const cdouble_t *)&tab->pow2[0][0];
+        const cdouble_t *__restrict__ G = (const cdouble_t *)Gp;
+        const int m = t >> 1, rail = t & 1, sh = rail << 4;
+        const uint32_t sel = rail ? 0x01000504u : 0x05040100u;
+        // the next tile's ticket: back long before it is needed.  (The counter's address goes through a register the
+        // compiler cannot see through: with a uniform address its atomic optimizer rewrites the add as a wave reduction
+        // whose result it broadcasts -- and waits for, with everything else in flight -- right here.)
+        unsigned int tkn = 0;
         {
-            const long j = b - 1 - t;                                  // lane t looks at tile b-1-t; tile -1 = the carried state
-            const bool want = t < horizon && j >= -1;
-            double a[D2];
+            uintptr_t ca = (uintptr_t)(A.ctl + cls * RL_CTL_STRIDE);
+            asm volatile("" : "+v"(ca));
+            if (A.dynamic && t == 0)
+                tkn = __hip_atomic_fetch_add((__attribute__((address_space(1))) unsigned int *)ca, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+
+        const long b = T / ns, s = T % ns;
+        const long tile0 = b * TILE;
+        const uint32_t *xin = A.in + s * A.stride + tile0;
+        uint32_t *xout = A.out + s * A.stride + tile0;
+        const bool whole = rail_tile_whole<SEG>(xin, xout, A.n - tile0);
+        if constexpr (!PF) rail_tile_issue<SEG>(xin, whole, raw, t);
+        rail_tile_commit<SEG>(xin, whole, A.n - tile0, raw, iir_sm, t);
+        __syncthreads();
+        RL_STAMP(1);
+        uint32_t *x = iir_sm + m * PITCH;
+        double v[D];
 #pragma unroll
-            for (int k = 0; k < D2; k++) a[k] = 0.0;
-            if (want && j == -1) {
-                const double *st = state_io + s * 2 * IIR_MAX_DIM;
+        for (int k = 0; k < D; k++) v[k] = 0.0;
+        if (!(A.dbg & 4)) rail_segment_fir<D, SEG>(v, x, G, sh);
+        RL_STAMP(2);
+        if (!(A.dbg & 8)) {
+            // Kogge-Stone over the 32 segments of the rail: v_m <- v_m + P^(2^d) v_(m - 2^d)
+#pragma unroll 1
+            for (int d = 0; d < 5; d++) {
+                double pv[D];
 #pragma unroll
-                for (int k = 0; k < D2; k++) a[k] = __builtin_bit_cast(double, __hip_atomic_load((const unsigned long long *)st + (k / D) * IIR_MAX_DIM + (k % D), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the old state is in registers before we say so
-                __hip_atomic_fetch_add(readers + s, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int k = 0; k < D; k++) pv[k] = __shfl_up(v[k], 2 << d, 64);
+                if (m >= (1 << d)) matvec<D, true>(pow2 + d * IIR_MSZ, pv, v);
             }
-            bool pending = want && j >= 0 && !(dbg & 1);
-            const unsigned long long *theirs = agg + (s * n_tiles + (j >= 0 ? j : 0)) * D2;
+        }
+        RL_STAMP(3);
+        unsigned long long *mine = A.agg + ((s * A.n_tiles + b) * 2 + rail) * D;
+        if (m == RL_SEGS - 1 && !(A.dbg & 32)) {
+#pragma unroll
+            for (int k = 0; k < D; k++)
+                __hip_atomic_store(mine + k, __builtin_bit_cast(unsigned long long, v[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        RL_STAMP(4);
+        // state entering the tile
+        double cv[D];
+        {
+            const int H = A.horizon;
+            const long j = b - 1 - m;                                  // lane pair m looks at tile b-1-m; tile -1 = the carried state
+            const bool want = m < H && j >= -1;
+            double a[D];
+#pragma unroll
+            for (int k = 0; k < D; k++) a[k] = 0.0;
+            // (the carried state is read like an aggregate that is already there: one code path, one wait)
+            bool pending = want && !(A.dbg & 1);
+            const unsigned long long *theirs = j >= 0 ? A.agg + ((s * A.n_tiles + j) * 2 + rail) * D
+                                                      : (const unsigned long long *)(A.state_in + s * 2 * IIR_MAX_DIM + rail * IIR_MAX_DIM);
             int guard = 0;
             while (__any(pending)) {
                 if (pending) {
-                    // the 2D stores land in any order: take all of them every time and check each (one round trip through
-                    // the fabric per poll; watching one word first would add a second trip to the poll that succeeds)
+                    // the D stores land in any order: take all of them every time and check each (one round trip through
+                    // the fabric per poll, the abort flag rides along)
                     bool ok = true;
 #pragma unroll
-                    for (int k = 0; k < D2; k++) {
+                    for (int k = 0; k < D; k++) {
                         const unsigned long long w = __hip_atomic_load(theirs + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         ok &= w != IIR_SENTINEL;
                         a[k] = __builtin_bit_cast(double, w);
                     }
-                    if (ok && poll_bound >= 0) pending = false;
-                    else if (++guard > poll_bound) {                      // never reached once the producer's wave is resident
-                        __hip_atomic_fetch_add(overruns, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // pinned host word: clhip_iir_overruns()
+                    // (the abort flag is ONE word for the whole launch: looked at on every poll by every waiting lane it
+                    // becomes the hottest address of the chip -- measured: 0.29 ms of a 0.52 ms launch; a healthy wait ends
+                    // within a few polls and never looks)
+                    unsigned ab = 0;
+                    if (!ok && (guard & 255) == 255) ab = __hip_atomic_load(A.ctl + RL_CTL_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (ok && A.poll_bound >= 0) pending = false;
+                    else if (ab || ++guard > A.poll_bound) {
+                        // gave up: the call is void (the host rolls it back), nothing undefined may travel on
+#pragma unroll
+                        for (int k = 0; k < D; k++) a[k] = 0.0;
+                        __hip_atomic_store(A.ctl + RL_CTL_ABORT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_fetch_add(A.overrun, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         pending = false;
                     }
                 }
-                if (__any(pending)) __builtin_amdgcn_s_sleep(2);       // ~128 cycles: leave the issue slots and the fabric to the others
+                if (__any(pending)) __builtin_amdgcn_s_sleep(2);
             }
-            // cv = a_0 + Q (a_1 + Q (a_2 + ...)): Horner over the lanes that looked, the lane's vector broadcast by
-            // v_readlane, the one matrix Q by scalar loads -- no per-lane tables, nothing to reduce
-            const cdouble_t *qm = (const cdouble_t *)&pl->Q[0];
+            RL_STAMP(5);
+            if (H <= RL_HORNER_MAX) {
+                // cv = a_0 + Q (a_1 + Q (a_2 + ...)), the pair's vector broadcast by one shuffle per word
+                const cdouble_t *qm = pow2 + 5 * IIR_MSZ;
 #pragma unroll
-            for (int k = 0; k < D2; k++) cv[k] = 0.0;
-            for (int h = horizon - 1; h >= 0; h--) {                   // uniform
-                double nx[D2];
+                for (int k = 0; k < D; k++) cv[k] = 0.0;
+                for (int h = H - 1; h >= 0; h--) {                     // uniform
+                    double nx[D];
 #pragma unroll
-                for (int k = 0; k < D2; k++) {
-                    const unsigned long long bits = __builtin_bit_cast(unsigned long long, a[k]);
-                    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)bits, h);
-                    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(bits >> 32), h);
-                    nx[k] = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+                    for (int k = 0; k < D; k++) nx[k] = __shfl(a[k], 2 * h + rail, 64);
+                    matvec<D, true>(qm, cv, nx);
+#pragma unroll
+                    for (int k = 0; k < D; k++) cv[k] = nx[k];
                 }
-                matvec<D, true>(qm, cv, nx);
-                matvec<D, true>(qm, cv + D, nx + D);
-#pragma unroll
-                for (int k = 0; k < D2; k++) cv[k] = nx[k];
-            }
-        }
-        // the lane's true start state: what the lanes before it left (zero carry) + P^t cv.  P^t comes from the plan's
-        // per-lane table (its non-zero entries: D (D + 2) / 2 coalesced 8-byte loads from a 12 KB table that stays in
-        // L2) and is used once -- one product instead of the six a P^(2^d) ladder over the bits of t costs the wave.
-        // (Four biquads: 40 entries in flight would spill; they keep the ladder, on the scan's scalar tables.)
-        double zi[D], zq[D];
-        if constexpr (NS > 3) {
+            } else {
+                // sum_h Q^h a_h by a log-step tree: a_h <- a_h + Q^(2^d) a_(h + 2^d); pair 0 ends with the sum
 #pragma unroll 1
-            for (int d = 0; d < 6; d++) {
-                if (t & (1 << d)) {
-                    const cdouble_t *m = pow2 + d * IIR_MSZ;
-                    double nx[D2];
-                    matvec<D, false>(m, cv, nx);
-                    matvec<D, false>(m, cv + D, nx + D);
+                for (int d = 0; d < 5; d++) {
+                    double pv[D];
 #pragma unroll
-                    for (int k = 0; k < D2; k++) cv[k] = nx[k];
+                    for (int k = 0; k < D; k++) pv[k] = __shfl_down(a[k], 2 << d, 64);
+                    if (m + (1 << d) < RL_SEGS) matvec<D, true>(pow2 + (5 + d) * IIR_MSZ, pv, a);
                 }
-            }
 #pragma unroll
-            for (int k = 0; k < D2; k++) {
-                const double p = __shfl_up(v[k], 1, 64);
-                const double st = (t == 0 ? 0.0 : p) + cv[k];
-                if (k < D) zi[k] = st; else zq[k - D] = st;
+                for (int k = 0; k < D; k++) cv[k] = __shfl(a[k], rail, 64);
             }
+        }
+        RL_STAMP(6);
+        // the lane's true start state: what the segments before it left (zero carry) + P^m cv.  P^m for the lane's segment
+        // comes from a per-segment table by 8-byte loads (12 KB, stays in L2), issued here and not before the wait: at four
+        // waves per SIMD the other waves cover the round trip, and the D (D + 2) registers are free during the wait.
+        // Four biquads take the rows in two halves (80 registers of table entries would not fit beside the state).
+        double z[D];
+        if (A.dbg & 16) {
+#pragma unroll
+            for (int r = 0; r < D; r++) z[r] = v[r] + cv[r];
         } else {
-            const double *ptab = &pl->ptab[0][0] + t;
+            const gdouble_t *pt = (const gdouble_t *)&tab->ptab[0][0] + m;
+            constexpr int RCH = NS < 4 ? D : D / 2;
 #pragma unroll
-            for (int r = 0; r < D; r++) {
-                const double pi = __shfl_up(v[r], 1, 64), pq = __shfl_up(v[D + r], 1, 64);
-                double si = t == 0 ? 0.0 : pi, sq = t == 0 ? 0.0 : pq;
+            for (int r0 = 0; r0 < D; r0 += RCH) {
+                double pe[RCH][D];
 #pragma unroll
-                for (int cc = 0; cc < D; cc++)
-                    if (iir_mat_nonzero(r, cc)) {
-                        const double p = ptab[(r * IIR_MAX_DIM + cc) * IIR_TILE];
-                        si = __builtin_fma(p, cv[cc], si);
-                        sq = __builtin_fma(p, cv[D + cc], sq);
-                    }
-                zi[r] = si; zq[r] = sq;
-            }
-        }
-        // the next tile's words go out now and land while the recursion (the longest phase) runs
-#if IIR_PREFETCH
-        if (Tn < total) {
-            const long bn = Tn / n_streams, sn = Tn % n_streams;
-            iir_tile_issue(iq + sn * stride + bn * IIR_TILE * IIR_SEG, n - bn * IIR_TILE * IIR_SEG, raw, t);
-        }
-#endif
-        const long seg = b * IIR_TILE + t;
-        if (seg < n_seg && !(dbg & 2)) {
-            if (tile0 + (long)IIR_TILE * IIR_SEG <= n) iir_k3_segment<NS, true, true, B121>(c, x, IIR_SEG, zi, zq);
-            else {
-                const long cnt = n - seg * IIR_SEG < IIR_SEG ? n - seg * IIR_SEG : IIR_SEG;
-                iir_k3_segment<NS, false, true, B121>(c, x, cnt, zi, zq);
-            }
-            if (seg == n_seg - 1) {
-                // the stream's new carried state replaces the old one in place: wait until the first tiles (the only
-                // readers of the old one; all of them older than this tile) have taken it.  Counter starts at all-ones.
-                const unsigned want_readers = (unsigned)((long)horizon < n_tiles ? (long)horizon : n_tiles) - 1u;
-                int spin = 0;
-                while (__hip_atomic_load(readers + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want_readers) {
-                    if (++spin > poll_bound) { __hip_atomic_fetch_add(overruns, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
-                    __builtin_amdgcn_s_sleep(2);
+                for (int r = 0; r < RCH; r++)
+#pragma unroll
+                    for (int cc = 0; cc < D; cc++)
+                        if (iir_mat_nonzero(r0 + r, cc)) pe[r][cc] = pt[((r0 + r) * IIR_MAX_DIM + cc) * RL_SEGS];
+#pragma unroll
+                for (int r = 0; r < RCH; r++) {
+                    const double p = __shfl_up(v[r0 + r], 2, 64);
+                    double st = m == 0 ? 0.0 : p;
+#pragma unroll
+                    for (int cc = 0; cc < D; cc++)
+                        if (iir_mat_nonzero(r0 + r, cc)) st = __builtin_fma(pe[r][cc], cv[cc], st);
+                    z[r0 + r] = st;
                 }
-                double *so = state_io + s * 2 * IIR_MAX_DIM;
+                if (r0 + RCH < D) {
 #pragma unroll
-                for (int k = 0; k < D; k++) { so[k] = zi[k]; so[IIR_MAX_DIM + k] = zq[k]; }
+                    for (int r = 0; r < RCH; r++) asm volatile("" : "+v"(z[r0 + r]));
+                    asm volatile("" ::: "memory");
+                }
             }
         }
+        // the start states are complete (and the P^m entries dead) before the prefetch registers fill
+#pragma unroll
+        for (int k = 0; k < D; k++) asm volatile("" : "+v"(z[k]));
+        asm volatile("" ::: "memory");
+        RL_STAMP(7);
+        // the next tile: its index is known by now, its words go out and land while the recursion (the longest phase) runs
+        const unsigned Tn = A.dynamic ? rail_tile_of(cls, NC, (unsigned)__builtin_amdgcn_readfirstlane((int)tkn), total) : T + NW;
+        if constexpr (PF) {
+            const long bn = Tn / ns, sn = Tn % ns;
+            const uint32_t *xn = A.in + sn * A.stride + bn * TILE;
+            rail_tile_issue<SEG>(xn, Tn < total && rail_tile_whole<SEG>(xn, A.out + sn * A.stride + bn * TILE, A.n - bn * TILE), raw, t);
+        }
+        RL_STAMP(8);
+        const long seg = b * RL_SEGS + m;
+        if (seg < A.n_seg && !(A.dbg & 2)) {
+            if (tile0 + TILE <= A.n) rail_recursion<NS, SEG, true, B121>(A.c, x, SEG, z, sh, sel, rail);
+            else {
+                const long cnt = A.n - seg * SEG < SEG ? A.n - seg * SEG : SEG;
+                rail_recursion<NS, SEG, false, B121>(A.c, x, cnt, z, sh, sel, rail);
+            }
+            if (seg == A.n_seg - 1) {
+                double *so = A.state_out + s * 2 * IIR_MAX_DIM + rail * IIR_MAX_DIM;
+#pragma unroll
+                for (int k = 0; k < D; k++) so[k] = z[k];
+            }
+        }
+        RL_STAMP(9);
         __syncthreads();
-        iir_tile_store(xt, n - tile0, iir_sm, t);
+        if (!(A.dbg & 64)) rail_tile_store<SEG>(xout, whole, A.n - tile0, iir_sm, t);
         __syncthreads();                                               // the rows are free for the next tile
+        RL_STAMP(10);
         T = Tn;
+    }
+    if (A.stamps && t0 == 0 && blockIdx.x < RL_STAMP_ALLWAVES) {
+        A.stamps[(size_t)RL_STAMP_WAVES * RL_STAMP_TILES * RL_STAMP_PHASES + 3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+        A.stamps[(size_t)RL_STAMP_WAVES * RL_STAMP_TILES * RL_STAMP_PHASES + 3 * blockIdx.x + 2] = (unsigned long long)(it + 1);
+    }
+    // the last wave out puts the counters back for the next launch
+    if (t0 == 0) {
+        if (atomicAdd(A.ctl + RL_CTL_EXIT, 1u) == (unsigned)gridDim.x - 1u) {
+            for (int k = 0; k < 66; k++) __hip_atomic_store(A.ctl + k * RL_CTL_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -834,6 +1053,44 @@ static double host_step(const IirCoef &c, double *z, double in)
     case 2: return iir_step<2>(c, z, in);
     case 3: return iir_step<3>(c, z, in);
     default: return iir_step<4>(c, z, in);
+    }
+}
+
+static const int kRailSegs[3] = {16, 32, 64};
+
+// Horizon of the single-pass kernel for tiles of RL_SEGS x seg samples.  int16 inputs bound every reachable state
+// component c by 32768 * sum_n |h_c[n]| (h_c = impulse response of that component); a state entering tile b-H reaches
+// tile b as Q^H s, so max_r sum_c |Q^H[r][c]| smax[c] bounds what dropping it costs.  Below 1e-18 (absolute; the
+// outputs are integers and the fp64 sums themselves carry ~1e-8 of rounding) the tile may ignore it.  0 = no such H
+// within RL_HMAX, or the cascade's l1 gain lets 32768 x it pass 2^30 (the kernel's v_cvt_i32_f32 equals cvttss2si's low half only for |y| < 2^31).
+static void iir_rail_tab_build(int dim, const double *F, int seg, const double *smax, bool bounded, IirRailTab *tb)
+{
+    memset(tb, 0, sizeof *tb);
+    tb->seg = seg;
+    double P[IIR_MSZ];
+    memcpy(P, F, sizeof P);
+    for (int k = 1; k < seg; k++) mat_mul(dim, P, F, P);
+    memcpy(tb->pow2[0], P, sizeof P);
+    for (int d = 1; d < 10; d++) mat_mul(dim, tb->pow2[d - 1], tb->pow2[d - 1], tb->pow2[d]);
+    static_assert(RL_SEGS == 32, "Q = P^32 = pow2[5]");
+    double Pt[IIR_MSZ] = {0};
+    for (int r = 0; r < dim; r++) Pt[r * IIR_MAX_DIM + r] = 1.0;
+    for (int m = 0; m < RL_SEGS; m++) {
+        for (int e = 0; e < IIR_MSZ; e++) tb->ptab[e][m] = Pt[e];
+        mat_mul(dim, Pt, P, Pt);
+    }
+    if (!bounded) return;
+    double Qk[IIR_MSZ];
+    memcpy(Qk, tb->pow2[5], sizeof Qk);
+    for (int k = 1; k <= RL_HMAX; k++) {
+        double worst = 0;
+        for (int r = 0; r < dim; r++) {
+            double acc = 0;
+            for (int cc = 0; cc < dim; cc++) acc += fabs(Qk[r * IIR_MAX_DIM + cc]) * 65536.0 * smax[cc];
+            worst = fmax(worst, acc);
+        }
+        if (worst < 1e-18) { tb->horizon = k; break; }
+        mat_mul(dim, Qk, tb->pow2[5], Qk);
     }
 }
 
@@ -869,59 +1126,32 @@ static void iir_plan_build(const double *sos, int n_stages, IirPlan *pl)
     for (int d = 1; d < 8; d++) mat_mul(dim, pl->pow2[d - 1], pl->pow2[d - 1], pl->pow2[d]);
     static_assert(IIR_TILE == 64, "Q = P^TILE = P^(2^6)");
     memcpy(pl->Q, pl->pow2[6], sizeof pl->Q);
-    {   // P^t per lane, entry-major
-        double Pt[IIR_MSZ] = {0};
-        for (int r = 0; r < dim; r++) Pt[r * IIR_MAX_DIM + r] = 1.0;
-        for (int t = 0; t < IIR_TILE; t++) {
-            for (int e = 0; e < IIR_MSZ; e++) pl->ptab[e][t] = Pt[e];
-            mat_mul(dim, Pt, P, Pt);
-        }
-    }
     static_assert(IIR_GROUP == 256, "Q^GROUP = Q^(2^8)");
     memcpy(pl->qpow2[0], pl->Q, sizeof pl->Q);
     for (int d = 1; d < 14; d++) mat_mul(dim, pl->qpow2[d - 1], pl->qpow2[d - 1], pl->qpow2[d]);
     for (int r = 0; r < dim; r++) pl->qpow[0][r * IIR_MAX_DIM + r] = 1.0;
     for (int i = 1; i < IIR_GROUP; i++) mat_mul(dim, pl->qpow[i - 1], pl->Q, pl->qpow[i]);
-    // Horizon of the single-pass kernel.  int16 inputs bound every reachable state component c by
-    // 32768 * sum_n |h_c[n]| (h_c = impulse response of that component); a state entering tile b-H reaches tile b
-    // as Q^H s, so max_r sum_c |Q^H[r][c]| smax[c] bounds what dropping it costs.  Below 1e-18 (absolute; the
-    // outputs are integers and the fp64 sums themselves carry ~1e-8 of rounding) the tile may ignore it.
-    pl->horizon = 0;
-    {
-        double smax[IIR_MAX_DIM] = {0}, z[IIR_MAX_DIM] = {0};
-        double ygain = fabs(host_step(c, z, 1.0));
-        bool settled = false;
-        for (long i = 0; i < 8000000 && !settled; i++) {
-            double m = 0;
-            for (int r = 0; r < dim; r++) { smax[r] += fabs(z[r]); m = fmax(m, fabs(z[r])); }
-            if (!(m < 1e300)) break;                             // diverging: not a filter this path can bound
-            if (i > 64 && m < 1e-40) settled = true;
-            ygain += fabs(host_step(c, z, 0.0));
-        }
-        if (settled && 32768.0 * ygain < 1073741824.0) {
-            double Qk[IIR_MSZ];
-            memcpy(Qk, pl->Q, sizeof Qk);
-            for (int k = 1; k <= IIR_HMAX; k++) {
-                double worst = 0;
-                for (int r = 0; r < dim; r++) {
-                    double acc = 0;
-                    for (int cc = 0; cc < dim; cc++) acc += fabs(Qk[r * IIR_MAX_DIM + cc]) * 65536.0 * smax[cc];
-                    worst = fmax(worst, acc);
-                }
-                if (worst < 1e-18) { pl->horizon = k; break; }
-                mat_mul(dim, Qk, pl->Q, Qk);
-            }
-        }
+    // what the states and the output can reach from int16 inputs (l1 gains by simulation until the response has died)
+    double smax[IIR_MAX_DIM] = {0}, z[IIR_MAX_DIM] = {0};
+    double ygain = fabs(host_step(c, z, 1.0));
+    bool settled = false;
+    for (long i = 0; i < 8000000 && !settled; i++) {
+        double m = 0;
+        for (int r = 0; r < dim; r++) { smax[r] += fabs(z[r]); m = fmax(m, fabs(z[r])); }
+        if (!(m < 1e300)) break;                             // diverging: not a filter this path can bound
+        if (i > 64 && m < 1e-40) settled = true;
+        ygain += fabs(host_step(c, z, 0.0));
     }
+    const bool bounded = settled && 32768.0 * ygain < 1073741824.0;
+    for (int i = 0; i < 3; i++) iir_rail_tab_build(dim, F, kRailSegs[i], smax, bounded, &pl->rail[i]);
 }
 
 // Transition tables per (device, filter): built once, uploaded once into a buffer the shim owns, kept for the life
-// of the process (a filter's tables are 175 KB; an SDR session uses a handful).  Nothing about a plan lives in the
-// caller's workspace, so a workspace freed and reallocated at the same address cannot resurrect a stale table.
+// of the process (a filter's tables are ~210 KB; an SDR session uses a handful).
 struct IirPlanEntry {
     int device, n_stages;
     double sos[5 * IIR_MAX_STAGES];
-    IirPlan host;                  // coef goes to K3 by value
+    IirPlan host;                  // coef goes to the kernels by value
     IirPlan *dev;                  // device copy
 };
 
@@ -934,23 +1164,15 @@ static const IirPlanEntry *iir_plan_for(const double *sos, int n_stages)
     std::lock_guard<std::mutex> lock(mu);
     for (const IirPlanEntry *e : cache)
         if (e->device == device && e->n_stages == n_stages && !memcmp(e->sos, sos, sizeof(double) * 5 * n_stages)) return e;
-    if (cache.size() >= 256) {                  // pathological filter churn: drop THIS device's tables once nothing is in
-        (void)hipDeviceSynchronize();           // flight on it (entries of other devices may be in use by other threads)
-        std::vector<IirPlanEntry *> keep;
-        for (IirPlanEntry *e : cache) {
-            if (e->device == device) { clhip_free(e->dev); delete e; }
-            else keep.push_back(e);
-        }
-        cache.swap(keep);
-    }
+    // entries are never dropped: filter objects keep pointers into them
     IirPlanEntry *e = new (std::nothrow) IirPlanEntry();
-    if (!e) { clhip_set_error("clhip_iir_cs16: out of memory"); return nullptr; }
+    if (!e) { clhip_set_error("clhip_iir: out of memory"); return nullptr; }
     e->device = device; e->n_stages = n_stages;
     memcpy(e->sos, sos, sizeof(double) * 5 * n_stages);
     iir_plan_build(sos, n_stages, &e->host);
     e->dev = (IirPlan *)clhip_malloc(sizeof(IirPlan));
     if (!e->dev || hipMemcpy(e->dev, &e->host, sizeof(IirPlan), hipMemcpyHostToDevice) != hipSuccess) {
-        clhip_set_error("clhip_iir_cs16: cannot place the filter tables on the device");
+        clhip_set_error("clhip_iir: cannot place the filter tables on the device");
         clhip_free(e->dev); delete e;
         return nullptr;
     }
@@ -958,110 +1180,193 @@ static const IirPlanEntry *iir_plan_for(const double *sos, int n_stages)
     return e;
 }
 
-static size_t iir_var_bytes(size_t n_samples)
+static size_t iir_scan_ws_doubles(size_t n_samples)
 {
     const size_t n_seg = clhip_div_up(n_samples, IIR_SEG), n_tiles = clhip_div_up(n_seg, IIR_TILE);
-    return (n_seg + 2 * n_tiles + 2 * clhip_div_up(n_tiles, IIR_GROUP) + 4) * 2 * IIR_MAX_DIM * sizeof(double);
+    return (n_seg + 2 * n_tiles + 2 * clhip_div_up(n_tiles, IIR_GROUP) + 4) * 2 * IIR_MAX_DIM;
 }
 
-extern "C" size_t clhip_iir_workspace_bytes(size_t n_samples, int n_stages)
+typedef void (*iir_rail_fn)(const IirRailArgs);
+template <int NS, int SEG>
+static iir_rail_fn rail_pick(bool b121)
 {
-    (void)n_stages;
-    return 256 + iir_var_bytes(n_samples);
+    if constexpr (NS > 1) { if (b121) return iir_rail_kernel<NS, SEG, true>; }
+    return iir_rail_kernel<NS, SEG, false>;
+}
+static iir_rail_fn rail_kernel_for(int ns, int seg, bool b121)
+{
+    switch (ns * 100 + seg) {
+    case 116: return rail_pick<1, 16>(b121);
+    case 132: return rail_pick<1, 32>(b121);
+    case 164: return rail_pick<1, 64>(b121);
+    case 216: return rail_pick<2, 16>(b121);
+    case 232: return rail_pick<2, 32>(b121);
+    case 264: return rail_pick<2, 64>(b121);
+    case 316: return rail_pick<3, 16>(b121);
+    case 332: return rail_pick<3, 32>(b121);
+    case 364: return rail_pick<3, 64>(b121);
+    case 416: return rail_pick<4, 16>(b121);
+    case 432: return rail_pick<4, 32>(b121);
+    case 464: return rail_pick<4, 64>(b121);
+    }
+    return nullptr;
 }
 
-// Workgroups (= waves) the single-pass kernel launches: as many as the device keeps resident at once, per kernel
-// instantiation and device.  Never more: a rank's first tiles wait for the aggregates of the ranks before it, so every
-// launched wave must be running (a wave that waits for a slot would be waited for by the waves that hold the slots).
-template <class K>
-static int iir_resident_waves(K kernel, int slot)
+// Waves the device keeps resident for a kernel instantiation: the launch's size (more would only queue up behind the
+// persistent ones and leave at once; progress does not depend on the number, see the kernel's header).
+static int iir_resident_waves(iir_rail_fn fn, int seg)
 {
+    struct Ent { int device; iir_rail_fn fn; int waves; };
     static std::mutex mu;
-    static int cached[32][64];
+    static std::vector<Ent> cache;
     int device = 0, cus = 256, per_cu = 0;
     (void)hipGetDevice(&device);
     std::lock_guard<std::mutex> lock(mu);
-    if (device >= 0 && device < 64 && cached[slot][device]) return cached[slot][device];
+    for (const Ent &e : cache) if (e.device == device && e.fn == fn) return e.waves;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, IIR_TILE, IIR_LDS_WORDS * 4) != hipSuccess || per_cu < 1) per_cu = 1;
-    if (per_cu > 4) per_cu -= per_cu % 4;                        // the same number of waves on each of the CU's four SIMDs: the ring
-                                                                 // advances at the pace of its slowest wave, and a SIMD with one
-                                                                 // wave more than the others sets that pace for everybody
-    const char *e = getenv("CLHIP_IIR_WG_PER_CU");               // experiment knob: fewer than the device would hold
-    if (e && atoi(e) > 0 && atoi(e) < per_cu) per_cu = atoi(e);
-    if (device >= 0 && device < 64) cached[slot][device] = cus * per_cu;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64, RL_SEGS * (seg + 4) * 4) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (per_cu > 4) per_cu -= per_cu % 4;                        // the same number of waves on each of the CU's four SIMDs
+    static const int env = getenv("CLHIP_IIR_WG_PER_CU") ? atoi(getenv("CLHIP_IIR_WG_PER_CU")) : 0;   // experiment knob
+    if (env > 0 && env < per_cu) per_cu = env;
+    cache.push_back({device, fn, cus * per_cu});
     return cus * per_cu;
 }
 
-// The single-pass kernel's polls are bounded (a wave waits only for waves that are running, so the bound is never
-// reached on a GPU the launch has to itself; a launch squeezed to a handful of resident waves by other work could reach
-// it).  A poll that gives up counts itself in one word of pinned, device-mapped host memory per device; the results of
-// that call are then wrong and clhip_iir_overruns() says so once the stream has been synchronised.
-static unsigned int *iir_overrun_word(unsigned int **dev_ptr)
+// ---------------------------------------------------------------------------
+// The filter object: coefficients, carried state (ping-pong), the single-pass kernel's control words and aggregate
+// buffers, a pinned overrun word of its own -- one per Soapy stream and filter selection, so two streams on one
+// GPU never see each other's verdicts.
+// ---------------------------------------------------------------------------
+struct clhip_iir {
+    int device, n_stages, n_streams;
+    const IirPlanEntry *pe;
+    bool b121;
+    double *d_state;                        // [2][n_streams][2 * IIR_MAX_DIM]
+    int cur;                                // the half that holds the state entering the next call
+    unsigned int *d_ctl;
+    unsigned long long *d_agg[2];
+    size_t agg_cap;                         // words per buffer
+    size_t dirty[2];                        // words of each buffer that may not be all-ones
+    int acur;
+    double *d_scan_ws; size_t scan_ws_doubles;
+    unsigned int *h_over, *d_over;          // pinned, device-mapped
+    int poll_bound, seg_force, dynamic;
+    bool force_scan;
+    // the last call, for the verdict and the redo
+    bool can_undo; int undo_cur;
+    const int16_t *last_in; int16_t *last_out; size_t last_stride, last_n; hipStream_t last_stream; bool last_valid;
+    bool last_was_rail;
+    unsigned long long *d_stamps;           // diagnostics
+};
+
+extern "C" void clhip_iir_destroy(clhip_iir *f)
 {
-    static std::mutex mu;
-    static unsigned int *host[64], *dev[64];
-    int device = 0;
-    (void)hipGetDevice(&device);
-    if (device < 0 || device >= 64) return nullptr;
-    std::lock_guard<std::mutex> lock(mu);
-    if (!host[device]) {
-        unsigned int *h = nullptr, *d = nullptr;
-        if (hipHostMalloc((void **)&h, 64, hipHostMallocMapped) != hipSuccess) return nullptr;
-        *h = 0;
-        if (hipHostGetDevicePointer((void **)&d, h, 0) != hipSuccess) { (void)hipHostFree(h); return nullptr; }
-        host[device] = h; dev[device] = d;
+    if (!f) return;
+    if (f->last_valid) (void)hipStreamSynchronize(f->last_stream);
+    clhip_free(f->d_stamps);
+    clhip_free(f->d_state); clhip_free(f->d_ctl); clhip_free(f->d_agg[0]); clhip_free(f->d_agg[1]); clhip_free(f->d_scan_ws);
+    if (f->h_over) (void)hipHostFree(f->h_over);
+    delete f;
+}
+
+extern "C" clhip_iir *clhip_iir_create(const double *h_sos, int n_stages, int n_streams)
+{
+    if (!h_sos || n_stages < 1 || n_stages > IIR_MAX_STAGES || n_streams < 1) {
+        clhip_set_error("clhip_iir_create: bad arguments (1..%d biquads)", IIR_MAX_STAGES);
+        return nullptr;
     }
-    if (dev_ptr) *dev_ptr = dev[device];
-    return host[device];
+    clhip_iir *f = new (std::nothrow) clhip_iir();
+    if (!f) return nullptr;
+    memset(f, 0, sizeof *f);
+    (void)hipGetDevice(&f->device);
+    f->n_stages = n_stages; f->n_streams = n_streams;
+    f->pe = iir_plan_for(h_sos, n_stages);
+    if (!f->pe) { delete f; return nullptr; }
+    const IirCoef &c = f->pe->host.coef;
+    f->b121 = n_stages > 1;                 // b = (1, 2, 1) exactly in every stage after the first: the four-operation stage form
+    for (int k = 1; k < n_stages; k++) f->b121 = f->b121 && c.b0[k] == 1.0 && c.b1[k] == 2.0 && c.b2[k] == 1.0;
+    const size_t st_bytes = sizeof(double) * 2 * 2 * IIR_MAX_DIM * n_streams;
+    f->d_state = (double *)clhip_malloc(st_bytes);
+    f->d_ctl = (unsigned int *)clhip_malloc(sizeof(unsigned int) * RL_CTL_WORDS);
+    if (hipHostMalloc((void **)&f->h_over, 64, hipHostMallocMapped) != hipSuccess) f->h_over = nullptr;
+    if (f->h_over) {
+        *f->h_over = 0;
+        if (hipHostGetDevicePointer((void **)&f->d_over, f->h_over, 0) != hipSuccess) f->d_over = nullptr;
+    }
+    if (!f->d_state || !f->d_ctl || !f->d_over || hipMemset(f->d_state, 0, st_bytes) != hipSuccess ||
+        hipMemset(f->d_ctl, 0, sizeof(unsigned int) * RL_CTL_WORDS) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) {
+        clhip_set_error("clhip_iir_create: device allocation failed");
+        clhip_iir_destroy(f);
+        return nullptr;
+    }
+    // tests force the give-up path with -1; the default bound is ~0.1 s of polling, after which the call is rolled back
+    // and repeated on the scan path (a launch that moves at all never gets there: see the kernel's header)
+    f->poll_bound = getenv("CLHIP_IIR_POLL_BOUND") ? atoi(getenv("CLHIP_IIR_POLL_BOUND")) : (1 << 16);
+    f->seg_force = getenv("CLHIP_IIR_SEG") ? atoi(getenv("CLHIP_IIR_SEG")) : 0;           // experiment knobs
+    f->dynamic = getenv("CLHIP_IIR_DYNAMIC") ? atoi(getenv("CLHIP_IIR_DYNAMIC")) : 1;
+    f->force_scan = getenv("CLHIP_IIR_ONEPASS") && atoi(getenv("CLHIP_IIR_ONEPASS")) == 0;   // A/B: the four-kernel scan for everything
+    if (getenv("CLHIP_IIR_STAMPS") && atoi(getenv("CLHIP_IIR_STAMPS"))) {
+        f->d_stamps = (unsigned long long *)clhip_malloc(sizeof(unsigned long long) * (RL_STAMP_WAVES * RL_STAMP_TILES * RL_STAMP_PHASES + 3 * RL_STAMP_ALLWAVES));
+        if (f->d_stamps) (void)hipMemset(f->d_stamps, 0, sizeof(unsigned long long) * (RL_STAMP_WAVES * RL_STAMP_TILES * RL_STAMP_PHASES + 3 * RL_STAMP_ALLWAVES));
+    }
+    return f;
 }
 
-extern "C" int clhip_iir_overruns(void)
+// diagnostics: the phase time stamps of the last single-pass launch (CLHIP_IIR_STAMPS=1 at create): [64 waves][16 tiles][12 phases]
+// of the 100 MHz real-time counter, 0 where nothing was recorded, then [8192 waves][start, end, tiles done]; returns the
+// number of words, 0 when not enabled
+extern "C" size_t clhip_iir_debug_stamps(clhip_iir *f, unsigned long long *h_out)
 {
-    unsigned int *h = iir_overrun_word(nullptr);
-    if (!h) return 0;
-    const unsigned int n = __atomic_exchange_n(h, 0u, __ATOMIC_RELAXED);
-    return n > 0x7fffffffu ? 0x7fffffff : (int)n;
+    if (!f || !f->d_stamps) return 0;
+    const size_t nw = (size_t)RL_STAMP_WAVES * RL_STAMP_TILES * RL_STAMP_PHASES + 3 * RL_STAMP_ALLWAVES;
+    if (f->last_valid) (void)hipStreamSynchronize(f->last_stream);
+    if (h_out && hipMemcpy(h_out, f->d_stamps, sizeof(unsigned long long) * nw, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return nw;
 }
 
-template <int NS>
-static int iir_launch_onepass(const IirPlan *d_plan, const IirPlan &plan, double *d_state, uint32_t *d_iq, long stride, long n,
-                              int n_streams, double *ws, hipStream_t s)
+extern "C" void clhip_iir_set_poll_bound(clhip_iir *f, int polls) { if (f) f->poll_bound = polls; }
+extern "C" int clhip_iir_on_scan_path(const clhip_iir *f) { return f && f->force_scan ? 1 : 0; }
+
+extern "C" int clhip_iir_set_state(clhip_iir *f, const double *h_state)
 {
-    constexpr int D2 = 4 * NS;
-    const long n_seg = (long)clhip_div_up((size_t)n, IIR_SEG), n_tiles = (long)clhip_div_up((size_t)n_seg, IIR_TILE);
-    // workspace, all of it pre-set to all-ones by ONE memset: [64 rank counters]
-    // [per stream: readers of the old carried state][aggregates: n_streams x n_tiles x 2D]
-    unsigned int *ticket = (unsigned int *)ws;
-    unsigned int *d_overruns = nullptr;
-    if (!iir_overrun_word(&d_overruns)) { clhip_set_error("clhip_iir_cs16: cannot map the overrun counter"); return -1; }
-    const char *pb = getenv("CLHIP_IIR_POLL_BOUND");                  // tests force the give-up path with -1
-    const int poll_bound = pb ? atoi(pb) : (1 << 20);
-    constexpr size_t TK = IIR_RANK_CLASSES * sizeof(unsigned int) / sizeof(double);
-    unsigned int *readers = (unsigned int *)(ws + TK);
-    const size_t rd_doubles = ((size_t)n_streams + 1) / 2;
-    unsigned long long *agg = (unsigned long long *)(ws + TK + rd_doubles);
-    CLHIP_CHECK(hipMemsetAsync(ws, 0xFF, sizeof(double) * (TK + rd_doubles + (size_t)n_tiles * n_streams * D2), s));
-    const long total = n_tiles * n_streams;
-    bool b121 = true;                       // b = (1, 2, 1) exactly in every stage after the first: the four-operation stage form
-    for (int k = 1; k < NS; k++) b121 = b121 && plan.coef.b0[k] == 1.0 && plan.coef.b1[k] == 2.0 && plan.coef.b2[k] == 1.0;
-    const int dbg = getenv("CLHIP_IIR_DBG") ? atoi(getenv("CLHIP_IIR_DBG")) : 0;                       // timing ablations only (results invalid)
-    const bool unit_b = b121 && NS > 1 && !(dbg & 16);
-    const int resident = unit_b ? iir_resident_waves(iir_onepass_kernel<NS, true>, 2 * NS) : iir_resident_waves(iir_onepass_kernel<NS, false>, 2 * NS + 1);
-    const unsigned grid = (unsigned)(total < resident ? total : resident);
-    const int stagger = total >= 2L * grid ? (getenv("CLHIP_IIR_STAGGER_US") ? atoi(getenv("CLHIP_IIR_STAGGER_US")) : 0) * 100 : 0;   // experiment knob: measured neutral
-    if (unit_b)
-        hipLaunchKernelGGL((iir_onepass_kernel<NS, true>), dim3(grid), dim3(IIR_TILE), IIR_LDS_WORDS * 4, s, d_plan, plan.coef, d_iq,
-                           stride, n, n_seg, n_tiles, n_streams, ticket, agg, readers, d_state, plan.horizon, d_overruns, poll_bound, dbg, stagger);
-    else
-        hipLaunchKernelGGL((iir_onepass_kernel<NS, false>), dim3(grid), dim3(IIR_TILE), IIR_LDS_WORDS * 4, s, d_plan, plan.coef, d_iq,
-                           stride, n, n_seg, n_tiles, n_streams, ticket, agg, readers, d_state, plan.horizon, d_overruns, poll_bound, dbg, stagger);
+    if (!f) return -1;
+    if (f->last_valid) CLHIP_CHECK(hipStreamSynchronize(f->last_stream));
+    const size_t half = (size_t)2 * IIR_MAX_DIM * f->n_streams;
+    if (h_state) CLHIP_CHECK(hipMemcpy(f->d_state + f->cur * half, h_state, sizeof(double) * half, hipMemcpyHostToDevice));
+    else CLHIP_CHECK(hipMemset(f->d_state + f->cur * half, 0, sizeof(double) * half));
+    CLHIP_CHECK(hipStreamSynchronize(nullptr));
+    f->can_undo = false;
     return 0;
 }
 
+extern "C" int clhip_iir_get_state(clhip_iir *f, double *h_state)
+{
+    if (!f || !h_state) return -1;
+    if (f->last_valid) CLHIP_CHECK(hipStreamSynchronize(f->last_stream));
+    const size_t half = (size_t)2 * IIR_MAX_DIM * f->n_streams;
+    CLHIP_CHECK(hipMemcpy(h_state, f->d_state + f->cur * half, sizeof(double) * half, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// segment length for a call: short segments spread a small call over many waves (one native batch of 131072 samples
+// is 256 tiles at 16-sample segments, 32 at 64) and shorten each wave's serial work fourfold; long ones pay the
+// per-tile scan and look-back least often.  -1 = no single-pass shape for this filter (memory too long): the scan.
+static int iir_pick_shape(const clhip_iir *f, size_t n)
+{
+    static const size_t tiles_max[3] = {1024, 2048, (size_t)-1};
+    const IirPlan &pl = f->pe->host;
+    for (int i = 0; i < 3; i++) {
+        if (!pl.rail[i].horizon) continue;
+        if (f->seg_force) { if (kRailSegs[i] == f->seg_force) return i; continue; }
+        const size_t tiles = clhip_div_up(clhip_div_up(n, (size_t)kRailSegs[i]), RL_SEGS) * f->n_streams;
+        if (tiles <= tiles_max[i]) return i;
+    }
+    return -1;
+}
+
 template <int NS>
-static void iir_launch(const IirPlan *d_plan, const IirCoef &coef, double *d_state, uint32_t *d_iq, long stride, long n,
-                       int n_streams, double *ws, hipStream_t s)
+static void iir_launch_scan(const IirPlan *d_plan, const IirCoef &coef, const double *st_in, double *st_out, const uint32_t *in,
+                            uint32_t *out, long stride, long n, int n_streams, double *ws, hipStream_t s)
 {
     constexpr int D2 = 4 * NS;               // doubles per state pair
     const long n_seg = (long)clhip_div_up((size_t)n, IIR_SEG), n_tiles = (long)clhip_div_up((size_t)n_seg, IIR_TILE);
@@ -1070,63 +1375,129 @@ static void iir_launch(const IirPlan *d_plan, const IirCoef &coef, double *d_sta
     double *gend = X + n_tiles * n_streams * D2, *gc = gend + n_groups * n_streams * D2;
     dim3 grid((unsigned)n_tiles, n_streams), block(IIR_TILE);
     static_assert(IIR_TILE * (2 * IIR_MAX_DIM + 1) * 8 <= IIR_LDS_WORDS * 4, "the scan exchange fits the tile's LDS");
-    hipLaunchKernelGGL(iir_k1_kernel<NS>, grid, block, IIR_LDS_WORDS * 4, s, d_plan, (const uint32_t *)d_iq, stride, n, n_seg,
-                       n_tiles, ZS, tend);
+    hipLaunchKernelGGL(iir_k1_kernel<NS>, grid, block, IIR_LDS_WORDS * 4, s, d_plan, in, stride, n, n_seg, n_tiles, ZS, tend);
     hipLaunchKernelGGL(iir_k2a_kernel<NS>, dim3((unsigned)n_groups, n_streams), dim3(IIR_GROUP), 0, s, d_plan, n_tiles, n_groups,
                        (const double *)tend, X, gend);
-    hipLaunchKernelGGL(iir_k2b_kernel<NS>, dim3((unsigned)n_streams), dim3(64), 0, s, d_plan, n_groups, (const double *)gend, gc,
-                       (const double *)d_state);
-    hipLaunchKernelGGL(iir_k3_kernel<NS>, grid, block, IIR_LDS_WORDS * 4, s, d_plan, coef, d_iq, stride, n, n_seg, n_tiles,
-                       n_groups, (const double *)ZS, (const double *)X, (const double *)gc, d_state);
+    hipLaunchKernelGGL(iir_k2b_kernel<NS>, dim3((unsigned)n_streams), dim3(64), 0, s, d_plan, n_groups, (const double *)gend, gc, st_in);
+    hipLaunchKernelGGL(iir_k3_kernel<NS>, grid, block, IIR_LDS_WORDS * 4, s, d_plan, coef, in, out, stride, n, n_seg, n_tiles,
+                       n_groups, (const double *)ZS, (const double *)X, (const double *)gc, st_out);
 }
 
-// d_state: 2*IIR_MAX_DIM doubles per stream, layout [rail][2*stage + {0:v1,1:v2}]
-extern "C" int clhip_iir_cs16_batch(const double *h_sos, int n_stages, double *d_state, int16_t *d_iq,
-                                    size_t stride_samples, size_t n_samples, int n_streams, void *d_ws,
-                                    size_t ws_bytes, void *stream)
+extern "C" int clhip_iir_run(clhip_iir *f, const int16_t *d_in, int16_t *d_out, size_t stride_samples, size_t n_samples, void *stream)
 {
-    if (n_samples == 0 || n_streams <= 0) return 0;
-    if (!h_sos || n_stages < 1 || n_stages > IIR_MAX_STAGES || !d_state || !d_iq || !d_ws) {
-        clhip_set_error("clhip_iir_cs16: bad arguments (1..%d biquads)", IIR_MAX_STAGES);
+    if (!f || !d_in || !d_out || (((uintptr_t)d_in | (uintptr_t)d_out) & 3)) {
+        clhip_set_error("clhip_iir_run: null / misaligned buffer");
         return -1;
     }
-    const size_t need = 256 + iir_var_bytes(n_samples) * n_streams;
-    if (ws_bytes < need) {
-        clhip_set_error("clhip_iir_cs16: workspace too small (%zu < %zu)", ws_bytes, need);
+    if (n_samples == 0) return 0;
+    if (f->n_streams > 1 && stride_samples < n_samples) { clhip_set_error("clhip_iir_run: streams overlap"); return -1; }
+    if (*(volatile unsigned int *)f->h_over) {                 // raised by an earlier launch nobody asked about
+        clhip_set_error("clhip_iir_run: an earlier call overran and clhip_iir_status() was not consulted; its output and the state are invalid");
+        *f->h_over = 0;
+        f->can_undo = false;
+        f->force_scan = true;
         return -1;
     }
     hipStream_t s = (hipStream_t)stream;
-    const IirPlanEntry *pe = iir_plan_for(h_sos, n_stages);
-    if (!pe) return -1;
-    const IirPlan &plan = pe->host;
-    const IirPlan *d_plan = pe->dev;
-    double *wsv = (double *)d_ws;
-    // single pass unless the filter's memory is too long for it (or CLHIP_IIR_ONEPASS=0: the four-kernel scan, A/B)
-    static const int onepass_env = getenv("CLHIP_IIR_ONEPASS") ? atoi(getenv("CLHIP_IIR_ONEPASS")) : 1;
-    if (onepass_env && plan.horizon >= 1 && plan.horizon <= IIR_HMAX) {
-        int rc;
-        switch (n_stages) {
-        case 1: rc = iir_launch_onepass<1>(d_plan, plan, d_state, (uint32_t *)d_iq, (long)stride_samples, (long)n_samples, n_streams, wsv, s); break;
-        case 2: rc = iir_launch_onepass<2>(d_plan, plan, d_state, (uint32_t *)d_iq, (long)stride_samples, (long)n_samples, n_streams, wsv, s); break;
-        case 3: rc = iir_launch_onepass<3>(d_plan, plan, d_state, (uint32_t *)d_iq, (long)stride_samples, (long)n_samples, n_streams, wsv, s); break;
-        default: rc = iir_launch_onepass<4>(d_plan, plan, d_state, (uint32_t *)d_iq, (long)stride_samples, (long)n_samples, n_streams, wsv, s); break;
+    const IirPlan &plan = f->pe->host;
+    const size_t half = (size_t)2 * IIR_MAX_DIM * f->n_streams;
+    const double *st_in = f->d_state + f->cur * half;
+    double *st_out = f->d_state + (f->cur ^ 1) * half;
+    const long n = (long)n_samples, stride = (long)stride_samples;
+    const int shape = f->force_scan ? -1 : iir_pick_shape(f, n_samples);
+    if (shape >= 0) {
+        const int seg = kRailSegs[shape];
+        const long n_seg = (long)clhip_div_up(n_samples, (size_t)seg), n_tiles = (long)clhip_div_up((size_t)n_seg, RL_SEGS);
+        const size_t words = (size_t)n_tiles * f->n_streams * 4 * f->n_stages;      // [stream][tile][rail][D]
+        if (words > f->agg_cap) {
+            // grow both buffers (rare: the first call, or a longer one than any before)
+            if (f->last_valid) CLHIP_CHECK(hipStreamSynchronize(f->last_stream));
+            for (int i = 0; i < 2; i++) {
+                clhip_free(f->d_agg[i]);
+                f->d_agg[i] = (unsigned long long *)clhip_malloc(sizeof(unsigned long long) * words);
+                if (!f->d_agg[i]) { f->agg_cap = 0; return -1; }
+                CLHIP_CHECK(hipMemsetAsync(f->d_agg[i], 0xFF, sizeof(unsigned long long) * words, s));
+                f->dirty[i] = 0;
+            }
+            f->agg_cap = words;
         }
-        if (rc) return -1;
+        iir_rail_fn fn = rail_kernel_for(f->n_stages, seg, f->b121);
+        const long total = n_tiles * f->n_streams;
+        const int resident = iir_resident_waves(fn, seg);
+        const unsigned grid = (unsigned)(total < resident ? total : resident);
+        int nc = RL_CLASSES;
+        while ((unsigned)nc > grid) nc >>= 1;
+        static const int dbg = getenv("CLHIP_IIR_DBG") ? atoi(getenv("CLHIP_IIR_DBG")) : 0;          // timing ablations only (results invalid)
+        IirRailArgs a;
+        a.G = &f->pe->dev->G[0][0]; a.tab = &f->pe->dev->rail[shape]; a.c = plan.coef;
+        a.in = (const uint32_t *)d_in; a.out = (uint32_t *)d_out;
+        a.stride = stride; a.n = n; a.n_seg = n_seg; a.n_tiles = n_tiles;
+        a.n_streams = f->n_streams; a.horizon = plan.rail[shape].horizon;
+        a.ctl = f->d_ctl;
+        a.agg = f->d_agg[f->acur]; a.agg_other = f->d_agg[f->acur ^ 1]; a.other_words = (long)f->dirty[f->acur ^ 1];
+        a.state_in = st_in; a.state_out = st_out;
+        a.overrun = f->d_over; a.poll_bound = f->poll_bound; a.dbg = dbg; a.n_classes = nc; a.dynamic = f->dynamic;
+        a.stamps = f->d_stamps;
+        static const int verbose = getenv("CLHIP_IIR_VERBOSE") ? atoi(getenv("CLHIP_IIR_VERBOSE")) : 0;
+        if (verbose) fprintf(stderr, "clhip_iir_run: seg %d tiles %ld grid %u (resident %d) classes %d horizon %d dynamic %d\n", seg, total, grid, resident, nc, a.horizon, a.dynamic);
+        hipLaunchKernelGGL(fn, dim3(grid), dim3(64), RL_SEGS * (seg + 4) * 4, s, a);
         CLHIP_CHECK_LAUNCH();
-        return 0;
+        f->dirty[f->acur] = words > f->dirty[f->acur] ? words : f->dirty[f->acur];
+        f->dirty[f->acur ^ 1] = 0;
+        f->acur ^= 1;
+        f->last_was_rail = true;
+    } else {
+        const size_t need = iir_scan_ws_doubles(n_samples) * f->n_streams;
+        if (need > f->scan_ws_doubles) {
+            if (f->last_valid) CLHIP_CHECK(hipStreamSynchronize(f->last_stream));
+            clhip_free(f->d_scan_ws);
+            f->d_scan_ws = (double *)clhip_malloc(sizeof(double) * need);
+            f->scan_ws_doubles = f->d_scan_ws ? need : 0;
+            if (!f->d_scan_ws) return -1;
+        }
+        const IirPlan *dp = f->pe->dev;
+        const uint32_t *in = (const uint32_t *)d_in;
+        uint32_t *out = (uint32_t *)d_out;
+        switch (f->n_stages) {
+        case 1: iir_launch_scan<1>(dp, plan.coef, st_in, st_out, in, out, stride, n, f->n_streams, f->d_scan_ws, s); break;
+        case 2: iir_launch_scan<2>(dp, plan.coef, st_in, st_out, in, out, stride, n, f->n_streams, f->d_scan_ws, s); break;
+        case 3: iir_launch_scan<3>(dp, plan.coef, st_in, st_out, in, out, stride, n, f->n_streams, f->d_scan_ws, s); break;
+        default: iir_launch_scan<4>(dp, plan.coef, st_in, st_out, in, out, stride, n, f->n_streams, f->d_scan_ws, s); break;
+        }
+        CLHIP_CHECK_LAUNCH();
+        f->last_was_rail = false;
     }
-    switch (n_stages) {
-    case 1: iir_launch<1>(d_plan, plan.coef, d_state, (uint32_t *)d_iq, (long)stride_samples, (long)n_samples, n_streams, wsv, s); break;
-    case 2: iir_launch<2>(d_plan, plan.coef, d_state, (uint32_t *)d_iq, (long)stride_samples, (long)n_samples, n_streams, wsv, s); break;
-    case 3: iir_launch<3>(d_plan, plan.coef, d_state, (uint32_t *)d_iq, (long)stride_samples, (long)n_samples, n_streams, wsv, s); break;
-    default: iir_launch<4>(d_plan, plan.coef, d_state, (uint32_t *)d_iq, (long)stride_samples, (long)n_samples, n_streams, wsv, s); break;
-    }
-    CLHIP_CHECK_LAUNCH();
+    f->undo_cur = f->cur; f->can_undo = true;
+    f->cur ^= 1;
+    f->last_in = d_in; f->last_out = d_out; f->last_stride = stride_samples; f->last_n = n_samples; f->last_stream = s; f->last_valid = true;
     return 0;
 }
 
-extern "C" int clhip_iir_cs16(const double *h_sos, int n_stages, double *d_state, int16_t *d_iq, size_t n_samples,
-                              void *d_ws, size_t ws_bytes, void *stream)
+// After the caller has synchronised the stream of the last clhip_iir_run: 0 = its output is valid.  -1 = a poll of the
+// single-pass kernel gave up: the samples of that call must not be used; the carried state is back where it was
+// before the call (the launch wrote the other half), and from now on this object takes the scan path (no waiting
+// between workgroups), so the call can simply be made again.
+extern "C" int clhip_iir_status(clhip_iir *f)
 {
-    return clhip_iir_cs16_batch(h_sos, n_stages, d_state, d_iq, n_samples, n_samples, 1, d_ws, ws_bytes, stream);
+    if (!f) return -1;
+    if (!*(volatile unsigned int *)f->h_over) return 0;
+    *f->h_over = 0;
+    f->force_scan = true;
+    if (f->can_undo) { f->cur = f->undo_cur; f->can_undo = false; }
+    clhip_set_error("clhip_iir_status: a tile of the single-pass kernel gave up waiting for its predecessors; the output of the last call is invalid, filter state restored");
+    return -1;
+}
+
+// Synchronise, ask, and repair: 0 = good; 1 = the call overran and has been made again on the scan path (d_out holds
+// the right samples now, the state has advanced once); -1 = overran in place (the input is gone: state restored,
+// the caller re-produces the input and calls again) or a runtime error.
+extern "C" int clhip_iir_finish(clhip_iir *f)
+{
+    if (!f || !f->last_valid) return 0;
+    CLHIP_CHECK(hipStreamSynchronize(f->last_stream));
+    if (clhip_iir_status(f) == 0) return 0;
+    if (f->last_in == f->last_out) return -1;
+    if (clhip_iir_run(f, f->last_in, f->last_out, f->last_stride, f->last_n, f->last_stream)) return -1;
+    CLHIP_CHECK(hipStreamSynchronize(f->last_stream));
+    return clhip_iir_status(f) == 0 ? 1 : -1;
 }

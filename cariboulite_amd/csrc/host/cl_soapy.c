@@ -30,8 +30,10 @@ struct cl_stream {
     size_t mtu_size;
     int filter_type;             /* CL_DIGFILT_*                                 */
     double sos[3][15];           /* filt20 / filt50 / filt100: 3 biquads x {b0,b1,b2,a1,a2} */
-    double *d_iir_state[3];      /* per filter, I and Q rails: never reset (CaribouliteStream.cpp:127-141) */
-    void *d_iir_ws; size_t iir_ws_cap;
+    clhip_iir *iir[3];           /* filt20 / filt50 / filt100 (CaribouliteStream.hpp:124-131): state per filter, I and Q rails, never
+                                  * reset, not even when the selection changes (CaribouliteStream.cpp:127-141) */
+    int16_t *d_filt; size_t filt_cap;    /* the filtered samples: the IIR runs out of place, so a call can be repeated */
+    unsigned long iir_overruns;          /* calls the single-pass kernel gave up on (each was repeated on the scan path) */
     void *d_conv; size_t conv_cap;       /* converted output / TX input staging (bytes) */
     void *h_conv; size_t h_conv_cap;     /* pinned host mirror */
     cl_dsp_cfg dsp;
@@ -178,8 +180,8 @@ static void stream_free(cl_stream *st)
 {
     if (!st) return;
     stream_stop_async(st);
-    for (int i = 0; i < 3; i++) clhip_free(st->d_iir_state[i]);
-    clhip_free(st->d_iir_ws); clhip_free(st->d_conv); clhip_host_free(st->h_conv);
+    for (int i = 0; i < 3; i++) clhip_iir_destroy(st->iir[i]);
+    clhip_free(st->d_filt); clhip_free(st->d_conv); clhip_host_free(st->h_conv);
     if (st->rx_pipe) clhip_rx_pipe_destroy(st->rx_pipe);
     if (st->tx_pipe) clhip_tx_pipe_destroy(st->tx_pipe);
     free(st);
@@ -198,10 +200,9 @@ static cl_stream *stream_new(cl_device *dev)
     const double bw[3] = {20e3, 50e3, 100e3};          /* :85-91 setup(4e6, bw/2) */
     for (int i = 0; i < 3; i++) {
         cl_design_butter_lowpass(DIG_FILT_ORDER, 4e6, bw[i] / 2, st->sos[i]);
-        st->d_iir_state[i] = (double *)clhip_malloc(16 * sizeof(double));
-        if (!st->d_iir_state[i] || clhip_memset(st->d_iir_state[i], 0, 16 * sizeof(double), dev->smi->stream)) { stream_free(st); return NULL; }
+        st->iir[i] = clhip_iir_create(st->sos[i], DIG_FILT_ORDER / 2, 1);
+        if (!st->iir[i]) { stream_free(st); return NULL; }
     }
-    clhip_stream_sync(dev->smi->stream);
     return st;
 }
 
@@ -417,14 +418,7 @@ static int read_native_device(cl_stream *st, size_t n, int *aligned, long timeou
         bad = bad || clhip_stream_sync(st->astream);
         cl_ring_get_end(st->rx_queue, claimed);
         if (bad) return 0;
-        const int got = (int)claimed;
-        if (st->filter_type != CL_DIGFILT_NONE) {
-            const int f = st->filter_type - 1;
-            const size_t need = clhip_iir_workspace_bytes((size_t)got, 3);
-            if (cl_ensure(&st->d_iir_ws, &st->iir_ws_cap, need, 1, 0)) return 0;
-            if (clhip_iir_cs16(st->sos[f], 3, st->d_iir_state[f], st->d_aiq, (size_t)got, st->d_iir_ws, st->iir_ws_cap, st->astream)) return 0;
-        }
-        return got;
+        return (int)claimed;
     }
     /* up to one native batch per call (what every client of the reference asks for): the chunk-at-a-time reader,
      * which has the NEXT batch's bytes on their way to the device while this one is analysed and copied out */
@@ -435,16 +429,29 @@ static int read_native_device(cl_stream *st, size_t n, int *aligned, long timeou
         if (ret == CL_SMI_ERR_IO) printf("reader thread failed to read SMI!\n");    /* :270 */
         ret = 0;                                                                    /* :266-276 */
     }
-    if (ret > 0 && st->filter_type != CL_DIGFILT_NONE) {                            /* :291-298 */
-        const int f = st->filter_type - 1;
-        const size_t need = clhip_iir_workspace_bytes((size_t)ret, 3);
-        if (cl_ensure(&st->d_iir_ws, &st->iir_ws_cap, need, 1, 0)) return 0;
-        /* NOTE: slots the reference leaves untouched after a re-sync hold stale samples there too;
-         * the filter runs over all `ret` slots exactly as the reference loop does */
-        if (clhip_iir_cs16(st->sos[f], 3, st->d_iir_state[f], smi->d_iq, (size_t)ret, st->d_iir_ws, st->iir_ws_cap, smi->stream)) return 0;
-        if (aligned) *aligned = 0;     /* filtered samples: the fused raw-word path no longer applies */
-    }
     return ret;
+}
+
+/* Stream::ReadSamples(int16*)  CaribouliteStream.cpp:291-298: the selected low-pass over all `n` slots of the native
+ * read exactly as the reference loop runs (slots it leaves untouched after a re-sync hold stale samples there too).
+ * Out of place -- d_raw keeps the unfiltered samples, st->d_filt takes the result -- so that a call the single-pass
+ * kernel gave up on can be made again.  Asynchronous on hs; the verdict is clhip_iir_status() after the synchronise. */
+static const int16_t *filter_native(cl_stream *st, const int16_t *d_raw, size_t n, void *hs)
+{
+    if (st->filter_type == CL_DIGFILT_NONE) return d_raw;
+    if (cl_ensure((void **)&st->d_filt, &st->filt_cap, n + 8, 4, 0)) return NULL;
+    if (clhip_iir_run(st->iir[st->filter_type - 1], d_raw, st->d_filt, n, n, hs)) return NULL;
+    return st->d_filt;
+}
+
+/* after the synchronise: 0 = the filtered samples are good (or no filter ran); 1 = the call overran -- the filter's state
+ * is back where it was, the object has switched to the scan path, the caller repeats its stages once */
+static int filter_overran(cl_device *dev, cl_stream *st)
+{
+    if (st->filter_type == CL_DIGFILT_NONE || clhip_iir_status(st->iir[st->filter_type - 1]) == 0) return 0;
+    st->iir_overruns++;
+    cl_seterr(dev->err, sizeof dev->err, "readStream: %s", clhip_last_error());
+    return 1;
 }
 
 static int read_stream(cl_device *dev, cl_stream *st, void *const *buffs, size_t numElems, long timeoutUs);
@@ -453,14 +460,13 @@ static int read_stream(cl_device *dev, cl_stream *st, void *const *buffs, size_t
 int cl_readStream(cl_device *dev, cl_stream *st, void *const *buffs, size_t numElems, int *flags, long long *timeNs, long timeoutUs)
 {
     (void)flags; (void)timeNs;                         /* never written; timeoutUs only matters in ASYNC mode */
-    const int ret = read_stream(dev, st, buffs, numElems, timeoutUs);
-    /* every successful return has synchronised the stream the IIR ran on: a bounded poll of the single-pass kernel
-     * that gave up (clhip_iir_overruns) means wrong samples -- they are not handed out as good ones */
-    if (ret > 0 && st->filter_type != CL_DIGFILT_NONE && clhip_iir_overruns() > 0) {
-        cl_seterr(dev->err, sizeof dev->err, "readStream: the IIR kernel could not order its tiles (GPU shared with other work?); samples dropped, filter state is undefined");
-        return 0;                                                                   /* :266-276: errors read as 0 */
-    }
-    return ret;
+    return read_stream(dev, st, buffs, numElems, timeoutUs);
+}
+
+unsigned long cl_stream_iir_overruns(const cl_stream *st) { return st ? st->iir_overruns : 0; }
+void cl_stream_set_iir_poll_bound(cl_stream *st, int polls)
+{
+    if (st) for (int i = 0; i < 3; i++) clhip_iir_set_poll_bound(st->iir[i], polls);
 }
 
 static int read_stream(cl_device *dev, cl_stream *st, void *const *buffs, size_t numElems, long timeoutUs)
@@ -528,14 +534,27 @@ static int read_stream(cl_device *dev, cl_stream *st, void *const *buffs, size_t
         int res = read_native_device(st, numElems, &aligned, timeoutUs);
         if (res <= 0) return res;
         if (st->use_async) {            /* one PCIe crossing: device -> pinned mirror -> the client's buffer */
-            if (aligned != 2 &&
-                (cl_ensure((void **)&st->h_conv, &st->h_conv_cap, (size_t)res * 4 + 64, 1, 1) ||
-                 clhip_memcpy_d2h(st->h_conv, st->d_aiq, (size_t)res * 4, st->astream) || clhip_stream_sync(st->astream))) return 0;
+            if (aligned != 2) {
+                if (cl_ensure((void **)&st->h_conv, &st->h_conv_cap, (size_t)res * 4 + 64, 1, 1)) return 0;
+                for (int attempt = 0;; attempt++) {
+                    const int16_t *d_f = filter_native(st, st->d_aiq, (size_t)res, st->astream);
+                    if (!d_f || clhip_memcpy_d2h(st->h_conv, d_f, (size_t)res * 4, st->astream) || clhip_stream_sync(st->astream)) return 0;
+                    if (!filter_overran(dev, st)) break;
+                    if (attempt) return 0;
+                }
+            }
             memcpy(out, st->h_conv, (size_t)res * 4);
             return res;
         }
         if (st->filter_type == CL_DIGFILT_NONE) { if (cl_smi_copy_out(smi, (cl_sample_complex_int16 *)out, NULL, -1)) return 0; }
-        else if (clhip_memcpy_d2h(out, smi->d_iq, (size_t)res * 4, smi->stream) || clhip_stream_sync(smi->stream)) return 0;
+        else {
+            for (int attempt = 0;; attempt++) {      /* a call the single-pass kernel gave up on is made again, once */
+                const int16_t *d_f = filter_native(st, smi->d_iq, (size_t)res, smi->stream);
+                if (!d_f || clhip_memcpy_d2h(out, d_f, (size_t)res * 4, smi->stream) || clhip_stream_sync(smi->stream)) return 0;
+                if (!filter_overran(dev, st)) break;
+                if (attempt) return 0;
+            }
+        }
         return res;
     }
     if (numElems > st->mtu_size) numElems = st->mtu_size;                          /* :306,328,351 */
@@ -555,28 +574,38 @@ static int read_stream(cl_device *dev, cl_stream *st, void *const *buffs, size_t
     int res = read_native_device(st, numElems, &aligned, timeoutUs);
     if (res <= 0) return res;
     const size_t n = (size_t)res;
-    int16_t *d_iq = st->use_async ? st->d_aiq : smi->d_iq;      /* the native samples of this call */
+    const int16_t *d_raw = st->use_async ? st->d_aiq : smi->d_iq;      /* the native samples of this call */
     void *hs = st->use_async ? st->astream : smi->stream;
-    if (st->rx_pipe) {
-        /* extension stages where a client of readStream(CF32) would apply them */
-        const size_t n_out = clhip_rx_pipe_out_count(st->rx_pipe, n);
-        const size_t ob = st->dsp.demod_fm ? 4 : 8;
-        if (cl_ensure(&st->d_conv, &st->conv_cap, n_out * ob + 64, 1, 0)) return 0;
-        long got;
-        if (aligned)   /* every chunk in sync: one fused launch straight from the raw SMI words */
-            got = clhip_rx_pipe_run(st->rx_pipe, CL_PIPE_IN_SMI_WORDS, smi->d_bytes, 0, n, st->d_conv, 0, hs);
-        else           /* re-synchronised, IIR-filtered or popped from the ring: from the native int16 samples */
-            got = clhip_rx_pipe_run(st->rx_pipe, CL_PIPE_IN_CS16, d_iq, 0, n, st->d_conv, 0, hs);
-        if (got < 0) return 0;
-        if (got && (clhip_memcpy_d2h(out, st->d_conv, (size_t)got * ob, hs) || clhip_stream_sync(hs))) return 0;
-        return (int)got;
+    if (st->filter_type != CL_DIGFILT_NONE) aligned = 0;              /* filtered samples: the fused raw-word path no longer applies */
+    /* everything behind the native read is queued on one stream and synchronised once; if the filter's verdict then says
+     * the single-pass kernel gave up, its state is already back where it was: the stages are queued again, once */
+    for (int attempt = 0;; attempt++) {
+        const int16_t *d_iq = filter_native(st, d_raw, n, hs);
+        if (!d_iq) return 0;
+        if (st->rx_pipe) {
+            /* extension stages where a client of readStream(CF32) would apply them */
+            const size_t n_out = clhip_rx_pipe_out_count(st->rx_pipe, n);
+            const size_t ob = st->dsp.demod_fm ? 4 : 8;
+            if (cl_ensure(&st->d_conv, &st->conv_cap, n_out * ob + 64, 1, 0)) return 0;
+            long got;
+            if (aligned)   /* every chunk in sync: one fused launch straight from the raw SMI words */
+                got = clhip_rx_pipe_run(st->rx_pipe, CL_PIPE_IN_SMI_WORDS, smi->d_bytes, 0, n, st->d_conv, 0, hs);
+            else           /* re-synchronised, IIR-filtered or popped from the ring: from the native int16 samples */
+                got = clhip_rx_pipe_run(st->rx_pipe, CL_PIPE_IN_CS16, d_iq, 0, n, st->d_conv, 0, hs);
+            if (got < 0) return 0;
+            if (clhip_memcpy_d2h(out, st->d_conv, (size_t)got * ob, hs) || clhip_stream_sync(hs)) return 0;
+            if (!filter_overran(dev, st)) return (int)got;
+            clhip_rx_pipe_rollback(st->rx_pipe);                       /* the pipe ran on invalid samples: undo it too */
+        } else {
+            /* :304-367: every one of the `res` slots is converted, stale ones included */
+            if (cl_ensure(&st->d_conv, &st->conv_cap, n * 16 + 64, 1, 0)) return 0;
+            if (clhip_convert_from_cs16(d_iq, n, st->format, st->d_conv, hs) ||
+                clhip_memcpy_d2h(out, st->d_conv, n * fmt_bytes(st->format), hs) || clhip_stream_sync(hs))
+                return 0;
+            if (!filter_overran(dev, st)) return res;
+        }
+        if (attempt) return 0;
     }
-    /* :304-367: every one of the `res` slots is converted, stale ones included */
-    if (cl_ensure(&st->d_conv, &st->conv_cap, n * 16 + 64, 1, 0)) return 0;
-    if (clhip_convert_from_cs16(d_iq, n, st->format, st->d_conv, hs) ||
-        clhip_memcpy_d2h(out, st->d_conv, n * fmt_bytes(st->format), hs) || clhip_stream_sync(hs))
-        return 0;
-    return res;
 }
 
 /* ------------------------------------------------------------------- TX path */

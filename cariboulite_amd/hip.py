@@ -49,11 +49,16 @@ _SIGS = {
     "clhip_convert_to_cs16": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]),
     "clhip_smi_debug_analyze": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p]),
     "clhip_smi_pack": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
-    "clhip_iir_cs16": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
-    "clhip_iir_workspace_bytes": (C.c_size_t, [C.c_size_t, C.c_int]),
-    "clhip_iir_overruns": (C.c_int, []),
-    "clhip_iir_cs16_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int,
-                                       C.c_void_p, C.c_size_t, C.c_void_p]),
+    "clhip_iir_create": (C.c_void_p, [C.c_void_p, C.c_int, C.c_int]),
+    "clhip_iir_destroy": (None, [C.c_void_p]),
+    "clhip_iir_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]),
+    "clhip_iir_status": (C.c_int, [C.c_void_p]),
+    "clhip_iir_finish": (C.c_int, [C.c_void_p]),
+    "clhip_iir_set_state": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "clhip_iir_get_state": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "clhip_iir_set_poll_bound": (None, [C.c_void_p, C.c_int]),
+    "clhip_iir_on_scan_path": (C.c_int, [C.c_void_p]),
+    "clhip_iir_debug_stamps": (C.c_size_t, [C.c_void_p, C.c_void_p]),
     "clhip_rx_pipe_create": (C.c_void_p, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "clhip_rx_pipe_destroy": (None, [C.c_void_p]),
     "clhip_rx_pipe_reset": (None, [C.c_void_p]),
@@ -231,33 +236,62 @@ class RxPipe:
 
 
 class IIR:
-    """clhip_iir_cs16: in-place fp64 biquad cascade on CS16 streams (state carried on device)."""
+    """clhip_iir: fp64 biquad cascade on CS16 streams; the object carries the state (one per Soapy stream and filter)."""
 
     def __init__(self, sos, n_streams=1, device="cuda:0"):
-        import torch
         sos = np.asarray(sos, dtype=np.float64)
         if sos.shape[1] == 6:                       # scipy layout b0 b1 b2 a0 a1 a2 -> {b0,b1,b2,a1,a2}
             sos = np.concatenate([sos[:, :3] / sos[:, 3:4], sos[:, 4:] / sos[:, 3:4]], 1)
         self.sos = np.ascontiguousarray(sos)
         self.n_streams = n_streams
-        self.state = torch.zeros((n_streams, 16), dtype=torch.float64, device=device)
-        self.ws = None
-        self.device = device
+        require_gpu()
+        self.h = lib().clhip_iir_create(self.sos.ctypes.data, self.sos.shape[0], n_streams)
+        if not self.h:
+            raise RuntimeError("clhip_iir_create failed: " + last_error())
 
-    def run(self, d_iq, n, stride=None, stream=None):
-        import torch
-        need = lib().clhip_iir_workspace_bytes(n, self.sos.shape[0]) * self.n_streams
-        if self.ws is None or self.ws.numel() < need:
-            self.ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        _check(lib().clhip_iir_cs16_batch(self.sos.ctypes.data, self.sos.shape[0], ptr(self.state), ptr(d_iq),
-                                          n if stride is None else stride, n, self.n_streams, ptr(self.ws),
-                                          self.ws.numel(), stream if stream is not None else current_stream()),
-               "clhip_iir_cs16_batch")
+    def __del__(self):
+        if getattr(self, "h", None) and lib is not None:          # (module globals may be gone at interpreter exit)
+            lib().clhip_iir_destroy(self.h)
+            self.h = None
 
-    @staticmethod
-    def overruns():
-        """polls of the single-pass kernel that gave up on this device since the last call (after a synchronise)"""
-        return lib().clhip_iir_overruns()
+    def run(self, d_iq, n, stride=None, stream=None, out=None):
+        """in place unless `out` is given; asynchronous"""
+        _check(lib().clhip_iir_run(self.h, ptr(d_iq), ptr(out if out is not None else d_iq), n if stride is None else stride, n,
+                                   stream if stream is not None else current_stream()), "clhip_iir_run")
+
+    def status(self):
+        """after a synchronise: 0 = the last run is good, -1 = it overran (state restored, object now on the scan path)"""
+        return lib().clhip_iir_status(self.h)
+
+    def finish(self):
+        """synchronise + verdict + repeat on the scan path when the call was out of place: 0 good, 1 repaired, -1 failed"""
+        return lib().clhip_iir_finish(self.h)
+
+    def set_poll_bound(self, polls):
+        lib().clhip_iir_set_poll_bound(self.h, int(polls))
+
+    def on_scan_path(self):
+        return bool(lib().clhip_iir_on_scan_path(self.h))
+
+    def debug_stamps(self):
+        """([64 waves][16 tiles][12 phases] stamps, [8192 waves][start, end, tiles]) of the last launch (CLHIP_IIR_STAMPS=1), or None"""
+        n = lib().clhip_iir_debug_stamps(self.h, None)
+        if not n:
+            return None
+        out = np.zeros(n, dtype=np.uint64)
+        lib().clhip_iir_debug_stamps(self.h, out.ctypes.data)
+        return out[:64 * 16 * 12].reshape(64, 16, 12), out[64 * 16 * 12:].reshape(-1, 3)
+
+    @property
+    def state(self):
+        st = np.zeros((self.n_streams, 16), dtype=np.float64)
+        _check(lib().clhip_iir_get_state(self.h, st.ctypes.data), "clhip_iir_get_state")
+        return st
+
+    @state.setter
+    def state(self, st):
+        st = None if st is None else np.ascontiguousarray(st, dtype=np.float64).reshape(self.n_streams, 16)
+        _check(lib().clhip_iir_set_state(self.h, st.ctypes.data if st is not None else None), "clhip_iir_set_state")
 
 
 class TxPipe:

@@ -89,6 +89,8 @@ _SIGS = {
                                  C.c_longlong, C.c_long]),
     "cl_setBandwidth": (None, [C.c_void_p, C.c_int, C.c_size_t, C.c_double]),
     "cl_getDigitalFilter": (C.c_int, [C.c_void_p]),
+    "cl_stream_iir_overruns": (C.c_ulong, [C.c_void_p]),
+    "cl_stream_set_iir_poll_bound": (None, [C.c_void_p, C.c_int]),
     "cl_design_lowpass": (C.c_int, [C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p]),
     "cl_design_butter_lowpass": (C.c_int, [C.c_int, C.c_double, C.c_double, C.c_void_p]),
 }
@@ -291,3 +293,9 @@ class Device:
 
     def getDigitalFilter(self):
         return lib().cl_getDigitalFilter(self.h)
+
+    def streamIirOverruns(self, st):
+        return lib().cl_stream_iir_overruns(st)
+
+    def setStreamIirPollBound(self, st, polls):
+        lib().cl_stream_set_iir_poll_bound(st, int(polls))

@@ -153,26 +153,40 @@ int clhip_smi_pack(int mode, const int16_t *d_iq, size_t n_samples, uint8_t *d_b
 /*
  * IIR -- replaces the per-sample iir1 loop of Stream::ReadSamples
  * (CaribouliteStream.cpp:291-298): y = (int16)(float)LP(float(x)) on both
- * rails, Direct-Form-II biquad cascade in fp64, state carried in d_state
- * (16 doubles per stream: [rail I|Q][8] with entry 2*stage+0 = v1, 2*stage+1 = v2,
- * up to 4 biquads; zero it to reset).
+ * rails, Direct-Form-II biquad cascade in fp64.  A filter OBJECT stands where
+ * the Stream's Iir::Butterworth::LowPass<6> members stand (CaribouliteStream.hpp:
+ * 124-131): it owns the coefficients and the carried state of n_streams
+ * independent streams -- 16 doubles per stream, [rail I|Q][8] with entry
+ * 2*stage+0 = v1, 2*stage+1 = v2, up to 4 biquads -- which persists from call
+ * to call for the life of the object (:84-91: the reference never resets it).
  * sos = n_stages rows of {b0,b1,b2,a1,a2} (host pointer, a0 = 1).
  */
-int clhip_iir_cs16(const double *h_sos, int n_stages, double *d_state,
-                   int16_t *d_iq, size_t n_samples, void *d_workspace, size_t workspace_bytes,
-                   void *stream);
-size_t clhip_iir_workspace_bytes(size_t n_samples, int n_stages);   /* per stream */
-/* the same for n_streams independent streams (stream s at d_iq + s*stride_samples,
- * state s at d_state + s*16 doubles); workspace = n_streams * clhip_iir_workspace_bytes() */
-int clhip_iir_cs16_batch(const double *h_sos, int n_stages, double *d_state, int16_t *d_iq,
-                         size_t stride_samples, size_t n_samples, int n_streams,
-                         void *d_workspace, size_t workspace_bytes, void *stream);
-/* The single-pass kernel orders its tiles by waiting for the waves before it, with bounded polls.  Number of polls
- * that gave up on the current device since the last call of this function (and reset to 0): non-zero means the IIR
- * calls that have completed since then produced wrong samples and left a wrong carried state (only a launch squeezed
- * to a handful of resident waves by other work on the GPU can get there).  Valid once the streams those calls ran on
- * have been synchronised; costs one read of pinned host memory. */
-int clhip_iir_overruns(void);
+typedef struct clhip_iir clhip_iir;
+clhip_iir *clhip_iir_create(const double *h_sos, int n_stages, int n_streams);   /* current device; state = rest */
+void   clhip_iir_destroy(clhip_iir *f);
+/* n_samples of every stream (stream s at d_in/d_out + s*stride_samples int16 pairs; 4-byte aligned; d_out may be
+ * d_in), asynchronous on `stream`; the state advances by the call.  One call in flight per object. */
+int    clhip_iir_run(clhip_iir *f, const int16_t *d_in, int16_t *d_out, size_t stride_samples, size_t n_samples,
+                     void *stream);
+/* Verdict on the LAST clhip_iir_run, to be asked after synchronising its stream and before its samples are used.
+ * 0 = good.  -1 = a tile of the single-pass kernel gave up waiting for the tiles before it (its polls are bounded;
+ * a launch that moves at all never gets there): the samples of that call are invalid, the carried state is back
+ * where it was before the call, and the object takes the four-kernel scan (no waiting between workgroups) from now
+ * on -- the call can simply be made again.  The word behind this is the object's own (pinned host memory): two
+ * streams filtering on one GPU never see each other's verdicts. */
+int    clhip_iir_status(clhip_iir *f);
+/* synchronise + status + repair: 0 = good; 1 = the call had overrun and has been repeated on the scan path (d_out is
+ * good now, the state has advanced once); -1 = overran with d_out == d_in (the input is gone: state restored, the
+ * caller re-produces the input and calls again), or a runtime error */
+int    clhip_iir_finish(clhip_iir *f);
+/* carried state: 16 doubles per stream (NULL = rest); both synchronise with the last call */
+int    clhip_iir_set_state(clhip_iir *f, const double *h_state);
+int    clhip_iir_get_state(clhip_iir *f, double *h_state);
+void   clhip_iir_set_poll_bound(clhip_iir *f, int polls);   /* test hook: -1 forces every poll to give up */
+int    clhip_iir_on_scan_path(const clhip_iir *f);           /* 1 once an overrun (or CLHIP_IIR_ONEPASS=0) has switched it */
+/* diagnostics (objects created under CLHIP_IIR_STAMPS=1): per-phase time stamps of the last single-pass launch,
+ * [64 waves][16 tiles][12 phases] of the 100 MHz real-time counter; returns the word count (0: not enabled) */
+size_t clhip_iir_debug_stamps(clhip_iir *f, unsigned long long *h_out);
 
 /*
  * The RX pipe: raw SMI words -> int13 I/Q -> x/4096 -> FIR(T) -> [L/M polyphase
@@ -414,6 +428,10 @@ int    cl_writeStream(cl_device *dev, cl_stream *stream, const void *const *buff
 /* setBandwidth Cariboulite.cpp:395-417: RX bw < 160 kHz selects the IIR */
 void   cl_setBandwidth(cl_device *dev, int direction, size_t channel, double bw);
 int    cl_getDigitalFilter(const cl_device *dev);
+/* readStream calls of this stream whose IIR launch gave up waiting (clhip_iir_status) and were repeated on the scan
+ * path; the test hook hands clhip_iir_set_poll_bound to the stream's three filters */
+unsigned long cl_stream_iir_overruns(const cl_stream *stream);
+void   cl_stream_set_iir_poll_bound(cl_stream *stream, int polls);
 
 /* host helper: scipy.signal.firwin(ntaps, cutoff, window="hamming", fs=fs)
  * (the tap design SURVEY.md section 8 a13 specifies), rounded to fp32 */

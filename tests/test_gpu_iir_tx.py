@@ -42,7 +42,7 @@ def test_iir_vs_oracle_and_scipy(G, orc, bw_khz):
     diff = np.abs(got.astype(np.int32) - want.astype(np.int32))
     assert diff.max() <= 1 and np.mean(diff != 0) < 1e-5, (diff.max(), np.mean(diff != 0))
     # the carried state equals the oracle's DF-II state
-    st = f.state.cpu().numpy()[0]
+    st = f.state[0]
     for s in range(3):
         assert abs(st[2 * s] - ref.fi.v1[s]) <= 1e-9 * max(1.0, abs(ref.fi.v1[s]))
         assert abs(st[8 + 2 * s + 1] - ref.fq.v2[s]) <= 1e-9 * max(1.0, abs(ref.fq.v2[s]))
@@ -411,34 +411,93 @@ def test_iir_narrowest_reference_filter_many_tiles(G, orc):
         assert diff.max() <= 1 and np.mean(diff != 0) < 1e-4, (s, diff.max(), np.mean(diff != 0))
 
 
-def test_iir_poll_overrun_is_counted_and_reported(G, orc, monkeypatch):
+def test_iir_overrun_is_reported_rolled_back_and_repaired(G, orc):
     """The single-pass kernel's polls are bounded.  With the bound forced below 0 every tile that looks at a predecessor's
-    aggregate gives up: the call must say so through clhip_iir_overruns() (the Soapy layer turns that
-    into a failed read), the counter resets when read, and a normal call afterwards is clean and exact again."""
+    aggregate gives up: clhip_iir_status() says so for that very call (the object's own pinned word), the carried state is
+    back where it was (the launch wrote the other half of the ping-pong), no NaN has travelled, and the object takes the
+    four-kernel scan from then on.  Out of place, clhip_iir_finish() repeats the call by itself; in place the caller
+    re-produces the input.  A second object on the same GPU never sees the first one's verdict."""
     if os.environ.get("CLHIP_IIR_ONEPASS") == "0":
         pytest.skip("the A/B switch in force replaces the single-pass kernel whose polls this test forces to give up")
     import torch
     from cariboulite_amd import hip
     rng = np.random.default_rng(5)
-    n = 600 * 4096 + 123
-    x = rng.integers(-4096, 4096, size=(n, 2), dtype=np.int16)
-    hip.IIR.overruns()                                   # whatever earlier tests left
-    monkeypatch.setenv("CLHIP_IIR_POLL_BOUND", "-1")
-    f = hip.IIR(_sos5(orc.IIR(6, 4e6, 50e3)), 1)
-    d = torch.from_numpy(x.copy()).to(G.DEV)
-    f.run(d, n)
-    torch.cuda.synchronize()
-    assert hip.IIR.overruns() > 0
-    assert hip.IIR.overruns() == 0                       # read-and-reset
-    monkeypatch.delenv("CLHIP_IIR_POLL_BOUND")
-    f = hip.IIR(_sos5(orc.IIR(6, 4e6, 50e3)), 1)
-    d = torch.from_numpy(x.copy()).to(G.DEV)
-    f.run(d, n)
-    torch.cuda.synchronize()
-    assert hip.IIR.overruns() == 0
+    n1, n2 = 37 * 4096 + 5, 600 * 4096 + 123
+    x = rng.integers(-4096, 4096, size=(n1 + n2, 2), dtype=np.int16)
+    sos = _sos5(orc.IIR(6, 4e6, 50e3))
     want = orc.IIR(6, 4e6, 50e3).apply_cs16(x.copy())
-    diff = np.abs(d.cpu().numpy().astype(np.int32) - want.astype(np.int32))
+    f, other = hip.IIR(sos, 1), hip.IIR(sos, 1)
+    d = torch.from_numpy(x.copy()).to(G.DEV)
+    out = torch.zeros_like(d)
+    f.run(d, n1, out=out)                                 # a good first call: the state is no longer at rest
+    other.run(d, n1, out=torch.empty_like(d))
+    torch.cuda.synchronize()
+    assert f.status() == 0 and other.status() == 0 and not f.on_scan_path()
+    st0 = f.state.copy()
+    assert np.abs(st0).max() > 0
+    # forced overrun, out of place
+    f.set_poll_bound(-1)
+    f.run(d[n1:], n2, out=out[n1:])
+    torch.cuda.synchronize()
+    assert other.status() == 0                            # not the other object's business
+    assert f.finish() == 1                                # overran -> rolled back -> repeated on the scan path
+    assert f.on_scan_path() and f.status() == 0
+    got = out.cpu().numpy()
+    diff = np.abs(got.astype(np.int32) - want.astype(np.int32))
     assert diff.max() <= 1 and np.mean(diff != 0) < 1e-4, (diff.max(), np.mean(diff != 0))
+    assert np.all(np.isfinite(f.state))
+    # forced overrun, in place: the verdict, the restored state, and the repeat is the caller's
+    g = hip.IIR(sos, 1)
+    g.run(d, n1, out=out)
+    torch.cuda.synchronize()
+    assert g.status() == 0 and np.array_equal(g.state, st0)
+    g.set_poll_bound(-1)
+    e = d[n1:].clone()
+    g.run(e, n2)
+    torch.cuda.synchronize()
+    assert g.finish() == -1 and np.array_equal(g.state, st0) and g.on_scan_path()
+    e.copy_(d[n1:])                                       # re-produce the input
+    g.run(e, n2)
+    assert g.finish() == 0
+    diff = np.abs(e.cpu().numpy().astype(np.int32) - want[n1:].astype(np.int32))
+    assert diff.max() <= 1 and np.mean(diff != 0) < 1e-4
+    # an unconsulted overrun is refused by the next run instead of silently chaining garbage
+    h = hip.IIR(sos, 1)
+    h.set_poll_bound(-1)
+    h.run(d, n2, out=out)
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError):
+        h.run(d, n2, out=out)
+
+
+@pytest.mark.parametrize("seg", [16, 32, 64])
+@pytest.mark.parametrize("dynamic", [1, 0])
+def test_iir_every_segment_length_and_tile_order(G, orc, seg, dynamic, monkeypatch):
+    """The single-pass kernel's three segment lengths (16 / 32 / 64 samples per lane, picked from the call's size) and
+    both tile orders (a ticket per tile / a rank per wave), forced here: three streams, a ragged tail, a second call
+    from the carried state, the narrowest reference filter where its horizon fits (fc = 10 kHz at 16-sample segments
+    would need 40 predecessor tiles: it takes 32) -- all against the sequential fp64 oracle."""
+    if os.environ.get("CLHIP_IIR_ONEPASS") == "0":
+        pytest.skip("the A/B switch in force replaces the single-pass kernel")
+    import torch
+    from cariboulite_amd import hip
+    monkeypatch.setenv("CLHIP_IIR_SEG", str(seg))
+    monkeypatch.setenv("CLHIP_IIR_DYNAMIC", str(dynamic))
+    rng = np.random.default_rng(seg + dynamic)
+    ns, n1, n2 = 3, 70 * 32 * seg + 3 * seg + 5, 9 * 32 * seg + 17
+    x = rng.integers(-4096, 4096, size=(ns, n1 + n2, 2), dtype=np.int16)
+    for fc in (50e3, 25e3, 10e3):
+        f = hip.IIR(_sos5(orc.IIR(6, 4e6, fc)), ns)
+        d = torch.from_numpy(x.copy()).to(G.DEV)
+        f.run(d, n1, stride=n1 + n2)
+        f.run(d[:, n1:], n2, stride=n1 + n2)
+        assert f.finish() == 0
+        got = d.cpu().numpy()
+        assert not f.on_scan_path()                        # (fc = 10 kHz at 16-sample segments: that CALL took the scan, the object did not switch)
+        for s in range(ns):
+            want = orc.IIR(6, 4e6, fc).apply_cs16(x[s].copy())
+            diff = np.abs(got[s].astype(np.int32) - want.astype(np.int32))
+            assert diff.max() <= 1 and np.mean(diff != 0) < 1e-4, (fc, s, diff.max(), np.mean(diff != 0))
 
 
 @pytest.mark.parametrize("order", [4, 6, 8])
@@ -469,8 +528,7 @@ def test_iir_sections_with_general_numerators(G, orc, order):
     d = torch.from_numpy(x.copy()).to(G.DEV)
     f.run(d, n1)
     f.run(d[n1:], n2)                                    # carried state, ragged tails
-    torch.cuda.synchronize()
-    assert hip.IIR.overruns() == 0
+    assert f.finish() == 0
     want = oracle_filter().apply_cs16(x.copy())
     diff = np.abs(d.cpu().numpy().astype(np.int32) - want.astype(np.int32))
     assert diff.max() <= 1 and np.mean(diff != 0) < 1e-4, (diff.max(), np.mean(diff != 0))

@@ -158,26 +158,90 @@ def test_iir_via_set_bandwidth_state_persists(S, orc):
     sdr.close()
 
 
-def test_iir_overrun_fails_the_read_instead_of_handing_out_samples(S, orc, monkeypatch):
-    """A bounded poll of the single-pass IIR kernel that gives up (forced here with a negative bound) must not reach the
-    client as samples: readStream squashes it to 0 like every other read error (CaribouliteStream.cpp:266-276) and the
-    device says why."""
+def test_iir_overrun_is_repaired_inside_the_read(S, orc):
+    """A bounded poll of the single-pass IIR kernel that gives up (forced here with a negative bound on this stream's
+    filters) must not reach the client as samples, and must not poison the filter either: the reference's filter state
+    lives as long as the Stream (CaribouliteStream.cpp:84-91).  The read repeats the call on the scan path from the
+    unfiltered samples it still holds (the filter runs out of place) and delivers; the counter says it happened; the
+    following reads continue from the right state."""
     if os.environ.get("CLHIP_IIR_ONEPASS") == "0":
         pytest.skip("the A/B switch in force replaces the single-pass kernel whose polls this test forces to give up")
     from cariboulite_amd import synth
     sdr = S.Device(dict(driver="Cariboulite", channel="S1G"))
     rx = sdr.setupStream(S.SOAPY_SDR_RX, S.SOAPY_SDR_CS16)
     sdr.setBandwidth(S.SOAPY_SDR_RX, 0, 90e3)
-    K = 16                                                        # CS16 reads are not clamped to the MTU: 512 tiles in one launch
-    b, _, _ = synth.smi_stream_bytes((K + 1) * MTU, 0, stream=12)
+    K = 16                                                        # CS16 reads are not clamped to the MTU
+    b, i, q = synth.smi_stream_bytes((K + 3) * MTU, 0, stream=12)
+    want = orc.IIR(6, 4e6, 50e3).apply_cs16(np.stack([i, q], 1))
     sdr.feedSmiBytes(b)
-    buf = np.zeros((K * MTU, 2), np.int16)
-    monkeypatch.setenv("CLHIP_IIR_POLL_BOUND", "-1")
-    assert sdr.readStream(rx, [buf], K * MTU).ret == 0
-    assert "IIR" in sdr.lastError()
-    monkeypatch.delenv("CLHIP_IIR_POLL_BOUND")
-    assert sdr.readStream(rx, [buf], MTU).ret == MTU              # the next batch is read normally
+    got = []
+    buf = np.zeros((MTU, 2), np.int16)
+    assert sdr.readStream(rx, [buf], MTU).ret == MTU              # a normal read first: the state is not at rest
+    got.append(buf.copy())
+    assert sdr.streamIirOverruns(rx) == 0
+    sdr.setStreamIirPollBound(rx, -1)
+    big = np.zeros((K * MTU, 2), np.int16)
+    assert sdr.readStream(rx, [big], K * MTU).ret == K * MTU      # overran, rolled back, repeated: delivered
+    got.append(big.copy())
+    assert sdr.streamIirOverruns(rx) == 1 and "gave up" in sdr.lastError()
+    for _ in range(2):                                            # the following batches continue from the right state
+        assert sdr.readStream(rx, [buf], MTU).ret == MTU
+        got.append(buf.copy())
+    assert sdr.streamIirOverruns(rx) == 1                         # the filter stays on the scan path: nothing to give up
+    g = np.concatenate(got)
+    d = np.abs(g.astype(np.int32) - want.astype(np.int32))
+    assert d.max() <= 1 and np.mean(d != 0) < 1e-4, (d.max(), np.mean(d != 0))
     sdr.close()
+
+
+def test_two_filtered_streams_one_overruns_the_other_does_not_notice(S, orc):
+    """The board's two channels on one GPU, both with the IIR selected, one thread each (SoapyCariboulite.cpp:46-69).
+    HiF's filters are forced to overrun on every read; S1G's are not.  S1G's samples and carried state must be exact
+    (it never sees HiF's verdicts: the overrun word belongs to the filter object), and HiF's reads -- the overrun one and
+    the ones after it -- equal the oracle too (rollback + repeat on the scan path)."""
+    if os.environ.get("CLHIP_IIR_ONEPASS") == "0":
+        pytest.skip("the A/B switch in force replaces the single-pass kernel whose polls this test forces to give up")
+    import threading
+    from cariboulite_amd import synth
+    n_batches = 8
+    devs = {ch: S.Device(dict(driver="Cariboulite", channel=name)) for ch, name in ((0, "S1G"), (1, "HiF"))}
+    data = {ch: synth.smi_stream_bytes(n_batches * MTU, ch, stream=70 + ch) for ch in (0, 1)}
+    rx, fmt = {}, {0: S.SOAPY_SDR_CS16, 1: S.SOAPY_SDR_CF32}
+    for ch in (0, 1):
+        rx[ch] = devs[ch].setupStream(S.SOAPY_SDR_RX, fmt[ch])
+        devs[ch].setBandwidth(S.SOAPY_SDR_RX, 0, 45e3)            # fc = 25 kHz
+        devs[ch].feedSmiBytes(data[ch][0])
+    devs[1].setStreamIirPollBound(rx[1], -1)
+    got = {0: [], 1: []}
+    errs = []
+
+    def reader(ch):
+        try:
+            for _ in range(n_batches):
+                buf = np.zeros((MTU, 2), np.int16 if ch == 0 else np.float32)
+                r = devs[ch].readStream(rx[ch], [buf], MTU).ret
+                got[ch].append(buf[:r].copy())
+        except Exception as e:                                   # pragma: no cover
+            errs.append(e)
+
+    th = [threading.Thread(target=reader, args=(ch,)) for ch in (0, 1)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join(timeout=120)
+    assert not errs and all(len(got[ch]) == n_batches for ch in (0, 1))
+    assert devs[0].streamIirOverruns(rx[0]) == 0
+    assert devs[1].streamIirOverruns(rx[1]) == 1                  # the first read overran; from then on HiF's filter is on the scan path
+    for ch in (0, 1):
+        want = orc.IIR(6, 4e6, 25e3).apply_cs16(np.stack([data[ch][1], data[ch][2]], 1))
+        g = np.concatenate(got[ch])
+        if ch == 1:
+            assert np.array_equal(g * 4096.0, np.round(g * 4096.0))
+            g = (g * 4096.0).astype(np.int16)
+        d = np.abs(g.astype(np.int32) - want.astype(np.int32))
+        assert g.shape == want.shape and d.max() <= 1 and np.mean(d != 0) < 1e-4, (ch, d.max(), np.mean(d != 0))
+    for ch in (0, 1):
+        devs[ch].close()
 
 
 def test_rx_extension_stages_via_kwargs(S, orc):
