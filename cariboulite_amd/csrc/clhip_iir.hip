@@ -562,7 +562,7 @@ __global__ __launch_bounds__(IIR_TILE) void iir_k3_kernel(const IirPlan *__restr
 }
 
 // ---------------------------------------------------------------------------
-// Single pass (default).  The stream is read ONCE and written once.
+// Single pass (default): one launch, every output written once, every input read once (+ the chunk tails, below).
 //
 // Shape: the two rails of a segment sit on NEIGHBOURING LANES -- lane t = (segment t >> 1, rail t & 1) -- so a lane
 // carries D doubles of state where a lane that owns both rails carries 2D, a tile is 32 segments x SEG samples
@@ -573,24 +573,34 @@ __global__ __launch_bounds__(IIR_TILE) void iir_k3_kernel(const IirPlan *__restr
 //
 // Per tile: coalesced load -> LDS rows -> every segment's zero-state end vector as a SEG-tap matrix FIR (taps by
 // scalar loads, double-buffered in SGPRs) -> Kogge-Stone shuffle scan over the 32 segments with P^(2^d), P = F^SEG ->
-// the tile's zero-carry end vector, its AGGREGATE, published by the last lane pair.  The state entering the tile is
-//     cv = sum_{k=1..H} Q^(k-1) aggregate(tile - k)     (the carried state stands in for tile -1),   Q = P^32
-// where H = the horizon: the number of tiles after which ANY reachable state has decayed below 1e-18 absolute (host:
-// iir_horizon).  So a tile waits for H predecessors' aggregates, never for their prefixes: no chain through the
-// launch.  Lane pair h fetches aggregate(tile-1-h); H <= 6 folds them by Horner, longer horizons (short tiles of a
-// narrow filter) by a log-step tree with Q^(2^d).  Lane start state = exclusive scan value + P^m cv (P^m from a per-
-// segment table), DF-II recursion two samples per cascade pass over the LDS row, coalesced store.
+// lane start state = exclusive scan value + P^m cv (cv = the state entering the tile, P^m from a per-segment table)
+// -> DF-II recursion two samples per cascade pass over the LDS row -> coalesced store.
 //
-// Order and progress: a wave takes its tiles by atomic ticket from one of 64 counters (its class = block index mod
-// 64): tile = class + 64 * ticket.  Same-address atomics retire at ~12 ns each, so one counter would serialise the
-// launch; 64 counters hand out tiles in start order to within a few tiles.  The ticket of the NEXT tile is requested
-// at the top of the current one, so its round trip is never waited for.  A tile's predecessors have smaller indices;
-// the smallest tile nobody has taken is taken as soon as a wave of its class finishes what it holds, and that wave
-// only waits for tiles that HAVE been taken (whose aggregates are published before their owners wait for anything):
-// the launch moves as long as one wave of every class is running -- the first 64 workgroups dispatched -- whatever
-// else shares the GPU, and however many of the launched waves are resident.  Polls are bounded all the same: one
-// that gives up zeroes what it did not get (no NaN reaches the state), raises the object's pinned overrun word and a
-// device-side abort flag that ends every other poll of the launch at once; the host rolls the call back.
+// Ownership: a wave takes CHUNKS of consecutive tiles of one stream (as many as share the call evenly over the
+// resident waves: 8 for 2^26 samples, 1 for a native batch) and walks a chunk in order, so cv of every tile but the
+// chunk's first is simply the state the wave's own recursion has just left in lane pair 31 -- exact, nothing to wait
+// for, no lock step between waves (waves that free-run drift apart, so the loads of one overlap the recursion of
+// another; waves that wait for each other every tile all load, compute and store at the same time).  The state
+// entering a chunk's FIRST tile comes from other waves:
+//     cv = sum_{k=1..H} Q^(k-1) aggregate(tile - k)     (the carried state stands in for tile -1),   Q = P^32
+// where an AGGREGATE is a tile's zero-carry end vector (the scan's last value) and H the horizon: the number of tiles
+// after which ANY reachable state has decayed below 1e-18 absolute (host: iir_rail_tab_build).  Lane pair h fetches
+// aggregate(tile-1-h); H <= 6 folds them by Horner, longer horizons (short tiles of a narrow filter) by a log-step
+// tree with Q^(2^d).  The aggregates a chunk's successor will ask for -- those of the chunk's last H tiles -- are the
+// first thing a wave produces (prologue: load, segment FIR, scan, publish; nothing waited for; the chunk tail is read
+// twice: H / chunk of the input), so a wave that asks finds them there or on their way.
+//
+// Order and progress: chunks are handed out by atomic ticket from one of 64 counters (class = block index mod 64;
+// chunk = class + 64 * ticket; counters 4 KB apart -- atomics to one 256-byte block retire one at a time); the next
+// ticket is requested at the top of a chunk, so its round trip is never waited for.  A chunk's predecessors have
+// smaller indices and every chunk that has been taken publishes without waiting, so the smallest chunk nobody has
+// taken is the only thing the launch can be waiting for, and it is taken as soon as a wave of its class finishes what
+// it holds: the launch moves as long as one wave of every class is running -- the first 64 workgroups dispatched --
+// whatever else shares the GPU and however many of the launched waves are resident.  Polls are bounded all the same:
+// one that gives up zeroes what it did not get (no NaN reaches the state), raises the object's pinned overrun word and
+// a device-side abort flag that ends every other poll of the launch; the host rolls the call back.
+//
+// Priority: waves of a SIMD issue by priority, then age, so four equal shares end far apart (rail_set_priority).
 //
 // Publication: an aggregate is D doubles per rail written with relaxed agent-scope 64-bit atomic stores into slots
 // pre-set to all-ones (a NaN no aggregate can be): a reader polls until none of its D words is the sentinel, so no
@@ -623,6 +633,8 @@ struct IirRailArgs {
     uint32_t *out;
     long stride, n, n_seg, n_tiles;
     int n_streams, horizon;
+    int chunk_tiles;                       // consecutive tiles of one stream a wave takes per ticket
+    long chunks_per_stream;
     unsigned int *ctl;
     unsigned long long *agg;               // this launch's aggregates: [stream][tile][rail][D], all-ones on entry
     unsigned long long *agg_other;         // the other buffer and how much of it the launches before this one used
@@ -630,7 +642,7 @@ struct IirRailArgs {
     const double *state_in;
     double *state_out;
     unsigned int *overrun;                 // the object's pinned host word (device address)
-    int poll_bound, dbg, n_classes, dynamic;
+    int poll_bound, dbg, n_classes, dynamic, prio;
     unsigned long long *stamps;            // diagnostics (CLHIP_IIR_STAMPS=1): [RL_STAMP_WAVES][RL_STAMP_TILES][RL_STAMP_PHASES] of s_memrealtime
 };
 #define RL_STAMP_WAVES 64
@@ -788,6 +800,19 @@ __device__ __forceinline__ void rail_tile_store(uint32_t *__restrict__ x, bool w
     }
 }
 
+// Waves of a SIMD issue by priority, then age: at equal priority the oldest wave of four runs nearly unimpeded and the
+// youngest gets what is left, so equal shares of work end far apart (measured: the first wave of a SIMD leaves after
+// 100 us, the last after 211) and the SIMD spends its last third under-occupied.  A wave therefore lowers its priority as it
+// advances through its share (3 -> 0): whoever is behind issues first, and the four finish together.
+__device__ __forceinline__ void rail_set_priority(int done, int of)
+{
+    const int q = (4 * done) / (of > 0 ? of : 1);
+    if (q <= 0) __builtin_amdgcn_s_setprio(3);
+    else if (q == 1) __builtin_amdgcn_s_setprio(2);
+    else if (q == 2) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+}
+
 __device__ __forceinline__ unsigned rail_tile_of(unsigned cls, unsigned nc, unsigned ticket, unsigned total)
 {
     const unsigned long long t = (unsigned long long)cls + (unsigned long long)nc * ticket;
@@ -801,7 +826,8 @@ __global__ __launch_bounds__(64, RL_WAVES) void iir_rail_kernel(const IirRailArg
     constexpr long TILE = (long)RL_SEGS * SEG;
     extern __shared__ __attribute__((aligned(16))) uint32_t iir_sm[];
     const int t0 = threadIdx.x;
-    const unsigned total = (unsigned)(A.n_tiles * A.n_streams), ns = (unsigned)A.n_streams;    // < 2^31 tiles (host-checked)
+    const unsigned ns = (unsigned)A.n_streams, C = (unsigned)A.chunk_tiles;
+    const unsigned total = (unsigned)A.chunks_per_stream * ns;         // chunks of the launch (< 2^31, host-checked)
     const unsigned NC = (unsigned)A.n_classes;
     const unsigned cls = blockIdx.x & (NC - 1);
 
@@ -812,212 +838,272 @@ __global__ __launch_bounds__(64, RL_WAVES) void iir_rail_kernel(const IirRailArg
         A.stamps[(size_t)RL_STAMP_WAVES * RL_STAMP_TILES * RL_STAMP_PHASES + 3 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
     unsigned int tk = 0;
     if (t0 == 0) tk = atomicAdd(A.ctl + cls * RL_CTL_STRIDE, 1u);
-    // (a ticket beyond the launch's tiles saturates: more tickets than tiles are only ever taken by waves on their way out)
+    // (a ticket beyond the launch's chunks saturates: more tickets than chunks are only ever taken by waves on their way out)
     unsigned T = rail_tile_of(cls, NC, (unsigned)__builtin_amdgcn_readfirstlane((int)tk), total);
     const unsigned NW = gridDim.x;
     constexpr bool PF = RL_PREFETCH && NS < 4;      // (four biquads: the start-state phase needs the registers)
-    u32x4 raw[NLD];
-    if constexpr (PF) {
-        const long b = T / ns, s = T % ns;
-        const uint32_t *xin = A.in + s * A.stride + b * TILE;
-        rail_tile_issue<SEG>(xin, T < total && rail_tile_whole<SEG>(xin, A.out + s * A.stride + b * TILE, A.n - b * TILE), raw, t0);
-    }
     int it = -1;
     while (T < total) {
-        it++;
-        RL_STAMP(0);
-        // per-iteration values stay per-iteration: otherwise the compiler hoists every lane address of the staging
-        // code and every scalar table load out of the persistent loop and spills them
-        int t = t0;
-        const IirRailTab *tab = A.tab;
-        const double *Gp = A.G;
-        asm volatile("" : "+v"(t));
-        asm volatile("" : "+s"(tab), "+s"(Gp));
-        const cdouble_t *pow2 = (const cdouble_t *)&tab->pow2[0][0];
-        const cdouble_t *__restrict__ G = (const cdouble_t *)Gp;
-        const int m = t >> 1, rail = t & 1, sh = rail << 4;
-        const uint32_t sel = rail ? 0x01000504u : 0x05040100u;
-        // the next tile's ticket: back long before it is needed.  (The counter's address goes through a register the
-        // compiler cannot see through: with a uniform address its atomic optimizer rewrites the add as a wave reduction
-        // whose result it broadcasts -- and waits for, with everything else in flight -- right here.)
+        // ---- one chunk: tiles b0..b1 of stream s, taken in order by this wave alone.  The state entering the chunk's
+        // first tile comes from the H tiles before it (other waves' -- their aggregates, below); every later tile starts
+        // from the exact state the wave itself has just left.  The aggregates the NEXT chunk's owner will look for, those of
+        // this chunk's last H tiles, are made first of all (prologue: load, segment FIR, scan, publish -- nothing waited
+        // for), so that nobody ever waits long for them.
         unsigned int tkn = 0;
         {
             uintptr_t ca = (uintptr_t)(A.ctl + cls * RL_CTL_STRIDE);
             asm volatile("" : "+v"(ca));
-            if (A.dynamic && t == 0)
+            // the next chunk's ticket: back long before it is needed.  (The counter's address goes through a register the
+            // compiler cannot see through: with a uniform address its atomic optimizer rewrites the add as a wave reduction
+            // whose result it broadcasts -- and waits for, with everything else in flight -- right here.)
+            if (A.dynamic && t0 == 0)
                 tkn = __hip_atomic_fetch_add((__attribute__((address_space(1))) unsigned int *)ca, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-
-        const long b = T / ns, s = T % ns;
-        const long tile0 = b * TILE;
-        const uint32_t *xin = A.in + s * A.stride + tile0;
-        uint32_t *xout = A.out + s * A.stride + tile0;
-        const bool whole = rail_tile_whole<SEG>(xin, xout, A.n - tile0);
-        if constexpr (!PF) rail_tile_issue<SEG>(xin, whole, raw, t);
-        rail_tile_commit<SEG>(xin, whole, A.n - tile0, raw, iir_sm, t);
-        __syncthreads();
-        RL_STAMP(1);
-        uint32_t *x = iir_sm + m * PITCH;
-        double v[D];
-#pragma unroll
-        for (int k = 0; k < D; k++) v[k] = 0.0;
-        if (!(A.dbg & 4)) rail_segment_fir<D, SEG>(v, x, G, sh);
-        RL_STAMP(2);
-        if (!(A.dbg & 8)) {
-            // Kogge-Stone over the 32 segments of the rail: v_m <- v_m + P^(2^d) v_(m - 2^d)
-#pragma unroll 1
-            for (int d = 0; d < 5; d++) {
-                double pv[D];
-#pragma unroll
-                for (int k = 0; k < D; k++) pv[k] = __shfl_up(v[k], 2 << d, 64);
-                if (m >= (1 << d)) matvec<D, true>(pow2 + d * IIR_MSZ, pv, v);
-            }
+        const long s = T % ns;
+        const long b0 = (long)(T / ns) * C;
+        const long b1 = (b0 + C < A.n_tiles ? b0 + C : A.n_tiles) - 1;
+        const int H = A.horizon;
+        // prologue tiles: those of the chunk's last H that come after its first tile (the stream's last chunk has no
+        // successor: none); the first tile, when it is among the last H (chunks no longer than the horizon -- small
+        // calls: one tile per wave), publishes in its own full pass, before it waits for anything
+        const bool has_succ = b1 + 1 < A.n_tiles;
+        const long pa = b1 + 1 - H > b0 + 1 ? b1 + 1 - H : b0 + 1;     // first prologue tile
+        const int np = has_succ && pa <= b1 ? (int)(b1 - pa + 1) : 0;
+        const bool first_publishes = has_succ && b0 >= b1 + 1 - H;
+        const uint32_t *sin = A.in + s * A.stride;
+        uint32_t *sout = A.out + s * A.stride;
+        u32x4 raw[NLD];
+        auto tile_whole = [&](long b) { return rail_tile_whole<SEG>(sin + b * TILE, sout + b * TILE, A.n - b * TILE); };
+        if constexpr (PF) {
+            const long b = np ? pa : b0;
+            rail_tile_issue<SEG>(sin + b * TILE, tile_whole(b), raw, t0);
         }
-        RL_STAMP(3);
-        unsigned long long *mine = A.agg + ((s * A.n_tiles + b) * 2 + rail) * D;
-        if (m == RL_SEGS - 1 && !(A.dbg & 32)) {
-#pragma unroll
-            for (int k = 0; k < D; k++)
-                __hip_atomic_store(mine + k, __builtin_bit_cast(unsigned long long, v[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        RL_STAMP(4);
-        // state entering the tile
-        double cv[D];
-        {
-            const int H = A.horizon;
-            const long j = b - 1 - m;                                  // lane pair m looks at tile b-1-m; tile -1 = the carried state
-            const bool want = m < H && j >= -1;
-            double a[D];
-#pragma unroll
-            for (int k = 0; k < D; k++) a[k] = 0.0;
-            // (the carried state is read like an aggregate that is already there: one code path, one wait)
-            bool pending = want && !(A.dbg & 1);
-            const unsigned long long *theirs = j >= 0 ? A.agg + ((s * A.n_tiles + j) * 2 + rail) * D
-                                                      : (const unsigned long long *)(A.state_in + s * 2 * IIR_MAX_DIM + rail * IIR_MAX_DIM);
-            int guard = 0;
-            while (__any(pending)) {
-                if (pending) {
-                    // the D stores land in any order: take all of them every time and check each (one round trip through
-                    // the fabric per poll, the abort flag rides along)
-                    bool ok = true;
-#pragma unroll
-                    for (int k = 0; k < D; k++) {
-                        const unsigned long long w = __hip_atomic_load(theirs + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        ok &= w != IIR_SENTINEL;
-                        a[k] = __builtin_bit_cast(double, w);
-                    }
-                    // (the abort flag is ONE word for the whole launch: looked at on every poll by every waiting lane it
-                    // becomes the hottest address of the chip -- measured: 0.29 ms of a 0.52 ms launch; a healthy wait ends
-                    // within a few polls and never looks)
-                    unsigned ab = 0;
-                    if (!ok && (guard & 255) == 255) ab = __hip_atomic_load(A.ctl + RL_CTL_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (ok && A.poll_bound >= 0) pending = false;
-                    else if (ab || ++guard > A.poll_bound) {
-                        // gave up: the call is void (the host rolls it back), nothing undefined may travel on
-#pragma unroll
-                        for (int k = 0; k < D; k++) a[k] = 0.0;
-                        __hip_atomic_store(A.ctl + RL_CTL_ABORT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_fetch_add(A.overrun, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        pending = false;
-                    }
-                }
-                if (__any(pending)) __builtin_amdgcn_s_sleep(2);
+        // rows <- tile b; v <- after the scan, the state the lane's segment leaves when the tile is entered at rest.
+        // bn (when have_next) is the tile the NEXT step works on: a prologue step requests its words as soon as its own
+        // have left the registers.
+        auto rows_fir_scan = [&](long b, bool have_next, long bn, bool issue_next_now, int t, const cdouble_t *G, const cdouble_t *pow2, double (&v)[D]) {
+            const int m = t >> 1, sh = (t & 1) << 4;
+            const uint32_t *xin = sin + b * TILE;
+            const bool whole = tile_whole(b);
+            if constexpr (!PF) rail_tile_issue<SEG>(xin, whole, raw, t);
+            rail_tile_commit<SEG>(xin, whole, A.n - b * TILE, raw, iir_sm, t);
+            __syncthreads();
+            if constexpr (PF) {
+                if (issue_next_now) rail_tile_issue<SEG>(sin + bn * TILE, have_next && tile_whole(bn), raw, t);
             }
-            RL_STAMP(5);
-            if (H <= RL_HORNER_MAX) {
-                // cv = a_0 + Q (a_1 + Q (a_2 + ...)), the pair's vector broadcast by one shuffle per word
-                const cdouble_t *qm = pow2 + 5 * IIR_MSZ;
+            RL_STAMP(1);
 #pragma unroll
-                for (int k = 0; k < D; k++) cv[k] = 0.0;
-                for (int h = H - 1; h >= 0; h--) {                     // uniform
-                    double nx[D];
-#pragma unroll
-                    for (int k = 0; k < D; k++) nx[k] = __shfl(a[k], 2 * h + rail, 64);
-                    matvec<D, true>(qm, cv, nx);
-#pragma unroll
-                    for (int k = 0; k < D; k++) cv[k] = nx[k];
-                }
-            } else {
-                // sum_h Q^h a_h by a log-step tree: a_h <- a_h + Q^(2^d) a_(h + 2^d); pair 0 ends with the sum
+            for (int k = 0; k < D; k++) v[k] = 0.0;
+            if (!(A.dbg & 4)) rail_segment_fir<D, SEG>(v, iir_sm + m * PITCH, G, sh);
+            RL_STAMP(2);
+            if (!(A.dbg & 8)) {
+                // Kogge-Stone over the 32 segments of the rail: v_m <- v_m + P^(2^d) v_(m - 2^d)
 #pragma unroll 1
                 for (int d = 0; d < 5; d++) {
                     double pv[D];
 #pragma unroll
-                    for (int k = 0; k < D; k++) pv[k] = __shfl_down(a[k], 2 << d, 64);
-                    if (m + (1 << d) < RL_SEGS) matvec<D, true>(pow2 + (5 + d) * IIR_MSZ, pv, a);
-                }
-#pragma unroll
-                for (int k = 0; k < D; k++) cv[k] = __shfl(a[k], rail, 64);
-            }
-        }
-        RL_STAMP(6);
-        // the lane's true start state: what the segments before it left (zero carry) + P^m cv.  P^m for the lane's segment
-        // comes from a per-segment table by 8-byte loads (12 KB, stays in L2), issued here and not before the wait: at four
-        // waves per SIMD the other waves cover the round trip, and the D (D + 2) registers are free during the wait.
-        // Four biquads take the rows in two halves (80 registers of table entries would not fit beside the state).
-        double z[D];
-        if (A.dbg & 16) {
-#pragma unroll
-            for (int r = 0; r < D; r++) z[r] = v[r] + cv[r];
-        } else {
-            const gdouble_t *pt = (const gdouble_t *)&tab->ptab[0][0] + m;
-            constexpr int RCH = NS < 4 ? D : D / 2;
-#pragma unroll
-            for (int r0 = 0; r0 < D; r0 += RCH) {
-                double pe[RCH][D];
-#pragma unroll
-                for (int r = 0; r < RCH; r++)
-#pragma unroll
-                    for (int cc = 0; cc < D; cc++)
-                        if (iir_mat_nonzero(r0 + r, cc)) pe[r][cc] = pt[((r0 + r) * IIR_MAX_DIM + cc) * RL_SEGS];
-#pragma unroll
-                for (int r = 0; r < RCH; r++) {
-                    const double p = __shfl_up(v[r0 + r], 2, 64);
-                    double st = m == 0 ? 0.0 : p;
-#pragma unroll
-                    for (int cc = 0; cc < D; cc++)
-                        if (iir_mat_nonzero(r0 + r, cc)) st = __builtin_fma(pe[r][cc], cv[cc], st);
-                    z[r0 + r] = st;
-                }
-                if (r0 + RCH < D) {
-#pragma unroll
-                    for (int r = 0; r < RCH; r++) asm volatile("" : "+v"(z[r0 + r]));
-                    asm volatile("" ::: "memory");
+                    for (int k = 0; k < D; k++) pv[k] = __shfl_up(v[k], 2 << d, 64);
+                    if (m >= (1 << d)) matvec<D, true>(pow2 + d * IIR_MSZ, pv, v);
                 }
             }
-        }
-        // the start states are complete (and the P^m entries dead) before the prefetch registers fill
+            RL_STAMP(3);
+        };
+        auto publish = [&](long b, int t, const double (&v)[D]) {
+            if ((t >> 1) == RL_SEGS - 1 && !(A.dbg & 32)) {
+                unsigned long long *mine = A.agg + ((s * A.n_tiles + b) * 2 + (t & 1)) * D;
 #pragma unroll
-        for (int k = 0; k < D; k++) asm volatile("" : "+v"(z[k]));
-        asm volatile("" ::: "memory");
-        RL_STAMP(7);
-        // the next tile: its index is known by now, its words go out and land while the recursion (the longest phase) runs
-        const unsigned Tn = A.dynamic ? rail_tile_of(cls, NC, (unsigned)__builtin_amdgcn_readfirstlane((int)tkn), total) : T + NW;
-        if constexpr (PF) {
-            const long bn = Tn / ns, sn = Tn % ns;
-            const uint32_t *xn = A.in + sn * A.stride + bn * TILE;
-            rail_tile_issue<SEG>(xn, Tn < total && rail_tile_whole<SEG>(xn, A.out + sn * A.stride + bn * TILE, A.n - bn * TILE), raw, t);
-        }
-        RL_STAMP(8);
-        const long seg = b * RL_SEGS + m;
-        if (seg < A.n_seg && !(A.dbg & 2)) {
-            if (tile0 + TILE <= A.n) rail_recursion<NS, SEG, true, B121>(A.c, x, SEG, z, sh, sel, rail);
-            else {
-                const long cnt = A.n - seg * SEG < SEG ? A.n - seg * SEG : SEG;
-                rail_recursion<NS, SEG, false, B121>(A.c, x, cnt, z, sh, sel, rail);
+                for (int k = 0; k < D; k++)
+                    __hip_atomic_store(mine + k, __builtin_bit_cast(unsigned long long, v[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            if (seg == A.n_seg - 1) {
-                double *so = A.state_out + s * 2 * IIR_MAX_DIM + rail * IIR_MAX_DIM;
+        };
+        // ---- prologue
+        const int nsteps = np + (int)(b1 - b0 + 1);
+#pragma unroll 1
+        for (int i = 0; i < np; i++) {
+            it++;
+            if (A.prio) rail_set_priority(i, nsteps);
+            RL_STAMP(0);
+            int t = t0;
+            const IirRailTab *tab = A.tab;
+            const double *Gp = A.G;
+            asm volatile("" : "+v"(t));
+            asm volatile("" : "+s"(tab), "+s"(Gp));
+            const long b = pa + i, bn = i + 1 < np ? b + 1 : b0;
+            double v[D];
+            rows_fir_scan(b, true, bn, true, t, (const cdouble_t *)Gp, (const cdouble_t *)&tab->pow2[0][0], v);
+            publish(b, t, v);
+            RL_STAMP(4); RL_STAMP(5); RL_STAMP(6); RL_STAMP(7); RL_STAMP(8); RL_STAMP(9);
+            __syncthreads();                                           // (single wave: orders this step's row reads before the next commit)
+            RL_STAMP(10);
+        }
+        // ---- the chunk's tiles in order
+        double zend[D];                                 // the state the wave's previous tile left (lane pair 31's, after its recursion)
 #pragma unroll
-                for (int k = 0; k < D; k++) so[k] = z[k];
+        for (int k = 0; k < D; k++) zend[k] = 0.0;
+#pragma unroll 1
+        for (long b = b0; b <= b1; b++) {
+            it++;
+            if (A.prio) rail_set_priority(np + (int)(b - b0), nsteps);
+            RL_STAMP(0);
+            // per-iteration values stay per-iteration: otherwise the compiler hoists every lane address of the staging
+            // code and every scalar table load out of the persistent loop and spills them
+            int t = t0;
+            const IirRailTab *tab = A.tab;
+            const double *Gp = A.G;
+            asm volatile("" : "+v"(t));
+            asm volatile("" : "+s"(tab), "+s"(Gp));
+            const cdouble_t *pow2 = (const cdouble_t *)&tab->pow2[0][0];
+            const int m = t >> 1, rail = t & 1, sh = rail << 4;
+            const uint32_t sel = rail ? 0x01000504u : 0x05040100u;
+            const long tile0 = b * TILE;
+            uint32_t *xout = sout + tile0;
+            const bool whole = tile_whole(b);
+            uint32_t *x = iir_sm + m * PITCH;
+            const bool have_next = b < b1;
+            const long bn = have_next ? b + 1 : b;
+            double v[D];
+            rows_fir_scan(b, have_next, bn, false, t, (const cdouble_t *)Gp, pow2, v);
+            if (b == b0 && first_publishes) publish(b, t, v);
+            RL_STAMP(4);
+            // state entering the tile
+            double cv[D];
+            if (b == b0) {
+                const long j = b - 1 - m;                              // lane pair m looks at tile b-1-m; tile -1 = the carried state
+                const bool want = m < H && j >= -1;
+                double a[D];
+#pragma unroll
+                for (int k = 0; k < D; k++) a[k] = 0.0;
+                // (the carried state is read like an aggregate that is already there: one code path, one wait)
+                bool pending = want && !(A.dbg & 1);
+                const unsigned long long *theirs = j >= 0 ? A.agg + ((s * A.n_tiles + j) * 2 + rail) * D
+                                                          : (const unsigned long long *)(A.state_in + s * 2 * IIR_MAX_DIM + rail * IIR_MAX_DIM);
+                int guard = 0;
+                while (__any(pending)) {
+                    if (pending) {
+                        // the D stores land in any order: take all of them every time and check each (one round trip through
+                        // the fabric per poll)
+                        bool ok = true;
+#pragma unroll
+                        for (int k = 0; k < D; k++) {
+                            const unsigned long long w = __hip_atomic_load(theirs + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            ok &= w != IIR_SENTINEL;
+                            a[k] = __builtin_bit_cast(double, w);
+                        }
+                        // (the abort flag is ONE word for the whole launch: looked at on every poll by every waiting lane it
+                        // becomes the hottest address of the chip -- measured: 0.29 ms of a 0.52 ms launch; a healthy wait ends
+                        // within a few polls and never looks)
+                        unsigned ab = 0;
+                        if (!ok && (guard & 255) == 255) ab = __hip_atomic_load(A.ctl + RL_CTL_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (ok && A.poll_bound >= 0) pending = false;
+                        else if (ab || ++guard > A.poll_bound) {
+                            // gave up: the call is void (the host rolls it back), nothing undefined may travel on
+#pragma unroll
+                            for (int k = 0; k < D; k++) a[k] = 0.0;
+                            __hip_atomic_store(A.ctl + RL_CTL_ABORT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_fetch_add(A.overrun, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            pending = false;
+                        }
+                    }
+                    if (__any(pending)) __builtin_amdgcn_s_sleep(2);
+                }
+                RL_STAMP(5);
+                if (H <= RL_HORNER_MAX) {
+                    // cv = a_0 + Q (a_1 + Q (a_2 + ...)), the pair's vector broadcast by one shuffle per word
+                    const cdouble_t *qm = pow2 + 5 * IIR_MSZ;
+#pragma unroll
+                    for (int k = 0; k < D; k++) cv[k] = 0.0;
+                    for (int h = H - 1; h >= 0; h--) {                 // uniform
+                        double nx[D];
+#pragma unroll
+                        for (int k = 0; k < D; k++) nx[k] = __shfl(a[k], 2 * h + rail, 64);
+                        matvec<D, true>(qm, cv, nx);
+#pragma unroll
+                        for (int k = 0; k < D; k++) cv[k] = nx[k];
+                    }
+                } else {
+                    // sum_h Q^h a_h by a log-step tree: a_h <- a_h + Q^(2^d) a_(h + 2^d); pair 0 ends with the sum
+#pragma unroll 1
+                    for (int d = 0; d < 5; d++) {
+                        double pv[D];
+#pragma unroll
+                        for (int k = 0; k < D; k++) pv[k] = __shfl_down(a[k], 2 << d, 64);
+                        if (m + (1 << d) < RL_SEGS) matvec<D, true>(pow2 + (5 + d) * IIR_MSZ, pv, a);
+                    }
+#pragma unroll
+                    for (int k = 0; k < D; k++) cv[k] = __shfl(a[k], rail, 64);
+                }
+            } else {
+                RL_STAMP(5);
+#pragma unroll
+                for (int k = 0; k < D; k++) cv[k] = zend[k];
             }
+            RL_STAMP(6);
+            // the lane's true start state: what the segments before it left (zero carry) + P^m cv.  P^m for the lane's segment
+            // comes from a per-segment table by 8-byte loads (12 KB, stays in L2), issued here and not before the wait: at four
+            // waves per SIMD the other waves cover the round trip, and the D (D + 2) registers are free during the wait.
+            // Four biquads take the rows in two halves (80 registers of table entries would not fit beside the state).
+            double z[D];
+            if (A.dbg & 16) {
+#pragma unroll
+                for (int r = 0; r < D; r++) z[r] = v[r] + cv[r];
+            } else {
+                const gdouble_t *pt = (const gdouble_t *)&tab->ptab[0][0] + m;
+                constexpr int RCH = NS < 4 ? D : D / 2;
+#pragma unroll
+                for (int r0 = 0; r0 < D; r0 += RCH) {
+                    double pe[RCH][D];
+#pragma unroll
+                    for (int r = 0; r < RCH; r++)
+#pragma unroll
+                        for (int cc = 0; cc < D; cc++)
+                            if (iir_mat_nonzero(r0 + r, cc)) pe[r][cc] = pt[((r0 + r) * IIR_MAX_DIM + cc) * RL_SEGS];
+#pragma unroll
+                    for (int r = 0; r < RCH; r++) {
+                        const double p = __shfl_up(v[r0 + r], 2, 64);
+                        double st = m == 0 ? 0.0 : p;
+#pragma unroll
+                        for (int cc = 0; cc < D; cc++)
+                            if (iir_mat_nonzero(r0 + r, cc)) st = __builtin_fma(pe[r][cc], cv[cc], st);
+                        z[r0 + r] = st;
+                    }
+                    if (r0 + RCH < D) {
+#pragma unroll
+                        for (int r = 0; r < RCH; r++) asm volatile("" : "+v"(z[r0 + r]));
+                        asm volatile("" ::: "memory");
+                    }
+                }
+            }
+            // the start states are complete (and the P^m entries dead) before the prefetch registers fill
+#pragma unroll
+            for (int k = 0; k < D; k++) asm volatile("" : "+v"(z[k]));
+            asm volatile("" ::: "memory");
+            RL_STAMP(7);
+            // the next tile's words go out now and land while the recursion (the longest phase) runs
+            if constexpr (PF) rail_tile_issue<SEG>(sin + bn * TILE, have_next && tile_whole(bn), raw, t);
+            RL_STAMP(8);
+            const long seg = b * RL_SEGS + m;
+            if (seg < A.n_seg && !(A.dbg & 2)) {
+                if (tile0 + TILE <= A.n) rail_recursion<NS, SEG, true, B121>(A.c, x, SEG, z, sh, sel, rail);
+                else {
+                    const long cnt = A.n - seg * SEG < SEG ? A.n - seg * SEG : SEG;
+                    rail_recursion<NS, SEG, false, B121>(A.c, x, cnt, z, sh, sel, rail);
+                }
+                if (seg == A.n_seg - 1) {
+                    double *so = A.state_out + s * 2 * IIR_MAX_DIM + rail * IIR_MAX_DIM;
+#pragma unroll
+                    for (int k = 0; k < D; k++) so[k] = z[k];
+                }
+            }
+            // what the tile leaves: lane pair 31's state (only a whole tile has a successor in the chunk)
+#pragma unroll
+            for (int k = 0; k < D; k++) zend[k] = __shfl(z[k], 2 * (RL_SEGS - 1) + rail, 64);
+            RL_STAMP(9);
+            __syncthreads();
+            if (!(A.dbg & 64)) rail_tile_store<SEG>(xout, whole, A.n - tile0, iir_sm, t);
+            __syncthreads();                                           // the rows are free for the next tile
+            RL_STAMP(10);
         }
-        RL_STAMP(9);
-        __syncthreads();
-        if (!(A.dbg & 64)) rail_tile_store<SEG>(xout, whole, A.n - tile0, iir_sm, t);
-        __syncthreads();                                               // the rows are free for the next tile
-        RL_STAMP(10);
-        T = Tn;
+        T = A.dynamic ? rail_tile_of(cls, NC, (unsigned)__builtin_amdgcn_readfirstlane((int)tkn), total) : T + NW;
     }
     if (A.stamps && t0 == 0 && blockIdx.x < RL_STAMP_ALLWAVES) {
         A.stamps[(size_t)RL_STAMP_WAVES * RL_STAMP_TILES * RL_STAMP_PHASES + 3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
@@ -1349,11 +1435,12 @@ extern "C" int clhip_iir_get_state(clhip_iir *f, double *h_state)
 }
 
 // segment length for a call: short segments spread a small call over many waves (one native batch of 131072 samples
-// is 256 tiles at 16-sample segments, 32 at 64) and shorten each wave's serial work fourfold; long ones pay the
-// per-tile scan and look-back least often.  -1 = no single-pass shape for this filter (memory too long): the scan.
+// is 128 tiles at 32-sample segments, 32 at 64) and shorten each wave's serial work; long ones pay the per-tile scan
+// least often (measured, one stream: 2^17 samples 13.6 / 13.1 / 15.3 us at 16 / 32 / 64; 2^26: 0.28 ms at 32, 0.23 at 64).
+// -1 = no single-pass shape for this filter (memory too long): the scan.
 static int iir_pick_shape(const clhip_iir *f, size_t n)
 {
-    static const size_t tiles_max[3] = {1024, 2048, (size_t)-1};
+    static const size_t tiles_max[3] = {64, 2048, (size_t)-1};
     const IirPlan &pl = f->pe->host;
     for (int i = 0; i < 3; i++) {
         if (!pl.rail[i].horizon) continue;
@@ -1422,8 +1509,15 @@ extern "C" int clhip_iir_run(clhip_iir *f, const int16_t *d_in, int16_t *d_out, 
             f->agg_cap = words;
         }
         iir_rail_fn fn = rail_kernel_for(f->n_stages, seg, f->b121);
-        const long total = n_tiles * f->n_streams;
         const int resident = iir_resident_waves(fn, seg);
+        // a wave takes CHUNKS of consecutive tiles of one stream: as many as share the launch evenly over the resident
+        // waves (one native batch: 1; 2^26 samples: 8), so that only a chunk's first tile looks at other waves' work
+        static const int chunk_env = getenv("CLHIP_IIR_CHUNK") ? atoi(getenv("CLHIP_IIR_CHUNK")) : 0;        // experiment knob
+        long chunk = chunk_env > 0 ? chunk_env : (long)clhip_div_up((size_t)(n_tiles * f->n_streams), (size_t)resident);
+        if (chunk > n_tiles) chunk = n_tiles;
+        const long chunks_per_stream = (long)clhip_div_up((size_t)n_tiles, (size_t)chunk);
+        const long total = chunks_per_stream * f->n_streams;
+        if (total >= 0x7fffffffL) { clhip_set_error("clhip_iir_run: call too large"); return -1; }
         const unsigned grid = (unsigned)(total < resident ? total : resident);
         int nc = RL_CLASSES;
         while ((unsigned)nc > grid) nc >>= 1;
@@ -1433,13 +1527,16 @@ extern "C" int clhip_iir_run(clhip_iir *f, const int16_t *d_in, int16_t *d_out, 
         a.in = (const uint32_t *)d_in; a.out = (uint32_t *)d_out;
         a.stride = stride; a.n = n; a.n_seg = n_seg; a.n_tiles = n_tiles;
         a.n_streams = f->n_streams; a.horizon = plan.rail[shape].horizon;
+        a.chunk_tiles = (int)chunk; a.chunks_per_stream = chunks_per_stream;
         a.ctl = f->d_ctl;
         a.agg = f->d_agg[f->acur]; a.agg_other = f->d_agg[f->acur ^ 1]; a.other_words = (long)f->dirty[f->acur ^ 1];
         a.state_in = st_in; a.state_out = st_out;
         a.overrun = f->d_over; a.poll_bound = f->poll_bound; a.dbg = dbg; a.n_classes = nc; a.dynamic = f->dynamic;
         a.stamps = f->d_stamps;
+        static const int prio_env = getenv("CLHIP_IIR_PRIO") ? atoi(getenv("CLHIP_IIR_PRIO")) : 1;       // A/B: 0 = every wave at priority 0
+        a.prio = prio_env && chunk > 1;
         static const int verbose = getenv("CLHIP_IIR_VERBOSE") ? atoi(getenv("CLHIP_IIR_VERBOSE")) : 0;
-        if (verbose) fprintf(stderr, "clhip_iir_run: seg %d tiles %ld grid %u (resident %d) classes %d horizon %d dynamic %d\n", seg, total, grid, resident, nc, a.horizon, a.dynamic);
+        if (verbose) fprintf(stderr, "clhip_iir_run: seg %d tiles %ld chunk %ld chunks %ld grid %u (resident %d) classes %d horizon %d dynamic %d\n", seg, n_tiles * f->n_streams, chunk, total, grid, resident, nc, a.horizon, a.dynamic);
         hipLaunchKernelGGL(fn, dim3(grid), dim3(64), RL_SEGS * (seg + 4) * 4, s, a);
         CLHIP_CHECK_LAUNCH();
         f->dirty[f->acur] = words > f->dirty[f->acur] ? words : f->dirty[f->acur];

@@ -24,14 +24,18 @@ waves = {"waves": int(len(wv)), "start_us_p0_10_50_90_100": q(start), "end_us_p0
          "life_us": q(end - start), "tiles_per_wave_min_mean_max": [int(wv[:, 2].min()), round(float(wv[:, 2].mean()), 2), int(wv[:, 2].max())]}
 names = ["load wait + commit", "segment FIR", "scan", "publish (+P^m issue)", "wait for predecessors", "fold aggregates",
          "start states", "ticket + prefetch issue", "recursion", "store", "(loop)"]
-ok = (st[:, :, 0] > 0) & (st[:, :, 10] > 0)
 d = np.diff(st, axis=2)[:, :, :10] * 10e-3          # us per phase (100 MHz)
+done = (st[:, :, 0] > 0) & (st[:, :, 10] > 0)
+ok = done & (d[:, :, 8] > 0)                        # full steps (a prologue step stops after the scan: no recursion)
+pro = done & ~ok
 res = {}
 for k in range(10):
     v = d[:, :, k][ok]
     res[names[k]] = (round(float(v.mean()), 2), round(float(np.median(v)), 2), round(float(v.max()), 2))
 tile = (st[:, :, 10] - st[:, :, 0])[ok] * 10e-3
-gap = (st[:, 1:, 0] - st[:, :-1, 10])[ok[:, 1:] & ok[:, :-1]] * 10e-3
-print(json.dumps({"n": n, "fc": fc, "waves": waves, "tiles_sampled": int(ok.sum()), "us_per_phase_mean_median_max": res,
+gap = (st[:, 1:, 0] - st[:, :-1, 10])[done[:, 1:] & done[:, :-1]] * 10e-3
+protime = (st[:, :, 10] - st[:, :, 0])[pro] * 10e-3
+print(json.dumps({"n": n, "fc": fc, "waves": waves, "tiles_sampled": int(ok.sum()), "prologue_steps_sampled": int(pro.sum()),
+                  "prologue_step_us_mean": round(float(protime.mean()), 2) if protime.size else None, "us_per_phase_mean_median_max": res,
                   "tile_us_mean": round(float(tile.mean()), 2), "between_tiles_us_mean": round(float(gap.mean()), 2) if gap.size else None,
                   "env": {k: v for k, v in os.environ.items() if k.startswith("CLHIP_")}}, indent=1))
