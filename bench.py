@@ -5,6 +5,10 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Started plainly with --gpus N > 1 (no WORLD_SIZE in the environment) it launches that second form itself: the parent
+touches no GPU (it has not even imported torch), starts torch.distributed.run as a child process on 127.0.0.1 with a
+free port, relays the child's output -- rank 0's JSON line -- and exits with its code.
+
 A "step" is one pass of the hot path over one batch of synthetic SMI bytes that
 is already resident in HBM: ONE launch of the fused kernel (which also verifies the
 sync words of each of the 2048 native 512 KiB chunks, caribou_smi.c:235-292) over a
@@ -23,6 +27,7 @@ is the oracle's fp32 CPU pipe (oracle/cl_oracle.c, "port") on this host's cores.
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -31,7 +36,8 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("OMP_WAIT_POLICY", "active")     # libgomp barriers spin (sandboxed futexes are slow)
 
 import numpy as np  # noqa: E402
-import torch  # noqa: E402
+
+torch = None          # imported by main() once it is clear that THIS process is a rank (the self-launching parent never does)
 
 ALGO_BYTES_PER_SAMPLE = 16.0      # R 4 B + W 8*3/2 B
 FLOP_PER_SAMPLE = 304.0           # 64*2*2 (FIR) + 1.5*8*2*2 (3/2 polyphase)
@@ -56,7 +62,33 @@ def parse():
                          "per GPU (weak scaling), same JSON shape with their own algorithmic bytes")
     ap.add_argument("--streams", type=int, default=256, help="c4 only: total streams (32 = the share of one GPU of the 8-GPU job)")
     ap.add_argument("--fanout", action="store_true", help="c4 only: rank 0 holds all raw buffers and scatters them over xGMI first")
+    ap.add_argument("--print-launch", action="store_true",
+                    help="with --gpus N > 1 and no WORLD_SIZE: print the launcher command this process would start, and exit")
     return ap.parse_args()
+
+
+def self_launch_argv(n_gpus, argv, port):
+    """The command a plain `python bench.py --gpus N ...` turns itself into: one rank per GPU of this node over
+    torch.distributed.run, rendezvous on 127.0.0.1 (the container's hostname may not resolve)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py")] + list(argv)
+
+
+def self_launch(a):
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    argv = [x for x in sys.argv[1:] if x != "--print-launch"]
+    cmd = self_launch_argv(a.gpus, argv, port)
+    if a.print_launch:
+        print(json.dumps({"argv": cmd, "torch_imported": "torch" in sys.modules,
+                          "hip_imported": "cariboulite_amd.hip" in sys.modules}), flush=True)
+        return 0
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # a child process, never an exec: this process stays the one the caller waits for and times
+    return subprocess.run(cmd, env=env).returncode
 
 
 def cpu_baseline(taps, d_words, budget_s):
@@ -239,6 +271,10 @@ def bench_secondary(a, world, rank, dev, dist, red_dev, arch, taps):
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(a)
+    global torch
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -382,4 +418,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -109,7 +109,13 @@ def build_all(force=False, verbose=False):
     build_hip(force, verbose)
     build_host(force, verbose)
     build_cpp(force, verbose)
-    build_fanout(force, verbose)
+    try:
+        build_fanout(force, verbose)
+    except (subprocess.CalledProcessError, OSError) as e:
+        # only the multi-GPU fan-out (shard.fanout_streams) needs RCCL: a box without its headers or library still gets
+        # the data path; cariboulite_amd.fanout raises ImportError when someone asks for the missing library
+        import warnings
+        warnings.warn(f"libcariboulite_fanout.so not built ({e}); the RCCL fan-out is unavailable")
 
 
 if __name__ == "__main__":

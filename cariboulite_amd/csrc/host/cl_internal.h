@@ -18,23 +18,32 @@
  *                         read() has not been confirmed yet -- they still belong to the FIFO and can be taken back;
  *     [head, head + len)  bytes pending;
  * The RX FIFO lives in pinned host memory: the feeder (or read(fd, ...) itself, cl_smi_feed_reserve / _commit) writes
- * where the DMA engine reads, no staging copy in between.  A move of the buffer (compaction, growth) first waits for
- * the copies in flight (`dma_stream`). */
+ * where the DMA engine reads, no staging copy in between.  Ownership of the buffer's MOVES: only the producer side
+ * (cl_fifo_reserve: compaction, growth) ever moves it, after waiting for the copies in flight (`dma_stream`); one
+ * producer at a time, so a pointer handed out by a reservation stays good until its commit.  The consumer side never
+ * moves it: bytes a reader gives back that do not fit in front of `head` go to the FRONT STASH, a second small buffer
+ * only the consumer touches, which pop drains first and the in-place readers step around (they take the copying route
+ * while it holds anything). */
 typedef struct {
     uint8_t *data;
     size_t cap, keep, head, len;
     int pinned;                  /* hipHostMalloc'ed */
     void *dma_stream[2];         /* streams whose copies read FIFO memory in place (waited for before the buffer moves) */
+    uint8_t *front;              /* front stash: [front_head, front_cap) are pending bytes OLDER than everything in `data` */
+    size_t front_cap, front_head;
 } cl_fifo;
 
 void   cl_fifo_free(cl_fifo *f);
 uint8_t *cl_fifo_reserve(cl_fifo *f, size_t n);              /* room for n more bytes at the tail (may move the buffer) */
 void   cl_fifo_commit(cl_fifo *f, size_t n);
 int    cl_fifo_push(cl_fifo *f, const uint8_t *src, size_t n);
-size_t cl_fifo_pop(cl_fifo *f, uint8_t *dst, size_t n);      /* consume with a copy; dst may be NULL (discard) */
+size_t cl_fifo_pop(cl_fifo *f, uint8_t *dst, size_t n);      /* consume with a copy (front stash first); dst may be NULL (discard) */
 size_t cl_fifo_stage(cl_fifo *f, size_t n, uint8_t **where); /* take up to n bytes IN PLACE: they stay owned until confirmed */
 void   cl_fifo_confirm(cl_fifo *f, size_t n);                /* the oldest n staged bytes are consumed for good */
 void   cl_fifo_unstage(cl_fifo *f, size_t n);                /* the NEWEST n staged bytes are pending again */
+int    cl_fifo_unpop(cl_fifo *f, const uint8_t *src, size_t n);   /* give bytes back at the FRONT of the pending ones; never moves `data` */
+static inline size_t cl_fifo_front_len(const cl_fifo *f) { return f->front_cap - f->front_head; }
+static inline size_t cl_fifo_pending(const cl_fifo *f) { return f->len + cl_fifo_front_len(f); }
 
 #define CL_MAX_CHUNKS_INLINE 64
 
@@ -80,8 +89,9 @@ struct cl_smi {
     int next_slot;
     int ra_pending; size_t ra_samples;     /* between cl_smi_ra_launch and cl_smi_ra_finish */
     int ra_certain, stage_certain;         /* the host has seen the sync pattern at the head of every chunk of the call */
+    size_t inplace_len;                    /* bytes of a one-read() call staged in place on `stream`: confirmed once that stream has been synchronised */
     /* statistics (SURVEY.md section 5 "Metrics"): */
-    uint64_t stat_samples, stat_resyncs, stat_sync_failures;
+    uint64_t stat_samples, stat_resyncs, stat_sync_failures, stat_timeouts, stat_io_errors, stat_written;
     char err[256];
 };
 

@@ -19,6 +19,7 @@ void cl_seterr(char *dst, size_t n, const char *fmt, ...)
 void cl_fifo_free(cl_fifo *f)
 {
     if (f->pinned) clhip_host_free(f->data); else free(f->data);
+    free(f->front);
     memset(f, 0, sizeof *f);
 }
 
@@ -59,15 +60,25 @@ int cl_fifo_push(cl_fifo *f, const uint8_t *src, size_t n)
 
 size_t cl_fifo_pop(cl_fifo *f, uint8_t *dst, size_t n)
 {
+    size_t done = 0;
+    const size_t fl = cl_fifo_front_len(f);
+    if (fl) {                                           /* what a reader gave back is older than anything in `data` */
+        done = n < fl ? n : fl;
+        if (dst) memcpy(dst, f->front + f->front_head, done);
+        f->front_head += done;
+        if (dst) dst += done;
+        n -= done;
+    }
     if (n > f->len) n = f->len;
     if (dst && n) memcpy(dst, f->data + f->head, n);
     if (f->keep == f->head) f->keep += n;               /* nothing staged in front: consumed for good */
     f->head += n; f->len -= n;
-    return n;
+    return done + n;
 }
 
 size_t cl_fifo_stage(cl_fifo *f, size_t n, uint8_t **where)
 {
+    if (cl_fifo_front_len(f)) { *where = NULL; return 0; }   /* older bytes wait in the front stash: callers take the copying route */
     if (n > f->len) n = f->len;
     *where = f->data + f->head;
     f->head += n; f->len -= n;
@@ -82,26 +93,31 @@ void cl_fifo_unstage(cl_fifo *f, size_t n)
     f->head -= n; f->len += n;
 }
 
-/* put bytes back at the FRONT of the pending ones (a batched call read them with a copy and did not consume them) */
-static int cl_fifo_unpop(cl_fifo *f, const uint8_t *src, size_t n)
+/* put bytes back at the FRONT of the pending ones (a batched call read them with a copy and did not consume them).
+ * `data` is never moved or reallocated here: a producer may be writing into a reservation it holds (read(fd) straight
+ * into the pinned buffer, outside the lock), and in-place copies may be reading it.  Bytes that do not fit in front of
+ * `head` go to the front stash. */
+int cl_fifo_unpop(cl_fifo *f, const uint8_t *src, size_t n)
 {
     if (n == 0) return 0;
-    if (f->keep == f->head && f->head >= n) {           /* room in front, nothing staged there */
+    if (!cl_fifo_front_len(f) && f->keep == f->head && f->head >= n) {   /* room in front of `head`, nothing staged there, no older bytes */
         f->head -= n; f->keep = f->head; f->len += n;
         memcpy(f->data + f->head, src, n);
         return 0;
     }
-    /* rebuild: [staged-unconfirmed | src | pending] */
-    const size_t staged = f->head - f->keep, cap = staged + n + f->len + ((size_t)1 << 16);
-    for (int k = 0; k < 2; k++)
-        if (f->dma_stream[k]) clhip_stream_sync(f->dma_stream[k]);
-    uint8_t *p = f->pinned ? (uint8_t *)clhip_host_alloc(cap) : (uint8_t *)malloc(cap);
-    if (!p) return -1;
-    if (staged) memcpy(p, f->data + f->keep, staged);
-    memcpy(p + staged, src, n);
-    if (f->len) memcpy(p + staged + n, f->data + f->head, f->len);
-    if (f->pinned) clhip_host_free(f->data); else free(f->data);
-    f->data = p; f->cap = cap; f->keep = 0; f->head = staged; f->len += n;
+    if (f->keep != f->head) return -1;                  /* staged bytes are older than what is given back: callers confirm or unstage first */
+    if (f->front_head < n) {                            /* grow the stash at its front */
+        const size_t live = cl_fifo_front_len(f);
+        size_t cap = f->front_cap ? f->front_cap : (size_t)1 << 16;
+        while (cap < 2 * (live + n)) cap *= 2;
+        uint8_t *p = (uint8_t *)malloc(cap);
+        if (!p) return -1;
+        if (live) memcpy(p + cap - live, f->front + f->front_head, live);
+        free(f->front);
+        f->front = p; f->front_cap = cap; f->front_head = cap - live;
+    }
+    f->front_head -= n;
+    memcpy(f->front + f->front_head, src, n);
     return 0;
 }
 
@@ -193,19 +209,34 @@ int cl_smi_wait_bytes(cl_smi *dev, long timeout_us)
     if (until.tv_nsec >= 1000000000L) { until.tv_sec++; until.tv_nsec -= 1000000000L; }
     pthread_mutex_lock(&dev->fifo_mu);
     int expired = 0;
-    while (dev->rx.len == 0 && !dev->ahead.valid && !expired)
+    while (cl_fifo_pending(&dev->rx) == 0 && !dev->ahead.valid && !expired)
         expired = pthread_cond_timedwait(&dev->fifo_fed, &dev->fifo_mu, &until) != 0;
-    const int ready = dev->rx.len != 0 || dev->ahead.valid;
+    const int ready = cl_fifo_pending(&dev->rx) != 0 || dev->ahead.valid;
     pthread_mutex_unlock(&dev->fifo_mu);
     return ready;
 }
-size_t cl_smi_pending_bytes(const cl_smi *dev) { return dev->rx.len + (dev->ahead.valid ? dev->ahead.len : 0); }   /* staged ahead = still pending */
+size_t cl_smi_pending_bytes(const cl_smi *dev) { return cl_fifo_pending(&dev->rx) + (dev->ahead.valid ? dev->ahead.len : 0); }   /* staged ahead = still pending */
 void   cl_smi_set_max_read(cl_smi *dev, size_t m) { dev->max_read = m; }
 size_t cl_smi_drain_bytes(cl_smi *dev, uint8_t *b, size_t max) { return cl_fifo_pop(&dev->tx, b, max); }
 void   cl_smi_set_tx_mode(cl_smi *dev, int mode) { dev->tx_mode = mode; }
 size_t cl_smi_get_native_batch_samples(cl_smi *dev) { return dev->native_batch_len / CL_BYTES_PER_SAMPLE; }
 void   cl_smi_set_debug_mode(cl_smi *dev, int mode) { dev->debug_mode = mode; }       /* caribou_smi.c:612-615 */
 const cl_smi_debug_data *cl_smi_get_debug_data(const cl_smi *dev) { return &dev->debug_data; }
+void cl_smi_get_stats(const cl_smi *dev, cl_smi_stats *out)
+{
+    if (!out) return;
+    memset(out, 0, sizeof *out);
+    if (!dev) return;
+    out->samples_read = dev->stat_samples; out->resyncs = dev->stat_resyncs; out->sync_losses = dev->stat_sync_failures;
+    out->timeouts = dev->stat_timeouts; out->io_errors = dev->stat_io_errors; out->samples_written = dev->stat_written;
+}
+/* every read call's return passes through here on its way out */
+static int smi_count(cl_smi *dev, int ret)
+{
+    if (ret == 0) dev->stat_timeouts++;
+    else if (ret == CL_SMI_ERR_IO) dev->stat_io_errors++;
+    return ret;
+}
 
 /* debug modes: one chunk is read and analysed, then the call returns -2 (caribou_smi.c:650-675) */
 static int cl_smi_read_debug(cl_smi *dev, size_t length_samples)
@@ -337,7 +368,9 @@ static long smi_stage_call(cl_smi *dev, size_t length_samples, int *contiguous)
         return CL_SMI_ERR_IO;
     if (left <= dev->native_batch_len && !(dev->max_read && dev->max_read < left)) {
         /* the call is ONE read(): its bytes go to the device straight from the pinned FIFO (no staging copy).  They are
-         * consumed whatever the analysis says (a failed chunk is consumed too, :665-668), and the copy is enqueued
+         * consumed whatever the analysis says (a failed chunk is consumed too, :665-668) -- but only once the copy has
+         * RUN: until the caller has synchronised dev->stream they stay staged (smi_inplace_done), so that a feeder
+         * cannot be handed their memory (an empty FIFO restarts at the front of its buffer).  The copy is enqueued
          * under the FIFO lock: a feeder that must move the buffer waits for this stream first. */
         uint8_t *src = NULL;
         int bad = 0;
@@ -348,8 +381,9 @@ static long smi_stage_call(cl_smi *dev, size_t length_samples, int *contiguous)
         else if (got) {
             dev->stage_certain = cl_smi_head_in_sync(src, got);
             bad = clhip_memcpy_h2d(dev->d_bytes, src, got, dev->stream);
-            if (bad) cl_fifo_unstage(&dev->rx, got); else cl_fifo_confirm(&dev->rx, got);
+            if (bad) cl_fifo_unstage(&dev->rx, got); else dev->inplace_len = got;
         }
+        else if (cl_fifo_front_len(&dev->rx)) bad = 2;                               /* given-back bytes first: the copying loop below */
         pthread_mutex_unlock(&dev->fifo_mu);
         if (bad == 1) return CL_SMI_ERR_IO;
         if (bad == 0) {
@@ -377,6 +411,17 @@ static long smi_stage_call(cl_smi *dev, size_t length_samples, int *contiguous)
     }
     if (dev->n_chunks && clhip_memcpy_h2d(dev->d_bytes, dev->h_stage, stage_off, dev->stream)) return CL_SMI_ERR_IO;
     return (long)read_so_far;
+}
+
+/* dev->stream has been synchronised (or is, here): the bytes a one-read() call staged in place are consumed for good */
+static void smi_inplace_done(cl_smi *dev, int synced)
+{
+    if (!dev->inplace_len) return;
+    if (!synced) clhip_stream_sync(dev->stream);
+    pthread_mutex_lock(&dev->fifo_mu);
+    cl_fifo_confirm(&dev->rx, dev->inplace_len);
+    pthread_mutex_unlock(&dev->fifo_mu);
+    dev->inplace_len = 0;
 }
 
 /* The sync-search results of a staged call are on the host (dev->h_offs): statistics, and the reference's exit
@@ -422,12 +467,15 @@ int cl_smi_read_device_to(cl_smi *dev, int channel, size_t length_samples, int16
         const size_t stride = dev->native_batch_len, total = (j - i - 1) * stride + dev->chunks[j - 1].len;
         if (clhip_smi_find_offsets(dev->d_bytes + c->stage_off, total, stride, stride, (int)(j - i), dev->d_offs + i, dev->stream) ||
             clhip_smi_unpack(channel, dev->d_bytes + c->stage_off, total, stride, stride, (int)(j - i), dev->d_offs + i,
-                             CL_FORMAT_CS16, d_iq + 2 * c->slot0, d_meta ? d_meta + c->slot0 : NULL, dev->stream))
+                             CL_FORMAT_CS16, d_iq + 2 * c->slot0, d_meta ? d_meta + c->slot0 : NULL, dev->stream)) {
+            smi_inplace_done(dev, 0);
             return CL_SMI_ERR_IO;
+        }
         i = j;
     }
-    if (clhip_memcpy_d2h(dev->h_offs, dev->d_offs, dev->n_chunks * 4, dev->stream) || clhip_stream_sync(dev->stream))
-        return CL_SMI_ERR_IO;
+    const int bad_sync = clhip_memcpy_d2h(dev->h_offs, dev->d_offs, dev->n_chunks * 4, dev->stream) || clhip_stream_sync(dev->stream);
+    smi_inplace_done(dev, !bad_sync);
+    if (bad_sync) return CL_SMI_ERR_IO;
     const int v = smi_call_verdict(dev, all_aligned);
     if (v) return v;
     dev->stat_samples += (uint64_t)read_so_far;
@@ -472,6 +520,7 @@ int cl_smi_read_pipe_device(cl_smi *dev, int channel, size_t length_samples, clh
     const int direct = h_out && dev->stage_certain;
     clhip_rx_pipe_set_host_sink(pipe, direct ? h_out : NULL);
     long got = clhip_rx_pipe_run_smi(pipe, dev->d_bytes, 0, total, nb, dev->d_offs, dev->h_offs, NULL, d_out, 0, dev->stream);
+    smi_inplace_done(dev, got >= 0 || got == CL_SMI_ERR_SYNC || got == CL_PIPE_ERR_RESYNC);     /* run_smi synchronises the stream on those returns */
     if (got < 0 && got != CL_SMI_ERR_SYNC && got != CL_PIPE_ERR_RESYNC) return CL_SMI_ERR_IO;
     const int v = smi_call_verdict(dev, NULL);
     if (v) return v;                                           /* -3: pipe and FIFO as the reference leaves them */
@@ -603,6 +652,11 @@ long cl_smi_ra_launch(cl_smi *dev, int channel, size_t length_samples, int16_t *
     }
     if (cl_ensure((void **)&dev->d_offs, &dev->offs_cap, 4, 4, 0) || cl_ensure((void **)&dev->h_offs, &dev->h_offs_cap, 4, 4, 1))
         return CL_SMI_ERR_IO;
+    if (cl_fifo_front_len(&dev->rx)) {
+        /* bytes a batched call gave back wait in the front stash (after a "-3", a ragged call): this call takes the
+         * copying chunk loop -- same chunks, slots and return codes -- and the in-place reader resumes behind it */
+        return smi_count(dev, cl_smi_read_device_to(dev, channel, length_samples, d_iq, NULL, NULL));
+    }
     const size_t cap_read = dev->max_read && dev->max_read < nb ? dev->max_read : nb;
     size_t left = length_samples * CL_BYTES_PER_SAMPLE, read_so_far = 0;
     if (cl_ensure((void **)&dev->chunks, &dev->chunks_cap, left / cap_read + 2, sizeof(cl_chunk), 2)) return CL_SMI_ERR_IO;
@@ -649,6 +703,7 @@ long cl_smi_ra_launch(cl_smi *dev, int channel, size_t length_samples, int16_t *
         if (v) return v;
     }
     dev->stat_samples += read_so_far;
+    if (!read_so_far) dev->stat_timeouts++;
     return (long)read_so_far;
 }
 
@@ -656,7 +711,7 @@ int cl_smi_ra_finish(cl_smi *dev)
 {
     if (!dev->ra_pending) return 0;
     dev->ra_pending = 0;
-    if (clhip_stream_sync(dev->stream)) return CL_SMI_ERR_IO;
+    if (clhip_stream_sync(dev->stream)) return smi_count(dev, CL_SMI_ERR_IO);
     const int v = ra_chunk_verdict(dev);
     if (v) return v;
     dev->stat_samples += dev->ra_samples;
@@ -666,7 +721,7 @@ int cl_smi_ra_finish(cl_smi *dev)
 int cl_smi_read_device_ra(cl_smi *dev, int channel, size_t length_samples, int16_t *d_iq)
 {
     const long exp = cl_smi_ra_launch(dev, channel, length_samples, d_iq);
-    if (exp < 0 || !dev->ra_pending) return (int)exp;
+    if (exp < 0 || !dev->ra_pending) return (int)exp;          /* (both halves count their own exits) */
     return cl_smi_ra_finish(dev);
 }
 
@@ -704,8 +759,8 @@ int cl_smi_read(cl_smi *dev, int channel, cl_sample_complex_int16 *buffer, cl_sa
     if (dev->debug_mode != CL_SMI_DEBUG_NONE) return cl_smi_read_debug(dev, length_samples);
     int ret = cl_smi_read_device(dev, channel, length_samples, metadata != NULL, NULL);
     if (ret == CL_SMI_ERR_SYNC) { cl_smi_copy_out(dev, buffer, metadata, -1); return ret; }
-    if (ret <= 0) return ret;
-    if (cl_smi_copy_out(dev, buffer, metadata, -1)) return CL_SMI_ERR_IO;
+    if (ret <= 0) return smi_count(dev, ret);
+    if (cl_smi_copy_out(dev, buffer, metadata, -1)) return smi_count(dev, CL_SMI_ERR_IO);
     return ret;
 }
 
@@ -715,7 +770,7 @@ int cl_smi_read_to_device(cl_smi *dev, int channel, int16_t *d_iq, uint8_t *d_me
 {
     if (!dev || !d_iq) return CL_SMI_ERR_IO;
     if (dev->debug_mode != CL_SMI_DEBUG_NONE) return cl_smi_read_debug(dev, length_samples);
-    return cl_smi_read_device_to(dev, channel, length_samples, d_iq, d_meta, NULL);
+    return smi_count(dev, cl_smi_read_device_to(dev, channel, length_samples, d_iq, d_meta, NULL));
 }
 
 /* caribou_smi_flush_fifo caribou_smi.c:772-783: drop what the driver FIFO holds (and what was staged ahead of it) */
@@ -724,7 +779,7 @@ int cl_smi_flush_fifo(cl_smi *dev)
     if (!dev) return -1;
     cl_smi_readahead_cancel(dev);
     pthread_mutex_lock(&dev->fifo_mu);
-    cl_fifo_pop(&dev->rx, NULL, dev->rx.len);
+    cl_fifo_pop(&dev->rx, NULL, cl_fifo_pending(&dev->rx));
     pthread_mutex_unlock(&dev->fifo_mu);
     return 0;
 }
@@ -759,6 +814,7 @@ static int smi_write_core(cl_smi *dev, const cl_sample_complex_int16 *h_buffer, 
         written_so_far += cur / CL_BYTES_PER_SAMPLE;            /* :757 */
         left -= cur;                                            /* :758 (ret == len) */
     }
+    dev->stat_written += written_so_far;
     return (int)written_so_far;
 }
 

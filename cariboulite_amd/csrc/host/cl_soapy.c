@@ -33,7 +33,7 @@ struct cl_stream {
     clhip_iir *iir[3];           /* filt20 / filt50 / filt100 (CaribouliteStream.hpp:124-131): state per filter, I and Q rails, never
                                   * reset, not even when the selection changes (CaribouliteStream.cpp:127-141) */
     int16_t *d_filt; size_t filt_cap;    /* the filtered samples: the IIR runs out of place, so a call can be repeated */
-    unsigned long iir_overruns;          /* calls the single-pass kernel gave up on (each was repeated on the scan path) */
+    cl_stream_stats stats;               /* (iir_overruns: calls the single-pass kernel gave up on; each was repeated on the scan path) */
     void *d_conv; size_t conv_cap;       /* converted output / TX input staging (bytes) */
     void *h_conv; size_t h_conv_cap;     /* pinned host mirror */
     cl_dsp_cfg dsp;
@@ -449,7 +449,7 @@ static const int16_t *filter_native(cl_stream *st, const int16_t *d_raw, size_t 
 static int filter_overran(cl_device *dev, cl_stream *st)
 {
     if (st->filter_type == CL_DIGFILT_NONE || clhip_iir_status(st->iir[st->filter_type - 1]) == 0) return 0;
-    st->iir_overruns++;
+    st->stats.iir_overruns++;
     cl_seterr(dev->err, sizeof dev->err, "readStream: %s", clhip_last_error());
     return 1;
 }
@@ -460,10 +460,19 @@ static int read_stream(cl_device *dev, cl_stream *st, void *const *buffs, size_t
 int cl_readStream(cl_device *dev, cl_stream *st, void *const *buffs, size_t numElems, int *flags, long long *timeNs, long timeoutUs)
 {
     (void)flags; (void)timeNs;                         /* never written; timeoutUs only matters in ASYNC mode */
-    return read_stream(dev, st, buffs, numElems, timeoutUs);
+    const int ret = read_stream(dev, st, buffs, numElems, timeoutUs);
+    st->stats.read_calls++;
+    if (ret > 0) st->stats.elements_read += (uint64_t)ret; else if (ret == 0) st->stats.reads_empty++;
+    return ret;
 }
 
-unsigned long cl_stream_iir_overruns(const cl_stream *st) { return st ? st->iir_overruns : 0; }
+void cl_getStreamStats(const cl_device *dev, const cl_stream *st, cl_stream_stats *out)
+{
+    (void)dev;
+    if (!out) return;
+    if (st) *out = st->stats; else memset(out, 0, sizeof *out);
+}
+unsigned long cl_stream_iir_overruns(const cl_stream *st) { return st ? (unsigned long)st->stats.iir_overruns : 0; }
 void cl_stream_set_iir_poll_bound(cl_stream *st, int polls)
 {
     if (st) for (int i = 0; i < 3; i++) clhip_iir_set_poll_bound(st->iir[i], polls);
@@ -610,9 +619,19 @@ static int read_stream(cl_device *dev, cl_stream *st, void *const *buffs, size_t
 
 /* ------------------------------------------------------------------- TX path */
 /* Stream::WriteSamplesGen  CaribouliteStream.cpp:247-258 */
+static int write_stream(cl_device *dev, cl_stream *st, const void *const *buffs, size_t numElems);
+
 int cl_writeStream(cl_device *dev, cl_stream *st, const void *const *buffs, size_t numElems, int *flags, long long timeNs, long timeoutUs)
 {
     (void)flags; (void)timeNs; (void)timeoutUs;
+    const int ret = write_stream(dev, st, buffs, numElems);
+    st->stats.write_calls++;
+    if (ret > 0) st->stats.elements_written += (uint64_t)ret; else if (ret == 0) st->stats.writes_empty++;
+    return ret;
+}
+
+static int write_stream(cl_device *dev, cl_stream *st, const void *const *buffs, size_t numElems)
+{
     if (st->native_dir != CL_SOAPY_SDR_TX) return CL_SOAPY_SDR_NOT_SUPPORTED;       /* :285-288 */
     cl_smi *smi = dev->smi;
     clhip_set_device(smi->device);
@@ -660,6 +679,7 @@ int cl_writeStream(cl_device *dev, cl_stream *st, const void *const *buffs, size
          * write error, CaribouliteStream.cpp:185-194) */
         if (!st->tx_pipe || clhip_tx_pipe_status(st->tx_pipe) == 0) break;
         cl_seterr(dev->err, sizeof dev->err, "writeStream: %s", clhip_last_error());
+        st->stats.tx_overruns++;
         if (attempt) return 0;
     }
     /* caribou_smi_write's chunk loop (caribou_smi.c:738-759) over the packed bytes */

@@ -90,6 +90,8 @@ _SIGS = {
     "cl_setBandwidth": (None, [C.c_void_p, C.c_int, C.c_size_t, C.c_double]),
     "cl_getDigitalFilter": (C.c_int, [C.c_void_p]),
     "cl_stream_iir_overruns": (C.c_ulong, [C.c_void_p]),
+    "cl_getStreamStats": (None, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cl_smi_get_stats": (None, [C.c_void_p, C.c_void_p]),
     "cl_stream_set_iir_poll_bound": (None, [C.c_void_p, C.c_int]),
     "cl_design_lowpass": (C.c_int, [C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p]),
     "cl_design_butter_lowpass": (C.c_int, [C.c_int, C.c_double, C.c_double, C.c_void_p]),
@@ -293,6 +295,17 @@ class Device:
 
     def getDigitalFilter(self):
         return lib().cl_getDigitalFilter(self.h)
+
+    def streamStats(self, st):
+        out = (C.c_uint64 * 8)()
+        lib().cl_getStreamStats(self.h, st, out)
+        return dict(zip(("read_calls", "elements_read", "reads_empty", "iir_overruns", "write_calls", "elements_written",
+                         "writes_empty", "tx_overruns"), [int(v) for v in out]))
+
+    def smiStats(self):
+        out = (C.c_uint64 * 6)()
+        lib().cl_smi_get_stats(self.smi, out)
+        return dict(zip(("samples_read", "resyncs", "sync_losses", "timeouts", "io_errors", "samples_written"), [int(v) for v in out]))
 
     def streamIirOverruns(self, st):
         return lib().cl_stream_iir_overruns(st)

@@ -340,6 +340,17 @@ typedef struct {                /* caribou_smi_debug_data_st (caribou_smi.h:30-3
 } cl_smi_debug_data;
 void    cl_smi_set_debug_mode(cl_smi *dev, int cl_smi_debug_mode);
 const cl_smi_debug_data *cl_smi_get_debug_data(const cl_smi *dev);
+/* counters of the seam: what the reference only logs (cariboulite_radio.c:1276-1283 "SMI reading operation failed" /
+ * "synchronization failed", caribou_smi.c:657-668 "Reading timed-out" / the -3 exit) a caller can now read */
+typedef struct {
+    uint64_t samples_read;       /* samples delivered by read calls (read_so_far summed, caribou_smi.c:677)           */
+    uint64_t resyncs;            /* chunks that came back with a sync offset > 0 (re-sync + extrapolated sample, :319-325,382-389) */
+    uint64_t sync_losses;        /* chunks without sync: the call returned -3 (:665-668)                              */
+    uint64_t timeouts;           /* read calls that found nothing pending ("Reading timed-out", :657-661)             */
+    uint64_t io_errors;          /* calls that returned -1                                                            */
+    uint64_t samples_written;    /* samples packed and queued by write calls (:757)                                   */
+} cl_smi_stats;
+void cl_smi_get_stats(const cl_smi *dev, cl_smi_stats *out);
 /* caribou_smi_get_native_batch_samples caribou_smi.c:765-769 */
 size_t  cl_smi_get_native_batch_samples(cl_smi *dev);
 int     cl_smi_flush_fifo(cl_smi *dev);                /* caribou_smi_flush_fifo :772-783: drop the pending RX bytes */
@@ -428,9 +439,19 @@ int    cl_writeStream(cl_device *dev, cl_stream *stream, const void *const *buff
 /* setBandwidth Cariboulite.cpp:395-417: RX bw < 160 kHz selects the IIR */
 void   cl_setBandwidth(cl_device *dev, int direction, size_t channel, double bw);
 int    cl_getDigitalFilter(const cl_device *dev);
-/* readStream calls of this stream whose IIR launch gave up waiting (clhip_iir_status) and were repeated on the scan
- * path; the test hook hands clhip_iir_set_poll_bound to the stream's three filters */
-unsigned long cl_stream_iir_overruns(const cl_stream *stream);
+/* counters of the stream calls (SURVEY.md section 5 "metrics"): the reference squashes every error to 0 elements
+ * (CaribouliteStream.cpp:185-194,266-276) and prints; here the caller can ask what happened */
+typedef struct {
+    uint64_t read_calls, elements_read;      /* readStream calls / elements they returned                              */
+    uint64_t reads_empty;                    /* readStream calls that returned 0 (timeout, -1, -3: all squashed)       */
+    uint64_t iir_overruns;                   /* reads whose IIR launch gave up waiting and was repeated on the scan path */
+    uint64_t write_calls, elements_written;  /* writeStream calls / elements they consumed                             */
+    uint64_t writes_empty;                   /* writeStream calls that returned 0                                      */
+    uint64_t tx_overruns;                    /* writes whose modulator look-back gave up and was repeated in ticket order */
+} cl_stream_stats;
+void   cl_getStreamStats(const cl_device *dev, const cl_stream *stream, cl_stream_stats *out);
+unsigned long cl_stream_iir_overruns(const cl_stream *stream);         /* = iir_overruns above */
+/* test hook: hands clhip_iir_set_poll_bound to the stream's three filters */
 void   cl_stream_set_iir_poll_bound(cl_stream *stream, int polls);
 
 /* host helper: scipy.signal.firwin(ntaps, cutoff, window="hamming", fs=fs)

@@ -672,3 +672,92 @@ def test_two_devices_two_threads_concurrently(S, orc):
     assert g1.shape == want1.shape and d.max() <= 1 and np.mean(d != 0) < 1e-4
     for ch in (0, 1):
         devs[ch].close()
+
+
+def test_feeder_thread_races_the_in_place_reads(S, orc):
+    """The threading model fifo_mu exists for: a producer (the kernel FIFO's stand-in) feeds while the consumer reads.
+    Every read here is ONE read() that EMPTIES the pinned FIFO and is copied to the device from where it lies; the feeder
+    pushes the next batch the moment the FIFO runs dry -- into the very memory the copy may still be reading if the
+    consumed bytes were released before the copy had run (an empty FIFO restarts at the front of its buffer).  Three
+    read paths: caribou_smi_read's seam (cl_smi_read), readStream CF32 (the chunk-at-a-time reader) and the fused pipe
+    straight from the staged words.  Every batch must equal the oracle's analysis of the bytes that were fed."""
+    import threading
+    import time
+    from cariboulite_amd import synth
+    t = load_golden("taps.npz")
+    n_batches = 40
+    for mode in ("smi_read", "cf32", "pipe"):
+        sdr = S.Device(dict(driver="Cariboulite", channel="S1G"))
+        b, i, q = synth.smi_stream_bytes(n_batches * MTU, 0, stream=30)
+        raw = np.frombuffer(b, dtype=np.uint8) if not isinstance(b, np.ndarray) else b.view(np.uint8)
+        batches = [np.ascontiguousarray(raw[4 * MTU * k: 4 * MTU * (k + 1)]) for k in range(n_batches)]
+        stop = threading.Event()
+
+        def feeder():
+            k = 0
+            while k < n_batches and not stop.is_set():
+                if sdr.pendingSmiBytes() == 0:                  # the moment the FIFO runs dry
+                    sdr.feedSmiBytes(batches[k]); k += 1
+                else:
+                    time.sleep(0)
+
+        th = threading.Thread(target=feeder)
+        got = []
+        if mode == "cf32":
+            rx = sdr.setupStream(S.SOAPY_SDR_RX, S.SOAPY_SDR_CF32)
+        elif mode == "pipe":
+            rx = sdr.setupStream(S.SOAPY_SDR_RX, S.SOAPY_SDR_CF32, args={"FIR": "64:1000000", "RESAMP": "3/2"})
+        th.start()
+        try:
+            deadline = time.time() + 120
+            while len(got) < n_batches and time.time() < deadline:
+                if mode == "smi_read":
+                    ret, iq, _ = sdr.smiRead(0, MTU, want_meta=False)
+                    if ret > 0:
+                        assert ret == MTU
+                        got.append(iq[:MTU].copy())
+                else:
+                    buf = np.zeros((MTU * 3 // 2 + 8, 2), np.float32)
+                    r = sdr.readStream(rx, [buf], MTU).ret
+                    if r > 0:
+                        got.append(buf[:r].copy())
+        finally:
+            stop.set(); th.join(timeout=30)
+        assert len(got) == n_batches, (mode, len(got))
+        g = np.concatenate(got)
+        x = np.stack([i, q], 1)
+        if mode == "smi_read":
+            assert np.array_equal(g, x), mode
+        elif mode == "cf32":
+            assert np.array_equal(g, orc.cs16_to_cf32(x)), mode
+        else:
+            want = orc.Resampler(t["rs_3_2"], 3, 2).f64(orc.FIR(t["fir64_c2"]).f64(orc.cs16_to_cf32(x)))
+            assert g.shape == want.shape and np.max(np.abs(g - want)) <= 1e-5 * np.max(np.abs(want)), mode
+        sdr.close()
+
+
+def test_seam_and_stream_counters(S, orc):
+    """What the reference only prints (cariboulite_radio.c:1276-1283, caribou_smi.c:657-668, CaribouliteStream.cpp:266-276)
+    can be read back: samples, re-syncs, -3 exits and time-outs at the seam; calls, elements and squashed-to-zero calls
+    at the stream."""
+    from cariboulite_amd import synth
+    sdr = S.Device(dict(driver="Cariboulite", channel="S1G"))
+    rx = sdr.setupStream(S.SOAPY_SDR_RX, S.SOAPY_SDR_CS16)
+    buf = np.zeros((MTU, 2), np.int16)
+    assert sdr.readStream(rx, [buf], MTU).ret == 0                       # nothing pending: "Reading timed-out"
+    b, _, _ = synth.smi_stream_bytes(3 * MTU, 0, stream=3)
+    shifted = np.concatenate([np.zeros(6, np.uint8), b[4 * MTU: 8 * MTU - 6]])       # a batch that re-syncs at byte 6
+    garbage = np.zeros(4 * MTU, np.uint8)                                 # a batch without any sync word
+    sdr.feedSmiBytes(np.concatenate([b[: 4 * MTU], shifted, garbage, b[8 * MTU:]]))
+    rets = [sdr.readStream(rx, [buf], MTU).ret for _ in range(4)]
+    assert rets == [MTU, MTU, 0, MTU]
+    assert sdr.readStream(rx, [buf], MTU).ret == 0
+    st, sm = sdr.streamStats(rx), sdr.smiStats()
+    assert st["read_calls"] == 6 and st["elements_read"] == 3 * MTU and st["reads_empty"] == 3 and st["iir_overruns"] == 0
+    assert sm["samples_read"] == 3 * MTU and sm["resyncs"] == 1 and sm["sync_losses"] == 1 and sm["timeouts"] == 2 and sm["io_errors"] == 0
+    tx = S.Device(dict(driver="Cariboulite", channel="HiF"))
+    ts = tx.setupStream(S.SOAPY_SDR_TX, S.SOAPY_SDR_CS16)
+    assert tx.writeStream(ts, [buf], 1000).ret == 1000
+    assert tx.streamStats(ts)["write_calls"] == 1 and tx.streamStats(ts)["elements_written"] == 1000
+    assert tx.smiStats()["samples_written"] == 1000
+    sdr.close(); tx.close()
