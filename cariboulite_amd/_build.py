@@ -55,6 +55,24 @@ def build_hip(force=False, verbose=False):
     return HIP_LIB
 
 
+def build_hip_variant(name, defines, source="clhip_rx_pipe.hip", verbose=False):
+    """A diagnostic build of the shim with one source recompiled under extra -D flags (timing / energy ablations,
+    A/B experiments): abl/<name>/libcariboulite_hip.so, loaded through CLHIP_LIB.  The other objects are the shipped ones."""
+    build_hip(False, verbose)
+    out_dir = os.path.join(ROOT, "abl", name)
+    os.makedirs(out_dir, exist_ok=True)
+    obj = os.path.join(out_dir, source[:-4] + ".o")
+    cmd = [_hipcc(), "-O3", f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
+           "-Wno-unused-but-set-variable", "-fno-slp-vectorize", "-I", INC] + [f"-D{d}" for d in defines] + ["-c", os.path.join(CSRC, source), "-o", obj]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    others = [os.path.join(OBJ, f[:-4] + ".o") for f in sorted(os.listdir(CSRC)) if f.endswith(".hip") and f != source]
+    lib = os.path.join(out_dir, "libcariboulite_hip.so")
+    subprocess.run([_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib, obj] + others, check=True)
+    return lib
+
+
 def build_host(force=False, verbose=False):
     hdir = os.path.join(CSRC, "host")
     if not os.path.isdir(hdir):

@@ -33,6 +33,23 @@ typedef __attribute__((address_space(4))) float cfloat_t;   // constant address 
 #ifndef CLHIP_FFA_DPP
 #define CLHIP_FFA_DPP 0
 #endif
+// Timing / energy ablations of the fused kernel (tools/c2_energy_budget.sh builds one library per mask into abl/ and
+// measures time, socket power and clock of each; RESULTS ARE INVALID for every non-zero mask).  Default 0: nothing of
+// this is compiled into the shipped kernel.
+//   1 no unpack (raw words bit-cast)      2 FIR window from registers, no ds_read_b128      4 one tap per block instead of a
+//   tap window (no scalar tap traffic)    8 no staging ds_write_b128     16 output stores without the LDS transposes
+//   32 no output stores, no transposes    64 no resampler FMAs           128 no input loads
+//   256 no workgroup barriers             512 no FIR FMAs
+#ifndef CLHIP_RX_ABL
+#define CLHIP_RX_ABL 0
+#endif
+// Wave priority by phase: a wave that is moving data (staging, issuing the next tile's loads, second stage, transposes,
+// output stores) issues ahead of the waves of its SIMD that are inside their FIR, so that memory traffic starts as early
+// as it can and flows while others compute.  2 (default): all of those phases at priority 3, the FIR at 0; 1: staging +
+// load issue only; 0: off.  Measured on one box: 0.932-0.937 / 0.935 / 0.917-0.918 ms for 0 / 1 / 2.
+#ifndef CLHIP_RX_PRIO
+#define CLHIP_RX_PRIO 2
+#endif
 // dst[lane] = src[lane + 1] across the whole wave (DPP wave_shl:1, ctrl 0x130); lane 63 keeps its own value
 __device__ __forceinline__ float clhip_wave_shl1(float v)
 {
@@ -132,6 +149,12 @@ __device__ __forceinline__ f32x2 load_sample(const PipeArgs &a, const void *base
     }
 }
 
+#if (CLHIP_RX_ABL & 256)
+#define RX_BARRIER() __builtin_amdgcn_wave_barrier()
+#else
+#define RX_BARRIER() __syncthreads()
+#endif
+
 // acc += x * tap on an (I,Q) pair: one v_pk_fma_f32 (PK) or two v_fmac_f32.
 template <bool PK>
 __device__ __forceinline__ void fma2(f32x2 &acc, const f32x2 x, const float tap)
@@ -150,7 +173,9 @@ __device__ __forceinline__ void convert4(const u32x4 w, f32x2 (&v)[4])
 {
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        if constexpr (KIND == CL_PIPE_IN_SMI_WORDS) {
+        if constexpr ((CLHIP_RX_ABL & 1) != 0) {
+            v[k].x = __builtin_bit_cast(float, w[k] & 0x3fffffffu); v[k].y = v[k].x;
+        } else if constexpr (KIND == CL_PIPE_IN_SMI_WORDS) {
             const int fa = clhip_field_a(w[k]), fb = clhip_field_b(w[k]);
             v[k].x = (float)(HIF ? fb : fa);        // caribou_smi.c:342-378
             v[k].y = (float)(HIF ? fa : fb);
@@ -192,6 +217,8 @@ __device__ __forceinline__ void tile_issue_loads(TileRegs<C, KIND> &r, const voi
             if constexpr (KIND == CL_PIPE_IN_CF32) {
                 r.w[2 * it] = *(const u32x4 *)((const f32x2 *)in + g0 + 4 * grp);
                 r.w[2 * it + 1] = *(const u32x4 *)((const f32x2 *)in + g0 + 4 * grp + 2);
+            } else if constexpr ((CLHIP_RX_ABL & 128) != 0) {
+                r.w[it] = u32x4{(uint32_t)grp, (uint32_t)g0, 3u, 4u};
             } else {
                 r.w[it] = __builtin_nontemporal_load((const u32x4 *)((const uint32_t *)in + g0 + 4 * grp));
             }
@@ -220,8 +247,12 @@ __device__ __forceinline__ void tile_regs_to_lds(const TileRegs<C, KIND> &r, uns
                 f32x2 v[4];
                 convert4<KIND, HIF>(r.w[it], v);
                 f32x4 q0 = {v[0].x, v[0].y, v[1].x, v[1].y}, q1 = {v[2].x, v[2].y, v[3].x, v[3].y};
-                *(f32x4 *)d = q0;
-                *(f32x4 *)(d + 16) = q1;
+                if constexpr ((CLHIP_RX_ABL & 8) != 0) {
+                    asm volatile("" :: "v"(q0), "v"(q1));                    // converted, not written
+                } else {
+                    *(f32x4 *)d = q0;
+                    *(f32x4 *)(d + 16) = q1;
+                }
             }
         }
     }
@@ -335,12 +366,21 @@ __device__ __forceinline__ void fir_tile_ffa(const unsigned char *lds, int t, co
     f32x2 x0[RH], x1[RH];
     // decimated block b holds j = RH*b + jj (window samples 2j, 2j+1 = one ds_read_b128);
     // sample jj meets output u through tap d = (TH - RH*b) + (u - jj)
+#if (CLHIP_RX_ABL & 2)
+#define LOAD_DBLOCK_LDS(B)                                                                  \
+    _Pragma("unroll") for (int jj = 0; jj < RH; jj++) {                                     \
+        f32x4 xx = {(float)t, (float)(B), (float)jj, 1.0f};                                 \
+        asm volatile("" : "+v"(xx));                                                        \
+        x0[jj] = xx.xy; x1[jj] = xx.zw;                                                     \
+    }
+#else
 #define LOAD_DBLOCK_LDS(B)                                                                  \
     _Pragma("unroll") for (int jj = 0; jj < RH; jj++) {                                     \
         const int w = 2 * (RH * (B) + jj);                                                  \
         const f32x4 xx = *(const f32x4 *)(win + w * 8 + (w / R) * 16);                      \
         x0[jj] = xx.xy; x1[jj] = xx.zw;                                                     \
     }
+#endif
 #if CLHIP_FFA_DPP
     // Window block B of lane t is block 0 of lane t + B (lanes own R consecutive outputs and a block is R samples): after
     // block 0 has been read from LDS, every later block arrives from the next lane by a one-lane wave shift
@@ -383,16 +423,27 @@ __device__ __forceinline__ void fir_tile_ffa(const unsigned char *lds, int t, co
         const int base = TH - RH * b;               // d = base + u - jj in [base-RH, base+RH-1]
         float t0[2 * RH], t1[2 * RH], ts[2 * RH];
 #pragma unroll
-        for (int i = 0; i < 2 * RH; i++) { t0[i] = h0[base - RH + i]; t1[i] = h1[base - RH + i]; ts[i] = hs[base - RH + i]; }
+        for (int i = 0; i < 2 * RH; i++) {
+            const int ii = (CLHIP_RX_ABL & 4) ? 0 : i;
+            t0[i] = h0[base - RH + ii]; t1[i] = h1[base - RH + ii]; ts[i] = hs[base - RH + ii];
+        }
 #pragma unroll
         for (int jj = 0; jj < RH; jj++) {
             const f32x2 xs = x0[jj] + x1[jj];
 #pragma unroll
             for (int u = U0; u < RH; u++) {
                 const int i = RH + u - jj;          // d - (base - RH), always in [0, 2RH-1]
-                fma2<C::PK>(Bm[u + 1], x1[jj], t1[i]);
-                if (u >= 0) { fma2<C::PK>(A[u], x0[jj], t0[i]); fma2<C::PK>(Cc[u], xs, ts[i]); }
+                if constexpr ((CLHIP_RX_ABL & 512) != 0) {
+                    if (jj == 0) { Bm[u + 1] += x1[0]; if (u >= 0) { A[u] += x0[0]; Cc[u] += xs; } }     // the window is consumed, the products are not formed
+                } else {
+                    fma2<C::PK>(Bm[u + 1], x1[jj], t1[i]);
+                    if (u >= 0) { fma2<C::PK>(A[u], x0[jj], t0[i]); fma2<C::PK>(Cc[u], xs, ts[i]); }
+                }
             }
+        }
+        if constexpr ((CLHIP_RX_ABL & 512) != 0) {
+#pragma unroll
+            for (int jj = 1; jj < RH; jj++) asm volatile("" :: "v"(x0[jj]), "v"(x1[jj]));
         }
     }
     {   // last block (b = TH/RH): d = u - jj >= 0; taps [0 .. RH-1]
@@ -433,7 +484,7 @@ __device__ __forceinline__ void second_stage(unsigned char *lds, int t, const fl
             if constexpr (C::BSHUF) tslot[wave * 8 + 7] = b_last;      // HF <= 7: slot 7 is free
         }
     }
-    __syncthreads();       // FIR reads of the staged tile are done (its LDS is reused below); tail slots visible
+    RX_BARRIER();          // FIR reads of the staged tile are done (its LDS is reused below); tail slots visible
     if constexpr (HF > 0) {
         const f32x2 *tslot = (const f32x2 *)(lds + C::IN_BYTES);
 #pragma unroll
@@ -465,7 +516,7 @@ __device__ __forceinline__ void second_stage(unsigned char *lds, int t, const fl
                 const int tp = m * M, b = tp / L, p = tp % L;
                 f32x2 sacc = {0.f, 0.f};
 #pragma unroll
-                for (int i = 0; i < KP; i++) fma2<C::PK>(sacc, YY(b - i), rsv[p + i * L]);
+                for (int i = 0; i < ((CLHIP_RX_ABL & 64) ? 1 : KP); i++) fma2<C::PK>(sacc, YY(b - i), rsv[p + i * L]);
                 o[m] = sacc;
             }
         } else {
@@ -506,6 +557,21 @@ __device__ __forceinline__ void store_tile(unsigned char *lds, int t, unsigned c
     constexpr int NJ = (HALF_PIECES + 63) / 64;
     static_assert(32 * PITCH * (C::NT / 64) <= C::IN_BYTES, "per-wave transpose slices must fit the input tile");
     const int lane = t & 63, wave = t >> 6;
+    if constexpr ((CLHIP_RX_ABL & 32) != 0) {
+#pragma unroll
+        for (int k = 0; k < PL; k++) asm volatile("" :: "v"(pc[k]));
+        return;
+    }
+    if constexpr ((CLHIP_RX_ABL & 16) != 0 && !CHECKED) {        // (interior tiles only: edge tiles keep their bounds checks)
+        // the same 1 KiB-contiguous store instructions, fed from the lane's own pieces (wrong data in the right places)
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            unsigned char *hb = outb + (tile_e0 + (long)NOUT * (wave * 64 + h * 32)) * OB + lane * 16;
+#pragma unroll
+            for (int j = 0; j < NJ; j++) __builtin_nontemporal_store(pc[(h * NJ + j) % PL], (f32x4 *)(hb + j * 1024));
+        }
+        return;
+    }
     unsigned char *scr = lds + wave * (32 * PITCH);
     // piece p = lane + 64 j sits at row p / PL, column p % PL of the scratch: divide once, then step
     const int row0 = lane / PL, col0 = lane % PL;
@@ -632,6 +698,23 @@ __device__ __forceinline__ void rx_pipe_edge_worker(const PipeArgs &a, unsigned 
 // into registers while the current one computes, so HBM latency hides under the FIR.
 // One kernel per (config, input kind, channel type): each gets its own register allocation.
 // ---------------------------------------------------------------------------
+// queue[0] = items handed out, queue[1] = workers that have left; from word RX_QUEUE_IDLE on, one idle word per worker
+// (16 words apart) for the tiles on which a worker takes nothing from the queue (see the kernel)
+#define RX_QUEUE_IDLE 64
+#define RX_QUEUE_MAX_WORKERS 4096
+#define RX_QUEUE_WORDS (RX_QUEUE_IDLE + 16 * RX_QUEUE_MAX_WORKERS)
+// One grab of the tile queue, whose result is not needed before the next tile.  The counter's address goes through a
+// register the compiler cannot see through: with a uniform address its atomic optimizer rewrites the add as a wave
+// reduction whose result it broadcasts (v_readfirstlane) -- and waits for, with s_waitcnt vmcnt(0), right where the
+// atomic is issued: behind the previous tile's twelve output stores, whose full drain time every second tile then
+// stood in front of the next tile's loads.
+__device__ __forceinline__ unsigned int rx_queue_grab(unsigned int *queue, unsigned int by = 1u)
+{
+    uintptr_t qa = (uintptr_t)queue;
+    asm volatile("" : "+v"(qa));
+    return __hip_atomic_fetch_add((__attribute__((address_space(1))) unsigned int *)qa, by, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // s_memtime stamp (diagnostic build only; the shipped kernels execute none)
 #define DIAG_STAMP(T) do { if constexpr (DIAG) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(T) :: "memory"); __builtin_amdgcn_sched_barrier(0); } } while (0)
 
@@ -660,7 +743,6 @@ void rx_pipe_fused_kernel(const PipeArgs a)
     // queue_k == 0: static striding by grid_int (A/B switch).
     int *qslot = (int *)(lds + C::IN_BYTES + C::TAIL_BYTES);
     const int K = a.queue_k;
-    unsigned int grabbed = 0;
     int pos = 0, end = 0, nb_base = 0;           // current chunk [pos, end), base of the chunk after it
 
     TileRegs<C, KIND> regs;
@@ -676,11 +758,14 @@ void rx_pipe_fused_kernel(const PipeArgs a)
         const void *in0 = KIND == CL_PIPE_IN_CF32 ? (const void *)((const f32x2 *)a.in + (long)s0 * a.in_stride)
                                                  : (const void *)((const uint32_t *)a.in + (long)s0 * a.in_stride);
         tile_issue_loads<C, KIND>(regs, in0, (long)tile0 * C::TILE_IN - C::HALO, threadIdx.x);
-        if (K > 0 && threadIdx.x == 0) grabbed = atomicAdd(a.queue, 1u);
+        unsigned int g0 = 0;
+        if (K > 0 && threadIdx.x == 0) g0 = rx_queue_grab(a.queue);
         // the first tile's words are waited for here (once per worker), so that no path into the loop carries
         // pending loads: the staging at the loop top then needs no vmcnt wait at all (see the note after the FIR)
 #pragma unroll
         for (int k = 0; k < TileRegs<C, KIND>::NV; k++) asm volatile("" : "+v"(regs.w[k]));
+        asm volatile("" : "+v"(g0));
+        if (K > 0 && threadIdx.x == 0) *qslot = (int)g0;     // read behind the loop's first barrier
     }
     while (item < items) {
         // Keep per-iteration values per-iteration: without these the compiler hoists every tap load
@@ -695,19 +780,35 @@ void rx_pipe_fused_kernel(const PipeArgs a)
         const bool bad = tile_sync_bad<C>(a, s, S);
 
         DIAG_STAMP(ts0);
+#if CLHIP_RX_PRIO
+        __builtin_amdgcn_s_setprio(3);                       // a wave that is moving data issues ahead of the waves that are in their FIR
+#endif
         tile_regs_to_lds<C, KIND, HIF>(regs, lds, t);
-        if (threadIdx.x == 0) *qslot = (int)grabbed;         // the latest grab arrived together with the prefetched words
         DIAG_STAMP(ts1);
-        __syncthreads();
+        RX_BARRIER();
         DIAG_STAMP(ts2);
         int next;
+        bool want_grab = false;
         if (K == 0) next = item + a.grid_int;
         else if (pos < end) next = pos++;
-        else {                                               // enter the next chunk; ask for the one after it
+        else {                                               // enter the next chunk; ask for the one after it (below)
             pos = nb_base; end = pos + K;
             nb_base = a.grid_int + K * __builtin_amdgcn_readfirstlane(*qslot);
             next = pos++;
-            if (next < items && threadIdx.x == 0) grabbed = atomicAdd(a.queue, 1u);
+            want_grab = next < items;
+        }
+        // The grab for the chunk after next goes out in front of the prefetch loads and is collected with them, behind
+        // the FIR.  EVERY tile issues the atomic -- on the tiles that take nothing from the queue it adds 0 to an idle word
+        // of the worker's own -- so that the register it returns in is written by the atomic and by nothing else.  With a
+        // second definition (a zero, a copy) on the other path the compiler protects that write against the atomic it
+        // believes may still be in flight from an earlier tile: s_waitcnt vmcnt(0) at the top of EVERY tile, right
+        // behind the previous tile's twelve output stores -- each tile's loads then left only after the previous tile's
+        // stores had drained (measured: the kernel took 0.92 ms whatever arithmetic was removed from it).
+        unsigned int grabbed = 0;
+        if (K > 0 && threadIdx.x == 0) {
+            const int wk = (int)blockIdx.x - n_edge_wg;
+            unsigned int *slot = want_grab ? a.queue : a.queue + RX_QUEUE_IDLE + 16 * (wk & (RX_QUEUE_MAX_WORKERS - 1));
+            grabbed = rx_queue_grab(slot, want_grab ? 1u : 0u);
         }
         if (next < items) {                                  // prefetch the next item's raw words
             const int sn = next / per_stream, tn = 1 + next % per_stream;
@@ -718,12 +819,21 @@ void rx_pipe_fused_kernel(const PipeArgs a)
         f32x2 acc[C::R];
         f32x4 pc[PL];
         f32x2 b_last = {0.f, 0.f};
+#if CLHIP_RX_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         if constexpr (C::FFA) fir_tile_ffa<C>(lds, t, fir, acc, b_last); else fir_tile<C>(lds, t, fir, acc);
+#if CLHIP_RX_PRIO
+        __builtin_amdgcn_s_setprio(CLHIP_RX_PRIO > 1 ? 3 : 0);
+#endif
         // Retire the prefetch here, where only loads are outstanding and they have long landed.  vmcnt counts
         // loads and stores together: waiting for these registers at the top of the next tile would also wait
         // for this tile's 12 output stores to reach memory.
 #pragma unroll
         for (int k = 0; k < TileRegs<C, KIND>::NV; k++) asm volatile("" : "+v"(regs.w[k]));
+        // (the grab, older than those loads, has returned with them: it moves to its LDS slot, read behind barriers)
+        asm volatile("" : "+v"(grabbed));
+        if (want_grab && threadIdx.x == 0) *qslot = (int)grabbed;
         if constexpr (DIAG) {                                // pin the phase's results before its stamp
 #pragma unroll
             for (int k = 0; k < C::R; k++) asm volatile("" : "+v"(acc[k]));
@@ -739,7 +849,7 @@ void rx_pipe_fused_kernel(const PipeArgs a)
         const long lo = C::MODE == MODE_FM ? S : S / C::M * C::L;
         if (!bad) store_tile<C, false>(lds, t, (unsigned char *)a.out + (long)s * a.out_stride * OB, tile_e0, lo, 0, pc);
         DIAG_STAMP(ts5);
-        __syncthreads();                                     // the next item's staging overwrites this LDS
+        RX_BARRIER();                                        // the next item's staging overwrites this LDS
         DIAG_STAMP(ts6);
         if constexpr (DIAG) {
             d_stage += ts1 - ts0; d_bar0 += ts2 - ts1; d_fir += ts3 - ts2; d_second += ts4 - ts3;
@@ -1005,9 +1115,9 @@ extern "C" clhip_rx_pipe *clhip_rx_pipe_create(int n_streams, int channel, const
     p->d_fir = (float *)clhip_malloc(sizeof(float) * PIPE_MAX_FIR);
     p->d_fir_int = (float *)clhip_malloc(sizeof(float) * PIPE_MAX_FIR);
     p->d_rs = (float *)clhip_malloc(sizeof(float) * PIPE_MAX_RS);
-    p->queue = (unsigned int *)clhip_malloc(2 * sizeof(unsigned int));
+    p->queue = (unsigned int *)clhip_malloc(RX_QUEUE_WORDS * sizeof(unsigned int));
     if (!p->d_fir || !p->d_fir_int || !p->d_rs || !p->queue) { clhip_rx_pipe_destroy(p); return nullptr; }
-    (void)hipMemset(p->queue, 0, 2 * sizeof(unsigned int));
+    (void)hipMemset(p->queue, 0, RX_QUEUE_WORDS * sizeof(unsigned int));
     float scaled[PIPE_MAX_FIR];
     for (int k = 0; k < PIPE_MAX_FIR; k++) scaled[k] = p->fir[k] / 4096.0f;   // exact: power of two
     (void)hipMemcpy(p->d_fir, p->fir, sizeof(float) * PIPE_MAX_FIR, hipMemcpyHostToDevice);

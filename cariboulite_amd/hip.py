@@ -98,7 +98,7 @@ def exported_symbols():
 def lib():
     global _lib
     if _lib is None:
-        path = os.environ.get("CLHIP_LIB", LIB_PATH)      # an alternative build of the shim (diagnostic / ablation builds)
+        path = os.environ.get("CLHIP_LIB") or LIB_PATH      # an alternative build of the shim (diagnostic / ablation builds)
         if not os.path.exists(path):
             raise ImportError(
                 f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "

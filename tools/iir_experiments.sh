@@ -12,5 +12,5 @@ echo "# prio, waves per CU 12 / 8"; CLHIP_IIR_WG_PER_CU=12 $B 26 20; CLHIP_IIR_W
 echo "# round-2 library"; CLHIP_LIB=abl/r2/libcariboulite_hip.so $B 26 20
 echo "# 2^22 / 2^24"; $B 22 50; $B 24 50
 echo "# fc 10 kHz / 25 kHz at 2^26"; $B 26 20 10e3; $B 26 20 25e3
-echo "# stamps"; timeout -k 10 120 python tools/phase_stamps.py 26
+echo "# stamps"; timeout -k 10 120 python tools/iir_phase_stamps.py 26
 } 2>&1 | grep -v amdgpu.ids | tee $O/bench7.log
