@@ -309,10 +309,20 @@ __global__ __launch_bounds__(FM_BLOCK) void tx_fm_fused_kernel(
 // TXQ_KEEP=1 (compile-time experiment): the superblock's messages stay in registers between the sum pass and the
 // sub-block loop, so the stream is read once -- 147 / 179 / 234 VGPRs at 3 / 4 / 6 sub-blocks instead of 85, and
 // 0.295 / 0.318 / 0.284 ms on config 5 against 0.268 with the re-read: occupancy, which hides the look-back, is worth more
+// TXQ_KEEP=2: the superblock's messages wait in LDS instead (4 bytes per message: 48 KB at four sub-blocks, beside the
+// 29 KB of phasor rows: two workgroups per CU as before), so the stream is read from memory once -- see the table at
+// TXQ_NSUB for what it costs
 #ifndef TXQ_KEEP
 #define TXQ_KEEP 0
 #endif
-#define TXQ_NSUB 6      // sub-blocks per superblock: 4 -> 0.290 ms, 5 -> 0.276, 6 -> 0.268, 7 -> 0.276, 8 -> 0.274 (config 5, 2^27 messages)
+// sub-blocks per superblock (round 2, look-back in front of the arithmetic): 4 -> 0.290 ms, 5 -> 0.276, 6 -> 0.268, 7 -> 0.276,
+// 8 -> 0.274 (config 5, 2^27 messages)
+#ifndef TXQ_NSUB
+#define TXQ_NSUB 6
+#endif
+#ifndef TXQ_P1_REVERSE
+#define TXQ_P1_REVERSE 1                   // the sum pass walks the superblock backwards: the second pass then starts on the most recently read lines (-4 % HBM reads, -1 % time)
+#endif
 typedef __attribute__((address_space(4))) float tx_cfloat_t;
 typedef f32x4 __attribute__((aligned(4))) f32x4_a4;      // 16-byte global access at dword alignment (unaligned mode)
 typedef u32x4 __attribute__((aligned(4))) u32x4_a4;
@@ -612,6 +622,172 @@ __device__ __forceinline__ unsigned long long txlb_fix(double turns)
     return (unsigned long long)(f * 281474976710656.0) & TXLB_MASK;       // 2^48
 }
 
+// ---------------------------------------------------------------------------
+// A sub-block worked RELATIVE to its own start (phase 0 there), for when the phase it starts at is not known yet:
+//   tx_unit_compute   fp64 prefix inside the sub-block -> phasors -> LDS rows (row -1: the HS samples before the
+//                     sub-block, rebuilt from the H messages before it -- relative phasors need no offset) -> polyphase
+//                     outputs, unrotated.  Returns the sub-block's phase sum (turns).
+//   tx_unit_emit      rotate the outputs by the phase the sub-block starts at -- the resampler is linear, so rotating its
+//                     outputs equals rotating its inputs -- quantise, pack, store; the stream's history for the next call.
+// The stream's first sub-block (base == 0) knows its phase, the carried one, takes the carried phasors as they are, and
+// is emitted with the identity rotation.
+// ---------------------------------------------------------------------------
+template <class C>
+__device__ __forceinline__ double tx_unit_compute(const float *mm, size_t n, int phi, double wt, double start, size_t base, bool interior,
+                                                  unsigned char *rows, double *sh, const f32x2 *hist_in_s, const tx_cfloat_t *__restrict__ rs,
+                                                  f32x2 (&o)[C::NOUT], const float *lds_msgs = nullptr)
+{
+    constexpr int L = C::L, M = C::M, KP = C::KP, PER = C::PER, NOUT = C::NOUT, ROW = C::ROW, HS = C::HSLOT, H = KP - 1;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const size_t tb = base + (size_t)t * PER;
+    unsigned char *myrow = rows + (t + 1) * ROW;
+    float mv[PER];
+    if (lds_msgs) {
+#pragma unroll
+        for (int q = 0; q < PER / 4; q++) {
+            const f32x4 v = *(const f32x4 *)(lds_msgs + t * PER + 4 * q);
+            mv[4 * q] = v.x; mv[4 * q + 1] = v.y; mv[4 * q + 2] = v.z; mv[4 * q + 3] = v.w;
+        }
+    } else if (interior) tx_load_msgs<C, false>(mm, n, phi, tb, mv); else tx_load_msgs<C, true>(mm, n, phi, tb, mv);
+    double c[PER], run = 0.0;
+#pragma unroll
+    for (int k = 0; k < PER; k++) { run = __builtin_fma((double)mv[k], wt, run); c[k] = run; }
+    double incl = run;
+#pragma unroll
+    for (int oo = 1; oo < 64; oo <<= 1) {
+        const double up = __shfl_up(incl, oo, 64);
+        if (lane >= oo) incl += up;
+    }
+    if (lane == 63) sh[wave] = incl;
+    __syncthreads();                                           // also: an earlier sub-block's window reads are done
+    double woff = start, total = 0.0;
+#pragma unroll
+    for (int k = 0; k < TXQ_NT / 64; k++) { const double v = sh[k]; total += v; if (k < wave) woff += v; }
+    const double excl = woff + (incl - run);
+#pragma unroll
+    for (int k = 0; k < PER; k += 2) {
+        f32x2 a = phasor_turns(excl + c[k]), bb = phasor_turns(excl + c[k + 1]);
+        if (!interior) {
+            if (tb + k >= n) a = f32x2{0.f, 0.f};
+            if (tb + k + 1 >= n) bb = f32x2{0.f, 0.f};
+            if (tb == 0) {                                         // virtual messages before the call: carried history (absolute frame)
+                if (k < phi) a = hist_in_s[H - phi + k];
+                if (k + 1 < phi) bb = hist_in_s[H - phi + k + 1];
+            }
+        }
+        const f32x4 q = {a.x, a.y, bb.x, bb.y};
+        *(f32x4 *)(myrow + 8 * k) = q;
+    }
+    if (t < HS) {                                                  // the HS samples before the sub-block -> tail of row -1
+        const int k = t + 1;                                       // message base - k
+        f32x2 hv = {0.f, 0.f};
+        if (k <= H) {
+            if (base >= (size_t)k) {
+                double ph = start;
+                for (int i = 1; i < k; i++) ph -= wt * (double)mm[base - i];
+                hv = phasor_turns(ph);
+            } else {                                               // base == 0: real message -k - phi
+                const long idx = (long)H - k - phi;
+                if (idx >= 0) hv = hist_in_s[idx];
+            }
+        }
+        *(f32x2 *)(rows + 8 * (PER - k)) = hv;
+    }
+    __syncthreads();
+    f32x2 x[HS + PER];                                             // window: the HS samples before the lane's first message + its PER messages
+#pragma unroll
+    for (int k = 0; k < HS; k += 2) {
+        const f32x4 q = *(const f32x4 *)(myrow - ROW + 8 * (PER - HS + k));
+        x[k] = q.xy; x[k + 1] = q.zw;
+    }
+#pragma unroll
+    for (int k = 0; k < PER; k += 2) {
+        const f32x4 q = *(const f32x4 *)(myrow + 8 * k);
+        x[HS + k] = q.xy; x[HS + k + 1] = q.zw;
+    }
+    float tp[KP * L];
+#pragma unroll
+    for (int i = 0; i < KP * L; i++) tp[i] = rs[i];
+#pragma unroll
+    for (int u = 0; u < NOUT; u++) {
+        const int bq = (u * M) / L, p = (u * M) % L;          // newest message (lane-relative), polyphase leg
+        f32x2 acc = {0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < KP; i++) acc += x[HS + bq - i] * tp[p + i * L];
+        o[u] = acc;
+    }
+    return total;
+}
+
+template <class C>
+__device__ __forceinline__ void tx_unit_emit(f32x2 (&o)[C::NOUT], const f32x2 rot, size_t n, int skip, size_t base, bool interior,
+                                             const unsigned char *rows, f32x2 *hist_out_s, long n_out, int pack_mode, uint32_t *words_s, f32x2 *tap_s)
+{
+    constexpr int L = C::L, M = C::M, KP = C::KP, PER = C::PER, NOUT = C::NOUT, ROW = C::ROW, H = KP - 1;
+    const int t = threadIdx.x;
+    const size_t tb = base + (size_t)t * PER;
+    // history for the next call: the last H phasors of the stream live in this sub-block's rows (or row -1), unrotated
+    if (!interior && H > 0 && base + C::SUB >= n && t < H) {
+        const long rel = (long)n - H + t - (long)base;             // >= -H
+        const long r = rel >= 0 ? rel / PER : -1, cidx = rel >= 0 ? rel % PER : PER + rel;
+        const f32x2 hv = *(const f32x2 *)(rows + (r + 1) * ROW + 8 * cidx);
+        hist_out_s[t] = f32x2{hv.x * rot.x - hv.y * rot.y, hv.x * rot.y + hv.y * rot.x};
+    }
+    uint32_t wd[NOUT];
+#pragma unroll
+    for (int u = 0; u < NOUT; u++) {
+        const f32x2 v = {__builtin_fmaf(o[u].x, rot.x, -o[u].y * rot.y), __builtin_fmaf(o[u].x, rot.y, o[u].y * rot.x)};
+        o[u] = v;
+        wd[u] = tx_pack_word(CL_TX_DOCUMENTED, tx_f2i16_fast(v.x * 4096.0f), tx_f2i16_fast(v.y * 4096.0f));
+    }
+    if (pack_mode == CL_TX_AS_WRITTEN) {                       // uniform: the shipped packer ignores its input
+#pragma unroll
+        for (int u = 0; u < NOUT; u++) wd[u] = tx_pack_word(CL_TX_AS_WRITTEN, 0, 0);
+    }
+    const long j0 = (long)(tb / M) * L - skip;                 // tb is a multiple of M; the first `skip` outputs are not ours
+    uint32_t *wp = words_s + j0;
+    if (interior || (j0 >= 0 && j0 + NOUT <= n_out)) {
+#pragma unroll
+        for (int q = 0; q < NOUT / 4; q++) { const u32x4 v = {wd[4 * q], wd[4 * q + 1], wd[4 * q + 2], wd[4 * q + 3]}; *(u32x4_a4 *)(wp + 4 * q) = v; }
+    } else {
+#pragma unroll
+        for (int u = 0; u < NOUT; u++) if (j0 + u >= 0 && j0 + u < n_out) wp[u] = wd[u];
+    }
+    if (tap_s) {
+#pragma unroll
+        for (int u = 0; u < NOUT; u++) if (interior || (j0 + u >= 0 && j0 + u < n_out)) tap_s[j0 + u] = o[u];
+    }
+}
+
+// The decoupled look-back of one wave over the words before st[b] (see TxLookBack): the phase, as 48-bit fixed point,
+// after the last message before unit b.  Bounded polls; an overrun raises *lb.err and carries on with a made-up word.
+__device__ __forceinline__ unsigned long long tx_look_back(const TxLookBack &lb, const unsigned long long *st, long b, unsigned long long pin, int lane)
+{
+    const unsigned long long e = (unsigned long long)lb.epoch << 48;
+    unsigned long long acc = 0;
+    long j0 = b - 1;
+    bool done = false;
+    int guard = 0;
+    while (!done) {
+        const long j = j0 - lane;
+        unsigned long long w = (3ull << 62) | pin;                 // state 3 = before the stream's first unit
+        if (j >= 0) {
+            do {
+                w = __hip_atomic_load(st + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (++guard > lb.poll_bound) { *lb.err = 1; w = (2ull << 62) | e; }
+            } while (((w >> 48) & 0x3FFF) != lb.epoch || (w >> 62) == 0);
+        }
+        const unsigned long long have = __ballot((w >> 62) >= 2);
+        const int first = have ? __builtin_ctzll(have) : 64;
+        unsigned long long v = lane <= first ? (w & TXLB_MASK) : 0ull;
+#pragma unroll
+        for (int oo = 32; oo > 0; oo >>= 1) v += __shfl_xor(v, oo, 64);
+        acc += v;
+        if (first < 64) done = true; else j0 -= 64;
+    }
+    return acc & TXLB_MASK;
+}
+
 template <class C>
 __global__ __launch_bounds__(TXQ_NT, 2) void tx_fm_chain_kernel(
     const float *__restrict__ m, long m_stride, size_t n, int phi, int skip, double wt, TxLookBack lb, long n_super,
@@ -633,7 +809,10 @@ __global__ __launch_bounds__(TXQ_NT, 2) void tx_fm_chain_kernel(
         __syncthreads();
     }
     const unsigned int T = lb.ticket ? sh_ticket : blockIdx.x;
-    if (T >= (unsigned)(n_super * n_streams)) return;              // (workgroup-uniform) never index past the launch's superblocks
+    if (T >= (unsigned)(n_super * n_streams)) {                    // (workgroup-uniform) never index past the launch's superblocks --
+        if (t == 0) *lb.err = 1;                                   // and never silently: a skipped superblock fails the call
+        return;
+    }
     const int s = (int)(T % (unsigned)n_streams);
     const long b = (long)(T / (unsigned)n_streams);
     const float *mm = m + (long)s * m_stride - phi;
@@ -644,57 +823,57 @@ __global__ __launch_bounds__(TXQ_NT, 2) void tx_fm_chain_kernel(
     // aggregate of the superblock; the messages are read again from L2 / Infinity Cache by the sub-block loop
     // (keeping 48 of them per lane in registers would cost two waves of occupancy, and occupancy hides the look-back)
     double part = 0.0;
-    float kept[TXQ_KEEP ? TXQ_NSUB : 1][PER];                     // TXQ_KEEP: the superblock's messages stay in registers
+    float kept[TXQ_KEEP == 1 ? TXQ_NSUB : 1][PER];                // TXQ_KEEP = 1: the superblock's messages stay in registers
+    extern __shared__ __attribute__((aligned(16))) float kept_lds[];   // TXQ_KEEP = 2: in LDS, [sub-block][lane][PER]
 #pragma unroll
-    for (int sb = 0; sb < TXQ_NSUB; sb++) {
+    for (int sbr = 0; sbr < TXQ_NSUB; sbr++) {
+        const int sb = TXQ_P1_REVERSE ? TXQ_NSUB - 1 - sbr : sbr;   // last sub-block first: the second pass then starts on the most recently read lines
         const size_t tb = sbase + (size_t)sb * C::SUB + (size_t)t * PER;
         float mv[PER];
         if (interior) tx_load_msgs<C, false>(mm, n, phi, tb, mv);
         else tx_load_msgs<C, true>(mm, n, phi, tb, mv);
         double r = 0.0;
 #pragma unroll
-        for (int k = 0; k < PER; k++) { r = __builtin_fma((double)mv[k], wt, r); if (TXQ_KEEP) kept[sb][k] = mv[k]; }
+        for (int k = 0; k < PER; k++) { r = __builtin_fma((double)mv[k], wt, r); if (TXQ_KEEP == 1) kept[sb][k] = mv[k]; }
+        if (TXQ_KEEP == 2) {
+#pragma unroll
+            for (int q = 0; q < PER / 4; q++) *(f32x4 *)(kept_lds + (sb * TXQ_NT + t) * PER + 4 * q) = f32x4{mv[4 * q], mv[4 * q + 1], mv[4 * q + 2], mv[4 * q + 3]};
+        }
         part += r;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);
     if (lane == 0) sh[wave] = part;
     __syncthreads();
+    unsigned long long *st = lb.st + (long)s * n_super;
+    const unsigned long long e = (unsigned long long)lb.epoch << 48;
+    const double pin_turns = phase_in[s] * (1.0 / TWO_PI);
+    unsigned long long mine = 0;
     if (wave == 0) {
         double total = 0.0;
 #pragma unroll
         for (int k = 0; k < TXQ_NT / 64; k++) total += sh[k];
-        unsigned long long *st = lb.st + (long)s * n_super;
-        const unsigned long long e = (unsigned long long)lb.epoch << 48;
-        const unsigned long long mine = txlb_fix(total);
+        mine = txlb_fix(total);
         if (lane == 0) __hip_atomic_store(st + b, (1ull << 62) | e | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long pin = txlb_fix(phase_in[s] * (1.0 / TWO_PI));
-        unsigned long long acc = 0;
-        long j0 = b - 1;
-        bool done = false;
-        int guard = 0;
-        while (!done) {
-            const long j = j0 - lane;
-            unsigned long long w = (3ull << 62) | pin;             // state 3 = before the stream's first superblock
-            if (j >= 0) {
-                do {
-                    w = __hip_atomic_load(st + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (++guard > lb.poll_bound) { *lb.err = 1; w = (2ull << 62) | e; }
-                } while (((w >> 48) & 0x3FFF) != lb.epoch || (w >> 62) == 0);
-            }
-            const unsigned long long have = __ballot((w >> 62) >= 2);
-            const int first = have ? __builtin_ctzll(have) : 64;
-            unsigned long long v = lane <= first ? (w & TXLB_MASK) : 0ull;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-            acc += v;
-            if (first < 64) done = true; else j0 -= 64;
-        }
-        acc &= TXLB_MASK;
+    }
+    __syncthreads();                                               // sh[] is free again
+    uint32_t *words_s = words + (long)s * w_stride;
+    f32x2 *tap_s = tap ? tap + (long)s * tap_stride : nullptr;
+    // The superblock's FIRST sub-block is worked before its phase is known -- relative to its own start, its outputs held
+    // back (tx_unit_compute) -- so that the look-back stands behind a sixth of the superblock's arithmetic instead of
+    // in front of all of it: by then the predecessors have long published.  (Ablation, round 2: no look-back wait 0.253
+    // against 0.281 ms.)  The stream's first superblock knows its phase and works in the absolute frame throughout.
+    f32x2 o0[C::NOUT];
+    const bool int0 = sbase > 0 && sbase + C::SUB < n;
+    const double tot0 = tx_unit_compute<C>(mm, n, phi, wt, b == 0 ? pin_turns : 0.0, sbase, int0, rows, sh, hist_in + (long)s * H, rs, o0,
+                                           TXQ_KEEP == 2 ? kept_lds : nullptr);
+    if (wave == 0) {
+        const unsigned long long pin = txlb_fix(pin_turns);
+        const unsigned long long acc = b > 0 ? tx_look_back(lb, st, b, pin, lane) : pin;
         if (lane == 0) {
             const unsigned long long inc = (acc + mine) & TXLB_MASK;
             __hip_atomic_store(st + b, (2ull << 62) | e | inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            sh_off = (double)acc * (1.0 / 281474976710656.0);
+            sh_off = (double)acc * (1.0 / 281474976710656.0);     // phase (turns) after message sbase-1
             if (b == n_super - 1) {
                 const double it = (double)inc * (1.0 / 281474976710656.0);
                 phase_new[s] = wrap_pi(TWO_PI * (it - rint(it)));
@@ -702,34 +881,33 @@ __global__ __launch_bounds__(TXQ_NT, 2) void tx_fm_chain_kernel(
         }
     }
     __syncthreads();
-    double off = sh_off;                                           // phase (turns) after message sbase-1
-
-    // the HS samples before the superblock -> tail of row -1
+    const double off0 = b == 0 ? pin_turns : sh_off;
+    const f32x2 rot = phasor_turns(b == 0 ? 0.0 : off0);
+    tx_unit_emit<C>(o0, rot, n, skip, sbase, int0, rows, hist_out + (long)s * H, n_out, pack_mode, words_s, tap_s);
+    // the last HS samples of sub-block 0, turned into the absolute frame, become row -1 of sub-block 1
+    f32x2 keep = {0.f, 0.f};
     if (t < HS) {
-        const int k = t + 1;                                       // message sbase - k
-        f32x2 hv = {0.f, 0.f};
-        if (k <= H) {
-            if (sbase >= (size_t)k) {
-                double ph = off;
-                for (int i = 1; i < k; i++) ph -= wt * (double)mm[sbase - i];
-                hv = phasor_turns(ph);
-            } else {                                               // sbase == 0: real message -k - phi
-                const long idx = (long)H - k - phi;
-                if (idx >= 0) hv = hist_in[(long)s * H + idx];
-            }
-        }
-        *(f32x2 *)(rows + 8 * (PER - k)) = hv;
+        const f32x2 kv = *(const f32x2 *)(rows + TXQ_NT * ROW + 8 * (PER - HS + t));
+        keep = f32x2{kv.x * rot.x - kv.y * rot.y, kv.x * rot.y + kv.y * rot.x};
     }
-    uint32_t *words_s = words + (long)s * w_stride;
-    f32x2 *tap_s = tap ? tap + (long)s * tap_stride : nullptr;
+    __syncthreads();
+    if (t < HS) *(f32x2 *)(rows + 8 * (PER - HS + t)) = keep;
+    double off = off0 + tot0;
+    off -= floor(off);
 #pragma unroll
-    for (int sb = 0; sb < TXQ_NSUB; sb++) {
+    for (int sb = 1; sb < TXQ_NSUB; sb++) {
         const size_t base = sbase + (size_t)sb * C::SUB;          // workgroup-uniform
         if (base >= n) break;
         float mv[PER];
-        if (TXQ_KEEP) {
+        if (TXQ_KEEP == 1) {
 #pragma unroll
             for (int k = 0; k < PER; k++) mv[k] = kept[sb][k];
+        } else if (TXQ_KEEP == 2) {
+#pragma unroll
+            for (int q = 0; q < PER / 4; q++) {
+                const f32x4 v = *(const f32x4 *)(kept_lds + (sb * TXQ_NT + t) * PER + 4 * q);
+                mv[4 * q] = v.x; mv[4 * q + 1] = v.y; mv[4 * q + 2] = v.z; mv[4 * q + 3] = v.w;
+            }
         }
         if (base > 0 && base + C::SUB < n) {
             if (!TXQ_KEEP) tx_load_msgs<C, false>(mm, n, phi, base + (size_t)t * PER, mv);
@@ -741,6 +919,69 @@ __global__ __launch_bounds__(TXQ_NT, 2) void tx_fm_chain_kernel(
                                             hist_out + (long)s * H, rs, n_out, pack_mode, words_s, tap_s);
         }
     }
+}
+
+// ---------------------------------------------------------------------------
+// Single read, one sub-block per workgroup (CLHIP_TX_CHAIN=3; measured, not the default).  The look-back unit is ONE
+// sub-block of 256 x PER messages, the whole of which a workgroup holds in registers and LDS: every message is read
+// from memory once, the unit's sum is published at once and its look-back stands BEHIND its own arithmetic.  Correct
+// and traffic-minimal, but a look-back per 3072 messages costs more than it saves: 0.394 ms on config 5 against 0.269
+// for the superblock kernel (a unit's arithmetic is ~3 us, its look-back ~8 us with a thousand equally young units
+// resident; the ticket order, one atomic per unit, 0.54 ms).
+// ---------------------------------------------------------------------------
+template <class C>
+__global__ __launch_bounds__(TXQ_NT, 4) void tx_fm_chain1_kernel(
+    const float *__restrict__ m, long m_stride, size_t n, int phi, int skip, double wt, TxLookBack lb, long n_units,
+    int n_streams, const double *__restrict__ phase_in, double *__restrict__ phase_new,
+    const f32x2 *__restrict__ hist_in, f32x2 *__restrict__ hist_out, const float *__restrict__ rs_dev,
+    long n_out, int pack_mode, uint32_t *__restrict__ words, long w_stride, f32x2 *__restrict__ tap, long tap_stride)
+{
+    constexpr int KP = C::KP, ROW = C::ROW, H = KP - 1;
+    __shared__ __attribute__((aligned(16))) unsigned char rows[(TXQ_NT + 1) * ROW];   // row r at (r + 1) * ROW
+    __shared__ double sh[TXQ_NT / 64 + 1];
+    __shared__ double sh_off;
+    __shared__ unsigned int sh_ticket;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (lb.ticket) {
+        if (t == 0) sh_ticket = atomicAdd(lb.ticket, 1u) - lb.ticket_base;
+        __syncthreads();
+    }
+    const unsigned int T = lb.ticket ? sh_ticket : blockIdx.x;
+    if (T >= (unsigned)(n_units * n_streams)) {                    // (workgroup-uniform) a ticket beyond the launch's units: the host's
+        if (t == 0) *lb.err = 1;                                   // base is out of step -- say so, a skipped unit must not go unnoticed
+        return;
+    }
+    const int s = (int)(T % (unsigned)n_streams);
+    const long b = (long)(T / (unsigned)n_streams);
+    const float *mm = m + (long)s * m_stride - phi;                // indexed by the virtual message index; n = virtual count
+    const size_t base = (size_t)b * C::SUB;
+    const bool interior = base > 0 && base + C::SUB < n;          // workgroup-uniform: no bounds tests, no history
+    unsigned long long *st = lb.st + (long)s * n_units;
+    const unsigned long long e = (unsigned long long)lb.epoch << 48;
+    const double pin_turns = phase_in[s] * (1.0 / TWO_PI);
+
+    f32x2 o[C::NOUT];
+    const double total = tx_unit_compute<C>(mm, n, phi, wt, b == 0 ? pin_turns : 0.0, base, interior, rows, sh, hist_in + (long)s * H,
+                                            (const tx_cfloat_t *)rs_dev, o);
+    const unsigned long long mine = txlb_fix(total);
+    // (the aggregate leaves behind the arithmetic here: one barrier earlier it would need a second pass over the sums)
+    if (t == 0) __hip_atomic_store(st + b, (1ull << 62) | e | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wave == 0) {
+        const unsigned long long pin = txlb_fix(pin_turns);
+        const unsigned long long acc = b > 0 ? tx_look_back(lb, st, b, pin, lane) : pin;
+        if (lane == 0) {
+            const unsigned long long inc = (acc + mine) & TXLB_MASK;
+            __hip_atomic_store(st + b, (2ull << 62) | e | inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sh_off = b > 0 ? (double)acc * (1.0 / 281474976710656.0) : 0.0;      // (the first unit's phasors are absolute already)
+            if (b == n_units - 1) {
+                const double it = (double)inc * (1.0 / 281474976710656.0);
+                phase_new[s] = wrap_pi(TWO_PI * (it - rint(it)));
+            }
+        }
+    }
+    __syncthreads();
+    tx_unit_emit<C>(o, phasor_turns(sh_off), n, skip, base, interior, rows, hist_out + (long)s * H, n_out, pack_mode,
+                    words + (long)s * w_stride, tap ? tap + (long)s * tap_stride : nullptr);
 }
 
 typedef TxCfg<2, 3, 8> TxCfgC5;      // config 5: 2/3 resampler, 16 prototype taps
@@ -965,9 +1206,13 @@ extern "C" long clhip_tx_pipe_run(clhip_tx_pipe *p, int in_kind, const void *d_i
         const double wt = p->w * (1.0 / TWO_PI);
         dim3 grid((unsigned)n_super, p->n_streams);
         static const int tx_chain = getenv("CLHIP_TX_CHAIN") ? atoi(getenv("CLHIP_TX_CHAIN")) : 1;
+        // 1 (default): single launch, superblocks of TXQ_NSUB sub-blocks, the look-back behind the first sub-block's
+        // arithmetic (tx_fm_chain_kernel); 3: single launch, single read, one sub-block per workgroup (tx_fm_chain1_kernel:
+        // measured slower); 0: three launches
+        const long n_units = (long)clhip_div_up(nv, (size_t)C::SUB);
         if (tx_chain) {
-            // single pass: tickets + decoupled look-back (tx_fm_chain_kernel)
-            const size_t need = (size_t)n_super * p->n_streams;
+            const long n_lb = tx_chain == 3 ? n_units : n_super;   // look-back words per stream
+            const size_t need = (size_t)n_lb * p->n_streams;
             if (need > p->lb_cap || !p->lb_ticket) {
                 clhip_free(p->lb_st);
                 p->lb_st = (unsigned long long *)clhip_malloc(sizeof(unsigned long long) * need);
@@ -1010,12 +1255,24 @@ extern "C" long clhip_tx_pipe_run(clhip_tx_pipe *p, int in_kind, const void *d_i
             // dispatch order: give up after ~0.2 s of polling and let the ticket order take over; tickets: the wait is always finite
             const int bound = p->poll_bound >= 0 ? p->poll_bound : (use_ticket ? 1 << 22 : 1 << 18);
             TxLookBack lb = {p->lb_st, use_ticket ? p->lb_ticket : nullptr, p->ticket_total, p->epoch, p->lb_err_dev, bound};
-            const unsigned n_wg = (unsigned)(n_super * p->n_streams);
+            const unsigned n_wg = (unsigned)(n_lb * p->n_streams);
             double *phase_new = p->d_phase2 + (size_t)(p->pcur ^ 1) * p->n_streams;   // the other half: late workgroups still read d_phase
-            hipLaunchKernelGGL(tx_fm_chain_kernel<C>, dim3(n_wg), dim3(TXQ_NT), 0, s, (const float *)d_in, (long)in_stride, nv, phi,
-                               skip, wt, lb, n_super, p->n_streams, (const double *)p->d_phase, phase_new, p->hist[p->cur],
-                               p->hist[p->cur ^ 1], p->d_rs, (long)n_out, p->pack_mode, (uint32_t *)d_bytes,
-                               (long)(out_stride_bytes / 4), (f32x2 *)d_iq_tap, (long)iq_tap_stride);
+            if (tx_chain == 3)
+                hipLaunchKernelGGL(tx_fm_chain1_kernel<C>, dim3(n_wg), dim3(TXQ_NT), 0, s, (const float *)d_in, (long)in_stride, nv, phi,
+                                   skip, wt, lb, n_units, p->n_streams, (const double *)p->d_phase, phase_new, p->hist[p->cur],
+                                   p->hist[p->cur ^ 1], p->d_rs, (long)n_out, p->pack_mode, (uint32_t *)d_bytes,
+                                   (long)(out_stride_bytes / 4), (f32x2 *)d_iq_tap, (long)iq_tap_stride);
+            else {
+                constexpr size_t keep_bytes = TXQ_KEEP == 2 ? sizeof(float) * TXQ_NSUB * C::SUB : 0;
+                if (keep_bytes) {
+                    static const hipError_t attr = hipFuncSetAttribute((const void *)tx_fm_chain_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)keep_bytes);
+                    if (attr != hipSuccess) { clhip_set_error("clhip_tx_pipe_run: cannot reserve %zu bytes of LDS", keep_bytes); return -1; }
+                }
+                hipLaunchKernelGGL(tx_fm_chain_kernel<C>, dim3(n_wg), dim3(TXQ_NT), keep_bytes, s, (const float *)d_in, (long)in_stride, nv, phi,
+                                   skip, wt, lb, n_super, p->n_streams, (const double *)p->d_phase, phase_new, p->hist[p->cur],
+                                   p->hist[p->cur ^ 1], p->d_rs, (long)n_out, p->pack_mode, (uint32_t *)d_bytes,
+                                   (long)(out_stride_bytes / 4), (f32x2 *)d_iq_tap, (long)iq_tap_stride);
+            }
             if (use_ticket) p->ticket_total += n_wg;               // the device counter moves only when tickets are taken
             CLHIP_CHECK_LAUNCH();
             p->pcur ^= 1; p->d_phase = phase_new;

@@ -150,6 +150,17 @@ def test_fm_mod_vs_oracle(G, orc):
     assert np.max(np.abs(o.cpu().numpy() - want)) <= TOL
 
 
+def _tx_words_to_iq(words):
+    """(i, q) as signed 13-bit integers from TX words in the documented layout (caribou_smi.c:693-696): in memory order
+    byte0 = [SOF, TXC, CTX, I12..I8], byte1 = [0, I7..I1], byte2 = [0, I0, Q12..Q7], byte3 = [0, Q6..Q0]"""
+    w = words.astype(np.uint32)
+    b0, b1, b2, b3 = w & 0xFF, (w >> 8) & 0xFF, (w >> 16) & 0xFF, (w >> 24) & 0xFF
+    i13 = ((b0 & 0x1F) << 8) | ((b1 & 0x7F) << 1) | ((b2 >> 6) & 1)
+    q13 = ((b2 & 0x3F) << 7) | (b3 & 0x7F)
+    sx = lambda v: ((v.astype(np.int32) + 4096) & 0x1FFF) - 4096
+    return np.stack([sx(i13), sx(q13)], 1)
+
+
 def test_tx_pipe_config5(G, orc):
     """float message -> FM mod -> 2/3 resample -> x4096 truncate -> int13 pack (BASELINE config 5).
     Float stages to 1e-5 (tap output); the integer tail is bit-exact on the GPU's own floats."""
@@ -186,8 +197,10 @@ def test_tx_pipe_config5(G, orc):
     assert pos == n
     chunked = np.concatenate(outs).view(np.uint32)
     one = by.cpu().numpy().view(np.uint32)
-    # identical up to rare 1-LSB truncation flips from the re-associated fp64 phase sums
-    assert chunked.size == one.size and np.mean(chunked != one) < 1e-3
+    # identical up to rare 1-LSB truncation flips: the fp64 phase sums are re-associated, and a superblock's first
+    # sub-block is worked relative to its own start and rotated into place afterwards (one more fp32 rounding)
+    assert chunked.size == one.size and np.mean(chunked != one) < 2e-3
+    assert np.abs(_tx_words_to_iq(chunked) - _tx_words_to_iq(one)).max() <= 1          # and a flip is one LSB
     # as-written mode reproduces the reference's constant output
     pipe3 = hip.TxPipe(1, 75e3, 4e6, t["rs_2_3"], 2, 3, hip.TX_AS_WRITTEN)
     assert pipe3.run(hip.TXPIPE_IN_FM_MESSAGE, d, 0, 300, by, 4 * no) == 200
