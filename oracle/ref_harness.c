@@ -67,6 +67,19 @@ int ref_smi_read_file(const char *path, int channel, int16_t *iq, uint8_t *meta,
     return ret;
 }
 
+/* caribou_smi_read() on a descriptor the caller owns (a pipe, non-blocking or not): the read()/poll()/read() pattern of
+ * caribou_smi_timeout_read runs against it as it does against /dev/smi */
+int ref_smi_read_fd(int fd, int channel, int16_t *iq, uint8_t *meta, size_t length_samples, size_t native_batch_len)
+{
+    caribou_smi_st dev;
+    ref_dev_init(&dev, fd, native_batch_len);
+    int ret = caribou_smi_read(&dev, (caribou_smi_channel_en)channel,
+                               (caribou_smi_sample_complex_int16 *)iq,
+                               (caribou_smi_sample_meta *)meta, length_samples);
+    ref_dev_free(&dev);
+    return ret;
+}
+
 void ref_generate_data(const int16_t *iq, size_t n_samples, uint8_t *out)
 {
     caribou_smi_st dev;
