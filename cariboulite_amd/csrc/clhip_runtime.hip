@@ -67,6 +67,28 @@ extern "C" void *clhip_host_alloc(size_t bytes)
 
 extern "C" void clhip_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
+// the address kernels use for pinned host memory of clhip_host_alloc (NULL when the device cannot reach it)
+extern "C" void *clhip_host_device_ptr(void *h)
+{
+    void *d = nullptr;
+    if (!h || hipHostGetDevicePointer(&d, h, 0) != hipSuccess) return nullptr;
+    return d;
+}
+
+// Pin and map memory the CALLER owns (a client's sample buffer) so that kernels can store into it: returns the address kernels
+// use, NULL when the range cannot be registered (already registered in part, not mapped, limits).  Until clhip_host_unregister
+// the range has to stay mapped in the process.
+extern "C" void *clhip_host_register(void *h, size_t bytes)
+{
+    void *d = nullptr;
+    if (!h || !bytes) return nullptr;
+    if (hipHostRegister(h, bytes, hipHostRegisterMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess || !d) { (void)hipGetLastError(); (void)hipHostUnregister(h); return nullptr; }
+    return d;
+}
+
+extern "C" void clhip_host_unregister(void *h) { if (h && hipHostUnregister(h) != hipSuccess) (void)hipGetLastError(); }
+
 extern "C" int clhip_memcpy_h2d(void *d, const void *h, size_t n, void *s)
 {
     CLHIP_CHECK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, (hipStream_t)s));

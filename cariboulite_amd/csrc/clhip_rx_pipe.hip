@@ -657,7 +657,9 @@ __device__ __forceinline__ bool tile_sync_bad(const PipeArgs &a, int s, long S)
                 }
             }
         }
-        if (bad && threadIdx.x == 0) atomicOr(a.bad_flag, 1);          // the tile writes nothing
+        // (the flag may live in mapped host memory -- clhip_rx_pipe_run_smi reads it without a copy -- hence a store that
+        // needs no PCIe atomics; every writer stores the same 1)
+        if (bad && threadIdx.x == 0) __hip_atomic_store(a.bad_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // the tile writes nothing
     }
     return bad;
 }
@@ -1038,7 +1040,9 @@ struct clhip_rx_pipe {
     int cur;
     unsigned long long n_total;    // inputs consumed so far (per stream)
     unsigned long long undo_n_total; bool can_undo;   // pre-call state of the last run (clhip_rx_pipe_rollback)
-    int32_t *d_flag, *h_flag;      // clhip_rx_pipe_run_smi: device-side sync verdict and its pinned host mirror
+    int32_t *d_flag, *h_flag;      // clhip_rx_pipe_run_smi: the device-side sync verdict, a word of pinned host memory the kernel
+    bool flag_mapped;              //  stores to directly (d_flag = its device address); if the device cannot reach it, a device word + copy
+    bool offs_writeback;           // run_smi zeroes d_offs after an in-kernel verdict (off: the caller only reads h_offs)
     void *h_sink;                  // one-shot: the next run_smi also copies its outputs here (before its synchronisation)
     hipStream_t last_stream; bool last_stream_valid;   // where the last run was queued (reset waits for it)
     bool force_generic;
@@ -1097,6 +1101,7 @@ extern "C" clhip_rx_pipe *clhip_rx_pipe_create(int n_streams, int channel, const
     clhip_rx_pipe *p = new (std::nothrow) clhip_rx_pipe();
     if (!p) return nullptr;
     memset(p, 0, sizeof *p);
+    p->offs_writeback = true;
     p->n_streams = n_streams; p->channel = channel; p->T = n_fir; p->L = up; p->M = down;
     p->n_rs = resamp ? n_rs : 0; p->mode = out_mode;
     memcpy(p->fir, h_fir, sizeof(float) * n_fir);
@@ -1158,7 +1163,8 @@ extern "C" void clhip_rx_pipe_destroy(clhip_rx_pipe *p)
     clhip_free(p->hist[0]); clhip_free(p->hist[1]);
     clhip_free(p->d_fir); clhip_free(p->d_fir_int); clhip_free(p->d_rs); clhip_free(p->d_fir_pad); clhip_free(p->d_ffa); clhip_free(p->d_ffa_int);
     clhip_free(p->X); clhip_free(p->Y); clhip_free(p->queue);
-    clhip_free(p->d_flag); clhip_host_free(p->h_flag);
+    if (!p->flag_mapped) clhip_free(p->d_flag);
+    clhip_host_free(p->h_flag);
     delete p;
 }
 
@@ -1180,6 +1186,7 @@ extern "C" void clhip_rx_pipe_seek(clhip_rx_pipe *p, unsigned long long n_total)
 // the stream of that run (its kernels may still be writing the other history buffer).
 extern "C" size_t clhip_rx_pipe_out_elem_bytes(const clhip_rx_pipe *p) { return p->mode == CL_PIPE_OUT_FM_DEMOD ? sizeof(float) : sizeof(f32x2); }
 extern "C" void clhip_rx_pipe_set_host_sink(clhip_rx_pipe *p, void *h_out) { if (p) p->h_sink = h_out; }
+extern "C" void clhip_rx_pipe_set_offs_writeback(clhip_rx_pipe *p, int on) { if (p) p->offs_writeback = on != 0; }
 
 extern "C" int clhip_rx_pipe_rollback(clhip_rx_pipe *p)
 {
@@ -1420,9 +1427,12 @@ extern "C" long clhip_rx_pipe_run_smi(clhip_rx_pipe *p, const uint8_t *d_bytes, 
     hipStream_t s = (hipStream_t)stream;
     const int n_chunks = (int)clhip_div_up(n_bytes, chunk_len_bytes);
     if (!p->d_flag) {
-        p->d_flag = (int32_t *)clhip_malloc(sizeof(int32_t));
         p->h_flag = (int32_t *)clhip_host_alloc(sizeof(int32_t));
-        if (!p->d_flag || !p->h_flag) return -1;
+        if (!p->h_flag) return -1;
+        p->d_flag = (int32_t *)clhip_host_device_ptr(p->h_flag);
+        p->flag_mapped = p->d_flag != nullptr;
+        if (!p->flag_mapped) p->d_flag = (int32_t *)clhip_malloc(sizeof(int32_t));
+        if (!p->d_flag) return -1;
     }
     const size_t chunk_samples = chunk_len_bytes / 4;
     const bool dev_check = (chunk_samples & (chunk_samples - 1)) == 0 && (n_bytes & 3) == 0 && ((uintptr_t)d_bytes & 15) == 0;
@@ -1443,20 +1453,22 @@ extern "C" long clhip_rx_pipe_run_smi(clhip_rx_pipe *p, const uint8_t *d_bytes, 
     if (dev_check) {
         // the generic kernels do not look at the chunk table: a call that takes them is judged from the table itself
         const bool flag_valid = clhip_rx_pipe_uses_fused(p, n_in, CL_PIPE_IN_SMI_WORDS) != 0;
-        CLHIP_CHECK(hipMemsetAsync(p->d_flag, 0, sizeof(int32_t), s));
+        // (every earlier launch that could raise the flag has been synchronised with: this function always does)
+        if (p->flag_mapped) *(volatile int32_t *)p->h_flag = 0;
+        else CLHIP_CHECK(hipMemsetAsync(p->d_flag, 0, sizeof(int32_t), s));
         clhip_rx_pipe_set_sync_check(p, in_kernel ? nullptr : d_offs, chunk_samples, p->d_flag);
         got = clhip_rx_pipe_run(p, CL_PIPE_IN_SMI_WORDS, d_bytes, stream_stride_bytes / 4, n_in, d_out, out_stride, stream);
         p->chk_offs = keep_offs; p->chk_chunk_samples = keep_cs; p->chk_flag = keep_flag;
         if (got < 0) return -1;
-        CLHIP_CHECK(hipMemcpyAsync(p->h_flag, p->d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        if (!p->flag_mapped) CLHIP_CHECK(hipMemcpyAsync(p->h_flag, p->d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         // the outputs ride out under the same synchronisation (speculatively: a redo below overwrites all of them)
         if (sink && got > 0) CLHIP_CHECK(hipMemcpyAsync(sink, d_out, (size_t)got * ob, hipMemcpyDeviceToHost, s));
         CLHIP_CHECK(hipStreamSynchronize(s));
-        redo = !flag_valid || *p->h_flag != 0;
+        redo = !flag_valid || *(volatile int32_t *)p->h_flag != 0;
     }
     if (!redo) {
         if (h_offs) memset(h_offs, 0, sizeof(int32_t) * (size_t)n_chunks * p->n_streams);
-        if (in_kernel) CLHIP_CHECK(hipMemsetAsync(d_offs, 0, sizeof(int32_t) * (size_t)n_chunks * p->n_streams, s));   // what the search would have written
+        if (in_kernel && p->offs_writeback) CLHIP_CHECK(hipMemsetAsync(d_offs, 0, sizeof(int32_t) * (size_t)n_chunks * p->n_streams, s));   // what the search would have written
         return got;
     }
     if (in_kernel && search()) return -1;                   // now the byte-granular search

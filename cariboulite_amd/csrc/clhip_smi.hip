@@ -265,6 +265,69 @@ extern "C" int clhip_smi_unpack(int channel, const uint8_t *d_bytes, size_t tota
     return 0;
 }
 
+// One read() chunk the caller KNOWS to be in sync (caribou_smi_find_buffer_offset returns 0 exactly when the chunk's words at
+// byte offsets 0, 4, 8, 12 carry the sync pattern, and the host has looked at them in its pinned staging memory): no search,
+// every slot is written, and the samples leave twice in one pass -- as int16 pairs into the persistent native buffer
+// (what the Stream's interm buffer holds for the calls that follow) and, in the client's format, into `out`, which may be
+// mapped pinned HOST memory: the stores then cross PCIe themselves and the call needs no device-to-host copy.
+template <int FMT>
+__global__ __launch_bounds__(256) void smi_unpack_aligned_kernel(int channel, const u32x4 *__restrict__ words, size_t n_groups,
+                                                                typename OutElem<FMT>::type *__restrict__ out, u32x4 *__restrict__ cs16)
+{
+    typedef typename OutElem<FMT>::type elem_t;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += (size_t)gridDim.x * blockDim.x) {
+        const u32x4 w = __builtin_nontemporal_load(words + g);
+        elem_t e[4];
+        u32x4 c;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            int i, q;
+            unpack_word(w[t], channel, i, q);
+            e[t] = make_elem<FMT>(i, q);
+            c[t] = ((uint32_t)i & 0xFFFFu) | ((uint32_t)q << 16);
+        }
+        if (cs16) cs16[g] = c;
+        if constexpr (FMT == CL_FORMAT_CS16) {
+            *((u32x4 *)out + g) = c;
+        } else if constexpr (sizeof(elem_t) == 2) {
+            u32x2 v = {(uint32_t)e[0] | ((uint32_t)e[1] << 16), (uint32_t)e[2] | ((uint32_t)e[3] << 16)};
+            *((u32x2 *)out + g) = v;
+        } else if constexpr (sizeof(elem_t) == 8) {
+            f32x4 v0 = {e[0].x, e[0].y, e[1].x, e[1].y}, v1 = {e[2].x, e[2].y, e[3].x, e[3].y};
+            *((f32x4 *)out + 2 * g) = v0;
+            *((f32x4 *)out + 2 * g + 1) = v1;
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; t++) out[4 * g + t] = e[t];
+        }
+    }
+}
+
+extern "C" int clhip_smi_unpack_aligned(int channel, const uint8_t *d_bytes, size_t n_bytes, int format, void *out, int16_t *d_cs16,
+                                        void *stream)
+{
+    if (n_bytes == 0) return 0;
+    if (!d_bytes || !out || (n_bytes & 15) || (((uintptr_t)d_bytes | (uintptr_t)out | (uintptr_t)d_cs16) & 15)) {
+        clhip_set_error("clhip_smi_unpack_aligned: 16-byte aligned buffers and a multiple of 4 samples");
+        return -1;
+    }
+    const size_t n_groups = n_bytes / 16;
+    unsigned grid = (unsigned)clhip_div_up(n_groups, 256);
+    if (grid > 2048) grid = 2048;
+    hipStream_t s = (hipStream_t)stream;
+    const u32x4 *w = (const u32x4 *)d_bytes;
+    u32x4 *c = (u32x4 *)d_cs16;
+    switch (format) {
+    case CL_FORMAT_CS16: hipLaunchKernelGGL(smi_unpack_aligned_kernel<CL_FORMAT_CS16>, dim3(grid), dim3(256), 0, s, channel, w, n_groups, (OutElem<CL_FORMAT_CS16>::type *)out, c); break;
+    case CL_FORMAT_CF32: hipLaunchKernelGGL(smi_unpack_aligned_kernel<CL_FORMAT_CF32>, dim3(grid), dim3(256), 0, s, channel, w, n_groups, (OutElem<CL_FORMAT_CF32>::type *)out, c); break;
+    case CL_FORMAT_CS8: hipLaunchKernelGGL(smi_unpack_aligned_kernel<CL_FORMAT_CS8>, dim3(grid), dim3(256), 0, s, channel, w, n_groups, (OutElem<CL_FORMAT_CS8>::type *)out, c); break;
+    case CL_FORMAT_CF64: hipLaunchKernelGGL(smi_unpack_aligned_kernel<CL_FORMAT_CF64>, dim3(grid), dim3(256), 0, s, channel, w, n_groups, (OutElem<CL_FORMAT_CF64>::type *)out, c); break;
+    default: clhip_set_error("clhip_smi_unpack_aligned: unknown format %d", format); return -1;
+    }
+    CLHIP_CHECK_LAUNCH();
+    return 0;
+}
+
 // ---------------------------------------------------------------------------
 // CS16 <-> other formats
 // ---------------------------------------------------------------------------

@@ -55,6 +55,8 @@ typedef struct {
     int32_t offs;       /* sync offset found on the GPU (-1 = none)                    */
 } cl_chunk;
 
+#define CL_FAST_NATIVE_ONLY ((void *)(uintptr_t)1)
+
 struct cl_smi {
     int device;
     void *stream;                 /* hipStream_t of this SMI instance */
@@ -90,6 +92,10 @@ struct cl_smi {
     int ra_pending; size_t ra_samples;     /* between cl_smi_ra_launch and cl_smi_ra_finish */
     int ra_certain, stage_certain;         /* the host has seen the sync pattern at the head of every chunk of the call */
     size_t inplace_len;                    /* bytes of a one-read() call staged in place on `stream`: confirmed once that stream has been synchronised */
+    /* cl_smi_ra_launch's short cut for a call that is ONE read() the host has seen to be in sync: set fast_out (device-visible
+     * address of the caller's pinned mirror) + fast_format before the call; fast_used says whether it was taken */
+    void *fast_out; int fast_format, fast_used;   /* fast_out = CL_FAST_NATIVE_ONLY: only the int16 buffer (a device stage of the caller follows) */
+    void *pipe_out_used;                   /* cl_smi_read_pipe_device: d_out or d_out_certain, whichever took the outputs */
     /* statistics (SURVEY.md section 5 "Metrics"): */
     uint64_t stat_samples, stat_resyncs, stat_sync_failures, stat_timeouts, stat_io_errors, stat_written;
     char err[256];
@@ -102,7 +108,8 @@ int cl_smi_read_device(cl_smi *dev, int channel, size_t length_samples, int want
 /* the same chunk loop with results in caller-owned DEVICE buffers (NULL = the seam's own / no metadata) */
 int cl_smi_read_device_to(cl_smi *dev, int channel, size_t length_samples, int16_t *d_iq, uint8_t *d_meta, int *all_aligned);
 /* the same chunk loop feeding an RX pipe straight from the staged raw words (fused launch + device-side sync verdict) */
-int cl_smi_read_pipe_device(cl_smi *dev, int channel, size_t length_samples, clhip_rx_pipe *pipe, void *d_out, long *n_out, void *h_out);
+int cl_smi_read_pipe_device(cl_smi *dev, int channel, size_t length_samples, clhip_rx_pipe *pipe, void *d_out, long *n_out, void *h_out,
+                            void *d_out_certain);
 /* the same chunk loop, one chunk at a time, with the next read() staged and copied ahead (reader threads) */
 int cl_smi_read_device_ra(cl_smi *dev, int channel, size_t length_samples, int16_t *d_iq);
 long cl_smi_ra_launch(cl_smi *dev, int channel, size_t length_samples, int16_t *d_iq);   /* its two halves: the caller may queue */

@@ -13,8 +13,11 @@
  * The ring never touches sample data on the device path: cl_ring_put_begin / cl_ring_get_begin hand out a SPAN --
  * at most two linear pieces of the storage -- and the caller moves the data with whatever engine owns it
  * (hipMemcpyAsync device-to-device on its HIP stream, a kernel, memcpy) before calling the matching _end.  The
- * mutex is held from _begin to _end, so a writer that overwrites the oldest elements cannot race a reader that
- * is still copying them out.  cl_ring_put / cl_ring_get are the one-call forms with host data on either kind
+ * mutex is NOT held in between (the data movement includes a stream synchronisation: tens of microseconds during which
+ * the other side would stand still): an open put owns the elements behind `written`, which no get can see before
+ * _end publishes them; an open get owns the oldest elements, and the one thing that could touch those -- a put that
+ * has to displace the oldest elements of a full ring -- waits for the get to end.  One producer, one consumer.
+ * cl_ring_put / cl_ring_get are the one-call forms with host data on either kind
  * of storage; their observable behaviour (accepted / returned counts, order, fill level) replays the op
  * sequences recorded from the reference's template (tests/golden/ring_cases.npz).
  */
@@ -29,12 +32,14 @@ struct cl_ring {
     int on_device, device;
     size_t elem, cap;            /* cap is a power of two */
     uint64_t written, released;  /* written - released = elements held, never more than cap */
-    uint64_t released_before_put;/* what `released` was when the open cl_ring_put_begin took the lock */
+    int put_open, get_open;      /* a span is handed out and its _end has not been called yet */
+    uint64_t released_before_put, released_after_drop;   /* around the displacement of the open put (cl_ring_put_cancel) */
     int drop_oldest;             /* a put that does not fit discards the oldest elements instead of being cut */
     int whole_requests;          /* a get waits for its full length and yields nothing otherwise */
     void *xfer;                  /* HIP stream of the host-data convenience calls on device storage */
     pthread_mutex_t mu;
-    pthread_cond_t grown;
+    pthread_cond_t grown;        /* a put was published (whole-request gets wait for it) */
+    pthread_cond_t get_done;     /* an open get ended (a displacing put waits for it) */
 };
 
 static cl_ring *ring_new(size_t size_elems, size_t elem_bytes, int override_write, int block_read, int on_device, int device)
@@ -58,6 +63,7 @@ static cl_ring *ring_new(size_t size_elems, size_t elem_bytes, int override_writ
     }
     pthread_mutex_init(&r->mu, NULL);
     pthread_cond_init(&r->grown, NULL);
+    pthread_cond_init(&r->get_done, NULL);
     return r;
 }
 
@@ -82,6 +88,7 @@ void cl_ring_destroy(cl_ring *r)
     } else
         free(r->store);
     pthread_cond_destroy(&r->grown);
+    pthread_cond_destroy(&r->get_done);
     pthread_mutex_destroy(&r->mu);
     free(r);
 }
@@ -100,43 +107,64 @@ static void ring_span(const cl_ring *r, uint64_t at, size_t count, cl_ring_span 
 }
 
 /* Reserve room for `length` elements.  When they do not fit: a drop_oldest ring releases just enough of its
- * oldest elements (circular_buffer.h:41-45), any other ring accepts only what fits (:47).  Returns the number
- * accepted and their span; the ring stays locked until cl_ring_put_end. */
+ * oldest elements (circular_buffer.h:41-45) -- after an open get, which owns exactly those, has ended -- any other
+ * ring accepts only what fits (:47).  Returns the number accepted and their span; nobody sees them before
+ * cl_ring_put_end. */
 size_t cl_ring_put_begin(cl_ring *r, size_t length, cl_ring_span *sp)
 {
     pthread_mutex_lock(&r->mu);
-    r->released_before_put = r->released;
     size_t held = (size_t)(r->written - r->released);
+    r->released_before_put = r->released;
     if (r->drop_oldest && length > r->cap - held) {
-        size_t drop = length - (r->cap - held);
-        if (drop > held) drop = held;                  /* a request beyond the capacity keeps its first cap elements */
-        r->released += drop;
-        held -= drop;
+        while (r->get_open) pthread_cond_wait(&r->get_done, &r->mu);
+        held = (size_t)(r->written - r->released);
+        r->released_before_put = r->released;
+        if (length > r->cap - held) {
+            size_t drop = length - (r->cap - held);
+            if (drop > held) drop = held;              /* a request beyond the capacity keeps its first cap elements */
+            r->released += drop;
+            held -= drop;
+        }
     }
+    r->released_after_drop = r->released;
     const size_t take = length < r->cap - held ? length : r->cap - held;
     ring_span(r, r->written, take, sp);
+    r->put_open = 1;
+    pthread_mutex_unlock(&r->mu);
     return take;
 }
 
 void cl_ring_put_end(cl_ring *r, size_t accepted)
 {
+    pthread_mutex_lock(&r->mu);
     r->written += accepted;
+    r->put_open = 0;
     if (r->whole_requests) pthread_cond_signal(&r->grown);
     pthread_mutex_unlock(&r->mu);
 }
 
-/* Give up an open put: nothing is published and the elements it would have displaced are held again (nobody
- * saw them released: the ring was locked throughout). */
+/* Give up an open put whose span has NOT been written to: nothing is published, and the elements a full ring displaced
+ * for it are held again -- unless a get has claimed elements in the meantime (then they stay displaced). */
 void cl_ring_put_cancel(cl_ring *r)
 {
-    r->released = r->released_before_put;
+    pthread_mutex_lock(&r->mu);
+    if (!r->get_open && r->released == r->released_after_drop) r->released = r->released_before_put;
+    r->put_open = 0;
+    pthread_mutex_unlock(&r->mu);
+}
+
+/* Give up an open put whose span may have been written to (a copy was queued before the caller learnt that it has to give
+ * up): nothing is published; what a full ring displaced for it is gone, its slots may hold the abandoned data. */
+void cl_ring_put_abandon(cl_ring *r)
+{
+    pthread_mutex_lock(&r->mu);
+    r->put_open = 0;
     pthread_mutex_unlock(&r->mu);
 }
 
 /* Claim up to `length` of the oldest elements.  whole_requests: wait up to timeout_us until all `length` are
  * held; if they never are, nothing is claimed and what is held stays queued (circular_buffer.h:68-82).  Returns
- * the number claimed and their span; 0 = nothing claimed and the ring is NOT locked; otherwise it stays locked
- * until cl_ring_get_end. */
+ * the number claimed and their span (0 = nothing claimed); the elements stay the caller's until cl_ring_get_end. */
 size_t cl_ring_get_begin(cl_ring *r, size_t length, int timeout_us, cl_ring_span *sp)
 {
     pthread_mutex_lock(&r->mu);
@@ -155,12 +183,17 @@ size_t cl_ring_get_begin(cl_ring *r, size_t length, int timeout_us, cl_ring_span
     const size_t take = length < held ? length : held;
     if (!take) { pthread_mutex_unlock(&r->mu); return 0; }
     ring_span(r, r->released, take, sp);
+    r->get_open = 1;
+    pthread_mutex_unlock(&r->mu);
     return take;
 }
 
 void cl_ring_get_end(cl_ring *r, size_t claimed)
 {
+    pthread_mutex_lock(&r->mu);
     r->released += claimed;
+    r->get_open = 0;
+    pthread_cond_broadcast(&r->get_done);
     pthread_mutex_unlock(&r->mu);
 }
 

@@ -486,9 +486,14 @@ int cl_smi_read_device_to(cl_smi *dev, int channel, size_t length_samples, int16
  * above; when they form one contiguous word sequence the pipe runs straight from the raw bytes
  * (clhip_rx_pipe_run_smi: per-chunk sync search + ONE fused launch, verdict checked on the device, re-sync and "-3"
  * handled with the reference's semantics); otherwise the chunks are unpacked first and the pipe runs from int16.
- * *n_out = outputs the pipe produced (left in d_out, complete).  Returns samples consumed, 0, or CL_SMI_ERR_*. */
-int cl_smi_read_pipe_device(cl_smi *dev, int channel, size_t length_samples, clhip_rx_pipe *pipe, void *d_out, long *n_out, void *h_out)
+ * *n_out = outputs the pipe produced (left in d_out, complete).  d_out_certain (may be NULL): where the outputs go INSTEAD
+ * when the host has seen every chunk of the call in sync, i.e. the call will deliver -- memory the client can see (its own
+ * registered buffer, a mapped mirror); h_out is then left alone.  dev->pipe_out_used says which of the two took them.
+ * Returns samples consumed, 0, or CL_SMI_ERR_*. */
+int cl_smi_read_pipe_device(cl_smi *dev, int channel, size_t length_samples, clhip_rx_pipe *pipe, void *d_out, long *n_out, void *h_out,
+                            void *d_out_certain)
 {
+    dev->pipe_out_used = d_out;
     const size_t out_bytes = clhip_rx_pipe_out_elem_bytes(pipe);
     clhip_set_device(dev->device);
     cl_smi_readahead_cancel(dev);
@@ -517,9 +522,11 @@ int cl_smi_read_pipe_device(cl_smi *dev, int channel, size_t length_samples, clh
     const size_t total = last->stage_off + last->len, nb = dev->native_batch_len;
     /* every chunk known to be in sync: the outputs leave for the client's buffer under run_smi's own synchronisation;
      * otherwise the client's buffer is only written once the call is known to deliver (a lost chunk delivers nothing) */
-    const int direct = h_out && dev->stage_certain;
+    const int zc = d_out_certain && dev->stage_certain;
+    const int direct = !zc && h_out && dev->stage_certain;
     clhip_rx_pipe_set_host_sink(pipe, direct ? h_out : NULL);
-    long got = clhip_rx_pipe_run_smi(pipe, dev->d_bytes, 0, total, nb, dev->d_offs, dev->h_offs, NULL, d_out, 0, dev->stream);
+    clhip_rx_pipe_set_offs_writeback(pipe, 0);                 /* the verdict is read from h_offs */
+    long got = clhip_rx_pipe_run_smi(pipe, dev->d_bytes, 0, total, nb, dev->d_offs, dev->h_offs, NULL, zc ? d_out_certain : d_out, 0, dev->stream);
     smi_inplace_done(dev, got >= 0 || got == CL_SMI_ERR_SYNC || got == CL_PIPE_ERR_RESYNC);     /* run_smi synchronises the stream on those returns */
     if (got < 0 && got != CL_SMI_ERR_SYNC && got != CL_PIPE_ERR_RESYNC) return CL_SMI_ERR_IO;
     const int v = smi_call_verdict(dev, NULL);
@@ -546,7 +553,8 @@ int cl_smi_read_pipe_device(cl_smi *dev, int channel, size_t length_samples, clh
         if (h_out && got > 0 && clhip_memcpy_d2h(h_out, d_out, (size_t)got * out_bytes, dev->stream)) return CL_SMI_ERR_IO;
         if (clhip_stream_sync(dev->stream)) return CL_SMI_ERR_IO;
     } else {
-        if (h_out && !direct && got > 0 &&
+        if (zc) dev->pipe_out_used = d_out_certain;
+        else if (h_out && !direct && got > 0 &&
             (clhip_memcpy_d2h(h_out, d_out, (size_t)got * out_bytes, dev->stream) || clhip_stream_sync(dev->stream))) return CL_SMI_ERR_IO;
         /* fused route: keep these raw words until the next call has been through */
         uint8_t *tb = dev->d_bytes; dev->d_bytes = dev->d_bytes_prev; dev->d_bytes_prev = tb;
@@ -634,6 +642,7 @@ long cl_smi_ra_launch(cl_smi *dev, int channel, size_t length_samples, int16_t *
     clhip_set_device(dev->device);
     const size_t nb = dev->native_batch_len;
     dev->ra_pending = 0;
+    dev->fast_used = 0;
     dev->ra_certain = 1;                                       /* every read() of the call known to be in sync, whole samples */
     if (!dev->cstream) {
         dev->cstream = clhip_stream_create();
@@ -684,6 +693,24 @@ long cl_smi_ra_launch(cl_smi *dev, int channel, size_t length_samples, int16_t *
         int ahead_ok = 0;
         const size_t a = ra_stage(dev, slot ^ 1, want_next, &ahead_ok);
         if (a) { dev->ahead.valid = 1; dev->ahead.slot = slot ^ 1; dev->ahead.len = a; dev->ahead.head_ok = ahead_ok; }
+        if (dev->fast_out && read_so_far == 0 && got == left && head_ok && !(got & 15)) {
+            /* The call is this one read(), and the host has seen the sync pattern on its first four words: offset 0
+             * (caribou_smi.c:235-292) without asking the device, every slot written.  One launch unpacks it into the
+             * persistent int16 buffer AND, in the caller's format, straight into the caller's pinned mirror: no search
+             * launch, no offset read-back, no conversion launch, no device-to-host copy. */
+            void *fo = dev->fast_out;
+            dev->fast_out = NULL;
+            if (clhip_stream_wait_event(dev->stream, dev->ev_copied[slot]) ||
+                (fo == CL_FAST_NATIVE_ONLY ? clhip_smi_unpack_aligned(channel, dev->d_slot[slot], got, CL_FORMAT_CS16, d_iq, NULL, dev->stream)
+                                           : clhip_smi_unpack_aligned(channel, dev->d_slot[slot], got, dev->fast_format, fo, d_iq, dev->stream)))
+                return CL_SMI_ERR_IO;
+            dev->h_offs[0] = 0;
+            dev->fast_used = 1;
+            cl_chunk *c = &dev->chunks[dev->n_chunks];
+            c->stage_off = 0; c->len = got; c->slot0 = 0; c->offs = 0;
+            dev->ra_pending = 1; dev->ra_samples = got / CL_BYTES_PER_SAMPLE;
+            return (long)dev->ra_samples;
+        }
         if (clhip_stream_wait_event(dev->stream, dev->ev_copied[slot]) ||
             clhip_smi_find_offsets(dev->d_slot[slot], got, nb, nb, 1, dev->d_offs, dev->stream) ||
             clhip_smi_unpack(channel, dev->d_slot[slot], got, nb, nb, 1, dev->d_offs, CL_FORMAT_CS16, d_iq + 2 * read_so_far, NULL, dev->stream) ||
@@ -709,6 +736,7 @@ long cl_smi_ra_launch(cl_smi *dev, int channel, size_t length_samples, int16_t *
 
 int cl_smi_ra_finish(cl_smi *dev)
 {
+    dev->fast_out = NULL;
     if (!dev->ra_pending) return 0;
     dev->ra_pending = 0;
     if (clhip_stream_sync(dev->stream)) return smi_count(dev, CL_SMI_ERR_IO);

@@ -13,6 +13,7 @@
 
 #define DIG_FILT_ORDER 6     /* CaribouliteStream.hpp:24 */
 #define NUM_NATIVE_MTUS_PER_QUEUE 10   /* CaribouliteStream.cpp:8 */
+#define CL_ZC_SLOTS 8                  /* client buffers a ZEROCOPY stream keeps registered */
 
 typedef struct {
     int enabled;
@@ -36,6 +37,9 @@ struct cl_stream {
     cl_stream_stats stats;               /* (iir_overruns: calls the single-pass kernel gave up on; each was repeated on the scan path) */
     void *d_conv; size_t conv_cap;       /* converted output / TX input staging (bytes) */
     void *h_conv; size_t h_conv_cap;     /* pinned host mirror */
+    int zero_copy;                       /* kwarg ZEROCOPY=1: client buffers are registered with the GPU and written by the last kernel */
+    struct { uint8_t *base, *dev; size_t len; } zc[CL_ZC_SLOTS];
+    int zc_n, zc_next;
     cl_dsp_cfg dsp;
     clhip_rx_pipe *rx_pipe;
     clhip_tx_pipe *tx_pipe;
@@ -150,6 +154,7 @@ static void *reader_thread_fn(void *arg)
         if (ret < 0) ret = 0;                                            /* :34-42 */
         if (put_open) {
             if (ret == expect && room) cl_ring_put_end(st->rx_queue, room);
+            else if (room) cl_ring_put_abandon(st->rx_queue);            /* the copy into the span was queued already */
             else cl_ring_put_cancel(st->rx_queue);
         } else if (ret > 0) {                                            /* (a call whose last read() was already waited for) */
             size_t n = cl_ring_put_begin(st->rx_queue, (size_t)ret, &sp);
@@ -161,6 +166,8 @@ static void *reader_thread_fn(void *arg)
     cl_smi_readahead_cancel(smi);
     return NULL;
 }
+
+static void zc_drop_all(cl_stream *st);
 
 static void stream_stop_async(cl_stream *st)
 {
@@ -181,6 +188,8 @@ static void stream_free(cl_stream *st)
     if (!st) return;
     stream_stop_async(st);
     for (int i = 0; i < 3; i++) clhip_iir_destroy(st->iir[i]);
+    if (st->dev && st->dev->smi) clhip_stream_sync(st->dev->smi->stream);
+    zc_drop_all(st);
     clhip_free(st->d_filt); clhip_free(st->d_conv); clhip_host_free(st->h_conv);
     if (st->rx_pipe) clhip_rx_pipe_destroy(st->rx_pipe);
     if (st->tx_pipe) clhip_tx_pipe_destroy(st->tx_pipe);
@@ -341,6 +350,10 @@ cl_stream *cl_setupStream(cl_device *dev, int direction, const char *format, con
     }
     st->stream_active = 0;                             /* :137 activate_channel(..., false) */
     stream_stop_async(st);
+    clhip_stream_sync(dev->smi->stream);
+    zc_drop_all(st);
+    const char *zc = kw(keys, vals, n_kwargs, "ZEROCOPY");
+    st->zero_copy = zc && !strcmp(zc, "1") && st->native_dir == CL_SOAPY_SDR_RX;
     const char *as = kw(keys, vals, n_kwargs, "ASYNC");
     if (as && !strcmp(as, "1") && st->native_dir == CL_SOAPY_SDR_RX) {
         /* rx_queue(mtu * NUM_NATIVE_MTUS_PER_QUEUE, override writes, blocking reads)  :70-75 */
@@ -395,8 +408,9 @@ static int read_native_device(cl_stream *st, size_t n, int *aligned, long timeou
     cl_smi *smi = st->dev->smi;
     if (st->use_async) {
         /* Stream::Read with USE_ASYNC: rx_queue->get(buffer, num_samples, timeout_us)  :262-263.  The popped samples
-         * move device-to-device into the consumer's linear buffer (the ring stays locked until the copy is done:
-         * the reader thread may overwrite the oldest slots), and every later stage reads them there. */
+         * move device-to-device into the consumer's linear buffer (the claimed span stays this call's until get_end --
+         * the reader thread's puts go on meanwhile, only one that would have to displace these very elements waits),
+         * and every later stage reads them there. */
         if (cl_ensure((void **)&st->d_aiq, &st->aiq_cap, n + 8, 4, 0)) return 0;
         cl_ring_span sp;
         const size_t claimed = cl_ring_get_begin(st->rx_queue, n, (int)timeout_us, &sp);
@@ -436,12 +450,92 @@ static int read_native_device(cl_stream *st, size_t n, int *aligned, long timeou
  * read exactly as the reference loop runs (slots it leaves untouched after a re-sync hold stale samples there too).
  * Out of place -- d_raw keeps the unfiltered samples, st->d_filt takes the result -- so that a call the single-pass
  * kernel gave up on can be made again.  Asynchronous on hs; the verdict is clhip_iir_status() after the synchronise. */
-static const int16_t *filter_native(cl_stream *st, const int16_t *d_raw, size_t n, void *hs)
+static const int16_t *filter_native(cl_stream *st, const int16_t *d_raw, size_t n, void *hs, int16_t *d_dst)
 {
     if (st->filter_type == CL_DIGFILT_NONE) return d_raw;
-    if (cl_ensure((void **)&st->d_filt, &st->filt_cap, n + 8, 4, 0)) return NULL;
-    if (clhip_iir_run(st->iir[st->filter_type - 1], d_raw, st->d_filt, n, n, hs)) return NULL;
-    return st->d_filt;
+    if (!d_dst) {
+        if (cl_ensure((void **)&st->d_filt, &st->filt_cap, n + 8, 4, 0)) return NULL;
+        d_dst = st->d_filt;
+    }
+    if (clhip_iir_run(st->iir[st->filter_type - 1], d_raw, d_dst, n, n, hs)) return NULL;
+    return d_dst;
+}
+
+/* ---- where the LAST device stage of a read stores its results, and how they reach the client's (pageable) buffer ----
+ * Host wall time of one native batch, launch to samples in the client's buffer (tools/microbench/ingest_shape.hip,
+ * profiles/r03/ingest_shape.txt; 4 / 8 / 12 output bytes per sample):
+ *   CL_SINK_CLIENT  the client's buffer itself, registered with the GPU on first use (stream kwarg ZEROCOPY=1: the client
+ *                   promises that a buffer it has passed stays mapped while the stream exists) -- the kernel's stores cross
+ *                   PCIe themselves, nothing is left to do after the synchronisation: 29 / 39 / 48 us;
+ *   CL_SINK_MIRROR  the stream's mapped pinned mirror, memcpy into the client's buffer after the synchronisation: 48 / 80 /
+ *                   107 us (the memcpy reads lines the device has just written: 12 us per 512 KiB, three times its warm rate);
+ *   CL_SINK_STAGED  a device buffer, copied by the copy engine into the pageable buffer before the synchronisation:
+ *                   58 / 91 / 65 us -- above 1 MiB the runtime pins the target in place instead of bouncing it, which
+ *                   is why this is the route for outputs larger than that. */
+enum { CL_SINK_CLIENT, CL_SINK_MIRROR, CL_SINK_STAGED };
+#define CL_MIRROR_MAX_BYTES ((size_t)1 << 20)
+typedef struct { int kind; void *d_dst; } cl_sink;
+
+static void *mirror_for(cl_stream *st, size_t bytes)
+{
+    if (cl_ensure((void **)&st->h_conv, &st->h_conv_cap, bytes + 64, 1, 1)) return NULL;
+    return clhip_host_device_ptr(st->h_conv);
+}
+
+/* ZEROCOPY=1: the address kernels use for the client's buffer (registering the pages it covers on first sight; a small
+ * table, oldest entry dropped first), or NULL: not asked for, misaligned for the 16-byte stores, or the runtime refused
+ * (e.g. the range overlaps an older registration only in part) -- the caller then takes one of the other routes. */
+static void zc_drop_all(cl_stream *st)
+{
+    for (int i = 0; i < st->zc_n; i++) clhip_host_unregister(st->zc[i].base);
+    st->zc_n = st->zc_next = 0;
+}
+
+static void *client_device_addr(cl_stream *st, void *out, size_t bytes)
+{
+    if (!st->zero_copy || !bytes || ((uintptr_t)out & 15)) return NULL;
+    uint8_t *p = (uint8_t *)out;
+    for (int i = 0; i < st->zc_n; i++)
+        if (p >= st->zc[i].base && p + bytes <= st->zc[i].base + st->zc[i].len) return st->zc[i].dev + (p - st->zc[i].base);
+    const uintptr_t pg = 4096, lo = (uintptr_t)p & ~(pg - 1), hi = ((uintptr_t)p + bytes + pg - 1) & ~(pg - 1);
+    int slot = st->zc_n;
+    if (slot == CL_ZC_SLOTS) { slot = st->zc_next; st->zc_next = (st->zc_next + 1) % CL_ZC_SLOTS; clhip_host_unregister(st->zc[slot].base); st->zc[slot].len = 0; }
+    uint8_t *dev = (uint8_t *)clhip_host_register((void *)lo, hi - lo);
+    if (!dev) {
+        if (slot < st->zc_n) { st->zc[slot] = st->zc[st->zc_n - 1]; st->zc_n--; st->zc_next = 0; }   /* the evicted entry is gone */
+        return NULL;
+    }
+    st->zc[slot].base = (uint8_t *)lo; st->zc[slot].len = hi - lo; st->zc[slot].dev = dev;
+    if (slot == st->zc_n) st->zc_n++;
+    st->stats.zero_copy_registrations++;
+    return dev + ((uintptr_t)p - lo);
+}
+
+static int sink_open(cl_stream *st, void *out, size_t bytes, cl_sink *sk)
+{
+    sk->d_dst = client_device_addr(st, out, bytes);
+    if (sk->d_dst) { sk->kind = CL_SINK_CLIENT; return 0; }
+    if (bytes <= CL_MIRROR_MAX_BYTES) {
+        sk->d_dst = mirror_for(st, bytes);
+        if (!st->h_conv) return -1;
+        if (sk->d_dst) { sk->kind = CL_SINK_MIRROR; return 0; }
+    }
+    if (cl_ensure(&st->d_conv, &st->conv_cap, bytes + 64, 1, 0)) return -1;
+    sk->kind = CL_SINK_STAGED; sk->d_dst = st->d_conv;
+    return 0;
+}
+
+/* before the synchronisation (hs = the stream the last stage was queued on) ... */
+static int sink_queue(const cl_sink *sk, void *out, size_t bytes, void *hs)
+{
+    return sk->kind == CL_SINK_STAGED && bytes ? clhip_memcpy_d2h(out, sk->d_dst, bytes, hs) : 0;
+}
+
+/* ... and after it, once the call is known to deliver */
+static void sink_deliver(cl_stream *st, const cl_sink *sk, void *out, size_t bytes)
+{
+    if (sk->kind == CL_SINK_MIRROR) memcpy(out, st->h_conv, bytes);
+    if (sk->kind == CL_SINK_CLIENT) st->stats.zero_copy_reads++;
 }
 
 /* after the synchronise: 0 = the filtered samples are good (or no filter ran); 1 = the call overran -- the filter's state
@@ -497,10 +591,30 @@ static int read_stream(cl_device *dev, cl_stream *st, void *const *buffs, size_t
          * last read() arrives with it and a failed read simply discards what was queued.  Host side: CS16 copies
          * exactly the slots the reference writes (caribou_smi.c:344-389), the other formats all of them. */
         const size_t eb = fmt_bytes(st->format);
-        if (cl_ensure((void **)&st->h_conv, &st->h_conv_cap, numElems * eb + 64, 1, 1) ||
+        cl_sink sk;
+        if (sink_open(st, out, numElems * eb, &sk) ||
+            cl_ensure((void **)&st->h_conv, &st->h_conv_cap, numElems * eb + 64, 1, 1) ||
             (st->format != CL_FORMAT_CS16 && cl_ensure(&st->d_conv, &st->conv_cap, numElems * 16 + 64, 1, 0)))
             return 0;
+        if (sk.kind == CL_SINK_STAGED) sk.d_dst = st->d_conv;              /* (the line above may have moved it) */
+        /* the short cut: a call that is one read() the host can see to be in sync is unpacked by ONE launch, in the
+         * client's format, straight into the sink (cl_smi_ra_launch): no search launch, no offset read-back, no conversion
+         * launch; what is left here is the one synchronisation and the sink's own last step */
+        static int fast_path = -1;
+        if (fast_path < 0) fast_path = getenv("CL_READ_FAST") ? atoi(getenv("CL_READ_FAST")) : 1;
+        smi->fast_out = fast_path ? sk.d_dst : NULL;
+        smi->fast_format = st->format;
         const long expect = cl_smi_ra_launch(smi, dev->channel, numElems, NULL);
+        smi->fast_out = NULL;
+        if (smi->fast_used) {
+            const int bad = expect > 0 ? sink_queue(&sk, out, (size_t)expect * eb, smi->stream) : 0;
+            int fr = cl_smi_ra_finish(smi);
+            if (bad) fr = CL_SMI_ERR_IO;
+            if (fr == CL_SMI_ERR_IO) printf("reader thread failed to read SMI!\n");      /* :270 */
+            if (fr <= 0) return 0;
+            sink_deliver(st, &sk, out, (size_t)fr * eb);
+            return fr;
+        }
         /* the staged bytes are in pinned host memory: when every chunk of the call starts with the sync pattern the
          * call WILL deliver `expect` samples into every slot (offset 0 <=> those four words), so the device-to-host
          * copy may target the client's buffer itself.  Otherwise it goes to the pinned mirror and the client's
@@ -540,43 +654,78 @@ static int read_stream(cl_device *dev, cl_stream *st, void *const *buffs, size_t
     }
     if (st->format == CL_FORMAT_CS16) {                /* :282-301, no MTU clamp */
         int aligned = 0;
-        int res = read_native_device(st, numElems, &aligned, timeoutUs);
-        if (res <= 0) return res;
-        if (st->use_async) {            /* one PCIe crossing: device -> pinned mirror -> the client's buffer */
-            if (aligned != 2) {
-                if (cl_ensure((void **)&st->h_conv, &st->h_conv_cap, (size_t)res * 4 + 64, 1, 1)) return 0;
-                for (int attempt = 0;; attempt++) {
-                    const int16_t *d_f = filter_native(st, st->d_aiq, (size_t)res, st->astream);
-                    if (!d_f || clhip_memcpy_d2h(st->h_conv, d_f, (size_t)res * 4, st->astream) || clhip_stream_sync(st->astream)) return 0;
-                    if (!filter_overran(dev, st)) break;
-                    if (attempt) return 0;
+        int res;
+        if (!st->use_async && st->filter_type != CL_DIGFILT_NONE && numElems && numElems <= st->mtu_size) {
+            /* One native batch through the low-pass: when the call is one read() the host can see to be in sync, the
+             * unpack launch and the filter launch are queued back to back and the call pays ONE synchronisation (the
+             * read's verdict arrives with it); the filter stores straight into the sink. */
+            smi->fast_out = CL_FAST_NATIVE_ONLY;
+            const long expect = cl_smi_ra_launch(smi, dev->channel, numElems, NULL);
+            smi->fast_out = NULL;
+            if (smi->fast_used && expect > 0) {
+                cl_sink sk;
+                const int bad = sink_open(st, out, (size_t)expect * 4, &sk) ||
+                                !filter_native(st, smi->d_iq, (size_t)expect, smi->stream, (int16_t *)sk.d_dst) ||
+                                sink_queue(&sk, out, (size_t)expect * 4, smi->stream);
+                int fr = cl_smi_ra_finish(smi);                              /* the synchronisation */
+                if (bad) fr = CL_SMI_ERR_IO;
+                if (fr == CL_SMI_ERR_IO) printf("reader thread failed to read SMI!\n");    /* :270 */
+                if (fr <= 0) return 0;
+                if (filter_overran(dev, st)) {                               /* made again, once, on the scan path */
+                    if (!filter_native(st, smi->d_iq, (size_t)fr, smi->stream, (int16_t *)sk.d_dst) ||
+                        sink_queue(&sk, out, (size_t)fr * 4, smi->stream) || clhip_stream_sync(smi->stream) || filter_overran(dev, st))
+                        return 0;
                 }
+                sink_deliver(st, &sk, out, (size_t)fr * 4);
+                return fr;
             }
+            res = (expect < 0 || !smi->ra_pending) ? (int)expect : cl_smi_ra_finish(smi);
+            if (res < 0) {
+                if (res == CL_SMI_ERR_IO) printf("reader thread failed to read SMI!\n");   /* :270 */
+                res = 0;                                                                    /* :266-276 */
+            }
+        } else
+            res = read_native_device(st, numElems, &aligned, timeoutUs);
+        if (res <= 0) return res;
+        if (st->use_async && aligned == 2) {        /* the ring's slots went straight to the pinned mirror */
             memcpy(out, st->h_conv, (size_t)res * 4);
             return res;
         }
-        if (st->filter_type == CL_DIGFILT_NONE) { if (cl_smi_copy_out(smi, (cl_sample_complex_int16 *)out, NULL, -1)) return 0; }
-        else {
-            for (int attempt = 0;; attempt++) {      /* a call the single-pass kernel gave up on is made again, once */
-                const int16_t *d_f = filter_native(st, smi->d_iq, (size_t)res, smi->stream);
-                if (!d_f || clhip_memcpy_d2h(out, d_f, (size_t)res * 4, smi->stream) || clhip_stream_sync(smi->stream)) return 0;
-                if (!filter_overran(dev, st)) break;
-                if (attempt) return 0;
-            }
+        if (!st->use_async && st->filter_type == CL_DIGFILT_NONE) { if (cl_smi_copy_out(smi, (cl_sample_complex_int16 *)out, NULL, -1)) return 0; return res; }
+        /* the filter (or, ASYNC without one, nothing) is the last device stage: its results go straight into the sink */
+        void *hs = st->use_async ? st->astream : smi->stream;
+        const int16_t *d_raw = st->use_async ? st->d_aiq : smi->d_iq;
+        cl_sink sk;
+        if (sink_open(st, out, (size_t)res * 4, &sk)) return 0;
+        for (int attempt = 0;; attempt++) {          /* a call the single-pass kernel gave up on is made again, once */
+            const int filt = st->filter_type != CL_DIGFILT_NONE;
+            const int16_t *d_f = filter_native(st, d_raw, (size_t)res, hs, filt ? (int16_t *)sk.d_dst : NULL);
+            if (!d_f) return 0;
+            if (!filt ? clhip_memcpy_d2h(sk.kind == CL_SINK_MIRROR ? st->h_conv : out, d_f, (size_t)res * 4, hs)
+                      : sink_queue(&sk, out, (size_t)res * 4, hs)) return 0;
+            if (clhip_stream_sync(hs)) return 0;
+            if (!filter_overran(dev, st)) break;
+            if (attempt) return 0;
         }
+        sink_deliver(st, &sk, out, (size_t)res * 4);
         return res;
     }
     if (numElems > st->mtu_size) numElems = st->mtu_size;                          /* :306,328,351 */
     if (st->rx_pipe && !st->use_async && st->filter_type == CL_DIGFILT_NONE) {
         /* extension stages straight from the staged raw words: no int16 intermediate, one fused launch, the sync
          * verdict checked on the device; re-sync / "-3" as caribou_smi_read has them (clhip_rx_pipe_run_smi) */
-        const size_t ob = st->dsp.demod_fm ? 4 : 8;
-        if (cl_ensure(&st->d_conv, &st->conv_cap, clhip_rx_pipe_out_count(st->rx_pipe, numElems) * ob + 64, 1, 0)) return 0;
+        const size_t ob = st->dsp.demod_fm ? 4 : 8, max_out = clhip_rx_pipe_out_count(st->rx_pipe, numElems) * ob;
+        cl_sink sk;
+        if (sink_open(st, out, max_out, &sk) || cl_ensure(&st->d_conv, &st->conv_cap, max_out + 64, 1, 0)) return 0;
         long got = 0;
-        /* the outputs are copied into the client's buffer under the pipe call's own synchronisation */
-        const int ret = cl_smi_read_pipe_device(smi, dev->channel, numElems, st->rx_pipe, st->d_conv, &got, out);
+        /* a call the host can see to be in sync stores its outputs straight into the client's registered buffer or the mapped
+         * mirror; any other call (and every output larger than the mirror route pays for) leaves them on the device and
+         * copies them into the client's buffer under the pipe call's own synchronisation, once it is known to deliver */
+        const int ret = cl_smi_read_pipe_device(smi, dev->channel, numElems, st->rx_pipe, st->d_conv, &got, out,
+                                                sk.kind != CL_SINK_STAGED ? sk.d_dst : NULL);
         if (ret == CL_SMI_ERR_IO) printf("reader thread failed to read SMI!\n");    /* :270 */
         if (ret <= 0 || got <= 0) return 0;                                         /* :266-276 */
+        if (sk.kind != CL_SINK_STAGED && smi->pipe_out_used == sk.d_dst) sink_deliver(st, &sk, out, (size_t)got * ob);
         return (int)got;
     }
     int aligned = 0;
@@ -588,31 +737,33 @@ static int read_stream(cl_device *dev, cl_stream *st, void *const *buffs, size_t
     if (st->filter_type != CL_DIGFILT_NONE) aligned = 0;              /* filtered samples: the fused raw-word path no longer applies */
     /* everything behind the native read is queued on one stream and synchronised once; if the filter's verdict then says
      * the single-pass kernel gave up, its state is already back where it was: the stages are queued again, once */
+    const size_t ob = st->rx_pipe ? (st->dsp.demod_fm ? 4 : 8) : fmt_bytes(st->format);
+    const size_t max_out = (st->rx_pipe ? clhip_rx_pipe_out_count(st->rx_pipe, n) : n) * ob;
+    cl_sink sk;                                                       /* the last stage stores straight into the sink */
+    if (sink_open(st, out, max_out, &sk)) return 0;
     for (int attempt = 0;; attempt++) {
-        const int16_t *d_iq = filter_native(st, d_raw, n, hs);
+        const int16_t *d_iq = filter_native(st, d_raw, n, hs, NULL);
         if (!d_iq) return 0;
+        long got;
         if (st->rx_pipe) {
             /* extension stages where a client of readStream(CF32) would apply them */
-            const size_t n_out = clhip_rx_pipe_out_count(st->rx_pipe, n);
-            const size_t ob = st->dsp.demod_fm ? 4 : 8;
-            if (cl_ensure(&st->d_conv, &st->conv_cap, n_out * ob + 64, 1, 0)) return 0;
-            long got;
             if (aligned)   /* every chunk in sync: one fused launch straight from the raw SMI words */
-                got = clhip_rx_pipe_run(st->rx_pipe, CL_PIPE_IN_SMI_WORDS, smi->d_bytes, 0, n, st->d_conv, 0, hs);
+                got = clhip_rx_pipe_run(st->rx_pipe, CL_PIPE_IN_SMI_WORDS, smi->d_bytes, 0, n, sk.d_dst, 0, hs);
             else           /* re-synchronised, IIR-filtered or popped from the ring: from the native int16 samples */
-                got = clhip_rx_pipe_run(st->rx_pipe, CL_PIPE_IN_CS16, d_iq, 0, n, st->d_conv, 0, hs);
+                got = clhip_rx_pipe_run(st->rx_pipe, CL_PIPE_IN_CS16, d_iq, 0, n, sk.d_dst, 0, hs);
             if (got < 0) return 0;
-            if (clhip_memcpy_d2h(out, st->d_conv, (size_t)got * ob, hs) || clhip_stream_sync(hs)) return 0;
-            if (!filter_overran(dev, st)) return (int)got;
-            clhip_rx_pipe_rollback(st->rx_pipe);                       /* the pipe ran on invalid samples: undo it too */
         } else {
             /* :304-367: every one of the `res` slots is converted, stale ones included */
-            if (cl_ensure(&st->d_conv, &st->conv_cap, n * 16 + 64, 1, 0)) return 0;
-            if (clhip_convert_from_cs16(d_iq, n, st->format, st->d_conv, hs) ||
-                clhip_memcpy_d2h(out, st->d_conv, n * fmt_bytes(st->format), hs) || clhip_stream_sync(hs))
-                return 0;
-            if (!filter_overran(dev, st)) return res;
+            if (clhip_convert_from_cs16(d_iq, n, st->format, sk.d_dst, hs)) return 0;
+            got = res;
         }
+        if (sink_queue(&sk, out, (size_t)got * ob, hs)) return 0;
+        if (clhip_stream_sync(hs)) return 0;
+        if (!filter_overran(dev, st)) {
+            sink_deliver(st, &sk, out, (size_t)got * ob);
+            return (int)got;
+        }
+        if (st->rx_pipe) clhip_rx_pipe_rollback(st->rx_pipe);         /* the pipe ran on invalid samples: undo it too */
         if (attempt) return 0;
     }
 }

@@ -30,6 +30,10 @@ _SIGS = {
     "clhip_free": (None, [C.c_void_p]),
     "clhip_host_alloc": (C.c_void_p, [C.c_size_t]),
     "clhip_host_free": (None, [C.c_void_p]),
+    "clhip_host_device_ptr": (C.c_void_p, [C.c_void_p]),
+    "clhip_host_register": (C.c_void_p, [C.c_void_p, C.c_size_t]),
+    "clhip_host_unregister": (None, [C.c_void_p]),
+    "clhip_smi_unpack_aligned": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "clhip_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "clhip_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "clhip_memcpy_d2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -72,6 +76,7 @@ _SIGS = {
     "clhip_rx_pipe_set_sync_check": (None, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "clhip_rx_pipe_rollback": (C.c_int, [C.c_void_p]),
     "clhip_rx_pipe_set_host_sink": (None, [C.c_void_p, C.c_void_p]),
+    "clhip_rx_pipe_set_offs_writeback": (None, [C.c_void_p, C.c_int]),
     "clhip_rx_pipe_out_elem_bytes": (C.c_size_t, [C.c_void_p]),
     "clhip_rx_pipe_run_smi": (C.c_long, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

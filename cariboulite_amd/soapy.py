@@ -58,6 +58,7 @@ _SIGS = {
     "cl_ring_put_begin": (C.c_size_t, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "cl_ring_put_end": (None, [C.c_void_p, C.c_size_t]),
     "cl_ring_put_cancel": (None, [C.c_void_p]),
+    "cl_ring_put_abandon": (None, [C.c_void_p]),
     "cl_ring_get_begin": (C.c_size_t, [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "cl_ring_get_end": (None, [C.c_void_p, C.c_size_t]),
     "cl_ring_destroy": (None, [C.c_void_p]),
@@ -297,10 +298,10 @@ class Device:
         return lib().cl_getDigitalFilter(self.h)
 
     def streamStats(self, st):
-        out = (C.c_uint64 * 8)()
+        out = (C.c_uint64 * 10)()
         lib().cl_getStreamStats(self.h, st, out)
         return dict(zip(("read_calls", "elements_read", "reads_empty", "iir_overruns", "write_calls", "elements_written",
-                         "writes_empty", "tx_overruns"), [int(v) for v in out]))
+                         "writes_empty", "tx_overruns", "zero_copy_registrations", "zero_copy_reads"), [int(v) for v in out]))
 
     def smiStats(self):
         out = (C.c_uint64 * 6)()

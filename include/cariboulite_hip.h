@@ -89,6 +89,10 @@ void       *clhip_malloc(size_t bytes);             /* device memory            
 void        clhip_free(void *d_ptr);
 void       *clhip_host_alloc(size_t bytes);         /* pinned, device-visible host  */
 void        clhip_host_free(void *h_ptr);
+void       *clhip_host_device_ptr(void *h_ptr);     /* the address kernels use for that memory (NULL: not reachable) */
+void       *clhip_host_register(void *h_ptr, size_t bytes);   /* pin + map memory the caller owns; returns the address kernels
+                                                               * use, NULL when it cannot be registered */
+void        clhip_host_unregister(void *h_ptr);
 int         clhip_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream);
 int         clhip_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream);
 int         clhip_memcpy_d2d(void *d_dst, const void *d_src, size_t bytes, void *stream);
@@ -129,6 +133,14 @@ int clhip_smi_unpack(int channel, const uint8_t *d_bytes, size_t total_bytes,
                      size_t chunk_stride_bytes, size_t chunk_len_bytes, int n_chunks,
                      const int32_t *d_offs, int format, void *d_out, uint8_t *d_meta,
                      void *stream);
+
+/* One read() chunk KNOWN to be in sync (sync offset 0: caribou_smi_find_buffer_offset returns 0 exactly when the words at
+ * byte offsets 0, 4, 8, 12 carry the pattern, caribou_smi.c:235-292 -- the host can see that in its pinned staging
+ * memory): no search, every slot written; the int16 pairs go to d_cs16 (the persistent native buffer; may be NULL) and, in
+ * `format`, to `out`, which may be mapped pinned host memory (clhip_host_device_ptr): the call then needs no
+ * device-to-host copy.  16-byte aligned buffers, n_bytes a multiple of 16. */
+int clhip_smi_unpack_aligned(int channel, const uint8_t *d_bytes, size_t n_bytes, int format, void *out,
+                             int16_t *d_cs16, void *stream);
 
 /*
  * Link-integrity (debug) modes -- replaces caribou_smi_anayze_smi_debug and the debug branches of
@@ -257,6 +269,9 @@ int    clhip_rx_pipe_rollback(clhip_rx_pipe *p);
 /* One-shot, single-stream pipes: the NEXT clhip_rx_pipe_run_smi also copies its outputs to h_out (host memory) before its
  * synchronisation, so a host caller pays one synchronisation per call (cl_readStream does this). */
 void   clhip_rx_pipe_set_host_sink(clhip_rx_pipe *p, void *h_out);
+/* A call whose chunks the fused kernel itself found in sync leaves zeros in h_offs and (default, on != 0) writes the same
+ * zeros to d_offs with one more memset on the stream; a caller that only ever reads h_offs turns that off. */
+void   clhip_rx_pipe_set_offs_writeback(clhip_rx_pipe *p, int on);
 size_t clhip_rx_pipe_out_elem_bytes(const clhip_rx_pipe *p);       /* 8 (complex float) or 4 (FM demod) */
 long   clhip_rx_pipe_run_smi(clhip_rx_pipe *p, const uint8_t *d_bytes, size_t stream_stride_bytes, size_t n_bytes,
                              size_t chunk_len_bytes, int32_t *d_offs, int32_t *h_offs, int16_t *d_cs16,
@@ -368,9 +383,11 @@ int     cl_smi_device(const cl_smi *dev);  /* its HIP device */
  * get() waits up to timeout_us and yields nothing unless all `length` elements are present (block_read), else
  * min(length, held) at once -- the observable behaviour of the reference's template.  The STORAGE is one array in
  * device memory (cl_ring_create_device) or host memory (cl_ring_create); the bookkeeping is on the host.  Producers
- * and consumers that own a GPU stream use the span calls: _begin locks the ring and names at most two linear
- * pieces of the storage (element positions), the caller moves the data itself (hipMemcpyAsync D2D, a kernel), makes
- * sure the move is complete, and calls _end, which publishes / releases and unlocks. */
+ * and consumers that own a GPU stream use the span calls: _begin names at most two linear pieces of the storage
+ * (element positions), the caller moves the data itself (hipMemcpyAsync D2D, a kernel), makes sure the move is complete,
+ * and calls _end, which publishes / releases.  The ring is NOT locked in between (one producer, one consumer): an open
+ * put owns the elements behind the newest one, an open get the oldest ones, and a put that has to displace the oldest
+ * elements of a full ring waits for an open get to end. */
 typedef struct cl_ring cl_ring;
 typedef struct { size_t pos[2], len[2]; } cl_ring_span;      /* elements; piece 1 is the wrapped part (pos 0) */
 cl_ring *cl_ring_create(size_t size_elems, size_t elem_bytes, int override_write, int block_read);
@@ -380,8 +397,9 @@ void    *cl_ring_storage(const cl_ring *r);                  /* base of the arra
 int      cl_ring_on_device(const cl_ring *r);
 size_t   cl_ring_put_begin(cl_ring *r, size_t length, cl_ring_span *span);              /* returns elements accepted */
 void     cl_ring_put_end(cl_ring *r, size_t accepted);
-void     cl_ring_put_cancel(cl_ring *r);                       /* instead of _end: the put never happened */
-size_t   cl_ring_get_begin(cl_ring *r, size_t length, int timeout_us, cl_ring_span *span); /* 0: nothing claimed, not locked */
+void     cl_ring_put_cancel(cl_ring *r);                       /* instead of _end, span untouched: the put never happened */
+void     cl_ring_put_abandon(cl_ring *r);                      /* instead of _end, span possibly written: nothing published, what was displaced is gone */
+size_t   cl_ring_get_begin(cl_ring *r, size_t length, int timeout_us, cl_ring_span *span); /* 0: nothing claimed */
 void     cl_ring_get_end(cl_ring *r, size_t claimed);
 size_t   cl_ring_put(cl_ring *r, const void *data, size_t length);                      /* host data, either storage */
 size_t   cl_ring_get(cl_ring *r, void *data, size_t length, int timeout_us);
@@ -423,7 +441,10 @@ const char *cl_getNativeStreamFormat(const cl_device *dev, int direction, size_t
 /* setupStream :100-139 -- NULL + cl_device_last_error() where the reference throws.
  * Extension kwargs (SURVEY.md section 5 "Config / flags"): FIR=<ntaps>:<cutoff_hz>,
  * RESAMP=<L>/<M>, DEMOD=FM, MOD=FM:<kf_hz>; ASYNC=1 enables the reader thread + ring of the reference's
- * compiled-out USE_ASYNC path (CaribouliteStream.cpp:11,16-49,70-75); defaults = reference behaviour. */
+ * compiled-out USE_ASYNC path (CaribouliteStream.cpp:11,16-49,70-75); ZEROCOPY=1 (RX) registers the buffers the client
+ * passes to readStream with the GPU on first sight (up to 8, 16-byte aligned) so that the last kernel of a read stores
+ * into them directly -- the client promises that such a buffer stays mapped until the stream is set up again or the
+ * device is closed; defaults = reference behaviour. */
 cl_stream *cl_setupStream(cl_device *dev, int direction, const char *format,
                           const size_t *channels, size_t n_channels,
                           const char *const *keys, const char *const *vals, size_t n_kwargs);
@@ -448,6 +469,8 @@ typedef struct {
     uint64_t write_calls, elements_written;  /* writeStream calls / elements they consumed                             */
     uint64_t writes_empty;                   /* writeStream calls that returned 0                                      */
     uint64_t tx_overruns;                    /* writes whose modulator look-back gave up and was repeated in ticket order */
+    uint64_t zero_copy_registrations;        /* ZEROCOPY=1: client buffers registered with the GPU so far                */
+    uint64_t zero_copy_reads;                /* ZEROCOPY=1: reads whose last kernel stored into the client's buffer itself */
 } cl_stream_stats;
 void   cl_getStreamStats(const cl_device *dev, const cl_stream *stream, cl_stream_stats *out);
 unsigned long cl_stream_iir_overruns(const cl_stream *stream);         /* = iir_overruns above */

@@ -18,6 +18,8 @@ def pytest_configure(config):
 def pytest_sessionstart(session):
     """The native libraries are build artefacts (git-ignored): build them in-tree when a fresh
     checkout runs the tests before __graft_entry__.build() (hipcc cross-compiles without a GPU)."""
+    import torch  # noqa: F401  -- torch's bundled HIP runtime has to be the first one in the process: a test that loads a
+    #                      HIP library of ours first (tests/test_binding_b.py) would otherwise leave torch.cuda blind
     from cariboulite_amd import _build
     if not (os.path.exists(_build.HIP_LIB) and os.path.exists(_build.HOST_LIB)):
         _build.build_all()

@@ -761,3 +761,82 @@ def test_seam_and_stream_counters(S, orc):
     assert tx.streamStats(ts)["write_calls"] == 1 and tx.streamStats(ts)["elements_written"] == 1000
     assert tx.smiStats()["samples_written"] == 1000
     sdr.close(); tx.close()
+
+
+def test_zero_copy_streams_deliver_what_the_default_route_delivers(S, orc):
+    """ZEROCOPY=1: the client's buffers are registered with the GPU and written by the last kernel of the read.  Same
+    samples as the default route, for every format, through the IIR, through the fused stages, with a re-synchronising
+    and a lost batch in between (those calls fall back to the mirror: the client's buffer sees nothing of a failed read),
+    with an unaligned and a ninth buffer (table eviction)."""
+    from cariboulite_amd import synth
+    t = load_golden("taps.npz")
+    b, i, q = synth.smi_stream_bytes(4 * MTU, 0, stream=21)
+    iq = np.stack([i, q], 1)
+    for fmt, dt, conv in ((S.SOAPY_SDR_CS16, np.int16, lambda v: v), ("CF32", np.float32, orc.cs16_to_cf32),
+                          ("CF64", np.float64, orc.cs16_to_cf64), ("CS8", np.int8, orc.cs16_to_cs8)):
+        sdr = S.Device(dict(driver="Cariboulite", channel="S1G"))
+        rx = sdr.setupStream(S.SOAPY_SDR_RX, fmt, args={"ZEROCOPY": "1"})
+        sdr.activateStream(rx)
+        shifted = np.concatenate([np.zeros(6, np.uint8), b[4 * MTU: 8 * MTU - 6]])
+        garbage = np.zeros(4 * MTU, np.uint8)
+        sdr.feedSmiBytes(np.concatenate([b[: 4 * MTU], shifted, garbage, b[8 * MTU:]]))
+        bufs = [np.full((MTU + 4, 2), 77, dt) for _ in range(2)]
+        assert sdr.readStream(rx, [bufs[0]], MTU).ret == MTU
+        assert np.array_equal(bufs[0][:MTU], conv(iq[:MTU])) and (bufs[0][MTU:] == 77).all()
+        assert sdr.readStream(rx, [bufs[1]], MTU).ret == MTU                # re-sync at byte 6: not the one-launch route
+        _, want, _ = orc.rx_data_analyze(0, shifted)
+        if dt == np.int16:
+            assert np.array_equal(bufs[1][:MTU - 2], want[:MTU - 2])
+        else:
+            assert np.array_equal(bufs[1][:MTU - 2], conv(want[:MTU - 2]))
+        before = bufs[0].copy()
+        assert sdr.readStream(rx, [bufs[0]], MTU).ret == 0                  # the batch without sync: nothing delivered,
+        assert np.array_equal(bufs[0], before)                              # nothing written
+        for k in range(2):
+            assert sdr.readStream(rx, [bufs[k]], MTU).ret == MTU
+            assert np.array_equal(bufs[k][:MTU], conv(iq[(2 + k) * MTU:(3 + k) * MTU]))
+        st = sdr.streamStats(rx)
+        assert st["zero_copy_registrations"] == 2 and st["zero_copy_reads"] == 3, st
+        sdr.close()
+    # an odd address (not 16-byte aligned) takes the default route; nine buffers cycle through the table of eight
+    sdr = S.Device(dict(driver="Cariboulite", channel="S1G"))
+    rx = sdr.setupStream(S.SOAPY_SDR_RX, S.SOAPY_SDR_CS16, args={"ZEROCOPY": "1"})
+    raw = np.zeros(4 * MTU + 64, np.uint8)
+    off = (-raw.ctypes.data) % 16 + 4
+    odd = raw[off: off + 4 * MTU].view(np.int16).reshape(-1, 2)
+    sdr.feedSmiBytes(b[: 4 * MTU])
+    assert sdr.readStream(rx, [odd], MTU).ret == MTU and np.array_equal(odd, iq[:MTU])
+    assert sdr.streamStats(rx)["zero_copy_reads"] == 0
+    many = [np.zeros((MTU, 2), np.int16) for _ in range(9)]
+    for rep in range(2):
+        for k, m in enumerate(many):
+            sdr.feedSmiBytes(b[4 * MTU * (k % 4): 4 * MTU * (k % 4 + 1)])
+            assert sdr.readStream(rx, [m], MTU).ret == MTU and np.array_equal(m, iq[(k % 4) * MTU:(k % 4 + 1) * MTU])
+    st = sdr.streamStats(rx)
+    assert st["zero_copy_reads"] == 18 and st["zero_copy_registrations"] >= 10, st
+    # the IIR and the fused stages as last kernels
+    sdr.setupStream(S.SOAPY_SDR_RX, S.SOAPY_SDR_CS16, args={"ZEROCOPY": "1"})
+    ref = S.Device(dict(driver="Cariboulite", channel="S1G"))
+    rr = ref.setupStream(S.SOAPY_SDR_RX, S.SOAPY_SDR_CS16)
+    for d in (sdr, ref):
+        d.setBandwidth(S.SOAPY_SDR_RX, 0, 100e3)
+        d.feedSmiBytes(b)
+    zc0 = sdr.streamStats(rx)["zero_copy_reads"]
+    o1, o2 = np.zeros((MTU, 2), np.int16), np.zeros((MTU, 2), np.int16)
+    for k in range(4):
+        assert sdr.readStream(rx, [o1], MTU).ret == MTU and ref.readStream(rr, [o2], MTU).ret == MTU
+        assert np.array_equal(o1, o2)
+    assert sdr.streamStats(rx)["zero_copy_reads"] == zc0 + 4
+    ref.close()
+    rx = sdr.setupStream(S.SOAPY_SDR_RX, S.SOAPY_SDR_CF32, args={"FIR": "64:1000000", "RESAMP": "3/2", "ZEROCOPY": "1"})
+    sdr.setBandwidth(S.SOAPY_SDR_RX, 0, 2.5e6)
+    sdr.feedSmiBytes(b[: 8 * MTU])
+    x = orc.cs16_to_cf32(iq)
+    fir, rs = orc.FIR(t["fir64_c2"]), orc.Resampler(t["rs_3_2"], 3, 2)
+    out = np.zeros((MTU * 3 // 2, 2), np.float32)
+    for k in range(2):
+        assert sdr.readStream(rx, [out], MTU).ret == MTU * 3 // 2
+        want = rs.f64(fir.f64(x[k * MTU:(k + 1) * MTU]))
+        assert np.max(np.abs(out - want)) <= 1e-5 * np.max(np.abs(want))
+    assert sdr.streamStats(rx)["zero_copy_reads"] == zc0 + 6
+    sdr.close()

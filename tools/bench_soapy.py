@@ -16,7 +16,14 @@ for name, fmt, dt, width, args, bw in (
         ("cf32", S.SOAPY_SDR_CF32, np.float32, 2, None, None),
         ("cs16_iir", S.SOAPY_SDR_CS16, np.int16, 2, None, 100e3),
         ("cf32_fir64_rs_3_2", S.SOAPY_SDR_CF32, np.float32, 2, {"FIR": "64:1000000", "RESAMP": "3/2"}, None),
-        ("cs16_async_ring", S.SOAPY_SDR_CS16, np.int16, 2, {"ASYNC": "1"}, None)):
+        ("cs16_async_ring", S.SOAPY_SDR_CS16, np.int16, 2, {"ASYNC": "1"}, None),
+        # ZEROCOPY=1: the client's buffer is registered with the GPU, the last kernel of the read stores into it
+        ("zc_cs16", S.SOAPY_SDR_CS16, np.int16, 2, {"ZEROCOPY": "1"}, None),
+        ("zc_cf32", S.SOAPY_SDR_CF32, np.float32, 2, {"ZEROCOPY": "1"}, None),
+        ("zc_cs16_iir", S.SOAPY_SDR_CS16, np.int16, 2, {"ZEROCOPY": "1"}, 100e3),
+        ("zc_cf32_fir64_rs_3_2", S.SOAPY_SDR_CF32, np.float32, 2, {"FIR": "64:1000000", "RESAMP": "3/2", "ZEROCOPY": "1"}, None)):
+    if os.environ.get("BENCH_SOAPY_ONLY") and name not in os.environ["BENCH_SOAPY_ONLY"].split(","):
+        continue
     sdr = S.Device(dict(driver="Cariboulite", channel="S1G"))
     rx = sdr.setupStream(S.SOAPY_SDR_RX, fmt, args=args)
     if bw:
