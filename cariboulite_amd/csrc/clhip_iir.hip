@@ -569,7 +569,7 @@ __global__ __launch_bounds__(IIR_TILE) void iir_k3_kernel(const IirPlan *__restr
 // (8.5 KB of LDS at SEG = 64) and the kernel fits four waves per SIMD at full-length segments: fp64 issue needs
 // that many waves to approach its rate (tools/microbench/fir64_phase.hip: 15 T DFMA-lanes/s at one wave per SIMD, 20 at
 // two, 25-31 at four to eight).  Both lanes of a pair read the same LDS words (a broadcast), each takes its half;
-// the (int16)(float) results of a pair meet again through one DPP quad swap + one v_perm_b32 per sample.
+// each lane writes its own (int16)(float) results back into the row with 16-bit LDS stores.
 //
 // Per tile: coalesced load -> LDS rows -> every segment's zero-state end vector as a SEG-tap matrix FIR (taps by
 // scalar loads, double-buffered in SGPRs) -> Kogge-Stone shuffle scan over the 32 segments with P^(2^d), P = F^SEG ->
@@ -696,40 +696,34 @@ __device__ __forceinline__ void rail_segment_fir(double *v, const uint32_t *x, c
     iir_taps_wait<D>(ta);
 }
 
-// the other lane of the pair's value (DPP quad_perm [1,0,3,2]: a full-rate VALU move, no LDS)
-__device__ __forceinline__ uint32_t rail_partner(uint32_t v)
-{
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
-}
-
-// The recursion of one rail over the lane's row, in place: both lanes of a pair end up with the packed (i, q) words
-// (sel: the lane's byte selector for v_perm_b32), the I lane writes them back.
+// The recursion of one rail over the lane's row, in place: a lane reads the pair's packed words 16 bytes at a time and
+// writes its own 16-bit results back with ds_write_b16 at constant offsets from its row (+2 bytes for the Q rail) -- the
+// write goes down the LDS pipe, where there is room, instead of a DPP move + v_perm_b32 per sample on the VALU, which
+// is the unit this kernel is bound by.  Both lanes of a pair have read a 16-byte group before either writes into it
+// (one wave, LDS operations in order).
 template <int NS, int SEG, bool FULL, bool B121>
-__device__ __forceinline__ void rail_recursion(const IirCoef &c, uint32_t *x, long cnt, double *z, int sh, uint32_t sel, int rail)
+__device__ __forceinline__ void rail_recursion(const IirCoef &c, uint32_t *x, long cnt, double *z, int sh, int rail)
 {
+    uint16_t *xo = (uint16_t *)x + rail;
 #pragma unroll 2
     for (int k = 0; k < SEG; k += 4) {
         if (!FULL && k >= cnt) break;
-        u32x4 w = *(const u32x4 *)(x + k);
+        const u32x4 w = *(const u32x4 *)(x + k);
         if (FULL || k + 4 <= cnt) {
 #pragma unroll
             for (int j = 0; j < 4; j += 2) {
                 double y0, y1;
                 iir_step2<NS, B121>(c, z, (double)(int)__builtin_amdgcn_sbfe((int)w[j], sh, 16), (double)(int)__builtin_amdgcn_sbfe((int)w[j + 1], sh, 16), y0, y1);
-                const uint32_t r0 = (uint32_t)(int)(float)y0, r1 = (uint32_t)(int)(float)y1;   // v_perm_b32 takes the low halves
-                w[j] = __builtin_amdgcn_perm(rail_partner(r0), r0, sel);
-                w[j + 1] = __builtin_amdgcn_perm(rail_partner(r1), r1, sel);
+                xo[2 * (k + j)] = (uint16_t)(uint32_t)(int)(float)y0;            // (the low half: cvttss2si's, see iir_to_i16)
+                xo[2 * (k + j + 1)] = (uint16_t)(uint32_t)(int)(float)y1;
             }
         } else {
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                if (k + j < cnt) {                                  // uniform over the pair
-                    const uint32_t r = (uint32_t)(int)(float)iir_step<NS>(c, z, (double)(int)__builtin_amdgcn_sbfe((int)w[j], sh, 16));
-                    w[j] = __builtin_amdgcn_perm(rail_partner(r), r, sel);
-                }
+                if (k + j < cnt)                                        // uniform over the pair
+                    xo[2 * (k + j)] = (uint16_t)(uint32_t)(int)(float)iir_step<NS>(c, z, (double)(int)__builtin_amdgcn_sbfe((int)w[j], sh, 16));
             }
         }
-        if (rail == 0) *(u32x4 *)(x + k) = w;
     }
 }
 
@@ -954,7 +948,6 @@ __global__ __launch_bounds__(64, RL_WAVES) void iir_rail_kernel(const IirRailArg
             asm volatile("" : "+s"(tab), "+s"(Gp));
             const cdouble_t *pow2 = (const cdouble_t *)&tab->pow2[0][0];
             const int m = t >> 1, rail = t & 1, sh = rail << 4;
-            const uint32_t sel = rail ? 0x01000504u : 0x05040100u;
             const long tile0 = b * TILE;
             uint32_t *xout = sout + tile0;
             const bool whole = tile_whole(b);
@@ -1083,10 +1076,10 @@ __global__ __launch_bounds__(64, RL_WAVES) void iir_rail_kernel(const IirRailArg
             RL_STAMP(8);
             const long seg = b * RL_SEGS + m;
             if (seg < A.n_seg && !(A.dbg & 2)) {
-                if (tile0 + TILE <= A.n) rail_recursion<NS, SEG, true, B121>(A.c, x, SEG, z, sh, sel, rail);
+                if (tile0 + TILE <= A.n) rail_recursion<NS, SEG, true, B121>(A.c, x, SEG, z, sh, rail);
                 else {
                     const long cnt = A.n - seg * SEG < SEG ? A.n - seg * SEG : SEG;
-                    rail_recursion<NS, SEG, false, B121>(A.c, x, cnt, z, sh, sel, rail);
+                    rail_recursion<NS, SEG, false, B121>(A.c, x, cnt, z, sh, rail);
                 }
                 if (seg == A.n_seg - 1) {
                     double *so = A.state_out + s * 2 * IIR_MAX_DIM + rail * IIR_MAX_DIM;
@@ -1107,7 +1100,11 @@ __global__ __launch_bounds__(64, RL_WAVES) void iir_rail_kernel(const IirRailArg
     }
     if (A.stamps && t0 == 0 && blockIdx.x < RL_STAMP_ALLWAVES) {
         A.stamps[(size_t)RL_STAMP_WAVES * RL_STAMP_TILES * RL_STAMP_PHASES + 3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
-        A.stamps[(size_t)RL_STAMP_WAVES * RL_STAMP_TILES * RL_STAMP_PHASES + 3 * blockIdx.x + 2] = (unsigned long long)(it + 1);
+        // steps done | HW_ID (wave, SIMD, CU, SH, SE: where the wave ran) << 16 | XCC_ID << 48   (tools/iir_wave_balance.py)
+        const unsigned hw = __builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (0 << 6) | (31 << 11));
+        const unsigned xcc = __builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | (31 << 11));
+        A.stamps[(size_t)RL_STAMP_WAVES * RL_STAMP_TILES * RL_STAMP_PHASES + 3 * blockIdx.x + 2] =
+            (unsigned long long)(it + 1) | ((unsigned long long)hw << 16) | ((unsigned long long)(xcc & 0xF) << 48);
     }
     // the last wave out puts the counters back for the next launch
     if (t0 == 0) {
@@ -1146,9 +1143,18 @@ static const int kRailSegs[3] = {16, 32, 64};
 
 // Horizon of the single-pass kernel for tiles of RL_SEGS x seg samples.  int16 inputs bound every reachable state
 // component c by 32768 * sum_n |h_c[n]| (h_c = impulse response of that component); a state entering tile b-H reaches
-// tile b as Q^H s, so max_r sum_c |Q^H[r][c]| smax[c] bounds what dropping it costs.  Below 1e-18 (absolute; the
-// outputs are integers and the fp64 sums themselves carry ~1e-8 of rounding) the tile may ignore it.  0 = no such H
+// tile b as Q^H s, so max_r sum_c |Q^H[r][c]| smax[c] bounds what dropping it costs.  Below 1e-12 absolute the tile may
+// ignore it: the outputs are integers, a state of this filter is of the order of 1e5..1e6 for full-scale input, so one
+// ulp of it is 1e-11..1e-10 and the blocked evaluation's own rounding (a few hundred fp64 operations per state word)
+// is orders of magnitude above the bound.  (1e-18 until round 3: H = 2 tiles for the reference's 50 kHz filter at
+// 64-sample segments where 1e-12 gives 1 -- one prologue tile per chunk instead of two, 3 % of the run time.)  0 = no such H
 // within RL_HMAX, or the cascade's l1 gain lets 32768 x it pass 2^30 (the kernel's v_cvt_i32_f32 equals cvttss2si's low half only for |y| < 2^31).
+static double iir_horizon_eps()
+{
+    static const double eps = getenv("CLHIP_IIR_HORIZON_EPS") ? atof(getenv("CLHIP_IIR_HORIZON_EPS")) : 1e-12;     // experiment knob
+    return eps > 0 ? eps : 1e-12;
+}
+
 static void iir_rail_tab_build(int dim, const double *F, int seg, const double *smax, bool bounded, IirRailTab *tb)
 {
     memset(tb, 0, sizeof *tb);
@@ -1175,7 +1181,7 @@ static void iir_rail_tab_build(int dim, const double *F, int seg, const double *
             for (int cc = 0; cc < dim; cc++) acc += fabs(Qk[r * IIR_MAX_DIM + cc]) * 65536.0 * smax[cc];
             worst = fmax(worst, acc);
         }
-        if (worst < 1e-18) { tb->horizon = k; break; }
+        if (worst < iir_horizon_eps()) { tb->horizon = k; break; }
         mat_mul(dim, Qk, tb->pow2[5], Qk);
     }
 }
