@@ -106,8 +106,28 @@ struct PipeCfg {
     static constexpr int T = T_, L = L_, M = M_, KP = KP_, MODE = MODE_, R = R_, NT = NT_;
     static constexpr bool RESAMP = !(L == 1 && M == 1);
     static constexpr int HF = MODE == MODE_FM ? 1 : (RESAMP ? KP - 1 : 0);   // FIR outputs of history
-    static constexpr int HFA = HF == 0 ? 0 : round_up(HF, clcm(4, M));      // recomputed per tile
     static constexpr int NFIR = NT * R;             // FIR outputs per tile
+    // FIR outputs recomputed per tile as the second stage's history.  At least HF, a multiple of lcm(4, M) -- and, above
+    // all, such that a tile's NEW outputs fill whole 128-byte lines (and its new inputs too): tile k's outputs start at
+    // k x (NFIR - HFA) x L / M elements, and when that is not a multiple of a line, every 1 KiB store instruction of three
+    // tiles in four straddles lines -- 7 whole ones and 2 partial ones -- which the memory system takes 30 % longer to
+    // write (tools/microbench/write_shape.hip: 0.80 -> 1.06 ms for config 2's traffic with the output base 32 bytes off
+    // a line; the kernel with every arithmetic instruction removed took the same 0.92 ms as the whole kernel).  Config 2:
+    // 32 instead of 8 (two lanes of the tile's 256 recompute history: 0.6 % more arithmetic).
+    static constexpr int pick_hfa()
+    {
+        if (HF == 0) return 0;
+        constexpr int step = clcm(4, M), ob = MODE == MODE_FM ? 4 : 8;
+        const int least = round_up(HF, step);
+#ifndef CLHIP_RX_UNALIGNED_TILES
+        for (int h = least; h <= NFIR / 8; h += step) {
+            const long in = NFIR - h, out = MODE == MODE_FM ? in : in * L / M;
+            if ((in * L) % M == 0 && (out * ob) % 128 == 0 && (in * 4) % 128 == 0) return h;
+        }
+#endif
+        return least;
+    }
+    static constexpr int HFA = pick_hfa();
     static constexpr int TILE_IN = NFIR - HFA;      // new inputs per tile
     // FFA: y[0] of a lane needs B[-1] = the previous lane's B[R/2-1].  When the tile's very first FIR output
     // is never consumed (HFA > HF) it can come by shuffle instead of being recomputed by every lane.

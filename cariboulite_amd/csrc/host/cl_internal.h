@@ -81,6 +81,7 @@ struct cl_smi {
     cl_chunk *chunks; size_t chunks_cap, n_chunks;
     int debug_mode;               /* caribou_smi_debug_mode_en */
     cl_smi_debug_data debug_data;
+    cl_smi_clock_fn debug_clock; void *debug_clock_user;   /* NULL: gettimeofday */
     int32_t *d_dbg; int32_t *h_dbg; /* 4 ints each */
     /* read-ahead reader (cl_smi_read_device_ra): the NEXT read() is popped into the other pinned slot and its
      * host-to-device copy runs on `cstream` while the current chunk is analysed on `stream`.  The bytes are taken IN

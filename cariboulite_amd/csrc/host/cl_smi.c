@@ -3,6 +3,7 @@
  * behaviour as caribou_smi_read / caribou_smi_write, with the /dev/smi fd
  * replaced by an injected byte FIFO and the per-chunk analysis
  * (caribou_smi.c:235-393) / packing (:684-717) done by HIP kernels. */
+#include <sys/time.h>
 #include <time.h>
 
 #include "cl_internal.h"
@@ -222,6 +223,21 @@ void   cl_smi_set_tx_mode(cl_smi *dev, int mode) { dev->tx_mode = mode; }
 size_t cl_smi_get_native_batch_samples(cl_smi *dev) { return dev->native_batch_len / CL_BYTES_PER_SAMPLE; }
 void   cl_smi_set_debug_mode(cl_smi *dev, int mode) { dev->debug_mode = mode; }       /* caribou_smi.c:612-615 */
 const cl_smi_debug_data *cl_smi_get_debug_data(const cl_smi *dev) { return &dev->debug_data; }
+void   cl_smi_set_debug_clock(cl_smi *dev, cl_smi_clock_fn now, void *user) { if (dev) { dev->debug_clock = now; dev->debug_clock_user = user; } }
+
+/* smi_calculate_performance (smi_utils.c:233-244), called once per analysed chunk (caribou_smi.c:210): the reference forms
+ * the elapsed time in SECONDS (it calls it elapsed_us), so bytes * 8 / elapsed / 1e6 is Mbit/s; 0.98 : 0.02 blend */
+static void smi_debug_bitrate(cl_smi *dev, size_t bytes)
+{
+    cl_smi_debug_data *d = &dev->debug_data;
+    long sec, usec;
+    if (dev->debug_clock) dev->debug_clock(dev->debug_clock_user, &sec, &usec);
+    else { struct timeval t; gettimeofday(&t, NULL); sec = (long)t.tv_sec; usec = (long)t.tv_usec; }
+    const double elapsed_us = (sec - d->last_time_sec) + ((double)(usec - d->last_time_usec)) / 1000000.0;
+    const double speed_mbps = (double)(bytes * 8) / elapsed_us / 1e6;
+    d->last_time_sec = sec; d->last_time_usec = usec;
+    d->bitrate = d->bitrate * 0.98 + speed_mbps * 0.02;
+}
 void cl_smi_get_stats(const cl_smi *dev, cl_smi_stats *out)
 {
     if (!out) return;
@@ -268,6 +284,7 @@ static int cl_smi_read_debug(cl_smi *dev, size_t length_samples)
     d->cur_err_cnt = (uint32_t)dev->h_dbg[1];
     d->error_accum_counter += d->cur_err_cnt;
     d->last_correct_byte = (uint8_t)dev->h_dbg[3];
+    smi_debug_bitrate(dev, alen);                             /* :210, before the error rate like the reference */
     d->error_rate = d->error_rate * 0.9 + (double)d->cur_err_cnt / (double)alen * 0.1;
     if (d->error_rate < 1e-8) d->error_rate = 0.0;
     return CL_SMI_ERR_DEBUGMODE;

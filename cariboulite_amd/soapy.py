@@ -43,6 +43,7 @@ _SIGS = {
     "cl_smi_get_native_batch_samples": (C.c_size_t, [C.c_void_p]),
     "cl_smi_set_debug_mode": (None, [C.c_void_p, C.c_int]),
     "cl_smi_get_debug_data": (C.c_void_p, [C.c_void_p]),
+    "cl_smi_set_debug_clock": (None, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "cl_smi_read_to_device": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
     "cl_smi_write_from_device": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
     "cl_smi_flush_fifo": (C.c_int, [C.c_void_p]),
@@ -142,7 +143,11 @@ def design_butter_lowpass(order, fs_hz, fc_hz):
 
 class SmiDebugData(C.Structure):
     _fields_ = [("error_accum_counter", C.c_uint32), ("cur_err_cnt", C.c_uint32),
-                ("last_correct_byte", C.c_uint8), ("error_rate", C.c_double)]
+                ("last_correct_byte", C.c_uint8), ("error_rate", C.c_double), ("bitrate", C.c_double),
+                ("last_time_sec", C.c_long), ("last_time_usec", C.c_long)]
+
+
+SMI_CLOCK_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long))
 
 
 class Ring:
@@ -233,6 +238,24 @@ class Device:
     def smiDebugData(self):
         d = C.cast(lib().cl_smi_get_debug_data(self.smi), C.POINTER(SmiDebugData)).contents
         return (d.error_accum_counter, d.cur_err_cnt, d.last_correct_byte, d.error_rate)
+
+    def smiDebugBitrate(self):
+        d = C.cast(lib().cl_smi_get_debug_data(self.smi), C.POINTER(SmiDebugData)).contents
+        return d.bitrate, (d.last_time_sec, d.last_time_usec)
+
+    def setSmiDebugClock(self, readings):
+        """Replay (sec, usec) clock readings, one per analysed chunk (None: back to gettimeofday)."""
+        if readings is None:
+            self._clock_cb = None
+            lib().cl_smi_set_debug_clock(self.smi, None, None)
+            return
+        it = iter(readings)
+
+        def now(_user, sec, usec):
+            s_, u_ = next(it)
+            sec[0], usec[0] = s_, u_
+        self._clock_cb = SMI_CLOCK_FN(now)          # kept alive with the device
+        lib().cl_smi_set_debug_clock(self.smi, self._clock_cb, None)
 
     # ---- lower seam (caribou_smi_read / caribou_smi_write)
     def smiRead(self, channel, n, want_meta=True, fill=-21846):

@@ -347,14 +347,20 @@ int     cl_smi_read(cl_smi *dev, int channel, cl_sample_complex_int16 *buffer,
 int     cl_smi_write(cl_smi *dev, int channel, cl_sample_complex_int16 *buffer, size_t length_samples);
 /* caribou_smi_set_debug_mode caribou_smi.c:612-615; in a debug mode cl_smi_read analyses ONE chunk,
  * updates the counters and returns CL_SMI_ERR_DEBUGMODE (-2), like caribou_smi.c:670-675 */
-typedef struct {                /* caribou_smi_debug_data_st (caribou_smi.h:30-39) minus the wall-clock fields */
+typedef struct {                /* caribou_smi_debug_data_st (caribou_smi.h:30-39) */
     uint32_t error_accum_counter;
     uint32_t cur_err_cnt;
     uint8_t  last_correct_byte;
     double   error_rate;
-} cl_smi_debug_data;
+    double   bitrate;           /* Mbit/s, smi_calculate_performance's 0.98 : 0.02 blend (smi_utils.c:233-244)      */
+    long     last_time_sec, last_time_usec;   /* the clock reading of the previous analysed chunk ({0, 0} at first, */
+} cl_smi_debug_data;                          /* as the reference's zero-initialised struct timeval)                */
 void    cl_smi_set_debug_mode(cl_smi *dev, int cl_smi_debug_mode);
 const cl_smi_debug_data *cl_smi_get_debug_data(const cl_smi *dev);
+/* The wall clock behind `bitrate`: gettimeofday() unless a caller supplies its own (tests replay recorded readings, a
+ * file replay can pass the capture's own time base).  now(user, &sec, &usec); NULL restores gettimeofday. */
+typedef void (*cl_smi_clock_fn)(void *user, long *sec, long *usec);
+void    cl_smi_set_debug_clock(cl_smi *dev, cl_smi_clock_fn now, void *user);
 /* counters of the seam: what the reference only logs (cariboulite_radio.c:1276-1283 "SMI reading operation failed" /
  * "synchronization failed", caribou_smi.c:657-668 "Reading timed-out" / the -3 exit) a caller can now read */
 typedef struct {

@@ -607,7 +607,7 @@ int orc_debug_find_offset(int mode, const uint8_t *buffer, size_t len)
 }
 
 /* caribou_smi_rx_data_analyze (:295-330) + caribou_smi_anayze_smi_debug (:172-215) for one read()
- * chunk; the wall-clock bitrate EMA is not modelled.  Returns offs (or -1). */
+ * chunk; the wall-clock bitrate EMA is orc_bitrate_ema below (the caller supplies the clock).  Returns offs (or -1). */
 int orc_debug_analyze(orc_debug_data *d, int mode, const uint8_t *data, size_t len)
 {
     int offs = orc_debug_find_offset(mode, data, len);
@@ -629,6 +629,18 @@ int orc_debug_analyze(orc_debug_data *d, int mode, const uint8_t *data, size_t l
     d->error_rate = d->error_rate * 0.9 + (double)cur / (double)alen * 0.1;
     if (d->error_rate < 1e-8) d->error_rate = 0.0;
     return offs;
+}
+
+/* smi_calculate_performance (caribou_smi/smi_utils.c:233-244) with the two clock readings as arguments: the reference
+ * names the difference elapsed_us but forms it in SECONDS (tv_sec difference + tv_usec difference / 1e6), so the figure is
+ * bytes * 8 / seconds / 1e6 = Mbit/s, blended 0.98 : 0.02 into the running value.  (caribou_smi.c:210 calls it once per
+ * analysed chunk with the chunk's length.) */
+__attribute__((optimize("fp-contract=off")))     /* the reference's plain build rounds the product and the sum separately */
+double orc_bitrate_ema(size_t bytes, long old_sec, long old_usec, long cur_sec, long cur_usec, double old_mbps)
+{
+    double elapsed_us = (cur_sec - old_sec) + ((double)(cur_usec - old_usec)) / 1000000.0;
+    double speed_mbps = (double)(bytes * 8) / elapsed_us / 1e6;
+    return old_mbps * 0.98 + speed_mbps * 0.02;
 }
 
 /* ======================================================================== */

@@ -127,6 +127,7 @@ typedef struct {
 uint8_t orc_lfsr(uint8_t n);
 int orc_debug_find_offset(int mode, const uint8_t *buffer, size_t len);
 int orc_debug_analyze(orc_debug_data *d, int mode, const uint8_t *data, size_t len);
+double orc_bitrate_ema(size_t bytes, long old_sec, long old_usec, long cur_sec, long cur_usec, double old_mbps);   /* smi_utils.c:233-244 */
 
 /* ---- circular_buffer<T> semantics (datatypes/circular_buffer.h) on 32-bit elements ---- */
 typedef struct {

@@ -310,6 +310,20 @@ def lfsr_stream(n, seed=0x56):
     return out
 
 
+def bitrate_ema(nbytes, old, cur, old_mbps):
+    """smi_calculate_performance with the two clock readings (sec, usec) as arguments."""
+    lib().orc_bitrate_ema.restype = C.c_double
+    return lib().orc_bitrate_ema(C.c_size_t(nbytes), C.c_long(old[0]), C.c_long(old[1]), C.c_long(cur[0]), C.c_long(cur[1]), C.c_double(old_mbps))
+
+
+def ref_bitrate_ema(nbytes, old, old_mbps):
+    """The compiled reference's smi_calculate_performance: (result, the (sec, usec) wall-clock reading it used)."""
+    ref().ref_bitrate_ema.restype = C.c_double
+    cs, cu = C.c_long(0), C.c_long(0)
+    r = ref().ref_bitrate_ema(C.c_size_t(nbytes), C.c_long(old[0]), C.c_long(old[1]), C.c_double(old_mbps), C.byref(cs), C.byref(cu))
+    return r, (cs.value, cu.value)
+
+
 def ref_debug_read(mode, stream_bytes, length_samples, state, native_batch_len=NATIVE_BATCH_LEN):
     """state = (accum, cur, last_byte, error_rate) -> (ret, new state) through the compiled reference."""
     b = np.ascontiguousarray(stream_bytes, dtype=np.uint8)

@@ -114,3 +114,14 @@ int ref_debug_read_file(const char *path, int mode, size_t length_samples, size_
     close(fd);
     return ret;
 }
+
+/* smi_calculate_performance() itself (smi_utils.c:233-244).  It reads the wall clock and leaves the reading in *old_time:
+ * the caller gets result AND the (sec, usec) the reference used, and can so check a restatement bit for bit. */
+double ref_bitrate_ema(size_t bytes, long old_sec, long old_usec, double old_mbps, long *cur_sec, long *cur_usec)
+{
+    struct timeval t;
+    t.tv_sec = old_sec; t.tv_usec = old_usec;
+    const double r = smi_calculate_performance(bytes, &t, old_mbps);
+    *cur_sec = (long)t.tv_sec; *cur_usec = (long)t.tv_usec;
+    return r;
+}

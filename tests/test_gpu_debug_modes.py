@@ -65,3 +65,36 @@ def test_debug_kernel_large_random_vs_oracle(S, orc):
     buf = np.zeros((1000, 2), np.int16)
     assert sdr.readStream(rx, [buf], 1000).ret == 0
     sdr.close()
+
+
+def test_debug_bitrate_ema_on_a_replayed_clock(S, orc):
+    """caribou_smi.c:210: one smi_calculate_performance per analysed chunk with the chunk's analysed length.  With the clock
+    readings replayed (cl_smi_set_debug_clock) the running Mbit/s figure equals the restatement that the compiled reference
+    pins (tests/test_oracle_golden.py::test_bitrate_ema_vs_the_reference_itself), chunk after chunk -- first call from {0, 0}."""
+    g = load_golden("smi_debug_cases.npz")
+    name = _names()[0]
+    mode, n_calls, length_samples, nb = [int(v) for v in g[f"{name}__args"]]
+    stream = g[f"{name}__bytes"]
+    clock = [(1_760_000_000 + k // 3, (137 + 400_003 * k) % 1_000_000) for k in range(n_calls)]
+    sdr = S.Device(dict(driver="Cariboulite", channel="S1G"))
+    sdr.setSmiDebugMode(mode)
+    sdr.setMaxRead(nb)
+    sdr.setSmiDebugClock(clock)
+    sdr.feedSmiBytes(stream)
+    st = orc.DebugState()
+    want, old, pos, analysed = 0.0, (0, 0), 0, 0
+    for k in range(n_calls):
+        chunk = stream[pos:pos + min(nb, 4 * length_samples)]
+        pos += chunk.size
+        ret, _, _ = sdr.smiRead(0, length_samples)
+        offs = st.analyze(mode, chunk)
+        if offs < 0:
+            assert ret == -3
+            continue                                          # no analysis, no clock reading (caribou_smi.c:665-668)
+        alen = chunk.size - 4 * ((offs // 4 + 1) if offs > 0 else 0)
+        want = orc.bitrate_ema(alen, old, clock[analysed], want)
+        old = clock[analysed]; analysed += 1
+        got, last = sdr.smiDebugBitrate()
+        assert got == want and last == old
+    assert analysed > 1
+    sdr.close()

@@ -234,3 +234,22 @@ def test_debug_modes_vs_reference_fixture(orc, name):
         # the EMA is one fp64 multiply-add: the oracle's -march build may fuse it (1 ulp)
         assert st.tuple()[3] == pytest.approx(float(g[f"{name}__rates"][k]), rel=1e-14, abs=0)
         pos += chunk.size
+
+
+def test_bitrate_ema_vs_the_reference_itself(orc):
+    """smi_calculate_performance (smi_utils.c:233-244) reads the wall clock and leaves its reading in *old_time: fed the same
+    two readings, the restatement gives the reference's value bit for bit -- including the quirk that the 'elapsed_us' it
+    divides by is in seconds, and the first call's elapsed time since {0, 0}."""
+    if not orc.have_ref():
+        pytest.skip("oracle/_ref was not built (no reference tree in the build container)")
+    import time
+    mbps, old = 0.0, (0, 0)                                  # the zero-initialised debug_data of caribou_smi_init
+    for k, nbytes in enumerate((524288, 524288, 4096, 524284, 16)):
+        if k == 2:
+            time.sleep(0.003)
+        got, cur = orc.ref_bitrate_ema(nbytes, old, mbps)
+        assert cur[0] > 1_600_000_000 and 0 <= cur[1] < 1_000_000
+        assert orc.bitrate_ema(nbytes, old, cur, mbps) == got
+        mbps, old = got, cur
+    # and with a clock that runs backwards across a second boundary (negative usec difference)
+    assert orc.bitrate_ema(1000, (10, 900000), (11, 100000), 5.0) == 5.0 * 0.98 + (8000 / 0.2 / 1e6) * 0.02

@@ -58,6 +58,12 @@ int main()
         run<1, 3, true>("1:3  (config 2's shape), NT stores", in, out, c13, grid);
         run<1, 3, false>("1:3  (config 2's shape), plain stores", in, out, c13, grid);
     }
+    // the same, every wave's 1 KiB store instruction straddling 128-byte lines (base + 32 bytes): 7 whole lines + 2 partial ones
+    run<1, 3, true>("1:3, NT stores, output base + 32 B", in, out + 2, c13 - 1, 1024);
+    run<1, 3, false>("1:3, plain stores, output base + 32 B", in, out + 2, c13 - 1, 1024);
+    run<1, 3, true>("1:3, NT stores, output base + 32 B", in, out + 2, c13 - 1, 4096);
+    run<1, 3, true>("1:3, NT, input base + 96 B, output + 32 B", in + 6, out + 2, c13 - 1, 1024);
+    run<1, 3, true>("1:3, NT, input base + 96 B", in + 6, out, c13 - 1, 1024);
     run<0, 3, true>("pure write 3 GiB, NT", in, out, c13, 4096);
     run<0, 3, false>("pure write 3 GiB, plain", in, out, c13, 4096);
     run<0, 3, false>("pure write 3 GiB, plain", in, out, c13, 65536);
