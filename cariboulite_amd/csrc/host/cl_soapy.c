@@ -550,6 +550,15 @@ static int filter_overran(cl_device *dev, cl_stream *st)
 
 static int read_stream(cl_device *dev, cl_stream *st, void *const *buffs, size_t numElems, long timeoutUs);
 
+/* A/B switch CL_READ_FAST=0: no one-launch unpack of a read() the host has seen to be in sync (search + unpack + offset
+ * read-back for every call, as for the calls that do not qualify) */
+static int read_fast_enabled(void)
+{
+    static int on = -1;
+    if (on < 0) on = getenv("CL_READ_FAST") ? atoi(getenv("CL_READ_FAST")) != 0 : 1;
+    return on;
+}
+
 /* Stream::ReadSamplesGen  CaribouliteStream.cpp:370-382 */
 int cl_readStream(cl_device *dev, cl_stream *st, void *const *buffs, size_t numElems, int *flags, long long *timeNs, long timeoutUs)
 {
@@ -600,9 +609,7 @@ static int read_stream(cl_device *dev, cl_stream *st, void *const *buffs, size_t
         /* the short cut: a call that is one read() the host can see to be in sync is unpacked by ONE launch, in the
          * client's format, straight into the sink (cl_smi_ra_launch): no search launch, no offset read-back, no conversion
          * launch; what is left here is the one synchronisation and the sink's own last step */
-        static int fast_path = -1;
-        if (fast_path < 0) fast_path = getenv("CL_READ_FAST") ? atoi(getenv("CL_READ_FAST")) : 1;
-        smi->fast_out = fast_path ? sk.d_dst : NULL;
+        smi->fast_out = read_fast_enabled() ? sk.d_dst : NULL;
         smi->fast_format = st->format;
         const long expect = cl_smi_ra_launch(smi, dev->channel, numElems, NULL);
         smi->fast_out = NULL;
@@ -655,7 +662,7 @@ static int read_stream(cl_device *dev, cl_stream *st, void *const *buffs, size_t
     if (st->format == CL_FORMAT_CS16) {                /* :282-301, no MTU clamp */
         int aligned = 0;
         int res;
-        if (!st->use_async && st->filter_type != CL_DIGFILT_NONE && numElems && numElems <= st->mtu_size) {
+        if (read_fast_enabled() && !st->use_async && st->filter_type != CL_DIGFILT_NONE && numElems && numElems <= st->mtu_size) {
             /* One native batch through the low-pass: when the call is one read() the host can see to be in sync, the
              * unpack launch and the filter launch are queued back to back and the call pays ONE synchronisation (the
              * read's verdict arrives with it); the filter stores straight into the sink. */

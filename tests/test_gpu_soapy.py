@@ -769,6 +769,8 @@ def test_zero_copy_streams_deliver_what_the_default_route_delivers(S, orc):
     and a lost batch in between (those calls fall back to the mirror: the client's buffer sees nothing of a failed read),
     with an unaligned and a ninth buffer (table eviction)."""
     from cariboulite_amd import synth
+    # (the A/B switches that turn the one-launch route off leave the samples alone and the zero-copy counters at zero)
+    one_launch = os.environ.get("CL_READ_FAST", "1") != "0" and os.environ.get("CL_READ_SINGLE_SYNC", "2") != "0"
     t = load_golden("taps.npz")
     b, i, q = synth.smi_stream_bytes(4 * MTU, 0, stream=21)
     iq = np.stack([i, q], 1)
@@ -796,7 +798,7 @@ def test_zero_copy_streams_deliver_what_the_default_route_delivers(S, orc):
             assert sdr.readStream(rx, [bufs[k]], MTU).ret == MTU
             assert np.array_equal(bufs[k][:MTU], conv(iq[(2 + k) * MTU:(3 + k) * MTU]))
         st = sdr.streamStats(rx)
-        assert st["zero_copy_registrations"] == 2 and st["zero_copy_reads"] == 3, st
+        assert not one_launch or (st["zero_copy_registrations"] == 2 and st["zero_copy_reads"] == 3), st
         sdr.close()
     # an odd address (not 16-byte aligned) takes the default route; nine buffers cycle through the table of eight
     sdr = S.Device(dict(driver="Cariboulite", channel="S1G"))
@@ -813,7 +815,7 @@ def test_zero_copy_streams_deliver_what_the_default_route_delivers(S, orc):
             sdr.feedSmiBytes(b[4 * MTU * (k % 4): 4 * MTU * (k % 4 + 1)])
             assert sdr.readStream(rx, [m], MTU).ret == MTU and np.array_equal(m, iq[(k % 4) * MTU:(k % 4 + 1) * MTU])
     st = sdr.streamStats(rx)
-    assert st["zero_copy_reads"] == 18 and st["zero_copy_registrations"] >= 10, st
+    assert not one_launch or (st["zero_copy_reads"] == 18 and st["zero_copy_registrations"] >= 10), st
     # the IIR and the fused stages as last kernels
     sdr.setupStream(S.SOAPY_SDR_RX, S.SOAPY_SDR_CS16, args={"ZEROCOPY": "1"})
     ref = S.Device(dict(driver="Cariboulite", channel="S1G"))
@@ -826,7 +828,7 @@ def test_zero_copy_streams_deliver_what_the_default_route_delivers(S, orc):
     for k in range(4):
         assert sdr.readStream(rx, [o1], MTU).ret == MTU and ref.readStream(rr, [o2], MTU).ret == MTU
         assert np.array_equal(o1, o2)
-    assert sdr.streamStats(rx)["zero_copy_reads"] == zc0 + 4
+    assert sdr.streamStats(rx)["zero_copy_reads"] == zc0 + 4          # (the filter is the last kernel on either route)
     ref.close()
     rx = sdr.setupStream(S.SOAPY_SDR_RX, S.SOAPY_SDR_CF32, args={"FIR": "64:1000000", "RESAMP": "3/2", "ZEROCOPY": "1"})
     sdr.setBandwidth(S.SOAPY_SDR_RX, 0, 2.5e6)
