@@ -428,6 +428,10 @@ __device__ __forceinline__ uint32_t tx_f2i16_fast(float v)
     const int t = v < 2147483648.0f ? (int)v : 0;
     return (uint32_t)t & 0xFFFFu;
 }
+// The config-5 kernels quantise resampled UNIT phasors: the host has shown |v| < 2^31 (clhip_tx_pipe::q_bounded), so the
+// overflow branch cannot be taken and v_cvt_i32_f32 alone has cvttss2si's low half (NaN -> 0 on both): one instruction
+// where the general form needs a compare and a select as well.
+__device__ __forceinline__ uint32_t tx_f2i16_bounded(float v) { return (uint32_t)(int)v & 0xFFFFu; }
 
 // One sub-block of tx_fm_fast_kernel.  CHECKED = false: every message and every output of the sub-block is inside
 // the call (workgroup-uniform), so there is not a single bounds test or divergent branch in it.
@@ -519,7 +523,7 @@ __device__ __forceinline__ double tx_fast_subblock(const float (&mv)[C::PER], si
 #pragma unroll
         for (int i = 0; i < KP; i++) acc += x[HS + bb - i] * tp[p + i * L];
         o[u] = acc;
-        wd[u] = tx_pack_word(CL_TX_DOCUMENTED, tx_f2i16_fast(acc.x * 4096.0f), tx_f2i16_fast(acc.y * 4096.0f));
+        wd[u] = tx_pack_word(CL_TX_DOCUMENTED, tx_f2i16_bounded(acc.x * 4096.0f), tx_f2i16_bounded(acc.y * 4096.0f));
     }
     if (pack_mode == CL_TX_AS_WRITTEN) {                       // uniform: the shipped packer ignores its input
 #pragma unroll
@@ -738,7 +742,7 @@ __device__ __forceinline__ void tx_unit_emit(f32x2 (&o)[C::NOUT], const f32x2 ro
     for (int u = 0; u < NOUT; u++) {
         const f32x2 v = {__builtin_fmaf(o[u].x, rot.x, -o[u].y * rot.y), __builtin_fmaf(o[u].x, rot.y, o[u].y * rot.x)};
         o[u] = v;
-        wd[u] = tx_pack_word(CL_TX_DOCUMENTED, tx_f2i16_fast(v.x * 4096.0f), tx_f2i16_fast(v.y * 4096.0f));
+        wd[u] = tx_pack_word(CL_TX_DOCUMENTED, tx_f2i16_bounded(v.x * 4096.0f), tx_f2i16_bounded(v.y * 4096.0f));
     }
     if (pack_mode == CL_TX_AS_WRITTEN) {                       // uniform: the shipped packer ignores its input
 #pragma unroll
@@ -1034,6 +1038,7 @@ struct clhip_tx_pipe {
     int poll_bound;                  // look-back poll bound (diagnostic knob, default 2^22)
     hipStream_t last_stream; bool last_stream_valid;
     bool force_ticket;               // a look-back poll overran once in dispatch order: this pipe orders by ticket from now on
+    bool q_bounded;                  // FM mode: |resampled phasor| x 4096 < 2^31 whatever the message (finite taps, sum |taps| bounded)
     unsigned long long n_total;
     f32x2 *Y; size_t y_cap;          // modulated signal workspace (per stream)
     double *ws; size_t ws_cap;
@@ -1106,6 +1111,13 @@ extern "C" clhip_tx_pipe *clhip_tx_pipe_create(int n_streams, double fm_kf_hz, d
     if (resamp) { p->n_rs = n_rs; memcpy(p->rs, h_rs, sizeof(float) * n_rs); }
     else { p->n_rs = 1; p->rs[0] = 1.0f; }
     p->kp = (p->n_rs + up - 1) / up;
+    {   // the FM modulator's resampler input is a unit phasor (or NaN, from a NaN / infinite message): its outputs are bounded by
+        // the l1 norm of the taps, and the quantiser of the config-5 kernels may then skip cvttss2si's overflow branch
+        double l1 = 0;
+        bool finite = true;
+        for (int i = 0; i < p->n_rs; i++) { finite = finite && isfinite(p->rs[i]); l1 += fabs((double)p->rs[i]); }
+        p->q_bounded = finite && l1 * 4096.0 * 1.5 < 2147483648.0;      // (x 1.5: both components through the fp32 rotation)
+    }
     const int H = p->kp - 1 > 0 ? p->kp - 1 : 1;
     p->d_rs = (float *)clhip_malloc(sizeof p->rs);
     p->d_phase2 = (double *)clhip_malloc(sizeof(double) * 2 * n_streams);
@@ -1189,7 +1201,7 @@ extern "C" long clhip_tx_pipe_run(clhip_tx_pipe *p, int in_kind, const void *d_i
     const f32x2 *x = (const f32x2 *)d_in;
     long x_stride = (long)in_stride;
     static const int tx_fast = getenv("CLHIP_TX_FAST") ? atoi(getenv("CLHIP_TX_FAST")) : 1;
-    if (tx_fast && in_kind == CL_TXPIPE_IN_FM_MESSAGE && p->L == TxCfgC5::L && p->M == TxCfgC5::M &&
+    if (tx_fast && p->q_bounded && in_kind == CL_TXPIPE_IN_FM_MESSAGE && p->L == TxCfgC5::L && p->M == TxCfgC5::M &&
         p->n_rs == TxCfgC5::KP * TxCfgC5::L && (((uintptr_t)d_in) & 3) == 0) {
         // config 5 instantiation (see tx_fm_fast_kernel), in the virtual index space i' = i + phi
         typedef TxCfgC5 C;
