@@ -423,3 +423,59 @@ def test_config2_at_baseline_size_by_properties(G, orc):
     assert abs(float(dc[0]) - want_i) < 2e-3 and abs(float(dc[1]) - want_q) < 2e-3       # unit DC gain of both filters, to their ripple
     dev_ = (d[3000:].double().reshape(-1, 3, 2) - legs).abs().max()
     assert float(dev_) <= 4e-6, float(dev_)                        # the difference is the same constant everywhere: linear, shift-invariant
+
+
+def test_configs_3_and_4_at_baseline_size_by_properties(G, orc):
+    """BASELINE.json config 3 (S1G + HiF, 2^27 samples each, FIR64 + FM demod) and one GPU's share of config 4 (32 streams x
+    2^24 samples, FIR128 + 5/4) at the sizes bench.py runs them, through properties: a clean tone demodulates to its
+    constant phase step everywhere (a frequency the FIR passes), on both channel types; in the 32-stream pipe every stream
+    answers an impulse at its own position with the oracle's response scaled by its own amplitude and is zero elsewhere --
+    no stream sees another's samples."""
+    import torch
+    from cariboulite_amd import hip, synth
+    t = load_golden("taps.npz")
+    dev = G.DEV
+    # ---- config 3
+    n = 1 << 27
+    f0 = 137e3
+    step = 2 * np.pi * f0 / 4e6
+    for ch in (0, 1):
+        idx = torch.arange(n, device=dev, dtype=torch.float64)
+        i = torch.round(3000.0 * torch.cos(step * idx)).to(torch.int64) & 0x1FFF
+        q = torch.round(3000.0 * torch.sin(step * idx)).to(torch.int64) & 0x1FFF
+        a, b = (i, q) if ch == 0 else (q, i)
+        w = 0x80004000 | (a << 17) | (b << 1)
+        words = ((w + 2 ** 31) % 2 ** 32 - 2 ** 31).to(torch.int32)
+        del idx, i, q, a, b, w
+        pipe = hip.RxPipe(1, ch, t["fir64_c3"], None, 1, 1, hip.PIPE_OUT_FM_DEMOD)
+        out = torch.full((n + 8,), float("nan"), dtype=torch.float32, device=dev)
+        assert pipe.run(hip.PIPE_IN_SMI_WORDS, words, 0, n, out, 0) == n
+        torch.cuda.synchronize()
+        assert torch.isnan(out[n:]).all()
+        err = (out[64:n].double() - step).abs().max()              # behind the FIR's transient
+        assert float(err) < 2e-3, float(err)                       # 13-bit quantisation of a 3000-LSB tone: ~1/3000 rad
+        assert abs(float(out[64:n].double().mean()) - step) < 1e-6
+        del words, out
+    # ---- config 4, one GPU's share
+    ns, n4 = 32, 1 << 24
+    zero = int(synth.iq_to_words([0], [0], 0)[0]) - (1 << 32)
+    words = torch.full((ns, n4), zero, dtype=torch.int32, device=dev)
+    pos = [1000 + 524287 * s for s in range(ns)]                   # every stream somewhere else, the last near the end
+    for s in range(ns):
+        wv = int(synth.iq_to_words([100 * (s + 1)], [-50 * (s + 1)], 0)[0])
+        words[s, pos[s]] = wv - (1 << 32) if wv >= (1 << 31) else wv
+    pipe = hip.RxPipe(ns, 0, t["fir128_c4"], t["rs_5_4"], 5, 4, hip.PIPE_OUT_IQ)
+    no = pipe.out_count(n4)
+    out = torch.full((ns, no + 4, 2), float("nan"), dtype=torch.float32, device=dev)
+    assert pipe.run(hip.PIPE_IN_SMI_WORDS, words, n4, n4, out, no + 4) == no
+    torch.cuda.synchronize()
+    assert torch.isnan(out[:, no:]).all()
+    for s in range(ns):
+        lo = pos[s] // 4 * 4                                       # a multiple of M: the resampler's phase there is 0
+        x = np.zeros((512, 2)); x[pos[s] - lo] = (100 * (s + 1) / 4096.0, -50 * (s + 1) / 4096.0)
+        want = orc.Resampler(t["rs_5_4"], 5, 4).f64(orc.FIR(t["fir128_c4"]).f64(x))
+        m0 = lo * 5 // 4
+        got = out[s, m0:m0 + want.shape[0]].cpu().numpy()
+        assert np.max(np.abs(got - want)) <= TOL * np.max(np.abs(want)), s
+        rest = out[s, :no].clone(); rest[m0:m0 + want.shape[0]] = 0
+        assert int(torch.count_nonzero(rest)) == 0, s
