@@ -523,7 +523,7 @@ __device__ __forceinline__ double tx_fast_subblock(const float (&mv)[C::PER], si
 #pragma unroll
         for (int i = 0; i < KP; i++) acc += x[HS + bb - i] * tp[p + i * L];
         o[u] = acc;
-        wd[u] = tx_pack_word(CL_TX_DOCUMENTED, tx_f2i16_bounded(acc.x * 4096.0f), tx_f2i16_bounded(acc.y * 4096.0f));
+        wd[u] = tx_pack_word(CL_TX_DOCUMENTED, tx_f2i16_bounded(acc.x), tx_f2i16_bounded(acc.y));      // (the taps carry the 4096)
     }
     if (pack_mode == CL_TX_AS_WRITTEN) {                       // uniform: the shipped packer ignores its input
 #pragma unroll
@@ -540,7 +540,7 @@ __device__ __forceinline__ double tx_fast_subblock(const float (&mv)[C::PER], si
     }
     if (tap_s) {
 #pragma unroll
-        for (int u = 0; u < NOUT; u++) if (!CHECKED || (j0 + u >= 0 && j0 + u < n_out)) tap_s[j0 + u] = o[u];
+        for (int u = 0; u < NOUT; u++) if (!CHECKED || (j0 + u >= 0 && j0 + u < n_out)) tap_s[j0 + u] = o[u] * (1.0f / 4096.0f);   // exact
     }
     // the last HS samples of this sub-block become row -1 of the next one
     f32x2 keep = {0.f, 0.f};
@@ -742,7 +742,7 @@ __device__ __forceinline__ void tx_unit_emit(f32x2 (&o)[C::NOUT], const f32x2 ro
     for (int u = 0; u < NOUT; u++) {
         const f32x2 v = {__builtin_fmaf(o[u].x, rot.x, -o[u].y * rot.y), __builtin_fmaf(o[u].x, rot.y, o[u].y * rot.x)};
         o[u] = v;
-        wd[u] = tx_pack_word(CL_TX_DOCUMENTED, tx_f2i16_bounded(v.x * 4096.0f), tx_f2i16_bounded(v.y * 4096.0f));
+        wd[u] = tx_pack_word(CL_TX_DOCUMENTED, tx_f2i16_bounded(v.x), tx_f2i16_bounded(v.y));          // (the taps carry the 4096)
     }
     if (pack_mode == CL_TX_AS_WRITTEN) {                       // uniform: the shipped packer ignores its input
 #pragma unroll
@@ -759,7 +759,7 @@ __device__ __forceinline__ void tx_unit_emit(f32x2 (&o)[C::NOUT], const f32x2 ro
     }
     if (tap_s) {
 #pragma unroll
-        for (int u = 0; u < NOUT; u++) if (interior || (j0 + u >= 0 && j0 + u < n_out)) tap_s[j0 + u] = o[u];
+        for (int u = 0; u < NOUT; u++) if (interior || (j0 + u >= 0 && j0 + u < n_out)) tap_s[j0 + u] = o[u] * (1.0f / 4096.0f);   // exact
     }
 }
 
@@ -1031,6 +1031,7 @@ struct clhip_tx_pipe {
     double w;                        // 2 pi kf / fs
     float rs[TX_MAX_RS];
     float *d_rs;
+    float *d_rs_q;                   // the taps x 4096 (exact: a power of two) for the config-5 kernels, whose quantiser then needs no multiply
     f32x2 *hist[2]; int cur;         // [n_streams][kp-1] modulated samples preceding the call
     double *d_phase2; int pcur;      // [2][n_streams] ping-pong: the single-launch path writes the other half directly
     double *d_phase;                 // = d_phase2 + pcur * n_streams: the current phase of every stream
@@ -1126,6 +1127,13 @@ extern "C" clhip_tx_pipe *clhip_tx_pipe_create(int n_streams, double fm_kf_hz, d
     for (int i = 0; i < 2; i++) p->hist[i] = (f32x2 *)clhip_malloc(sizeof(f32x2) * H * n_streams);
     if (!p->d_rs || !p->d_phase || !p->hist[0] || !p->hist[1]) { clhip_tx_pipe_destroy(p); return nullptr; }
     (void)hipMemcpy(p->d_rs, p->rs, sizeof p->rs, hipMemcpyHostToDevice);
+    {
+        float q[TX_MAX_RS];
+        for (int i = 0; i < TX_MAX_RS; i++) q[i] = p->rs[i] * 4096.0f;
+        p->d_rs_q = (float *)clhip_malloc(sizeof q);
+        if (!p->d_rs_q) { clhip_tx_pipe_destroy(p); return nullptr; }
+        (void)hipMemcpy(p->d_rs_q, q, sizeof q, hipMemcpyHostToDevice);
+    }
     clhip_tx_pipe_reset(p);
     return p;
 }
@@ -1133,7 +1141,7 @@ extern "C" clhip_tx_pipe *clhip_tx_pipe_create(int n_streams, double fm_kf_hz, d
 extern "C" void clhip_tx_pipe_destroy(clhip_tx_pipe *p)
 {
     if (!p) return;
-    clhip_free(p->d_rs); clhip_free(p->d_phase2); clhip_free(p->hist[0]); clhip_free(p->hist[1]);
+    clhip_free(p->d_rs); clhip_free(p->d_rs_q); clhip_free(p->d_phase2); clhip_free(p->hist[0]); clhip_free(p->hist[1]);
     clhip_free(p->Y); clhip_free(p->ws);
     clhip_free(p->lb_st); clhip_free(p->lb_ticket);
     if (p->lb_err) (void)hipHostFree(p->lb_err);
@@ -1272,7 +1280,7 @@ extern "C" long clhip_tx_pipe_run(clhip_tx_pipe *p, int in_kind, const void *d_i
             if (tx_chain == 3)
                 hipLaunchKernelGGL(tx_fm_chain1_kernel<C>, dim3(n_wg), dim3(TXQ_NT), 0, s, (const float *)d_in, (long)in_stride, nv, phi,
                                    skip, wt, lb, n_units, p->n_streams, (const double *)p->d_phase, phase_new, p->hist[p->cur],
-                                   p->hist[p->cur ^ 1], p->d_rs, (long)n_out, p->pack_mode, (uint32_t *)d_bytes,
+                                   p->hist[p->cur ^ 1], p->d_rs_q, (long)n_out, p->pack_mode, (uint32_t *)d_bytes,
                                    (long)(out_stride_bytes / 4), (f32x2 *)d_iq_tap, (long)iq_tap_stride);
             else {
                 constexpr size_t keep_bytes = TXQ_KEEP == 2 ? sizeof(float) * TXQ_NSUB * C::SUB : 0;
@@ -1282,7 +1290,7 @@ extern "C" long clhip_tx_pipe_run(clhip_tx_pipe *p, int in_kind, const void *d_i
                 }
                 hipLaunchKernelGGL(tx_fm_chain_kernel<C>, dim3(n_wg), dim3(TXQ_NT), keep_bytes, s, (const float *)d_in, (long)in_stride, nv, phi,
                                    skip, wt, lb, n_super, p->n_streams, (const double *)p->d_phase, phase_new, p->hist[p->cur],
-                                   p->hist[p->cur ^ 1], p->d_rs, (long)n_out, p->pack_mode, (uint32_t *)d_bytes,
+                                   p->hist[p->cur ^ 1], p->d_rs_q, (long)n_out, p->pack_mode, (uint32_t *)d_bytes,
                                    (long)(out_stride_bytes / 4), (f32x2 *)d_iq_tap, (long)iq_tap_stride);
             }
             if (use_ticket) p->ticket_total += n_wg;               // the device counter moves only when tickets are taken
@@ -1297,7 +1305,7 @@ extern "C" long clhip_tx_pipe_run(clhip_tx_pipe *p, int in_kind, const void *d_i
                            p->ws, n_super);
         hipLaunchKernelGGL(fm_super_scan_kernel, dim3(p->n_streams), dim3(256), 0, s, p->ws, n_super, p->d_phase, phase_new);
         hipLaunchKernelGGL(tx_fm_fast_kernel<C>, grid, dim3(TXQ_NT), 0, s, (const float *)d_in, (long)in_stride, nv, phi, skip, wt,
-                           p->ws, n_super, p->hist[p->cur], p->hist[p->cur ^ 1], p->d_rs, (long)n_out, p->pack_mode,
+                           p->ws, n_super, p->hist[p->cur], p->hist[p->cur ^ 1], p->d_rs_q, (long)n_out, p->pack_mode,
                            (uint32_t *)d_bytes, (long)(out_stride_bytes / 4), (f32x2 *)d_iq_tap, (long)iq_tap_stride);
         CLHIP_CHECK(hipMemcpyAsync(p->d_phase, phase_new, sizeof(double) * p->n_streams, hipMemcpyDeviceToDevice, s));
         CLHIP_CHECK_LAUNCH();
