@@ -793,7 +793,7 @@ __device__ __forceinline__ unsigned long long tx_look_back(const TxLookBack &lb,
 }
 
 template <class C>
-__global__ __launch_bounds__(TXQ_NT, 2) void tx_fm_chain_kernel(
+__global__ __launch_bounds__(TXQ_NT, 5) void tx_fm_chain_kernel(
     const float *__restrict__ m, long m_stride, size_t n, int phi, int skip, double wt, TxLookBack lb, long n_super,
     int n_streams, const double *__restrict__ phase_in, double *__restrict__ phase_new,
     const f32x2 *__restrict__ hist_in, f32x2 *__restrict__ hist_out, const float *__restrict__ rs_dev,
