@@ -43,3 +43,17 @@ def load_golden(name):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Leave nothing of ours for the interpreter's shutdown to destroy in arbitrary order: objects that own GPU memory, HIP
+    streams or a reader thread (pipes, filters, Soapy devices a failed test left open) are collected here, while the HIP
+    runtime is certainly alive, and the GPU is idle when the process starts to exit."""
+    import gc
+    gc.collect()
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+    except Exception:
+        pass
