@@ -320,6 +320,14 @@ __global__ __launch_bounds__(FM_BLOCK) void tx_fm_fused_kernel(
 #ifndef TXQ_NSUB
 #define TXQ_NSUB 6
 #endif
+#ifndef TXQ_CHAIN_WAVES
+#define TXQ_CHAIN_WAVES 5                  // waves per SIMD the chain kernel's register budget is cut for (96 VGPRs; 97 would round to 104 and leave four)
+#endif
+#ifndef TXQ_PREFETCH
+#define TXQ_PREFETCH 0                     // 1: the chain kernel requests sub-block sb + 1's messages before it works sub-block sb: 12 registers more, 122 VGPRs
+                                           // = four waves per SIMD; config 5, one box: 0.267-0.272 ms without (five waves), 0.274-0.282 with (four), 0.277-0.282
+                                           // without at four waves, 0.39 with at five (spills): the fifth wave hides what the prefetch would
+#endif
 #ifndef TXQ_P1_REVERSE
 #define TXQ_P1_REVERSE 1                   // the sum pass walks the superblock backwards: the second pass then starts on the most recently read lines (-4 % HBM reads, -1 % time)
 #endif
@@ -793,7 +801,7 @@ __device__ __forceinline__ unsigned long long tx_look_back(const TxLookBack &lb,
 }
 
 template <class C>
-__global__ __launch_bounds__(TXQ_NT, 5) void tx_fm_chain_kernel(
+__global__ __launch_bounds__(TXQ_NT, TXQ_CHAIN_WAVES) void tx_fm_chain_kernel(
     const float *__restrict__ m, long m_stride, size_t n, int phi, int skip, double wt, TxLookBack lb, long n_super,
     int n_streams, const double *__restrict__ phase_in, double *__restrict__ phase_new,
     const f32x2 *__restrict__ hist_in, f32x2 *__restrict__ hist_out, const float *__restrict__ rs_dev,
@@ -898,6 +906,36 @@ __global__ __launch_bounds__(TXQ_NT, 5) void tx_fm_chain_kernel(
     if (t < HS) *(f32x2 *)(rows + 8 * (PER - HS + t)) = keep;
     double off = off0 + tot0;
     off -= floor(off);
+#if TXQ_PREFETCH && !TXQ_KEEP
+    // the messages of sub-block sb + 1 are requested before sub-block sb is worked (12 registers more per lane)
+    float mvn[PER];
+    {
+        const size_t base1 = sbase + (size_t)C::SUB;
+        if (base1 < n) {
+            if (base1 > 0 && base1 + C::SUB < n) tx_load_msgs<C, false>(mm, n, phi, base1 + (size_t)t * PER, mvn);
+            else tx_load_msgs<C, true>(mm, n, phi, base1 + (size_t)t * PER, mvn);
+        }
+    }
+#pragma unroll
+    for (int sb = 1; sb < TXQ_NSUB; sb++) {
+        const size_t base = sbase + (size_t)sb * C::SUB;          // workgroup-uniform
+        if (base >= n) break;
+        float mv[PER];
+#pragma unroll
+        for (int k = 0; k < PER; k++) mv[k] = mvn[k];
+        const size_t basen = base + (size_t)C::SUB;
+        if (sb + 1 < TXQ_NSUB && basen < n) {
+            if (basen + C::SUB < n) tx_load_msgs<C, false>(mm, n, phi, basen + (size_t)t * PER, mvn);
+            else tx_load_msgs<C, true>(mm, n, phi, basen + (size_t)t * PER, mvn);
+        }
+        if (base > 0 && base + C::SUB < n)
+            off = tx_fast_subblock<C, false>(mv, n, phi, skip, wt, off, base, rows, sh, hist_in + (long)s * H,
+                                             hist_out + (long)s * H, rs, n_out, pack_mode, words_s, tap_s);
+        else
+            off = tx_fast_subblock<C, true>(mv, n, phi, skip, wt, off, base, rows, sh, hist_in + (long)s * H,
+                                            hist_out + (long)s * H, rs, n_out, pack_mode, words_s, tap_s);
+    }
+#else
 #pragma unroll
     for (int sb = 1; sb < TXQ_NSUB; sb++) {
         const size_t base = sbase + (size_t)sb * C::SUB;          // workgroup-uniform
@@ -923,6 +961,7 @@ __global__ __launch_bounds__(TXQ_NT, 5) void tx_fm_chain_kernel(
                                             hist_out + (long)s * H, rs, n_out, pack_mode, words_s, tap_s);
         }
     }
+#endif
 }
 
 // ---------------------------------------------------------------------------
