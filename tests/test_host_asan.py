@@ -20,3 +20,21 @@ def test_fifo_and_ring_bookkeeping_under_asan(tmp_path):
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0 and "harness ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_ring_span_calls_two_threads_under_tsan(tmp_path):
+    """The ring is not locked between a span's _begin and _end (round 3): one producer and one consumer thread hammer it under
+    ThreadSanitizer -- a storage access of one inside the other's open span would be a reported race -- and the consumer
+    checks that what it reads is strictly increasing (tests/cpp/test_ring_tsan.c)."""
+    from cariboulite_amd import _build
+    _build.build_all()
+    pkg = os.path.join(ROOT, "cariboulite_amd")
+    host = os.path.join(pkg, "csrc", "host")
+    exe = str(tmp_path / "ring_tsan")
+    cmd = ["gcc", "-std=gnu11", "-O1", "-g", "-fsanitize=thread", "-fno-omit-frame-pointer",
+           os.path.join(ROOT, "tests", "cpp", "test_ring_tsan.c"), os.path.join(host, "cl_ring.c"),
+           "-I", host, "-I", os.path.join(ROOT, "include"), "-L", pkg, "-lcariboulite_hip", f"-Wl,-rpath,{pkg}", "-lpthread", "-o", exe]
+    subprocess.run(cmd, check=True)
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1:exitcode=66")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "ring tsan harness ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
