@@ -1417,6 +1417,24 @@ extern "C" size_t clhip_iir_debug_stamps(clhip_iir *f, unsigned long long *h_out
 }
 
 extern "C" void clhip_iir_set_poll_bound(clhip_iir *f, int polls) { if (f) f->poll_bound = polls; }
+
+// The filter's MEMORY in samples: after that many samples nothing a state could have held is left above the single-pass
+// kernel's bound (1e-12 absolute for full-scale int16 input: iir_rail_tab_build).  A filter that starts from rest that far
+// before a point of the stream is, from that point on, in the state of a filter that has seen the whole stream -- which is
+// what lets one long stream be cut into time slices for several GPUs with a halo instead of a state hand-off
+// (cariboulite_amd/shard.py run_iir_time_slice).  0: the memory is longer than the kernel's horizon.
+extern "C" size_t clhip_iir_memory_samples(const clhip_iir *f)
+{
+    if (!f) return 0;
+    size_t best = 0;
+    for (int i = 0; i < 3; i++) {
+        const int h = f->pe->host.rail[i].horizon;
+        if (h <= 0) continue;
+        const size_t m = (size_t)h * RL_SEGS * (size_t)kRailSegs[i];
+        if (!best || m < best) best = m;
+    }
+    return best;
+}
 extern "C" int clhip_iir_on_scan_path(const clhip_iir *f) { return f && f->force_scan ? 1 : 0; }
 
 extern "C" int clhip_iir_set_state(clhip_iir *f, const double *h_state)

@@ -1200,6 +1200,20 @@ extern "C" void clhip_tx_pipe_reset(clhip_tx_pipe *p)
     (void)hipStreamSynchronize(nullptr);       // the fills ran on the null stream; non-blocking streams do not wait for it
 }
 
+// Place a pipe inside a long stream (time slicing over GPUs): as after clhip_tx_pipe_reset, but the next
+// run is message n_total of the stream (polyphase phase n_total mod M) and the modulator's phase before it is h_phase_rad[s]
+// -- the 8-byte hand-off a slice owner receives: the phase is a prefix sum of the messages, the one state of the TX pipe
+// that no halo can rebuild.  The resampler history is zero: the owner runs the kp - 1 (or more) messages before its slice
+// first and discards what they produce (cariboulite_amd/shard.py run_fm_time_slice).
+extern "C" int clhip_tx_pipe_seek(clhip_tx_pipe *p, unsigned long long n_total, const double *h_phase_rad)
+{
+    if (!p || !h_phase_rad) { clhip_set_error("clhip_tx_pipe_seek: null argument"); return -1; }
+    clhip_tx_pipe_reset(p);
+    CLHIP_CHECK(hipMemcpy(p->d_phase, h_phase_rad, sizeof(double) * p->n_streams, hipMemcpyHostToDevice));
+    p->n_total = n_total;
+    return 0;
+}
+
 // After the caller has synchronised the stream of the last clhip_tx_pipe_run: 0 = its output is valid.  -1 = the
 // look-back guard fired (a workgroup gave up waiting for a predecessor's phase and carried on with a made-up one):
 // the bytes of that call must not be used; the pipe is put back to its pre-call state (phase, resampler history,

@@ -63,6 +63,7 @@ _SIGS = {
     "clhip_iir_set_poll_bound": (None, [C.c_void_p, C.c_int]),
     "clhip_iir_on_scan_path": (C.c_int, [C.c_void_p]),
     "clhip_iir_debug_stamps": (C.c_size_t, [C.c_void_p, C.c_void_p]),
+    "clhip_iir_memory_samples": (C.c_size_t, [C.c_void_p]),
     "clhip_rx_pipe_create": (C.c_void_p, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "clhip_rx_pipe_destroy": (None, [C.c_void_p]),
     "clhip_rx_pipe_reset": (None, [C.c_void_p]),
@@ -84,6 +85,7 @@ _SIGS = {
     "clhip_tx_pipe_destroy": (None, [C.c_void_p]),
     "clhip_tx_pipe_reset": (None, [C.c_void_p]),
     "clhip_tx_pipe_out_count": (C.c_size_t, [C.c_void_p, C.c_size_t]),
+    "clhip_tx_pipe_seek": (C.c_int, [C.c_void_p, C.c_ulonglong, C.c_void_p]),
     "clhip_tx_pipe_run": (C.c_long, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
                                      C.c_void_p, C.c_size_t, C.c_void_p]),
     "clhip_tx_pipe_status": (C.c_int, [C.c_void_p]),
@@ -275,6 +277,10 @@ class IIR:
     def set_poll_bound(self, polls):
         lib().clhip_iir_set_poll_bound(self.h, int(polls))
 
+    def memory_samples(self):
+        """samples after which nothing of an earlier state is left above 1e-12 (0: longer than the kernel's horizon)"""
+        return lib().clhip_iir_memory_samples(self.h)
+
     def on_scan_path(self):
         return bool(lib().clhip_iir_on_scan_path(self.h))
 
@@ -321,6 +327,11 @@ class TxPipe:
 
     def out_count(self, n_in):
         return lib().clhip_tx_pipe_out_count(self.h, n_in)
+
+    def seek(self, n_total, phase_rad):
+        """reset + place the pipe at message n_total of a longer stream with the modulator's phase (radians, per stream) there"""
+        ph = np.ascontiguousarray(np.atleast_1d(phase_rad), dtype=np.float64)
+        _check(lib().clhip_tx_pipe_seek(self.h, int(n_total), ph.ctypes.data), "clhip_tx_pipe_seek")
 
     def status(self):
         """0 = the last run's bytes are valid (ask after synchronising its stream), -1 = look-back overrun."""

@@ -46,6 +46,63 @@ def run_time_slice(pipe, in_kind, d_in, start, stop, d_out, out_count_fn, scratc
     return pipe.run(in_kind, d_in[start:], 0, stop - start, d_out, 0)
 
 
+def run_iir_time_slice(filt, d_iq, start, stop, d_out, scratch):
+    """Filter samples [start, stop) of one long device-resident CS16 stream `d_iq` (rows of (i, q) int16) with the IIR object
+    `filt` as if it had filtered everything before `start`: the filter has a finite memory (IIR.memory_samples(): nothing of
+    an older state is left above 1e-12), so it starts from rest that many samples earlier, its outputs over that halo go to
+    `scratch`, and from `start` on it is in the whole stream's state -- a halo, not a state hand-off, and no collective.
+    Returns the number of samples written to d_out."""
+    mem = filt.memory_samples()
+    if mem == 0:
+        raise ValueError("this filter's memory is longer than the single-pass kernel's horizon: slice with a state hand-off")
+    filt.state = None                                   # at rest
+    h0 = max(start - mem, 0)
+    if start > h0:
+        filt.run(d_iq[h0:], start - h0, out=scratch)
+    filt.run(d_iq[start:], stop - start, out=d_out)
+    return stop - start
+
+
+def fm_slice_phases(d_msg, slices, kf_hz, fs_hz, dist=None):
+    """The modulator's phase (radians, wrapped) at the start of every time slice of ONE long message stream: an exclusive
+    prefix over the slices' phase sums 2 pi kf / fs * sum(m) (fp64) -- 8 bytes per slice boundary.  Single process: all
+    slices are summed here; with torch.distributed every rank sums its own slice and the sums meet in one all_gather of a
+    double (the only exchange the sliced TX path has)."""
+    import math
+    import torch
+    w = 2.0 * math.pi * kf_hz / fs_hz
+    if dist is None:
+        sums = [float(d_msg[a:b].double().sum()) * w for (a, b) in slices]
+    else:
+        a, b = slices[dist.get_rank()]
+        mine = (d_msg[a:b].double().sum() * w).reshape(1)
+        gathered = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(gathered, mine)
+        sums = [float(g) for g in gathered]
+    out, acc = [], 0.0
+    for v in sums:
+        out.append(math.remainder(acc, 2.0 * math.pi))
+        acc += v
+    return out
+
+
+def run_fm_time_slice(pipe, d_msg, start, stop, phase_at_start, kf_hz, fs_hz, d_bytes, scratch_bytes, halo=64):
+    """FM-modulate, resample, quantise and pack messages [start, stop) of one long device-resident message stream with the TX
+    pipe `pipe` as if it had seen everything before `start`: the modulator's phase there is `phase_at_start`
+    (fm_slice_phases: the hand-off), the resampler's history is rebuilt from the `halo` messages before the slice (a
+    multiple of the decimation M; their outputs go to scratch_bytes).  Returns the number of output words written."""
+    import math
+    from . import hip
+    h0 = max(start - halo, 0)
+    w = 2.0 * math.pi * kf_hz / fs_hz
+    ph0 = phase_at_start - (float(d_msg[h0:start].double().sum()) * w if start > h0 else 0.0)
+    pipe.seek(h0, math.remainder(ph0, 2.0 * math.pi))
+    if start > h0:
+        pipe.run(hip.TXPIPE_IN_FM_MESSAGE, d_msg[h0:], 0, start - h0, scratch_bytes, scratch_bytes.numel())
+    no = pipe.out_count(stop - start)
+    return pipe.run(hip.TXPIPE_IN_FM_MESSAGE, d_msg[start:], 0, stop - start, d_bytes, 4 * no)
+
+
 def owner_of(stream, world):
     return stream % world
 

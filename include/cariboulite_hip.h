@@ -194,6 +194,10 @@ int    clhip_iir_finish(clhip_iir *f);
 /* carried state: 16 doubles per stream (NULL = rest); both synchronise with the last call */
 int    clhip_iir_set_state(clhip_iir *f, const double *h_state);
 int    clhip_iir_get_state(clhip_iir *f, double *h_state);
+/* Samples after which nothing of an earlier state is left above 1e-12 (full-scale int16 input): a filter started from rest
+ * that far before a point of a stream is in the whole stream's state from that point on -- time slices of one long stream
+ * for several GPUs need a halo of this length, not a state hand-off.  0 = longer than the single-pass kernel's horizon. */
+size_t clhip_iir_memory_samples(const clhip_iir *f);
 void   clhip_iir_set_poll_bound(clhip_iir *f, int polls);   /* test hook: -1 forces every poll to give up */
 int    clhip_iir_on_scan_path(const clhip_iir *f);           /* 1 once an overrun (or CLHIP_IIR_ONEPASS=0) has switched it */
 /* diagnostics (objects created under CLHIP_IIR_STAMPS=1): per-phase time stamps of the last single-pass launch,
@@ -290,6 +294,10 @@ clhip_tx_pipe *clhip_tx_pipe_create(int n_streams, double fm_kf_hz, double fs_hz
                                     int pack_mode);
 void   clhip_tx_pipe_destroy(clhip_tx_pipe *p);
 void   clhip_tx_pipe_reset(clhip_tx_pipe *p);
+/* as _reset, but the next run is message n_total of a longer stream and the modulator's phase before it is h_phase_rad[stream]
+ * (radians): the carried-state hand-off of a time slice; the resampler history is rebuilt by running
+ * the messages just before the slice and discarding their outputs */
+int    clhip_tx_pipe_seek(clhip_tx_pipe *p, unsigned long long n_total, const double *h_phase_rad);
 size_t clhip_tx_pipe_out_count(const clhip_tx_pipe *p, size_t n_in);
 long   clhip_tx_pipe_run(clhip_tx_pipe *p, int in_kind, const void *d_in, size_t in_stride_elems,
                          size_t n_in, uint8_t *d_bytes, size_t out_stride_bytes,

@@ -598,3 +598,75 @@ def test_tx_config5_at_baseline_size_by_properties(G, orc):
     ia, ib = _tx_words_to_iq(ba.cpu().numpy().view(np.uint32)), _tx_words_to_iq(bb.cpu().numpy().view(np.uint32))
     d13 = np.abs(ia - ib); d13 = np.minimum(d13, 8192 - d13)
     assert d13.max() <= 1
+
+
+@pytest.mark.parametrize("bw_khz", [100, 50, 20])
+def test_iir_time_slices_with_a_halo_equal_one_filter(G, orc, bw_khz):
+    """SURVEY.md section 8e names a carried-state hand-off for slicing one long stream through the IIR over several GPUs.  The
+    filter's memory is finite (clhip_iir_memory_samples: nothing of an older state is left above 1e-12), so a slice owner
+    starts from rest that many samples before its slice and discards the halo's outputs: the concatenated slices equal ONE
+    filter's output over the whole stream, sample for sample -- no state message, no collective (shard.run_iir_time_slice)."""
+    import torch
+    from cariboulite_amd import hip, shard, soapy as S
+    n = 6_000_000 + 12345
+    iq = torch.randint(-4096, 4096, (n, 2), dtype=torch.int16, device=G.DEV)
+    sos = S.design_butter_lowpass(6, 4e6, bw_khz * 1e3 / 2)
+    one = hip.IIR(sos)
+    ref = torch.empty_like(iq)
+    one.run(iq, n, out=ref)
+    torch.cuda.synchronize()
+    assert one.status() == 0
+    mem = one.memory_samples()
+    assert 0 < mem <= 65536, mem
+    for world in (2, 5):
+        got = torch.zeros_like(iq)
+        scratch = torch.empty((mem + 8, 2), dtype=torch.int16, device=G.DEV)
+        for (a, b) in shard.time_slices(n, world, 1):
+            f = hip.IIR(sos)
+            assert shard.run_iir_time_slice(f, iq, a, b, got[a:], scratch) == b - a
+            torch.cuda.synchronize()
+            assert f.status() == 0
+        assert torch.equal(got, ref), (bw_khz, world, int((got != ref).sum()))
+
+
+def test_tx_fm_time_slices_with_a_phase_hand_off_equal_one_pipe(G, orc):
+    """the FM modulator's phase is a prefix sum over the whole message stream -- the one state of the
+    TX pipe a halo cannot rebuild.  Time slices of one long stream (one per GPU in production) therefore get the phase at
+    their start as an 8-byte hand-off (an exclusive prefix over the slices' fp64 phase sums: shard.fm_slice_phases, one
+    all_gather of a double under torch.distributed) and rebuild the resampler history from a short halo
+    (clhip_tx_pipe_seek + shard.run_fm_time_slice): the concatenated words equal ONE pipe's up to the rare one-LSB
+    truncation flips that any re-association of the fp64 phase sums produces (the bar of the chunked-vs-one-shot test)."""
+    import torch
+    from cariboulite_amd import hip, shard
+    t = load_golden("taps.npz")
+    dev = G.DEV
+    n = 3 * 1_000_001
+    gen = torch.Generator(device=dev); gen.manual_seed(9)
+    msg = 0.3 * torch.randn(n, device=dev, generator=gen)
+    kf, fs = 75e3, 4e6
+    one = hip.TxPipe(1, kf, fs, t["rs_2_3"], 2, 3, hip.TX_DOCUMENTED)
+    no = one.out_count(n)
+    ref = torch.zeros(4 * no, dtype=torch.uint8, device=dev)
+    assert one.run(hip.TXPIPE_IN_FM_MESSAGE, msg, 0, n, ref, 4 * no) == no
+    torch.cuda.synchronize()
+    assert one.status() == 0
+    for world in (2, 5):
+        slices = shard.time_slices(n, world, 3)                    # slice starts on polyphase phase 0 (M = 3)
+        phases = shard.fm_slice_phases(msg, slices, kf, fs)
+        got = torch.zeros_like(ref)
+        scratch = torch.zeros(4 * 64, dtype=torch.uint8, device=dev)
+        pos = 0
+        for (a, b), ph in zip(slices, phases):
+            if b <= a:
+                continue
+            p = hip.TxPipe(1, kf, fs, t["rs_2_3"], 2, 3, hip.TX_DOCUMENTED)
+            assert pos == a * 2 // 3
+            k = shard.run_fm_time_slice(p, msg, a, b, ph, kf, fs, got[4 * pos:], scratch, halo=63)
+            torch.cuda.synchronize()
+            assert p.status() == 0
+            pos += k
+        assert pos == no
+        wa, wb = got.cpu().numpy().view(np.uint32), ref.cpu().numpy().view(np.uint32)
+        assert np.mean(wa != wb) < 2e-3, (world, float(np.mean(wa != wb)))
+        d13 = np.abs(_tx_words_to_iq(wa) - _tx_words_to_iq(wb)); d13 = np.minimum(d13, 8192 - d13)
+        assert d13.max() <= 1, world

@@ -129,3 +129,41 @@ def test_time_slices_cover_the_stream():
         for (a, b), (c, d) in zip(sl, sl[1:]):
             assert b == c and a <= b
         assert all(a % align == 0 for a, _ in sl if a < n)
+
+
+def _phase_worker(rank, world, port, n, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch
+    import torch.distributed as dist
+    from cariboulite_amd import shard
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator(); g.manual_seed(3)
+    msg = 0.3 * torch.randn(n, generator=g)                       # every rank can see the stream; it sums only its own slice
+    slices = shard.time_slices(n, world, 3)
+    q.put((rank, shard.fm_slice_phases(msg, slices, 75e3, 4e6, dist=dist)))
+    dist.destroy_process_group()
+
+
+def test_fm_slice_phase_hand_off_two_ranks_gloo():
+    """The sliced TX path's one exchange: every rank sums its own slice's phase increments (fp64) and ONE all_gather of a
+    double gives every rank the phase at the start of every slice -- the same values a single process computes."""
+    import torch
+    import torch.multiprocessing as mp
+    from cariboulite_amd import shard
+    world, n = 2, 300_003
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_phase_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = torch.Generator(); g.manual_seed(3)
+    msg = 0.3 * torch.randn(n, generator=g)
+    want = shard.fm_slice_phases(msg, shard.time_slices(n, world, 3), 75e3, 4e6)
+    assert res[0] == res[1] == want and want[0] == 0.0 and want[1] != 0.0
