@@ -316,7 +316,8 @@ __global__ __launch_bounds__(FM_BLOCK) void tx_fm_fused_kernel(
 #define TXQ_KEEP 0
 #endif
 // sub-blocks per superblock (round 2, look-back in front of the arithmetic): 4 -> 0.290 ms, 5 -> 0.276, 6 -> 0.268, 7 -> 0.276,
-// 8 -> 0.274 (config 5, 2^27 messages)
+// 8 -> 0.274 (config 5, 2^27 messages); round 3, at five waves per SIMD (96 VGPRs: 7 and 8 sub-blocks spill): 4 -> 0.281, 5 -> 0.277,
+// 6 -> 0.270, 7 -> 0.288-0.298, 8 -> 0.326 (tools/bench_tx.py, one box)
 #ifndef TXQ_NSUB
 #define TXQ_NSUB 6
 #endif
