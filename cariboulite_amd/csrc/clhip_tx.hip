@@ -305,7 +305,10 @@ __global__ __launch_bounds__(FM_BLOCK) void tx_fm_fused_kernel(
 // LDS rows: PER samples (8 B each) + 16 B pad -> lane pitch 112 B at PER = 12: ds_write_b128 /
 // ds_read_b128 are conflict-free.  Row -1 holds the 8 samples before the sub-block.
 // ---------------------------------------------------------------------------
-#define TXQ_NT 256
+#ifndef TXQ_NT
+#define TXQ_NT 256                         // lanes per workgroup.  Config 5 through the chain kernel, one box (round 3): 64 lanes x 12 / 24 sub-blocks
+#endif                                     // 0.43-0.50 ms, 128 x 6 / 12: 0.29 / 0.39, 256 x 6: 0.269-0.277, 512 x 3 / 4 / 6: 0.32 / 0.31 / 0.31, 1024 x 3: 0.37
+                                           // -- barriers are not what it waits for: smaller workgroups mean more look-back words per message
 // TXQ_KEEP=1 (compile-time experiment): the superblock's messages stay in registers between the sum pass and the
 // sub-block loop, so the stream is read once -- 147 / 179 / 234 VGPRs at 3 / 4 / 6 sub-blocks instead of 85, and
 // 0.295 / 0.318 / 0.284 ms on config 5 against 0.268 with the re-read: occupancy, which hides the look-back, is worth more
