@@ -643,6 +643,7 @@ struct IirRailArgs {
     double *state_out;
     unsigned int *overrun;                 // the object's pinned host word (device address)
     int poll_bound, dbg, n_classes, dynamic, prio;
+    int in_sh0, in_sh1, in_width;          // where the two rails sit in an input word: CS16 {0, 16, 16}; raw SMI words {17, 1, 13} (S1G) / {1, 17, 13} (HiF)
     unsigned long long *stamps;            // diagnostics (CLHIP_IIR_STAMPS=1): [RL_STAMP_WAVES][RL_STAMP_TILES][RL_STAMP_PHASES] of s_memrealtime
 };
 #define RL_STAMP_WAVES 64
@@ -654,9 +655,9 @@ struct IirRailArgs {
 
 // zs += sum_k (F^(SEG-1-k) g) x[k] for the lane's rail over its LDS row; taps as in iir_segment_fir
 template <int D>
-__device__ __forceinline__ void rail_fir_pair(double *v, const IirTaps2<D> &tp, uint32_t w0, uint32_t w1, int sh)
+__device__ __forceinline__ void rail_fir_pair(double *v, const IirTaps2<D> &tp, uint32_t w0, uint32_t w1, int sh, int wd)
 {
-    const double x0 = (double)(int)__builtin_amdgcn_sbfe((int)w0, sh, 16), x1 = (double)(int)__builtin_amdgcn_sbfe((int)w1, sh, 16);
+    const double x0 = (double)(int)__builtin_amdgcn_sbfe((int)w0, sh, wd), x1 = (double)(int)__builtin_amdgcn_sbfe((int)w1, sh, wd);
 #pragma unroll
     for (int r = 0; r < D; r++) v[r] = __builtin_fma(tp.g[0][r], x0, v[r]);
 #pragma unroll
@@ -664,7 +665,7 @@ __device__ __forceinline__ void rail_fir_pair(double *v, const IirTaps2<D> &tp, 
 }
 
 template <int D, int SEG>
-__device__ __forceinline__ void rail_segment_fir(double *v, const uint32_t *x, const cdouble_t *G, int sh)
+__device__ __forceinline__ void rail_segment_fir(double *v, const uint32_t *x, const cdouble_t *G, int sh, int wd)
 {
     constexpr int BLK = 16;
     static_assert(SEG % BLK == 0, "segments are whole blocks");
@@ -683,13 +684,13 @@ __device__ __forceinline__ void rail_segment_fir(double *v, const uint32_t *x, c
             iir_taps_wait<D>(ta);
             iir_taps_load<D>(tb, gb - (k + 2) * IIR_MAX_DIM);
             __builtin_amdgcn_sched_barrier(0);
-            rail_fir_pair<D>(v, ta, xr[k / 4][0], xr[k / 4][1], sh);
+            rail_fir_pair<D>(v, ta, xr[k / 4][0], xr[k / 4][1], sh, wd);
             __builtin_amdgcn_sched_barrier(0);
             iir_taps_wait<D>(tb);
             const cdouble_t *gn = (kb + k + 4 < SEG) ? gb - (k + 4) * IIR_MAX_DIM : G + IIR_MAX_DIM;
             iir_taps_load<D>(ta, gn);
             __builtin_amdgcn_sched_barrier(0);
-            rail_fir_pair<D>(v, tb, xr[k / 4][2], xr[k / 4][3], sh);
+            rail_fir_pair<D>(v, tb, xr[k / 4][2], xr[k / 4][3], sh, wd);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -702,7 +703,7 @@ __device__ __forceinline__ void rail_segment_fir(double *v, const uint32_t *x, c
 // is the unit this kernel is bound by.  Both lanes of a pair have read a 16-byte group before either writes into it
 // (one wave, LDS operations in order).
 template <int NS, int SEG, bool FULL, bool B121>
-__device__ __forceinline__ void rail_recursion(const IirCoef &c, uint32_t *x, long cnt, double *z, int sh, int rail)
+__device__ __forceinline__ void rail_recursion(const IirCoef &c, uint32_t *x, long cnt, double *z, int sh, int wd, int rail)
 {
     uint16_t *xo = (uint16_t *)x + rail;
 #pragma unroll 2
@@ -713,7 +714,7 @@ __device__ __forceinline__ void rail_recursion(const IirCoef &c, uint32_t *x, lo
 #pragma unroll
             for (int j = 0; j < 4; j += 2) {
                 double y0, y1;
-                iir_step2<NS, B121>(c, z, (double)(int)__builtin_amdgcn_sbfe((int)w[j], sh, 16), (double)(int)__builtin_amdgcn_sbfe((int)w[j + 1], sh, 16), y0, y1);
+                iir_step2<NS, B121>(c, z, (double)(int)__builtin_amdgcn_sbfe((int)w[j], sh, wd), (double)(int)__builtin_amdgcn_sbfe((int)w[j + 1], sh, wd), y0, y1);
                 xo[2 * (k + j)] = (uint16_t)(uint32_t)(int)(float)y0;            // (the low half: cvttss2si's, see iir_to_i16)
                 xo[2 * (k + j + 1)] = (uint16_t)(uint32_t)(int)(float)y1;
             }
@@ -721,7 +722,7 @@ __device__ __forceinline__ void rail_recursion(const IirCoef &c, uint32_t *x, lo
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 if (k + j < cnt)                                        // uniform over the pair
-                    xo[2 * (k + j)] = (uint16_t)(uint32_t)(int)(float)iir_step<NS>(c, z, (double)(int)__builtin_amdgcn_sbfe((int)w[j], sh, 16));
+                    xo[2 * (k + j)] = (uint16_t)(uint32_t)(int)(float)iir_step<NS>(c, z, (double)(int)__builtin_amdgcn_sbfe((int)w[j], sh, wd));
             }
         }
     }
@@ -876,7 +877,7 @@ __global__ __launch_bounds__(64, RL_WAVES) void iir_rail_kernel(const IirRailArg
         // bn (when have_next) is the tile the NEXT step works on: a prologue step requests its words as soon as its own
         // have left the registers.
         auto rows_fir_scan = [&](long b, bool have_next, long bn, bool issue_next_now, int t, const cdouble_t *G, const cdouble_t *pow2, double (&v)[D]) {
-            const int m = t >> 1, sh = (t & 1) << 4;
+            const int m = t >> 1, sh = (t & 1) ? A.in_sh1 : A.in_sh0;
             const uint32_t *xin = sin + b * TILE;
             const bool whole = tile_whole(b);
             if constexpr (!PF) rail_tile_issue<SEG>(xin, whole, raw, t);
@@ -888,7 +889,7 @@ __global__ __launch_bounds__(64, RL_WAVES) void iir_rail_kernel(const IirRailArg
             RL_STAMP(1);
 #pragma unroll
             for (int k = 0; k < D; k++) v[k] = 0.0;
-            if (!(A.dbg & 4)) rail_segment_fir<D, SEG>(v, iir_sm + m * PITCH, G, sh);
+            if (!(A.dbg & 4)) rail_segment_fir<D, SEG>(v, iir_sm + m * PITCH, G, sh, A.in_width);
             RL_STAMP(2);
             if (!(A.dbg & 8)) {
                 // Kogge-Stone over the 32 segments of the rail: v_m <- v_m + P^(2^d) v_(m - 2^d)
@@ -947,7 +948,7 @@ __global__ __launch_bounds__(64, RL_WAVES) void iir_rail_kernel(const IirRailArg
             asm volatile("" : "+v"(t));
             asm volatile("" : "+s"(tab), "+s"(Gp));
             const cdouble_t *pow2 = (const cdouble_t *)&tab->pow2[0][0];
-            const int m = t >> 1, rail = t & 1, sh = rail << 4;
+            const int m = t >> 1, rail = t & 1, sh = rail ? A.in_sh1 : A.in_sh0;
             const long tile0 = b * TILE;
             uint32_t *xout = sout + tile0;
             const bool whole = tile_whole(b);
@@ -1076,10 +1077,10 @@ __global__ __launch_bounds__(64, RL_WAVES) void iir_rail_kernel(const IirRailArg
             RL_STAMP(8);
             const long seg = b * RL_SEGS + m;
             if (seg < A.n_seg && !(A.dbg & 2)) {
-                if (tile0 + TILE <= A.n) rail_recursion<NS, SEG, true, B121>(A.c, x, SEG, z, sh, rail);
+                if (tile0 + TILE <= A.n) rail_recursion<NS, SEG, true, B121>(A.c, x, SEG, z, sh, A.in_width, rail);
                 else {
                     const long cnt = A.n - seg * SEG < SEG ? A.n - seg * SEG : SEG;
-                    rail_recursion<NS, SEG, false, B121>(A.c, x, cnt, z, sh, rail);
+                    rail_recursion<NS, SEG, false, B121>(A.c, x, cnt, z, sh, A.in_width, rail);
                 }
                 if (seg == A.n_seg - 1) {
                     double *so = A.state_out + s * 2 * IIR_MAX_DIM + rail * IIR_MAX_DIM;
@@ -1347,7 +1348,7 @@ struct clhip_iir {
     // the last call, for the verdict and the redo
     bool can_undo; int undo_cur;
     const int16_t *last_in; int16_t *last_out; size_t last_stride, last_n; hipStream_t last_stream; bool last_valid;
-    bool last_was_rail;
+    bool last_was_rail, last_is_words;
     unsigned long long *d_stamps;           // diagnostics
 };
 
@@ -1494,7 +1495,31 @@ static void iir_launch_scan(const IirPlan *d_plan, const IirCoef &coef, const do
                        n_groups, (const double *)ZS, (const double *)X, (const double *)gc, st_out);
 }
 
+static int iir_run_impl(clhip_iir *f, const int16_t *d_in, int16_t *d_out, size_t stride_samples, size_t n_samples, void *stream,
+                        int in_sh0, int in_sh1, int in_width);
+
 extern "C" int clhip_iir_run(clhip_iir *f, const int16_t *d_in, int16_t *d_out, size_t stride_samples, size_t n_samples, void *stream)
+{
+    return iir_run_impl(f, d_in, d_out, stride_samples, n_samples, stream, 0, 16, 16);
+}
+
+// The same filter fed straight from raw SMI RX words (4 bytes per sample, every word in sync: caribou_smi.c:338-378 -- S1G:
+// i = bits 29..17, q = bits 13..1; HiF: the other way round): the unpack is the filter's own field extraction, so a read
+// that is one in-sync read() needs no unpack launch and no int16 intermediate (cl_readStream does this).  Out of place
+// only.  Returns -2 when this call would take the scan path (a filter outside the single-pass kernel's horizon, or an
+// object that has overrun before): the caller then unpacks first and calls clhip_iir_run.  After an overrun of THIS call
+// clhip_iir_status() restores the state as usual; the repeat goes through clhip_smi_unpack* + clhip_iir_run.
+extern "C" int clhip_iir_run_smi(clhip_iir *f, int channel, const uint8_t *d_words, int16_t *d_out, size_t stride_samples,
+                                 size_t n_samples, void *stream)
+{
+    if (!f || !d_words || (const void *)d_words == (const void *)d_out) { clhip_set_error("clhip_iir_run_smi: null / in-place buffers"); return -1; }
+    if (f->force_scan || iir_pick_shape(f, n_samples) < 0) return -2;
+    const bool hif = channel == CL_CHANNEL_HIF;
+    return iir_run_impl(f, (const int16_t *)d_words, d_out, stride_samples, n_samples, stream, hif ? 1 : 17, hif ? 17 : 1, 13);
+}
+
+static int iir_run_impl(clhip_iir *f, const int16_t *d_in, int16_t *d_out, size_t stride_samples, size_t n_samples, void *stream,
+                        int in_sh0, int in_sh1, int in_width)
 {
     if (!f || !d_in || !d_out || (((uintptr_t)d_in | (uintptr_t)d_out) & 3)) {
         clhip_set_error("clhip_iir_run: null / misaligned buffer");
@@ -1557,6 +1582,7 @@ extern "C" int clhip_iir_run(clhip_iir *f, const int16_t *d_in, int16_t *d_out, 
         a.state_in = st_in; a.state_out = st_out;
         a.overrun = f->d_over; a.poll_bound = f->poll_bound; a.dbg = dbg; a.n_classes = nc; a.dynamic = f->dynamic;
         a.stamps = f->d_stamps;
+        a.in_sh0 = in_sh0; a.in_sh1 = in_sh1; a.in_width = in_width;
         static const int prio_env = getenv("CLHIP_IIR_PRIO") ? atoi(getenv("CLHIP_IIR_PRIO")) : 1;       // A/B: 0 = every wave at priority 0
         a.prio = prio_env && chunk > 1;
         static const int verbose = getenv("CLHIP_IIR_VERBOSE") ? atoi(getenv("CLHIP_IIR_VERBOSE")) : 0;
@@ -1568,6 +1594,7 @@ extern "C" int clhip_iir_run(clhip_iir *f, const int16_t *d_in, int16_t *d_out, 
         f->acur ^= 1;
         f->last_was_rail = true;
     } else {
+        if (in_width != 16) { clhip_set_error("clhip_iir_run: the scan path takes int16 samples"); return -1; }
         const size_t need = iir_scan_ws_doubles(n_samples) * f->n_streams;
         if (need > f->scan_ws_doubles) {
             if (f->last_valid) CLHIP_CHECK(hipStreamSynchronize(f->last_stream));
@@ -1591,6 +1618,7 @@ extern "C" int clhip_iir_run(clhip_iir *f, const int16_t *d_in, int16_t *d_out, 
     f->undo_cur = f->cur; f->can_undo = true;
     f->cur ^= 1;
     f->last_in = d_in; f->last_out = d_out; f->last_stride = stride_samples; f->last_n = n_samples; f->last_stream = s; f->last_valid = true;
+    f->last_is_words = in_width != 16;
     return 0;
 }
 
@@ -1617,7 +1645,7 @@ extern "C" int clhip_iir_finish(clhip_iir *f)
     if (!f || !f->last_valid) return 0;
     CLHIP_CHECK(hipStreamSynchronize(f->last_stream));
     if (clhip_iir_status(f) == 0) return 0;
-    if (f->last_in == f->last_out) return -1;
+    if (f->last_in == f->last_out || f->last_is_words) return -1;        // (raw words: the caller unpacks and calls clhip_iir_run)
     if (clhip_iir_run(f, f->last_in, f->last_out, f->last_stride, f->last_n, f->last_stream)) return -1;
     CLHIP_CHECK(hipStreamSynchronize(f->last_stream));
     return clhip_iir_status(f) == 0 ? 1 : -1;

@@ -56,6 +56,7 @@ typedef struct {
 } cl_chunk;
 
 #define CL_FAST_NATIVE_ONLY ((void *)(uintptr_t)1)
+#define CL_FAST_WORDS_ONLY  ((void *)(uintptr_t)2)   /* no launch at all: the caller's own kernel reads the staged raw words (dev->fast_words) */
 
 struct cl_smi {
     int device;
@@ -96,6 +97,7 @@ struct cl_smi {
     /* cl_smi_ra_launch's short cut for a call that is ONE read() the host has seen to be in sync: set fast_out (device-visible
      * address of the caller's pinned mirror) + fast_format before the call; fast_used says whether it was taken */
     void *fast_out; int fast_format, fast_used;   /* fast_out = CL_FAST_NATIVE_ONLY: only the int16 buffer (a device stage of the caller follows) */
+    const uint8_t *fast_words;             /* CL_FAST_WORDS_ONLY: the call's raw words on the device, ready on dev->stream */
     void *pipe_out_used;                   /* cl_smi_read_pipe_device: d_out or d_out_certain, whichever took the outputs */
     /* statistics (SURVEY.md section 5 "Metrics"): */
     uint64_t stat_samples, stat_resyncs, stat_sync_failures, stat_timeouts, stat_io_errors, stat_written;

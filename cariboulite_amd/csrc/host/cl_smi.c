@@ -717,8 +717,10 @@ long cl_smi_ra_launch(cl_smi *dev, int channel, size_t length_samples, int16_t *
              * launch, no offset read-back, no conversion launch, no device-to-host copy. */
             void *fo = dev->fast_out;
             dev->fast_out = NULL;
+            dev->fast_words = dev->d_slot[slot];
             if (clhip_stream_wait_event(dev->stream, dev->ev_copied[slot]) ||
-                (fo == CL_FAST_NATIVE_ONLY ? clhip_smi_unpack_aligned(channel, dev->d_slot[slot], got, CL_FORMAT_CS16, d_iq, NULL, dev->stream)
+                (fo == CL_FAST_WORDS_ONLY ? 0 :
+                 fo == CL_FAST_NATIVE_ONLY ? clhip_smi_unpack_aligned(channel, dev->d_slot[slot], got, CL_FORMAT_CS16, d_iq, NULL, dev->stream)
                                            : clhip_smi_unpack_aligned(channel, dev->d_slot[slot], got, dev->fast_format, fo, d_iq, dev->stream)))
                 return CL_SMI_ERR_IO;
             dev->h_offs[0] = 0;

@@ -666,20 +666,34 @@ static int read_stream(cl_device *dev, cl_stream *st, void *const *buffs, size_t
             /* One native batch through the low-pass: when the call is one read() the host can see to be in sync, the
              * unpack launch and the filter launch are queued back to back and the call pays ONE synchronisation (the
              * read's verdict arrives with it); the filter stores straight into the sink. */
-            smi->fast_out = CL_FAST_NATIVE_ONLY;
+            /* ... and the unpack is the filter's own input conversion (clhip_iir_run_smi): the raw words of the read() go
+             * straight into the filter launch -- no unpack launch, no int16 intermediate.  Only when the filter is on its
+             * scan path (it has overrun before, or its memory is too long for the single-pass kernel) are the words
+             * unpacked first. */
+            smi->fast_out = CL_FAST_WORDS_ONLY;
             const long expect = cl_smi_ra_launch(smi, dev->channel, numElems, NULL);
             smi->fast_out = NULL;
             if (smi->fast_used && expect > 0) {
                 cl_sink sk;
-                const int bad = sink_open(st, out, (size_t)expect * 4, &sk) ||
-                                !filter_native(st, smi->d_iq, (size_t)expect, smi->stream, (int16_t *)sk.d_dst) ||
-                                sink_queue(&sk, out, (size_t)expect * 4, smi->stream);
+                clhip_iir *flt = st->iir[st->filter_type - 1];
+                int bad = sink_open(st, out, (size_t)expect * 4, &sk);
+                int unpacked = 0;
+                if (!bad) {
+                    const int rc = clhip_iir_run_smi(flt, dev->channel, smi->fast_words, (int16_t *)sk.d_dst, (size_t)expect, (size_t)expect, smi->stream);
+                    if (rc == -2) {
+                        unpacked = 1;
+                        bad = clhip_smi_unpack_aligned(dev->channel, smi->fast_words, (size_t)expect * 4, CL_FORMAT_CS16, smi->d_iq, NULL, smi->stream) ||
+                              !filter_native(st, smi->d_iq, (size_t)expect, smi->stream, (int16_t *)sk.d_dst);
+                    } else bad = rc != 0;
+                }
+                bad = bad || sink_queue(&sk, out, (size_t)expect * 4, smi->stream);
                 int fr = cl_smi_ra_finish(smi);                              /* the synchronisation */
                 if (bad) fr = CL_SMI_ERR_IO;
                 if (fr == CL_SMI_ERR_IO) printf("reader thread failed to read SMI!\n");    /* :270 */
                 if (fr <= 0) return 0;
-                if (filter_overran(dev, st)) {                               /* made again, once, on the scan path */
-                    if (!filter_native(st, smi->d_iq, (size_t)fr, smi->stream, (int16_t *)sk.d_dst) ||
+                if (filter_overran(dev, st)) {                               /* made again, once, on the scan path (from int16 samples) */
+                    if ((!unpacked && clhip_smi_unpack_aligned(dev->channel, smi->fast_words, (size_t)fr * 4, CL_FORMAT_CS16, smi->d_iq, NULL, smi->stream)) ||
+                        !filter_native(st, smi->d_iq, (size_t)fr, smi->stream, (int16_t *)sk.d_dst) ||
                         sink_queue(&sk, out, (size_t)fr * 4, smi->stream) || clhip_stream_sync(smi->stream) || filter_overran(dev, st))
                         return 0;
                 }

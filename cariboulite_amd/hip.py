@@ -64,6 +64,7 @@ _SIGS = {
     "clhip_iir_on_scan_path": (C.c_int, [C.c_void_p]),
     "clhip_iir_debug_stamps": (C.c_size_t, [C.c_void_p, C.c_void_p]),
     "clhip_iir_memory_samples": (C.c_size_t, [C.c_void_p]),
+    "clhip_iir_run_smi": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]),
     "clhip_rx_pipe_create": (C.c_void_p, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "clhip_rx_pipe_destroy": (None, [C.c_void_p]),
     "clhip_rx_pipe_reset": (None, [C.c_void_p]),
@@ -265,6 +266,14 @@ class IIR:
         """in place unless `out` is given; asynchronous"""
         _check(lib().clhip_iir_run(self.h, ptr(d_iq), ptr(out if out is not None else d_iq), n if stride is None else stride, n,
                                    stream if stream is not None else current_stream()), "clhip_iir_run")
+
+    def run_smi(self, channel, d_words, n, out, stride=None, stream=None):
+        """raw in-sync SMI words in, filtered CS16 out (out of place); returns -2 when the call would take the scan path"""
+        rc = lib().clhip_iir_run_smi(self.h, channel, ptr(d_words), ptr(out), n if stride is None else stride, n,
+                                     stream if stream is not None else current_stream())
+        if rc == -1:
+            raise RuntimeError("clhip_iir_run_smi failed: " + last_error())
+        return rc
 
     def status(self):
         """after a synchronise: 0 = the last run is good, -1 = it overran (state restored, object now on the scan path)"""

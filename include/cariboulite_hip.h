@@ -180,6 +180,11 @@ void   clhip_iir_destroy(clhip_iir *f);
  * d_in), asynchronous on `stream`; the state advances by the call.  One call in flight per object. */
 int    clhip_iir_run(clhip_iir *f, const int16_t *d_in, int16_t *d_out, size_t stride_samples, size_t n_samples,
                      void *stream);
+/* The same filter fed straight from raw SMI RX words (4 bytes per sample, all in sync): the 13-bit field extraction of
+ * caribou_smi_rx_data_analyze (caribou_smi.c:338-378) is the filter's own input conversion -- no unpack launch, no int16
+ * intermediate.  Out of place.  -2 = this call would take the scan path: unpack first and call clhip_iir_run. */
+int    clhip_iir_run_smi(clhip_iir *f, int channel, const uint8_t *d_words, int16_t *d_out, size_t stride_samples,
+                         size_t n_samples, void *stream);
 /* Verdict on the LAST clhip_iir_run, to be asked after synchronising its stream and before its samples are used.
  * 0 = good.  -1 = a tile of the single-pass kernel gave up waiting for the tiles before it (its polls are bounded;
  * a launch that moves at all never gets there): the samples of that call are invalid, the carried state is back

@@ -670,3 +670,32 @@ def test_tx_fm_time_slices_with_a_phase_hand_off_equal_one_pipe(G, orc):
         assert np.mean(wa != wb) < 2e-3, (world, float(np.mean(wa != wb)))
         d13 = np.abs(_tx_words_to_iq(wa) - _tx_words_to_iq(wb)); d13 = np.minimum(d13, 8192 - d13)
         assert d13.max() <= 1, world
+
+
+@pytest.mark.parametrize("ch", [0, 1])
+def test_iir_fed_from_raw_smi_words_equals_unpack_then_filter(G, orc, ch):
+    """clhip_iir_run_smi: the 13-bit field extraction of caribou_smi_rx_data_analyze as the filter's own input conversion.
+    Same outputs and same carried state, bit for bit, as clhip_smi_unpack -> clhip_iir_run on the same words, for both channel
+    types, across calls (one native batch, a ragged one, a long one) -- and against the sequential oracle."""
+    import torch
+    from cariboulite_amd import hip, synth, soapy as S
+    sos = S.design_butter_lowpass(6, 4e6, 50e3)
+    fa, fb = hip.IIR(sos), hip.IIR(sos)
+    calls = [131072, 4097, 3_000_000, 64]
+    n = sum(calls)
+    b, i, q = synth.smi_stream_bytes(n, ch, stream=31 + ch)
+    words = torch.from_numpy(b.view(np.int32).copy()).to(G.DEV)
+    iq = torch.from_numpy(np.stack([i, q], 1).astype(np.int16)).to(G.DEV)
+    oa, ob_ = torch.zeros((n, 2), dtype=torch.int16, device=G.DEV), torch.zeros((n, 2), dtype=torch.int16, device=G.DEV)
+    pos = 0
+    for cn in calls:
+        assert fa.run_smi(ch, words[pos:], cn, oa[pos:]) == 0
+        fb.run(iq[pos:], cn, out=ob_[pos:])
+        torch.cuda.synchronize()
+        assert fa.status() == 0 and fb.status() == 0
+        pos += cn
+    assert torch.equal(oa, ob_)
+    assert np.array_equal(fa.state, fb.state)
+    want = orc.IIR(6, 4e6, 50e3).apply_cs16(np.stack([i, q], 1).astype(np.int16))
+    d = np.abs(oa.cpu().numpy().astype(np.int32) - want.astype(np.int32))
+    assert d.max() <= 1 and np.mean(d != 0) < 1e-5
