@@ -97,7 +97,42 @@ struct PipeArgs {
     // first grid_int, queue[1] = workers that have left; the last one out zeroes both for the next launch
     unsigned int *queue;
     int queue_k;                 // items per grab; 0 = static striding
+#if CLHIP_RX_BOUNDS
+    const void *b_in_lo, *b_in_hi, *b_out_lo, *b_out_hi;       // extent of the call's input and output buffers (diagnostic build)
+#endif
 };
+
+// Diagnostic build (-DCLHIP_RX_BOUNDS=1, tools/oob_bounds_check.py): every global access of the fused kernel is compared with
+// the extent of the call's buffers; an access outside is counted, its site and address recorded, and NOT performed.  Nothing of
+// this is compiled into the shipped kernel.
+#ifndef CLHIP_RX_BOUNDS
+#define CLHIP_RX_BOUNDS 0
+#endif
+#if CLHIP_RX_BOUNDS
+__device__ unsigned long long g_rxb[16];          // [0] violations, [1] first site, [2] first address, [3] its lower bound, [4] upper bound, [8 + site] per-site counts
+__device__ __forceinline__ bool rxb_ok(const PipeArgs &a, int site, const void *p, size_t bytes, const void *lo, const void *hi)
+{
+    const unsigned char *q = (const unsigned char *)p;
+    if (q >= (const unsigned char *)lo && q + bytes <= (const unsigned char *)hi) return true;
+    if (atomicAdd(&g_rxb[0], 1ull) == 0) { g_rxb[1] = (unsigned long long)site; g_rxb[2] = (unsigned long long)q; g_rxb[3] = (unsigned long long)lo; g_rxb[4] = (unsigned long long)hi; }
+    atomicAdd(&g_rxb[8 + (site & 7)], 1ull);
+    return false;
+}
+#define RXB_IN(a, site, p, bytes) rxb_ok(a, site, p, bytes, (a).b_in_lo, (a).b_in_hi)
+#define RXB_OUT(a, site, p, bytes) rxb_ok(a, site, p, bytes, (a).b_out_lo, (a).b_out_hi)
+extern "C" int clhip_rx_debug_bounds(unsigned long long *h16)
+{
+    return hipMemcpyFromSymbol(h16, HIP_SYMBOL(g_rxb), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -1;
+}
+extern "C" int clhip_rx_debug_bounds_reset(void)
+{
+    unsigned long long z[16] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_rxb), z, sizeof z) == hipSuccess ? 0 : -1;
+}
+#else
+#define RXB_IN(a, site, p, bytes) true
+#define RXB_OUT(a, site, p, bytes) true
+#endif
 
 template <int T_, int L_, int M_, int KP_, int MODE_, int R_, int NT_, bool FFA_ = false, bool PK_ = true>
 struct PipeCfg {
@@ -155,6 +190,7 @@ template <int R> __device__ __forceinline__ int lds_off(int j) { return j * 8 + 
 __device__ __forceinline__ f32x2 load_sample(const PipeArgs &a, const void *base, long g)
 {
     // one pre-FIR sample in the LDS domain (unscaled integers for integer inputs)
+    if (a.in_kind != CL_PIPE_IN_CF32 ? !RXB_IN(a, 1, (const uint32_t *)base + g, 4) : !RXB_IN(a, 1, (const f32x2 *)base + g, 8)) { f32x2 z = {0.f, 0.f}; return z; }
     if (a.in_kind == CL_PIPE_IN_SMI_WORDS) {
         const uint32_t w = ((const uint32_t *)base)[g];
         const int fa = clhip_field_a(w), fb = clhip_field_b(w);
@@ -227,7 +263,7 @@ struct TileRegs {
 };
 
 template <class C, int KIND>
-__device__ __forceinline__ void tile_issue_loads(TileRegs<C, KIND> &r, const void *in, long g0, int t)
+__device__ __forceinline__ void tile_issue_loads(const PipeArgs &a, TileRegs<C, KIND> &r, const void *in, long g0, int t)
 {
     constexpr int NG = TileRegs<C, KIND>::NG, IT = TileRegs<C, KIND>::IT;
 #pragma unroll
@@ -235,11 +271,14 @@ __device__ __forceinline__ void tile_issue_loads(TileRegs<C, KIND> &r, const voi
         const int grp = t + it * C::NT;
         if (NG % C::NT == 0 || it < IT - 1 || grp < NG) {
             if constexpr (KIND == CL_PIPE_IN_CF32) {
+                if (RXB_IN(a, 2, (const f32x2 *)in + g0 + 4 * grp, 32)) {
                 r.w[2 * it] = *(const u32x4 *)((const f32x2 *)in + g0 + 4 * grp);
                 r.w[2 * it + 1] = *(const u32x4 *)((const f32x2 *)in + g0 + 4 * grp + 2);
+                }
             } else if constexpr ((CLHIP_RX_ABL & 128) != 0) {
                 r.w[it] = u32x4{(uint32_t)grp, (uint32_t)g0, 3u, 4u};
             } else {
+                if (RXB_IN(a, 2, (const uint32_t *)in + g0 + 4 * grp, 16))
                 r.w[it] = __builtin_nontemporal_load((const u32x4 *)((const uint32_t *)in + g0 + 4 * grp));
             }
         }
@@ -567,7 +606,7 @@ __device__ __forceinline__ void second_stage(unsigned char *lds, int t, const fl
 // CHECKED = per-element bounds [lo, hi) (edge tiles); interior tiles only mask the history-only
 // outputs of the tile's first lane (e < lo).
 template <class C, bool CHECKED>
-__device__ __forceinline__ void store_tile(unsigned char *lds, int t, unsigned char *outb, long tile_e0, long lo, long hi,
+__device__ __forceinline__ void store_tile(const PipeArgs &a, unsigned char *lds, int t, unsigned char *outb, long tile_e0, long lo, long hi,
                                            const f32x4 (&pc)[C::NOUT * (C::MODE == MODE_FM ? 4 : 8) / 16])
 {
     constexpr int NOUT = C::NOUT, OB = C::MODE == MODE_FM ? 4 : 8, LB = NOUT * OB, PL = LB / 16;
@@ -622,6 +661,7 @@ __device__ __forceinline__ void store_tile(unsigned char *lds, int t, unsigned c
 #pragma unroll
             for (int j = 0; j < NJ; j++)
                 if (HALF_PIECES % 64 == 0 || lane + 64 * j < HALF_PIECES)
+                    if (RXB_OUT(a, 4, hb + j * 1024, 16))
                     __builtin_nontemporal_store(v[j], (f32x4 *)(hb + j * 1024));     // streamed out, never read back here
         } else {
 #pragma unroll
@@ -630,11 +670,13 @@ __device__ __forceinline__ void store_tile(unsigned char *lds, int t, unsigned c
                 if (HALF_PIECES % 64 == 0 || p < HALF_PIECES) {
                     const long e = half_e0 + (long)p * EPP;
                     if (e >= lo && (!CHECKED || e + EPP <= hi)) {
+                        if (RXB_OUT(a, 5, hb + j * 1024, 16))
                         *(f32x4 *)(hb + j * 1024) = v[j];
                     } else if (CHECKED) {
 #pragma unroll
                         for (int k = 0; k < EPP; k++) {
                             if (e + k >= lo && e + k < hi) {
+                                if (!RXB_OUT(a, 6, hb + j * 1024 + k * OB, OB)) continue;
                                 if constexpr (OB == 8) { f32x2 q = {v[j][2 * k], v[j][2 * k + 1]}; *(f32x2 *)(hb + j * 1024 + k * OB) = q; }
                                 else *(float *)(hb + j * 1024 + k * OB) = v[j][k];
                             }
@@ -670,7 +712,7 @@ __device__ __forceinline__ bool tile_sync_bad(const PipeArgs &a, int s, long S)
             const cu32_t *w = (const cu32_t *)((const uint32_t *)a.in + (long)s * a.in_stride);
             for (long c = first >> a.chunk_shift; c <= (last >> a.chunk_shift); c++) {
                 const long c0 = c << a.chunk_shift;
-                if (a.n_in - c0 > 4) {                              // len <= 16 bytes: offset 0 by definition (:249-252)
+                if (a.n_in - c0 > 4 && RXB_IN(a, 3, (const uint32_t *)a.in + (long)s * a.in_stride + c0, 16)) {     // len <= 16 bytes: offset 0 by definition (:249-252)
                     const uint32_t m = (w[c0] & w[c0 + 1] & w[c0 + 2] & w[c0 + 3]) & 0xC001C000u;
                     const uint32_t z = (w[c0] | w[c0 + 1] | w[c0 + 2] | w[c0 + 3]) & 0xC001C000u;
                     bad |= m != 0x80004000u || z != 0x80004000u;    // every word: (w & 0xC001C000) == 0x80004000
@@ -710,7 +752,7 @@ __device__ __forceinline__ void rx_pipe_edge_worker(const PipeArgs &a, unsigned 
     second_stage<C>(lds, t, a.rs, acc, pc, b_last);
     const long tile_e0 = C::MODE == MODE_FM ? (S - C::HFA) : (S - C::HFA) / C::M * C::L;
     const long lo = C::MODE == MODE_FM ? S : S / C::M * C::L;
-    store_tile<C, true>(lds, t, (unsigned char *)a.out + (long)s * a.out_stride * OB, tile_e0, lo, bad ? 0 : a.n_out, pc);
+    store_tile<C, true>(a, lds, t, (unsigned char *)a.out + (long)s * a.out_stride * OB, tile_e0, lo, bad ? 0 : a.n_out, pc);
     if (ei == 0) pipe_update_hist(a, s, t, C::NT);
 }
 
@@ -779,7 +821,7 @@ void rx_pipe_fused_kernel(const PipeArgs a)
         const int s0 = item / per_stream, tile0 = 1 + item % per_stream;
         const void *in0 = KIND == CL_PIPE_IN_CF32 ? (const void *)((const f32x2 *)a.in + (long)s0 * a.in_stride)
                                                  : (const void *)((const uint32_t *)a.in + (long)s0 * a.in_stride);
-        tile_issue_loads<C, KIND>(regs, in0, (long)tile0 * C::TILE_IN - C::HALO, threadIdx.x);
+        tile_issue_loads<C, KIND>(a, regs, in0, (long)tile0 * C::TILE_IN - C::HALO, threadIdx.x);
         unsigned int g0 = 0;
         if (K > 0 && threadIdx.x == 0) g0 = rx_queue_grab(a.queue);
         // the first tile's words are waited for here (once per worker), so that no path into the loop carries
@@ -836,7 +878,7 @@ void rx_pipe_fused_kernel(const PipeArgs a)
             const int sn = next / per_stream, tn = 1 + next % per_stream;
             const void *inn = KIND == CL_PIPE_IN_CF32 ? (const void *)((const f32x2 *)a.in + (long)sn * a.in_stride)
                                                      : (const void *)((const uint32_t *)a.in + (long)sn * a.in_stride);
-            tile_issue_loads<C, KIND>(regs, inn, (long)tn * C::TILE_IN - C::HALO, t);
+            tile_issue_loads<C, KIND>(a, regs, inn, (long)tn * C::TILE_IN - C::HALO, t);
         }
         f32x2 acc[C::R];
         f32x4 pc[PL];
@@ -869,7 +911,7 @@ void rx_pipe_fused_kernel(const PipeArgs a)
         DIAG_STAMP(ts4);
         const long tile_e0 = C::MODE == MODE_FM ? (S - C::HFA) : (S - C::HFA) / C::M * C::L;
         const long lo = C::MODE == MODE_FM ? S : S / C::M * C::L;
-        if (!bad) store_tile<C, false>(lds, t, (unsigned char *)a.out + (long)s * a.out_stride * OB, tile_e0, lo, 0, pc);
+        if (!bad) store_tile<C, false>(a, lds, t, (unsigned char *)a.out + (long)s * a.out_stride * OB, tile_e0, lo, 0, pc);
         DIAG_STAMP(ts5);
         RX_BARRIER();                                        // the next item's staging overwrites this LDS
         DIAG_STAMP(ts6);
@@ -1368,6 +1410,13 @@ extern "C" long clhip_rx_pipe_run(clhip_rx_pipe *p, int in_kind, const void *d_i
         a.bad_flag = p->chk_flag;
     }
 
+#if CLHIP_RX_BOUNDS
+    {   // the extent of the call's buffers (all streams)
+        const size_t esz = in_kind == CL_PIPE_IN_CF32 ? 8 : 4, ob = p->mode == CL_PIPE_OUT_FM_DEMOD ? 4 : 8;
+        a.b_in_lo = d_in; a.b_in_hi = (const unsigned char *)d_in + ((size_t)(p->n_streams - 1) * in_stride + n_in) * esz;
+        a.b_out_lo = d_out; a.b_out_hi = (unsigned char *)d_out + ((size_t)(p->n_streams - 1) * out_stride + n_out) * ob;
+    }
+#endif
     if (getenv("CLHIP_DEBUG_NOSTORE")) a.n_out = 0;     // timing ablation only: every store masked off
     bool fused_done = false;
     if (clhip_rx_pipe_uses_fused(p, n_in, in_kind)) {

@@ -681,6 +681,9 @@ def test_iir_fed_from_raw_smi_words_equals_unpack_then_filter(G, orc, ch):
     from cariboulite_amd import hip, synth, soapy as S
     sos = S.design_butter_lowpass(6, 4e6, 50e3)
     fa, fb = hip.IIR(sos), hip.IIR(sos)
+    if fa.on_scan_path():                  # CLHIP_IIR_ONEPASS=0: the scan takes int16 samples, run_smi says -2 and the caller unpacks first
+        assert fa.run_smi(ch, torch.zeros(64, dtype=torch.int32, device=G.DEV), 64, torch.zeros((64, 2), dtype=torch.int16, device=G.DEV)) == -2
+        pytest.skip("the single-pass kernel is switched off")
     calls = [131072, 4097, 3_000_000, 64]
     n = sum(calls)
     b, i, q = synth.smi_stream_bytes(n, ch, stream=31 + ch)
