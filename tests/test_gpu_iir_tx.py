@@ -547,59 +547,6 @@ def test_iir_sections_with_general_numerators(G, orc, order):
     assert diff.max() <= 1 and np.mean(diff != 0) < 1e-4, (diff.max(), np.mean(diff != 0))
 
 
-def test_tx_config5_at_baseline_size_by_properties(G, orc):
-    """BASELINE.json config 5 at the size it is benchmarked (2^27 messages -> 2^27 * 2/3 SMI words) through properties:
-    every word carries the frame bits 111|0|0|0; decoded with torch on the device, the samples are a unit phasor through a
-    unit-DC-gain resampler (|z| = 4096 to the filter's ripple and the quantiser's step wherever the phase moves slowly);
-    and four calls of 2^25 messages give the one call's words up to rare one-LSB truncation flips (the fp64 phase sums are
-    re-associated across calls), both pipes continuing from the same phase afterwards."""
-    import torch
-    from cariboulite_amd import hip
-    t = load_golden("taps.npz")
-    dev = G.DEV
-    n = 1 << 27
-    gen = torch.Generator(device=dev); gen.manual_seed(5)
-    msg = 0.05 * torch.randn(n, device=dev, generator=gen)        # slow phase: the 2/3 resampler passes the phasor almost untouched
-    mk = lambda: hip.TxPipe(1, 75e3, 4e6, t["rs_2_3"], 2, 3, hip.TX_DOCUMENTED)
-    p1 = mk()
-    no = p1.out_count(n)
-    by = torch.zeros(4 * no, dtype=torch.uint8, device=dev)
-    assert p1.run(hip.TXPIPE_IN_FM_MESSAGE, msg, 0, n, by, 4 * no) == no and p1.status() == 0
-    torch.cuda.synchronize()
-    b = by.view(no, 4).to(torch.int32)
-    assert bool(((b[:, 0] & 0xE0) == 0xE0).all()) and not bool((b[:, 1:] & 0x80).any())
-    sx = lambda v: torch.where(v >= 4096, v - 8192, v)
-    i13 = sx(((b[:, 0] & 0x1F) << 8) | (b[:, 1] << 1) | ((b[:, 2] >> 6) & 1)).double()
-    q13 = sx(((b[:, 2] & 0x3F) << 7) | b[:, 3]).double()
-    mag = torch.sqrt(i13 * i13 + q13 * q13)[64:]
-    # 13 bits hold [-4096, 4095]: +4096 wraps, so a component at full scale is excluded from the magnitude property
-    ok = (i13[64:].abs() < 4090) & (q13[64:].abs() < 4090)
-    assert float(ok.double().mean()) > 0.9
-    assert float((mag[ok] - 4096.0).abs().max()) < 24.0, float((mag[ok] - 4096.0).abs().max())
-    del b, i13, q13, mag, ok
-    p4 = mk()
-    by4 = torch.zeros(4 * no, dtype=torch.uint8, device=dev)
-    q, pos_out = n // 4, 0
-    for k in range(4):
-        ko = p4.out_count(q)
-        assert p4.run(hip.TXPIPE_IN_FM_MESSAGE, msg.data_ptr() + 4 * k * q, 0, q, by4.data_ptr() + 4 * pos_out, 4 * ko) == ko and p4.status() == 0
-        pos_out += ko
-    torch.cuda.synchronize()
-    assert pos_out == no
-    diff = by.view(torch.int32) != by4.view(torch.int32)
-    assert float(diff.double().mean()) < 1e-3                      # truncation flips only
-    # ... and both pipes continue from the same phase and history: one more call each
-    tail = 0.05 * torch.randn(3072 * 7, device=dev, generator=gen)
-    ka = p1.out_count(tail.numel())
-    ba, bb = torch.zeros(4 * ka, dtype=torch.uint8, device=dev), torch.zeros(4 * ka, dtype=torch.uint8, device=dev)
-    assert p1.run(hip.TXPIPE_IN_FM_MESSAGE, tail, 0, tail.numel(), ba, 4 * ka) == ka
-    assert p4.run(hip.TXPIPE_IN_FM_MESSAGE, tail, 0, tail.numel(), bb, 4 * ka) == ka
-    torch.cuda.synchronize()
-    ia, ib = _tx_words_to_iq(ba.cpu().numpy().view(np.uint32)), _tx_words_to_iq(bb.cpu().numpy().view(np.uint32))
-    d13 = np.abs(ia - ib); d13 = np.minimum(d13, 8192 - d13)
-    assert d13.max() <= 1
-
-
 @pytest.mark.parametrize("bw_khz", [100, 50, 20])
 def test_iir_time_slices_with_a_halo_equal_one_filter(G, orc, bw_khz):
     """SURVEY.md section 8e names a carried-state hand-off for slicing one long stream through the IIR over several GPUs.  The

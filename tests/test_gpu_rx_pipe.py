@@ -339,143 +339,3 @@ def test_time_sliced_single_stream_equals_one_pipe(G, orc):
         assert pos == n_out
         torch.cuda.synchronize()
         assert torch.equal(got, ref), world
-
-
-def test_config2_at_baseline_size_by_properties(G, orc):
-    """BASELINE.json config 2 at the size bench.py runs it -- ONE 2^28-sample stream, 1 GiB in, 3 GiB out, output byte offsets
-    past 2^31 -- checked through properties that do not need an oracle pass over 2^28 samples:
-      * impulses scattered over the whole stream (tile seams, chunk seams, the last tile) come out as the oracle's response
-        to the same impulse, and every other output is exactly zero;
-      * four calls of 2^26 samples equal one call of 2^28, bit for bit (streaming state across calls);
-      * the pipe is linear in its input: pipe(a) + pipe(b) == pipe(a + b) to rounding, on the synthetic stream."""
-    import torch
-    from cariboulite_amd import hip, synth
-    t = load_golden("taps.npz")
-    n = 1 << 28
-    dev = G.DEV
-    mk = lambda: hip.RxPipe(1, 0, t["fir64_c2"], t["rs_3_2"], 3, 2, hip.PIPE_OUT_IQ)
-    zero_word = int(synth.iq_to_words([0], [0], 0)[0])
-    words = torch.full((n,), zero_word - (1 << 32), dtype=torch.int32, device=dev)       # (the sync bits set: 0x80004000)
-    spots = [5, 4063, 4064, 4095, 4096, 131071, 131072, (1 << 27) + 12345, (1 << 28) - 4100, (1 << 28) - 200]
-    amps = [(4095, -4096), (-4096, 4095), (1000, 0), (0, -1000), (77, 78), (-1, 1), (4095, 4095), (-4096, -4096), (2048, -2048), (1, 0)]
-    for p, (ai, aq) in zip(spots, amps):
-        w = int(synth.iq_to_words([ai], [aq], 0)[0])
-        words[p] = w - (1 << 32) if w >= (1 << 31) else w
-    pipe = mk()
-    no = pipe.out_count(n)
-    assert no == n * 3 // 2 and no * 8 > (1 << 31)
-    out = torch.full((no + 8, 2), float("nan"), dtype=torch.float32, device=dev)
-    assert pipe.run(hip.PIPE_IN_SMI_WORDS, words, 0, n, out, 0) == no
-    torch.cuda.synchronize()
-    assert torch.isnan(out[no:]).all() and not torch.isnan(out[:no]).any()
-    # the oracle's response to one impulse, placed at each spot: FIR64 then 3/2 with 24 taps -> outputs m with 2m/3 in [p, p + 64 + 8)
-    span = 128
-    nz = torch.zeros(no, dtype=torch.bool, device=dev)
-    clusters, cur = [], [0]
-    for k in range(1, len(spots)):
-        if spots[k] - spots[k - 1] < 2 * span: cur.append(k)
-        else: clusters.append(cur); cur = [k]
-    clusters.append(cur)
-    for cl in clusters:                                            # impulses closer than a response length are checked together
-        lo = (spots[cl[0]] // 2) * 2                               # an even input index: the resampler's phase there is 0
-        ln = (spots[cl[-1]] - lo) // 2 * 2 + 2 * span
-        x = np.zeros((ln, 2))
-        for k in cl: x[spots[k] - lo] = (amps[k][0] / 4096.0, amps[k][1] / 4096.0)
-        want = orc.Resampler(t["rs_3_2"], 3, 2).f64(orc.FIR(t["fir64_c2"]).f64(x))
-        m0 = lo * 3 // 2
-        m1 = min(m0 + want.shape[0], no)
-        got = out[m0:m1].cpu().numpy()
-        scale = max(np.max(np.abs(want)), 1e-30)
-        assert np.max(np.abs(got - want[:m1 - m0])) <= TOL * scale, (cl, np.max(np.abs(got - want[:m1 - m0])), scale)
-        nz[m0:m1] = True
-        assert np.all(want[(spots[cl[-1]] - lo + 80) * 3 // 2:] == 0)   # the window covers the whole response (64 + 8 input samples)
-    assert int(torch.count_nonzero(out[:no][~nz])) == 0           # everything else: exactly zero
-    del nz
-    # streaming: four calls of 2^26 == the one call, bit for bit
-    pipe2 = mk()
-    out2 = torch.empty((no, 2), dtype=torch.float32, device=dev)
-    q = n // 4
-    for k in range(4):
-        assert pipe2.run(hip.PIPE_IN_SMI_WORDS, words.data_ptr() + 4 * k * q, 0, q, out2.data_ptr() + 8 * (k * q * 3 // 2), 0) == q * 3 // 2
-    torch.cuda.synchronize()
-    assert torch.equal(out[:no], out2)
-    # linearity on the synthetic stream: a = the stream, b = a constant offset stream; a + b stays inside 13 bits
-    del out2
-    a = synth.torch_smi_words(n, dev, 0, 7)
-    ai = ((a >> 17) & 0x1FFF).to(torch.int64); ai = torch.where(ai >= 4096, ai - 8192, ai) // 4
-    aq = ((a >> 1) & 0x1FFF).to(torch.int64); aq = torch.where(aq >= 4096, aq - 8192, aq) // 4
-    bi, bq = 1500, -900
-
-    def pack(i, q_):
-        w = 0x80004000 | ((i & 0x1FFF) << 17) | ((q_ & 0x1FFF) << 1)
-        return ((w + 2 ** 31) % 2 ** 32 - 2 ** 31).to(torch.int32)
-    wa, wab = pack(ai, aq), pack(ai + bi, aq + bq)
-    del a, ai, aq
-    ya = torch.empty((no, 2), dtype=torch.float32, device=dev)
-    assert mk().run(hip.PIPE_IN_SMI_WORDS, wa, 0, n, ya, 0) == no
-    assert mk().run(hip.PIPE_IN_SMI_WORDS, wab, 0, n, out, 0) == no
-    torch.cuda.synchronize()
-    # pipe(b) for a constant b: the DC gains of FIR and resampler legs -- take it from the run itself, far from the start
-    d = (out[:no] - ya)
-    dc = d[3000:3003].double().mean(0)                             # three consecutive outputs = the three polyphase legs' mean
-    legs = d[3000:3000 + 3 * 1000].double().reshape(1000, 3, 2).mean(0)
-    want_i, want_q = bi / 4096.0, bq / 4096.0
-    assert abs(float(dc[0]) - want_i) < 2e-3 and abs(float(dc[1]) - want_q) < 2e-3       # unit DC gain of both filters, to their ripple
-    dev_ = (d[3000:].double().reshape(-1, 3, 2) - legs).abs().max()
-    assert float(dev_) <= 4e-6, float(dev_)                        # the difference is the same constant everywhere: linear, shift-invariant
-
-
-def test_configs_3_and_4_at_baseline_size_by_properties(G, orc):
-    """BASELINE.json config 3 (S1G + HiF, 2^27 samples each, FIR64 + FM demod) and one GPU's share of config 4 (32 streams x
-    2^24 samples, FIR128 + 5/4) at the sizes bench.py runs them, through properties: a clean tone demodulates to its
-    constant phase step everywhere (a frequency the FIR passes), on both channel types; in the 32-stream pipe every stream
-    answers an impulse at its own position with the oracle's response scaled by its own amplitude and is zero elsewhere --
-    no stream sees another's samples."""
-    import torch
-    from cariboulite_amd import hip, synth
-    t = load_golden("taps.npz")
-    dev = G.DEV
-    # ---- config 3
-    n = 1 << 27
-    f0 = 137e3
-    step = 2 * np.pi * f0 / 4e6
-    for ch in (0, 1):
-        idx = torch.arange(n, device=dev, dtype=torch.float64)
-        i = torch.round(3000.0 * torch.cos(step * idx)).to(torch.int64) & 0x1FFF
-        q = torch.round(3000.0 * torch.sin(step * idx)).to(torch.int64) & 0x1FFF
-        a, b = (i, q) if ch == 0 else (q, i)
-        w = 0x80004000 | (a << 17) | (b << 1)
-        words = ((w + 2 ** 31) % 2 ** 32 - 2 ** 31).to(torch.int32)
-        del idx, i, q, a, b, w
-        pipe = hip.RxPipe(1, ch, t["fir64_c3"], None, 1, 1, hip.PIPE_OUT_FM_DEMOD)
-        out = torch.full((n + 8,), float("nan"), dtype=torch.float32, device=dev)
-        assert pipe.run(hip.PIPE_IN_SMI_WORDS, words, 0, n, out, 0) == n
-        torch.cuda.synchronize()
-        assert torch.isnan(out[n:]).all()
-        err = (out[64:n].double() - step).abs().max()              # behind the FIR's transient
-        assert float(err) < 2e-3, float(err)                       # 13-bit quantisation of a 3000-LSB tone: ~1/3000 rad
-        assert abs(float(out[64:n].double().mean()) - step) < 1e-6
-        del words, out
-    # ---- config 4, one GPU's share
-    ns, n4 = 32, 1 << 24
-    zero = int(synth.iq_to_words([0], [0], 0)[0]) - (1 << 32)
-    words = torch.full((ns, n4), zero, dtype=torch.int32, device=dev)
-    pos = [1000 + 524287 * s for s in range(ns)]                   # every stream somewhere else, the last near the end
-    for s in range(ns):
-        wv = int(synth.iq_to_words([100 * (s + 1)], [-50 * (s + 1)], 0)[0])
-        words[s, pos[s]] = wv - (1 << 32) if wv >= (1 << 31) else wv
-    pipe = hip.RxPipe(ns, 0, t["fir128_c4"], t["rs_5_4"], 5, 4, hip.PIPE_OUT_IQ)
-    no = pipe.out_count(n4)
-    out = torch.full((ns, no + 4, 2), float("nan"), dtype=torch.float32, device=dev)
-    assert pipe.run(hip.PIPE_IN_SMI_WORDS, words, n4, n4, out, no + 4) == no
-    torch.cuda.synchronize()
-    assert torch.isnan(out[:, no:]).all()
-    for s in range(ns):
-        lo = pos[s] // 4 * 4                                       # a multiple of M: the resampler's phase there is 0
-        x = np.zeros((512, 2)); x[pos[s] - lo] = (100 * (s + 1) / 4096.0, -50 * (s + 1) / 4096.0)
-        want = orc.Resampler(t["rs_5_4"], 5, 4).f64(orc.FIR(t["fir128_c4"]).f64(x))
-        m0 = lo * 5 // 4
-        got = out[s, m0:m0 + want.shape[0]].cpu().numpy()
-        assert np.max(np.abs(got - want)) <= TOL * np.max(np.abs(want)), s
-        rest = out[s, :no].clone(); rest[m0:m0 + want.shape[0]] = 0
-        assert int(torch.count_nonzero(rest)) == 0, s
