@@ -649,3 +649,33 @@ def test_iir_fed_from_raw_smi_words_equals_unpack_then_filter(G, orc, ch):
     want = orc.IIR(6, 4e6, 50e3).apply_cs16(np.stack([i, q], 1).astype(np.int16))
     d = np.abs(oa.cpu().numpy().astype(np.int32) - want.astype(np.int32))
     assert d.max() <= 1 and np.mean(d != 0) < 1e-5
+
+
+def test_two_large_iir_launches_share_the_gpu(G, orc):
+    """Two filters, each on its own HIP stream, each launch large enough to want every resident wave of the chip, in
+    flight together (round-2 review: 'no test runs two IIR streams at once').  Chunks are taken by ticket, so a wave only
+    ever waits for chunks whose owners are already running: neither launch can starve the other, whatever share of the
+    chip each gets.  Each object's verdict is its own; a launch that did give up (static assignment, CLHIP_IIR_DYNAMIC=0)
+    is repaired by finish() and still has to be right."""
+    import torch
+    from cariboulite_amd import hip
+    rng = np.random.default_rng(77)
+    n = (1 << 24) + 1234
+    xs = [rng.integers(-4096, 4096, size=(n, 2), dtype=np.int16) for _ in range(2)]
+    bws = (50e3, 500e3)
+    wants = [orc.IIR(6, 4e6, bw).apply_cs16(x.copy()) for x, bw in zip(xs, bws)]
+    fs = [hip.IIR(_sos5(orc.IIR(6, 4e6, bw)), 1) for bw in bws]
+    ds = [torch.from_numpy(x).to(G.DEV) for x in xs]
+    outs = [torch.zeros_like(d) for d in ds]
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    torch.cuda.synchronize()
+    half = n // 2 + 77
+    for lo, cnt in ((0, half), (half, n - half)):                      # two rounds: the second starts from a carried state
+        for f, d, o, s in zip(fs, ds, outs, streams):
+            f.run(d[lo:], cnt, out=o[lo:], stream=s.cuda_stream)       # no synchronisation between the two launches
+        verdicts = [f.finish() for f in fs]
+        assert all(v in (0, 1) for v in verdicts), verdicts
+    torch.cuda.synchronize()
+    for o, want in zip(outs, wants):
+        diff = np.abs(o.cpu().numpy().astype(np.int32) - want.astype(np.int32))
+        assert diff.max() <= 1 and np.mean(diff != 0) < 1e-4, (diff.max(), np.mean(diff != 0))
