@@ -89,13 +89,49 @@ extern "C" void *clhip_host_register(void *h, size_t bytes)
 
 extern "C" void clhip_host_unregister(void *h) { if (h && hipHostUnregister(h) != hipSuccess) (void)hipGetLastError(); }
 
+// Copies between device memory and host memory the CALLER owns.  The HIP runtime copies pageable host memory of 1 MiB and
+// more (GPU_PINNED_MIN_XFER_SIZE) by pinning the caller's pages in place -- the copy engine then reads or writes the
+// process's heap through a user-pointer mapping, and the runtime keeps such pinnings cached by address.  In a long-lived
+// process whose heap is freed and reused that path has ended test sessions with "Memory access fault by GPU ... on address
+// <a host heap address>" and the HSA runtime's abort() (robustness record: five located cases, all
+// inside or right behind a 1.5 MiB pageable copy; none in 18 full runs once that path was closed).  A sample path that runs
+// for hours cannot afford that, so host memory that is not page-locked (hipHostMalloc / hipHostRegister: asked of the
+// runtime, ~1 us) is copied in pieces below the threshold: each piece goes through the runtime's own pinned staging buffers
+// and the device never touches the caller's pages.  Order on the stream is kept; pinned memory is copied in one piece.
+#define CLHIP_PAGEABLE_PIECE ((size_t)512 << 10)
+static bool clhip_host_is_pinned(const void *h)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, h) != hipSuccess) { (void)hipGetLastError(); return false; }   // unknown to the runtime: plain pageable memory
+    return a.type == hipMemoryTypeHost;
+}
+static bool clhip_copy_in_pieces(const void *h, size_t n)
+{
+    static const bool off = getenv("CLHIP_PAGEABLE_WHOLE") && atoi(getenv("CLHIP_PAGEABLE_WHOLE"));   // A/B: what round 2 did
+    return !off && n > CLHIP_PAGEABLE_PIECE && !clhip_host_is_pinned(h);
+}
+
 extern "C" int clhip_memcpy_h2d(void *d, const void *h, size_t n, void *s)
 {
+    if (clhip_copy_in_pieces(h, n)) {
+        for (size_t o = 0; o < n; o += CLHIP_PAGEABLE_PIECE) {
+            const size_t m = n - o < CLHIP_PAGEABLE_PIECE ? n - o : CLHIP_PAGEABLE_PIECE;
+            CLHIP_CHECK(hipMemcpyAsync((char *)d + o, (const char *)h + o, m, hipMemcpyHostToDevice, (hipStream_t)s));
+        }
+        return 0;
+    }
     CLHIP_CHECK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, (hipStream_t)s));
     return 0;
 }
 extern "C" int clhip_memcpy_d2h(void *h, const void *d, size_t n, void *s)
 {
+    if (clhip_copy_in_pieces(h, n)) {
+        for (size_t o = 0; o < n; o += CLHIP_PAGEABLE_PIECE) {
+            const size_t m = n - o < CLHIP_PAGEABLE_PIECE ? n - o : CLHIP_PAGEABLE_PIECE;
+            CLHIP_CHECK(hipMemcpyAsync((char *)h + o, (const char *)d + o, m, hipMemcpyDeviceToHost, (hipStream_t)s));
+        }
+        return 0;
+    }
     CLHIP_CHECK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, (hipStream_t)s));
     return 0;
 }

@@ -1531,7 +1531,7 @@ extern "C" long clhip_rx_pipe_run_smi(clhip_rx_pipe *p, const uint8_t *d_bytes, 
         if (got < 0) return -1;
         if (!p->flag_mapped) CLHIP_CHECK(hipMemcpyAsync(p->h_flag, p->d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         // the outputs ride out under the same synchronisation (speculatively: a redo below overwrites all of them)
-        if (sink && got > 0) CLHIP_CHECK(hipMemcpyAsync(sink, d_out, (size_t)got * ob, hipMemcpyDeviceToHost, s));
+        if (sink && got > 0 && clhip_memcpy_d2h(sink, d_out, (size_t)got * ob, s)) return -1;   // (in pieces when `sink` is pageable client memory)
         CLHIP_CHECK(hipStreamSynchronize(s));
         redo = !flag_valid || *(volatile int32_t *)p->h_flag != 0;
     }
@@ -1564,7 +1564,7 @@ extern "C" long clhip_rx_pipe_run_smi(clhip_rx_pipe *p, const uint8_t *d_bytes, 
             return -1;
     got = clhip_rx_pipe_run(p, CL_PIPE_IN_CS16, d_cs16, cs_stride, n_in, d_out, out_stride, stream);
     if (got < 0) return -1;
-    if (sink && got > 0) CLHIP_CHECK(hipMemcpyAsync(sink, d_out, (size_t)got * ob, hipMemcpyDeviceToHost, s));
+    if (sink && got > 0 && clhip_memcpy_d2h(sink, d_out, (size_t)got * ob, s)) return -1;   // (in pieces when `sink` is pageable client memory)
     CLHIP_CHECK(hipStreamSynchronize(s));
     return got;
 }

@@ -322,16 +322,23 @@ __global__ __launch_bounds__(FM_BLOCK) void tx_fm_fused_kernel(
 // 8 -> 0.274 (config 5, 2^27 messages); round 3, at five waves per SIMD (96 VGPRs: 7 and 8 sub-blocks spill): 4 -> 0.281, 5 -> 0.277,
 // 6 -> 0.270, 7 -> 0.288-0.298, 8 -> 0.326 (tools/bench_tx.py, one box)
 #ifndef TXQ_NSUB
-#define TXQ_NSUB 6
+#define TXQ_NSUB 8                         // (round 3, join-free interior path at four waves per SIMD: 6 -> 0.2447-0.2471 ms, 8 -> 0.2396-0.2398, 12 -> 0.298)
 #endif
 #ifndef TXQ_CHAIN_WAVES
-#define TXQ_CHAIN_WAVES 5                  // waves per SIMD the chain kernel's register budget is cut for (96 VGPRs; 97 would round to 104 and leave four)
-#endif
+#define TXQ_CHAIN_WAVES 4                  // waves per SIMD the chain kernel's register budget is cut for.  5 (96 VGPRs) was round 3's first choice; with the
+#endif                                     // interior superblocks on a path of their own (tx_chain_work<C, true>) the sum pass wants its 18-24 loads in flight
+                                           // at once, which 96 registers cannot hold without spilling: 4 waves (109 VGPRs, no spills) 0.2447 ms against 0.2487 at 5
 #ifndef TXQ_PREFETCH
 #define TXQ_PREFETCH 0                     // 1: the chain kernel requests sub-block sb + 1's messages before it works sub-block sb: 12 registers more, 122 VGPRs
                                            // = four waves per SIMD; config 5, one box: 0.267-0.272 ms without (five waves), 0.274-0.282 with (four), 0.277-0.282
                                            // without at four waves, 0.39 with at five (spills): the fifth wave hides what the prefetch would
 #endif
+#ifndef TXQ_ABL
+#define TXQ_ABL 0                          // timing ablations of the chain kernel (results invalid; tools/tx_ablations.sh): 1 = the sum pass reads sub-block 0 only,
+#endif                                     // 2 = the sub-block loop reads no messages, 4 = no output stores, 8 = no look-back
+#ifndef TXQ_CARRY
+#define TXQ_CARRY 1                        // interior superblocks: sub-block 0's messages stay in registers from the sum pass to its arithmetic, and
+#endif                                     // sub-block 1's are requested before the look-back instead of after it (0: round 3's first form)
 #ifndef TXQ_P1_REVERSE
 #define TXQ_P1_REVERSE 1                   // the sum pass walks the superblock backwards: the second pass then starts on the most recently read lines (-4 % HBM reads, -1 % time)
 #endif
@@ -445,6 +452,49 @@ __device__ __forceinline__ uint32_t tx_f2i16_fast(float v)
 // where the general form needs a compare and a select as well.
 __device__ __forceinline__ uint32_t tx_f2i16_bounded(float v) { return (uint32_t)(int)v & 0xFFFFu; }
 
+#ifndef TXQ_STAMPS
+#define TXQ_STAMPS 0                       // diagnostic build (tools/tx_phase_stamps.py): thread 0 of every workgroup stamps s_memrealtime at the phase boundaries
+#endif
+#define TX_STAMP_WGS 8192
+#define TX_STAMP_N 32                      // 0-5 the superblock's phases, 5 + sb the end of sub-block sb (sb < 16), 24-27 inside sub-block 3
+#if TXQ_STAMPS
+__device__ unsigned long long g_tx_stamps[TX_STAMP_WGS * TX_STAMP_N];
+#define TXS(i) do { if (threadIdx.x == 0) g_tx_stamps[(size_t)(stamp_id & (TX_STAMP_WGS - 1)) * TX_STAMP_N + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define TXS(i) do { } while (0)
+#endif
+// Interior stores of one sub-block, every store instruction 1 KiB-contiguous.  A lane owns NOUT consecutive packed words
+// (32 bytes at NOUT = 8): stored directly, an instruction writes 16 bytes of every 32 -- half of each 128-byte line, the
+// other half by the next instruction.  Instead the wave's 2 KiB go through LDS (the wave's OWN phasor rows, whose window
+// reads this wave has behind it; its last row, which the next wave's first lane and the hand-over of the tail still
+// read, is left alone) and come back lane-contiguous.  16 bytes of padding per 8 lanes keep both directions conflict-free.
+#ifndef TXQ_STORE_T
+#define TXQ_STORE_T 0                      // 1: through LDS as described; config 5, one box: 0.2665-0.2720 ms with, 0.2663-0.2690 without -- the
+                                           // stores' shape is not what this kernel waits for, and the transposes cost registers (the prefetch build spills with them)
+#endif
+template <class C>
+__device__ __forceinline__ void tx_store_words(unsigned char *rows, const uint32_t (&wd)[C::NOUT], uint32_t *wp)
+{
+    constexpr int NOUT = C::NOUT;
+    if constexpr (TXQ_STORE_T && NOUT == 8 && 63 * C::ROW >= 64 * 32 + 8 * 16) {
+        const int t = threadIdx.x, lane = t & 63;
+        unsigned char *reg = rows + ((t & ~63) + 1) * C::ROW;              // rows of this wave's lanes 0 .. 62
+        unsigned char *mine = reg + lane * 32 + (lane >> 3) * 16;
+        *(u32x4 *)mine = u32x4{wd[0], wd[1], wd[2], wd[3]};
+        *(u32x4 *)(mine + 16) = u32x4{wd[4], wd[5], wd[6], wd[7]};
+        uint32_t *wave_wp = wp - lane * NOUT;                                // (uniform per wave: lane 0's first word)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int piece = j * 64 + lane, owner = piece >> 1;
+            const u32x4 v = *(const u32x4 *)(reg + owner * 32 + (owner >> 3) * 16 + (piece & 1) * 16);
+            *(u32x4_a4 *)(wave_wp + 4 * piece) = v;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < NOUT / 4; q++) { const u32x4 v = {wd[4 * q], wd[4 * q + 1], wd[4 * q + 2], wd[4 * q + 3]}; *(u32x4_a4 *)(wp + 4 * q) = v; }
+    }
+}
+
 // One sub-block of tx_fm_fast_kernel.  CHECKED = false: every message and every output of the sub-block is inside
 // the call (workgroup-uniform), so there is not a single bounds test or divergent branch in it.
 template <class C, bool CHECKED>
@@ -463,16 +513,33 @@ __device__ __forceinline__ void tx_load_msgs(const float *mm, size_t n, int phi,
     }
 }
 
+// unchecked, the address as (workgroup-uniform base) + (32-bit lane offset): one offset register serves every sub-block,
+// the bases live in SGPRs (the 64-bit lane addresses of the general form cost a register pair per sub-block in flight)
+template <class C>
+__device__ __forceinline__ void tx_load_msgs_u(const float *ub, unsigned lane_off, float (&mv)[C::PER])
+{
+#pragma unroll
+    for (int q = 0; q < C::PER / 4; q++) {
+        const f32x4 v = *(const f32x4_a4 *)(ub + (lane_off + 4u * q));
+        mv[4 * q] = v.x; mv[4 * q + 1] = v.y; mv[4 * q + 2] = v.z; mv[4 * q + 3] = v.w;
+    }
+}
+
 template <class C, bool CHECKED>
 __device__ __forceinline__ double tx_fast_subblock(const float (&mv)[C::PER], size_t n, int phi, int skip, double wt, double off,
                                                    size_t base, unsigned char *rows, double *sh, const f32x2 *hist_in_s,
                                                    f32x2 *hist_out_s, const tx_cfloat_t *__restrict__ rs, long n_out,
-                                                   int pack_mode, uint32_t *words_s, f32x2 *tap_s)
+                                                   int pack_mode, uint32_t *words_s, f32x2 *tap_s, unsigned stamp_id = 0, bool stamped = false)
 {
     constexpr int L = C::L, M = C::M, KP = C::KP, PER = C::PER, NOUT = C::NOUT, ROW = C::ROW, HS = C::HSLOT, H = KP - 1;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     unsigned char *myrow = rows + (t + 1) * ROW;
     const size_t tb = base + (size_t)t * PER;
+    if (TXQ_STAMPS && stamped) {                               // (diagnostic build) the messages have landed
+#pragma unroll
+        for (int k = 0; k < PER; k++) asm volatile("" :: "v"(mv[k]));
+        TXS(24);
+    }
     // local fp64 prefix (turns)
     double c[PER], run = 0.0;
 #pragma unroll
@@ -485,6 +552,7 @@ __device__ __forceinline__ double tx_fast_subblock(const float (&mv)[C::PER], si
     }
     if (lane == 63) sh[wave] = incl;
     __syncthreads();                                           // also: the previous sub-block's window reads are done
+    if (TXQ_STAMPS && stamped) TXS(25);
     double woff = off, total = 0.0;
 #pragma unroll
     for (int k = 0; k < TXQ_NT / 64; k++) { const double v = sh[k]; total += v; if (k < wave) woff += v; }
@@ -505,6 +573,7 @@ __device__ __forceinline__ double tx_fast_subblock(const float (&mv)[C::PER], si
     }
     off += total; off -= floor(off);
     __syncthreads();
+    if (TXQ_STAMPS && stamped) TXS(26);
     // history for the next call: the last H phasors of the stream live in this sub-block's rows (or row -1)
     if (CHECKED && H > 0 && base + C::SUB >= n && t < H) {
         const long rel = (long)n - H + t - (long)base;         // >= -H
@@ -541,9 +610,16 @@ __device__ __forceinline__ double tx_fast_subblock(const float (&mv)[C::PER], si
 #pragma unroll
         for (int u = 0; u < NOUT; u++) wd[u] = tx_pack_word(CL_TX_AS_WRITTEN, 0, 0);
     }
+    if (TXQ_STAMPS && stamped) {
+#pragma unroll
+        for (int u = 0; u < NOUT; u++) asm volatile("" :: "v"(wd[u]));
+        TXS(27);
+    }
     const long j0 = (long)(tb / M) * L - skip;                 // tb is a multiple of M; the first `skip` outputs are not ours
     uint32_t *wp = words_s + j0;
-    if (!CHECKED || (j0 >= 0 && j0 + NOUT <= n_out)) {
+    if (!CHECKED) {
+        if (!(TXQ_ABL & 4) || n_out < 0) tx_store_words<C>(rows, wd, wp);
+    } else if (j0 >= 0 && j0 + NOUT <= n_out) {
 #pragma unroll
         for (int q = 0; q < NOUT / 4; q++) { const u32x4 v = {wd[4 * q], wd[4 * q + 1], wd[4 * q + 2], wd[4 * q + 3]}; *(u32x4_a4 *)(wp + 4 * q) = v; }
     } else {
@@ -632,6 +708,11 @@ struct TxLookBack {
     int poll_bound;                  // polls of one predecessor word before giving up
 };
 #define TXLB_MASK 0xFFFFFFFFFFFFull
+#ifndef TXLB_W
+#define TXLB_W 1                            // look-back words per lane and round.  4 was built to make the ~150-word window one round trip instead of
+                                           // three and is SLOWER (config 5: 0.299 against 0.248 ms at five waves, 0.312 against 0.239 at four; the look-back phase
+                                           // 6.8 us against 5.1): the words are read past the XCD's L2 (agent scope), a round's cost is the number of requests
+#endif
 __device__ __forceinline__ unsigned long long txlb_fix(double turns)
 {
     const double f = turns - floor(turns);
@@ -651,14 +732,17 @@ __device__ __forceinline__ unsigned long long txlb_fix(double turns)
 template <class C>
 __device__ __forceinline__ double tx_unit_compute(const float *mm, size_t n, int phi, double wt, double start, size_t base, bool interior,
                                                   unsigned char *rows, double *sh, const f32x2 *hist_in_s, const tx_cfloat_t *__restrict__ rs,
-                                                  f32x2 (&o)[C::NOUT], const float *lds_msgs = nullptr)
+                                                  f32x2 (&o)[C::NOUT], const float *lds_msgs = nullptr, const float *pre_regs = nullptr)
 {
     constexpr int L = C::L, M = C::M, KP = C::KP, PER = C::PER, NOUT = C::NOUT, ROW = C::ROW, HS = C::HSLOT, H = KP - 1;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const size_t tb = base + (size_t)t * PER;
     unsigned char *myrow = rows + (t + 1) * ROW;
     float mv[PER];
-    if (lds_msgs) {
+    if (pre_regs) {                                                // (inlined: the caller's registers)
+#pragma unroll
+        for (int k = 0; k < PER; k++) mv[k] = pre_regs[k];
+    } else if (lds_msgs) {
 #pragma unroll
         for (int q = 0; q < PER / 4; q++) {
             const f32x4 v = *(const f32x4 *)(lds_msgs + t * PER + 4 * q);
@@ -737,7 +821,7 @@ __device__ __forceinline__ double tx_unit_compute(const float *mm, size_t n, int
 
 template <class C>
 __device__ __forceinline__ void tx_unit_emit(f32x2 (&o)[C::NOUT], const f32x2 rot, size_t n, int skip, size_t base, bool interior,
-                                             const unsigned char *rows, f32x2 *hist_out_s, long n_out, int pack_mode, uint32_t *words_s, f32x2 *tap_s)
+                                             unsigned char *rows, f32x2 *hist_out_s, long n_out, int pack_mode, uint32_t *words_s, f32x2 *tap_s)
 {
     constexpr int L = C::L, M = C::M, KP = C::KP, PER = C::PER, NOUT = C::NOUT, ROW = C::ROW, H = KP - 1;
     const int t = threadIdx.x;
@@ -762,7 +846,9 @@ __device__ __forceinline__ void tx_unit_emit(f32x2 (&o)[C::NOUT], const f32x2 ro
     }
     const long j0 = (long)(tb / M) * L - skip;                 // tb is a multiple of M; the first `skip` outputs are not ours
     uint32_t *wp = words_s + j0;
-    if (interior || (j0 >= 0 && j0 + NOUT <= n_out)) {
+    if (interior) {                                            // (workgroup-uniform)
+        if (!(TXQ_ABL & 4) || n_out < 0) tx_store_words<C>(rows, wd, wp);
+    } else if (j0 >= 0 && j0 + NOUT <= n_out) {
 #pragma unroll
         for (int q = 0; q < NOUT / 4; q++) { const u32x4 v = {wd[4 * q], wd[4 * q + 1], wd[4 * q + 2], wd[4 * q + 3]}; *(u32x4_a4 *)(wp + 4 * q) = v; }
     } else {
@@ -779,66 +865,77 @@ __device__ __forceinline__ void tx_unit_emit(f32x2 (&o)[C::NOUT], const f32x2 ro
 // after the last message before unit b.  Bounded polls; an overrun raises *lb.err and carries on with a made-up word.
 __device__ __forceinline__ unsigned long long tx_look_back(const TxLookBack &lb, const unsigned long long *st, long b, unsigned long long pin, int lane)
 {
+    // TXLB_W words per lane and round, all requested at once: the window back to the nearest finished prefix is ~150 words
+    // in the steady state of config 5 (a workgroup publishes its prefix ~11 us after its sum, and 14 workgroups start per
+    // microsecond), which at one word per lane was three dependent round trips to L2 (tools/tx_phase_stamps.py: 5.1 us).
     const unsigned long long e = (unsigned long long)lb.epoch << 48;
     unsigned long long acc = 0;
     long j0 = b - 1;
     bool done = false;
     int guard = 0;
     while (!done) {
-        const long j = j0 - lane;
-        unsigned long long w = (3ull << 62) | pin;                 // state 3 = before the stream's first unit
-        if (j >= 0) {
-            do {
-                w = __hip_atomic_load(st + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (++guard > lb.poll_bound) { *lb.err = 1; w = (2ull << 62) | e; }
-            } while (((w >> 48) & 0x3FFF) != lb.epoch || (w >> 62) == 0);
+        unsigned long long w[TXLB_W];
+        bool ok;
+        do {
+            ok = true;
+#pragma unroll
+            for (int i = 0; i < TXLB_W; i++) {
+                const long j = j0 - (long)TXLB_W * lane - i;
+                w[i] = j >= 0 ? __hip_atomic_load(st + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                              : ((3ull << 62) | e | pin);          // state 3 = before the stream's first unit
+            }
+#pragma unroll
+            for (int i = 0; i < TXLB_W; i++) ok = ok && ((w[i] >> 48) & 0x3FFF) == lb.epoch && (w[i] >> 62) != 0;
+            if (++guard > lb.poll_bound) {                         // bounded: give up, say so, carry on with made-up words
+                *lb.err = 1;
+#pragma unroll
+                for (int i = 0; i < TXLB_W; i++) w[i] = (2ull << 62) | e;
+                ok = true;
+            }
+        } while (!ok);
+        // the lane's own words, nearest first: sum up to and including its first finished prefix
+        unsigned long long mine = 0;
+        bool have = false;
+#pragma unroll
+        for (int i = 0; i < TXLB_W; i++) {
+            if (!have) mine += w[i] & TXLB_MASK;
+            have = have || (w[i] >> 62) >= 2;
         }
-        const unsigned long long have = __ballot((w >> 62) >= 2);
-        const int first = have ? __builtin_ctzll(have) : 64;
-        unsigned long long v = lane <= first ? (w & TXLB_MASK) : 0ull;
+        const unsigned long long hv = __ballot(have);
+        const int first = hv ? __builtin_ctzll(hv) : 64;
+        unsigned long long v = lane <= first ? mine : 0ull;
 #pragma unroll
         for (int oo = 32; oo > 0; oo >>= 1) v += __shfl_xor(v, oo, 64);
         acc += v;
-        if (first < 64) done = true; else j0 -= 64;
+        if (first < 64) done = true; else j0 -= 64 * TXLB_W;
     }
     return acc & TXLB_MASK;
 }
 
-template <class C>
-__global__ __launch_bounds__(TXQ_NT, TXQ_CHAIN_WAVES) void tx_fm_chain_kernel(
-    const float *__restrict__ m, long m_stride, size_t n, int phi, int skip, double wt, TxLookBack lb, long n_super,
-    int n_streams, const double *__restrict__ phase_in, double *__restrict__ phase_new,
-    const f32x2 *__restrict__ hist_in, f32x2 *__restrict__ hist_out, const float *__restrict__ rs_dev,
-    long n_out, int pack_mode, uint32_t *__restrict__ words, long w_stride, f32x2 *__restrict__ tap, long tap_stride)
+// The work of one superblock.  INT = true: the superblock lies strictly inside the call (all but the stream's first and
+// last one or two), every bounds test is gone at compile time and so is every join between a checked and an unchecked
+// variant of a sub-block: with those joins in the instruction stream the compiler's wait-count insertion (which has to
+// cover the pending loads of EITHER arm) put `s_waitcnt vmcnt(1)` in front of the third and every later sub-block's loads
+// of the sum pass, so the pass made four round trips to memory with three loads in flight instead of one with eighteen.
+template <class C, bool INT>
+__device__ __forceinline__ void tx_chain_work(
+    const float *__restrict__ mm, size_t n, int phi, int skip, double wt, const TxLookBack &lb, long n_super, int s, long b,
+    size_t sbase, const double *__restrict__ phase_in, double *__restrict__ phase_new,
+    const f32x2 *__restrict__ hist_in, f32x2 *__restrict__ hist_out, const tx_cfloat_t *__restrict__ rs,
+    long n_out, int pack_mode, uint32_t *__restrict__ words, long w_stride, f32x2 *__restrict__ tap, long tap_stride,
+    unsigned char *rows, double *sh, double &sh_off)
 {
     constexpr int KP = C::KP, PER = C::PER, ROW = C::ROW, HS = C::HSLOT, H = KP - 1;
-    __shared__ __attribute__((aligned(16))) unsigned char rows[(TXQ_NT + 1) * ROW];
-    __shared__ double sh[TXQ_NT / 64 + 1];
-    __shared__ double sh_off;
-    __shared__ unsigned int sh_ticket;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    // Order: workgroups are dispatched in index order, so every superblock before this one belongs to a
-    // workgroup that has at least been dispatched and does not wait for us.  lb.ticket != NULL: take a ticket
-    // instead (same-address atomics retire at ~12 ns each, which throttles the start of 10^4 workgroups).
-    if (lb.ticket) {
-        if (t == 0) sh_ticket = atomicAdd(lb.ticket, 1u) - lb.ticket_base;
-        __syncthreads();
-    }
-    const unsigned int T = lb.ticket ? sh_ticket : blockIdx.x;
-    if (T >= (unsigned)(n_super * n_streams)) {                    // (workgroup-uniform) never index past the launch's superblocks --
-        if (t == 0) *lb.err = 1;                                   // and never silently: a skipped superblock fails the call
-        return;
-    }
-    const int s = (int)(T % (unsigned)n_streams);
-    const long b = (long)(T / (unsigned)n_streams);
-    const float *mm = m + (long)s * m_stride - phi;
-    const size_t sbase = (size_t)b * C::SB;
-    const tx_cfloat_t *__restrict__ rs = (const tx_cfloat_t *)rs_dev;
-    const bool interior = sbase > 0 && sbase + C::SB < n;         // workgroup-uniform: all four sub-blocks unchecked
+    const bool interior = INT || (sbase > 0 && sbase + C::SB < n);   // workgroup-uniform: all sub-blocks unchecked
+    const unsigned stamp_id = (unsigned)b;
+    TXS(0);
 
     // aggregate of the superblock; the messages are read again from L2 / Infinity Cache by the sub-block loop
     // (keeping 48 of them per lane in registers would cost two waves of occupancy, and occupancy hides the look-back)
     double part = 0.0;
+    constexpr bool CARRY = INT && TXQ_CARRY && !TXQ_KEEP && !TXQ_PREFETCH && !TXQ_ABL;
+    float mv0[PER], mv1[PER];                                      // CARRY: sub-block 0's messages from the sum pass; sub-block 1's, requested early
     float kept[TXQ_KEEP == 1 ? TXQ_NSUB : 1][PER];                // TXQ_KEEP = 1: the superblock's messages stay in registers
     extern __shared__ __attribute__((aligned(16))) float kept_lds[];   // TXQ_KEEP = 2: in LDS, [sub-block][lane][PER]
 #pragma unroll
@@ -846,11 +943,15 @@ __global__ __launch_bounds__(TXQ_NT, TXQ_CHAIN_WAVES) void tx_fm_chain_kernel(
         const int sb = TXQ_P1_REVERSE ? TXQ_NSUB - 1 - sbr : sbr;   // last sub-block first: the second pass then starts on the most recently read lines
         const size_t tb = sbase + (size_t)sb * C::SUB + (size_t)t * PER;
         float mv[PER];
-        if (interior) tx_load_msgs<C, false>(mm, n, phi, tb, mv);
+        if ((TXQ_ABL & 1) && sb > 0) {
+#pragma unroll
+            for (int k = 0; k < PER; k++) mv[k] = 0.f;
+        } else if (INT) tx_load_msgs_u<C>(mm + (sbase + (size_t)sb * C::SUB), (unsigned)t * PER, mv);
+        else if (interior) tx_load_msgs<C, false>(mm, n, phi, tb, mv);
         else tx_load_msgs<C, true>(mm, n, phi, tb, mv);
         double r = 0.0;
 #pragma unroll
-        for (int k = 0; k < PER; k++) { r = __builtin_fma((double)mv[k], wt, r); if (TXQ_KEEP == 1) kept[sb][k] = mv[k]; }
+        for (int k = 0; k < PER; k++) { r = __builtin_fma((double)mv[k], wt, r); if (TXQ_KEEP == 1) kept[sb][k] = mv[k]; if (CARRY && sb == 0) mv0[k] = mv[k]; }
         if (TXQ_KEEP == 2) {
 #pragma unroll
             for (int q = 0; q < PER / 4; q++) *(f32x4 *)(kept_lds + (sb * TXQ_NT + t) * PER + 4 * q) = f32x4{mv[4 * q], mv[4 * q + 1], mv[4 * q + 2], mv[4 * q + 3]};
@@ -861,6 +962,7 @@ __global__ __launch_bounds__(TXQ_NT, TXQ_CHAIN_WAVES) void tx_fm_chain_kernel(
     for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);
     if (lane == 0) sh[wave] = part;
     __syncthreads();
+    TXS(1);
     unsigned long long *st = lb.st + (long)s * n_super;
     const unsigned long long e = (unsigned long long)lb.epoch << 48;
     const double pin_turns = phase_in[s] * (1.0 / TWO_PI);
@@ -873,6 +975,7 @@ __global__ __launch_bounds__(TXQ_NT, TXQ_CHAIN_WAVES) void tx_fm_chain_kernel(
         if (lane == 0) __hip_atomic_store(st + b, (1ull << 62) | e | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();                                               // sh[] is free again
+    TXS(2);
     uint32_t *words_s = words + (long)s * w_stride;
     f32x2 *tap_s = tap ? tap + (long)s * tap_stride : nullptr;
     // The superblock's FIRST sub-block is worked before its phase is known -- relative to its own start, its outputs held
@@ -880,12 +983,14 @@ __global__ __launch_bounds__(TXQ_NT, TXQ_CHAIN_WAVES) void tx_fm_chain_kernel(
     // in front of all of it: by then the predecessors have long published.  (Ablation, round 2: no look-back wait 0.253
     // against 0.281 ms.)  The stream's first superblock knows its phase and works in the absolute frame throughout.
     f32x2 o0[C::NOUT];
-    const bool int0 = sbase > 0 && sbase + C::SUB < n;
+    const bool int0 = INT || (sbase > 0 && sbase + C::SUB < n);
     const double tot0 = tx_unit_compute<C>(mm, n, phi, wt, b == 0 ? pin_turns : 0.0, sbase, int0, rows, sh, hist_in + (long)s * H, rs, o0,
-                                           TXQ_KEEP == 2 ? kept_lds : nullptr);
+                                           TXQ_KEEP == 2 ? kept_lds : nullptr, CARRY ? mv0 : nullptr);
+    if (CARRY) tx_load_msgs_u<C>(mm + (sbase + (size_t)C::SUB), (unsigned)t * PER, mv1);   // in flight across the look-back
+    TXS(3);
     if (wave == 0) {
         const unsigned long long pin = txlb_fix(pin_turns);
-        const unsigned long long acc = b > 0 ? tx_look_back(lb, st, b, pin, lane) : pin;
+        const unsigned long long acc = (b > 0 && !(TXQ_ABL & 8)) ? tx_look_back(lb, st, b, pin, lane) : pin;
         if (lane == 0) {
             const unsigned long long inc = (acc + mine) & TXLB_MASK;
             __hip_atomic_store(st + b, (2ull << 62) | e | inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -897,6 +1002,7 @@ __global__ __launch_bounds__(TXQ_NT, TXQ_CHAIN_WAVES) void tx_fm_chain_kernel(
         }
     }
     __syncthreads();
+    TXS(4);
     const double off0 = b == 0 ? pin_turns : sh_off;
     const f32x2 rot = phasor_turns(b == 0 ? 0.0 : off0);
     tx_unit_emit<C>(o0, rot, n, skip, sbase, int0, rows, hist_out + (long)s * H, n_out, pack_mode, words_s, tap_s);
@@ -910,12 +1016,14 @@ __global__ __launch_bounds__(TXQ_NT, TXQ_CHAIN_WAVES) void tx_fm_chain_kernel(
     if (t < HS) *(f32x2 *)(rows + 8 * (PER - HS + t)) = keep;
     double off = off0 + tot0;
     off -= floor(off);
+    TXS(5);
 #if TXQ_PREFETCH && !TXQ_KEEP
     // the messages of sub-block sb + 1 are requested before sub-block sb is worked (12 registers more per lane)
     float mvn[PER];
     {
         const size_t base1 = sbase + (size_t)C::SUB;
-        if (base1 < n) {
+        if (INT) tx_load_msgs_u<C>(mm + base1, (unsigned)t * PER, mvn);
+        else if (base1 < n) {
             if (base1 > 0 && base1 + C::SUB < n) tx_load_msgs<C, false>(mm, n, phi, base1 + (size_t)t * PER, mvn);
             else tx_load_msgs<C, true>(mm, n, phi, base1 + (size_t)t * PER, mvn);
         }
@@ -923,16 +1031,17 @@ __global__ __launch_bounds__(TXQ_NT, TXQ_CHAIN_WAVES) void tx_fm_chain_kernel(
 #pragma unroll
     for (int sb = 1; sb < TXQ_NSUB; sb++) {
         const size_t base = sbase + (size_t)sb * C::SUB;          // workgroup-uniform
-        if (base >= n) break;
+        if (!INT && base >= n) break;
         float mv[PER];
 #pragma unroll
         for (int k = 0; k < PER; k++) mv[k] = mvn[k];
         const size_t basen = base + (size_t)C::SUB;
-        if (sb + 1 < TXQ_NSUB && basen < n) {
+        if (sb + 1 < TXQ_NSUB && INT) tx_load_msgs_u<C>(mm + basen, (unsigned)t * PER, mvn);
+        else if (sb + 1 < TXQ_NSUB && basen < n) {
             if (basen + C::SUB < n) tx_load_msgs<C, false>(mm, n, phi, basen + (size_t)t * PER, mvn);
             else tx_load_msgs<C, true>(mm, n, phi, basen + (size_t)t * PER, mvn);
         }
-        if (base > 0 && base + C::SUB < n)
+        if (INT || (base > 0 && base + C::SUB < n))
             off = tx_fast_subblock<C, false>(mv, n, phi, skip, wt, off, base, rows, sh, hist_in + (long)s * H,
                                              hist_out + (long)s * H, rs, n_out, pack_mode, words_s, tap_s);
         else
@@ -943,7 +1052,7 @@ __global__ __launch_bounds__(TXQ_NT, TXQ_CHAIN_WAVES) void tx_fm_chain_kernel(
 #pragma unroll
     for (int sb = 1; sb < TXQ_NSUB; sb++) {
         const size_t base = sbase + (size_t)sb * C::SUB;          // workgroup-uniform
-        if (base >= n) break;
+        if (!INT && base >= n) break;
         float mv[PER];
         if (TXQ_KEEP == 1) {
 #pragma unroll
@@ -955,17 +1064,337 @@ __global__ __launch_bounds__(TXQ_NT, TXQ_CHAIN_WAVES) void tx_fm_chain_kernel(
                 mv[4 * q] = v.x; mv[4 * q + 1] = v.y; mv[4 * q + 2] = v.z; mv[4 * q + 3] = v.w;
             }
         }
-        if (base > 0 && base + C::SUB < n) {
-            if (!TXQ_KEEP) tx_load_msgs<C, false>(mm, n, phi, base + (size_t)t * PER, mv);
+        if (TXQ_ABL & 2) {
+#pragma unroll
+            for (int k = 0; k < PER; k++) mv[k] = __builtin_bit_cast(float, 0x3C000000 + ((t * PER + k) << 8));
+        }
+        if (CARRY && sb == 1) {
+#pragma unroll
+            for (int k = 0; k < PER; k++) mv[k] = mv1[k];
+        }
+        if (INT || (base > 0 && base + C::SUB < n)) {
+            if (!TXQ_KEEP && !(TXQ_ABL & 2) && !(CARRY && sb == 1)) {
+                if (INT) tx_load_msgs_u<C>(mm + base, (unsigned)t * PER, mv);
+                else tx_load_msgs<C, false>(mm, n, phi, base + (size_t)t * PER, mv);
+            }
+            off = tx_fast_subblock<C, false>(mv, n, phi, skip, wt, off, base, rows, sh, hist_in + (long)s * H,
+                                             hist_out + (long)s * H, rs, n_out, pack_mode, words_s, tap_s, stamp_id, sb == 3);
+        } else {
+            if (!TXQ_KEEP && !(TXQ_ABL & 2)) tx_load_msgs<C, true>(mm, n, phi, base + (size_t)t * PER, mv);
+            off = tx_fast_subblock<C, true>(mv, n, phi, skip, wt, off, base, rows, sh, hist_in + (long)s * H,
+                                            hist_out + (long)s * H, rs, n_out, pack_mode, words_s, tap_s);
+        }
+        TXS(5 + sb);
+    }
+#endif
+}
+
+template <class C>
+__global__ __launch_bounds__(TXQ_NT, TXQ_CHAIN_WAVES) void tx_fm_chain_kernel(
+    const float *__restrict__ m, long m_stride, size_t n, int phi, int skip, double wt, TxLookBack lb, long n_super,
+    int n_streams, const double *__restrict__ phase_in, double *__restrict__ phase_new,
+    const f32x2 *__restrict__ hist_in, f32x2 *__restrict__ hist_out, const float *__restrict__ rs_dev,
+    long n_out, int pack_mode, uint32_t *__restrict__ words, long w_stride, f32x2 *__restrict__ tap, long tap_stride)
+{
+    constexpr int ROW = C::ROW;
+    __shared__ __attribute__((aligned(16))) unsigned char rows[(TXQ_NT + 1) * ROW];
+    __shared__ double sh[TXQ_NT / 64 + 1];
+    __shared__ double sh_off;
+    __shared__ unsigned int sh_ticket;
+    const int t = threadIdx.x;
+    // Order: workgroups are dispatched in index order, so every superblock before this one belongs to a
+    // workgroup that has at least been dispatched and does not wait for us.  lb.ticket != NULL: take a ticket
+    // instead (same-address atomics retire at ~12 ns each, which throttles the start of 10^4 workgroups).
+    if (lb.ticket) {
+        if (t == 0) sh_ticket = atomicAdd(lb.ticket, 1u) - lb.ticket_base;
+        __syncthreads();
+    }
+    // (read through readfirstlane: a value that has been through LDS counts as divergent, and with it every address, pointer
+    // and loop bound derived from the superblock's number would live in vector registers)
+    const unsigned int T = __builtin_amdgcn_readfirstlane(lb.ticket ? sh_ticket : blockIdx.x);
+    if (T >= (unsigned)(n_super * n_streams)) {                    // (workgroup-uniform) never index past the launch's superblocks --
+        if (t == 0) *lb.err = 1;                                   // and never silently: a skipped superblock fails the call
+        return;
+    }
+    const int s = (int)(T % (unsigned)n_streams);
+    const long b = (long)(T / (unsigned)n_streams);
+    const float *mm = m + (long)s * m_stride - phi;
+    const size_t sbase = (size_t)b * C::SB;
+    const tx_cfloat_t *__restrict__ rs = (const tx_cfloat_t *)rs_dev;
+    if (sbase > 0 && sbase + C::SB < n)                            // workgroup-uniform
+        tx_chain_work<C, true>(mm, n, phi, skip, wt, lb, n_super, s, b, sbase, phase_in, phase_new, hist_in, hist_out, rs, n_out, pack_mode,
+                               words, w_stride, tap, tap_stride, rows, sh, sh_off);
+    else
+        tx_chain_work<C, false>(mm, n, phi, skip, wt, lb, n_super, s, b, sbase, phase_in, phase_new, hist_in, hist_out, rs, n_out, pack_mode,
+                                words, w_stride, tap, tap_stride, rows, sh, sh_off);
+}
+
+// ---------------------------------------------------------------------------
+// Two roles in one launch (CLHIP_TX_CHAIN=4).  tools/tx_phase_stamps.py on the chain kernel: of a workgroup's 42 us per
+// superblock, 8 are the sum pass (loads in flight, nothing to compute), 5 the look-back (the nearest finished prefix is
+// ~150 superblocks back, because a workgroup publishes its prefix 10 us after its sum) and 6 the detour of the first
+// sub-block (worked before its phase is known, rotated afterwards); the sub-block loop itself is 3.3 us per sub-block.
+// Here the first n_sum workgroups of the grid are SUMMERS: persistent, they walk the superblocks in order, n_sum apart,
+// and publish each one's aggregate (state 1) -- memory-bound work that needs no look-back and stays `ahead` superblocks in
+// front of the chain at most (it waits for the prefix of superblock T - ahead), so that what it has pulled through the
+// Infinity Cache is still there when the workers read it again.  Every other workgroup is a WORKER for one superblock, in
+// dispatch order: it requests its first sub-block's messages, takes its aggregate from the word its summer wrote, looks
+// back (the aggregates are all there and prefixes are published within a round trip of a worker's start: one round of 64
+// words), publishes its prefix and runs ALL its sub-blocks in the absolute frame (tx_fast_subblock, as the three-launch
+// variant does).  Forward progress: the summers are dispatched first and never leave; a worker waits for its summer and
+// for older workers only; a summer waits for older workers only, and that wait is a throttle -- when its (bounded) poll
+// runs out it simply carries on.  Every other poll is bounded as in the chain kernel and reports through *lb.err.
+// ---------------------------------------------------------------------------
+// A summer streams.  Its unit of work is a CHUNK of TXS_CH sub-blocks (six 16-byte loads per lane at TXS_CH = 2); three
+// chunk buffers rotate, so that two chunks -- 24 KB per workgroup each -- are on their way while the third is added up,
+// across superblock boundaries.  Summers take the INTERIOR superblocks only (every message inside the call: no bounds
+// tests); a stream's first and last superblocks are summed by their own workers.  Everything about "which superblock"
+// is workgroup-uniform and lives in scalar registers (32-bit, through readfirstlane: the compiler's division sequences are
+// vector code, and an address that has been through one would cost a register pair per load in flight).
+#ifndef TXS_CH
+#define TXS_CH 2
+#endif
+template <class C>
+__device__ __forceinline__ void tx_summer_issue(const float *ub, int q0, float (&mv)[TXS_CH][C::PER])
+{
+#pragma unroll
+    for (int q = 0; q < TXS_CH; q++) tx_load_msgs_u<C>(ub + (size_t)(q0 + q) * C::SUB, (unsigned)threadIdx.x * C::PER, mv[q]);
+}
+template <class C>
+__device__ __forceinline__ double tx_summer_reduce(const float (&mv)[TXS_CH][C::PER], double wt)
+{
+    double part = 0.0;
+#pragma unroll
+    for (int q = 0; q < TXS_CH; q++) {
+        double r = 0.0;
+#pragma unroll
+        for (int k = 0; k < C::PER; k++) r = __builtin_fma((double)mv[q][k], wt, r);
+        part += r;
+    }
+    return part;
+}
+
+template <class C>
+__device__ __forceinline__ void tx_roles_summer(const float *__restrict__ m, long m_stride, size_t n, int phi, double wt, const TxLookBack &lb,
+                                                long n_super, int n_streams, unsigned id, int n_sum, int ahead, double *sh)
+{
+    static_assert(TXQ_NSUB % TXS_CH == 0, "whole chunks per superblock");
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const unsigned total = (unsigned)(n_super * n_streams), ns = (unsigned)n_streams;
+    const unsigned long long e = (unsigned long long)lb.epoch << 48;
+    auto stream_of = [&](unsigned T) -> unsigned { return ns == 1 ? 0u : (unsigned)__builtin_amdgcn_readfirstlane(T % ns); };
+    auto block_of = [&](unsigned T) -> unsigned { return ns == 1 ? T : (unsigned)__builtin_amdgcn_readfirstlane(T / ns); };
+    auto interior = [&](unsigned T) { const size_t sb0 = (size_t)block_of(T) * C::SB; return sb0 > 0 && sb0 + C::SB < n; };
+    auto base_of = [&](unsigned T) { return m + (long)stream_of(T) * m_stride - phi + (size_t)block_of(T) * C::SB; };
+    auto next_super = [&](unsigned T) { unsigned Tn = T + (unsigned)n_sum; while (Tn < total && !interior(Tn)) Tn += (unsigned)n_sum; return Tn; };
+    unsigned T0 = id;
+    while (T0 < total && !interior(T0)) T0 += (unsigned)n_sum;
+    if (T0 >= total) return;
+    // issue cursor (Ti, qi, ub) runs two chunks ahead of the reduce cursor (Tr, qr)
+    unsigned Ti = T0, Tr = T0;
+    int qi = 0, qr = 0;
+    const float *ub = base_of(Ti);
+    double part = 0.0;
+    auto advance_issue = [&]() {
+        qi += TXS_CH;
+        if (qi >= TXQ_NSUB) {
+            qi = 0;
+            Ti = next_super(Ti);
+            if (Ti < total) {
+                if (Ti >= (unsigned)ahead) {                       // throttle (not a dependency): the chain has reached Ti - ahead
+                    if (t == 0) {
+                        const unsigned Tw = Ti - (unsigned)ahead;
+                        const unsigned long long *wp = lb.st + (long)stream_of(Tw) * n_super + block_of(Tw);
+                        int guard = 0;
+                        unsigned long long w;
+                        do {
+                            w = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (((w >> 48) & 0x3FFF) == lb.epoch && (w >> 62) >= 2) break;
+                            __builtin_amdgcn_s_sleep(8);
+                        } while (++guard <= lb.poll_bound);
+                    }
+                    __syncthreads();
+                }
+                ub = base_of(Ti);
+            }
+        }
+    };
+    auto advance_reduce = [&]() {                                  // a chunk has been added to `part`
+        qr += TXS_CH;
+        if (qr >= TXQ_NSUB) {                                      // the superblock is complete: publish its aggregate
+            double v = part;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+            if (lane == 0) sh[wave] = v;
+            __syncthreads();
+            if (t == 0) {
+                double tot = 0.0;
+#pragma unroll
+                for (int k = 0; k < TXQ_NT / 64; k++) tot += sh[k];
+                __hip_atomic_store(lb.st + (long)stream_of(Tr) * n_super + block_of(Tr), (1ull << 62) | e | txlb_fix(tot), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();                                       // sh[] is free again
+            part = 0.0;
+            qr = 0;
+            Tr = next_super(Tr);
+        }
+    };
+    float A[TXS_CH][C::PER], B[TXS_CH][C::PER], Cc[TXS_CH][C::PER];
+    tx_summer_issue<C>(ub, qi, A); advance_issue();
+    if (Ti < total) { tx_summer_issue<C>(ub, qi, B); advance_issue(); }
+    while (true) {
+        if (Ti < total) { tx_summer_issue<C>(ub, qi, Cc); advance_issue(); }
+        part += tx_summer_reduce<C>(A, wt); advance_reduce();
+        if (Tr >= total) break;
+        if (Ti < total) { tx_summer_issue<C>(ub, qi, A); advance_issue(); }
+        part += tx_summer_reduce<C>(B, wt); advance_reduce();
+        if (Tr >= total) break;
+        if (Ti < total) { tx_summer_issue<C>(ub, qi, B); advance_issue(); }
+        part += tx_summer_reduce<C>(Cc, wt); advance_reduce();
+        if (Tr >= total) break;
+    }
+}
+
+template <class C, bool INT>
+__device__ __forceinline__ void tx_roles_worker(
+    const float *__restrict__ mm, size_t n, int phi, int skip, double wt, const TxLookBack &lb, long n_super, int s, long b,
+    size_t sbase, const double *__restrict__ phase_in, double *__restrict__ phase_new,
+    const f32x2 *__restrict__ hist_in, f32x2 *__restrict__ hist_out, const tx_cfloat_t *__restrict__ rs,
+    long n_out, int pack_mode, uint32_t *__restrict__ words, long w_stride, f32x2 *__restrict__ tap, long tap_stride,
+    unsigned char *rows, double *sh, double &sh_off)
+{
+    constexpr int KP = C::KP, PER = C::PER, HS = C::HSLOT, H = KP - 1;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    float mv0[PER];                                                // the first sub-block's messages: in flight across the look-back
+    if (INT) tx_load_msgs_u<C>(mm + sbase, (unsigned)t * PER, mv0);
+    else tx_load_msgs<C, true>(mm, n, phi, sbase + (size_t)t * PER, mv0);
+    unsigned long long *st = lb.st + (long)s * n_super;
+    const unsigned long long e = (unsigned long long)lb.epoch << 48;
+    const double pin_turns = phase_in[s] * (1.0 / TWO_PI);
+    if (!INT) {                                                    // a stream's first / last superblock: nobody sums it for us
+        double part = 0.0;
+        for (int sb = 0; sb < TXQ_NSUB; sb++) {
+            float mv[PER];
+            tx_load_msgs<C, true>(mm, n, phi, sbase + (size_t)sb * C::SUB + (size_t)t * PER, mv);
+#pragma unroll
+            for (int k = 0; k < PER; k++) part = __builtin_fma((double)mv[k], wt, part);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);
+        if (lane == 0) sh[wave] = part;
+        __syncthreads();
+        if (t == 0) {
+            double tot = 0.0;
+#pragma unroll
+            for (int k = 0; k < TXQ_NT / 64; k++) tot += sh[k];
+            __hip_atomic_store(st + b, (1ull << 62) | e | txlb_fix(tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();                                           // sh[] is free again
+    }
+    if (wave == 0) {
+        unsigned long long w;
+        int guard = 0;
+        do {                                                       // this superblock's aggregate, from its summer
+            w = __hip_atomic_load(st + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (++guard > lb.poll_bound) { *lb.err = 1; w = (1ull << 62) | e; }
+        } while (((w >> 48) & 0x3FFF) != lb.epoch || (w >> 62) == 0);
+        const unsigned long long mine = w & TXLB_MASK;
+        const unsigned long long pin = txlb_fix(pin_turns);
+        const unsigned long long acc = b > 0 ? tx_look_back(lb, st, b, pin, lane) : pin;
+        if (lane == 0) {
+            const unsigned long long inc = (acc + mine) & TXLB_MASK;
+            __hip_atomic_store(st + b, (2ull << 62) | e | inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sh_off = (double)acc * (1.0 / 281474976710656.0);     // phase (turns) after message sbase-1
+            if (b == n_super - 1) {
+                const double it = (double)inc * (1.0 / 281474976710656.0);
+                phase_new[s] = wrap_pi(TWO_PI * (it - rint(it)));
+            }
+        }
+    }
+    __syncthreads();
+    double off = b == 0 ? pin_turns : sh_off;
+    if (t < HS) {                                                  // the HS samples before the superblock -> tail of row -1
+        const int k = t + 1;                                       // message sbase - k
+        f32x2 hv = {0.f, 0.f};
+        if (k <= H) {
+            if (sbase >= (size_t)k) {
+                double ph = off;
+                for (int i = 1; i < k; i++) ph -= wt * (double)mm[sbase - i];
+                hv = phasor_turns(ph);
+            } else {                                               // sbase == 0: real message -k - phi
+                const long idx = (long)H - k - phi;
+                if (idx >= 0) hv = hist_in[(long)s * H + idx];
+            }
+        }
+        *(f32x2 *)(rows + 8 * (PER - k)) = hv;
+    }
+    uint32_t *words_s = words + (long)s * w_stride;
+    f32x2 *tap_s = tap ? tap + (long)s * tap_stride : nullptr;
+#pragma unroll
+    for (int sb = 0; sb < TXQ_NSUB; sb++) {
+        const size_t base = sbase + (size_t)sb * C::SUB;          // workgroup-uniform
+        if (!INT && base >= n) break;
+        float mv[PER];
+        if (sb == 0) {
+#pragma unroll
+            for (int k = 0; k < PER; k++) mv[k] = mv0[k];
+        }
+        if (INT || (base > 0 && base + C::SUB < n)) {
+            if (sb > 0) {
+                if (INT) tx_load_msgs_u<C>(mm + base, (unsigned)t * PER, mv);
+                else tx_load_msgs<C, false>(mm, n, phi, base + (size_t)t * PER, mv);
+            }
             off = tx_fast_subblock<C, false>(mv, n, phi, skip, wt, off, base, rows, sh, hist_in + (long)s * H,
                                              hist_out + (long)s * H, rs, n_out, pack_mode, words_s, tap_s);
         } else {
-            if (!TXQ_KEEP) tx_load_msgs<C, true>(mm, n, phi, base + (size_t)t * PER, mv);
+            if (sb > 0) tx_load_msgs<C, true>(mm, n, phi, base + (size_t)t * PER, mv);
             off = tx_fast_subblock<C, true>(mv, n, phi, skip, wt, off, base, rows, sh, hist_in + (long)s * H,
                                             hist_out + (long)s * H, rs, n_out, pack_mode, words_s, tap_s);
         }
     }
-#endif
+}
+
+template <class C>
+__global__ __launch_bounds__(TXQ_NT, TXQ_CHAIN_WAVES) void tx_fm_roles_kernel(
+    const float *__restrict__ m, long m_stride, size_t n, int phi, int skip, double wt, TxLookBack lb, long n_super,
+    int n_streams, const double *__restrict__ phase_in, double *__restrict__ phase_new,
+    const f32x2 *__restrict__ hist_in, f32x2 *__restrict__ hist_out, const float *__restrict__ rs_dev,
+    long n_out, int pack_mode, uint32_t *__restrict__ words, long w_stride, f32x2 *__restrict__ tap, long tap_stride,
+    int n_sum, int ahead)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char rows[(TXQ_NT + 1) * C::ROW];
+    __shared__ double sh[TXQ_NT / 64 + 1];
+    __shared__ double sh_off;
+    __shared__ unsigned int sh_ticket;
+    // Who is who: by blockIdx (workgroups are dispatched in index order, so the summers are the first to run and every
+    // worker's predecessors have at least been dispatched), or -- lb.ticket != NULL, after an overrun -- by ticket: the
+    // first n_sum workgroups to START are the summers and a worker's predecessors are running, whatever the dispatch order.
+    if (lb.ticket) {
+        if (threadIdx.x == 0) sh_ticket = atomicAdd(lb.ticket, 1u) - lb.ticket_base;
+        __syncthreads();
+    }
+    const unsigned int id = __builtin_amdgcn_readfirstlane(lb.ticket ? sh_ticket : blockIdx.x);
+    if (id < (unsigned)n_sum) {                                    // workgroup-uniform
+        tx_roles_summer<C>(m, m_stride, n, phi, wt, lb, n_super, n_streams, id, n_sum, ahead, sh);
+        return;
+    }
+    const unsigned int T = id - (unsigned)n_sum;
+    if (T >= (unsigned)(n_super * n_streams)) {                    // never index past the launch's superblocks, and never silently
+        if (threadIdx.x == 0) *lb.err = 1;
+        return;
+    }
+    const int s = (int)(T % (unsigned)n_streams);
+    const long b = (long)(T / (unsigned)n_streams);
+    const float *mm = m + (long)s * m_stride - phi;
+    const size_t sbase = (size_t)b * C::SB;
+    const tx_cfloat_t *__restrict__ rs = (const tx_cfloat_t *)rs_dev;
+    if (sbase > 0 && sbase + C::SB < n)                            // workgroup-uniform
+        tx_roles_worker<C, true>(mm, n, phi, skip, wt, lb, n_super, s, b, sbase, phase_in, phase_new, hist_in, hist_out, rs, n_out, pack_mode,
+                                 words, w_stride, tap, tap_stride, rows, sh, sh_off);
+    else
+        tx_roles_worker<C, false>(mm, n, phi, skip, wt, lb, n_super, s, b, sbase, phase_in, phase_new, hist_in, hist_out, rs, n_out, pack_mode,
+                                  words, w_stride, tap, tap_stride, rows, sh, sh_off);
 }
 
 // ---------------------------------------------------------------------------
@@ -1285,7 +1714,9 @@ extern "C" long clhip_tx_pipe_run(clhip_tx_pipe *p, int in_kind, const void *d_i
         static const int tx_chain = getenv("CLHIP_TX_CHAIN") ? atoi(getenv("CLHIP_TX_CHAIN")) : 1;
         // 1 (default): single launch, superblocks of TXQ_NSUB sub-blocks, the look-back behind the first sub-block's
         // arithmetic (tx_fm_chain_kernel); 3: single launch, single read, one sub-block per workgroup (tx_fm_chain1_kernel:
-        // measured slower); 0: three launches
+        // measured slower); 4: single launch, summers + workers (tx_fm_roles_kernel: measured equal at best -- 0.249 ms with
+        // 192 summers against 0.245, and time ~ 1 / summers below that: the bytes that have to be in flight to stream the
+        // messages at HBM latency cost the same share of the machine whoever holds them); 0: three launches
         const long n_units = (long)clhip_div_up(nv, (size_t)C::SUB);
         if (tx_chain) {
             const long n_lb = tx_chain == 3 ? n_units : n_super;   // look-back words per stream
@@ -1334,7 +1765,18 @@ extern "C" long clhip_tx_pipe_run(clhip_tx_pipe *p, int in_kind, const void *d_i
             TxLookBack lb = {p->lb_st, use_ticket ? p->lb_ticket : nullptr, p->ticket_total, p->epoch, p->lb_err_dev, bound};
             const unsigned n_wg = (unsigned)(n_lb * p->n_streams);
             double *phase_new = p->d_phase2 + (size_t)(p->pcur ^ 1) * p->n_streams;   // the other half: late workgroups still read d_phase
-            if (tx_chain == 3)
+            if (tx_chain == 4) {
+                // summers + workers in one launch
+                static const int sum_env = getenv("CLHIP_TX_SUMMERS") ? atoi(getenv("CLHIP_TX_SUMMERS")) : 192;
+                static const int ahead_env = getenv("CLHIP_TX_AHEAD") ? atoi(getenv("CLHIP_TX_AHEAD")) : 1024;
+                const int n_sum = (int)(n_wg < (unsigned)sum_env ? n_wg : (unsigned)sum_env);
+                const int ahead = ahead_env > 4 * n_sum ? ahead_env : 4 * n_sum;    // (a throttle shorter than the summers' own stride would stall them on workers that wait for them)
+                hipLaunchKernelGGL(tx_fm_roles_kernel<C>, dim3(n_wg + (unsigned)n_sum), dim3(TXQ_NT), 0, s, (const float *)d_in, (long)in_stride, nv, phi,
+                                   skip, wt, lb, n_super, p->n_streams, (const double *)p->d_phase, phase_new, p->hist[p->cur],
+                                   p->hist[p->cur ^ 1], p->d_rs_q, (long)n_out, p->pack_mode, (uint32_t *)d_bytes,
+                                   (long)(out_stride_bytes / 4), (f32x2 *)d_iq_tap, (long)iq_tap_stride, n_sum, ahead);
+                if (use_ticket) p->ticket_total += (unsigned)n_sum;     // (+ n_wg below)
+            } else if (tx_chain == 3)
                 hipLaunchKernelGGL(tx_fm_chain1_kernel<C>, dim3(n_wg), dim3(TXQ_NT), 0, s, (const float *)d_in, (long)in_stride, nv, phi,
                                    skip, wt, lb, n_units, p->n_streams, (const double *)p->d_phase, phase_new, p->hist[p->cur],
                                    p->hist[p->cur ^ 1], p->d_rs_q, (long)n_out, p->pack_mode, (uint32_t *)d_bytes,
@@ -1429,4 +1871,16 @@ extern "C" long clhip_tx_pipe_run(clhip_tx_pipe *p, int in_kind, const void *d_i
     CLHIP_CHECK_LAUNCH();
     p->n_total += n_in;
     return (long)n_out;
+}
+
+extern "C" int clhip_tx_debug_nsub(void) { return TXQ_NSUB; }
+extern "C" int clhip_tx_debug_stamps(void *h_out)
+{
+#if TXQ_STAMPS
+    if (h_out) CLHIP_CHECK(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_tx_stamps), sizeof(unsigned long long) * TX_STAMP_WGS * TX_STAMP_N));
+    return TX_STAMP_WGS * TX_STAMP_N;
+#else
+    (void)h_out;
+    return 0;
+#endif
 }

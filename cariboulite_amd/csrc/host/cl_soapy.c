@@ -471,10 +471,15 @@ static const int16_t *filter_native(cl_stream *st, const int16_t *d_raw, size_t 
  *                   107 us (the memcpy reads lines the device has just written: 12 us per 512 KiB, three times its warm rate);
  *   CL_SINK_STAGED  a device buffer, copied by the copy engine into the pageable buffer before the synchronisation:
  *                   58 / 91 / 65 us -- above 1 MiB the runtime pins the target in place instead of bouncing it, which
- *                   is why this is the route for outputs larger than that. */
-enum { CL_SINK_CLIENT, CL_SINK_MIRROR, CL_SINK_STAGED };
+ *                   is why this WAS the route for outputs larger than that (now only with CL_READ_STAGED=1);
+ *   CL_SINK_BOUNCE  a device buffer, copied by the copy engine into the stream's pinned mirror before the synchronisation
+ *                   and from there by memcpy: the route for outputs above 1 MiB.  (Round 3's first form handed the client's
+ *                   pageable buffer to the runtime -- CL_SINK_STAGED -- which pins such a target in place from 1 MiB up:
+ *                   77-81 us for FIR64 + 3/2 against 120 here, and the mechanism behind the GPU page faults on host heap
+ *                   addresses of DESIGN.md section 7.  Whoever wants the copy engine in his own buffers says so: ZEROCOPY=1.) */
+enum { CL_SINK_CLIENT, CL_SINK_MIRROR, CL_SINK_STAGED, CL_SINK_BOUNCE };
 #define CL_MIRROR_MAX_BYTES ((size_t)1 << 20)
-typedef struct { int kind; void *d_dst; } cl_sink;
+typedef struct { int kind; void *d_dst; void *bounce; } cl_sink;
 
 static void *mirror_for(cl_stream *st, size_t bytes)
 {
@@ -521,20 +526,28 @@ static int sink_open(cl_stream *st, void *out, size_t bytes, cl_sink *sk)
         if (sk->d_dst) { sk->kind = CL_SINK_MIRROR; return 0; }
     }
     if (cl_ensure(&st->d_conv, &st->conv_cap, bytes + 64, 1, 0)) return -1;
-    sk->kind = CL_SINK_STAGED; sk->d_dst = st->d_conv;
+    sk->d_dst = st->d_conv;
+    static int staged = -1;                                        /* A/B: CL_READ_STAGED=1 = the runtime copies into the client's buffer */
+    if (staged < 0) staged = getenv("CL_READ_STAGED") ? atoi(getenv("CL_READ_STAGED")) != 0 : 0;
+    if (staged) { sk->kind = CL_SINK_STAGED; return 0; }
+    if (cl_ensure((void **)&st->h_conv, &st->h_conv_cap, bytes + 64, 1, 1)) return -1;
+    sk->kind = CL_SINK_BOUNCE; sk->bounce = st->h_conv;
     return 0;
 }
 
 /* before the synchronisation (hs = the stream the last stage was queued on) ... */
 static int sink_queue(const cl_sink *sk, void *out, size_t bytes, void *hs)
 {
-    return sk->kind == CL_SINK_STAGED && bytes ? clhip_memcpy_d2h(out, sk->d_dst, bytes, hs) : 0;
+    if (!bytes) return 0;
+    if (sk->kind == CL_SINK_STAGED) return clhip_memcpy_d2h(out, sk->d_dst, bytes, hs);
+    if (sk->kind == CL_SINK_BOUNCE) return clhip_memcpy_d2h(sk->bounce, sk->d_dst, bytes, hs);
+    return 0;
 }
 
 /* ... and after it, once the call is known to deliver */
 static void sink_deliver(cl_stream *st, const cl_sink *sk, void *out, size_t bytes)
 {
-    if (sk->kind == CL_SINK_MIRROR) memcpy(out, st->h_conv, bytes);
+    if (sk->kind == CL_SINK_MIRROR || sk->kind == CL_SINK_BOUNCE) memcpy(out, st->h_conv, bytes);
     if (sk->kind == CL_SINK_CLIENT) st->stats.zero_copy_reads++;
 }
 
@@ -605,7 +618,7 @@ static int read_stream(cl_device *dev, cl_stream *st, void *const *buffs, size_t
             cl_ensure((void **)&st->h_conv, &st->h_conv_cap, numElems * eb + 64, 1, 1) ||
             (st->format != CL_FORMAT_CS16 && cl_ensure(&st->d_conv, &st->conv_cap, numElems * 16 + 64, 1, 0)))
             return 0;
-        if (sk.kind == CL_SINK_STAGED) sk.d_dst = st->d_conv;              /* (the line above may have moved it) */
+        if (sk.kind == CL_SINK_STAGED || sk.kind == CL_SINK_BOUNCE) { sk.d_dst = st->d_conv; sk.bounce = st->h_conv; }   /* (the line above may have moved them) */
         /* the short cut: a call that is one read() the host can see to be in sync is unpacked by ONE launch, in the
          * client's format, straight into the sink (cl_smi_ra_launch): no search launch, no offset read-back, no conversion
          * launch; what is left here is the one synchronisation and the sink's own last step */
@@ -722,7 +735,7 @@ static int read_stream(cl_device *dev, cl_stream *st, void *const *buffs, size_t
             const int filt = st->filter_type != CL_DIGFILT_NONE;
             const int16_t *d_f = filter_native(st, d_raw, (size_t)res, hs, filt ? (int16_t *)sk.d_dst : NULL);
             if (!d_f) return 0;
-            if (!filt ? clhip_memcpy_d2h(sk.kind == CL_SINK_MIRROR ? st->h_conv : out, d_f, (size_t)res * 4, hs)
+            if (!filt ? clhip_memcpy_d2h(sk.kind == CL_SINK_MIRROR || sk.kind == CL_SINK_BOUNCE ? st->h_conv : out, d_f, (size_t)res * 4, hs)
                       : sink_queue(&sk, out, (size_t)res * 4, hs)) return 0;
             if (clhip_stream_sync(hs)) return 0;
             if (!filter_overran(dev, st)) break;
@@ -742,11 +755,13 @@ static int read_stream(cl_device *dev, cl_stream *st, void *const *buffs, size_t
         /* a call the host can see to be in sync stores its outputs straight into the client's registered buffer or the mapped
          * mirror; any other call (and every output larger than the mirror route pays for) leaves them on the device and
          * copies them into the client's buffer under the pipe call's own synchronisation, once it is known to deliver */
-        const int ret = cl_smi_read_pipe_device(smi, dev->channel, numElems, st->rx_pipe, st->d_conv, &got, out,
-                                                sk.kind != CL_SINK_STAGED ? sk.d_dst : NULL);
+        const int held = sk.kind == CL_SINK_STAGED || sk.kind == CL_SINK_BOUNCE;   /* outputs stay on the device until the call is known to deliver */
+        const int ret = cl_smi_read_pipe_device(smi, dev->channel, numElems, st->rx_pipe, st->d_conv, &got,
+                                                sk.kind == CL_SINK_BOUNCE ? st->h_conv : out, held ? NULL : sk.d_dst);
         if (ret == CL_SMI_ERR_IO) printf("reader thread failed to read SMI!\n");    /* :270 */
         if (ret <= 0 || got <= 0) return 0;                                         /* :266-276 */
-        if (sk.kind != CL_SINK_STAGED && smi->pipe_out_used == sk.d_dst) sink_deliver(st, &sk, out, (size_t)got * ob);
+        if (sk.kind == CL_SINK_BOUNCE) memcpy(out, st->h_conv, (size_t)got * ob);   /* (the copy engine wrote the pinned mirror) */
+        else if (!held && smi->pipe_out_used == sk.d_dst) sink_deliver(st, &sk, out, (size_t)got * ob);
         return (int)got;
     }
     int aligned = 0;

@@ -93,6 +93,11 @@ void       *clhip_host_device_ptr(void *h_ptr);     /* the address kernels use f
 void       *clhip_host_register(void *h_ptr, size_t bytes);   /* pin + map memory the caller owns; returns the address kernels
                                                                * use, NULL when it cannot be registered */
 void        clhip_host_unregister(void *h_ptr);
+/* host <-> device copies on a stream.  Host memory that is not page-locked (not from clhip_host_alloc / hipHostMalloc, not
+ * registered) is copied in pieces of 512 KiB: the HIP runtime would pin the caller's pages in place for a pageable copy of
+ * 1 MiB and more and let the copy engine into the process's heap, which has ended long-lived processes with a GPU page
+ * fault on a host address; in pieces every byte goes through the runtime's own pinned staging buffers.
+ * CLHIP_PAGEABLE_WHOLE=1 in the environment restores the single copy (A/B). */
 int         clhip_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream);
 int         clhip_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream);
 int         clhip_memcpy_d2d(void *d_dst, const void *d_src, size_t bytes, void *stream);
@@ -463,7 +468,9 @@ const char *cl_getNativeStreamFormat(const cl_device *dev, int direction, size_t
  * compiled-out USE_ASYNC path (CaribouliteStream.cpp:11,16-49,70-75); ZEROCOPY=1 (RX) registers the buffers the client
  * passes to readStream with the GPU on first sight (up to 8, 16-byte aligned) so that the last kernel of a read stores
  * into them directly -- the client promises that such a buffer stays mapped until the stream is set up again or the
- * device is closed; defaults = reference behaviour. */
+ * device is closed (a user-pointer mapping of the client's pages: the same mechanism as the runtime's in-place pinning the
+ * copy helpers above avoid -- meant for buffers the client allocates once and keeps, not for a heap that churns);
+ * defaults = reference behaviour. */
 cl_stream *cl_setupStream(cl_device *dev, int direction, const char *format,
                           const size_t *channels, size_t n_channels,
                           const char *const *keys, const char *const *vals, size_t n_kwargs);

@@ -7,6 +7,8 @@ reference's caribou_smi_read -> FIR -> L/M chain ends up (caribou_smi.c:235-292 
 int16 samples, a chunk without sync leaves the pipe where it was.  Outputs, the carried history (through the
 following call) and the return codes are compared with orc.smi_read -> orc.FIR -> orc.Resampler on the same bytes.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -95,6 +97,10 @@ def gpu_calls(G, pipe, calls, chunk_len, n_streams=1, stream_of_interest=0, othe
         no = pipe.out_count(n)
         out = torch.full((n_streams, no + 8, 2), float("nan"), dtype=torch.float32, device=G.DEV)
         h_offs = np.full(n_streams * nch, 99, dtype=np.int32)
+        if os.environ.get("CL_TEST_TRACE_PTRS") == "1":           # (robustness record: a GPU page fault's address can be placed)
+            os.write(2, ("[ptrs] call %d %s n=%d d=%#x+%d offs=%#x cs16=%#x+%d out=%#x+%d\n" % (
+                ci, kind, n, d.data_ptr(), d.numel(), offs.data_ptr(), cs16.data_ptr(), cs16.numel() * 2,
+                out.data_ptr(), out.numel() * 4)).encode())
         rc = pipe.run_smi(d, stride, b.size, chunk_len, offs, cs16, out, no + 8, h_offs=h_offs)
         torch.cuda.synchronize()
         o = out.cpu().numpy()
