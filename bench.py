@@ -273,6 +273,7 @@ def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(a)
+    import cariboulite_amd  # noqa: F401  (first: its import sets the runtime's pageable-copy default before the first HIP call)
     global torch
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
