@@ -346,6 +346,43 @@ typedef __attribute__((address_space(4))) float tx_cfloat_t;
 typedef f32x4 __attribute__((aligned(4))) f32x4_a4;      // 16-byte global access at dword alignment (unaligned mode)
 typedef u32x4 __attribute__((aligned(4))) u32x4_a4;
 
+// Inclusive prefix sum of one double per lane over the wave's 64 lanes, by DPP: row_shr 1, 2, 4, 8 inside the rows of 16,
+// then row_bcast:15 (rows 1 and 3 take the totals of rows 0 and 2) and row_bcast:31 (rows 2 and 3 take the total of the
+// lower half).  Six steps of two v_mov_dpp and one v_add_f64 -- no LDS round trip; the shuffle form (__shfl_up = two
+// ds_bpermute_b32 per step and a select) was 0.7 us of a sub-block's 3.3 in the config-5 kernel's dependent chain.
+// Lanes a step does not reach add +0.0.  TXQ_DPP_SCAN=0: the shuffle form.
+#ifndef TXQ_DPP_SCAN
+#define TXQ_DPP_SCAN 1
+#endif
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_take_f64(double v)
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, ROW_MASK, 0xF, false);
+    return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double wave_inclusive_scan_f64(double v)
+{
+#if TXQ_DPP_SCAN
+    v += dpp_take_f64<0x111, 0xF>(v);          // row_shr:1
+    v += dpp_take_f64<0x112, 0xF>(v);          // row_shr:2
+    v += dpp_take_f64<0x114, 0xF>(v);          // row_shr:4
+    v += dpp_take_f64<0x118, 0xF>(v);          // row_shr:8
+    v += dpp_take_f64<0x142, 0xA>(v);          // row_bcast:15 -> rows 1, 3
+    v += dpp_take_f64<0x143, 0xC>(v);          // row_bcast:31 -> rows 2, 3
+    return v;
+#else
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double up = __shfl_up(v, o, 64);
+        if (lane >= o) v += up;
+    }
+    return v;
+#endif
+}
+
 template <int L_, int M_, int KP_> struct TxCfg {
     static constexpr int L = L_, M = M_, KP = KP_;
     static constexpr int PER = 4 * M_;                   // messages per lane per sub-block (float4 loads, whole output groups)
@@ -544,12 +581,7 @@ __device__ __forceinline__ double tx_fast_subblock(const float (&mv)[C::PER], si
     double c[PER], run = 0.0;
 #pragma unroll
     for (int k = 0; k < PER; k++) { run = __builtin_fma((double)mv[k], wt, run); c[k] = run; }
-    double incl = run;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const double up = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += up;
-    }
+    const double incl = wave_inclusive_scan_f64(run);
     if (lane == 63) sh[wave] = incl;
     __syncthreads();                                           // also: the previous sub-block's window reads are done
     if (TXQ_STAMPS && stamped) TXS(25);
@@ -752,12 +784,7 @@ __device__ __forceinline__ double tx_unit_compute(const float *mm, size_t n, int
     double c[PER], run = 0.0;
 #pragma unroll
     for (int k = 0; k < PER; k++) { run = __builtin_fma((double)mv[k], wt, run); c[k] = run; }
-    double incl = run;
-#pragma unroll
-    for (int oo = 1; oo < 64; oo <<= 1) {
-        const double up = __shfl_up(incl, oo, 64);
-        if (lane >= oo) incl += up;
-    }
+    const double incl = wave_inclusive_scan_f64(run);
     if (lane == 63) sh[wave] = incl;
     __syncthreads();                                           // also: an earlier sub-block's window reads are done
     double woff = start, total = 0.0;
@@ -1089,6 +1116,207 @@ __device__ __forceinline__ void tx_chain_work(
 #endif
 }
 
+// ---------------------------------------------------------------------------
+// Interior superblocks without a barrier in the sub-block loop (TXQ_FREE=1).  tools/tx_phase_stamps.py: a sub-block is a
+// chain of dependent steps -- messages land, prefix + wave scan, BARRIER (the waves' totals), phasors -> LDS, BARRIER (the
+// lane before a wave's first is in the wave before), window reads, resample, pack, store, BARRIER (the tail for the next
+// sub-block) -- 3.3 us against 0.64 us of VALU issue, and the four waves of a workgroup walk it in lock step.  All three
+// barriers exchange things a wave can have by itself: (1) the sum pass keeps every wave's total of every sub-block in a
+// small LDS table, so a wave's phase offset inside any sub-block is a sum over that table; (2) the seven samples before a
+// wave's first message are seven phasors the wave makes itself, from seven messages it loads through the scalar unit (the
+// address is wave-uniform) and the same offset; (3) with that nothing is handed from one sub-block to the next.  Each wave
+// owns 65 LDS rows (row -1 + its 64 lanes); after the look-back the four waves of a workgroup never wait for each other.
+// ---------------------------------------------------------------------------
+#ifndef TXQ_FREE
+#define TXQ_FREE 0                         // measured, not the default: the sub-block loop drops from 3.3 to 2.5 us per sub-block, but the sum pass that now
+#endif                                     // also makes the table of wave totals takes 11.6 us instead of 7.7 and the look-back 6.5 instead of 4.7:
+                                           // 0.250 ms against 0.2425 on config 5 (tools/tx_variants.sh, one box; all 35 TX tests pass with it)
+template <class C>
+__device__ __forceinline__ void tx_wave_compute(const float (&mv)[C::PER], const float *__restrict__ wp /* the wave's first message */,
+                                                double wt, double woff, unsigned char *wr, const tx_cfloat_t *__restrict__ rs,
+                                                f32x2 (&o)[C::NOUT])
+{
+    constexpr int L = C::L, M = C::M, KP = C::KP, PER = C::PER, NOUT = C::NOUT, ROW = C::ROW, HS = C::HSLOT, H = KP - 1;
+    const int lane = threadIdx.x & 63;
+    unsigned char *myrow = wr + (lane + 1) * ROW;
+    float tm[H];                                                   // the H messages before the wave's first (wave-uniform: scalar loads)
+#pragma unroll
+    for (int j = 0; j < H; j++) tm[j] = wp[-1 - j];
+    double c[PER], run = 0.0;
+#pragma unroll
+    for (int k = 0; k < PER; k++) { run = __builtin_fma((double)mv[k], wt, run); c[k] = run; }
+    const double incl = wave_inclusive_scan_f64(run);
+    const double excl = woff + (incl - run);
+#pragma unroll
+    for (int k = 0; k < PER; k += 2) {
+        const f32x2 a = phasor_turns(excl + c[k]), b = phasor_turns(excl + c[k + 1]);
+        *(f32x4 *)(myrow + 8 * k) = f32x4{a.x, a.y, b.x, b.y};
+    }
+    if (lane < HS) {                                               // sample (first - k), k = lane + 1, into the tail of the wave's row -1
+        const int k = lane + 1;
+        double ph = woff;
+#pragma unroll
+        for (int i = 1; i < H; i++) if (i < k) ph -= wt * (double)tm[i - 1];
+        const f32x2 hv = k <= H ? phasor_turns(ph) : f32x2{0.f, 0.f};
+        *(f32x2 *)(wr + 8 * (PER - k)) = hv;
+    }
+    // Same wave: the LDS performs its operations in order, no s_barrier.  But the COMPILER may move a load above a store it
+    // can prove not to overlap for this thread -- and the row a lane reads next was written by ANOTHER lane: a fence at
+    // wavefront scope (no instruction on this target beyond the ordering) pins the reads behind the writes; the same again
+    // at the end of the window reads, for the next sub-block's writes.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    f32x2 x[HS + PER];
+#pragma unroll
+    for (int k = 0; k < HS; k += 2) {
+        const f32x4 q = *(const f32x4 *)(myrow - ROW + 8 * (PER - HS + k));
+        x[k] = q.xy; x[k + 1] = q.zw;
+    }
+#pragma unroll
+    for (int k = 0; k < PER; k += 2) {
+        const f32x4 q = *(const f32x4 *)(myrow + 8 * k);
+        x[HS + k] = q.xy; x[HS + k + 1] = q.zw;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float tp[KP * L];
+#pragma unroll
+    for (int i = 0; i < KP * L; i++) tp[i] = rs[i];
+#pragma unroll
+    for (int u = 0; u < NOUT; u++) {
+        const int bq = (u * M) / L, p = (u * M) % L;
+        f32x2 acc = {0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < KP; i++) acc += x[HS + bq - i] * tp[p + i * L];
+        o[u] = acc;
+    }
+}
+
+template <class C>
+__device__ __forceinline__ void tx_wave_store(const f32x2 (&o)[C::NOUT], size_t tb, int skip, int pack_mode, uint32_t *words_s, f32x2 *tap_s)
+{
+    constexpr int L = C::L, M = C::M, NOUT = C::NOUT;
+    uint32_t wd[NOUT];
+#pragma unroll
+    for (int u = 0; u < NOUT; u++) wd[u] = tx_pack_word(CL_TX_DOCUMENTED, tx_f2i16_bounded(o[u].x), tx_f2i16_bounded(o[u].y));   // (the taps carry the 4096)
+    if (pack_mode == CL_TX_AS_WRITTEN) {
+#pragma unroll
+        for (int u = 0; u < NOUT; u++) wd[u] = tx_pack_word(CL_TX_AS_WRITTEN, 0, 0);
+    }
+    const long j0 = (long)(tb / M) * L - skip;
+    uint32_t *wp = words_s + j0;
+#pragma unroll
+    for (int q = 0; q < NOUT / 4; q++) { const u32x4 v = {wd[4 * q], wd[4 * q + 1], wd[4 * q + 2], wd[4 * q + 3]}; *(u32x4_a4 *)(wp + 4 * q) = v; }
+    if (tap_s) {
+#pragma unroll
+        for (int u = 0; u < NOUT; u++) tap_s[j0 + u] = o[u] * (1.0f / 4096.0f);   // exact
+    }
+}
+
+template <class C>
+__device__ __forceinline__ void tx_chain_free(
+    const float *__restrict__ mm, int skip, double wt, const TxLookBack &lb, long n_super, int s, long b,
+    size_t sbase, const double *__restrict__ phase_in, double *__restrict__ phase_new, const tx_cfloat_t *__restrict__ rs,
+    int pack_mode, uint32_t *__restrict__ words, long w_stride, f32x2 *__restrict__ tap, long tap_stride,
+    unsigned char *rows, double (*wsum)[TXQ_NT / 64], double &sh_off)
+{
+    constexpr int PER = C::PER, ROW = C::ROW, NW = TXQ_NT / 64;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    unsigned char *wr = rows + (size_t)wave * 65 * ROW;
+    const unsigned stamp_id = (unsigned)b; (void)stamp_id;
+    TXS(0);
+    // sum pass: every wave's total of every sub-block
+    float mv0[PER], mv1[PER];
+#pragma unroll
+    for (int sbr = 0; sbr < TXQ_NSUB; sbr++) {
+        const int sb = TXQ_P1_REVERSE ? TXQ_NSUB - 1 - sbr : sbr;
+        float mv[PER];
+        tx_load_msgs_u<C>(mm + (sbase + (size_t)sb * C::SUB), (unsigned)t * PER, mv);
+        double r = 0.0;
+#pragma unroll
+        for (int k = 0; k < PER; k++) { r = __builtin_fma((double)mv[k], wt, r); if (sb == 0) mv0[k] = mv[k]; }
+        // the wave's total as a scalar (lane 63 of the scan), stored by every lane alike: no branch, so that the loop stays one
+        // basic block and the compiler keeps all the sub-blocks' loads in flight together (with `if (lane == 63)` around the
+        // store it issued them one sub-block at a time: eight round trips, 15.6 us instead of 7.7)
+        const unsigned long long wb = __builtin_bit_cast(unsigned long long, wave_inclusive_scan_f64(r));
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)wb, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(wb >> 32), 63);
+        wsum[sb][wave] = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+    }
+    __syncthreads();
+    TXS(1);
+    unsigned long long *st = lb.st + (long)s * n_super;
+    const unsigned long long e = (unsigned long long)lb.epoch << 48;
+    const double pin_turns = phase_in[s] * (1.0 / TWO_PI);
+    unsigned long long mine = 0;
+    if (wave == 0) {
+        double total = 0.0;
+#pragma unroll
+        for (int sb = 0; sb < TXQ_NSUB; sb++)
+#pragma unroll
+            for (int k = 0; k < NW; k++) total += wsum[sb][k];
+        mine = txlb_fix(total);
+        if (lane == 0) __hip_atomic_store(st + b, (1ull << 62) | e | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    TXS(2);
+    uint32_t *words_s = words + (long)s * w_stride;
+    f32x2 *tap_s = tap ? tap + (long)s * tap_stride : nullptr;
+    const size_t wfirst = sbase + (size_t)wave * 64 * PER;         // the wave's first message of sub-block 0
+    // sub-block 0, relative to the superblock's start; its outputs wait for the look-back
+    f32x2 o0[C::NOUT];
+    {
+        double woff = 0.0;
+#pragma unroll
+        for (int k = 0; k < NW; k++) if (k < wave) woff += wsum[0][k];
+        tx_wave_compute<C>(mv0, mm + wfirst, wt, woff, wr, rs, o0);
+    }
+    tx_load_msgs_u<C>(mm + (sbase + (size_t)C::SUB), (unsigned)t * PER, mv1);   // in flight across the look-back
+    TXS(3);
+    if (wave == 0) {
+        const unsigned long long pin = txlb_fix(pin_turns);
+        const unsigned long long acc = (b > 0 && !(TXQ_ABL & 8)) ? tx_look_back(lb, st, b, pin, lane) : pin;
+        if (lane == 0) {
+            const unsigned long long inc = (acc + mine) & TXLB_MASK;
+            __hip_atomic_store(st + b, (2ull << 62) | e | inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sh_off = (double)acc * (1.0 / 281474976710656.0);     // phase (turns) after message sbase-1
+            if (b == n_super - 1) {
+                const double it = (double)inc * (1.0 / 281474976710656.0);
+                phase_new[s] = wrap_pi(TWO_PI * (it - rint(it)));
+            }
+        }
+    }
+    __syncthreads();                                               // the last time the workgroup's waves meet
+    TXS(4);
+    double off = sh_off;
+    {
+        const f32x2 rot = phasor_turns(off);
+#pragma unroll
+        for (int u = 0; u < C::NOUT; u++)
+            o0[u] = f32x2{__builtin_fmaf(o0[u].x, rot.x, -o0[u].y * rot.y), __builtin_fmaf(o0[u].x, rot.y, o0[u].y * rot.x)};
+        tx_wave_store<C>(o0, sbase + (size_t)t * PER, skip, pack_mode, words_s, tap_s);
+    }
+    TXS(5);
+#pragma unroll
+    for (int sb = 1; sb < TXQ_NSUB; sb++) {
+        double tot = 0.0, before = 0.0;                            // of the previous sub-block / of the waves before this one
+#pragma unroll
+        for (int k = 0; k < NW; k++) { tot += wsum[sb - 1][k]; if (k < wave) before += wsum[sb][k]; }
+        off += tot; off -= floor(off);
+        const size_t base = sbase + (size_t)sb * C::SUB;
+        float mv[PER];
+        if (sb == 1) {
+#pragma unroll
+            for (int k = 0; k < PER; k++) mv[k] = mv1[k];
+        } else tx_load_msgs_u<C>(mm + base, (unsigned)t * PER, mv);
+        f32x2 o[C::NOUT];
+        tx_wave_compute<C>(mv, mm + (base + (size_t)wave * 64 * PER), wt, off + before, wr, rs, o);
+        tx_wave_store<C>(o, base + (size_t)t * PER, skip, pack_mode, words_s, tap_s);
+        TXS(5 + sb);
+    }
+}
+
 template <class C>
 __global__ __launch_bounds__(TXQ_NT, TXQ_CHAIN_WAVES) void tx_fm_chain_kernel(
     const float *__restrict__ m, long m_stride, size_t n, int phi, int skip, double wt, TxLookBack lb, long n_super,
@@ -1097,8 +1325,9 @@ __global__ __launch_bounds__(TXQ_NT, TXQ_CHAIN_WAVES) void tx_fm_chain_kernel(
     long n_out, int pack_mode, uint32_t *__restrict__ words, long w_stride, f32x2 *__restrict__ tap, long tap_stride)
 {
     constexpr int ROW = C::ROW;
-    __shared__ __attribute__((aligned(16))) unsigned char rows[(TXQ_NT + 1) * ROW];
+    __shared__ __attribute__((aligned(16))) unsigned char rows[(TXQ_NT + TXQ_NT / 64) * ROW];   // (the barrier-free path: 65 rows per wave)
     __shared__ double sh[TXQ_NT / 64 + 1];
+    __shared__ double wsum[TXQ_NSUB][TXQ_NT / 64];
     __shared__ double sh_off;
     __shared__ unsigned int sh_ticket;
     const int t = threadIdx.x;
@@ -1121,9 +1350,14 @@ __global__ __launch_bounds__(TXQ_NT, TXQ_CHAIN_WAVES) void tx_fm_chain_kernel(
     const float *mm = m + (long)s * m_stride - phi;
     const size_t sbase = (size_t)b * C::SB;
     const tx_cfloat_t *__restrict__ rs = (const tx_cfloat_t *)rs_dev;
-    if (sbase > 0 && sbase + C::SB < n)                            // workgroup-uniform
-        tx_chain_work<C, true>(mm, n, phi, skip, wt, lb, n_super, s, b, sbase, phase_in, phase_new, hist_in, hist_out, rs, n_out, pack_mode,
-                               words, w_stride, tap, tap_stride, rows, sh, sh_off);
+    if (sbase > 0 && sbase + C::SB < n) {                          // workgroup-uniform
+        if (TXQ_FREE && !TXQ_KEEP && !TXQ_PREFETCH && !(TXQ_ABL & 7))
+            tx_chain_free<C>(mm, skip, wt, lb, n_super, s, b, sbase, phase_in, phase_new, rs, pack_mode, words, w_stride, tap, tap_stride,
+                             rows, wsum, sh_off);
+        else
+            tx_chain_work<C, true>(mm, n, phi, skip, wt, lb, n_super, s, b, sbase, phase_in, phase_new, hist_in, hist_out, rs, n_out, pack_mode,
+                                   words, w_stride, tap, tap_stride, rows, sh, sh_off);
+    }
     else
         tx_chain_work<C, false>(mm, n, phi, skip, wt, lb, n_super, s, b, sbase, phase_in, phase_new, hist_in, hist_out, rs, n_out, pack_mode,
                                 words, w_stride, tap, tap_stride, rows, sh, sh_off);
