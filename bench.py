@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--log2-samples", type=int, default=28, help="samples per GPU per step (2^k)")
+    ap.add_argument("--samples", type=int, default=0, help="c2 only: samples per GPU per step, any multiple of 4 (e.g. 4000000 = one second of "
+                    "one stream, SURVEY.md section 8d's cache-resident case); overrides --log2-samples")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--settle", type=int, default=40, help="untimed steps before the warm-up (DVFS settle)")
@@ -308,8 +310,8 @@ def main():
     if a.workload != "c2":
         return bench_secondary(a, world, rank, dev, dist, red_dev, arch, taps)
 
-    n = 1 << a.log2_samples
-    n_chunks = n // NATIVE_CHUNK_SAMPLES
+    n = a.samples if a.samples > 0 else 1 << a.log2_samples
+    n_chunks = -(-n // NATIVE_CHUNK_SAMPLES)
     words = synth.torch_smi_words(n, dev, channel=0, stream=rank)             # int32 RX words in HBM
     pipe = hip.RxPipe(1, hip.CHANNEL_S1G, taps["fir64_c2"], taps["rs_3_2"], 3, 2, hip.PIPE_OUT_IQ)
     n_out = pipe.out_count(n)
@@ -373,8 +375,9 @@ def main():
     if rank == 0:
         # HBM traffic of the fused kernel from PMC counters: measured in separate rocprofv3 --pmc passes
         # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; tools/pmc_summ.py) and committed under profiles/
-        traffic, traffic_src = pmc_traffic("c2") if a.log2_samples == 28 else (None, None)
-        if traffic is None and a.log2_samples == 28:
+        full = a.log2_samples == 28 and not a.samples
+        traffic, traffic_src = pmc_traffic("c2") if full else (None, None)
+        if traffic is None and full:
             traffic, traffic_src = pmc_traffic("c")            # round 1 named its files c_*
         value = shard.job_throughput(n, a.steps, dt, world) / 1e6
         achieved = ALGO_BYTES_PER_SAMPLE * n / kern_avg_s / 1e9
@@ -383,7 +386,7 @@ def main():
             "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic", "settle_steps": a.settle,
-            "config": {"workload": f"config 2: 1 ch/GPU, 4 MS/s stream replayed as one 2^{a.log2_samples}-sample "
+            "config": {"workload": f"config 2: 1 ch/GPU, 4 MS/s stream replayed as one {(str(n) if a.samples else '2^' + str(a.log2_samples))}-sample "
                                    f"buffer per GPU ({n_chunks} native 512 KiB chunks), sync check + int13 unpack + "
                                    f"64-tap FIR + 3/2 polyphase resample, CF32 out",
                        "samples_per_gpu_per_step": n, "fir_taps": 64, "resample": "3/2", "arch": arch,
