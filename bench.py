@@ -17,7 +17,7 @@ Infinity Cache).  Streams are independent, so N GPUs run N such streams with
 no data-path collective (weak scaling); the only collectives are the timing
 barrier and the max-over-ranks reduction.
 
---workload c1|c3|c4|c5|iir times the other configs of BASELINE.json (and the a6 IIR) through the same contract;
+--workload c1|c3|c4|c5|iir|tags times the other configs of BASELINE.json (the a6 IIR, the pps tag compaction) through the same contract;
 the default (c2) is the headline metric.
 
 One JSON line on rank 0.  `roofline` prices the fused kernel against HBM
@@ -58,7 +58,7 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--settle", type=int, default=40, help="untimed steps before the warm-up (DVFS settle)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal on one GPU)")
-    ap.add_argument("--workload", default="c2", choices=["c2", "c4", "c1", "c3", "c5", "iir"],
+    ap.add_argument("--workload", default="c2", choices=["c2", "c4", "c1", "c3", "c5", "iir", "tags"],
                     help="c2 (default, the BASELINE.json metric) | c4: 256 streams x 2^24, FIR128 + 5/4, sharded (strong "
                          "scaling) | c1 / c3 / c5 / iir: the other BASELINE.json configs and the a6 filter, one stream set "
                          "per GPU (weak scaling), same JSON shape with their own algorithmic bytes")
@@ -236,6 +236,18 @@ def bench_secondary(a, world, rank, dev, dist, red_dev, arch, taps):
         units, bytes_per, metric = n, 4.0 + 8.0 / 3.0, "Msamples/s through FM mod + 2/3 resample + int13 pack (TX)"
         desc = f"config 5: 2^{a.log2_samples - 1} fp32 messages -> FM modulate -> 2/3 polyphase -> (int16)(f*4096) -> SMI TX words"
         kern = "tx_fm_chain_kernel<TxCfg<2,3,8>>"
+    elif a.workload == "tags":
+        n = 1 << a.log2_samples
+        meta = ((torch.arange(n, device=dev) % 4_000_000) == 0).to(torch.uint8)         # one pps marker per second of stream
+        ws = torch.empty(hip.lib().clhip_sync_tags_ws_bytes(n), dtype=torch.uint8, device=dev)
+        idx = torch.empty(4096, dtype=torch.int32, device=dev)
+        cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+        def step():
+            hip.sync_tags(meta, n, idx, 4096, cnt, ws, stream)
+        units, bytes_per, metric = n, 1.0, "Msamples/s through the pps tag compaction of the meta plane"
+        desc = f"GNU Radio source's tag loop (caribouLiteSource_impl.cc:113-119): 2^{a.log2_samples} meta bytes -> ordered positions of meta == 1"
+        kern = "sync_tags_count_kernel + sync_tags_emit_kernel"
+        checks.append(lambda: int(cnt.item()) == (n + 3_999_999) // 4_000_000)
     else:
         n = 1 << (a.log2_samples - 2)
         iq = torch.randint(-4096, 4096, (n, 2), dtype=torch.int16, device=dev)
@@ -258,7 +270,7 @@ def bench_secondary(a, world, rank, dev, dist, red_dev, arch, taps):
         print(json.dumps({
             "metric": metric, "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64" if a.workload == "iir" else "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": {"iir": "f64", "tags": "u8"}.get(a.workload, "f32"), "data": "synthetic",
             "config": {"workload": desc, "arch": arch, "parallelism": f"{world} independent copy(ies), no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s per GPU",
                          "frac": round(ach / HBM_PEAK_GBS, 4),

@@ -546,3 +546,218 @@ extern "C" int clhip_smi_debug_analyze(int mode, const uint8_t *d_bytes, size_t 
     CLHIP_CHECK_LAUNCH();
     return 0;
 }
+
+// ---------------------------------------------------------------------------
+// pps tags: the positions i with meta[i].sync == 1, ascending -- what the GNU Radio source's work() finds with a
+// host loop over every sample of the meta plane (gr-caribouLite/lib/caribouLiteSource_impl.cc:113-119) as one
+// ordered compaction on the device, so that only the (few) positions cross PCIe and the host touches no sample.
+// HBM-bound byte work: 16 bytes per lane and round, `== 1` on four bytes at a time with an exact zero-byte test
+// (18 VALU operations per 16 bytes: at 1 byte per sample the test, not the memory, would bound a naive loop).
+// The plane may start at any byte address: lanes work on the 16-byte grid of the ADDRESS (virtual index
+// v = i + mis, mis = address & 15); the at most two groups that straddle an end of the plane are read byte by byte
+// by the one lane that owns them.  Two passes over a workgroup's 16 rounds: a FAST one that only asks "any marker in
+// my group?" with all 16 loads in flight, and -- for the rounds that hold one, a handful per second of stream -- a
+// placing one that re-reads the group (cache hit), scans the workgroup and stores the positions.
+// Small planes (one MTU): ONE workgroup of 1024 lanes.  Large ones: a counting launch (one 64 KiB tile per
+// workgroup) and an emitting launch in which a workgroup whose tile holds a marker adds up the counts before it (a
+// few KB from L2) and places its tile; tiles without markers are not read twice.
+// ---------------------------------------------------------------------------
+#define TAG_TILE 65536u                         // bytes of the plane per workgroup tile: 256 lanes x 16 B x 16 rounds
+#define TAG_SMALL (4u * TAG_TILE)               // up to here one workgroup of 1024 lanes does it all in one launch
+
+// per dword: all-ones unless one of its bytes equals 1 (then the 0x80 of that byte is clear) -- exact, no borrow between bytes
+__device__ __forceinline__ uint32_t tag_t(uint32_t x)
+{
+    const uint32_t y = x ^ 0x01010101u;
+    return ((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu;
+}
+__device__ __forceinline__ uint32_t tag_ones4(uint32_t x)      // bit k <- byte k of x == 1
+{
+    const uint32_t z = ~tag_t(x);
+    return ((z >> 7) & 1u) | ((z >> 14) & 2u) | ((z >> 21) & 4u) | ((z >> 28) & 8u);
+}
+__device__ __forceinline__ bool tag_whole(size_t v0, size_t v_lo, size_t v_hi) { return v0 >= v_lo && v0 + 16 <= v_hi; }
+// the group at v0 if it lies wholly inside the plane, else words without a marker (nothing uses the result at once: a
+// lane's loads of all its rounds are in flight together)
+__device__ __forceinline__ u32x4 tag_load16(const uint8_t *__restrict__ m_al, size_t v0, size_t v_lo, size_t v_hi)
+{
+    u32x4 w = {0u, 0u, 0u, 0u};
+    if (tag_whole(v0, v_lo, v_hi)) w = __builtin_nontemporal_load((const u32x4 *)(m_al + v0));
+    return w;
+}
+__device__ __forceinline__ uint32_t tag_count16(u32x4 w)       // how many of the 16 bytes equal 1
+{
+    return 128u - (__popc(tag_t(w.x)) + __popc(tag_t(w.y)) + __popc(tag_t(w.z)) + __popc(tag_t(w.w)));
+}
+// bit b <- the byte at virtual index v0 + b lies inside the plane and equals 1 (any group: the placing pass, the edge groups)
+__device__ __forceinline__ uint32_t tag_mask16(const uint8_t *__restrict__ m_al, size_t v0, size_t v_lo, size_t v_hi)
+{
+    if (v0 >= v_hi || v0 + 16 <= v_lo) return 0;
+    if (tag_whole(v0, v_lo, v_hi)) {
+        const u32x4 w = *(const u32x4 *)(m_al + v0);
+        return tag_ones4(w.x) | (tag_ones4(w.y) << 4) | (tag_ones4(w.z) << 8) | (tag_ones4(w.w) << 12);
+    }
+    uint32_t mask = 0;
+    for (int b = 0; b < 16; b++)
+        if (v0 + b >= v_lo && v0 + b < v_hi && m_al[v0 + b] == 1) mask |= 1u << b;
+    return mask;
+}
+
+// The fast pass over a workgroup's 16 rounds of NT lanes x 16 bytes from virtual index v_wg: bit r of the result <- this
+// lane's group of round r holds a marker; *n_mine <- how many markers this lane's groups hold.
+template <int NT>
+__device__ __forceinline__ uint32_t tag_fast_pass(const uint8_t *__restrict__ m_al, size_t v_wg, size_t v_lo, size_t v_hi, uint32_t *n_mine)
+{
+    const size_t v_lane = v_wg + (size_t)threadIdx.x * 16;
+    u32x4 w[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) w[r] = tag_load16(m_al, v_lane + (size_t)r * (NT * 16), v_lo, v_hi);
+    uint32_t mine = 0, n = 0;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const uint32_t c = tag_count16(w[r]);
+        n += c;
+        mine |= (c ? 1u : 0u) << r;
+    }
+    // the groups that straddle the plane's ends (none when the plane starts and ends on the 16-byte grid): the fast pass
+    // saw them as empty; the lane whose round grid they lie on reads them byte by byte
+    const size_t g_lo = v_lo & ~(size_t)15, g_hi = v_hi & ~(size_t)15;
+    const bool lo_partial = (v_lo & 15) != 0;
+    const bool hi_partial = (v_hi & 15) != 0 && !(lo_partial && g_hi == g_lo);
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        const size_t g = e == 0 ? g_lo : g_hi;
+        if ((e == 0 ? lo_partial : hi_partial) && g >= v_lane && (g - v_lane) % (NT * 16) == 0 && (g - v_lane) / (NT * 16) < 16) {
+            const uint32_t c = __popc(tag_mask16(m_al, g, v_lo, v_hi));
+            n += c;
+            mine |= (c ? 1u : 0u) << (int)((g - v_lane) / (NT * 16));
+        }
+    }
+    *n_mine = n;
+    return mine;
+}
+
+// One round of the placing pass (this lane: the group at v0): positions are appended at idx[base ...] in address order;
+// returns the round's number of markers (uniform).  s_w: NT / 64 words of LDS.
+template <int NT>
+__device__ __forceinline__ uint32_t tag_place(const uint8_t *__restrict__ m_al, size_t v0, size_t v_lo, size_t v_hi, uint32_t base,
+                                              uint32_t *__restrict__ idx, size_t cap, uint32_t *s_w)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t mask = tag_mask16(m_al, v0, v_lo, v_hi);
+    const uint32_t c = __popc(mask);
+    uint32_t inc = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += up;
+    }
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; w++) {
+        const uint32_t t = s_w[w];
+        if (w < wave) before += t;
+        total += t;
+    }
+    __syncthreads();                                           // s_w is free for the next round
+    size_t at = (size_t)base + before + (inc - c);
+    while (mask) {
+        const int b = __builtin_ctz(mask);
+        mask &= mask - 1;
+        if (at < cap) idx[at] = (uint32_t)(v0 + b - v_lo);
+        at++;
+    }
+    return total;
+}
+
+// the placing pass over the rounds whose bit is set in the workgroup's bitmap (s_bits: the lanes' bitmaps OR-ed together)
+template <int NT>
+__device__ __forceinline__ uint32_t tag_place_rounds(const uint8_t *__restrict__ m_al, size_t v_wg, size_t v_lo, size_t v_hi, uint32_t mine,
+                                                     uint32_t base, uint32_t *__restrict__ idx, size_t cap, uint32_t *s_w, uint32_t *s_bits)
+{
+    if (mine) atomicOr(s_bits, mine);
+    __syncthreads();
+    const uint32_t rounds = *s_bits;
+    for (int r = 0; r < 16; r++)
+        if (rounds >> r & 1u)
+            base += tag_place<NT>(m_al, v_wg + (size_t)r * (NT * 16) + (size_t)threadIdx.x * 16, v_lo, v_hi, base, idx, cap, s_w);
+    return base;
+}
+
+__global__ __launch_bounds__(1024) void sync_tags_small_kernel(const uint8_t *__restrict__ m_al, size_t v_lo, size_t v_hi,
+                                                               uint32_t *__restrict__ idx, size_t cap, uint32_t *__restrict__ count)
+{
+    __shared__ uint32_t s_w[16], s_bits;
+    if (threadIdx.x == 0) s_bits = 0;
+    __syncthreads();
+    uint32_t n_mine;
+    const uint32_t mine = tag_fast_pass<1024>(m_al, 0, v_lo, v_hi, &n_mine);
+    const uint32_t total = tag_place_rounds<1024>(m_al, 0, v_lo, v_hi, mine, 0, idx, cap, s_w, &s_bits);
+    if (threadIdx.x == 0) *count = total;
+}
+
+__global__ __launch_bounds__(256) void sync_tags_count_kernel(const uint8_t *__restrict__ m_al, size_t v_lo, size_t v_hi,
+                                                              uint32_t *__restrict__ tile_counts)
+{
+    __shared__ uint32_t s_w[4];
+    const int tid = threadIdx.x;
+    uint32_t c;
+    (void)tag_fast_pass<256>(m_al, (size_t)blockIdx.x * TAG_TILE, v_lo, v_hi, &c);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+    if ((tid & 63) == 0) s_w[tid >> 6] = c;
+    __syncthreads();
+    if (tid == 0) tile_counts[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+__global__ __launch_bounds__(256) void sync_tags_emit_kernel(const uint8_t *__restrict__ m_al, size_t v_lo, size_t v_hi,
+                                                             const uint32_t *__restrict__ tile_counts, uint32_t *__restrict__ idx,
+                                                             size_t cap, uint32_t *__restrict__ count)
+{
+    __shared__ uint32_t s_w[4], s_bits;
+    const int tid = threadIdx.x;
+    const unsigned t = blockIdx.x, last = gridDim.x - 1;
+    const uint32_t in_tile = tile_counts[t];
+    if (in_tile == 0 && t != last) return;                     // nothing to place, and the total is the last tile's to write
+    if (tid == 0) s_bits = 0;
+    uint32_t part = 0;
+    for (unsigned u = tid; u < t; u += 256) part += tile_counts[u];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);
+    if ((tid & 63) == 0) s_w[tid >> 6] = part;
+    __syncthreads();
+    const uint32_t base = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    __syncthreads();
+    if (t == last && tid == 0) *count = base + in_tile;
+    if (in_tile == 0 || (size_t)base >= cap) return;
+    uint32_t n_mine;
+    const uint32_t mine = tag_fast_pass<256>(m_al, (size_t)t * TAG_TILE, v_lo, v_hi, &n_mine);
+    (void)tag_place_rounds<256>(m_al, (size_t)t * TAG_TILE, v_lo, v_hi, mine, base, idx, cap, s_w, &s_bits);
+}
+
+extern "C" size_t clhip_sync_tags_ws_bytes(size_t n)
+{
+    return n + 15 <= TAG_SMALL ? 0 : sizeof(uint32_t) * clhip_div_up(n + 15, TAG_TILE);
+}
+
+extern "C" int clhip_sync_tags(const uint8_t *d_meta, size_t n, uint32_t *d_idx, size_t cap, uint32_t *d_count,
+                               void *d_ws, void *stream)
+{
+    if (!d_count || (n && !d_meta) || (cap && !d_idx) || n > 0xFFFFFFFFull) { clhip_set_error("clhip_sync_tags: bad arguments"); return -1; }
+    hipStream_t s = (hipStream_t)stream;
+    const size_t mis = (size_t)((uintptr_t)d_meta & 15);
+    const uint8_t *m_al = d_meta - mis;
+    const size_t v_lo = mis, v_hi = mis + n;
+    if (v_hi <= TAG_SMALL) {
+        hipLaunchKernelGGL(sync_tags_small_kernel, dim3(1), dim3(1024), 0, s, m_al, v_lo, v_hi, d_idx, cap, d_count);
+    } else {
+        if (!d_ws) { clhip_set_error("clhip_sync_tags: %zu bytes need a workspace of clhip_sync_tags_ws_bytes()", n); return -1; }
+        const unsigned tiles = (unsigned)clhip_div_up(v_hi, TAG_TILE);
+        hipLaunchKernelGGL(sync_tags_count_kernel, dim3(tiles), dim3(256), 0, s, m_al, v_lo, v_hi, (uint32_t *)d_ws);
+        hipLaunchKernelGGL(sync_tags_emit_kernel, dim3(tiles), dim3(256), 0, s, m_al, v_lo, v_hi, (const uint32_t *)d_ws, d_idx, cap, d_count);
+    }
+    CLHIP_CHECK_LAUNCH();
+    return 0;
+}

@@ -57,14 +57,26 @@ struct CaribouLiteRadio::SampleEngine {
     PinnedArray<std::complex<short>> h_native;
     PinnedArray<CaribouLiteMeta> h_sync;
     PinnedArray<std::complex<float>> h_float;
+    // pps tags of the fetched chunk: word 0 = how many, words 1.. = positions (one copy brings the count and the first
+    // TAGS_EAGER positions; a chunk with more of them -- a test stream, never a real second marker -- costs a second copy)
+    enum { TAGS_EAGER = 1023 };
+    DeviceArray<uint32_t> d_tags;
+    DeviceArray<uint8_t> d_tag_ws;         // per-tile counts of clhip_sync_tags (only a native batch above 256 KiB needs any)
+    PinnedArray<uint32_t> h_tags;
+    std::atomic<bool> tags_wanted{false};
 
     SampleEngine(cl_smi *s, int channel)
         : smi(s), seam(cl_radio_create(s, channel)), mtu(cl_radio_get_native_mtu_size_samples(seam)), stream(cl_smi_stream(s)),
-          d_native(2 * (mtu + 8)), d_sync(mtu + 8), d_float(2 * (mtu + 8)), h_native(mtu + 8), h_sync(mtu + 8), h_float(mtu + 8) {}
+          d_native(2 * (mtu + 8)), d_sync(mtu + 8), d_float(2 * (mtu + 8)), h_native(mtu + 8), h_sync(mtu + 8), h_float(mtu + 8),
+          d_tags(1 + mtu + 8), d_tag_ws(clhip_sync_tags_ws_bytes(mtu + 8) + 4), h_tags(1 + mtu + 8)
+    {
+        if (h_tags.get()) h_tags.get()[0] = 0;
+    }
     ~SampleEngine() { cl_radio_destroy(seam); }
     bool usable() const
     {
-        return seam && d_native.get() && d_sync.get() && d_float.get() && h_native.get() && h_sync.get() && h_float.get();
+        return seam && d_native.get() && d_sync.get() && d_float.get() && h_native.get() && h_sync.get() && h_float.get() &&
+               d_tags.get() && d_tag_ws.get() && h_tags.get();
     }
 
     // One seam read of up to `count` samples (count <= mtu).  Afterwards the pinned mirrors hold: the sync plane,
@@ -72,16 +84,26 @@ struct CaribouLiteRadio::SampleEngine {
     int fetch(size_t count, bool as_float)
     {
         clhip_set_device(cl_smi_device(smi));
+        h_tags.get()[0] = 0;
         const int got = cl_radio_read_samples_device(seam, d_native.get(), d_sync.get(), count);
         if (got <= 0) return got;
         const size_t n = static_cast<size_t>(got);
         int bad = clhip_memcpy_d2h(h_sync.get(), d_sync.get(), n, stream);
+        const bool tags = tags_wanted.load();
+        if (tags)           // the callers' `if (meta[i] == 1)` loop, on the plane where it lies (caribouLiteSource_impl.cc:113-119)
+            bad = bad || clhip_sync_tags(d_sync.get(), n, d_tags.get() + 1, mtu + 8, d_tags.get(), d_tag_ws.get(), stream) ||
+                  clhip_memcpy_d2h(h_tags.get(), d_tags.get(), sizeof(uint32_t) * (1 + (n < TAGS_EAGER ? n : (size_t)TAGS_EAGER)), stream);
         if (as_float)       // ((float)v) / 4096.0f on every slot, stale ones included (CaribouLiteRadioCpp.cpp:41-45,:91)
             bad = bad || clhip_convert_from_cs16(d_native.get(), n, CL_FORMAT_CF32, d_float.get(), stream) ||
                   clhip_memcpy_d2h(h_float.get(), d_float.get(), n * sizeof(std::complex<float>), stream);
         else
             bad = bad || clhip_memcpy_d2h(h_native.get(), d_native.get(), n * sizeof(std::complex<short>), stream);
-        return (bad || clhip_stream_sync(stream)) ? -1 : got;
+        if (bad || clhip_stream_sync(stream)) return -1;
+        if (tags && h_tags.get()[0] > TAGS_EAGER &&
+            (clhip_memcpy_d2h(h_tags.get() + 1 + TAGS_EAGER, d_tags.get() + 1 + TAGS_EAGER,
+                              sizeof(uint32_t) * (h_tags.get()[0] - TAGS_EAGER), stream) || clhip_stream_sync(stream)))
+            return -1;
+        return got;
     }
 
     // float samples -> the 16-bit store of CaribouLiteRadioCpp.cpp:148-149 -> seam write, at most one MTU.
@@ -238,6 +260,13 @@ int CaribouLiteRadio::WriteSamples(std::complex<float> *samples, size_t num_to_w
 int CaribouLiteRadio::WriteSamples(std::complex<short> *samples, size_t num_to_write)
 {
     return cl_radio_write_samples(engine_->seam, reinterpret_cast<cl_sample_complex_int16 *>(samples), num_to_write);
+}
+
+void CaribouLiteRadio::EnableSyncTags(bool on) { engine_->tags_wanted = on; }
+size_t CaribouLiteRadio::GetSyncTags(const uint32_t **positions) const
+{
+    if (positions) *positions = engine_->h_tags.get() + 1;
+    return engine_->h_tags.get()[0];
 }
 
 size_t CaribouLiteRadio::GetNativeMtuSample() { return engine_->mtu; }                    // :667-670

@@ -55,6 +55,14 @@ public:
     int WriteSamples(std::complex<float> *samples, size_t num_to_write);
     int WriteSamples(std::complex<short> *samples, size_t num_to_write);
 
+    // pps tags (not in the reference's class: the device-side form of the loop its callers run over `meta`, e.g. the
+    // GNU Radio source's work(), gr-caribouLite/lib/caribouLiteSource_impl.cc:113-119).  Once enabled, every fetch also
+    // compacts the positions with meta[i].sync == 1 on the GPU (clhip_sync_tags) and brings them over with the samples;
+    // GetSyncTags() returns how many the LAST ReadSamples / the chunk a callback is being handed holds and points
+    // `*positions` at them (ascending; valid until the next fetch).
+    void EnableSyncTags(bool on);
+    size_t GetSyncTags(const uint32_t **positions) const;
+
     // General
     size_t GetNativeMtuSample();
     std::string GetRadioName();

@@ -53,6 +53,8 @@ _SIGS = {
     "clhip_convert_to_cs16": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]),
     "clhip_smi_debug_analyze": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p]),
     "clhip_smi_pack": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "clhip_sync_tags_ws_bytes": (C.c_size_t, [C.c_size_t]),
+    "clhip_sync_tags": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "clhip_iir_create": (C.c_void_p, [C.c_void_p, C.c_int, C.c_int]),
     "clhip_iir_destroy": (None, [C.c_void_p]),
     "clhip_iir_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]),
@@ -161,6 +163,13 @@ def smi_unpack(channel, d_bytes, total_bytes, chunk_stride, chunk_len, n_chunks,
     _check(lib().clhip_smi_unpack(channel, ptr(d_bytes), total_bytes, chunk_stride, chunk_len, n_chunks,
                                   ptr(d_offs), fmt, ptr(d_out), ptr(d_meta),
                                   stream if stream is not None else current_stream()), "clhip_smi_unpack")
+
+
+def sync_tags(d_meta, n, d_idx, cap, d_count, d_ws=None, stream=None):
+    """pps tags of a meta plane (caribouLiteSource_impl.cc:113-119): d_idx[:min(count, cap)] = ascending positions of
+    meta == 1, d_count[0] = how many there are.  d_meta may be a torch tensor or a raw device address (any alignment)."""
+    _check(lib().clhip_sync_tags(ptr(d_meta), n, ptr(d_idx), cap, ptr(d_count),
+                                 ptr(d_ws), stream if stream is not None else current_stream()), "clhip_sync_tags")
 
 
 def convert_from_cs16(d_iq, n, fmt, d_out, stream=None):

@@ -160,6 +160,17 @@ int clhip_smi_unpack_aligned(int channel, const uint8_t *d_bytes, size_t n_bytes
 int clhip_smi_debug_analyze(int mode, const uint8_t *d_bytes, size_t len, uint32_t last_correct_byte,
                             int32_t *d_res, void *stream);
 
+/*
+ * pps tags -- replaces the per-sample host loop of the GNU Radio source block's work()
+ * (software/gr-caribouLite/lib/caribouLiteSource_impl.cc:113-119: `if (out_meta[i] == 1) add_item_tag(0, i, "pps", true)`)
+ * by one ordered compaction of the meta plane on the device: d_idx[0 .. min(count, cap)) = the positions i < n with
+ * d_meta[i] == 1 (exactly 1, as the loop tests), ascending; *d_count = how many there are (also beyond cap).
+ * d_meta may start at any byte address (a plane the unpack wrote at an offset).  n < 2^32.  Planes above 256 KiB
+ * need d_ws = clhip_sync_tags_ws_bytes(n) bytes of device memory (per-tile counts; no initialisation needed).
+ */
+size_t clhip_sync_tags_ws_bytes(size_t n);
+int clhip_sync_tags(const uint8_t *d_meta, size_t n, uint32_t *d_idx, size_t cap, uint32_t *d_count, void *d_ws, void *stream);
+
 /* RX/TX format conversions on native CS16 (CaribouliteStream.cpp:199-244,304-367) */
 int clhip_convert_from_cs16(const int16_t *d_iq, size_t n_samples, int format, void *d_out, void *stream);
 int clhip_convert_to_cs16(const void *d_in, int format, size_t n_samples, int16_t *d_iq, void *stream);

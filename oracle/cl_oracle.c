@@ -685,3 +685,17 @@ size_t orc_ring_get(orc_ring *r, uint32_t *data, size_t length, int block_read)
     r->tail += len;
     return len;
 }
+
+/* ---- pps tags: the GNU Radio source block's work()  (software/gr-caribouLite/lib/caribouLiteSource_impl.cc:113-119) ----
+ * `for (i = 0; i < read_samples; i++) if (out_meta[i] == 1) add_item_tag(0, i, "pps", true)`: the offsets it tags, in the
+ * order it tags them.  Returns how many there are; the first `cap` are stored. */
+size_t orc_sync_tags(const uint8_t *meta, size_t n, uint32_t *idx, size_t cap)
+{
+    size_t k = 0;
+    for (size_t i = 0; i < n; i++)
+        if (meta[i] == 1) {
+            if (k < cap) idx[k] = (uint32_t)i;
+            k++;
+        }
+    return k;
+}

@@ -141,6 +141,9 @@ size_t orc_ring_size(const orc_ring *r);
 size_t orc_ring_put(orc_ring *r, const uint32_t *data, size_t length);
 size_t orc_ring_get(orc_ring *r, uint32_t *data, size_t length, int block_read);
 
+/* pps tags of a meta plane: caribouLiteSource_impl.cc:113-119 */
+size_t orc_sync_tags(const uint8_t *meta, size_t n, uint32_t *idx, size_t cap);
+
 size_t orc_rx_pipe_f32_mt(int channel, const uint8_t *bytes, size_t n_bytes, size_t native_batch_len,
                           const float *fir_taps, int fir_n, const float *rs_taps, int rs_n, int L, int M,
                           int16_t *iq_buf, float *x_buf, float *y_buf, float *out, int n_threads);

@@ -53,6 +53,7 @@ def lib():
         _lib.orc_resamp_f32.restype = C.c_size_t
         _lib.orc_rx_pipe_f32.restype = C.c_size_t
         _lib.orc_fpga_tx_parse.restype = C.c_size_t
+        _lib.orc_sync_tags.restype = C.c_size_t
     return _lib
 
 
@@ -112,6 +113,16 @@ def fpga_tx_parse(b):
     w = np.empty(b.size, dtype=np.uint32)
     n = lib().orc_fpga_tx_parse(_p(b, C.c_uint8), C.c_size_t(b.size), _p(w, C.c_uint32))
     return w[:n].copy()
+
+
+# ------------------------------------------------------------------ pps tags
+def sync_tags(meta, cap=None):
+    """(positions the GNU Radio source's work() tags, how many there are): caribouLiteSource_impl.cc:113-119."""
+    meta = np.ascontiguousarray(meta, dtype=np.uint8)
+    cap = meta.size if cap is None else cap
+    idx = np.empty(max(cap, 1), dtype=np.uint32)
+    k = lib().orc_sync_tags(_p(meta, C.c_uint8), C.c_size_t(meta.size), _p(idx, C.c_uint32), C.c_size_t(cap))
+    return idx[:min(k, cap)].copy(), int(k)
 
 
 # --------------------------------------------------------------- conversions

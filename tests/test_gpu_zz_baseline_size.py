@@ -270,3 +270,50 @@ def test_tx_config5_at_baseline_size_by_properties(G, orc):
     ia, ib = _tx_words_to_iq(ba.cpu().numpy().view(np.uint32)), _tx_words_to_iq(bb.cpu().numpy().view(np.uint32))
     d13 = np.abs(ia - ib); d13 = np.minimum(d13, 8192 - d13)
     assert d13.max() <= 1
+
+
+def test_pps_tags_at_baseline_size_by_properties(G, orc):
+    """The meta plane of ONE 2^28-sample stream (config 1 / 2's size): unpack writes it, clhip_sync_tags compacts it.
+      * the synthetic stream marks every 4 000 000th sample (SURVEY 8d): the tags are exactly 0, 4e6, 8e6, ...;
+      * a plane with ~3 % markers: the count equals torch's, the positions are strictly increasing, every position holds a 1,
+        and their checksum equals the checksum of torch.nonzero; a capacity smaller than the count keeps the first `cap`."""
+    import torch
+    from cariboulite_amd import hip, synth
+    dev = G.DEV
+    n = 1 << 28
+    words = synth.torch_smi_words(n, torch.device(dev), channel=0, stream=3)
+    nch = n // 131072
+    offs = torch.zeros(nch, dtype=torch.int32, device=dev)
+    iq = torch.empty((n, 2), dtype=torch.int16, device=dev)
+    meta = torch.full((n,), 0xAA, dtype=torch.uint8, device=dev)
+    hip.smi_find_offsets(words, 4 * n, 524288, 524288, nch, offs)
+    hip.smi_unpack(0, words, 4 * n, 524288, 524288, nch, offs, hip.FORMAT_CS16, iq, meta)
+    del words, iq
+    ws = torch.empty(hip.lib().clhip_sync_tags_ws_bytes(n), dtype=torch.uint8, device=dev)
+    idx = torch.full((1024,), -1, dtype=torch.int32, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    hip.sync_tags(meta, n, idx, 1024, cnt, ws)
+    torch.cuda.synchronize()
+    want = list(range(0, n, 4_000_000))
+    assert int(cnt.item()) == len(want) and idx.cpu().numpy()[:len(want)].tolist() == want
+
+    g = torch.Generator(device=dev); g.manual_seed(9)
+    meta = (torch.rand(n, device=dev, generator=g) < 0.03).to(torch.uint8) * 1 + \
+           (torch.rand(n, device=dev, generator=g) < 0.01).to(torch.uint8) * 2          # values 0, 1, 2, 3: only 1 is a marker
+    k = int((meta == 1).sum().item())
+    idx = torch.full((k + 16,), -1, dtype=torch.int32, device=dev)
+    hip.sync_tags(meta, n, idx, k + 16, cnt, ws)
+    torch.cuda.synchronize()
+    assert int(cnt.item()) == k
+    got = idx[:k].to(torch.int64)
+    assert bool((idx[k:] == -1).all())
+    assert bool((got[1:] > got[:-1]).all()) and int(got[0]) >= 0 and int(got[-1]) < n
+    assert bool((meta[got] == 1).all())
+    ref = torch.nonzero(meta == 1).flatten()
+    assert bool((ref == got).all())
+    del ref
+    cap = 100_000
+    idx2 = torch.full((cap + 16,), -1, dtype=torch.int32, device=dev)
+    hip.sync_tags(meta, n, idx2, cap, cnt, ws)
+    torch.cuda.synchronize()
+    assert int(cnt.item()) == k and bool((idx2[:cap] == idx[:cap]).all()) and bool((idx2[cap:] == -1).all())

@@ -253,3 +253,24 @@ def test_bitrate_ema_vs_the_reference_itself(orc):
         mbps, old = got, cur
     # and with a clock that runs backwards across a second boundary (negative usec difference)
     assert orc.bitrate_ema(1000, (10, 900000), (11, 100000), 5.0) == 5.0 * 0.98 + (8000 / 0.2 / 1e6) * 0.02
+
+
+def test_sync_tags_is_the_work_loop(orc):
+    """orc_sync_tags restates the GNU Radio source's tag loop (caribouLiteSource_impl.cc:113-119): offsets of meta == 1
+    (not 'non-zero': a slot a re-sync left untouched may hold anything), ascending, count beyond the capacity kept."""
+    rng = np.random.default_rng(11)
+    idx0, k0 = orc.sync_tags(np.zeros(0, np.uint8))
+    assert k0 == 0 and idx0.size == 0
+    for n in (1, 17, 4000, 131072):
+        meta = rng.choice(np.array([0, 0, 1, 2, 0xAA, 0xFF], np.uint8), n)
+        idx, k = orc.sync_tags(meta)
+        want = [i for i in range(n) if meta[i] == 1]          # the loop as written
+        assert k == len(want) and idx.tolist() == want
+        idx2, k2 = orc.sync_tags(meta, cap=min(3, k))
+        assert k2 == k and idx2.tolist() == want[:min(3, k)]
+    # the stream's own pps: one tag per 4 000 000 samples (SURVEY 8d), through the oracle's unpack
+    from cariboulite_amd import synth
+    b, _, _ = synth.smi_stream_bytes(70000, n0=4_000_000 - 1234)
+    _, _, meta = orc.rx_data_analyze(orc.CH_S1G, b)
+    idx, k = orc.sync_tags(meta[:70000])
+    assert k == 1 and idx.tolist() == [1234]

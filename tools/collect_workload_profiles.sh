@@ -9,7 +9,7 @@ OUT=$1; shift
 R=$(pwd)
 export TMPDIR=/tmp
 mkdir -p $OUT
-declare -A ALG=( [c1]=$((12*(1<<28))) [c3]=$((8*(1<<28))) [c4]=$((14*32*(1<<24))) [c5]=$(( (4*3+8)*(1<<27)/3 )) [iir]=$((8*(1<<26))) [c2]=$((16*(1<<28))) )
+declare -A ALG=( [c1]=$((12*(1<<28))) [c3]=$((8*(1<<28))) [c4]=$((14*32*(1<<24))) [c5]=$(( (4*3+8)*(1<<27)/3 )) [iir]=$((8*(1<<26))) [c2]=$((16*(1<<28))) [tags]=$((1<<28)) )
 PS=20; PW=5; PSETTLE=5; TOTAL=$((PS+PW+PSETTLE))
 for WL in "$@"; do
   EXTRA=""
