@@ -807,17 +807,18 @@ void rx_pipe_fused_kernel(const PipeArgs a)
     // queue_k == 0: static striding by grid_int (A/B switch).
     int *qslot = (int *)(lds + C::IN_BYTES + C::TAIL_BYTES);
     const int K = a.queue_k;
+    const int dyn0 = a.grid_int + K * a.grid_int;              // first item handed out by ticket (see below)
     int pos = 0, end = 0, nb_base = 0;           // current chunk [pos, end), base of the chunk after it
 
     TileRegs<C, KIND> regs;
     int item = (int)blockIdx.x - n_edge_wg;
     {
-        if (K > 0) {
-            if (threadIdx.x == 0) *qslot = (int)atomicAdd(a.queue, 1u);
-            __syncthreads();
-            nb_base = a.grid_int + K * __builtin_amdgcn_readfirstlane(*qslot);
-            __syncthreads();                                 // everyone has read the slot before it is rewritten
-        }
+        // The worker's first chunk is static -- the K items behind the grid's first tiles that its own number selects -- so
+        // that nothing stands between the launch and the first tile's loads: a ticket drawn here cost every workgroup of the
+        // grid one same-address atomic before its first load (~12 ns each, one after the other: the last of 1 024 workers
+        // started 12 us late, which is what a one-round launch -- one second of one stream -- mostly consisted of).
+        // Tickets number the chunks behind those: [dyn0 + K * ticket, + K).
+        if (K > 0) nb_base = a.grid_int + K * item;
         const int s0 = item / per_stream, tile0 = 1 + item % per_stream;
         const void *in0 = KIND == CL_PIPE_IN_CF32 ? (const void *)((const f32x2 *)a.in + (long)s0 * a.in_stride)
                                                  : (const void *)((const uint32_t *)a.in + (long)s0 * a.in_stride);
@@ -857,7 +858,7 @@ void rx_pipe_fused_kernel(const PipeArgs a)
         else if (pos < end) next = pos++;
         else {                                               // enter the next chunk; ask for the one after it (below)
             pos = nb_base; end = pos + K;
-            nb_base = a.grid_int + K * __builtin_amdgcn_readfirstlane(*qslot);
+            nb_base = dyn0 + K * __builtin_amdgcn_readfirstlane(*qslot);
             next = pos++;
             want_grab = next < items;
         }
@@ -1331,6 +1332,7 @@ static int launch_pipe(PipeArgs &a, hipStream_t s)
         resident = resident_on[slot];
     }
     a.grid_int = (int)(items < resident ? items : resident);
+    if (items <= resident) a.queue_k = 0;                      // one tile per worker: nothing to hand out, no atomics at all
     const unsigned grid = (unsigned)a.grid_int + (unsigned)a.n_edge * a.n_streams;
     hipLaunchKernelGGL((rx_pipe_fused_kernel<C, KIND, HIF, DIAG>), dim3(grid), dim3(C::NT), C::LDS_BYTES, s, a);
     CLHIP_CHECK_LAUNCH();
