@@ -467,6 +467,78 @@ extern "C" int clhip_smi_pack(int mode, const int16_t *d_iq, size_t n, uint8_t *
 }
 
 // ---------------------------------------------------------------------------
+// writeStream of a non-native format in ONE launch: the conversion loop (CaribouliteStream.cpp:199-244) and the TX pack
+// (caribou_smi.c:684-717) on the same sample -- the int16 pair the reference parks in its intermediate buffer lives in
+// a register.  Same device functions as the two separate kernels: bit-identical bytes.
+// ---------------------------------------------------------------------------
+template <int FMT> __device__ __forceinline__ uint32_t sample_to_cs16(const typename OutElem<FMT>::type v)
+{
+    if constexpr (FMT == CL_FORMAT_CF32) return f2i16(v.x * 4096.0f) | (f2i16(v.y * 4096.0f) << 16);
+    else if constexpr (FMT == CL_FORMAT_CF64) return d2i16(v.x * 4096.0) | (d2i16(v.y * 4096.0) << 16);
+    else if constexpr (FMT == CL_FORMAT_CS8) {
+        const int i = (int8_t)(v & 0xFF), q = (int8_t)(v >> 8);
+        return ((uint32_t)(i << 5) & 0xFFFFu) | (((uint32_t)(q << 5) & 0xFFFFu) << 16);
+    } else return v;
+}
+
+template <int FMT>
+__global__ __launch_bounds__(256) void convert_pack_kernel(int mode, const typename OutElem<FMT>::type *__restrict__ in, size_t n,
+                                                           uint32_t *__restrict__ out)
+{
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if ((((uintptr_t)out) & 15) == 0) {                        // four words per lane: 16-byte stores
+        const size_t n4 = n / 4;
+        for (size_t j = k; j < n4; j += step) {
+            u32x4 r;
+#pragma unroll
+            for (int t = 0; t < 4; t++) r[t] = pack_tx_word(mode, sample_to_cs16<FMT>(in[4 * j + t]));
+            ((u32x4 *)out)[j] = r;
+        }
+        for (size_t j = 4 * n4 + k; j < n; j += step) out[j] = pack_tx_word(mode, sample_to_cs16<FMT>(in[j]));
+    } else {
+        for (size_t j = k; j < n; j += step) out[j] = pack_tx_word(mode, sample_to_cs16<FMT>(in[j]));
+    }
+}
+
+extern "C" int clhip_convert_pack(const void *d_in, int format, size_t n, int mode, uint8_t *d_bytes, void *stream)
+{
+    if (n == 0) return 0;
+    if (!d_in || !d_bytes || (((uintptr_t)d_bytes) & 3)) { clhip_set_error("clhip_convert_pack: bad arguments"); return -1; }
+    unsigned grid = (unsigned)clhip_div_up(clhip_div_up(n, 4), 256);
+    if (grid > 8192) grid = 8192;
+    hipStream_t s = (hipStream_t)stream;
+    uint32_t *out = (uint32_t *)d_bytes;
+    switch (format) {
+    case CL_FORMAT_CS16: hipLaunchKernelGGL(convert_pack_kernel<CL_FORMAT_CS16>, dim3(grid), dim3(256), 0, s, mode, (const uint32_t *)d_in, n, out); break;
+    case CL_FORMAT_CF32: hipLaunchKernelGGL(convert_pack_kernel<CL_FORMAT_CF32>, dim3(grid), dim3(256), 0, s, mode, (const f32x2 *)d_in, n, out); break;
+    case CL_FORMAT_CS8: hipLaunchKernelGGL(convert_pack_kernel<CL_FORMAT_CS8>, dim3(grid), dim3(256), 0, s, mode, (const uint16_t *)d_in, n, out); break;
+    case CL_FORMAT_CF64: hipLaunchKernelGGL(convert_pack_kernel<CL_FORMAT_CF64>, dim3(grid), dim3(256), 0, s, mode, (const double2 *)d_in, n, out); break;
+    default: clhip_set_error("clhip_convert_pack: unknown format %d", format); return -1;
+    }
+    CLHIP_CHECK_LAUNCH();
+    return 0;
+}
+
+// the I rail of interleaved CF32 as a dense fp32 message (the FM modulator's input: SURVEY.md a13 "if given I/Q, use I")
+__global__ __launch_bounds__(256) void take_i_rail_kernel(const f32x2 *__restrict__ in, size_t n, float *__restrict__ out)
+{
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += step) out[k] = in[k].x;
+}
+
+extern "C" int clhip_take_i_rail(const float *d_cf32, size_t n, float *d_msg, void *stream)
+{
+    if (n == 0) return 0;
+    if (!d_cf32 || !d_msg) { clhip_set_error("clhip_take_i_rail: bad arguments"); return -1; }
+    unsigned grid = (unsigned)clhip_div_up(n, 256);
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(take_i_rail_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const f32x2 *)d_cf32, n, d_msg);
+    CLHIP_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
 // link-integrity (debug) modes: caribou_smi.c:172-215 (analyse), :266-283 (search)
 //   LFSR  : every byte must be lfsr(previous byte) and non-zero (smi_utils.c:220-224)
 //   push / pull : every word must be 0xABCDEF01; the search accepts < 4 flipped bits

@@ -150,6 +150,7 @@ cl_smi *cl_smi_init(int device)
     pthread_mutex_init(&dev->fifo_mu, NULL);
     pthread_cond_init(&dev->fifo_fed, NULL);
     dev->rx.pinned = 1;                                /* the feeder writes where the DMA engine reads */
+    dev->tx.pinned = 1;                                /* ... and the TX side drains what the DMA engine wrote */
     return dev;
 }
 
@@ -841,8 +842,7 @@ static int smi_write_core(cl_smi *dev, const cl_sample_complex_int16 *h_buffer, 
     size_t left = length_samples * CL_BYTES_PER_SAMPLE, written_so_far = 0;
     if (length_samples == 0) return 0;
     if ((h_buffer && cl_ensure((void **)&dev->d_iq, &dev->iq_cap, length_samples + 8, 4, 0)) ||
-        cl_ensure((void **)&dev->d_bytes, &dev->bytes_cap, left + 256, 1, 0) ||
-        cl_ensure((void **)&dev->h_stage, &dev->h_stage_cap, left + 256, 1, 1))
+        cl_ensure((void **)&dev->d_bytes, &dev->bytes_cap, left + 256, 1, 0))
         return CL_SMI_ERR_IO;
     /* the chunk loop only slices the same contiguous arrays (len &= ~3 never bites: 4 B/sample), so
      * the whole call is one pack launch; the FIFO then receives it in native-batch writes */
@@ -850,17 +850,15 @@ static int smi_write_core(cl_smi *dev, const cl_sample_complex_int16 *h_buffer, 
         if (clhip_memcpy_h2d(dev->d_iq, h_buffer, left, dev->stream)) return CL_SMI_ERR_IO;
         d_src = dev->d_iq;
     }
+    /* the packed words go straight into the (pinned) TX FIFO, where the fd's write() side picks them up: the chunk loop of
+     * caribou_smi.c:738-759 appends native-batch pieces of one contiguous array one after the other, i.e. the array */
+    uint8_t *room = cl_fifo_reserve(&dev->tx, left);
+    if (!room) return CL_SMI_ERR_IO;
     if (clhip_smi_pack(dev->tx_mode, d_src, length_samples, dev->d_bytes, dev->stream) ||
-        clhip_memcpy_d2h(dev->h_stage, dev->d_bytes, left, dev->stream) || clhip_stream_sync(dev->stream))
+        clhip_memcpy_d2h(room, dev->d_bytes, left, dev->stream) || clhip_stream_sync(dev->stream))
         return CL_SMI_ERR_IO;
-    while (left) {
-        size_t cur = left > dev->native_batch_len ? dev->native_batch_len : left;
-        cur &= 0xFFFFFFFCu;                                     /* :745 */
-        if (!cur) break;
-        if (cl_fifo_push(&dev->tx, dev->h_stage + written_so_far * 4, cur)) return CL_SMI_ERR_IO;
-        written_so_far += cur / CL_BYTES_PER_SAMPLE;            /* :757 */
-        left -= cur;                                            /* :758 (ret == len) */
-    }
+    cl_fifo_commit(&dev->tx, left);                             /* len &= ~3 (:745) never bites: 4 bytes per sample */
+    written_so_far = left / CL_BYTES_PER_SAMPLE;                /* :757 */
     dev->stat_written += written_so_far;
     return (int)written_so_far;
 }

@@ -833,10 +833,13 @@ static int write_stream(cl_device *dev, cl_stream *st, const void *const *buffs,
     const size_t n = numElems, ib = fmt_bytes(st->format);
     if (cl_ensure(&st->d_conv, &st->conv_cap, n * 16 + 64, 1, 0) ||
         cl_ensure((void **)&smi->d_iq, &smi->iq_cap, n + 8, 4, 0) ||
-        cl_ensure((void **)&smi->d_bytes, &smi->bytes_cap, 4 * n * (size_t)(st->tx_pipe ? st->dsp.up : 1) + 256, 1, 0) ||
-        cl_ensure((void **)&smi->h_stage, &smi->h_stage_cap, 4 * n * (size_t)(st->tx_pipe ? st->dsp.up : 1) + 256, 1, 1))
+        cl_ensure((void **)&smi->d_bytes, &smi->bytes_cap, 4 * n * (size_t)(st->tx_pipe ? st->dsp.up : 1) + 256, 1, 0))
         return 0;
-    if (!(st->tx_pipe && st->dsp.mod_fm) && clhip_memcpy_h2d(st->d_conv, in, n * ib, smi->stream)) return 0;
+    if (clhip_memcpy_h2d(st->d_conv, in, n * ib, smi->stream)) return 0;
+    /* the packed words go straight into the pinned TX FIFO (caribou_smi_write's chunk loop, caribou_smi.c:738-759, appends
+     * native-batch pieces of one contiguous array): room for the most a call can produce, committed once it is known to be good */
+    uint8_t *room = cl_fifo_reserve(&smi->tx, 4 * n * (size_t)(st->tx_pipe ? st->dsp.up : 1) + 64);
+    if (!room) return 0;
     size_t n_packed = n;
     /* a modulator call whose look-back gave up (dispatch-order mode) has put the pipe back where it was and switched it
      * to ticket order: the call is simply made again, once */
@@ -846,22 +849,19 @@ static int write_stream(cl_device *dev, cl_stream *st, const void *const *buffs,
             /* MOD=FM: the I component carries the real message (SURVEY.md a13 "if given I/Q, use I") */
             long got;
             if (st->dsp.mod_fm) {
-                /* compact the I rail into a dense message on the host side of the copy (pinned staging, no allocation) */
-                if (cl_ensure((void **)&st->h_conv, &st->h_conv_cap, n * 4 + 64, 1, 1)) return 0;
-                float *msg = (float *)st->h_conv;
-                for (size_t k = 0; k < n; k++) msg[k] = ((const float *)in)[2 * k];
-                if (clhip_memcpy_h2d(st->d_conv, msg, n * 4, smi->stream)) return 0;
-                got = clhip_tx_pipe_run(st->tx_pipe, CL_TXPIPE_IN_FM_MESSAGE, st->d_conv, 0, n, smi->d_bytes, 0, NULL, 0, smi->stream);
+                /* the I rail as a dense message, taken on the device behind the samples (d_conv holds 16 bytes per element) */
+                float *d_msg = (float *)st->d_conv + 2 * n;
+                if (clhip_take_i_rail((const float *)st->d_conv, n, d_msg, smi->stream)) return 0;
+                got = clhip_tx_pipe_run(st->tx_pipe, CL_TXPIPE_IN_FM_MESSAGE, d_msg, 0, n, smi->d_bytes, 0, NULL, 0, smi->stream);
             } else
                 got = clhip_tx_pipe_run(st->tx_pipe, CL_TXPIPE_IN_CF32, st->d_conv, 0, n, smi->d_bytes, 0, NULL, 0, smi->stream);
             if (got < 0) return 0;
             n_packed = (size_t)got;
         } else {
-            if (clhip_convert_to_cs16(st->d_conv, st->format, n, smi->d_iq, smi->stream) ||      /* :199-244 */
-                clhip_smi_pack(smi->tx_mode, smi->d_iq, n, smi->d_bytes, smi->stream))            /* caribou_smi.c:684-717 */
-                return 0;
+            /* :199-244 and caribou_smi.c:684-717 on the same sample, one launch */
+            if (clhip_convert_pack(st->d_conv, st->format, n, smi->tx_mode, smi->d_bytes, smi->stream)) return 0;
         }
-        if (n_packed && (clhip_memcpy_d2h(smi->h_stage, smi->d_bytes, 4 * n_packed, smi->stream) || clhip_stream_sync(smi->stream))) return 0;
+        if (n_packed && (clhip_memcpy_d2h(room, smi->d_bytes, 4 * n_packed, smi->stream) || clhip_stream_sync(smi->stream))) return 0;
         /* the modulator's verdict on this very call: invalid words never reach the fd (squashed to 0 like every
          * write error, CaribouliteStream.cpp:185-194) */
         if (!st->tx_pipe || clhip_tx_pipe_status(st->tx_pipe) == 0) break;
@@ -869,12 +869,6 @@ static int write_stream(cl_device *dev, cl_stream *st, const void *const *buffs,
         st->stats.tx_overruns++;
         if (attempt) return 0;
     }
-    /* caribou_smi_write's chunk loop (caribou_smi.c:738-759) over the packed bytes */
-    size_t left = 4 * n_packed, done = 0;
-    while (left) {
-        size_t cur = left > smi->native_batch_len ? smi->native_batch_len : left;
-        if (cl_fifo_push(&smi->tx, smi->h_stage + done, cur)) return 0;
-        done += cur; left -= cur;
-    }
+    cl_fifo_commit(&smi->tx, 4 * n_packed);
     return (int)n;      /* elements consumed from the caller's buffer */
 }

@@ -174,6 +174,13 @@ int clhip_sync_tags(const uint8_t *d_meta, size_t n, uint32_t *d_idx, size_t cap
 /* RX/TX format conversions on native CS16 (CaribouliteStream.cpp:199-244,304-367) */
 int clhip_convert_from_cs16(const int16_t *d_iq, size_t n_samples, int format, void *d_out, void *stream);
 int clhip_convert_to_cs16(const void *d_in, int format, size_t n_samples, int16_t *d_iq, void *stream);
+/* The two steps of a non-native writeStream -- the conversion loop (CaribouliteStream.cpp:199-244) and
+ * caribou_smi_generate_data (caribou_smi.c:684-717) -- in one launch; bit-identical to clhip_convert_to_cs16 + clhip_smi_pack.
+ * d_bytes: 4-byte aligned, 4 * n_samples bytes.  mode = CL_TX_DOCUMENTED / CL_TX_AS_WRITTEN. */
+int clhip_convert_pack(const void *d_in, int format, size_t n_samples, int mode, uint8_t *d_bytes, void *stream);
+/* The I rail of interleaved CF32 samples as a dense fp32 message: what Stream::WriteSamples would hand an FM modulator
+ * ("if given I/Q, use I"), taken on the device instead of in a host loop. */
+int clhip_take_i_rail(const float *d_cf32, size_t n_samples, float *d_msg, void *stream);
 
 /* TX pack -- replaces caribou_smi_generate_data (caribou_smi.c:684-717) */
 int clhip_smi_pack(int mode, const int16_t *d_iq, size_t n_samples, uint8_t *d_bytes, void *stream);

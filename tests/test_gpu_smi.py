@@ -148,3 +148,47 @@ def test_pack_and_conversions(G, orc):
     i8 = rng.integers(-128, 128, (n, 2)).astype(np.int8)
     hip.convert_to_cs16(torch.from_numpy(i8).to(G.DEV), hip.FORMAT_CS8, n, back)
     assert np.array_equal(back.cpu().numpy(), orc.cs8_to_cs16(i8))
+
+
+@pytest.mark.parametrize("fmt_name", ["CS16", "CF32", "CF64", "CS8"])
+def test_convert_pack_in_one_launch_equals_the_two_steps_and_the_oracle(orc, fmt_name):
+    """writeStream's conversion loop (CaribouliteStream.cpp:199-244) + caribou_smi_generate_data (caribou_smi.c:684-717) in one
+    launch: the same bytes as clhip_convert_to_cs16 -> clhip_smi_pack and as the oracle, ragged lengths, both pack modes,
+    an output that is only 4-byte aligned; float inputs include the values the x86 truncating conversion wraps."""
+    import torch
+    from cariboulite_amd import hip
+    rng = np.random.default_rng(21)
+    fmt = getattr(hip, "FORMAT_" + fmt_name)
+    for n in (1, 3, 4, 1023, 131072, 131075):
+        if fmt_name == "CS16":
+            host = rng.integers(-32768, 32768, (n, 2)).astype(np.int16); to16 = lambda a: a
+        elif fmt_name == "CF32":
+            host = ((rng.random((n, 2)) - 0.5) * 20).astype(np.float32); host[:: 97] = [[7.99, -8.0]]; to16 = orc.cf32_to_cs16
+        elif fmt_name == "CF64":
+            host = (rng.random((n, 2)) - 0.5) * 20; host[:: 89] = [[-8.0, 7.999999]]; to16 = orc.cf64_to_cs16
+        else:
+            host = rng.integers(-128, 128, (n, 2)).astype(np.int8); to16 = orc.cs8_to_cs16
+        d_in = torch.from_numpy(host.copy()).to("cuda:0")
+        for mode, mis in ((hip.TX_DOCUMENTED, 0), (hip.TX_AS_WRITTEN, 0), (hip.TX_DOCUMENTED, 4)):
+            raw = torch.full((4 * n + 64,), 0xEE, dtype=torch.uint8, device="cuda:0")
+            assert hip.lib().clhip_convert_pack(d_in.data_ptr(), fmt, n, mode, raw.data_ptr() + mis, hip.current_stream()) == 0
+            iq = torch.empty((n, 2), dtype=torch.int16, device="cuda:0")
+            two = torch.empty(4 * n, dtype=torch.uint8, device="cuda:0")
+            hip.convert_to_cs16(d_in, fmt, n, iq)
+            hip.smi_pack(mode, iq, n, two)
+            torch.cuda.synchronize()
+            got = raw.cpu().numpy()
+            assert (got[:mis] == 0xEE).all() and (got[mis + 4 * n:] == 0xEE).all()
+            assert np.array_equal(got[mis:mis + 4 * n], two.cpu().numpy())
+            assert np.array_equal(got[mis:mis + 4 * n], orc.generate_data(to16(host), mode))
+
+
+def test_take_i_rail():
+    import torch
+    from cariboulite_amd import hip
+    for n in (1, 255, 131072, 1 << 20):
+        x = torch.randn((n, 2), device="cuda:0")
+        m = torch.full((n + 4,), 7.0, device="cuda:0")
+        assert hip.lib().clhip_take_i_rail(x.data_ptr(), n, m.data_ptr(), hip.current_stream()) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(m[:n], x[:, 0]) and bool((m[n:] == 7.0).all())

@@ -62,3 +62,30 @@ for name, fmt, dt, width, args, bw in (
                      feed_gbps=2 * b.size / t_feed / 1e9, out_elems=got)
     sdr.close()
 print(json.dumps(res, indent=1))
+
+# TX: host samples in (writeStream, one MTU per call), host SMI bytes out (cl_smi_drain_bytes between the timed regions)
+tx = {}
+rng = np.random.default_rng(3)
+for name, fmt, mk, args in (
+        ("tx_cs16", S.SOAPY_SDR_CS16, lambda: rng.integers(-4096, 4096, (MTU, 2)).astype(np.int16), None),
+        ("tx_cf32", S.SOAPY_SDR_CF32, lambda: (rng.random((MTU, 2), dtype=np.float32) - 0.5), None),
+        ("tx_cf32_fm_rs_2_3", S.SOAPY_SDR_CF32, lambda: (rng.random((MTU, 2), dtype=np.float32) - 0.5) * 0.6, {"MOD": "FM:75000", "RESAMP": "2/3"})):
+    if os.environ.get("BENCH_SOAPY_ONLY") and name not in os.environ["BENCH_SOAPY_ONLY"].split(","):
+        continue
+    sdr = S.Device(dict(driver="Cariboulite", channel="S1G"))
+    st = sdr.setupStream(S.SOAPY_SDR_TX, fmt, args=args)
+    sdr.activateStream(st)
+    buf = mk()
+    t_write, calls = 0.0, 0
+    for rep in range(4):
+        t0 = time.perf_counter()
+        for k in range(32):
+            assert sdr.writeStream(st, [buf], MTU).ret == MTU
+        t1 = time.perf_counter()
+        sdr.drainSmiBytes()
+        if rep:
+            t_write += t1 - t0; calls += 32
+    tx[name] = dict(msps_in=calls * MTU / t_write / 1e6, ms_per_mtu_call=t_write / calls * 1e3)
+    sdr.close()
+if tx:
+    print(json.dumps(tx, indent=1))

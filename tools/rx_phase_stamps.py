@@ -8,7 +8,7 @@ import numpy as np, torch
 from cariboulite_amd import hip, synth
 dev = torch.device("cuda", 0)
 taps = np.load(os.path.join(ROOT, "tests", "golden", "taps.npz"))
-n = 1 << 28
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 28     # e.g. 4000000: one second of one stream, a one-round launch
 words = synth.torch_smi_words(n, dev, 0, 0)
 pipe = hip.RxPipe(1, 0, taps["fir64_c2"], taps["rs_3_2"], 3, 2, 0)
 out = torch.empty((pipe.out_count(n), 2), dtype=torch.float32, device=dev)
@@ -29,4 +29,5 @@ for i, nme in enumerate(names):
 dt = (d[:, 7].astype(np.uint64) >> np.uint64(32)).astype(np.float64)
 dr = (d[:, 7].astype(np.uint64) & np.uint64(0xffffffff)).astype(np.float64)
 clk = dt / np.maximum(dr, 1) * 100e6
-print("in-kernel shader clock (median over waves): %.3f GHz   wave lifetime median %.1f us" % (np.median(clk) / 1e9, np.median(dr) / 100.0))
+print("in-kernel shader clock (median over waves): %.3f GHz   wave lifetime median %.1f us (p10 %.1f, p90 %.1f, max %.1f)" % (np.median(clk) / 1e9, np.median(dr) / 100.0, np.percentile(dr, 10) / 100.0, np.percentile(dr, 90) / 100.0, dr.max() / 100.0))
+print("stamped phases per tile: %.1f us at that clock" % (tot / d[:, 6].sum() / np.median(clk) * 1e6))
