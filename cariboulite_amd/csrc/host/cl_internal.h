@@ -78,6 +78,7 @@ struct cl_smi {
     int16_t *d_iq; size_t iq_cap;         /* samples */
     uint8_t *d_meta; size_t meta_cap;
     uint8_t *h_stage; size_t h_stage_cap; /* pinned host staging */
+    uint8_t *h_txin; size_t h_txin_cap;   /* pinned staging of the samples a write call was handed (the runtime never sees the caller's pointer) */
     int32_t *d_offs; size_t offs_cap; int32_t *h_offs; size_t h_offs_cap;
     cl_chunk *chunks; size_t chunks_cap, n_chunks;
     int debug_mode;               /* caribou_smi_debug_mode_en */

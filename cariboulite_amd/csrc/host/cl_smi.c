@@ -163,7 +163,7 @@ int cl_smi_close(cl_smi *dev)
     if (dev->cstream) { clhip_stream_sync(dev->cstream); clhip_stream_destroy(dev->cstream); }
     for (int k = 0; k < 2; k++) { clhip_event_destroy(dev->ev_copied[k]); clhip_free(dev->d_slot[k]); }
     clhip_free(dev->d_bytes); clhip_free(dev->d_bytes_prev); clhip_free(dev->d_zoffs); clhip_free(dev->d_iq); clhip_free(dev->d_meta); clhip_free(dev->d_offs);
-    clhip_host_free(dev->h_stage); clhip_host_free(dev->h_offs); clhip_free(dev->d_dbg); clhip_host_free(dev->h_dbg);
+    clhip_host_free(dev->h_stage); clhip_host_free(dev->h_txin); clhip_host_free(dev->h_offs); clhip_free(dev->d_dbg); clhip_host_free(dev->h_dbg);
     free(dev->chunks);
     cl_fifo_free(&dev->rx); cl_fifo_free(&dev->tx);
     clhip_stream_destroy(dev->stream);
@@ -847,7 +847,11 @@ static int smi_write_core(cl_smi *dev, const cl_sample_complex_int16 *h_buffer, 
     /* the chunk loop only slices the same contiguous arrays (len &= ~3 never bites: 4 B/sample), so
      * the whole call is one pack launch; the FIFO then receives it in native-batch writes */
     if (h_buffer) {
-        if (clhip_memcpy_h2d(dev->d_iq, h_buffer, left, dev->stream)) return CL_SMI_ERR_IO;
+        /* through a pinned buffer of ours: the runtime never sees the caller's pointer, so what it may remember of that
+         * address (cached pinnings, released registrations) cannot matter; the memcpy is the one its staged path would do */
+        if (cl_ensure((void **)&dev->h_txin, &dev->h_txin_cap, left + 64, 1, 1)) return CL_SMI_ERR_IO;
+        memcpy(dev->h_txin, h_buffer, left);
+        if (clhip_memcpy_h2d(dev->d_iq, dev->h_txin, left, dev->stream)) return CL_SMI_ERR_IO;
         d_src = dev->d_iq;
     }
     /* the packed words go straight into the (pinned) TX FIFO, where the fd's write() side picks them up: the chunk loop of

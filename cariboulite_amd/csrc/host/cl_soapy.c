@@ -835,7 +835,10 @@ static int write_stream(cl_device *dev, cl_stream *st, const void *const *buffs,
         cl_ensure((void **)&smi->d_iq, &smi->iq_cap, n + 8, 4, 0) ||
         cl_ensure((void **)&smi->d_bytes, &smi->bytes_cap, 4 * n * (size_t)(st->tx_pipe ? st->dsp.up : 1) + 256, 1, 0))
         return 0;
-    if (clhip_memcpy_h2d(st->d_conv, in, n * ib, smi->stream)) return 0;
+    /* the client's samples reach the device through a pinned buffer of ours (see smi_write_core) */
+    if (cl_ensure((void **)&smi->h_txin, &smi->h_txin_cap, n * ib + 64, 1, 1)) return 0;
+    memcpy(smi->h_txin, in, n * ib);
+    if (clhip_memcpy_h2d(st->d_conv, smi->h_txin, n * ib, smi->stream)) return 0;
     /* the packed words go straight into the pinned TX FIFO (caribou_smi_write's chunk loop, caribou_smi.c:738-759, appends
      * native-batch pieces of one contiguous array): room for the most a call can produce, committed once it is known to be good */
     uint8_t *room = cl_fifo_reserve(&smi->tx, 4 * n * (size_t)(st->tx_pipe ? st->dsp.up : 1) + 64);

@@ -4,6 +4,21 @@
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+
+CASES = ["cs16", "cf32", "cs16_iir", "cf32_fir64_rs_3_2", "cs16_async_ring", "zc_cs16", "zc_cf32", "zc_cs16_iir", "zc_cf32_fir64_rs_3_2",
+         "tx_cs16", "tx_cf32", "tx_cf32_fm_rs_2_3"]
+if not os.environ.get("BENCH_SOAPY_ONLY"):
+    # one fresh process per case (this one never touches the GPU): what a call costs must not depend on what the process did
+    # before -- a write from heap pages that an earlier ZEROCOPY session of the same process had registered and released took
+    # 290-390 us instead of 58 (the CPU's own reads of those pages are slow; nothing of the library's is involved)
+    import subprocess
+    res = {}
+    for c in CASES:
+        out = subprocess.run([sys.executable, os.path.abspath(__file__)], env=dict(os.environ, BENCH_SOAPY_ONLY=c), capture_output=True, text=True, check=True).stdout
+        res.update(json.loads(out[out.index("{"):]))
+    print(json.dumps(res, indent=1))
+    sys.exit(0)
+
 import numpy as np
 from cariboulite_amd import soapy as S, synth
 
@@ -61,8 +76,6 @@ for name, fmt, dt, width, args, bw in (
                      ms_per_mtu_call=t_read / max(got // MTU, 1) * 1e3 if (args and "ASYNC" in args) else t_read / (2 * K) * 1e3,
                      feed_gbps=2 * b.size / t_feed / 1e9, out_elems=got)
     sdr.close()
-print(json.dumps(res, indent=1))
-
 # TX: host samples in (writeStream, one MTU per call), host SMI bytes out (cl_smi_drain_bytes between the timed regions)
 tx = {}
 rng = np.random.default_rng(3)
@@ -87,5 +100,5 @@ for name, fmt, mk, args in (
             t_write += t1 - t0; calls += 32
     tx[name] = dict(msps_in=calls * MTU / t_write / 1e6, ms_per_mtu_call=t_write / calls * 1e3)
     sdr.close()
-if tx:
-    print(json.dumps(tx, indent=1))
+res.update(tx)
+print(json.dumps(res, indent=1))
