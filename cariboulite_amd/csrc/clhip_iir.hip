@@ -1465,7 +1465,10 @@ extern "C" int clhip_iir_get_state(clhip_iir *f, double *h_state)
 // -1 = no single-pass shape for this filter (memory too long): the scan.
 static int iir_pick_shape(const clhip_iir *f, size_t n)
 {
-    static const size_t tiles_max[3] = {64, 2048, (size_t)-1};
+    // measured per size (tools/bench_iir.py, CLHIP_IIR_SEG forced; us per call at SEG 16 / 32 / 64): 2^16 11.6 / 12.1 / 14.9,
+    // 2^17 13.1 / 12.7 / 14.9, 2^18 16.2 / 14.4 / 15.5, 2^19 22.9 / 17.5 / 17.1, 2^20 34.9 / 24.3 / 20.5, 2^21 60 / 36.6 / 27.6:
+    // short segments pay only while the call is too small to give every CU a wave
+    static const size_t tiles_max[3] = {128, 256, (size_t)-1};
     const IirPlan &pl = f->pe->host;
     for (int i = 0; i < 3; i++) {
         if (!pl.rail[i].horizon) continue;
