@@ -1945,7 +1945,11 @@ extern "C" long clhip_tx_pipe_run(clhip_tx_pipe *p, int in_kind, const void *d_i
         }
         const double wt = p->w * (1.0 / TWO_PI);
         dim3 grid((unsigned)n_super, p->n_streams);
-        static const int tx_chain = getenv("CLHIP_TX_CHAIN") ? atoi(getenv("CLHIP_TX_CHAIN")) : 1;
+        // By size unless CLHIP_TX_CHAIN forces one: calls of up to 2^22 messages take the one-sub-block-per-workgroup kernel (3) --
+        // an MTU is 43 workgroups there and 6 superblocks of 8 sequential sub-blocks in the chain kernel: 7.4 us against 17
+        // (tools/bench_tx.py: 2^20 8.4 / 17.6, 2^21 10.9 / 18.2, 2^22 17.7 / 20.9, 2^23 30.5 / 25.9, 2^24 55 / 38) -- larger ones (1).
+        static const int tx_chain_env = getenv("CLHIP_TX_CHAIN") ? atoi(getenv("CLHIP_TX_CHAIN")) : -1;
+        const int tx_chain = tx_chain_env >= 0 ? tx_chain_env : ((size_t)nv * (size_t)p->n_streams <= ((size_t)1 << 22) ? 3 : 1);
         // 1 (default): single launch, superblocks of TXQ_NSUB sub-blocks, the look-back behind the first sub-block's
         // arithmetic (tx_fm_chain_kernel); 3: single launch, single read, one sub-block per workgroup (tx_fm_chain1_kernel:
         // measured slower); 4: single launch, summers + workers (tx_fm_roles_kernel: measured equal at best -- 0.249 ms with

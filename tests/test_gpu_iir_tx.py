@@ -685,3 +685,51 @@ def test_two_large_iir_launches_share_the_gpu(G, orc):
     for o, want in zip(outs, wants):
         diff = np.abs(o.cpu().numpy().astype(np.int32) - want.astype(np.int32))
         assert diff.max() <= 1 and np.mean(diff != 0) < 1e-4, (diff.max(), np.mean(diff != 0))
+
+
+def test_tx_pipe_calls_on_either_side_of_the_kernel_choice_equal_one_shot(G, orc):
+    """clhip_tx_pipe_run picks its kernel by the call's size (up to 2^22 messages: one sub-block per workgroup; above: superblocks
+    of eight).  One pipe fed calls on either side of that line, in turn, gives the SMI words of one call over the whole message
+    (and of a pipe held to either kernel by the A/B switch: the suite runs under CLHIP_TX_CHAIN=1 and =3 too) -- phase,
+    resampler history and polyphase phase are one state whatever kernel wrote it."""
+    import torch
+    from cariboulite_amd import hip
+    t = load_golden("taps.npz")
+    sizes = [5_000_000, 131_072, 4_500_000, 1_000, (1 << 22) + 1, 1 << 22]
+    n = sum(sizes)
+    g = torch.Generator(device=G.DEV); g.manual_seed(77)
+    msg = torch.randn(n, device=G.DEV, generator=g) * 0.35
+    one = hip.TxPipe(1, 75e3, 4e6, t["rs_2_3"], 2, 3, hip.TX_DOCUMENTED)
+    k = one.out_count(n)
+    want = torch.zeros(4 * k, dtype=torch.uint8, device=G.DEV)
+    assert one.run(hip.TXPIPE_IN_FM_MESSAGE, msg, 0, n, want, 4 * k) == k
+    torch.cuda.synchronize()
+    assert one.status() == 0
+    p = hip.TxPipe(1, 75e3, 4e6, t["rs_2_3"], 2, 3, hip.TX_DOCUMENTED)
+    got, pos = [], 0
+    for cn in sizes:
+        kc = p.out_count(cn)
+        by = torch.zeros(4 * max(kc, 1), dtype=torch.uint8, device=G.DEV)
+        assert p.run(hip.TXPIPE_IN_FM_MESSAGE, msg[pos:], 0, cn, by, 4 * max(kc, 1)) == kc
+        torch.cuda.synchronize()
+        assert p.status() == 0
+        got.append(by[:4 * kc]); pos += cn
+    got = torch.cat(got)
+    assert got.numel() == want.numel()
+
+    def iq(b):          # documented TX layout (caribou_smi.c:693-696) -> signed 13-bit (i, q)
+        b = b.view(-1, 4).to(torch.int32)
+        i13 = ((b[:, 0] & 0x1F) << 8) | ((b[:, 1] & 0x7F) << 1) | ((b[:, 2] >> 6) & 1)
+        q13 = ((b[:, 2] & 0x3F) << 7) | (b[:, 3] & 0x7F)
+        sx = lambda v: ((v + 4096) & 0x1FFF) - 4096
+        return torch.stack([sx(i13), sx(q13)], 1)
+
+    # the frame bits are the same words; the samples agree to the quantiser's last bit: two calls that cut the message at
+    # different places round the fp64 phase scan differently (1e-16 turns), and an (int16)(f * 4096) now and then falls on the
+    # other side of an integer -- the bar of the float stages (1e-5 relative) is five orders of magnitude above that
+    a, b = iq(got), iq(want)
+    d = (a - b).abs()
+    d = torch.minimum(d, 8192 - d)       # 13-bit words: a unit phasor's 4096 and 4095 sit on either side of the wrap
+    assert int(d.max()) <= 1, int(d.max())
+    assert float((d != 0).float().mean()) < 1e-4, float((d != 0).float().mean())
+    assert torch.equal(got.view(-1, 4)[:, 0] & 0xE0, want.view(-1, 4)[:, 0] & 0xE0)
