@@ -93,9 +93,12 @@ struct PipeArgs {
     int chunk_shift;             // log2(samples per chunk): chunks are a power of two (native = 2^17)
     long chunks_per_stream;
     int32_t *bad_flag;           // set to 1 when a needed chunk has offs != 0 (tile writes nothing)
-    // dynamic tile queue of the persistent interior workers: queue[0] = items handed out beyond the
-    // first grid_int, queue[1] = workers that have left; the last one out zeroes both for the next launch
-    unsigned int *queue;
+    // dynamic tile queue of the persistent interior workers: queue[0] = tickets drawn.  Two counters take turns between
+    // the launches of a pipe; a launch's first worker zeroes the one the next launch will use (an exit count that the last
+    // worker out reset had every worker of the grid end on a same-address atomic: ~12 ns each, one after the other)
+    unsigned int *queue;         // base of the workers' idle words (RX_QUEUE_IDLE ...)
+    unsigned int *tickets;       // this launch's ticket counter
+    unsigned int *queue_next;    // the counter the pipe's NEXT launch will draw from: zeroed by this launch's first worker
     int queue_k;                 // items per grab; 0 = static striding
 #if CLHIP_RX_BOUNDS
     const void *b_in_lo, *b_in_hi, *b_out_lo, *b_out_hi;       // extent of the call's input and output buffers (diagnostic build)
@@ -819,12 +822,13 @@ void rx_pipe_fused_kernel(const PipeArgs a)
         // started 12 us late, which is what a one-round launch -- one second of one stream -- mostly consisted of).
         // Tickets number the chunks behind those: [dyn0 + K * ticket, + K).
         if (K > 0) nb_base = a.grid_int + K * item;
+        if (K > 0 && item == 0 && threadIdx.x == 0) __atomic_store_n(a.queue_next, 0u, __ATOMIC_RELAXED);   // (the next launch starts behind this one's end)
         const int s0 = item / per_stream, tile0 = 1 + item % per_stream;
         const void *in0 = KIND == CL_PIPE_IN_CF32 ? (const void *)((const f32x2 *)a.in + (long)s0 * a.in_stride)
                                                  : (const void *)((const uint32_t *)a.in + (long)s0 * a.in_stride);
         tile_issue_loads<C, KIND>(a, regs, in0, (long)tile0 * C::TILE_IN - C::HALO, threadIdx.x);
         unsigned int g0 = 0;
-        if (K > 0 && threadIdx.x == 0) g0 = rx_queue_grab(a.queue);
+        if (K > 0 && threadIdx.x == 0) g0 = rx_queue_grab(a.tickets);
         // the first tile's words are waited for here (once per worker), so that no path into the loop carries
         // pending loads: the staging at the loop top then needs no vmcnt wait at all (see the note after the FIR)
 #pragma unroll
@@ -872,7 +876,7 @@ void rx_pipe_fused_kernel(const PipeArgs a)
         unsigned int grabbed = 0;
         if (K > 0 && threadIdx.x == 0) {
             const int wk = (int)blockIdx.x - n_edge_wg;
-            unsigned int *slot = want_grab ? a.queue : a.queue + RX_QUEUE_IDLE + 16 * (wk & (RX_QUEUE_MAX_WORKERS - 1));
+            unsigned int *slot = want_grab ? a.tickets : a.queue + RX_QUEUE_IDLE + 16 * (wk & (RX_QUEUE_MAX_WORKERS - 1));
             grabbed = rx_queue_grab(slot, want_grab ? 1u : 0u);
         }
         if (next < items) {                                  // prefetch the next item's raw words
@@ -921,11 +925,6 @@ void rx_pipe_fused_kernel(const PipeArgs a)
             d_store += ts5 - ts4; d_bar2 += ts6 - ts5; d_tiles += 1;
         }
         item = next;
-    }
-    // every grab of this worker has returned; the last worker out re-arms the queue for the next launch
-    if (K > 0 && threadIdx.x == 0 && atomicAdd(a.queue + 1, 1u) == (unsigned)a.grid_int - 1u) {
-        __atomic_store_n(a.queue, 0u, __ATOMIC_RELAXED);
-        __atomic_store_n(a.queue + 1, 0u, __ATOMIC_RELEASE);
     }
     if constexpr (DIAG) {
         if (a.diag && (threadIdx.x & 63) == 0) {
@@ -1117,7 +1116,8 @@ struct clhip_rx_pipe {
     float *d_ffa, *d_ffa_int;          // [H0 | H1 | H0+H1] for the 2-parallel fast FIR, same two scalings
     bool ffa;                          // the selected fused instantiation uses them
     unsigned long long *diag;          // optional stamp buffer (diagnostic kernel build)
-    unsigned int *queue;               // tile queue of the fused kernel: {next item, workers done}, zero between launches
+    unsigned int *queue;               // tile queue of the fused kernel: two ticket counters that take turns between launches + the workers' idle words
+    int queue_parity;                  // which counter the next launch that draws tickets uses (the launch before it zeroed that one)
     f32x2 *X, *Y;
     size_t x_cap, y_cap;           // elements per stream
 };
@@ -1183,9 +1183,9 @@ extern "C" clhip_rx_pipe *clhip_rx_pipe_create(int n_streams, int channel, const
     p->d_fir = (float *)clhip_malloc(sizeof(float) * PIPE_MAX_FIR);
     p->d_fir_int = (float *)clhip_malloc(sizeof(float) * PIPE_MAX_FIR);
     p->d_rs = (float *)clhip_malloc(sizeof(float) * PIPE_MAX_RS);
-    p->queue = (unsigned int *)clhip_malloc(RX_QUEUE_WORDS * sizeof(unsigned int));
+    p->queue = (unsigned int *)clhip_malloc((RX_QUEUE_WORDS + 64) * sizeof(unsigned int));   // + the second ticket counter, 256 bytes behind
     if (!p->d_fir || !p->d_fir_int || !p->d_rs || !p->queue) { clhip_rx_pipe_destroy(p); return nullptr; }
-    (void)hipMemset(p->queue, 0, RX_QUEUE_WORDS * sizeof(unsigned int));
+    (void)hipMemset(p->queue, 0, (RX_QUEUE_WORDS + 64) * sizeof(unsigned int));
     float scaled[PIPE_MAX_FIR];
     for (int k = 0; k < PIPE_MAX_FIR; k++) scaled[k] = p->fir[k] / 4096.0f;   // exact: power of two
     (void)hipMemcpy(p->d_fir, p->fir, sizeof(float) * PIPE_MAX_FIR, hipMemcpyHostToDevice);
@@ -1398,6 +1398,7 @@ extern "C" long clhip_rx_pipe_run(clhip_rx_pipe *p, int in_kind, const void *d_i
     a.n_in = (long)n_in; a.n_out = (long)n_out;
     a.in_kind = in_kind; a.channel = p->channel; a.n_streams = p->n_streams;
     a.halo = p->halo; a.hist_out = p->hist[p->cur ^ 1]; a.diag = p->diag; a.queue = p->queue;
+    a.tickets = p->queue + (p->queue_parity ? RX_QUEUE_WORDS : 0); a.queue_next = p->queue + (p->queue_parity ? 0 : RX_QUEUE_WORDS);
     static const int queue_k = getenv("CLHIP_QUEUE_K") ? atoi(getenv("CLHIP_QUEUE_K")) : 2;
     a.queue_k = queue_k;
     a.in_scale = in_kind == CL_PIPE_IN_CF32 ? 1.0f : 4096.0f;
@@ -1443,6 +1444,7 @@ extern "C" long clhip_rx_pipe_run(clhip_rx_pipe *p, int in_kind, const void *d_i
         case 10: rc = ffa ? launch_fused<CfgS54f>(a, s) : launch_fused<CfgS54>(a, s); break;
         }
         if (rc) return -1;
+        if (a.queue_k > 0) p->queue_parity ^= 1;              // (a launch with one tile per worker draws no tickets: launch_pipe)
     } else {
         if (ensure_ws(p, n_in)) return -1;
         const unsigned gx = (unsigned)(clhip_div_up(p->halo + n_in, 256) > 4096 ? 4096 : clhip_div_up(p->halo + n_in, 256));
