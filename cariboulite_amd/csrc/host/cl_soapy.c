@@ -473,12 +473,20 @@ static const int16_t *filter_native(cl_stream *st, const int16_t *d_raw, size_t 
  *                   58 / 91 / 65 us -- above 1 MiB the runtime pins the target in place instead of bouncing it, which
  *                   is why this WAS the route for outputs larger than that (now only with CL_READ_STAGED=1);
  *   CL_SINK_BOUNCE  a device buffer, copied by the copy engine into the stream's pinned mirror before the synchronisation
- *                   and from there by memcpy: the route for outputs above 1 MiB.  (Round 3's first form handed the client's
+ *                   and from there by memcpy: the route for outputs above the mirror route's limit -- 1 MiB until the end of
+ *                   round 3, when FIR64 + 3/2 (1.5 MiB) was measured on both: 127-130 us here, 116-117 through the mapped
+ *                   mirror; the limit is 4 MiB now (CL_MIRROR_MAX_KB), above every MTU-sized output.  (Round 3's first form handed the client's
  *                   pageable buffer to the runtime -- CL_SINK_STAGED -- which pins such a target in place from 1 MiB up:
  *                   77-81 us for FIR64 + 3/2 against 120 here, and the mechanism behind the GPU page faults on host heap
  *                   addresses of DESIGN.md section 7.  Whoever wants the copy engine in his own buffers says so: ZEROCOPY=1.) */
 enum { CL_SINK_CLIENT, CL_SINK_MIRROR, CL_SINK_STAGED, CL_SINK_BOUNCE };
-#define CL_MIRROR_MAX_BYTES ((size_t)1 << 20)
+static size_t mirror_max_bytes(void)
+{
+    static size_t v;                                               /* A/B: CL_MIRROR_MAX_KB (default below) */
+    if (!v) v = getenv("CL_MIRROR_MAX_KB") ? (size_t)atol(getenv("CL_MIRROR_MAX_KB")) << 10 : (size_t)4 << 20;
+    return v;
+}
+#define CL_MIRROR_MAX_BYTES mirror_max_bytes()
 typedef struct { int kind; void *d_dst; void *bounce; } cl_sink;
 
 static void *mirror_for(cl_stream *st, size_t bytes)
