@@ -59,6 +59,22 @@ int cl_fifo_push(cl_fifo *f, const uint8_t *src, size_t n)
     return 0;
 }
 
+/* the address kernels use for a byte of a pinned FIFO's buffer (NULL: not pinned, or the device cannot reach it) */
+void *cl_fifo_device_ptr(const cl_fifo *f, const uint8_t *at)
+{
+    if (!f->pinned || !f->data) return NULL;
+    uint8_t *d = (uint8_t *)clhip_host_device_ptr(f->data);
+    return d ? d + (at - f->data) : NULL;
+}
+
+/* A/B: CL_WRITE_MAPPED_KB = largest write call (bytes in) whose kernel reads pinned samples and stores into pinned room itself */
+size_t cl_write_mapped_max(void)
+{
+    static size_t v = (size_t)-1;
+    if (v == (size_t)-1) v = getenv("CL_WRITE_MAPPED_KB") ? (size_t)atol(getenv("CL_WRITE_MAPPED_KB")) << 10 : (size_t)2 << 20;
+    return v;
+}
+
 size_t cl_fifo_pop(cl_fifo *f, uint8_t *dst, size_t n)
 {
     size_t done = 0;
@@ -846,20 +862,29 @@ static int smi_write_core(cl_smi *dev, const cl_sample_complex_int16 *h_buffer, 
         return CL_SMI_ERR_IO;
     /* the chunk loop only slices the same contiguous arrays (len &= ~3 never bites: 4 B/sample), so
      * the whole call is one pack launch; the FIFO then receives it in native-batch writes */
+    /* the packed words go straight into the (pinned) TX FIFO, where the fd's write() side picks them up: the chunk loop of
+     * caribou_smi.c:738-759 appends native-batch pieces of one contiguous array one after the other, i.e. the array */
+    uint8_t *room = cl_fifo_reserve(&dev->tx, left);
+    if (!room) return CL_SMI_ERR_IO;
+    void *d_room = left <= cl_write_mapped_max() ? cl_fifo_device_ptr(&dev->tx, room) : NULL;
     if (h_buffer) {
         /* through a pinned buffer of ours: the runtime never sees the caller's pointer, so what it may remember of that
          * address (cached pinnings, released registrations) cannot matter; the memcpy is the one its staged path would do */
         if (cl_ensure((void **)&dev->h_txin, &dev->h_txin_cap, left + 64, 1, 1)) return CL_SMI_ERR_IO;
         memcpy(dev->h_txin, h_buffer, left);
-        if (clhip_memcpy_h2d(dev->d_iq, dev->h_txin, left, dev->stream)) return CL_SMI_ERR_IO;
-        d_src = dev->d_iq;
+        /* up to a few native batches the pack kernel itself reads the pinned samples and stores into the FIFO's room across
+         * PCIe: one launch and one synchronisation, no copy-engine call on either side (cl_write_mapped_max: A/B) */
+        void *d_in = d_room ? clhip_host_device_ptr(dev->h_txin) : NULL;
+        if (d_in) d_src = (const int16_t *)d_in;
+        else {
+            if (clhip_memcpy_h2d(dev->d_iq, dev->h_txin, left, dev->stream)) return CL_SMI_ERR_IO;
+            d_src = dev->d_iq;
+        }
     }
-    /* the packed words go straight into the (pinned) TX FIFO, where the fd's write() side picks them up: the chunk loop of
-     * caribou_smi.c:738-759 appends native-batch pieces of one contiguous array one after the other, i.e. the array */
-    uint8_t *room = cl_fifo_reserve(&dev->tx, left);
-    if (!room) return CL_SMI_ERR_IO;
-    if (clhip_smi_pack(dev->tx_mode, d_src, length_samples, dev->d_bytes, dev->stream) ||
-        clhip_memcpy_d2h(room, dev->d_bytes, left, dev->stream) || clhip_stream_sync(dev->stream))
+    if (d_room) {
+        if (clhip_smi_pack(dev->tx_mode, d_src, length_samples, (uint8_t *)d_room, dev->stream) || clhip_stream_sync(dev->stream)) return CL_SMI_ERR_IO;
+    } else if (clhip_smi_pack(dev->tx_mode, d_src, length_samples, dev->d_bytes, dev->stream) ||
+               clhip_memcpy_d2h(room, dev->d_bytes, left, dev->stream) || clhip_stream_sync(dev->stream))
         return CL_SMI_ERR_IO;
     cl_fifo_commit(&dev->tx, left);                             /* len &= ~3 (:745) never bites: 4 bytes per sample */
     written_so_far = left / CL_BYTES_PER_SAMPLE;                /* :757 */

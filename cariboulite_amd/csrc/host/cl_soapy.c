@@ -846,11 +846,20 @@ static int write_stream(cl_device *dev, cl_stream *st, const void *const *buffs,
     /* the client's samples reach the device through a pinned buffer of ours (see smi_write_core) */
     if (cl_ensure((void **)&smi->h_txin, &smi->h_txin_cap, n * ib + 64, 1, 1)) return 0;
     memcpy(smi->h_txin, in, n * ib);
-    if (clhip_memcpy_h2d(st->d_conv, smi->h_txin, n * ib, smi->stream)) return 0;
     /* the packed words go straight into the pinned TX FIFO (caribou_smi_write's chunk loop, caribou_smi.c:738-759, appends
      * native-batch pieces of one contiguous array): room for the most a call can produce, committed once it is known to be good */
     uint8_t *room = cl_fifo_reserve(&smi->tx, 4 * n * (size_t)(st->tx_pipe ? st->dsp.up : 1) + 64);
     if (!room) return 0;
+    /* MTU-sized calls: the first kernel reads the pinned samples and the last one stores into the FIFO's room across PCIe
+     * themselves -- no copy-engine call on either side (cl_write_mapped_max: A/B).  Not for a pipe fed CF32: its kernel reads
+     * every input several times. */
+    const void *d_in = n * ib <= cl_write_mapped_max() && !(st->tx_pipe && !st->dsp.mod_fm) ? clhip_host_device_ptr(smi->h_txin) : NULL;
+    uint8_t *d_room = d_in ? (uint8_t *)cl_fifo_device_ptr(&smi->tx, room) : NULL;
+    if (!d_room) {
+        d_in = st->d_conv;
+        if (clhip_memcpy_h2d(st->d_conv, smi->h_txin, n * ib, smi->stream)) return 0;
+    }
+    uint8_t *d_words = d_room ? d_room : smi->d_bytes;
     size_t n_packed = n;
     /* a modulator call whose look-back gave up (dispatch-order mode) has put the pipe back where it was and switched it
      * to ticket order: the call is simply made again, once */
@@ -862,17 +871,17 @@ static int write_stream(cl_device *dev, cl_stream *st, const void *const *buffs,
             if (st->dsp.mod_fm) {
                 /* the I rail as a dense message, taken on the device behind the samples (d_conv holds 16 bytes per element) */
                 float *d_msg = (float *)st->d_conv + 2 * n;
-                if (clhip_take_i_rail((const float *)st->d_conv, n, d_msg, smi->stream)) return 0;
-                got = clhip_tx_pipe_run(st->tx_pipe, CL_TXPIPE_IN_FM_MESSAGE, d_msg, 0, n, smi->d_bytes, 0, NULL, 0, smi->stream);
+                if (clhip_take_i_rail((const float *)d_in, n, d_msg, smi->stream)) return 0;
+                got = clhip_tx_pipe_run(st->tx_pipe, CL_TXPIPE_IN_FM_MESSAGE, d_msg, 0, n, d_words, 0, NULL, 0, smi->stream);
             } else
-                got = clhip_tx_pipe_run(st->tx_pipe, CL_TXPIPE_IN_CF32, st->d_conv, 0, n, smi->d_bytes, 0, NULL, 0, smi->stream);
+                got = clhip_tx_pipe_run(st->tx_pipe, CL_TXPIPE_IN_CF32, d_in, 0, n, d_words, 0, NULL, 0, smi->stream);
             if (got < 0) return 0;
             n_packed = (size_t)got;
         } else {
             /* :199-244 and caribou_smi.c:684-717 on the same sample, one launch */
-            if (clhip_convert_pack(st->d_conv, st->format, n, smi->tx_mode, smi->d_bytes, smi->stream)) return 0;
+            if (clhip_convert_pack(d_in, st->format, n, smi->tx_mode, d_words, smi->stream)) return 0;
         }
-        if (n_packed && (clhip_memcpy_d2h(room, smi->d_bytes, 4 * n_packed, smi->stream) || clhip_stream_sync(smi->stream))) return 0;
+        if (n_packed && ((!d_room && clhip_memcpy_d2h(room, smi->d_bytes, 4 * n_packed, smi->stream)) || clhip_stream_sync(smi->stream))) return 0;
         /* the modulator's verdict on this very call: invalid words never reach the fd (squashed to 0 like every
          * write error, CaribouliteStream.cpp:185-194) */
         if (!st->tx_pipe || clhip_tx_pipe_status(st->tx_pipe) == 0) break;
