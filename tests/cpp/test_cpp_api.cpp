@@ -76,10 +76,21 @@ int main()
         s1g.SetSibling(&hif); hif.SetSibling(&s1g);
         std::mutex mx; std::vector<std::complex<float>> got; std::vector<uint8_t> gmeta; size_t calls = 0;
         auto b = make_stream(3 * 4096, 1, 11);
-        hif.StartReceiving([&](CaribouLiteRadio *, const std::complex<float> *d, CaribouLiteMeta *m, size_t n) {
+        // with the pps tags on: inside the callback GetSyncTags() describes the chunk being handed over -- the positions the
+        // GNU Radio source's loop over `m` would find (caribouLiteSource_impl.cc:113-119)
+        hif.EnableSyncTags(true);
+        bool tags_ok = true; size_t tags_seen = 0;
+        hif.StartReceiving([&](CaribouLiteRadio *r, const std::complex<float> *d, CaribouLiteMeta *m, size_t n) {
             std::lock_guard<std::mutex> g(mx);
             got.insert(got.end(), d, d + n);
             for (size_t k = 0; k < n; k++) gmeta.push_back(m[k].sync);
+            const uint32_t *at = NULL;
+            const size_t nt = r->GetSyncTags(&at);
+            size_t j = 0;
+            for (size_t k = 0; k < n; k++)
+                if (m[k].sync == 1) { if (j >= nt || at[j] != k) tags_ok = false; j++; }
+            if (j != nt) tags_ok = false;
+            tags_seen += nt;
             calls++;
         }, 4096);
         cl_smi_feed_bytes(smi, b.data(), b.size());
@@ -90,6 +101,7 @@ int main()
         hif.StopReceiving();
         std::lock_guard<std::mutex> g(mx);
         CHECK(got.size() == 3 * 4096 && calls == 3);
+        CHECK(tags_ok && tags_seen > 3 * 4096 / 4);                     // (the test stream's sync bit is random: about half the samples)
         std::vector<int16_t> want(2 * (3 * 4096 + 2)); std::vector<uint8_t> wmeta(3 * 4096 + 2);
         CHECK(orc_rx_data_analyze(1, b.data(), b.size(), want.data(), wmeta.data()) == 0);
         std::vector<float> wf(2 * 3 * 4096);
