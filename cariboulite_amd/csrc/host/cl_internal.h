@@ -39,6 +39,8 @@ void   cl_fifo_commit(cl_fifo *f, size_t n);
 int    cl_fifo_push(cl_fifo *f, const uint8_t *src, size_t n);
 void  *cl_fifo_device_ptr(const cl_fifo *f, const uint8_t *at);   /* device address of a byte of a pinned FIFO's buffer, or NULL */
 size_t cl_write_mapped_max(void);
+uint8_t *cl_smi_tx_reserve(struct cl_smi *dev, size_t n);           /* TX FIFO: producer side, under fifo_mu */
+void   cl_smi_tx_commit(struct cl_smi *dev, size_t n);
 size_t cl_fifo_pop(cl_fifo *f, uint8_t *dst, size_t n);      /* consume with a copy (front stash first); dst may be NULL (discard) */
 size_t cl_fifo_stage(cl_fifo *f, size_t n, uint8_t **where); /* take up to n bytes IN PLACE: they stay owned until confirmed */
 void   cl_fifo_confirm(cl_fifo *f, size_t n);                /* the oldest n staged bytes are consumed for good */

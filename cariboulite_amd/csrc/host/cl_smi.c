@@ -235,7 +235,30 @@ int cl_smi_wait_bytes(cl_smi *dev, long timeout_us)
 }
 size_t cl_smi_pending_bytes(const cl_smi *dev) { return cl_fifo_pending(&dev->rx) + (dev->ahead.valid ? dev->ahead.len : 0); }   /* staged ahead = still pending */
 void   cl_smi_set_max_read(cl_smi *dev, size_t m) { dev->max_read = m; }
-size_t cl_smi_drain_bytes(cl_smi *dev, uint8_t *b, size_t max) { return cl_fifo_pop(&dev->tx, b, max); }
+/* The TX FIFO has one producer (the write calls: reserve, fill by DMA or kernel, commit) and one consumer (the drain calls),
+ * which may be two threads: its bookkeeping moves under fifo_mu; the bytes of an open reservation lie behind everything a pop
+ * can touch, and only the producer's reserve ever moves the buffer. */
+uint8_t *cl_smi_tx_reserve(cl_smi *dev, size_t n)
+{
+    pthread_mutex_lock(&dev->fifo_mu);
+    uint8_t *room = cl_fifo_reserve(&dev->tx, n);
+    pthread_mutex_unlock(&dev->fifo_mu);
+    return room;
+}
+void cl_smi_tx_commit(cl_smi *dev, size_t n)
+{
+    pthread_mutex_lock(&dev->fifo_mu);
+    cl_fifo_commit(&dev->tx, n);
+    pthread_mutex_unlock(&dev->fifo_mu);
+}
+static size_t tx_pop(cl_smi *dev, uint8_t *b, size_t max)
+{
+    pthread_mutex_lock(&dev->fifo_mu);
+    const size_t n = cl_fifo_pop(&dev->tx, b, max);
+    pthread_mutex_unlock(&dev->fifo_mu);
+    return n;
+}
+size_t cl_smi_drain_bytes(cl_smi *dev, uint8_t *b, size_t max) { return tx_pop(dev, b, max); }
 void   cl_smi_set_tx_mode(cl_smi *dev, int mode) { dev->tx_mode = mode; }
 size_t cl_smi_get_native_batch_samples(cl_smi *dev) { return dev->native_batch_len / CL_BYTES_PER_SAMPLE; }
 void   cl_smi_set_debug_mode(cl_smi *dev, int mode) { dev->debug_mode = mode; }       /* caribou_smi.c:612-615 */
@@ -358,7 +381,7 @@ long cl_smi_drain_to_fd(cl_smi *dev, int fd, size_t max_bytes)
     size_t total = 0;
     while (total < max_bytes) {
         size_t want = max_bytes - total < dev->native_batch_len ? max_bytes - total : dev->native_batch_len;
-        size_t got = cl_fifo_pop(&dev->tx, tmp, want);
+        size_t got = tx_pop(dev, tmp, want);
         if (!got) break;
         size_t off = 0;
         while (off < got) {
@@ -864,7 +887,7 @@ static int smi_write_core(cl_smi *dev, const cl_sample_complex_int16 *h_buffer, 
      * the whole call is one pack launch; the FIFO then receives it in native-batch writes */
     /* the packed words go straight into the (pinned) TX FIFO, where the fd's write() side picks them up: the chunk loop of
      * caribou_smi.c:738-759 appends native-batch pieces of one contiguous array one after the other, i.e. the array */
-    uint8_t *room = cl_fifo_reserve(&dev->tx, left);
+    uint8_t *room = cl_smi_tx_reserve(dev, left);
     if (!room) return CL_SMI_ERR_IO;
     void *d_room = left <= cl_write_mapped_max() ? cl_fifo_device_ptr(&dev->tx, room) : NULL;
     if (h_buffer) {
@@ -886,7 +909,7 @@ static int smi_write_core(cl_smi *dev, const cl_sample_complex_int16 *h_buffer, 
     } else if (clhip_smi_pack(dev->tx_mode, d_src, length_samples, dev->d_bytes, dev->stream) ||
                clhip_memcpy_d2h(room, dev->d_bytes, left, dev->stream) || clhip_stream_sync(dev->stream))
         return CL_SMI_ERR_IO;
-    cl_fifo_commit(&dev->tx, left);                             /* len &= ~3 (:745) never bites: 4 bytes per sample */
+    cl_smi_tx_commit(dev, left);                                /* len &= ~3 (:745) never bites: 4 bytes per sample */
     written_so_far = left / CL_BYTES_PER_SAMPLE;                /* :757 */
     dev->stat_written += written_so_far;
     return (int)written_so_far;

@@ -848,7 +848,7 @@ static int write_stream(cl_device *dev, cl_stream *st, const void *const *buffs,
     memcpy(smi->h_txin, in, n * ib);
     /* the packed words go straight into the pinned TX FIFO (caribou_smi_write's chunk loop, caribou_smi.c:738-759, appends
      * native-batch pieces of one contiguous array): room for the most a call can produce, committed once it is known to be good */
-    uint8_t *room = cl_fifo_reserve(&smi->tx, 4 * n * (size_t)(st->tx_pipe ? st->dsp.up : 1) + 64);
+    uint8_t *room = cl_smi_tx_reserve(smi, 4 * n * (size_t)(st->tx_pipe ? st->dsp.up : 1) + 64);
     if (!room) return 0;
     /* MTU-sized calls: the first kernel reads the pinned samples and the last one stores into the FIFO's room across PCIe
      * themselves -- no copy-engine call on either side (cl_write_mapped_max: A/B).  Not for a pipe fed CF32: its kernel reads
@@ -889,6 +889,6 @@ static int write_stream(cl_device *dev, cl_stream *st, const void *const *buffs,
         st->stats.tx_overruns++;
         if (attempt) return 0;
     }
-    cl_fifo_commit(&smi->tx, 4 * n_packed);
+    cl_smi_tx_commit(smi, 4 * n_packed);
     return (int)n;      /* elements consumed from the caller's buffer */
 }

@@ -842,3 +842,38 @@ def test_zero_copy_streams_deliver_what_the_default_route_delivers(S, orc):
         assert np.max(np.abs(out - want)) <= 1e-5 * np.max(np.abs(want))
     assert sdr.streamStats(rx)["zero_copy_reads"] == zc0 + 6
     sdr.close()
+
+
+def test_write_stream_with_a_concurrent_drainer(S, orc):
+    """One thread writes (writeStream packs on the GPU into reserved room of the pinned TX FIFO), another drains what has been
+    committed (cl_smi_drain_bytes, where the fd's write() side stands): the drained bytes, in order, are the oracle's pack of
+    everything written -- the FIFO grows and is emptied under the writer's open reservations many times."""
+    import threading
+    sdr = S.Device(dict(driver="Cariboulite", channel="S1G"))
+    tx = sdr.setupStream(S.SOAPY_SDR_TX, S.SOAPY_SDR_CS16)
+    sdr.activateStream(tx)
+    rng = np.random.default_rng(31)
+    calls = [rng.integers(-4096, 4096, (int(n), 2)).astype(np.int16) for n in rng.integers(1000, 131072, 120)]
+    total = 4 * sum(c.shape[0] for c in calls)
+    got, stop = [], threading.Event()
+
+    def drain():
+        n = 0
+        while n < total and not stop.is_set():
+            b = sdr.drainSmiBytes(1 << 20)
+            if b.size:
+                got.append(b); n += b.size
+
+    t = threading.Thread(target=drain)
+    t.start()
+    try:
+        for c in calls:
+            assert sdr.writeStream(tx, [c], c.shape[0]).ret == c.shape[0]
+    finally:
+        t.join(timeout=30)
+        stop.set()
+        t.join()
+    out = np.concatenate(got) if got else np.zeros(0, np.uint8)
+    assert out.size == total
+    assert np.array_equal(out, orc.generate_data(np.concatenate(calls), orc.TX_DOCUMENTED))
+    sdr.close()
