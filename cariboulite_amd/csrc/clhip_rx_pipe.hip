@@ -1399,8 +1399,13 @@ extern "C" long clhip_rx_pipe_run(clhip_rx_pipe *p, int in_kind, const void *d_i
     a.in_kind = in_kind; a.channel = p->channel; a.n_streams = p->n_streams;
     a.halo = p->halo; a.hist_out = p->hist[p->cur ^ 1]; a.diag = p->diag; a.queue = p->queue;
     a.tickets = p->queue + (p->queue_parity ? RX_QUEUE_WORDS : 0); a.queue_next = p->queue + (p->queue_parity ? 0 : RX_QUEUE_WORDS);
-    static const int queue_k = getenv("CLHIP_QUEUE_K") ? atoi(getenv("CLHIP_QUEUE_K")) : 2;
-    a.queue_k = queue_k;
+    // items per ticket: by the shape's tile rate.  Same-address device-scope atomics retire at ~12 ns each, and a ticket per
+    // tile is one atomic per 13.5 ns for config 2 (0.9 ms / 66 052 tiles) -- within the counter's rate, asked for a whole tile
+    // ahead: 1 against 2 on four boxes 0.8926 / 0.8966, 0.919 / 0.925, 0.8953 / 0.8988, 0.8950 / 0.8976 ms (every pair in that
+    // order), config 4 2.448 / 2.455 -- but one per 11.9 ns for config 3 (FM demod: 4 bytes out per sample, short tiles), past
+    // it: 0.8164 against 0.7790 ms.  So: one tile per ticket for the two resampling shapes that were measured, two otherwise.
+    static const int queue_k_env = getenv("CLHIP_QUEUE_K") ? atoi(getenv("CLHIP_QUEUE_K")) : -1;
+    a.queue_k = queue_k_env >= 0 ? queue_k_env : ((p->fused_id == 0 || p->fused_id == 2) ? 1 : 2);
     a.in_scale = in_kind == CL_PIPE_IN_CF32 ? 1.0f : 4096.0f;
     a.fir = in_kind == CL_PIPE_IN_CF32 ? p->d_fir : p->d_fir_int;
     const float *ffa_taps = in_kind == CL_PIPE_IN_CF32 ? p->d_ffa : p->d_ffa_int;
