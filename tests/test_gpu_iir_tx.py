@@ -725,11 +725,13 @@ def test_tx_pipe_calls_on_either_side_of_the_kernel_choice_equal_one_shot(G, orc
         return torch.stack([sx(i13), sx(q13)], 1)
 
     # the frame bits are the same words; the samples agree to the quantiser's last bit: two calls that cut the message at
-    # different places round the fp64 phase scan differently (1e-16 turns), and an (int16)(f * 4096) now and then falls on the
-    # other side of an integer -- the bar of the float stages (1e-5 relative) is five orders of magnitude above that
+    # different places round differently (the fp64 phase scan, the fp32 rotation of a sub-block into place), and an
+    # (int16)(f * 4096) now and then falls on the other side of an integer -- the bar of the float stages (1e-5 relative) is five orders of magnitude above that
     a, b = iq(got), iq(want)
     d = (a - b).abs()
     d = torch.minimum(d, 8192 - d)       # 13-bit words: a unit phasor's 4096 and 4095 sit on either side of the wrap
     assert int(d.max()) <= 1, int(d.max())
-    assert float((d != 0).float().mean()) < 1e-4, float((d != 0).float().mean())
+    # (how often: a sub-block worked relative to its own start is rotated into place in fp32, so where the calls cut the message
+    # moves 1e-7-sized roundings around: 3e-4 of the samples with the one-sub-block kernel on both sides, CLHIP_TX_CHAIN=3)
+    assert float((d != 0).float().mean()) < 1e-3, float((d != 0).float().mean())
     assert torch.equal(got.view(-1, 4)[:, 0] & 0xE0, want.view(-1, 4)[:, 0] & 0xE0)
