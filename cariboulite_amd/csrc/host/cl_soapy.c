@@ -353,7 +353,7 @@ cl_stream *cl_setupStream(cl_device *dev, int direction, const char *format, con
     clhip_stream_sync(dev->smi->stream);
     zc_drop_all(st);
     const char *zc = kw(keys, vals, n_kwargs, "ZEROCOPY");
-    st->zero_copy = zc && !strcmp(zc, "1");        /* RX: the last kernel stores into the client's buffers; TX: the first kernel reads them */
+    st->zero_copy = zc && !strcmp(zc, "1") && st->native_dir == CL_SOAPY_SDR_RX;
     const char *as = kw(keys, vals, n_kwargs, "ASYNC");
     if (as && !strcmp(as, "1") && st->native_dir == CL_SOAPY_SDR_RX) {
         /* rx_queue(mtu * NUM_NATIVE_MTUS_PER_QUEUE, override writes, blocking reads)  :70-75 */
@@ -832,11 +832,7 @@ static int write_stream(cl_device *dev, cl_stream *st, const void *const *buffs,
     clhip_set_device(smi->device);
     const void *in = buffs[0];
     if (st->format == CL_FORMAT_CS16) {                /* :182-196 */
-        /* ZEROCOPY=1: the pack kernel reads the client's registered buffer where it lies */
-        const void *d_client = numElems * 4 <= cl_write_mapped_max() ? client_device_addr(st, (void *)(uintptr_t)in, numElems * 4) : NULL;
-        if (d_client) st->stats.zero_copy_reads++;
-        int ret = d_client ? cl_radio_write_samples_device(dev->radio, (const int16_t *)d_client, numElems)
-                           : cl_radio_write_samples(dev->radio, (cl_sample_complex_int16 *)in, numElems);
+        int ret = cl_radio_write_samples(dev->radio, (cl_sample_complex_int16 *)in, numElems);
         if (ret < 0) { if (ret == -1) printf("Failed to write\n"); ret = 0; }
         return ret;
     }
@@ -847,14 +843,9 @@ static int write_stream(cl_device *dev, cl_stream *st, const void *const *buffs,
         cl_ensure((void **)&smi->d_iq, &smi->iq_cap, n + 8, 4, 0) ||
         cl_ensure((void **)&smi->d_bytes, &smi->bytes_cap, 4 * n * (size_t)(st->tx_pipe ? st->dsp.up : 1) + 256, 1, 0))
         return 0;
-    /* the client's samples reach the device through a pinned buffer of ours (see smi_write_core) -- or, with ZEROCOPY=1 (the
-     * client keeps the buffers it passes while the stream exists: they are registered with the GPU on first sight), the first
-     * kernel reads them where they lie */
-    const void *d_client = n * ib <= cl_write_mapped_max() && !(st->tx_pipe && !st->dsp.mod_fm) ? client_device_addr(st, (void *)(uintptr_t)in, n * ib) : NULL;
-    if (!d_client) {
-        if (cl_ensure((void **)&smi->h_txin, &smi->h_txin_cap, n * ib + 64, 1, 1)) return 0;
-        memcpy(smi->h_txin, in, n * ib);
-    }
+    /* the client's samples reach the device through a pinned buffer of ours (see smi_write_core) */
+    if (cl_ensure((void **)&smi->h_txin, &smi->h_txin_cap, n * ib + 64, 1, 1)) return 0;
+    memcpy(smi->h_txin, in, n * ib);
     /* the packed words go straight into the pinned TX FIFO (caribou_smi_write's chunk loop, caribou_smi.c:738-759, appends
      * native-batch pieces of one contiguous array): room for the most a call can produce, committed once it is known to be good */
     uint8_t *room = cl_smi_tx_reserve(smi, 4 * n * (size_t)(st->tx_pipe ? st->dsp.up : 1) + 64);
@@ -862,17 +853,12 @@ static int write_stream(cl_device *dev, cl_stream *st, const void *const *buffs,
     /* MTU-sized calls: the first kernel reads the pinned samples and the last one stores into the FIFO's room across PCIe
      * themselves -- no copy-engine call on either side (cl_write_mapped_max: A/B).  Not for a pipe fed CF32: its kernel reads
      * every input several times. */
-    const void *d_in = d_client ? d_client : (n * ib <= cl_write_mapped_max() && !(st->tx_pipe && !st->dsp.mod_fm) ? clhip_host_device_ptr(smi->h_txin) : NULL);
+    const void *d_in = n * ib <= cl_write_mapped_max() && !(st->tx_pipe && !st->dsp.mod_fm) ? clhip_host_device_ptr(smi->h_txin) : NULL;
     uint8_t *d_room = d_in ? (uint8_t *)cl_fifo_device_ptr(&smi->tx, room) : NULL;
     if (!d_room) {
-        if (d_client) {                                            /* (no mapped room: take the copying route from our own pinned buffer) */
-            if (cl_ensure((void **)&smi->h_txin, &smi->h_txin_cap, n * ib + 64, 1, 1)) return 0;
-            memcpy(smi->h_txin, in, n * ib);
-        }
         d_in = st->d_conv;
         if (clhip_memcpy_h2d(st->d_conv, smi->h_txin, n * ib, smi->stream)) return 0;
     }
-    if (d_client && d_room) st->stats.zero_copy_reads++;          /* (counted with the reads: calls whose client buffer the GPU touched itself) */
     uint8_t *d_words = d_room ? d_room : smi->d_bytes;
     size_t n_packed = n;
     /* a modulator call whose look-back gave up (dispatch-order mode) has put the pipe back where it was and switched it

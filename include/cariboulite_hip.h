@@ -483,9 +483,9 @@ const char *cl_getNativeStreamFormat(const cl_device *dev, int direction, size_t
 /* setupStream :100-139 -- NULL + cl_device_last_error() where the reference throws.
  * Extension kwargs (SURVEY.md section 5 "Config / flags"): FIR=<ntaps>:<cutoff_hz>,
  * RESAMP=<L>/<M>, DEMOD=FM, MOD=FM:<kf_hz>; ASYNC=1 enables the reader thread + ring of the reference's
- * compiled-out USE_ASYNC path (CaribouliteStream.cpp:11,16-49,70-75); ZEROCOPY=1 registers the buffers the client
- * passes to readStream / writeStream with the GPU on first sight (up to 8, 16-byte aligned) so that the last kernel of a
- * read stores into them directly and the first kernel of a write reads them where they lie -- the client promises that such a buffer stays mapped until the stream is set up again or the
+ * compiled-out USE_ASYNC path (CaribouliteStream.cpp:11,16-49,70-75); ZEROCOPY=1 (RX) registers the buffers the client
+ * passes to readStream with the GPU on first sight (up to 8, 16-byte aligned) so that the last kernel of a read stores
+ * into them directly -- the client promises that such a buffer stays mapped until the stream is set up again or the
  * device is closed (a user-pointer mapping of the client's pages: the same mechanism as the runtime's in-place pinning the
  * copy helpers above avoid -- meant for buffers the client allocates once and keeps, not for a heap that churns);
  * defaults = reference behaviour. */
@@ -514,7 +514,7 @@ typedef struct {
     uint64_t writes_empty;                   /* writeStream calls that returned 0                                      */
     uint64_t tx_overruns;                    /* writes whose modulator look-back gave up and was repeated in ticket order */
     uint64_t zero_copy_registrations;        /* ZEROCOPY=1: client buffers registered with the GPU so far                */
-    uint64_t zero_copy_reads;                /* ZEROCOPY=1: calls whose kernel stored into / read the client's buffer itself */
+    uint64_t zero_copy_reads;                /* ZEROCOPY=1: reads whose last kernel stored into the client's buffer itself */
 } cl_stream_stats;
 void   cl_getStreamStats(const cl_device *dev, const cl_stream *stream, cl_stream_stats *out);
 unsigned long cl_stream_iir_overruns(const cl_stream *stream);         /* = iir_overruns above */

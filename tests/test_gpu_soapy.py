@@ -877,39 +877,3 @@ def test_write_stream_with_a_concurrent_drainer(S, orc):
     assert out.size == total
     assert np.array_equal(out, orc.generate_data(np.concatenate(calls), orc.TX_DOCUMENTED))
     sdr.close()
-
-
-def test_write_stream_zero_copy(S, orc):
-    """ZEROCOPY=1 on a TX stream: the first kernel of a write reads the client's registered buffer where it lies (no copy into
-    the library's pinned buffer, no copy-engine call).  Same bytes as the default route for CS16, CF32 and the FM route, from an
-    aligned buffer used over and over, from a misaligned one (falls back), and the counters say which calls took which way."""
-    rng = np.random.default_rng(41)
-    for fmt, mk, to16, args in (
-            (S.SOAPY_SDR_CS16, lambda n: rng.integers(-4096, 4096, (n, 2)).astype(np.int16), lambda a: a, {}),
-            (S.SOAPY_SDR_CF32, lambda n: (rng.standard_normal((n, 2)) * 0.4).astype(np.float32), orc.cf32_to_cs16, {})):
-        sdr = S.Device(dict(driver="Cariboulite", channel="S1G"))
-        tx = sdr.setupStream(S.SOAPY_SDR_TX, fmt, args=dict(args, ZEROCOPY="1"))
-        sdr.activateStream(tx)
-        buf = mk(MTU)
-        for rep in range(3):                                # the same buffer again and again: one registration
-            buf[:] = mk(MTU)
-            assert sdr.writeStream(tx, [buf], MTU).ret == MTU
-            assert np.array_equal(sdr.drainSmiBytes(), orc.generate_data(to16(buf), orc.TX_DOCUMENTED))
-        st = sdr.streamStats(tx)
-        assert st["zero_copy_registrations"] == 1 and st["zero_copy_reads"] == 3
-        odd = mk(5000 + 1)[1:]                              # 4 / 8 bytes off a 16-byte boundary: the copying route
-        assert sdr.writeStream(tx, [odd], 5000).ret == 5000
-        assert np.array_equal(sdr.drainSmiBytes(), orc.generate_data(to16(np.ascontiguousarray(odd)), orc.TX_DOCUMENTED))
-        assert sdr.streamStats(tx)["zero_copy_reads"] == 3
-        sdr.close()
-    # the FM route: equal to the default route's words, call by call (both streams carry the modulator's state along)
-    a = S.Device(dict(driver="Cariboulite", channel="S1G")); b = S.Device(dict(driver="Cariboulite", channel="S1G"))
-    ta = a.setupStream(S.SOAPY_SDR_TX, S.SOAPY_SDR_CF32, args={"MOD": "FM:75000", "RESAMP": "2/3"})
-    tb = b.setupStream(S.SOAPY_SDR_TX, S.SOAPY_SDR_CF32, args={"MOD": "FM:75000", "RESAMP": "2/3", "ZEROCOPY": "1"})
-    buf = np.zeros((MTU, 2), np.float32)
-    for rep in range(3):
-        buf[:] = (rng.standard_normal((MTU, 2)) * 0.3).astype(np.float32)
-        assert a.writeStream(ta, [buf], MTU).ret == MTU and b.writeStream(tb, [buf], MTU).ret == MTU
-        assert np.array_equal(a.drainSmiBytes(), b.drainSmiBytes())
-    assert b.streamStats(tb)["zero_copy_reads"] == 3
-    a.close(); b.close()
