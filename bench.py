@@ -307,7 +307,17 @@ def main():
         if a.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)   # RCCL; used only for barrier + max
         else:
-            dist.init_process_group(a.dist_backend)
+            # (gloo's C++ side prints its "Rank 0 is connected to ..." lines on stdout: point fd 1 at stderr while it
+            # connects, so that rank 0's JSON line stays the only thing on stdout)
+            sys.stdout.flush()
+            keep = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group(a.dist_backend)
+                dist.barrier()
+            finally:
+                os.dup2(keep, 1)
+                os.close(keep)
             red_dev = torch.device("cpu")
         # build the communicator NOW: a lazy first barrier right before the timed region would idle the GPU
         # for seconds and restart the DVFS transient

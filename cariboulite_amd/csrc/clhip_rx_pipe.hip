@@ -1102,6 +1102,10 @@ struct clhip_rx_pipe {
     int cur;
     unsigned long long n_total;    // inputs consumed so far (per stream)
     unsigned long long undo_n_total; bool can_undo;   // pre-call state of the last run (clhip_rx_pipe_rollback)
+    // streams advancing INDEPENDENTLY (stream groups at the host boundary: clhip_rx_pipe_epoch_begin / _run_range / _epoch_end):
+    unsigned long long *nt_s;      // [n_streams] inputs consumed per stream; the classic calls keep every entry == n_total
+    uint8_t *ran;                  // [n_streams] streams a range run of the open epoch has advanced
+    bool epoch_open;
     int32_t *d_flag, *h_flag;      // clhip_rx_pipe_run_smi: the device-side sync verdict, a word of pinned host memory the kernel
     bool flag_mapped;              //  stores to directly (d_flag = its device address); if the device cannot reach it, a device word + copy
     bool offs_writeback;           // run_smi zeroes d_offs after an in-kernel verdict (off: the caller only reads h_offs)
@@ -1180,6 +1184,9 @@ extern "C" clhip_rx_pipe *clhip_rx_pipe_create(int n_streams, int channel, const
         if (!p->hist[i]) { clhip_rx_pipe_destroy(p); return nullptr; }
         (void)hipMemset(p->hist[i], 0, hb);
     }
+    p->nt_s = (unsigned long long *)calloc((size_t)n_streams, sizeof(unsigned long long));
+    p->ran = (uint8_t *)calloc((size_t)n_streams, 1);
+    if (!p->nt_s || !p->ran) { clhip_rx_pipe_destroy(p); return nullptr; }
     p->d_fir = (float *)clhip_malloc(sizeof(float) * PIPE_MAX_FIR);
     p->d_fir_int = (float *)clhip_malloc(sizeof(float) * PIPE_MAX_FIR);
     p->d_rs = (float *)clhip_malloc(sizeof(float) * PIPE_MAX_RS);
@@ -1228,6 +1235,7 @@ extern "C" void clhip_rx_pipe_destroy(clhip_rx_pipe *p)
     clhip_free(p->X); clhip_free(p->Y); clhip_free(p->queue);
     if (!p->flag_mapped) clhip_free(p->d_flag);
     clhip_host_free(p->h_flag);
+    free(p->nt_s); free(p->ran);
     delete p;
 }
 
@@ -1239,10 +1247,15 @@ extern "C" void clhip_rx_pipe_reset(clhip_rx_pipe *p)
     (void)hipMemset(p->hist[0], 0, hb);
     (void)hipMemset(p->hist[1], 0, hb);
     (void)hipStreamSynchronize(nullptr);
-    p->cur = 0; p->n_total = 0; p->can_undo = false;
+    p->cur = 0; p->n_total = 0; p->can_undo = false; p->epoch_open = false;
+    for (int i = 0; i < p->n_streams; i++) p->nt_s[i] = 0;
 }
 
-extern "C" void clhip_rx_pipe_seek(clhip_rx_pipe *p, unsigned long long n_total) { p->n_total = n_total; p->can_undo = false; }
+extern "C" void clhip_rx_pipe_seek(clhip_rx_pipe *p, unsigned long long n_total)
+{
+    p->n_total = n_total; p->can_undo = false;
+    for (int i = 0; i < p->n_streams; i++) p->nt_s[i] = n_total;
+}
 
 // A run never touches the history it read (ping-pong buffers) and the polyphase phase is a host counter, so the
 // pre-call state of the LAST run is still complete: undoing it is a pointer flip.  The caller must have synchronised
@@ -1256,6 +1269,7 @@ extern "C" int clhip_rx_pipe_rollback(clhip_rx_pipe *p)
     if (!p || !p->can_undo) { clhip_set_error("clhip_rx_pipe_rollback: no run to undo"); return -1; }
     p->cur ^= 1;
     p->n_total = p->undo_n_total;
+    for (int i = 0; i < p->n_streams; i++) p->nt_s[i] = p->n_total;
     p->can_undo = false;
     return 0;
 }
@@ -1274,22 +1288,28 @@ extern "C" void clhip_rx_pipe_set_sync_check(clhip_rx_pipe *p, const int32_t *d_
     p->chk_offs = d_offs; p->chk_chunk_samples = chunk_samples; p->chk_flag = d_bad_flag;
 }
 
-extern "C" size_t clhip_rx_pipe_out_count(const clhip_rx_pipe *p, size_t n_in)
+static size_t out_count_at(const clhip_rx_pipe *p, unsigned long long n0, size_t n_in)
 {
     if (p->mode == CL_PIPE_OUT_FM_DEMOD || (p->L == 1 && p->M == 1)) return n_in;
-    const unsigned long long n0 = p->n_total, n1 = n0 + n_in;
+    const unsigned long long n1 = n0 + n_in;
     return (size_t)((n1 * p->L + p->M - 1) / p->M - (n0 * p->L + p->M - 1) / p->M);
 }
-
-extern "C" int clhip_rx_pipe_uses_fused(const clhip_rx_pipe *p, size_t n_in, int in_kind)
+extern "C" size_t clhip_rx_pipe_out_count(const clhip_rx_pipe *p, size_t n_in) { return out_count_at(p, p->n_total, n_in); }
+extern "C" size_t clhip_rx_pipe_out_count_stream(const clhip_rx_pipe *p, int s, size_t n_in)
 {
-    (void)n_in;
+    return p && s >= 0 && s < p->n_streams ? out_count_at(p, p->nt_s[s], n_in) : 0;
+}
+extern "C" unsigned long long clhip_rx_pipe_stream_total(const clhip_rx_pipe *p, int s) { return p && s >= 0 && s < p->n_streams ? p->nt_s[s] : 0; }
+
+static int uses_fused_at(const clhip_rx_pipe *p, unsigned long long n0, int in_kind)
+{
     if (p->force_generic || p->fused_id < 0) return 0;
     if (in_kind < 0 || in_kind > 2) return 0;
     // the tile-local polyphase pattern needs the call to start on a phase-0 input
-    if (((p->n_total % (unsigned long long)p->M) * p->L) % p->M != 0) return 0;
+    if (((n0 % (unsigned long long)p->M) * p->L) % p->M != 0) return 0;
     return 1;
 }
+extern "C" int clhip_rx_pipe_uses_fused(const clhip_rx_pipe *p, size_t n_in, int in_kind) { (void)n_in; return uses_fused_at(p, p->n_total, in_kind); }
 
 template <class C, int KIND, bool HIF, bool DIAG = false>
 static int launch_pipe(PipeArgs &a, hipStream_t s)
@@ -1380,24 +1400,23 @@ static int ensure_ws(clhip_rx_pipe *p, size_t n_in)
     return 0;
 }
 
-extern "C" long clhip_rx_pipe_run(clhip_rx_pipe *p, int in_kind, const void *d_in, size_t in_stride,
-                                  size_t n_in, void *d_out, size_t out_stride, void *stream)
+// One launch (fused) or launch chain (generic) over the streams [first, first + count) of the pipe, all of them at input position
+// `nt` (equal up to multiples of 2 M: the same polyphase phase and fast-FIR parity): reads hist[cur], writes hist[cur ^ 1]; the
+// callers move the pipe's state.  d_in / d_out point at stream `first`'s row.
+static long run_impl(clhip_rx_pipe *p, int first, int count, unsigned long long nt, int in_kind, const void *d_in, size_t in_stride,
+                     size_t n_in, void *d_out, size_t out_stride, hipStream_t s)
 {
-    if (!p || in_kind < 0 || in_kind > 2) { clhip_set_error("clhip_rx_pipe_run: bad arguments"); return -1; }
-    if (n_in == 0) return 0;
-    if (!d_in || !d_out) { clhip_set_error("clhip_rx_pipe_run: null buffer"); return -1; }
-    hipStream_t s = (hipStream_t)stream;
     p->last_stream = s; p->last_stream_valid = true;
-    const size_t n_out = clhip_rx_pipe_out_count(p, n_in);
+    const size_t n_out = out_count_at(p, nt, n_in);
 
     PipeArgs a;
     memset(&a, 0, sizeof a);
     a.in = d_in; a.in_stride = (long)in_stride;
-    a.hist_in = p->hist[p->cur];
+    a.hist_in = p->hist[p->cur] + (size_t)first * p->halo;
     a.out = d_out; a.out_stride = (long)out_stride;
     a.n_in = (long)n_in; a.n_out = (long)n_out;
-    a.in_kind = in_kind; a.channel = p->channel; a.n_streams = p->n_streams;
-    a.halo = p->halo; a.hist_out = p->hist[p->cur ^ 1]; a.diag = p->diag; a.queue = p->queue;
+    a.in_kind = in_kind; a.channel = p->channel; a.n_streams = count;
+    a.halo = p->halo; a.hist_out = p->hist[p->cur ^ 1] + (size_t)first * p->halo; a.diag = p->diag; a.queue = p->queue;
     a.tickets = p->queue + (p->queue_parity ? RX_QUEUE_WORDS : 0); a.queue_next = p->queue + (p->queue_parity ? 0 : RX_QUEUE_WORDS);
     // items per ticket: by the shape's tile rate.  Same-address device-scope atomics retire at ~12 ns each, and a ticket per
     // tile is one atomic per 13.5 ns for config 2 (0.9 ms / 66 052 tiles) -- within the counter's rate, asked for a whole tile
@@ -1421,19 +1440,19 @@ extern "C" long clhip_rx_pipe_run(clhip_rx_pipe *p, int in_kind, const void *d_i
 #if CLHIP_RX_BOUNDS
     {   // the extent of the call's buffers (all streams)
         const size_t esz = in_kind == CL_PIPE_IN_CF32 ? 8 : 4, ob = p->mode == CL_PIPE_OUT_FM_DEMOD ? 4 : 8;
-        a.b_in_lo = d_in; a.b_in_hi = (const unsigned char *)d_in + ((size_t)(p->n_streams - 1) * in_stride + n_in) * esz;
-        a.b_out_lo = d_out; a.b_out_hi = (unsigned char *)d_out + ((size_t)(p->n_streams - 1) * out_stride + n_out) * ob;
+        a.b_in_lo = d_in; a.b_in_hi = (const unsigned char *)d_in + ((size_t)(count - 1) * in_stride + n_in) * esz;
+        a.b_out_lo = d_out; a.b_out_hi = (unsigned char *)d_out + ((size_t)(count - 1) * out_stride + n_out) * ob;
     }
 #endif
     if (getenv("CLHIP_DEBUG_NOSTORE")) a.n_out = 0;     // timing ablation only: every store masked off
     bool fused_done = false;
-    if (clhip_rx_pipe_uses_fused(p, n_in, in_kind)) {
+    if (uses_fused_at(p, nt, in_kind)) {
         int rc = -1;
         fused_done = true;
         // 2-parallel fast FIR by default (CLHIP_FFA=0: direct form).  Its lane parity is tied to the
         // absolute sample index, so a call that starts on an odd index uses the direct form.
         static const int ffa_env = getenv("CLHIP_FFA") ? atoi(getenv("CLHIP_FFA")) : 1;
-        const bool ffa = ffa_env && ffa_taps && (p->n_total & 1) == 0;
+        const bool ffa = ffa_env && ffa_taps && (nt & 1) == 0;
         if (ffa) a.fir = ffa_taps;
         switch (p->fused_id) {
         case 0: rc = ffa ? launch_fused<CfgC2f>(a, s) : launch_fused<CfgC2>(a, s); break;
@@ -1453,10 +1472,10 @@ extern "C" long clhip_rx_pipe_run(clhip_rx_pipe *p, int in_kind, const void *d_i
     } else {
         if (ensure_ws(p, n_in)) return -1;
         const unsigned gx = (unsigned)(clhip_div_up(p->halo + n_in, 256) > 4096 ? 4096 : clhip_div_up(p->halo + n_in, 256));
-        dim3 grid(gx, p->n_streams), block(256);
+        dim3 grid(gx, count), block(256);               // (the workspaces are scratch: rows [0, count) whatever `first` is)
         hipLaunchKernelGGL(gen_stage_kernel, grid, block, 0, s, a, p->halo, p->X, (long)p->x_cap);
         const unsigned gf = (unsigned)(clhip_div_up(p->hfg + n_in, GEN_TILE) > 8192 ? 8192 : clhip_div_up(p->hfg + n_in, GEN_TILE));
-        hipLaunchKernelGGL(gen_fir_kernel, dim3(gf, p->n_streams), block, 0, s, p->X, (long)p->x_cap, p->halo, p->d_fir_pad, p->T,
+        hipLaunchKernelGGL(gen_fir_kernel, dim3(gf, count), block, 0, s, p->X, (long)p->x_cap, p->halo, p->d_fir_pad, p->T,
                            p->hfg, (long)n_in, p->Y, (long)p->y_cap);
         if (p->mode == CL_PIPE_OUT_FM_DEMOD)
             hipLaunchKernelGGL(gen_fm_kernel, grid, block, 0, s, p->Y, (long)p->y_cap, p->hfg, (long)n_in,
@@ -1466,17 +1485,93 @@ extern "C" long clhip_rx_pipe_run(clhip_rx_pipe *p, int in_kind, const void *d_i
                                (f32x2 *)d_out, (long)out_stride);
         else
             hipLaunchKernelGGL(gen_resample_kernel, grid, block, 0, s, p->Y, (long)p->y_cap, p->hfg, p->d_rs, p->n_rs,
-                               p->L, p->M, p->n_total, (long)n_out, (f32x2 *)d_out, (long)out_stride);
+                               p->L, p->M, nt, (long)n_out, (f32x2 *)d_out, (long)out_stride);
         CLHIP_CHECK_LAUNCH();
     }
     if (!fused_done) {
-        hipLaunchKernelGGL(pipe_update_hist_kernel, dim3(p->n_streams), dim3(128), 0, s, a);
+        hipLaunchKernelGGL(pipe_update_hist_kernel, dim3(count), dim3(128), 0, s, a);
         CLHIP_CHECK_LAUNCH();
     }
+    return (long)n_out;
+}
+
+extern "C" long clhip_rx_pipe_run(clhip_rx_pipe *p, int in_kind, const void *d_in, size_t in_stride,
+                                  size_t n_in, void *d_out, size_t out_stride, void *stream)
+{
+    if (!p || in_kind < 0 || in_kind > 2) { clhip_set_error("clhip_rx_pipe_run: bad arguments"); return -1; }
+    if (p->epoch_open) { clhip_set_error("clhip_rx_pipe_run: an epoch of range runs is open"); return -1; }
+    if (n_in == 0) return 0;
+    if (!d_in || !d_out) { clhip_set_error("clhip_rx_pipe_run: null buffer"); return -1; }
+    for (int i = 1; i < p->n_streams; i++)
+        if (p->nt_s[i] != p->nt_s[0]) { clhip_set_error("clhip_rx_pipe_run: the pipe's streams have advanced independently (range runs): they no longer move as one"); return -1; }
+    const long n_out = run_impl(p, 0, p->n_streams, p->n_total, in_kind, d_in, in_stride, n_in, d_out, out_stride, (hipStream_t)stream);
+    if (n_out < 0) return n_out;
     p->undo_n_total = p->n_total; p->can_undo = true;
     p->cur ^= 1;
     p->n_total += n_in;
-    return (long)n_out;
+    for (int i = 0; i < p->n_streams; i++) p->nt_s[i] = p->n_total;
+    return n_out;
+}
+
+// ---------------------------------------------------------------------------
+// Streams of ONE pipe advancing independently: what a stream group at the host boundary needs (cl_group_readStream: N Soapy
+// devices of one GPU read in one call -- the reference's unit is one device per channel, soapy_api/SoapyCariboulite.cpp:46-69,
+// each with its own caribou_smi_read chunk loop, caribou_smi.c:632-682, so one stream may deliver while its neighbour re-syncs
+// or returns -3).  An EPOCH is one such call: every stream reads hist[cur] and writes hist[cur ^ 1] at most once, through
+// range runs over disjoint runs of neighbouring streams (base + stride addressing: no kernel change, one launch per run); a
+// stream no run touched keeps its state (its history is copied across when the epoch ends); then the buffers flip for all.
+// ---------------------------------------------------------------------------
+extern "C" int clhip_rx_pipe_epoch_begin(clhip_rx_pipe *p)
+{
+    if (!p || p->epoch_open) { clhip_set_error("clhip_rx_pipe_epoch_begin: bad pipe or epoch already open"); return -1; }
+    memset(p->ran, 0, (size_t)p->n_streams);
+    p->epoch_open = true;
+    p->can_undo = false;
+    return 0;
+}
+
+extern "C" long clhip_rx_pipe_run_range(clhip_rx_pipe *p, int first, int count, int in_kind, const void *d_in, size_t in_stride,
+                                        size_t n_in, void *d_out, size_t out_stride, void *stream)
+{
+    if (!p || !p->epoch_open || in_kind < 0 || in_kind > 2 || first < 0 || count < 1 || first + count > p->n_streams) {
+        clhip_set_error("clhip_rx_pipe_run_range: bad arguments (is an epoch open?)");
+        return -1;
+    }
+    if (n_in == 0) return 0;
+    if (!d_in || !d_out) { clhip_set_error("clhip_rx_pipe_run_range: null buffer"); return -1; }
+    const unsigned long long cls = 2ull * (unsigned long long)p->M;
+    for (int i = first; i < first + count; i++) {
+        if (p->ran[i]) { clhip_set_error("clhip_rx_pipe_run_range: stream %d already ran in this epoch", i); return -1; }
+        if (p->nt_s[i] % cls != p->nt_s[first] % cls) {
+            clhip_set_error("clhip_rx_pipe_run_range: streams %d and %d are on different polyphase phases: split the range", first, i);
+            return -1;
+        }
+    }
+    const long n_out = run_impl(p, first, count, p->nt_s[first], in_kind, d_in, in_stride, n_in, d_out, out_stride, (hipStream_t)stream);
+    if (n_out < 0) return n_out;
+    for (int i = first; i < first + count; i++) { p->ran[i] = 1; p->nt_s[i] += n_in; }
+    return n_out;
+}
+
+extern "C" int clhip_rx_pipe_epoch_end(clhip_rx_pipe *p, void *stream)
+{
+    if (!p || !p->epoch_open) { clhip_set_error("clhip_rx_pipe_epoch_end: no epoch open"); return -1; }
+    hipStream_t s = (hipStream_t)stream;
+    const size_t row = sizeof(f32x2) * (size_t)p->halo;
+    int i = 0;
+    while (i < p->n_streams) {                       // runs of untouched streams: their history moves across unchanged
+        if (p->ran[i]) { i++; continue; }
+        int j = i;
+        while (j < p->n_streams && !p->ran[j]) j++;
+        CLHIP_CHECK(hipMemcpyAsync(p->hist[p->cur ^ 1] + (size_t)i * p->halo, p->hist[p->cur] + (size_t)i * p->halo, row * (size_t)(j - i),
+                                   hipMemcpyDeviceToDevice, s));
+        i = j;
+    }
+    p->last_stream = s; p->last_stream_valid = true;
+    p->cur ^= 1;
+    p->n_total = p->nt_s[0];
+    p->epoch_open = false;
+    return 0;
 }
 
 // ---------------------------------------------------------------------------

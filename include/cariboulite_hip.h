@@ -266,6 +266,21 @@ int    clhip_rx_pipe_uses_fused(const clhip_rx_pipe *p, size_t n_in, int in_kind
  * Returns outputs per stream (>= 0) or a negative error. */
 long   clhip_rx_pipe_run(clhip_rx_pipe *p, int in_kind, const void *d_in, size_t in_stride_elems,
                          size_t n_in, void *d_out, size_t out_stride_elems, void *stream);
+/* The streams of ONE pipe advancing independently -- what a stream group at the host boundary needs (cl_group_readStream
+ * below: the reference's unit is one Soapy device per channel, soapy_api/SoapyCariboulite.cpp:46-69, each with its own
+ * caribou_smi_read chunk loop, caribou_smi/caribou_smi.c:632-682, so one stream may deliver while its neighbour re-syncs or
+ * returns -3).  An EPOCH is one such call: between _epoch_begin and _epoch_end every stream runs at most once, through
+ * range runs over disjoint runs of NEIGHBOURING streams [first, first + count) -- one launch per run, same kernels, d_in /
+ * d_out pointing at stream `first`'s row; the streams of one range must be on the same polyphase phase (inputs consumed
+ * equal modulo 2 * down).  A stream no run touched keeps its state.  While an epoch is open, and once the streams have
+ * drifted apart, the whole-pipe calls (clhip_rx_pipe_run, _run_smi, _rollback) refuse.  _out_count_stream = outputs the
+ * next run of stream s yields for n_in inputs. */
+int    clhip_rx_pipe_epoch_begin(clhip_rx_pipe *p);
+long   clhip_rx_pipe_run_range(clhip_rx_pipe *p, int first, int count, int in_kind, const void *d_in, size_t in_stride_elems,
+                               size_t n_in, void *d_out, size_t out_stride_elems, void *stream);
+int    clhip_rx_pipe_epoch_end(clhip_rx_pipe *p, void *stream);
+size_t clhip_rx_pipe_out_count_stream(const clhip_rx_pipe *p, int s, size_t n_in);
+unsigned long long clhip_rx_pipe_stream_total(const clhip_rx_pipe *p, int s);   /* inputs stream s has consumed */
 /* diagnostic: route config 2 through the s_memtime-stamped build (tools/phase_stamps.py); NULL = off */
 void   clhip_rx_pipe_set_diag(clhip_rx_pipe *p, unsigned long long *d_buf);
 /* force the multi-kernel generic path (second implementation, used by tests) */

@@ -1,0 +1,41 @@
+"""gpu: the N > 1 path of bench.py executed for real on a one-GPU box -- two ranks started by bench.py's own self-launch
+(torch.distributed.run, rendezvous on 127.0.0.1), both on GPU 0 (CLHIP_BENCH_ALL_ON_GPU0=1), gloo for the barrier and the
+max-over-ranks reduction (RCCL refuses two ranks on one device; the data path has no collective, SURVEY.md section 8e: the
+independent unit is one Soapy device per channel, soapy_api/SoapyCariboulite.cpp:46-69).  Exactly what the driver's N = 2, 4, 8
+runs execute except for the backend name."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+
+def _run(extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["CLHIP_BENCH_ALL_ON_GPU0"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--steps", "3",
+                        "--warmup", "1", "--settle", "1", "--no-cpu"] + extra, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, f"rank 0 prints ONE line, got {len(lines)}: {r.stdout[-800:]}"
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_two_ranks_headline_workload():
+    d = _run(["--log2-samples", "20"])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["unit"] == "Msamples/s"
+    assert d["config"]["samples_per_gpu_per_step"] == 1 << 20
+    # whole-job value = both ranks' samples over the max-over-ranks time
+    assert abs(d["value"] - 2 * (1 << 20) * 3 / (d["ms_per_step"] * 3e-3) / 1e6) / d["value"] < 1e-2
+    assert "cpu_baseline" not in d                       # rank 0 at N = 1 only
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["achieved"] > 0
+
+
+@pytest.mark.gpu
+def test_two_ranks_sharded_config4():
+    d = _run(["--workload", "c4", "--streams", "6", "--log2-samples", "17"])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["streams_per_gpu"] == 3
