@@ -34,6 +34,10 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("OMP_WAIT_POLICY", "active")     # libgomp barriers spin (sandboxed futexes are slow)
+# torch moves this script's numpy arrays to and from the device; with the threshold (MiB) out of reach the HIP runtime stages
+# pageable copies >= 1 MiB through its own pinned buffers instead of pinning numpy's heap pages in place.
+# A tool's own setting: the product libraries neither set nor need it.
+os.environ.setdefault("GPU_PINNED_MIN_XFER_SIZE", "1048576")
 
 import numpy as np  # noqa: E402
 
@@ -287,7 +291,6 @@ def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(a)
-    import cariboulite_amd  # noqa: F401  (first: its import sets the runtime's pageable-copy default before the first HIP call)
     global torch
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))

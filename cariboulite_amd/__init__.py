@@ -11,15 +11,9 @@ This package is only the Python face used by tests and bench.py (ctypes; torch
 supplies device memory, streams and torch.distributed).  There is no CPU
 fallback: loading fails loudly when the HIP library is missing.
 """
-import os as _os
-
-# The tests, bench.py and the tools move numpy arrays to and from the device with torch.  The HIP runtime copies pageable
-# host memory of 1 MiB and more by pinning the caller's pages in place, and that path has ended long test sessions with a
-# GPU page fault on a host heap address (DESIGN.md section 7).  With the threshold (MiB) out of reach the runtime stages
-# such copies through its own pinned buffers.  Only a default, and only effective when this package is imported before the
-# process's first HIP call (importing torch is not one); the C libraries themselves never rely on it -- they copy
-# caller-owned pageable memory in pieces below the threshold (clhip_memcpy_h2d / _d2h).
-_os.environ.setdefault("GPU_PINNED_MIN_XFER_SIZE", "1048576")
+# (Nothing here touches the process's HIP runtime configuration: the C libraries copy caller-owned pageable memory in pieces
+# below the runtime's in-place pinning threshold themselves, clhip_memcpy_h2d / _d2h.  tests/conftest.py and bench.py set
+# GPU_PINNED_MIN_XFER_SIZE for THEIR OWN torch uploads of numpy temporaries, DESIGN.md section 7.)
 
 from . import hip  # noqa: F401,E402
 

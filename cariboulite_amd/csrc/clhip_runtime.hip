@@ -2,8 +2,79 @@
 // memory, streams, events, error string.  No kernels here.
 #include <stdarg.h>
 #include <string.h>
+#include <unistd.h>
+
+#include <atomic>
 
 #include "clhip_common.h"
+
+// ---- what this library has asked the runtime to do with HOST memory it does not own, most recent 256 operations ----
+// The robustness record of round 3 ends on a GPU page fault at a host heap address that could not be
+// set against the library's own registrations and copies, because nobody had written those down.  Every registration,
+// release and copy of caller-owned host memory is noted here (a store and a relaxed counter: nothing a call could feel);
+// clhip_debug_ops() reads the ring, clhip_debug_ops_dump(fd) writes it with write(2) only -- safe to call from the SIGABRT
+// handler the HSA runtime's fault handler ends in (tests/cpp/abrt_trace.c does), so that a fault address is decidable against
+// these ranges the next time one is seen.
+struct clhip_op_slot { std::atomic<uint64_t> seq; uint32_t op; uintptr_t base; size_t len; };
+static clhip_op_slot g_ops[256];
+static std::atomic<uint64_t> g_op_seq{0};
+static std::atomic<uint64_t> g_copy_ctr[4];      // [0] pageable copies made in pieces, [1] page-locked copies made whole,
+                                                 // [2] largest pageable range handed to ONE hipMemcpyAsync, [3] pageable bytes copied
+static void clhip_note_op(uint32_t op, const void *base, size_t len)
+{
+    const uint64_t n = g_op_seq.fetch_add(1, std::memory_order_relaxed) + 1;
+    clhip_op_slot &sl = g_ops[n & 255];
+    sl.seq.store(0, std::memory_order_relaxed);                  // being written
+    sl.op = op; sl.base = (uintptr_t)base; sl.len = len;
+    sl.seq.store(n, std::memory_order_release);
+}
+extern "C" size_t clhip_debug_ops(clhip_op_record *out, size_t max)
+{
+    const uint64_t last = g_op_seq.load(std::memory_order_acquire);
+    const uint64_t first = last > 256 ? last - 255 : 1;
+    size_t k = 0;
+    for (uint64_t n = first; n <= last && k < max; n++) {
+        const clhip_op_slot &sl = g_ops[n & 255];
+        if (sl.seq.load(std::memory_order_acquire) != n) continue;    // overwritten meanwhile, or half written
+        out[k].seq = n; out[k].op = sl.op; out[k].base = (uint64_t)sl.base; out[k].len = (uint64_t)sl.len;
+        k++;
+    }
+    return k;
+}
+static size_t hex_u64(char *dst, uint64_t v)
+{
+    char tmp[16];
+    int n = 0;
+    do { tmp[n++] = "0123456789abcdef"[v & 15]; v >>= 4; } while (v);
+    for (int i = 0; i < n; i++) dst[i] = tmp[n - 1 - i];
+    return (size_t)n;
+}
+extern "C" void clhip_debug_ops_dump(int fd)
+{
+    static const char *const names[] = {"?", "register", "register-failed", "unregister", "h2d-pageable-in-pieces", "d2h-pageable-in-pieces",
+                                        "h2d-page-locked", "d2h-page-locked", "h2d-pageable-small", "d2h-pageable-small"};
+    const char head[] = "[clhip] host-memory operations of libcariboulite_hip.so, oldest first (seq op base len, hex):\n";
+    if (write(fd, head, sizeof head - 1) < 0) return;
+    const uint64_t last = g_op_seq.load(std::memory_order_acquire);
+    for (uint64_t n = last > 256 ? last - 255 : 1; n <= last; n++) {
+        const clhip_op_slot &sl = g_ops[n & 255];
+        if (sl.seq.load(std::memory_order_acquire) != n) continue;
+        char line[160];
+        size_t k = 0;
+        line[k++] = ' '; line[k++] = ' ';
+        k += hex_u64(line + k, n); line[k++] = ' ';
+        const char *nm = names[sl.op < 10 ? sl.op : 0];
+        for (; *nm; nm++) line[k++] = *nm;
+        line[k++] = ' '; line[k++] = '0'; line[k++] = 'x'; k += hex_u64(line + k, (uint64_t)sl.base);
+        line[k++] = ' '; line[k++] = '+'; line[k++] = '0'; line[k++] = 'x'; k += hex_u64(line + k, (uint64_t)sl.len);
+        line[k++] = '\n';
+        if (write(fd, line, k) < 0) return;
+    }
+}
+extern "C" void clhip_debug_copy_counters(uint64_t out[4])
+{
+    for (int i = 0; i < 4; i++) out[i] = g_copy_ctr[i].load(std::memory_order_relaxed);
+}
 
 static thread_local char g_err[512] = "";
 
@@ -82,12 +153,24 @@ extern "C" void *clhip_host_register(void *h, size_t bytes)
 {
     void *d = nullptr;
     if (!h || !bytes) return nullptr;
-    if (hipHostRegister(h, bytes, hipHostRegisterMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess || !d) { (void)hipGetLastError(); (void)hipHostUnregister(h); return nullptr; }
+    hipError_t e = hipHostRegister(h, bytes, hipHostRegisterMapped);
+    if (e != hipSuccess) { clhip_set_error("hipHostRegister(%p, %zu): %s", h, bytes, hipGetErrorString(e)); (void)hipGetLastError(); clhip_note_op(CLHIP_OP_REGISTER_FAILED, h, bytes); return nullptr; }
+    if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess || !d) {
+        (void)hipGetLastError(); (void)hipHostUnregister(h);
+        clhip_set_error("hipHostGetDevicePointer(%p): the device cannot reach registered host memory", h);
+        clhip_note_op(CLHIP_OP_REGISTER_FAILED, h, bytes);
+        return nullptr;
+    }
+    clhip_note_op(CLHIP_OP_REGISTER, h, bytes);
     return d;
 }
 
-extern "C" void clhip_host_unregister(void *h) { if (h && hipHostUnregister(h) != hipSuccess) (void)hipGetLastError(); }
+extern "C" void clhip_host_unregister(void *h)
+{
+    if (!h) return;
+    clhip_note_op(CLHIP_OP_UNREGISTER, h, 0);
+    if (hipHostUnregister(h) != hipSuccess) (void)hipGetLastError();
+}
 
 // Copies between device memory and host memory the CALLER owns.  The HIP runtime copies pageable host memory of 1 MiB and
 // more (GPU_PINNED_MIN_XFER_SIZE) by pinning the caller's pages in place -- the copy engine then reads or writes the
@@ -105,17 +188,33 @@ static bool clhip_host_is_pinned(const void *h)
     if (hipPointerGetAttributes(&a, h) != hipSuccess) { (void)hipGetLastError(); return false; }   // unknown to the runtime: plain pageable memory
     return a.type == hipMemoryTypeHost;
 }
-static bool clhip_copy_in_pieces(const void *h, size_t n)
+// what kind of copy this is, noted in the operation ring and the counters (clhip_debug_copy_counters: a test asserts that no
+// pageable range above one piece ever reaches a single hipMemcpyAsync)
+static bool clhip_copy_in_pieces(const void *h, size_t n, bool h2d)
 {
-    static const bool off = getenv("CLHIP_PAGEABLE_WHOLE") && atoi(getenv("CLHIP_PAGEABLE_WHOLE"));   // A/B: what round 2 did
-    return !off && n > CLHIP_PAGEABLE_PIECE && !clhip_host_is_pinned(h);
+    if (n <= CLHIP_PAGEABLE_PIECE) {
+        // (small copies are staged by the runtime whatever the memory is; asking what it is would cost more than the copy's set-up)
+        return false;
+    }
+    const bool pinned = clhip_host_is_pinned(h);
+    clhip_note_op(pinned ? (h2d ? CLHIP_OP_H2D_LOCKED : CLHIP_OP_D2H_LOCKED) : (h2d ? CLHIP_OP_H2D_PIECES : CLHIP_OP_D2H_PIECES), h, n);
+    if (pinned) { g_copy_ctr[1].fetch_add(1, std::memory_order_relaxed); return false; }
+    g_copy_ctr[0].fetch_add(1, std::memory_order_relaxed);
+    g_copy_ctr[3].fetch_add(n, std::memory_order_relaxed);
+    return true;
+}
+static void clhip_note_pageable_piece(size_t m)
+{
+    uint64_t cur = g_copy_ctr[2].load(std::memory_order_relaxed);
+    while (m > cur && !g_copy_ctr[2].compare_exchange_weak(cur, m, std::memory_order_relaxed)) {}
 }
 
 extern "C" int clhip_memcpy_h2d(void *d, const void *h, size_t n, void *s)
 {
-    if (clhip_copy_in_pieces(h, n)) {
+    if (clhip_copy_in_pieces(h, n, true)) {
         for (size_t o = 0; o < n; o += CLHIP_PAGEABLE_PIECE) {
             const size_t m = n - o < CLHIP_PAGEABLE_PIECE ? n - o : CLHIP_PAGEABLE_PIECE;
+            clhip_note_pageable_piece(m);
             CLHIP_CHECK(hipMemcpyAsync((char *)d + o, (const char *)h + o, m, hipMemcpyHostToDevice, (hipStream_t)s));
         }
         return 0;
@@ -125,9 +224,10 @@ extern "C" int clhip_memcpy_h2d(void *d, const void *h, size_t n, void *s)
 }
 extern "C" int clhip_memcpy_d2h(void *h, const void *d, size_t n, void *s)
 {
-    if (clhip_copy_in_pieces(h, n)) {
+    if (clhip_copy_in_pieces(h, n, false)) {
         for (size_t o = 0; o < n; o += CLHIP_PAGEABLE_PIECE) {
             const size_t m = n - o < CLHIP_PAGEABLE_PIECE ? n - o : CLHIP_PAGEABLE_PIECE;
+            clhip_note_pageable_piece(m);
             CLHIP_CHECK(hipMemcpyAsync((char *)h + o, (const char *)d + o, m, hipMemcpyDeviceToHost, (hipStream_t)s));
         }
         return 0;
@@ -173,6 +273,11 @@ extern "C" void clhip_event_destroy(void *e) { if (e) (void)hipEventDestroy((hip
 extern "C" int clhip_event_record(void *e, void *s)
 {
     CLHIP_CHECK(hipEventRecord((hipEvent_t)e, (hipStream_t)s));
+    return 0;
+}
+extern "C" int clhip_event_sync(void *e)
+{
+    CLHIP_CHECK(hipEventSynchronize((hipEvent_t)e));
     return 0;
 }
 extern "C" int clhip_stream_wait_event(void *s, void *e)

@@ -1,0 +1,573 @@
+/* cl_group.c -- a STREAM GROUP at the Soapy boundary: N devices of one GPU read in one call.
+ *
+ * The reference's unit is one SoapySDR device per channel (soapy_api/SoapyCariboulite.cpp:46-69: every board enumerates
+ * an S1G and a HiF device), each readStream a caribou_smi_read chunk loop of its own (caribou_smi/caribou_smi.c:632-682,
+ * soapy_api/CaribouliteStreamFunctions.cpp:239-254).  A client with many boards calls readStream once per device and pays,
+ * on a GPU, one launch chain and one synchronisation per device for 512 KiB of input.  cl_group_readStream is those N
+ * calls as one: per-stream state, re-sync and "-3" semantics are exactly those of N single cl_readStream calls (a stream
+ * that cannot take the batched route takes its own device's single-stream route, here, inside the call), while the
+ * streams that are in sync -- the normal case -- share launches and cross PCIe as a pipeline:
+ *
+ *     sub-batch b (SUB streams):  FIFO bytes --copy engine--> d_in rows        stream s_in,  event in[b]
+ *                                 one launch over the rows (fused pipe / unpack) stream s_k,   event k[b]
+ *                                 d_out rows --copy engine--> pinned mirror      stream s_out, event out[b]
+ *                                 mirror rows --memcpy pool--> the clients' (pageable) buffers
+ *
+ * so that sub-batch b + 1 comes in and sub-batch b - 1 leaves while b computes, and the last hop (which one thread cannot
+ * do at PCIe rate: profiles/r04/pcie_duplex.json) is spread over a few threads with non-temporal stores.
+ *
+ * State: a lane of the group (members with one channel type and one stream configuration) owns ONE n-stream RX pipe whose
+ * streams advance independently (clhip_rx_pipe_epoch_begin / _run_range / _epoch_end); formats without extension stages
+ * are stateless behind the unpack.  What the single-stream route keeps for the reference's "untouched slots" (the
+ * persistent native buffer) is rebuilt lazily from the previous call's raw words when a member leaves the batched route. */
+#include <immintrin.h>
+#include <unistd.h>
+
+#include "cl_internal.h"
+
+enum { ROUTE_PIPE = 1, ROUTE_PLAIN = 2 };
+
+typedef struct { uint8_t *dst; const uint8_t *src; size_t bytes; } copy_job;
+
+typedef struct {
+    pthread_t *th; int n_threads;
+    pthread_mutex_t mu; pthread_cond_t work, idle;
+    copy_job *q; size_t q_cap, q_head, q_len;
+    size_t in_flight;                     /* queued + being copied */
+    int stop;
+} copy_pool;
+
+typedef struct {
+    int channel, route, format;
+    size_t elem_bytes;                    /* bytes per output element */
+    int up, down;
+    int n; int *member;                   /* indices into the group's device table */
+    clhip_rx_pipe *pipe;                  /* ROUTE_PIPE */
+    size_t in_stride;                     /* bytes per row of d_in */
+    uint8_t *d_in[2]; int cur_in;         /* raw words of this call / of the call before it */
+    size_t *prev_len;                     /* per row: bytes the PREVIOUS call put into d_in[cur_in ^ 1] on the batched route (0: none) */
+    size_t out_stride;                    /* elements per row of d_out / h_out */
+    uint8_t *d_out, *h_out;
+    int32_t *h_offs; int32_t *d_offs;     /* ROUTE_PLAIN: per row 0 (unpack) / -1 (skip), mapped pinned */
+    uint8_t *fast; size_t *len; long *got;   /* per call */
+    cl_dsp_cfg dsp;
+} lane_t;
+
+struct cl_group {
+    int device;
+    size_t n; cl_device **dev;
+    int *lane_of, *row_of;                /* member -> lane / row */
+    int n_lanes; lane_t *lane;
+    int sub;                              /* streams per sub-batch */
+    void *s_in, *s_k, *s_out;
+    void **ev; size_t n_ev;               /* 3 per sub-batch */
+    copy_pool pool;
+    uint8_t **reg_base; uint8_t **reg_dev; size_t *reg_len;   /* per member: a client buffer registered with the GPU (cl_group_register_buffers) */
+    cl_group_stats stats;
+    char err[256];
+};
+
+/* ------------------------------------------------------------------ the last hop: pinned mirror -> client memory */
+__attribute__((target("avx2"))) static void copy_stream_avx2(uint8_t *dst, const uint8_t *src, size_t n)
+{
+    /* non-temporal stores: the client's buffer is written once and read later, by someone else; going around the cache
+     * saves the read-for-ownership of every destination line (tools/microbench/pcie_duplex.hip: 44 against 31 GB/s on
+     * one thread, 120 against 90 on four) */
+    const size_t head = (32 - ((uintptr_t)dst & 31)) & 31;
+    if (head > n) { memcpy(dst, src, n); return; }
+    if (head) { memcpy(dst, src, head); dst += head; src += head; n -= head; }
+    size_t i = 0;
+    for (; i + 128 <= n; i += 128) {
+        const __m256i a = _mm256_loadu_si256((const __m256i *)(src + i)), b = _mm256_loadu_si256((const __m256i *)(src + i + 32)),
+                      c = _mm256_loadu_si256((const __m256i *)(src + i + 64)), d = _mm256_loadu_si256((const __m256i *)(src + i + 96));
+        _mm256_stream_si256((__m256i *)(dst + i), a); _mm256_stream_si256((__m256i *)(dst + i + 32), b);
+        _mm256_stream_si256((__m256i *)(dst + i + 64), c); _mm256_stream_si256((__m256i *)(dst + i + 96), d);
+    }
+    _mm_sfence();
+    if (i < n) memcpy(dst + i, src + i, n - i);
+}
+
+static void copy_out(uint8_t *dst, const uint8_t *src, size_t n)
+{
+    static int avx2 = -1;
+    if (avx2 < 0) avx2 = __builtin_cpu_supports("avx2") ? 1 : 0;
+    if (avx2 && n >= 4096) copy_stream_avx2(dst, src, n); else memcpy(dst, src, n);
+}
+
+static void *pool_thread(void *arg)
+{
+    copy_pool *p = (copy_pool *)arg;
+    pthread_mutex_lock(&p->mu);
+    for (;;) {
+        while (!p->q_len && !p->stop) pthread_cond_wait(&p->work, &p->mu);
+        if (!p->q_len && p->stop) break;
+        const copy_job j = p->q[p->q_head];
+        p->q_head = (p->q_head + 1) % p->q_cap; p->q_len--;
+        pthread_mutex_unlock(&p->mu);
+        copy_out(j.dst, j.src, j.bytes);
+        pthread_mutex_lock(&p->mu);
+        if (--p->in_flight == 0) pthread_cond_broadcast(&p->idle);
+    }
+    pthread_mutex_unlock(&p->mu);
+    return NULL;
+}
+
+static int pool_start(copy_pool *p, int n_threads, size_t q_cap)
+{
+    memset(p, 0, sizeof *p);
+    pthread_mutex_init(&p->mu, NULL); pthread_cond_init(&p->work, NULL); pthread_cond_init(&p->idle, NULL);
+    p->q = (copy_job *)calloc(q_cap, sizeof *p->q); p->q_cap = q_cap;
+    p->th = (pthread_t *)calloc((size_t)(n_threads > 0 ? n_threads : 1), sizeof *p->th);
+    if (!p->q || !p->th) return -1;
+    for (int i = 0; i < n_threads; i++) {
+        if (pthread_create(&p->th[i], NULL, pool_thread, p)) break;
+        p->n_threads++;
+    }
+    return 0;
+}
+
+static void pool_stop(copy_pool *p)
+{
+    pthread_mutex_lock(&p->mu);
+    p->stop = 1;
+    pthread_cond_broadcast(&p->work);
+    pthread_mutex_unlock(&p->mu);
+    for (int i = 0; i < p->n_threads; i++) pthread_join(p->th[i], NULL);
+    free(p->th); free(p->q);
+    pthread_mutex_destroy(&p->mu); pthread_cond_destroy(&p->work); pthread_cond_destroy(&p->idle);
+    memset(p, 0, sizeof *p);
+}
+
+/* queue [src, src + bytes) -> dst in pieces; without worker threads the caller copies */
+static void pool_submit(copy_pool *p, uint8_t *dst, const uint8_t *src, size_t bytes)
+{
+    const size_t piece = (size_t)512 << 10;
+    if (!p->n_threads) { copy_out(dst, src, bytes); return; }
+    pthread_mutex_lock(&p->mu);
+    for (size_t o = 0; o < bytes; o += piece) {
+        const size_t n = bytes - o < piece ? bytes - o : piece;
+        if (p->q_len == p->q_cap) {                     /* full: do this piece here */
+            pthread_mutex_unlock(&p->mu);
+            copy_out(dst + o, src + o, n);
+            pthread_mutex_lock(&p->mu);
+            continue;
+        }
+        p->q[(p->q_head + p->q_len) % p->q_cap] = (copy_job){dst + o, src + o, n};
+        p->q_len++; p->in_flight++;
+    }
+    pthread_cond_broadcast(&p->work);
+    pthread_mutex_unlock(&p->mu);
+}
+
+/* the caller helps until the queue is empty, then waits for the pieces still being copied */
+static void pool_drain(copy_pool *p)
+{
+    if (!p->n_threads) return;
+    pthread_mutex_lock(&p->mu);
+    while (p->q_len) {
+        const copy_job j = p->q[p->q_head];
+        p->q_head = (p->q_head + 1) % p->q_cap; p->q_len--;
+        pthread_mutex_unlock(&p->mu);
+        copy_out(j.dst, j.src, j.bytes);
+        pthread_mutex_lock(&p->mu);
+        if (--p->in_flight == 0) pthread_cond_broadcast(&p->idle);
+    }
+    while (p->in_flight) pthread_cond_wait(&p->idle, &p->mu);
+    pthread_mutex_unlock(&p->mu);
+}
+
+/* ------------------------------------------------------------------------------------------- make / unmake */
+static const char *kwget(const char *const *keys, const char *const *vals, size_t n, const char *key)
+{
+    for (size_t i = 0; i < n; i++)
+        if (keys && vals && keys[i] && vals[i] && !strcmp(keys[i], key)) return vals[i];
+    return NULL;
+}
+
+static size_t fmt_bytes(int fmt) { return fmt == CL_FORMAT_CF32 ? 8 : fmt == CL_FORMAT_CF64 ? 16 : fmt == CL_FORMAT_CS8 ? 2 : 4; }
+
+static int same_dsp(const cl_dsp_cfg *a, const cl_dsp_cfg *b)
+{
+    return a->enabled == b->enabled && a->n_fir == b->n_fir && a->up == b->up && a->down == b->down && a->n_rs == b->n_rs &&
+           a->demod_fm == b->demod_fm && !memcmp(a->fir, b->fir, sizeof(float) * (size_t)a->n_fir) &&
+           !memcmp(a->rs, b->rs, sizeof(float) * (size_t)a->n_rs);
+}
+
+static void lane_free(lane_t *l)
+{
+    if (l->pipe) clhip_rx_pipe_destroy(l->pipe);
+    clhip_free(l->d_in[0]); clhip_free(l->d_in[1]); clhip_free(l->d_out);
+    clhip_host_free(l->h_out); clhip_host_free(l->h_offs);
+    free(l->member); free(l->prev_len); free(l->fast); free(l->len); free(l->got);
+    memset(l, 0, sizeof *l);
+}
+
+void cl_group_unmake(cl_group *g)
+{
+    if (!g) return;
+    clhip_set_device(g->device);
+    if (g->s_in) clhip_stream_sync(g->s_in);
+    if (g->s_k) clhip_stream_sync(g->s_k);
+    if (g->s_out) clhip_stream_sync(g->s_out);
+    pool_stop(&g->pool);
+    cl_group_unregister_buffers(g);
+    for (int i = 0; i < g->n_lanes; i++) lane_free(&g->lane[i]);
+    for (size_t i = 0; i < g->n_ev; i++) clhip_event_destroy(g->ev[i]);
+    clhip_stream_destroy(g->s_in); clhip_stream_destroy(g->s_k); clhip_stream_destroy(g->s_out);
+    free(g->ev); free(g->lane); free(g->dev); free(g->lane_of); free(g->row_of);
+    free(g->reg_base); free(g->reg_dev); free(g->reg_len);
+    free(g);
+}
+
+static char g_make_err[256];
+const char *cl_group_last_error(const cl_group *g) { return g ? g->err : g_make_err; }
+
+cl_group *cl_group_make(cl_device *const *devs, size_t n, const char *const *keys, const char *const *vals, size_t n_kwargs)
+{
+    g_make_err[0] = 0;
+    if (!devs || !n) { cl_seterr(g_make_err, sizeof g_make_err, "cl_group_make: no devices"); return NULL; }
+    for (size_t i = 0; i < n; i++) {
+        if (!devs[i] || !devs[i]->stream || devs[i]->smi->device != devs[0]->smi->device) {
+            cl_seterr(g_make_err, sizeof g_make_err, "cl_group_make: device %zu is missing or on another GPU (a group lives on one GPU)", i);
+            return NULL;
+        }
+        for (size_t j = 0; j < i; j++)
+            if (devs[j] == devs[i]) { cl_seterr(g_make_err, sizeof g_make_err, "cl_group_make: device %zu appears twice", i); return NULL; }
+        if (devs[i]->stream->native_dir != CL_SOAPY_SDR_RX) { cl_seterr(g_make_err, sizeof g_make_err, "cl_group_make: device %zu is not set up for RX", i); return NULL; }
+    }
+    cl_group *g = (cl_group *)calloc(1, sizeof *g);
+    if (!g) return NULL;
+    g->device = devs[0]->smi->device;
+    clhip_set_device(g->device);
+    g->n = n;
+    g->dev = (cl_device **)calloc(n, sizeof *g->dev);
+    g->lane_of = (int *)calloc(n, sizeof(int)); g->row_of = (int *)calloc(n, sizeof(int));
+    g->lane = (lane_t *)calloc(n, sizeof *g->lane);
+    g->reg_base = (uint8_t **)calloc(n, sizeof *g->reg_base); g->reg_dev = (uint8_t **)calloc(n, sizeof *g->reg_dev);
+    g->reg_len = (size_t *)calloc(n, sizeof *g->reg_len);
+    if (!g->dev || !g->lane_of || !g->row_of || !g->lane || !g->reg_base || !g->reg_dev || !g->reg_len) { cl_group_unmake(g); return NULL; }
+    memcpy(g->dev, devs, n * sizeof *g->dev);
+    const char *sub = kwget(keys, vals, n_kwargs, "SUBBATCH"), *ct = kwget(keys, vals, n_kwargs, "COPY_THREADS");
+    g->sub = sub && atoi(sub) > 0 ? atoi(sub) : 8;
+    int threads = ct ? atoi(ct) : 4;
+    if (threads < 0) threads = 0;
+    if (threads > 16) threads = 16;
+    /* lanes: members of one channel type with one stream configuration, in the caller's order */
+    for (size_t i = 0; i < n; i++) {
+        const cl_stream *st = devs[i]->stream;
+        int li = -1;
+        for (int k = 0; k < g->n_lanes && li < 0; k++) {
+            const cl_stream *s0 = devs[g->lane[k].member[0]]->stream;
+            if (g->lane[k].channel == devs[i]->channel && s0->format == st->format && same_dsp(&s0->dsp, &st->dsp)) li = k;
+        }
+        if (li < 0) {
+            li = g->n_lanes++;
+            lane_t *l = &g->lane[li];
+            l->channel = devs[i]->channel; l->format = st->format; l->dsp = st->dsp;
+            l->route = st->dsp.enabled ? ROUTE_PIPE : ROUTE_PLAIN;
+            l->member = (int *)calloc(n, sizeof(int));
+            if (!l->member) { cl_group_unmake(g); return NULL; }
+        }
+        lane_t *l = &g->lane[li];
+        g->lane_of[i] = li; g->row_of[i] = l->n;
+        l->member[l->n++] = (int)i;
+    }
+    size_t n_sub = 0;
+    for (int k = 0; k < g->n_lanes; k++) {
+        lane_t *l = &g->lane[k];
+        const size_t nb = CL_NATIVE_BATCH_LEN, mtu = CL_NATIVE_MTU_SAMPLES;
+        l->in_stride = nb + 256;
+        l->up = l->dsp.enabled ? l->dsp.up : 1; l->down = l->dsp.enabled ? l->dsp.down : 1;
+        if (l->route == ROUTE_PIPE) {
+            l->elem_bytes = l->dsp.demod_fm ? 4 : 8;
+            l->pipe = clhip_rx_pipe_create(l->n, l->channel, l->dsp.fir, l->dsp.n_fir, l->dsp.n_rs ? l->dsp.rs : NULL, l->dsp.n_rs, l->dsp.up,
+                                           l->dsp.down, l->dsp.demod_fm ? CL_PIPE_OUT_FM_DEMOD : CL_PIPE_OUT_IQ);
+            if (!l->pipe) { cl_seterr(g_make_err, sizeof g_make_err, "cl_group_make: %s", clhip_last_error()); cl_group_unmake(g); return NULL; }
+            l->out_stride = ((mtu * (size_t)l->up + (size_t)l->down - 1) / (size_t)l->down + 2 + 31) & ~(size_t)31;
+        } else {
+            l->elem_bytes = fmt_bytes(l->format);
+            l->out_stride = l->in_stride / 4;            /* clhip_smi_unpack: sample k of chunk c lands in slot c * stride / 4 + k */
+        }
+        const size_t in_bytes = (size_t)l->n * l->in_stride + 256, out_bytes = (size_t)l->n * l->out_stride * l->elem_bytes + 256;
+        l->d_in[0] = (uint8_t *)clhip_malloc(in_bytes); l->d_in[1] = (uint8_t *)clhip_malloc(in_bytes);
+        l->d_out = (uint8_t *)clhip_malloc(out_bytes); l->h_out = (uint8_t *)clhip_host_alloc(out_bytes);
+        l->h_offs = (int32_t *)clhip_host_alloc(sizeof(int32_t) * (size_t)l->n + 64);
+        l->d_offs = l->h_offs ? (int32_t *)clhip_host_device_ptr(l->h_offs) : NULL;
+        l->prev_len = (size_t *)calloc((size_t)l->n, sizeof(size_t));
+        l->fast = (uint8_t *)calloc((size_t)l->n, 1); l->len = (size_t *)calloc((size_t)l->n, sizeof(size_t));
+        l->got = (long *)calloc((size_t)l->n, sizeof(long));
+        if (!l->d_in[0] || !l->d_in[1] || !l->d_out || !l->h_out || !l->h_offs || !l->d_offs || !l->prev_len || !l->fast || !l->len || !l->got) {
+            cl_seterr(g_make_err, sizeof g_make_err, "cl_group_make: buffers for %d streams could not be allocated", l->n);
+            cl_group_unmake(g);
+            return NULL;
+        }
+        n_sub += ((size_t)l->n + (size_t)g->sub - 1) / (size_t)g->sub;
+    }
+    g->s_in = clhip_stream_create(); g->s_k = clhip_stream_create(); g->s_out = clhip_stream_create();
+    g->n_ev = 3 * n_sub;
+    g->ev = (void **)calloc(g->n_ev, sizeof(void *));
+    int bad = !g->s_in || !g->s_k || !g->s_out || !g->ev;
+    for (size_t i = 0; !bad && i < g->n_ev; i++) bad = !(g->ev[i] = clhip_event_create());
+    if (bad || pool_start(&g->pool, threads, 16 * n + 64)) { cl_seterr(g_make_err, sizeof g_make_err, "cl_group_make: streams / events / threads"); cl_group_unmake(g); return NULL; }
+    return g;
+}
+
+size_t cl_group_size(const cl_group *g) { return g ? g->n : 0; }
+void cl_group_getStats(const cl_group *g, cl_group_stats *out) { if (out) { if (g) *out = g->stats; else memset(out, 0, sizeof *out); } }
+
+/* Client buffers the members' outputs may be written into by the copy engine directly (no pinned mirror, no memcpy): one
+ * buffer per member, registered with the GPU HERE, explicitly, for as long as the registration stands -- the client keeps them
+ * allocated until cl_group_unregister_buffers / cl_group_unmake.  A call whose buffs[i] lies inside member i's registered
+ * range takes the direct route; any other pointer takes the mirror route. */
+int cl_group_register_buffers(cl_group *g, void *const *buffs, size_t bytes_each)
+{
+    if (!g || !buffs || !bytes_each) return -1;
+    clhip_set_device(g->device);
+    cl_group_unregister_buffers(g);
+    for (size_t i = 0; i < g->n; i++) {
+        const uintptr_t pg = 4096, lo = (uintptr_t)buffs[i] & ~(pg - 1), hi = ((uintptr_t)buffs[i] + bytes_each + pg - 1) & ~(pg - 1);
+        uint8_t *d = (uint8_t *)clhip_host_register((void *)lo, hi - lo);
+        if (!d) {
+            cl_seterr(g->err, sizeof g->err, "cl_group_register_buffers: buffer %zu could not be registered (%s)", i, clhip_last_error());
+            cl_group_unregister_buffers(g);
+            return -1;
+        }
+        g->reg_base[i] = (uint8_t *)lo; g->reg_len[i] = hi - lo; g->reg_dev[i] = d;
+    }
+    return 0;
+}
+
+void cl_group_unregister_buffers(cl_group *g)
+{
+    if (!g || !g->reg_base) return;
+    clhip_set_device(g->device);
+    int any = 0;
+    for (size_t i = 0; i < g->n; i++) any |= g->reg_base[i] != NULL;
+    if (!any) return;
+    if (g->s_out) clhip_stream_sync(g->s_out);          /* nothing may still be writing them */
+    for (size_t i = 0; i < g->n; i++) {
+        if (g->reg_base[i]) clhip_host_unregister(g->reg_base[i]);
+        g->reg_base[i] = NULL; g->reg_dev[i] = NULL; g->reg_len[i] = 0;
+    }
+}
+
+static int registered(const cl_group *g, int m, const void *p, size_t bytes)
+{
+    const uint8_t *q = (const uint8_t *)p;
+    return g->reg_base[m] && q >= g->reg_base[m] && q + bytes <= g->reg_base[m] + g->reg_len[m];
+}
+
+/* ------------------------------------------------------------------------------------------- the call */
+/* Does member m's next read() qualify for the batched route?  Under its FIFO lock: `want` bytes pending as ONE in-place read()
+ * whose head carries the sync pattern (caribou_smi_find_buffer_offset returns 0 exactly then, caribou_smi.c:235-292 -- the
+ * bytes are in pinned host memory, so the host knows before the device has looked); they are staged and their copy to the
+ * lane's row is queued while they cannot move.  Everything else -- short, ragged or slipped reads, bytes given back earlier,
+ * reader threads, the IIR, debug modes -- is the single-stream route's business. */
+static int try_stage(cl_group *g, lane_t *l, int row, size_t want)
+{
+    cl_device *dev = g->dev[l->member[row]];
+    cl_stream *st = dev->stream;
+    cl_smi *smi = dev->smi;
+    if (st->use_async || st->filter_type != CL_DIGFILT_NONE || smi->debug_mode != CL_SMI_DEBUG_NONE || st->native_dir != CL_SOAPY_SDR_RX) return 0;
+    if (st->format != l->format || !want || (want & 15) || want > smi->native_batch_len || (smi->max_read && smi->max_read < want)) return 0;
+    if (l->route == ROUTE_PIPE && clhip_rx_pipe_stream_total(l->pipe, row) % (2ull * (unsigned long long)l->down)) return 0;   /* (off polyphase phase 0: generic kernels, one by one) */
+    cl_smi_readahead_cancel(smi);                              /* what a single-stream call staged ahead is pending again */
+    uint8_t *src = NULL;
+    int ok = 0;
+    pthread_mutex_lock(&smi->fifo_mu);
+    if (!cl_fifo_front_len(&smi->rx) && smi->rx.len >= want) {
+        smi->rx.dma_stream[1] = g->s_in;                       /* a feeder that has to move the buffer waits for this copy first */
+        const size_t got = cl_fifo_stage(&smi->rx, want, &src);
+        if (got == want && cl_smi_head_in_sync(src, got) &&
+            clhip_memcpy_h2d(l->d_in[l->cur_in] + (size_t)row * l->in_stride, src, got, g->s_in) == 0) ok = 1;
+        else if (got) cl_fifo_unstage(&smi->rx, got);
+    }
+    pthread_mutex_unlock(&smi->fifo_mu);
+    return ok;
+}
+
+static void confirm_staged(cl_smi *smi, size_t n)
+{
+    pthread_mutex_lock(&smi->fifo_mu);
+    cl_fifo_confirm(&smi->rx, n);
+    pthread_mutex_unlock(&smi->fifo_mu);
+}
+
+static void count_read(cl_stream *st, int ret)
+{
+    st->stats.read_calls++;
+    if (ret > 0) st->stats.elements_read += (uint64_t)ret; else if (ret == 0) st->stats.reads_empty++;
+}
+
+/* A member off the batched route: its own device's single-stream call, with the group's pipe slot standing where the
+ * device's own pipe would.  Before it, the persistent native buffer of its seam is brought up to date from the raw words of
+ * the previous (batched) call, so that a re-sync finds in the slots it leaves untouched what the reference's
+ * interm_native_buffer would hold (caribou_smi.c:382-389, CaribouliteStream.cpp:304-367). */
+static int single_member(cl_group *g, lane_t *l, int row, void *out, size_t numElems, long timeoutUs)
+{
+    const int m = l->member[row];
+    cl_device *dev = g->dev[m];
+    cl_stream *st = dev->stream;
+    cl_smi *smi = dev->smi;
+    g->stats.single_reads++;
+    if (l->prev_len[row] && (l->route == ROUTE_PIPE || st->format != CL_FORMAT_CS16)) {
+        const size_t pl = l->prev_len[row];
+        if (cl_ensure((void **)&smi->d_iq, &smi->iq_cap, pl / 4 + 8, 4, 0) ||
+            clhip_smi_unpack_aligned(l->channel, l->d_in[l->cur_in ^ 1] + (size_t)row * l->in_stride, pl, CL_FORMAT_CS16, smi->d_iq, NULL, smi->stream))
+            return 0;
+        smi->prev_fused_bytes = 0;
+    }
+    l->prev_len[row] = 0;
+    if (l->route == ROUTE_PLAIN || st->format != l->format || st->native_dir != CL_SOAPY_SDR_RX) {
+        void *const b[1] = {out};
+        return cl_stream_read(dev, st, b, numElems, timeoutUs);
+    }
+    /* pipe lane: Stream::Read (+ the low-pass) leaves the native samples on the device, the group's pipe slot runs from them */
+    if (numElems > st->mtu_size) numElems = st->mtu_size;                        /* CaribouliteStream.cpp:306,328,351 */
+    const int16_t *d_iq = NULL;
+    const int res = cl_stream_read_native(dev, st, numElems, timeoutUs, &d_iq);
+    if (res <= 0 || !d_iq) return 0;
+    uint8_t *d_row = l->d_out + (size_t)row * l->out_stride * l->elem_bytes, *h_row = l->h_out + (size_t)row * l->out_stride * l->elem_bytes;
+    const long got = clhip_rx_pipe_run_range(l->pipe, row, 1, CL_PIPE_IN_CS16, d_iq, 0, (size_t)res, d_row, 0, g->s_k);
+    if (got < 0) { cl_seterr(g->err, sizeof g->err, "cl_group_readStream: %s", clhip_last_error()); return 0; }
+    if (got == 0) return 0;
+    const size_t bytes = (size_t)got * l->elem_bytes;
+    if (registered(g, m, out, bytes)) {
+        if (clhip_memcpy_d2h(out, d_row, bytes, g->s_k) || clhip_stream_sync(g->s_k)) return 0;
+    } else {
+        if (clhip_memcpy_d2h(h_row, d_row, bytes, g->s_k) || clhip_stream_sync(g->s_k)) return 0;
+        memcpy(out, h_row, bytes);
+    }
+    return (int)got;
+}
+
+int cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems, int *rets, long timeoutUs)
+{
+    if (!g || !buffs || !rets) return -1;
+    clhip_set_device(g->device);
+    g->err[0] = 0;
+    g->stats.calls++;
+    for (size_t i = 0; i < g->n; i++) rets[i] = 0;
+    if (!numElems) return 0;
+    for (int k = 0; k < g->n_lanes; k++) memset(g->lane[k].fast, 0, (size_t)g->lane[k].n);
+    int hard = 0;
+    size_t b = 0;                                              /* sub-batch counter over all lanes */
+    /* ---- pass 1: stage, copy in, launch, copy out -- everything queued, nothing waited for */
+    for (int k = 0; k < g->n_lanes && !hard; k++) {
+        lane_t *l = &g->lane[k];
+        const size_t mtu = CL_NATIVE_MTU_SAMPLES;
+        /* CS16 is not clamped to the MTU by the reference (CaribouliteStream.cpp:282-301): longer calls are chunk loops, one by one */
+        const size_t n_el = l->format == CL_FORMAT_CS16 && l->route == ROUTE_PLAIN ? numElems : (numElems > mtu ? mtu : numElems);
+        const size_t want = n_el <= mtu ? n_el * 4 : 0;
+        l->cur_in ^= 1;
+        if (l->pipe && clhip_rx_pipe_epoch_begin(l->pipe)) { hard = 1; break; }
+        for (int a = 0; a < l->n && !hard; a += g->sub, b++) {
+            const int e = a + g->sub < l->n ? a + g->sub : l->n;
+            void *ev_in = g->ev[3 * b], *ev_k = g->ev[3 * b + 1], *ev_out = g->ev[3 * b + 2];
+            int any = 0;
+            for (int r = a; r < e; r++) {
+                l->fast[r] = (uint8_t)try_stage(g, l, r, want);
+                l->len[r] = l->fast[r] ? want : 0;
+                l->got[r] = 0;
+                any |= l->fast[r];
+            }
+            if (!any) { if (clhip_event_record(ev_out, g->s_out)) hard = 1; continue; }
+            hard = clhip_event_record(ev_in, g->s_in) || clhip_stream_wait_event(g->s_k, ev_in);
+            uint8_t *in = l->d_in[l->cur_in];
+            if (!hard && l->route == ROUTE_PIPE) {
+                /* maximal runs of neighbouring batched rows: one fused launch each, straight from the raw words */
+                int r = a;
+                while (r < e && !hard) {
+                    if (!l->fast[r]) { r++; continue; }
+                    int r1 = r + 1;
+                    while (r1 < e && l->fast[r1]) r1++;
+                    const long got = clhip_rx_pipe_run_range(l->pipe, r, r1 - r, CL_PIPE_IN_SMI_WORDS, in + (size_t)r * l->in_stride, l->in_stride / 4, want / 4,
+                                                             l->d_out + (size_t)r * l->out_stride * l->elem_bytes, l->out_stride, g->s_k);
+                    if (got < 0) hard = 1;
+                    for (int q = r; q < r1; q++) l->got[q] = got;
+                    g->stats.launches++;
+                    r = r1;
+                }
+            } else if (!hard) {
+                /* caribou_smi_rx_data_analyze at offset 0 + the format conversion, one launch over the sub-batch's rows (a row
+                 * off the batched route has offset -1: the kernel writes nothing for it) */
+                for (int r = a; r < e; r++) { l->h_offs[r] = l->fast[r] ? 0 : -1; l->got[r] = l->fast[r] ? (long)(want / 4) : 0; }
+                hard = clhip_smi_unpack(l->channel, in + (size_t)a * l->in_stride, (size_t)(e - a - 1) * l->in_stride + want, l->in_stride, want, e - a,
+                                        l->d_offs + a, l->format, l->d_out + (size_t)a * l->out_stride * l->elem_bytes, NULL, g->s_k);
+                g->stats.launches++;
+            }
+            hard = hard || clhip_event_record(ev_k, g->s_k) || clhip_stream_wait_event(g->s_out, ev_k);
+            /* out: rows whose client buffer is registered leave for it directly; the others as one block into the mirror */
+            int lo = -1, hi = -1;
+            for (int r = a; r < e && !hard; r++) {
+                if (!l->fast[r] || l->got[r] <= 0) continue;
+                const size_t bytes = (size_t)l->got[r] * l->elem_bytes;
+                if (registered(g, l->member[r], buffs[l->member[r]], bytes))
+                    hard = clhip_memcpy_d2h(buffs[l->member[r]], l->d_out + (size_t)r * l->out_stride * l->elem_bytes, bytes, g->s_out);
+                else { if (lo < 0) lo = r; hi = r; }
+            }
+            if (!hard && lo >= 0) {
+                const size_t o = (size_t)lo * l->out_stride * l->elem_bytes;
+                const size_t bytes = (size_t)(hi - lo) * l->out_stride * l->elem_bytes + (size_t)l->got[hi] * l->elem_bytes;
+                hard = clhip_memcpy_d2h(l->h_out + o, l->d_out + o, bytes, g->s_out);
+            }
+            hard = hard || clhip_event_record(ev_out, g->s_out);
+        }
+    }
+    /* ---- pass 2: as the sub-batches arrive, their bytes are consumed for good and their rows go to the clients */
+    const size_t n_queued = b;
+    b = 0;
+    for (int k = 0; k < g->n_lanes; k++) {
+        lane_t *l = &g->lane[k];
+        for (int a = 0; a < l->n; a += g->sub, b++) {
+            const int e = a + g->sub < l->n ? a + g->sub : l->n;
+            const int arrived = b < n_queued && !hard && clhip_event_sync(g->ev[3 * b + 2]) == 0;
+            for (int r = a; r < e; r++) {
+                if (!l->fast[r]) continue;
+                const int m = l->member[r];
+                cl_device *dev = g->dev[m];
+                if (!arrived) {                                    /* a runtime error: nothing is delivered, nothing is consumed */
+                    clhip_stream_sync(g->s_in);
+                    pthread_mutex_lock(&dev->smi->fifo_mu);
+                    cl_fifo_unstage(&dev->smi->rx, l->len[r]);
+                    pthread_mutex_unlock(&dev->smi->fifo_mu);
+                    l->fast[r] = 0; l->prev_len[r] = 0;
+                    count_read(dev->stream, 0);
+                    continue;
+                }
+                confirm_staged(dev->smi, l->len[r]);
+                dev->smi->stat_samples += (uint64_t)(l->len[r] / 4);
+                dev->smi->prev_fused_bytes = 0;
+                l->prev_len[r] = l->len[r];
+                const size_t bytes = (size_t)l->got[r] * l->elem_bytes;
+                if (!registered(g, m, buffs[m], bytes))
+                    pool_submit(&g->pool, (uint8_t *)buffs[m], l->h_out + (size_t)r * l->out_stride * l->elem_bytes, bytes);
+                else g->stats.direct_reads++;
+                rets[m] = (int)l->got[r];
+                g->stats.batched_reads++;
+                count_read(dev->stream, rets[m]);
+            }
+        }
+    }
+    /* ---- pass 3: the members off the batched route, one by one (while the pool still copies) */
+    for (int k = 0; k < g->n_lanes; k++) {
+        lane_t *l = &g->lane[k];
+        for (int r = 0; r < l->n; r++) {
+            if (l->fast[r]) continue;
+            const int m = l->member[r];
+            rets[m] = hard ? 0 : single_member(g, l, r, buffs[m], numElems, timeoutUs);
+            count_read(g->dev[m]->stream, rets[m]);
+        }
+        if (l->pipe && clhip_rx_pipe_epoch_end(l->pipe, g->s_k)) hard = 1;
+    }
+    pool_drain(&g->pool);
+    if (hard) {
+        clhip_stream_sync(g->s_in); clhip_stream_sync(g->s_k); clhip_stream_sync(g->s_out);
+        if (!g->err[0]) cl_seterr(g->err, sizeof g->err, "cl_group_readStream: %s", clhip_last_error());
+        g->stats.errors++;
+        return -1;
+    }
+    int delivered = 0;
+    for (size_t i = 0; i < g->n; i++) delivered += rets[i] > 0;
+    return delivered;
+}

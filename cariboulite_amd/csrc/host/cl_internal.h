@@ -136,4 +136,63 @@ struct cl_radio {
     int channel;
 };
 
+/* ---- the Soapy stream / device objects (cl_soapy.c; cl_group.c reads their configuration and drives their seams) ---- */
+#define CL_ZC_SLOTS 8                  /* client buffers a ZEROCOPY stream keeps registered */
+typedef struct {
+    int enabled;
+    int n_fir; float fir[128];
+    int up, down, n_rs; float rs[40];
+    int demod_fm;
+    int mod_fm; double mod_kf;
+} cl_dsp_cfg;
+
+struct cl_stream {
+    cl_device *dev;
+    int format;                  /* CL_FORMAT_*                                 */
+    int native_dir;              /* CL_SOAPY_SDR_RX / TX (setInnerStreamType)    */
+    int stream_active;
+    size_t mtu_size;
+    int filter_type;             /* CL_DIGFILT_*                                 */
+    double sos[3][15];           /* filt20 / filt50 / filt100: 3 biquads x {b0,b1,b2,a1,a2} */
+    clhip_iir *iir[3];           /* filt20 / filt50 / filt100 (CaribouliteStream.hpp:124-131): state per filter, I and Q rails, never
+                                  * reset, not even when the selection changes (CaribouliteStream.cpp:127-141) */
+    int16_t *d_filt; size_t filt_cap;    /* the filtered samples: the IIR runs out of place, so a call can be repeated */
+    cl_stream_stats stats;               /* (iir_overruns: calls the single-pass kernel gave up on; each was repeated on the scan path) */
+    void *d_conv; size_t conv_cap;       /* converted output / TX input staging (bytes) */
+    void *h_conv; size_t h_conv_cap;     /* pinned host mirror */
+    int zero_copy;                       /* kwarg ZEROCOPY=1: client buffers are registered with the GPU and written by the last kernel */
+    struct { uint8_t *base, *dev; size_t len; } zc[CL_ZC_SLOTS];
+    int zc_n, zc_next;
+    cl_dsp_cfg dsp;
+    clhip_rx_pipe *rx_pipe;
+    clhip_tx_pipe *tx_pipe;
+    /* ASYNC mode: reader thread + ring (CaribouliteStream.cpp:16-49,70-75).  The ring's storage is DEVICE memory:
+     * the reader thread's unpacked samples go device-to-device into it while the next native batch is already
+     * being copied host-to-device on a second HIP stream (cl_smi_read_device_ra); the consumer's stages read
+     * them from there, so a sample crosses PCIe once as raw bytes and once as the client's output format. */
+    int use_async;
+    cl_ring *rx_queue;
+    pthread_t reader_thread;
+    volatile int reader_thread_running;
+    int16_t *d_native1;                  /* interm_native_buffer1 of the reference, on the device (reader thread's) */
+    void *astream;                       /* consumer-side HIP stream and linear CS16 device buffer: the reader */
+    int16_t *d_aiq; size_t aiq_cap;      /* thread owns the cl_smi ones */
+};
+
+struct cl_device {
+    cl_smi *smi;
+    cl_radio *radio;
+    int channel;
+    cl_stream *stream;           /* ONE preallocated stream per device (Cariboulite.cpp:30) */
+    char err[256];
+};
+
+
+/* Stream::ReadSamplesGen (CaribouliteStream.cpp:370-382) without the call counters: what cl_readStream runs */
+int cl_stream_read(cl_device *dev, cl_stream *st, void *const *buffs, size_t numElems, long timeoutUs);
+/* Stream::Read + Stream::ReadSamples(int16*) (CaribouliteStream.cpp:260-301) with the result left on the DEVICE, complete:
+ * *d_iq = the call's native samples (through the selected low-pass, overrun redo included).  Returns what Stream::Read returns
+ * (errors squashed to 0). */
+int cl_stream_read_native(cl_device *dev, cl_stream *st, size_t n, long timeout_us, const int16_t **d_iq);
+
 #endif

@@ -46,6 +46,10 @@ _SIGS = {
     "clhip_event_record": (C.c_int, [C.c_void_p, C.c_void_p]),
     "clhip_event_elapsed_ms": (C.c_float, [C.c_void_p, C.c_void_p]),
     "clhip_stream_wait_event": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "clhip_event_sync": (C.c_int, [C.c_void_p]),
+    "clhip_debug_ops": (C.c_size_t, [C.c_void_p, C.c_size_t]),
+    "clhip_debug_ops_dump": (None, [C.c_int]),
+    "clhip_debug_copy_counters": (None, [C.c_void_p]),
     "clhip_smi_find_offsets": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]),
     "clhip_smi_unpack": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p,
                                    C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -81,6 +85,11 @@ _SIGS = {
     "clhip_rx_pipe_set_diag": (None, [C.c_void_p, C.c_void_p]),
     "clhip_rx_pipe_set_sync_check": (None, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "clhip_rx_pipe_rollback": (C.c_int, [C.c_void_p]),
+    "clhip_rx_pipe_epoch_begin": (C.c_int, [C.c_void_p]),
+    "clhip_rx_pipe_run_range": (C.c_long, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "clhip_rx_pipe_epoch_end": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "clhip_rx_pipe_out_count_stream": (C.c_size_t, [C.c_void_p, C.c_int, C.c_size_t]),
+    "clhip_rx_pipe_stream_total": (C.c_ulonglong, [C.c_void_p, C.c_int]),
     "clhip_rx_pipe_set_host_sink": (None, [C.c_void_p, C.c_void_p]),
     "clhip_rx_pipe_set_offs_writeback": (None, [C.c_void_p, C.c_int]),
     "clhip_rx_pipe_out_elem_bytes": (C.c_size_t, [C.c_void_p]),
@@ -242,6 +251,24 @@ class RxPipe:
 
     def rollback(self):
         return lib().clhip_rx_pipe_rollback(self.h)
+
+    # streams advancing independently (stream groups): an epoch of range runs
+    def epoch_begin(self):
+        _check(lib().clhip_rx_pipe_epoch_begin(self.h), "clhip_rx_pipe_epoch_begin")
+
+    def run_range(self, first, count, in_kind, d_in, in_stride, n_in, d_out, out_stride, stream=None):
+        """d_in / d_out: tensors (or views) that start at stream `first`'s row"""
+        return _check(lib().clhip_rx_pipe_run_range(self.h, first, count, in_kind, ptr(d_in), in_stride, n_in, ptr(d_out), out_stride,
+                                                    stream if stream is not None else current_stream()), "clhip_rx_pipe_run_range")
+
+    def epoch_end(self, stream=None):
+        _check(lib().clhip_rx_pipe_epoch_end(self.h, stream if stream is not None else current_stream()), "clhip_rx_pipe_epoch_end")
+
+    def out_count_stream(self, s, n_in):
+        return lib().clhip_rx_pipe_out_count_stream(self.h, s, n_in)
+
+    def stream_total(self, s):
+        return lib().clhip_rx_pipe_stream_total(self.h, s)
 
     def run_smi(self, d_bytes, stream_stride_bytes, n_bytes, chunk_len_bytes, d_offs, d_cs16, d_out, out_stride,
                 h_offs=None, stream=None):

@@ -95,6 +95,14 @@ _SIGS = {
     "cl_getStreamStats": (None, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "cl_smi_get_stats": (None, [C.c_void_p, C.c_void_p]),
     "cl_stream_set_iir_poll_bound": (None, [C.c_void_p, C.c_int]),
+    "cl_group_make": (C.c_void_p, [C.POINTER(C.c_void_p), C.c_size_t, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_size_t]),
+    "cl_group_unmake": (None, [C.c_void_p]),
+    "cl_group_size": (C.c_size_t, [C.c_void_p]),
+    "cl_group_readStream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t, C.POINTER(C.c_int), C.c_long]),
+    "cl_group_last_error": (C.c_char_p, [C.c_void_p]),
+    "cl_group_getStats": (None, [C.c_void_p, C.c_void_p]),
+    "cl_group_register_buffers": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t]),
+    "cl_group_unregister_buffers": (None, [C.c_void_p]),
     "cl_design_lowpass": (C.c_int, [C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p]),
     "cl_design_butter_lowpass": (C.c_int, [C.c_int, C.c_double, C.c_double, C.c_void_p]),
 }
@@ -336,3 +344,49 @@ class Device:
 
     def setStreamIirPollBound(self, st, polls):
         lib().cl_stream_set_iir_poll_bound(st, int(polls))
+
+
+class Group:
+    """cl_group: N devices of one GPU read in one call (include/cariboulite_hip.h, "stream group").  Make it after
+    setupStream of every member; `readStream(buffs, numElems)` returns (streams delivered, [ret per member])."""
+
+    def __init__(self, devices, args=None):
+        self.devices = list(devices)                # kept alive with the group
+        K, V, n = _kwargs(args)
+        arr = (C.c_void_p * len(self.devices))(*[d.h for d in self.devices])
+        self.h = lib().cl_group_make(arr, len(self.devices), K, V, n)
+        if not self.h:
+            raise RuntimeError(lib().cl_group_last_error(None).decode())
+        self._rets = (C.c_int * len(self.devices))()
+        self._ptrs = (C.c_void_p * len(self.devices))()
+
+    def readStream(self, buffs, numElems, timeoutUs=100000):
+        for i, b in enumerate(buffs):
+            self._ptrs[i] = b.ctypes.data
+        n = lib().cl_group_readStream(self.h, self._ptrs, numElems, self._rets, timeoutUs)
+        return n, list(self._rets)
+
+    def registerBuffers(self, buffs):
+        arr = (C.c_void_p * len(buffs))(*[b.ctypes.data for b in buffs])
+        if lib().cl_group_register_buffers(self.h, arr, buffs[0].nbytes) != 0:
+            raise RuntimeError(self.lastError())
+        self._registered = list(buffs)              # the client keeps them allocated while registered
+
+    def unregisterBuffers(self):
+        lib().cl_group_unregister_buffers(self.h)
+        self._registered = None
+
+    def lastError(self):
+        return lib().cl_group_last_error(self.h).decode()
+
+    def stats(self):
+        out = (C.c_uint64 * 6)()
+        lib().cl_group_getStats(self.h, out)
+        return dict(zip(("calls", "batched_reads", "single_reads", "direct_reads", "launches", "errors"), [int(v) for v in out]))
+
+    def close(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.cl_group_unmake(self.h)
+        self.h = None
+
+    __del__ = close

@@ -96,11 +96,27 @@ void        clhip_host_unregister(void *h_ptr);
 /* host <-> device copies on a stream.  Host memory that is not page-locked (not from clhip_host_alloc / hipHostMalloc, not
  * registered) is copied in pieces of 512 KiB: the HIP runtime would pin the caller's pages in place for a pageable copy of
  * 1 MiB and more and let the copy engine into the process's heap, which has ended long-lived processes with a GPU page
- * fault on a host address; in pieces every byte goes through the runtime's own pinned staging buffers.
- * CLHIP_PAGEABLE_WHOLE=1 in the environment restores the single copy (A/B). */
+ * fault on a host address; in pieces every byte goes through the runtime's own pinned staging buffers. */
 int         clhip_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream);
 int         clhip_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream);
 int         clhip_memcpy_d2d(void *d_dst, const void *d_src, size_t bytes, void *stream);
+/* Diagnostics: the last 256 things this library asked the runtime to do with host memory it does not own -- registrations,
+ * releases, copies above one piece (what kind of memory it found) -- so that a GPU page fault on a host address can be set
+ * against them.  _ops copies the ring (oldest first), _ops_dump writes it as text with write(2) only (callable from a signal
+ * handler: tests/cpp/abrt_trace.c does on SIGABRT), _copy_counters: [0] pageable copies made in pieces, [1] page-locked
+ * copies made whole, [2] the largest pageable range ever handed to ONE runtime copy (bytes; never above 512 KiB), [3]
+ * pageable bytes copied. */
+#define CLHIP_OP_REGISTER        1
+#define CLHIP_OP_REGISTER_FAILED 2
+#define CLHIP_OP_UNREGISTER      3
+#define CLHIP_OP_H2D_PIECES      4
+#define CLHIP_OP_D2H_PIECES      5
+#define CLHIP_OP_H2D_LOCKED      6
+#define CLHIP_OP_D2H_LOCKED      7
+typedef struct { uint64_t seq; uint32_t op; uint32_t pad; uint64_t base; uint64_t len; } clhip_op_record;
+size_t      clhip_debug_ops(clhip_op_record *out, size_t max);
+void        clhip_debug_ops_dump(int fd);
+void        clhip_debug_copy_counters(uint64_t out[4]);
 int         clhip_memset(void *d_dst, int value, size_t bytes, void *stream);
 void       *clhip_stream_create(void);
 void        clhip_stream_destroy(void *stream);
@@ -111,6 +127,7 @@ void        clhip_event_destroy(void *event);
 int         clhip_event_record(void *event, void *stream);
 float       clhip_event_elapsed_ms(void *start, void *stop); /* synchronises on stop */
 int         clhip_stream_wait_event(void *stream, void *event); /* later work on `stream` waits for `event` */
+int         clhip_event_sync(void *event);                       /* the host waits for `event` */
 
 /*
  * Sync search -- replaces caribou_smi_find_buffer_offset
@@ -535,6 +552,46 @@ void   cl_getStreamStats(const cl_device *dev, const cl_stream *stream, cl_strea
 unsigned long cl_stream_iir_overruns(const cl_stream *stream);         /* = iir_overruns above */
 /* test hook: hands clhip_iir_set_poll_bound to the stream's three filters */
 void   cl_stream_set_iir_poll_bound(cl_stream *stream, int polls);
+
+/* --- stream group: N devices of one GPU read in one call ------------------------------------------------------
+ * The reference's unit is one SoapySDR device per channel (soapy_api/SoapyCariboulite.cpp:46-69: every board enumerates an
+ * S1G and a HiF device), each readStream its own caribou_smi_read chunk loop (caribou_smi/caribou_smi.c:632-682,
+ * soapy_api/CaribouliteStreamFunctions.cpp:239-254).  cl_group_readStream(g, buffs, numElems, rets, timeoutUs) IS
+ *     for i in 0 .. n-1:  rets[i] = cl_readStream(devs[i], stream_i, &buffs[i], numElems, ...)
+ * -- per-stream state, re-sync, untouched slots and the "-3" / timeout squashing exactly those of the N single calls, every
+ * stream's result independent of its neighbours' -- executed as ONE pipeline: the pending native batches of the streams that
+ * are in sync (the host sees the sync words in its pinned FIFO memory) go to the device SUBBATCH streams at a time, one
+ * launch per sub-batch (the fused unpack + FIR + resample / demod kernel over several streams, or the unpack in the
+ * stream format), while the sub-batch before it is on its way back and the one behind it on its way in (three HIP
+ * streams), and the last hop into the clients' pageable buffers is shared by COPY_THREADS threads.  A stream that cannot take
+ * that route (a slipped or lost chunk, a short read, the IIR, ASYNC=1, a debug mode) takes its own device's single-stream
+ * route inside the same call.
+ * Make the group AFTER cl_setupStream of every member (RX); members are grouped by channel type and stream configuration
+ * (format, FIR / RESAMP / DEMOD kwargs); a group with extension stages owns their state (one n-stream pipe per
+ * configuration), so its members are read through the group from then on.  kwargs: SUBBATCH=<streams per launch> (8),
+ * COPY_THREADS=<n> (4; 0 = the caller copies).  Returns the number of streams that delivered (> 0 elements), or -1 on a
+ * runtime error (cl_group_last_error; NULL group = the last cl_group_make failure). */
+typedef struct cl_group cl_group;
+typedef struct {
+    uint64_t calls;              /* cl_group_readStream calls                                                      */
+    uint64_t batched_reads;      /* member reads that took the batched route                                       */
+    uint64_t single_reads;       /* member reads that took their device's single-stream route                      */
+    uint64_t direct_reads;       /* batched reads the copy engine wrote into a registered client buffer            */
+    uint64_t launches;           /* kernel launches of the batched route                                           */
+    uint64_t errors;             /* calls that ended with a runtime error                                          */
+} cl_group_stats;
+cl_group   *cl_group_make(cl_device *const *devs, size_t n_devs, const char *const *keys, const char *const *vals, size_t n_kwargs);
+void        cl_group_unmake(cl_group *g);
+size_t      cl_group_size(const cl_group *g);
+int         cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems, int *rets, long timeoutUs);
+const char *cl_group_last_error(const cl_group *g);
+void        cl_group_getStats(const cl_group *g, cl_group_stats *out);
+/* Explicit zero-copy: one client buffer per member (bytes_each long), registered with the GPU here and kept registered until
+ * _unregister_buffers / cl_group_unmake -- the client keeps them allocated that long.  A call whose buffs[i] lies inside
+ * member i's registered buffer has the copy engine write it directly (no pinned mirror, no memcpy); any other pointer takes
+ * the default route.  Nothing is ever registered behind the client's back. */
+int         cl_group_register_buffers(cl_group *g, void *const *buffs, size_t bytes_each);
+void        cl_group_unregister_buffers(cl_group *g);
 
 /* host helper: scipy.signal.firwin(ntaps, cutoff, window="hamming", fs=fs)
  * (the tap design SURVEY.md section 8 a13 specifies), rounded to fp32 */

@@ -1,0 +1,226 @@
+"""-m gpu: the stream group at the Soapy boundary (cl_group_readStream, cariboulite_amd/csrc/host/cl_group.c).
+
+The contract: one group call IS N single cl_readStream calls -- the reference's unit is one Soapy device per channel
+(soapy_api/SoapyCariboulite.cpp:46-69), each call its own caribou_smi_read chunk loop (caribou_smi/caribou_smi.c:632-682,
+soapy_api/CaribouliteStreamFunctions.cpp:239-254) -- so every stream of a group must deliver, call after call, bit for bit
+what its own device delivers when it is read alone with the same bytes: outputs, return values, untouched slots of the
+client's buffer, pending bytes, counters; slipped, lost and short batches in some streams must not be seen by the others.
+The single-stream route is itself checked against the oracle elsewhere (test_gpu_soapy.py, test_gpu_sync_recovery.py); a few
+streams are checked against the oracle here as well."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+NB = 524288
+MTU = 131072
+SENT = -21846
+
+
+@pytest.fixture(scope="module")
+def S():
+    import torch
+    from cariboulite_amd import hip, soapy
+    assert torch.cuda.is_available() and hip.require_gpu().startswith("gfx950")
+    return soapy
+
+
+def batch_bytes(stream, call, ch):
+    from cariboulite_amd import synth
+    return synth.smi_stream_bytes(MTU, ch, stream=200 + stream, n0=call * MTU)[0].copy()
+
+
+def slipped(b, k):
+    junk = (np.arange(k, dtype=np.uint8) * 7 + 3) & 0x3F          # never looks like a sync word
+    return np.concatenate([junk, b[: b.size - k]])
+
+
+def make_devices(S, n, fmt, args, channel_of):
+    devs, sts = [], []
+    for i in range(n):
+        d = S.Device(dict(driver="Cariboulite", channel=channel_of(i)))
+        sts.append(d.setupStream(S.SOAPY_SDR_RX, fmt, args=args))
+        d.activateStream(sts[-1])
+        devs.append(d)
+    return devs, sts
+
+
+def sentinel_buffers(n, shape, dtype):
+    fill = np.nan if np.issubdtype(dtype, np.floating) else SENT if dtype == np.int16 else -86
+    return [np.full(shape, fill, dtype) for _ in range(n)]
+
+
+def same(a, b):
+    return a.shape == b.shape and a.tobytes() == b.tobytes()       # NaN sentinels included
+
+
+def run_script(S, n, fmt, args, dtype, out_shape, script, n_calls, channel_of=lambda i: "S1G" if i % 3 else "HiF", group_args=None,
+               num_elems=MTU, register=False):
+    """`script[(call, stream)]` = how that stream's batch of that call is damaged: ("slip", k) | ("lost",) | ("short", bytes) | ("none",).
+    Runs the same byte streams through a group and through n lone devices; returns per call (group rets, single rets)."""
+    gdevs, _ = make_devices(S, n, fmt, args, channel_of)
+    sdevs, ssts = make_devices(S, n, fmt, args, channel_of)
+    grp = S.Group(gdevs, group_args)
+    gb = sentinel_buffers(n, out_shape, dtype)
+    sb = sentinel_buffers(n, out_shape, dtype)
+    if register:
+        grp.registerBuffers(gb)
+    log = []
+    for c in range(n_calls):
+        for i in range(n):
+            ch = 0 if channel_of(i) == "S1G" else 1
+            b = batch_bytes(i, c, ch)
+            what = script.get((c, i), ("good",))
+            if what[0] == "slip":
+                b = slipped(b, what[1])
+            elif what[0] == "lost":
+                b[:] = 0
+            elif what[0] == "short":
+                b = b[: what[1]]
+            elif what[0] == "none":
+                b = b[:0]
+            if b.size:
+                gdevs[i].feedSmiBytes(b); sdevs[i].feedSmiBytes(b)
+        for x in gb + sb:
+            x[...] = np.nan if np.issubdtype(dtype, np.floating) else SENT if dtype == np.int16 else -86
+        delivered, rets = grp.readStream(gb, num_elems)
+        srets = [sdevs[i].readStream(ssts[i], [sb[i]], num_elems).ret for i in range(n)]
+        assert delivered == sum(r > 0 for r in rets)
+        assert rets == srets, (c, rets, srets)
+        for i in range(n):
+            assert same(gb[i], sb[i]), f"call {c} stream {i} ({script.get((c, i), ('good',))}): group and lone device differ"
+            assert gdevs[i].pendingSmiBytes() == sdevs[i].pendingSmiBytes(), (c, i)
+        log.append((rets, [x.copy() for x in gb]))
+    gstats = [gdevs[i].smiStats() for i in range(n)]
+    sstats = [sdevs[i].smiStats() for i in range(n)]
+    for i in range(n):
+        for key in ("samples_read", "resyncs", "sync_losses"):
+            assert gstats[i][key] == sstats[i][key], (i, key, gstats[i], sstats[i])
+    st = grp.stats()
+    grp.close()
+    for d in gdevs + sdevs:
+        d.close()
+    return log, st
+
+
+def test_32_streams_fir64_resample_3_2_with_slipped_lost_and_short_batches(S, orc):
+    """BASELINE config 2's stages at the boundary, 32 streams (S1G and HiF mixed: two lanes), SUBBATCH=8: two streams with a
+    slipped and one with a lost batch in call 1, a short read in call 3, everything in sync otherwise -- each stream equal to
+    its own lone device bit for bit, and stream 3 (slipped in call 1) / 9 (lost) / 0 against the oracle chain."""
+    n, calls = 32, 5
+    script = {(1, 3): ("slip", 3), (1, 17): ("slip", 6), (1, 9): ("lost",), (3, 5): ("short", NB // 2), (3, 21): ("none",)}
+    args = {"FIR": "64:1000000", "RESAMP": "3/2"}
+    log, st = run_script(S, n, S.SOAPY_SDR_CF32, args, np.float32, (MTU * 3 // 2 + 8, 2), script, calls)
+    assert st["calls"] == calls and st["errors"] == 0
+    # a stream that took the single route at call c with an odd number of samples behind it stays there; here: 5 damaged reads + what follows a short one
+    assert st["single_reads"] >= 5 and st["batched_reads"] >= n * calls - 8
+    assert st["launches"] <= calls * 8                     # 2 lanes x <= 3 sub-batches, runs split around the damaged streams
+    t = load_golden("taps.npz")
+    for i in (0, 3, 9):
+        ch = 0 if i % 3 else 1
+        fir, rs = orc.FIR(t["fir64_c2"]), orc.Resampler(t["rs_3_2"], 3, 2)
+        interm = np.zeros((MTU + 2, 2), np.int16)
+        for c in range(calls):
+            b = batch_bytes(i, c, ch)
+            what = script.get((c, i), ("good",))
+            if what[0] == "slip":
+                b = slipped(b, what[1])
+            elif what[0] == "lost":
+                b[:] = 0
+            ret, iq, _ = orc.smi_read(ch, b, MTU, NB, fill=SENT)
+            rets, bufs = log[c]
+            if ret < 0:
+                assert rets[i] == 0 and np.isnan(bufs[i]).all()
+                continue
+            touched = (iq != SENT).any(axis=1)
+            interm[touched] = iq[touched]
+            want = rs.f64(fir.f64(orc.cs16_to_cf32(interm[:MTU])))
+            assert rets[i] == want.shape[0]
+            assert np.max(np.abs(bufs[i][: rets[i]] - want)) <= 1e-5 * np.max(np.abs(want)), (i, c)
+            assert np.isnan(bufs[i][rets[i]:]).all()
+
+
+@pytest.mark.parametrize("fmt,dtype,cols", [("CS16", np.int16, 2), ("CF32", np.float32, 2), ("CS8", np.int8, 2), ("CF64", np.float64, 2)])
+def test_plain_formats_equal_lone_devices(S, orc, fmt, dtype, cols):
+    """the reference's own formats (no extension stages): the unpack + conversion of a whole sub-batch is one launch; slipped,
+    lost and short batches as above.  CS16 also against the oracle: slot for slot, sentinels where the reference writes nothing."""
+    n, calls = 11, 4
+    script = {(1, 2): ("slip", 5), (1, 7): ("lost",), (2, 4): ("short", NB - 4096), (2, 2): ("slip", 1), (3, 10): ("none",)}
+    log, st = run_script(S, n, fmt, None, dtype, (MTU + 2, cols), script, calls, group_args={"SUBBATCH": "4", "COPY_THREADS": "2"})
+    assert st["errors"] == 0 and st["batched_reads"] >= n * calls - 7
+    if fmt == "CS16":
+        for i in (0, 2, 7):
+            ch = 0 if i % 3 else 1
+            for c in range(calls):
+                b = batch_bytes(i, c, ch)
+                what = script.get((c, i), ("good",))
+                if what[0] == "slip":
+                    b = slipped(b, what[1])
+                elif what[0] == "lost":
+                    b[:] = 0
+                ret, iq, _ = orc.smi_read(ch, b, MTU, NB, fill=SENT)
+                rets, bufs = log[c]
+                assert rets[i] == max(ret, 0)
+                if ret > 0:
+                    assert np.array_equal(bufs[i][:MTU], iq[:MTU]), (i, c)
+                else:
+                    assert (bufs[i] == SENT).all()
+
+
+def test_fm_demod_lane_and_copy_on_the_calling_thread(S):
+    """config 3's stages (FIR64 + FM demod, real fp32 out) through a group without copy threads, sub-batches of 3"""
+    script = {(0, 1): ("slip", 2), (2, 0): ("lost",)}
+    args = {"FIR": "64:100000", "DEMOD": "FM"}
+    log, st = run_script(S, 7, S.SOAPY_SDR_CF32, args, np.float32, (MTU + 8,), script, 3, group_args={"SUBBATCH": "3", "COPY_THREADS": "0"})
+    assert st["errors"] == 0 and st["batched_reads"] == 7 * 3 - 2 - 0
+
+
+def test_registered_client_buffers_take_the_direct_route(S):
+    """cl_group_register_buffers: the copy engine writes the clients' buffers itself -- same bytes as the mirror route, which a
+    pointer outside the registered range still takes"""
+    script = {(1, 2): ("slip", 3)}
+    args = {"FIR": "64:1000000", "RESAMP": "3/2"}
+    log, st = run_script(S, 6, S.SOAPY_SDR_CF32, args, np.float32, (MTU * 3 // 2 + 8, 2), script, 3, register=True)
+    assert st["direct_reads"] == 6 * 3 - 1 and st["errors"] == 0
+
+
+def test_a_member_with_the_iir_selected_is_read_by_its_own_device(S):
+    """setBandwidth(< 160 kHz) on one member (Cariboulite.cpp:395-417): its reads take the single-stream route inside the group
+    call, filter state and all, the others stay batched"""
+    n, calls = 5, 3
+    gdevs, _ = make_devices(S, n, S.SOAPY_SDR_CS16, None, lambda i: "S1G")
+    sdevs, ssts = make_devices(S, n, S.SOAPY_SDR_CS16, None, lambda i: "S1G")
+    gdevs[2].setBandwidth(S.SOAPY_SDR_RX, 0, 100e3); sdevs[2].setBandwidth(S.SOAPY_SDR_RX, 0, 100e3)
+    grp = S.Group(gdevs)
+    gb = sentinel_buffers(n, (MTU + 2, 2), np.int16); sb = sentinel_buffers(n, (MTU + 2, 2), np.int16)
+    for c in range(calls):
+        for i in range(n):
+            b = batch_bytes(i, c, 0)
+            gdevs[i].feedSmiBytes(b); sdevs[i].feedSmiBytes(b)
+        _, rets = grp.readStream(gb, MTU)
+        srets = [sdevs[i].readStream(ssts[i], [sb[i]], MTU).ret for i in range(n)]
+        assert rets == srets == [MTU] * n
+        for i in range(n):
+            assert same(gb[i], sb[i]), (c, i)
+    st = grp.stats()
+    assert st["single_reads"] == calls and st["batched_reads"] == (n - 1) * calls
+    grp.close()
+    for d in gdevs + sdevs:
+        d.close()
+
+
+def test_group_make_refuses_what_it_cannot_read(S):
+    d0 = S.Device(dict(driver="Cariboulite", channel="S1G"))
+    d0.setupStream(S.SOAPY_SDR_TX, S.SOAPY_SDR_CS16)
+    with pytest.raises(RuntimeError, match="not set up for RX"):
+        S.Group([d0])
+    d1 = S.Device(dict(driver="Cariboulite", channel="S1G"))
+    d1.setupStream(S.SOAPY_SDR_RX, S.SOAPY_SDR_CS16)
+    with pytest.raises(RuntimeError, match="twice"):
+        S.Group([d1, d1])
+    g = S.Group([d1])
+    buf = np.zeros((MTU, 2), np.int16)
+    assert g.readStream([buf], MTU) == (0, [0])           # nothing pending: every member times out like the lone device
+    assert g.readStream([buf], 0) == (0, [0])
+    g.close(); d0.close(); d1.close()

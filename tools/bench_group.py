@@ -1,0 +1,138 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive AGGREGATE rate of the Soapy boundary over many streams: host SMI bytes in (cl_smi_feed_bytes into every
+device's pinned FIFO), host samples out into the clients' pageable numpy buffers through cl_group_readStream (one MTU =
+131072 samples per stream and call), priced against the box's own concurrent H2D + D2H ceiling for the same message shape
+(tools/microbench/pcie_duplex, measured in the same run).  Never bench.py's headline `value` (inputs resident in HBM).
+
+    python tools/bench_group.py [--streams 32] [--calls 12] [--cases cf32_fir64_rs_3_2,cs16,cf32] [--sub 8] [--threads 4]
+
+One JSON object: per case the group's rate (default route: pinned mirror + copy threads), the same with registered client
+buffers (the copy engine writes them directly), the same N devices read ONE BY ONE through cl_readStream (round 3's way), and
+`roofline: {bound: "pcie", ...}`."""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+MTU, NB = 131072, 524288
+
+CASES = {
+    "cs16": ("CS16", "int16", 2, None, 4.0),
+    "cf32": ("CF32", "float32", 2, None, 8.0),
+    "cf32_fir64_rs_3_2": ("CF32", "float32", 2, {"FIR": "64:1000000", "RESAMP": "3/2"}, 12.0),
+    "cf32_fir64_fm_demod": ("CF32", "float32", 1, {"FIR": "64:100000", "DEMOD": "FM"}, 4.0),
+}
+
+
+def pcie_shape(in_mib, out_mib):
+    exe = os.path.join(ROOT, "tools", "microbench", "pcie_duplex")
+    if not os.path.exists(exe):
+        return None
+    try:
+        out = subprocess.run([exe, str(in_mib), str(out_mib)], capture_output=True, text=True, timeout=120, check=True).stdout
+        return json.loads(out[out.index("{"):])["shape"]
+    except Exception as e:                                 # the rows stay, unpriced
+        print("pcie_duplex failed:", e, file=sys.stderr)
+        return None
+
+
+def run_case(name, a):
+    import numpy as np
+    from cariboulite_amd import soapy as S, synth
+    fmt, dt, width, args, out_b = CASES[name]
+    n, K = a.streams, a.calls
+    words = [synth.smi_stream_bytes(K * MTU, i % 2, stream=i)[0] for i in range(min(n, 4))]      # a few distinct streams, reused
+    res = {}
+    n_out = MTU * 3 // 2 + 8 if args and "RESAMP" in args else MTU
+    shape = (n_out, width) if width > 1 else (n_out,)
+
+    def devices():
+        devs, sts = [], []
+        for i in range(n):
+            d = S.Device(dict(driver="Cariboulite", channel="S1G" if i % 2 == 0 else "HiF"))
+            sts.append(d.setupStream(S.SOAPY_SDR_RX, fmt, args=args))
+            d.activateStream(sts[-1])
+            devs.append(d)
+        return devs, sts
+
+    def feed(devs):
+        for i, d in enumerate(devs):
+            d.feedSmiBytes(words[i % len(words)])        # (device i and words i % 4 have the same channel type)
+
+    for mode in a.modes.split(","):
+        devs, sts = devices()
+        bufs = [np.zeros(shape, dt) for _ in range(n)]
+        grp = None
+        if mode != "one_by_one":
+            grp = S.Group(devs, {"SUBBATCH": str(a.sub), "COPY_THREADS": str(a.threads)})
+            if mode == "registered":
+                grp.registerBuffers(bufs)
+        best, got_total = None, 0
+        for rep in range(a.reps + 1):
+            feed(devs)
+            t0 = time.perf_counter()
+            got = 0
+            for k in range(K):
+                if grp is not None:
+                    nd, rets = grp.readStream(bufs, MTU)
+                    assert nd == n, (mode, k, nd, grp.lastError())
+                    got += sum(rets)
+                else:
+                    for i in range(n):
+                        r = devs[i].readStream(sts[i], [bufs[i]], MTU).ret
+                        assert r > 0
+                        got += r
+            dt_s = time.perf_counter() - t0
+            if rep and (best is None or dt_s < best):
+                best, got_total = dt_s, got
+        res[mode] = {"msps_in": round(n * K * MTU / best / 1e6, 1), "ms_per_group_call": round(best / K * 1e3, 4),
+                     "us_per_stream_call": round(best / K / n * 1e6, 2), "out_elems_per_call": got_total // K}
+        if grp is not None:
+            res[mode]["stats"] = grp.stats()
+            grp.close()
+        for d in devs:
+            d.close()
+    in_mib, out_mib = n * NB >> 20, max(int(n * MTU * out_b) >> 20, 1)
+    sh = pcie_shape(in_mib, out_mib)
+    if sh:
+        ceiling = n * MTU / (sh["duplex_ms"] * 1e-3) / 1e6
+        res["roofline"] = {"bound": "pcie", "unit": "Msamples/s", "peak": round(ceiling, 1),
+                           "peak_note": f"{in_mib} MiB H2D and {out_mib} MiB D2H queued together on two streams, pinned memory, copy engine: "
+                                        f"{sh['duplex_ms']:.3f} ms (alone: H2D {sh['h2d_GBs']} GB/s, D2H {sh['d2h_GBs']} GB/s)",
+                           **{f"frac_{m}": round(res[m]["msps_in"] / ceiling, 3) for m in res if m in ("default", "registered", "one_by_one")}}
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--streams", type=int, default=32)
+    ap.add_argument("--calls", type=int, default=12)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--sub", type=int, default=8)
+    ap.add_argument("--threads", type=int, default=4)
+    ap.add_argument("--cases", default="cf32_fir64_rs_3_2,cs16,cf32")
+    ap.add_argument("--modes", default="default,registered,one_by_one")
+    ap.add_argument("--only", default=None, help="(internal) one case in this process")
+    a = ap.parse_args()
+    if a.only:
+        print(json.dumps({a.only: run_case(a.only, a)}))
+        return 0
+    # one fresh process per case: what a call costs must not depend on what the process registered or freed before
+    out = {"streams": a.streams, "calls": a.calls, "subbatch": a.sub, "copy_threads": a.threads,
+           "runtime_env": {"GPU_PINNED_MIN_XFER_SIZE": os.environ.get("GPU_PINNED_MIN_XFER_SIZE", "(unset: the runtime's default)")}}
+    for c in a.cases.split(","):
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--only", c] + [x for x in sys.argv[1:]], capture_output=True, text=True)
+        if r.returncode:
+            out[c] = {"error": r.stderr[-1500:]}
+            continue
+        out.update(json.loads(r.stdout[r.stdout.index("{"):]))
+    print(json.dumps(out, indent=1))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

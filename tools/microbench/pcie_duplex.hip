@@ -48,9 +48,11 @@ static void *copy_thread(void *p)
     return NULL;
 }
 
-int main()
+int main(int argc, char **argv)
 {
-    const size_t MB = 1 << 20, in_b = 16 * MB, out_b = 48 * MB;
+    // pcie_duplex <in_MiB> <out_MiB>: only the copy-engine ceilings of that shape (tools/bench_group.py prices its rows with it)
+    const bool shape_only = argc == 3;
+    const size_t MB = 1 << 20, in_b = (shape_only ? (size_t)atoi(argv[1]) : 16) * MB, out_b = (shape_only ? (size_t)atoi(argv[2]) : 48) * MB;
     uint8_t *h_in, *h_out, *d_in, *d_out;
     if (hipHostMalloc((void **)&h_in, in_b, hipHostMallocMapped) != hipSuccess || hipHostMalloc((void **)&h_out, out_b, hipHostMallocMapped) != hipSuccess ||
         hipMalloc((void **)&d_in, in_b) != hipSuccess || hipMalloc((void **)&d_out, out_b) != hipSuccess) { fprintf(stderr, "alloc failed\n"); return 1; }
@@ -60,13 +62,14 @@ int main()
     const int reps = 20;
     auto timeit = [&](auto fn) { fn(); hipDeviceSynchronize(); const double t0 = now_s(); for (int r = 0; r < reps; r++) fn(); hipDeviceSynchronize(); return (now_s() - t0) / reps; };
     printf("{");
-    for (int small = 0; small < 2; small++) {
+    for (int small = 0; small < (shape_only ? 1 : 2); small++) {
         const size_t ib = small ? in_b / 4 : in_b, ob = small ? out_b / 4 : out_b;
         const double t_h2d = timeit([&] { hipMemcpyAsync(d_in, h_in, ib, hipMemcpyHostToDevice, s0); });
         const double t_d2h = timeit([&] { hipMemcpyAsync(h_out, d_out, ob, hipMemcpyDeviceToHost, s1); });
         const double t_both = timeit([&] { hipMemcpyAsync(d_in, h_in, ib, hipMemcpyHostToDevice, s0); hipMemcpyAsync(h_out, d_out, ob, hipMemcpyDeviceToHost, s1); });
         printf("\"copy_engine_%zu_in_%zu_out_MiB\": {\"h2d_GBs\": %.1f, \"d2h_GBs\": %.1f, \"duplex_ms\": %.3f, \"duplex_total_GBs\": %.1f, \"duplex_out_GBs\": %.1f}, ",
                ib / MB, ob / MB, ib / t_h2d / 1e9, ob / t_d2h / 1e9, t_both * 1e3, (ib + ob) / t_both / 1e9, ob / t_both / 1e9);
+        if (shape_only) { printf("\"shape\": {\"in_MiB\": %zu, \"out_MiB\": %zu, \"h2d_GBs\": %.2f, \"d2h_GBs\": %.2f, \"duplex_ms\": %.4f}}\n", ib / MB, ob / MB, ib / t_h2d / 1e9, ob / t_d2h / 1e9, t_both * 1e3); return 0; }
     }
     {   // the kernel's own stores across PCIe (mapped pinned target), the copy engine bringing input at the same time
         void *m_out = nullptr;
