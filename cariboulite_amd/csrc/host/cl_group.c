@@ -21,6 +21,7 @@
  * are stateless behind the unpack.  What the single-stream route keeps for the reference's "untouched slots" (the
  * persistent native buffer) is rebuilt lazily from the previous call's raw words when a member leaves the batched route. */
 #include <immintrin.h>
+#include <time.h>
 #include <unistd.h>
 
 #include "cl_internal.h"
@@ -49,6 +50,7 @@ typedef struct {
     size_t out_stride;                    /* elements per row of d_out / h_out */
     uint8_t *d_out, *h_out;
     int32_t *h_offs; int32_t *d_offs;     /* ROUTE_PLAIN: per row 0 (unpack) / -1 (skip), mapped pinned */
+    uint8_t *m_out;                       /* the device's address of h_out (mapped pinned): kernels may store into the mirror themselves */
     uint8_t *fast; size_t *len; long *got;   /* per call */
     cl_dsp_cfg dsp;
 } lane_t;
@@ -59,6 +61,7 @@ struct cl_group {
     int *lane_of, *row_of;                /* member -> lane / row */
     int n_lanes; lane_t *lane;
     int sub;                              /* streams per sub-batch */
+    int sink_mapped;                      /* kwarg SINK: "mapped" (default) = the sub-batch's kernel stores into the mapped pinned mirror itself; "copy" = device buffer + copy engine */
     void *s_in, *s_k, *s_out;
     void **ev; size_t n_ev;               /* 3 per sub-batch */
     copy_pool pool;
@@ -248,7 +251,9 @@ cl_group *cl_group_make(cl_device *const *devs, size_t n, const char *const *key
     if (!g->dev || !g->lane_of || !g->row_of || !g->lane || !g->reg_base || !g->reg_dev || !g->reg_len) { cl_group_unmake(g); return NULL; }
     memcpy(g->dev, devs, n * sizeof *g->dev);
     const char *sub = kwget(keys, vals, n_kwargs, "SUBBATCH"), *ct = kwget(keys, vals, n_kwargs, "COPY_THREADS");
-    g->sub = sub && atoi(sub) > 0 ? atoi(sub) : 8;
+    g->sub = sub && atoi(sub) > 0 ? atoi(sub) : 4;     /* profiles/r04/group_sweep_*.txt: 2 / 4 / 8 / 16 -> 3275 / 3400 / 3100 / 2700 Msamples/s (FIR64 + 3/2, 32 streams) */
+    const char *sk = kwget(keys, vals, n_kwargs, "SINK");
+    g->sink_mapped = !(sk && !strcmp(sk, "copy"));
     int threads = ct ? atoi(ct) : 4;
     if (threads < 0) threads = 0;
     if (threads > 16) threads = 16;
@@ -293,10 +298,11 @@ cl_group *cl_group_make(cl_device *const *devs, size_t n, const char *const *key
         l->d_out = (uint8_t *)clhip_malloc(out_bytes); l->h_out = (uint8_t *)clhip_host_alloc(out_bytes);
         l->h_offs = (int32_t *)clhip_host_alloc(sizeof(int32_t) * (size_t)l->n + 64);
         l->d_offs = l->h_offs ? (int32_t *)clhip_host_device_ptr(l->h_offs) : NULL;
+        l->m_out = l->h_out ? (uint8_t *)clhip_host_device_ptr(l->h_out) : NULL;
         l->prev_len = (size_t *)calloc((size_t)l->n, sizeof(size_t));
         l->fast = (uint8_t *)calloc((size_t)l->n, 1); l->len = (size_t *)calloc((size_t)l->n, sizeof(size_t));
         l->got = (long *)calloc((size_t)l->n, sizeof(long));
-        if (!l->d_in[0] || !l->d_in[1] || !l->d_out || !l->h_out || !l->h_offs || !l->d_offs || !l->prev_len || !l->fast || !l->len || !l->got) {
+        if (!l->d_in[0] || !l->d_in[1] || !l->d_out || !l->h_out || !l->h_offs || !l->d_offs || !l->m_out || !l->prev_len || !l->fast || !l->len || !l->got) {
             cl_seterr(g_make_err, sizeof g_make_err, "cl_group_make: buffers for %d streams could not be allocated", l->n);
             cl_group_unmake(g);
             return NULL;
@@ -415,7 +421,7 @@ static int single_member(cl_group *g, lane_t *l, int row, void *out, size_t numE
         if (cl_ensure((void **)&smi->d_iq, &smi->iq_cap, pl / 4 + 8, 4, 0) ||
             clhip_smi_unpack_aligned(l->channel, l->d_in[l->cur_in ^ 1] + (size_t)row * l->in_stride, pl, CL_FORMAT_CS16, smi->d_iq, NULL, smi->stream))
             return 0;
-        smi->prev_fused_bytes = 0;
+        smi->prev_words = NULL;
     }
     l->prev_len[row] = 0;
     if (l->route == ROUTE_PLAIN || st->format != l->format || st->native_dir != CL_SOAPY_SDR_RX) {
@@ -452,6 +458,8 @@ int cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems, int *r
     for (int k = 0; k < g->n_lanes; k++) memset(g->lane[k].fast, 0, (size_t)g->lane[k].n);
     int hard = 0;
     size_t b = 0;                                              /* sub-batch counter over all lanes */
+    struct timespec t0, t1, t2, t3;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
     /* ---- pass 1: stage, copy in, launch, copy out -- everything queued, nothing waited for */
     for (int k = 0; k < g->n_lanes && !hard; k++) {
         lane_t *l = &g->lane[k];
@@ -474,6 +482,13 @@ int cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems, int *r
             if (!any) { if (clhip_event_record(ev_out, g->s_out)) hard = 1; continue; }
             hard = clhip_event_record(ev_in, g->s_in) || clhip_stream_wait_event(g->s_k, ev_in);
             uint8_t *in = l->d_in[l->cur_in];
+            /* where the sub-batch's launch stores: the mapped pinned mirror itself (its stores cross PCIe as the kernel produces them --
+             * no second hop, no copy-engine call: tools/microbench/pcie_duplex.hip) unless one of its rows has a registered client
+             * buffer, which the copy engine fills from the device buffer */
+            int mapped = g->sink_mapped;
+            for (int r = a; r < e && mapped; r++)
+                if (l->fast[r] && g->reg_base[l->member[r]]) mapped = 0;
+            uint8_t *outb = mapped ? l->m_out : l->d_out;
             if (!hard && l->route == ROUTE_PIPE) {
                 /* maximal runs of neighbouring batched rows: one fused launch each, straight from the raw words */
                 int r = a;
@@ -482,7 +497,7 @@ int cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems, int *r
                     int r1 = r + 1;
                     while (r1 < e && l->fast[r1]) r1++;
                     const long got = clhip_rx_pipe_run_range(l->pipe, r, r1 - r, CL_PIPE_IN_SMI_WORDS, in + (size_t)r * l->in_stride, l->in_stride / 4, want / 4,
-                                                             l->d_out + (size_t)r * l->out_stride * l->elem_bytes, l->out_stride, g->s_k);
+                                                             outb + (size_t)r * l->out_stride * l->elem_bytes, l->out_stride, g->s_k);
                     if (got < 0) hard = 1;
                     for (int q = r; q < r1; q++) l->got[q] = got;
                     g->stats.launches++;
@@ -493,9 +508,10 @@ int cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems, int *r
                  * off the batched route has offset -1: the kernel writes nothing for it) */
                 for (int r = a; r < e; r++) { l->h_offs[r] = l->fast[r] ? 0 : -1; l->got[r] = l->fast[r] ? (long)(want / 4) : 0; }
                 hard = clhip_smi_unpack(l->channel, in + (size_t)a * l->in_stride, (size_t)(e - a - 1) * l->in_stride + want, l->in_stride, want, e - a,
-                                        l->d_offs + a, l->format, l->d_out + (size_t)a * l->out_stride * l->elem_bytes, NULL, g->s_k);
+                                        l->d_offs + a, l->format, outb + (size_t)a * l->out_stride * l->elem_bytes, NULL, g->s_k);
                 g->stats.launches++;
             }
+            if (mapped) { hard = hard || clhip_event_record(ev_out, g->s_k); continue; }     /* "arrived" = the launch has ended */
             hard = hard || clhip_event_record(ev_k, g->s_k) || clhip_stream_wait_event(g->s_out, ev_k);
             /* out: rows whose client buffer is registered leave for it directly; the others as one block into the mirror */
             int lo = -1, hi = -1;
@@ -514,6 +530,7 @@ int cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems, int *r
             hard = hard || clhip_event_record(ev_out, g->s_out);
         }
     }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
     /* ---- pass 2: as the sub-batches arrive, their bytes are consumed for good and their rows go to the clients */
     const size_t n_queued = b;
     b = 0;
@@ -537,7 +554,7 @@ int cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems, int *r
                 }
                 confirm_staged(dev->smi, l->len[r]);
                 dev->smi->stat_samples += (uint64_t)(l->len[r] / 4);
-                dev->smi->prev_fused_bytes = 0;
+                dev->smi->prev_words = NULL;                       /* (the lane's previous raw words stand in for them) */
                 l->prev_len[r] = l->len[r];
                 const size_t bytes = (size_t)l->got[r] * l->elem_bytes;
                 if (!registered(g, m, buffs[m], bytes))
@@ -549,6 +566,7 @@ int cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems, int *r
             }
         }
     }
+    clock_gettime(CLOCK_MONOTONIC, &t2);
     /* ---- pass 3: the members off the batched route, one by one (while the pool still copies) */
     for (int k = 0; k < g->n_lanes; k++) {
         lane_t *l = &g->lane[k];
@@ -567,6 +585,10 @@ int cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems, int *r
         g->stats.errors++;
         return -1;
     }
+    clock_gettime(CLOCK_MONOTONIC, &t3);
+    g->stats.last_queue_us = (uint64_t)((t1.tv_sec - t0.tv_sec) * 1000000L + (t1.tv_nsec - t0.tv_nsec) / 1000);
+    g->stats.last_arrive_us = (uint64_t)((t2.tv_sec - t0.tv_sec) * 1000000L + (t2.tv_nsec - t0.tv_nsec) / 1000);
+    g->stats.last_total_us = (uint64_t)((t3.tv_sec - t0.tv_sec) * 1000000L + (t3.tv_nsec - t0.tv_nsec) / 1000);
     int delivered = 0;
     for (size_t i = 0; i < g->n; i++) delivered += rets[i] > 0;
     return delivered;

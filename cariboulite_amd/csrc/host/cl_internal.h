@@ -59,8 +59,7 @@ typedef struct {
     int32_t offs;       /* sync offset found on the GPU (-1 = none)                    */
 } cl_chunk;
 
-#define CL_FAST_NATIVE_ONLY ((void *)(uintptr_t)1)
-#define CL_FAST_WORDS_ONLY  ((void *)(uintptr_t)2)   /* no launch at all: the caller's own kernel reads the staged raw words (dev->fast_words) */
+#define CL_RA_SLOTS 3          /* device slots the read-ahead rotates: this read(), the one staged ahead, and the previous call's words */
 
 struct cl_smi {
     int device;
@@ -74,11 +73,10 @@ struct cl_smi {
     int tx_mode;
     /* device / pinned buffers, grown on demand */
     uint8_t *d_bytes; size_t bytes_cap;
-    /* cl_smi_read_pipe_device: the raw words of the previous call when it took the fused route (which never
-     * materialises int16 samples), kept so that a re-sync in THIS call finds in d_iq what the reference's
-     * persistent intermediate buffer would hold in the slots it leaves untouched */
-    uint8_t *d_bytes_prev; size_t bytes_prev_cap, prev_fused_bytes;
-    int32_t *d_zoffs; size_t zoffs_cap;      /* all-zero sync offsets for that catch-up unpack */
+    /* the raw words of the previous call when they went straight into the caller's own kernel (which never materialises
+     * int16 samples in d_iq), kept so that a re-sync in a LATER call finds in d_iq what the reference's persistent
+     * intermediate buffer would hold in the slots it leaves untouched (cl_smi_restore_prev_words) */
+    const uint8_t *prev_words; size_t prev_words_len;
     int16_t *d_iq; size_t iq_cap;         /* samples */
     uint8_t *d_meta; size_t meta_cap;
     uint8_t *h_stage; size_t h_stage_cap; /* pinned host staging */
@@ -92,18 +90,16 @@ struct cl_smi {
     /* read-ahead reader (cl_smi_read_device_ra): the NEXT read() is popped into the other pinned slot and its
      * host-to-device copy runs on `cstream` while the current chunk is analysed on `stream`.  The bytes are taken IN
      * PLACE from the pinned RX FIFO (cl_fifo_stage): what the feeder wrote is what the DMA engine reads */
-    void *cstream; void *ev_copied[2];
-    uint8_t *d_slot[2]; size_t slot_cap;   /* device side of the double buffer; the host side is the pinned RX FIFO itself */
+    void *cstream; void *ev_copied[CL_RA_SLOTS];
+    uint8_t *d_slot[CL_RA_SLOTS]; size_t slot_cap;   /* device side of the read-ahead; the host side is the pinned RX FIFO itself */
     struct { int valid, slot, head_ok; size_t len; } ahead;
     int next_slot;
     int ra_pending; size_t ra_samples;     /* between cl_smi_ra_launch and cl_smi_ra_finish */
-    int ra_certain, stage_certain;         /* the host has seen the sync pattern at the head of every chunk of the call */
     size_t inplace_len;                    /* bytes of a one-read() call staged in place on `stream`: confirmed once that stream has been synchronised */
-    /* cl_smi_ra_launch's short cut for a call that is ONE read() the host has seen to be in sync: set fast_out (device-visible
-     * address of the caller's pinned mirror) + fast_format before the call; fast_used says whether it was taken */
-    void *fast_out; int fast_format, fast_used;   /* fast_out = CL_FAST_NATIVE_ONLY: only the int16 buffer (a device stage of the caller follows) */
-    const uint8_t *fast_words;             /* CL_FAST_WORDS_ONLY: the call's raw words on the device, ready on dev->stream */
-    void *pipe_out_used;                   /* cl_smi_read_pipe_device: d_out or d_out_certain, whichever took the outputs */
+    /* cl_smi_ra_launch's short cut for a call that is ONE read() the host has seen to be in sync: set want_words before the
+     * call; fast_used says whether it was taken; fast_words = the call's raw words on the device, ready on dev->stream */
+    int want_words, fast_used;
+    const uint8_t *fast_words;
     /* statistics (SURVEY.md section 5 "Metrics"): */
     uint64_t stat_samples, stat_resyncs, stat_sync_failures, stat_timeouts, stat_io_errors, stat_written;
     char err[256];
@@ -115,9 +111,7 @@ struct cl_smi {
 int cl_smi_read_device(cl_smi *dev, int channel, size_t length_samples, int want_meta, int *all_aligned);
 /* the same chunk loop with results in caller-owned DEVICE buffers (NULL = the seam's own / no metadata) */
 int cl_smi_read_device_to(cl_smi *dev, int channel, size_t length_samples, int16_t *d_iq, uint8_t *d_meta, int *all_aligned);
-/* the same chunk loop feeding an RX pipe straight from the staged raw words (fused launch + device-side sync verdict) */
-int cl_smi_read_pipe_device(cl_smi *dev, int channel, size_t length_samples, clhip_rx_pipe *pipe, void *d_out, long *n_out, void *h_out,
-                            void *d_out_certain);
+int cl_smi_restore_prev_words(cl_smi *dev, int channel);   /* bring dev->d_iq up to date from the previous call's raw words (0 / -1) */
 /* the same chunk loop, one chunk at a time, with the next read() staged and copied ahead (reader threads) */
 int cl_smi_read_device_ra(cl_smi *dev, int channel, size_t length_samples, int16_t *d_iq);
 long cl_smi_ra_launch(cl_smi *dev, int channel, size_t length_samples, int16_t *d_iq);   /* its two halves: the caller may queue */

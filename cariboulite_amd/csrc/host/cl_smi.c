@@ -67,13 +67,9 @@ void *cl_fifo_device_ptr(const cl_fifo *f, const uint8_t *at)
     return d ? d + (at - f->data) : NULL;
 }
 
-/* A/B: CL_WRITE_MAPPED_KB = largest write call (bytes in) whose kernel reads pinned samples and stores into pinned room itself */
-size_t cl_write_mapped_max(void)
-{
-    static size_t v = (size_t)-1;
-    if (v == (size_t)-1) v = getenv("CL_WRITE_MAPPED_KB") ? (size_t)atol(getenv("CL_WRITE_MAPPED_KB")) << 10 : (size_t)2 << 20;
-    return v;
-}
+/* largest write call (bytes in) whose kernel reads the pinned samples and stores into the pinned room itself, across PCIe (round 3, three
+ * alternations on one box: CS16 55-58 -> 40-43 us per MTU call, CF32 79-82 -> 69-70, FM + 2/3 81-88 -> 70-71); above it: copy engine both ways */
+size_t cl_write_mapped_max(void) { return (size_t)2 << 20; }
 
 size_t cl_fifo_pop(cl_fifo *f, uint8_t *dst, size_t n)
 {
@@ -177,8 +173,8 @@ int cl_smi_close(cl_smi *dev)
     clhip_stream_sync(dev->stream);
     cl_smi_readahead_cancel(dev);
     if (dev->cstream) { clhip_stream_sync(dev->cstream); clhip_stream_destroy(dev->cstream); }
-    for (int k = 0; k < 2; k++) { clhip_event_destroy(dev->ev_copied[k]); clhip_free(dev->d_slot[k]); }
-    clhip_free(dev->d_bytes); clhip_free(dev->d_bytes_prev); clhip_free(dev->d_zoffs); clhip_free(dev->d_iq); clhip_free(dev->d_meta); clhip_free(dev->d_offs);
+    for (int k = 0; k < CL_RA_SLOTS; k++) { clhip_event_destroy(dev->ev_copied[k]); clhip_free(dev->d_slot[k]); }
+    clhip_free(dev->d_bytes); clhip_free(dev->d_iq); clhip_free(dev->d_meta); clhip_free(dev->d_offs);
     clhip_host_free(dev->h_stage); clhip_host_free(dev->h_txin); clhip_host_free(dev->h_offs); clhip_free(dev->d_dbg); clhip_host_free(dev->h_dbg);
     free(dev->chunks);
     cl_fifo_free(&dev->rx); cl_fifo_free(&dev->tx);
@@ -413,7 +409,6 @@ static long smi_stage_call(cl_smi *dev, size_t length_samples, int *contiguous)
     size_t left = length_samples * CL_BYTES_PER_SAMPLE, read_so_far = 0, stage_off = 0;
     dev->n_chunks = 0;
     *contiguous = 1;
-    dev->stage_certain = 1;                                    /* every staged chunk's head carries the sync pattern */
     /* worst-case staging: every chunk rounded up to 256 B */
     const size_t max_chunks = left / (dev->max_read && dev->max_read < dev->native_batch_len ? dev->max_read : dev->native_batch_len) + 2;
     if (cl_ensure((void **)&dev->chunks, &dev->chunks_cap, max_chunks, sizeof(cl_chunk), 2)) return CL_SMI_ERR_IO;
@@ -436,7 +431,6 @@ static long smi_stage_call(cl_smi *dev, size_t length_samples, int *contiguous)
         size_t got = cl_fifo_stage(&dev->rx, left, &src);
         if (got & 3) { cl_fifo_unstage(&dev->rx, got); got = 0; bad = 2; }          /* ragged: the copying loop below */
         else if (got) {
-            dev->stage_certain = cl_smi_head_in_sync(src, got);
             bad = clhip_memcpy_h2d(dev->d_bytes, src, got, dev->stream);
             if (bad) cl_fifo_unstage(&dev->rx, got); else dev->inplace_len = got;
         }
@@ -461,7 +455,6 @@ static long smi_stage_call(cl_smi *dev, size_t length_samples, int *contiguous)
         cl_chunk *c = &dev->chunks[dev->n_chunks++];
         c->stage_off = stage_off; c->len = ret; c->slot0 = read_so_far; c->offs = 0;
         if ((ret & 3) || stage_off != 4 * read_so_far || (left > ret && ret != dev->native_batch_len)) *contiguous = 0;
-        if (!cl_smi_head_in_sync(dev->h_stage + stage_off, ret)) dev->stage_certain = 0;
         stage_off += (ret + 255) & ~(size_t)255;
         read_so_far += ret / CL_BYTES_PER_SAMPLE;              /* :677 */
         left -= ret;                                           /* :678 */
@@ -507,7 +500,7 @@ int cl_smi_read_device_to(cl_smi *dev, int channel, size_t length_samples, int16
 {
     clhip_set_device(dev->device);
     cl_smi_readahead_cancel(dev);
-    if (d_iq == dev->d_iq) dev->prev_fused_bytes = 0;          /* the seam's int16 buffer is brought up to date here */
+    if (d_iq == dev->d_iq && cl_smi_restore_prev_words(dev, channel)) return CL_SMI_ERR_IO;   /* the seam's int16 buffer is brought up to date first */
     if (all_aligned) *all_aligned = 1;
     int contiguous;
     const long read_so_far = smi_stage_call(dev, length_samples, &contiguous);
@@ -535,90 +528,6 @@ int cl_smi_read_device_to(cl_smi *dev, int channel, size_t length_samples, int16
     if (bad_sync) return CL_SMI_ERR_IO;
     const int v = smi_call_verdict(dev, all_aligned);
     if (v) return v;
-    dev->stat_samples += (uint64_t)read_so_far;
-    return (int)read_so_far;
-}
-
-/* caribou_smi_read feeding an RX pipe without materialising the int16 samples: the call's reads are staged as
- * above; when they form one contiguous word sequence the pipe runs straight from the raw bytes
- * (clhip_rx_pipe_run_smi: per-chunk sync search + ONE fused launch, verdict checked on the device, re-sync and "-3"
- * handled with the reference's semantics); otherwise the chunks are unpacked first and the pipe runs from int16.
- * *n_out = outputs the pipe produced (left in d_out, complete).  d_out_certain (may be NULL): where the outputs go INSTEAD
- * when the host has seen every chunk of the call in sync, i.e. the call will deliver -- memory the client can see (its own
- * registered buffer, a mapped mirror); h_out is then left alone.  dev->pipe_out_used says which of the two took them.
- * Returns samples consumed, 0, or CL_SMI_ERR_*. */
-int cl_smi_read_pipe_device(cl_smi *dev, int channel, size_t length_samples, clhip_rx_pipe *pipe, void *d_out, long *n_out, void *h_out,
-                            void *d_out_certain)
-{
-    dev->pipe_out_used = d_out;
-    const size_t out_bytes = clhip_rx_pipe_out_elem_bytes(pipe);
-    clhip_set_device(dev->device);
-    cl_smi_readahead_cancel(dev);
-    *n_out = 0;
-    if (cl_ensure((void **)&dev->d_iq, &dev->iq_cap, length_samples + 8, 4, 0)) return CL_SMI_ERR_IO;
-    int contiguous;
-    const long read_so_far = smi_stage_call(dev, length_samples, &contiguous);
-    if (read_so_far < 0) return (int)read_so_far;
-    if (dev->n_chunks == 0) return 0;
-    if (!contiguous) {                                         /* short / ragged reads: analyse chunk by chunk first */
-        /* the bytes are staged already: give them back and take the ordinary route (rare; keeps one code path) */
-        pthread_mutex_lock(&dev->fifo_mu);
-        for (size_t k = dev->n_chunks; k-- > 0;)
-            if (cl_fifo_unpop(&dev->rx, dev->h_stage + dev->chunks[k].stage_off, dev->chunks[k].len)) { pthread_mutex_unlock(&dev->fifo_mu); return CL_SMI_ERR_IO; }
-        pthread_mutex_unlock(&dev->fifo_mu);
-        clhip_stream_sync(dev->stream);
-        const int ret = cl_smi_read_device_to(dev, channel, length_samples, dev->d_iq, NULL, NULL);
-        if (ret <= 0) return ret;
-        *n_out = clhip_rx_pipe_run(pipe, CL_PIPE_IN_CS16, dev->d_iq, 0, (size_t)ret, d_out, 0, dev->stream);
-        if (*n_out < 0) return CL_SMI_ERR_IO;
-        if (h_out && *n_out > 0 && clhip_memcpy_d2h(h_out, d_out, (size_t)*n_out * out_bytes, dev->stream)) return CL_SMI_ERR_IO;
-        if (clhip_stream_sync(dev->stream)) return CL_SMI_ERR_IO;
-        return ret;
-    }
-    const cl_chunk *last = &dev->chunks[dev->n_chunks - 1];
-    const size_t total = last->stage_off + last->len, nb = dev->native_batch_len;
-    /* every chunk known to be in sync: the outputs leave for the client's buffer under run_smi's own synchronisation;
-     * otherwise the client's buffer is only written once the call is known to deliver (a lost chunk delivers nothing) */
-    const int zc = d_out_certain && dev->stage_certain;
-    const int direct = !zc && h_out && dev->stage_certain;
-    clhip_rx_pipe_set_host_sink(pipe, direct ? h_out : NULL);
-    clhip_rx_pipe_set_offs_writeback(pipe, 0);                 /* the verdict is read from h_offs */
-    long got = clhip_rx_pipe_run_smi(pipe, dev->d_bytes, 0, total, nb, dev->d_offs, dev->h_offs, NULL, zc ? d_out_certain : d_out, 0, dev->stream);
-    smi_inplace_done(dev, got >= 0 || got == CL_SMI_ERR_SYNC || got == CL_PIPE_ERR_RESYNC);     /* run_smi synchronises the stream on those returns */
-    if (got < 0 && got != CL_SMI_ERR_SYNC && got != CL_PIPE_ERR_RESYNC) return CL_SMI_ERR_IO;
-    const int v = smi_call_verdict(dev, NULL);
-    if (v) return v;                                           /* -3: pipe and FIFO as the reference leaves them */
-    if (got == CL_SMI_ERR_SYNC) return CL_SMI_ERR_IO;          /* the pipe saw a lost chunk the table does not show */
-    if (got == CL_PIPE_ERR_RESYNC) {
-        /* the reference's way: int16 samples in the persistent intermediate buffer, untouched slots keeping what
-         * the previous call left there.  That call's samples were never materialised if it took the fused route:
-         * unpack its raw words (all in sync, or it would not have) first, then this call's over them. */
-        const int nc = (int)dev->n_chunks;
-        if (dev->prev_fused_bytes) {
-            const int pc = (int)((dev->prev_fused_bytes + nb - 1) / nb);
-            if (cl_ensure((void **)&dev->d_zoffs, &dev->zoffs_cap, (size_t)pc, 4, 0)) return CL_SMI_ERR_IO;
-            if (clhip_memset(dev->d_zoffs, 0, 4 * (size_t)pc, dev->stream) ||
-                clhip_smi_unpack(channel, dev->d_bytes_prev, dev->prev_fused_bytes, nb, nb, pc, dev->d_zoffs, CL_FORMAT_CS16,
-                                 dev->d_iq, NULL, dev->stream))
-                return CL_SMI_ERR_IO;
-            dev->prev_fused_bytes = 0;
-        }
-        if (clhip_smi_unpack(channel, dev->d_bytes, total, nb, nb, nc, dev->d_offs, CL_FORMAT_CS16, dev->d_iq, NULL, dev->stream))
-            return CL_SMI_ERR_IO;
-        got = clhip_rx_pipe_run(pipe, CL_PIPE_IN_CS16, dev->d_iq, 0, (size_t)read_so_far, d_out, 0, dev->stream);
-        if (got < 0) return CL_SMI_ERR_IO;
-        if (h_out && got > 0 && clhip_memcpy_d2h(h_out, d_out, (size_t)got * out_bytes, dev->stream)) return CL_SMI_ERR_IO;
-        if (clhip_stream_sync(dev->stream)) return CL_SMI_ERR_IO;
-    } else {
-        if (zc) dev->pipe_out_used = d_out_certain;
-        else if (h_out && !direct && got > 0 &&
-            (clhip_memcpy_d2h(h_out, d_out, (size_t)got * out_bytes, dev->stream) || clhip_stream_sync(dev->stream))) return CL_SMI_ERR_IO;
-        /* fused route: keep these raw words until the next call has been through */
-        uint8_t *tb = dev->d_bytes; dev->d_bytes = dev->d_bytes_prev; dev->d_bytes_prev = tb;
-        size_t tc = dev->bytes_cap; dev->bytes_cap = dev->bytes_prev_cap; dev->bytes_prev_cap = tc;
-        dev->prev_fused_bytes = total;
-    }
-    *n_out = got;
     dev->stat_samples += (uint64_t)read_so_far;
     return (int)read_so_far;
 }
@@ -694,27 +603,46 @@ static int ra_chunk_verdict(cl_smi *dev)
     return 0;
 }
 
+/* The seam's persistent int16 buffer (dev->d_iq: it stands where the Stream's interm_native_buffer stands, so the slots a
+ * re-synchronised chunk leaves untouched keep what the call before left there, caribou_smi.c:382-389) is not written by a
+ * call whose raw words went straight into the caller's own kernel (cl_smi_ra_launch with want_words: the IIR's input
+ * conversion, the fused pipe).  Such a call leaves its words where they are -- the read-ahead rotates THREE device slots, so
+ * the slot of the previous call survives the next one's staging -- and the first call that needs the int16 samples (any call
+ * that is not one in-sync read()) unpacks them first.  Costs nothing until then. */
+int cl_smi_restore_prev_words(cl_smi *dev, int channel)
+{
+    if (!dev->prev_words) return 0;
+    const uint8_t *w = dev->prev_words;
+    const size_t n = dev->prev_words_len;
+    dev->prev_words = NULL;
+    if (cl_ensure((void **)&dev->d_iq, &dev->iq_cap, n / 4 + 8, 4, 0)) return -1;
+    /* (synchronised: the copy stream may stage into that slot as soon as this call moves on) */
+    return clhip_smi_unpack_aligned(channel, w, n, CL_FORMAT_CS16, dev->d_iq, NULL, dev->stream) || clhip_stream_sync(dev->stream) ? -1 : 0;
+}
+
 long cl_smi_ra_launch(cl_smi *dev, int channel, size_t length_samples, int16_t *d_iq)
 {
     clhip_set_device(dev->device);
     const size_t nb = dev->native_batch_len;
+    const int want_words = dev->want_words;
+    dev->want_words = 0;
     dev->ra_pending = 0;
     dev->fast_used = 0;
-    dev->ra_certain = 1;                                       /* every read() of the call known to be in sync, whole samples */
     if (!dev->cstream) {
         dev->cstream = clhip_stream_create();
-        for (int k = 0; k < 2; k++) {
+        int bad = !dev->cstream;
+        for (int k = 0; k < CL_RA_SLOTS; k++) {
             dev->ev_copied[k] = clhip_event_create();
             dev->d_slot[k] = (uint8_t *)clhip_malloc(nb + 256);
+            bad |= !dev->ev_copied[k] || !dev->d_slot[k];
         }
         dev->slot_cap = nb + 256;
-        if (!dev->cstream || !dev->ev_copied[0] || !dev->ev_copied[1] || !dev->d_slot[0] || !dev->d_slot[1])
-            return CL_SMI_ERR_IO;
+        if (bad) return CL_SMI_ERR_IO;
     }
-    if (!d_iq) {
+    const int own = !d_iq;                                     /* results in the seam's persistent int16 buffer */
+    if (own) {
         if (cl_ensure((void **)&dev->d_iq, &dev->iq_cap, length_samples + 8, 4, 0)) return CL_SMI_ERR_IO;
         d_iq = dev->d_iq;
-        dev->prev_fused_bytes = 0;
     }
     if (cl_ensure((void **)&dev->d_offs, &dev->offs_cap, 4, 4, 0) || cl_ensure((void **)&dev->h_offs, &dev->h_offs_cap, 4, 4, 1))
         return CL_SMI_ERR_IO;
@@ -744,25 +672,21 @@ long cl_smi_ra_launch(cl_smi *dev, int channel, size_t length_samples, int16_t *
             got = ra_stage(dev, slot, want, &head_ok);
             if (!got) break;                                   /* :657-661 "Reading timed-out" */
         }
-        dev->next_slot = slot ^ 1;
+        const int slot_next = (slot + 1) % CL_RA_SLOTS;
+        dev->next_slot = slot_next;
         /* the read() after this one: the rest of this call, or the head of the next call */
         const size_t rest = left - got, want_next = rest ? (rest < cap_read ? rest : cap_read) : cap_read;
         int ahead_ok = 0;
-        const size_t a = ra_stage(dev, slot ^ 1, want_next, &ahead_ok);
-        if (a) { dev->ahead.valid = 1; dev->ahead.slot = slot ^ 1; dev->ahead.len = a; dev->ahead.head_ok = ahead_ok; }
-        if (dev->fast_out && read_so_far == 0 && got == left && head_ok && !(got & 15)) {
+        const size_t a = ra_stage(dev, slot_next, want_next, &ahead_ok);
+        if (a) { dev->ahead.valid = 1; dev->ahead.slot = slot_next; dev->ahead.len = a; dev->ahead.head_ok = ahead_ok; }
+        if (want_words && own && read_so_far == 0 && got == left && head_ok && !(got & 15)) {
             /* The call is this one read(), and the host has seen the sync pattern on its first four words: offset 0
-             * (caribou_smi.c:235-292) without asking the device, every slot written.  One launch unpacks it into the
-             * persistent int16 buffer AND, in the caller's format, straight into the caller's pinned mirror: no search
-             * launch, no offset read-back, no conversion launch, no device-to-host copy. */
-            void *fo = dev->fast_out;
-            dev->fast_out = NULL;
+             * (caribou_smi.c:235-292) without asking the device, every slot written.  No launch here at all: the caller's
+             * own first kernel reads the raw words (dev->fast_words, ready on dev->stream) -- the unpack in the client's
+             * format, the IIR's input conversion, the fused pipe -- and cl_smi_ra_finish is the call's one synchronisation. */
+            if (clhip_stream_wait_event(dev->stream, dev->ev_copied[slot])) return CL_SMI_ERR_IO;
             dev->fast_words = dev->d_slot[slot];
-            if (clhip_stream_wait_event(dev->stream, dev->ev_copied[slot]) ||
-                (fo == CL_FAST_WORDS_ONLY ? 0 :
-                 fo == CL_FAST_NATIVE_ONLY ? clhip_smi_unpack_aligned(channel, dev->d_slot[slot], got, CL_FORMAT_CS16, d_iq, NULL, dev->stream)
-                                           : clhip_smi_unpack_aligned(channel, dev->d_slot[slot], got, dev->fast_format, fo, d_iq, dev->stream)))
-                return CL_SMI_ERR_IO;
+            dev->prev_words = dev->d_slot[slot]; dev->prev_words_len = got;   /* (a caller that writes dev->d_iq itself clears this) */
             dev->h_offs[0] = 0;
             dev->fast_used = 1;
             cl_chunk *c = &dev->chunks[dev->n_chunks];
@@ -770,12 +694,12 @@ long cl_smi_ra_launch(cl_smi *dev, int channel, size_t length_samples, int16_t *
             dev->ra_pending = 1; dev->ra_samples = got / CL_BYTES_PER_SAMPLE;
             return (long)dev->ra_samples;
         }
+        if (own && read_so_far == 0 && cl_smi_restore_prev_words(dev, channel)) return CL_SMI_ERR_IO;
         if (clhip_stream_wait_event(dev->stream, dev->ev_copied[slot]) ||
             clhip_smi_find_offsets(dev->d_slot[slot], got, nb, nb, 1, dev->d_offs, dev->stream) ||
             clhip_smi_unpack(channel, dev->d_slot[slot], got, nb, nb, 1, dev->d_offs, CL_FORMAT_CS16, d_iq + 2 * read_so_far, NULL, dev->stream) ||
             clhip_memcpy_d2h(dev->h_offs, dev->d_offs, 4, dev->stream))
             return CL_SMI_ERR_IO;
-        if ((got & 3) || !head_ok) dev->ra_certain = 0;
         cl_chunk *c = &dev->chunks[dev->n_chunks];             /* published (n_chunks++) once its verdict is in */
         c->stage_off = 0; c->len = got; c->slot0 = read_so_far; c->offs = 0;
         read_so_far += got / CL_BYTES_PER_SAMPLE;              /* :677 */
@@ -795,7 +719,6 @@ long cl_smi_ra_launch(cl_smi *dev, int channel, size_t length_samples, int16_t *
 
 int cl_smi_ra_finish(cl_smi *dev)
 {
-    dev->fast_out = NULL;
     if (!dev->ra_pending) return 0;
     dev->ra_pending = 0;
     if (clhip_stream_sync(dev->stream)) return smi_count(dev, CL_SMI_ERR_IO);
@@ -900,15 +823,16 @@ static int smi_write_core(cl_smi *dev, const cl_sample_complex_int16 *h_buffer, 
         void *d_in = d_room ? clhip_host_device_ptr(dev->h_txin) : NULL;
         if (d_in) d_src = (const int16_t *)d_in;
         else {
-            if (clhip_memcpy_h2d(dev->d_iq, dev->h_txin, left, dev->stream)) return CL_SMI_ERR_IO;
+            if (clhip_memcpy_h2d(dev->d_iq, dev->h_txin, left, dev->stream)) { clhip_stream_sync(dev->stream); return CL_SMI_ERR_IO; }
             d_src = dev->d_iq;
         }
     }
-    if (d_room) {
-        if (clhip_smi_pack(dev->tx_mode, d_src, length_samples, (uint8_t *)d_room, dev->stream) || clhip_stream_sync(dev->stream)) return CL_SMI_ERR_IO;
-    } else if (clhip_smi_pack(dev->tx_mode, d_src, length_samples, dev->d_bytes, dev->stream) ||
-               clhip_memcpy_d2h(room, dev->d_bytes, left, dev->stream) || clhip_stream_sync(dev->stream))
-        return CL_SMI_ERR_IO;
+    /* (every error exit behind a launch synchronises first: the kernels read dev->h_txin and store into the FIFO's reserved room,
+     * both of which the next call may move or overwrite) */
+    int bad;
+    if (d_room) bad = clhip_smi_pack(dev->tx_mode, d_src, length_samples, (uint8_t *)d_room, dev->stream);
+    else bad = clhip_smi_pack(dev->tx_mode, d_src, length_samples, dev->d_bytes, dev->stream) || clhip_memcpy_d2h(room, dev->d_bytes, left, dev->stream);
+    if (clhip_stream_sync(dev->stream) || bad) return CL_SMI_ERR_IO;
     cl_smi_tx_commit(dev, left);                                /* len &= ~3 (:745) never bites: 4 bytes per sample */
     written_so_far = left / CL_BYTES_PER_SAMPLE;                /* :757 */
     dev->stat_written += written_so_far;

@@ -380,9 +380,10 @@ class Group:
         return lib().cl_group_last_error(self.h).decode()
 
     def stats(self):
-        out = (C.c_uint64 * 6)()
+        out = (C.c_uint64 * 9)()
         lib().cl_group_getStats(self.h, out)
-        return dict(zip(("calls", "batched_reads", "single_reads", "direct_reads", "launches", "errors"), [int(v) for v in out]))
+        return dict(zip(("calls", "batched_reads", "single_reads", "direct_reads", "launches", "errors", "last_queue_us", "last_arrive_us",
+                         "last_total_us"), [int(v) for v in out]))
 
     def close(self):
         if getattr(self, "h", None) and _lib is not None:

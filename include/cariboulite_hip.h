@@ -568,8 +568,9 @@ void   cl_stream_set_iir_poll_bound(cl_stream *stream, int polls);
  * route inside the same call.
  * Make the group AFTER cl_setupStream of every member (RX); members are grouped by channel type and stream configuration
  * (format, FIR / RESAMP / DEMOD kwargs); a group with extension stages owns their state (one n-stream pipe per
- * configuration), so its members are read through the group from then on.  kwargs: SUBBATCH=<streams per launch> (8),
- * COPY_THREADS=<n> (4; 0 = the caller copies).  Returns the number of streams that delivered (> 0 elements), or -1 on a
+ * configuration), so its members are read through the group from then on.  kwargs: SUBBATCH=<streams per launch> (4),
+ * COPY_THREADS=<n> (4; 0 = the caller copies), SINK=copy (the sub-batch's outputs leave through
+ * a device buffer and the copy engine instead of being stored into the mapped pinned mirror by the kernel itself).  Returns the number of streams that delivered (> 0 elements), or -1 on a
  * runtime error (cl_group_last_error; NULL group = the last cl_group_make failure). */
 typedef struct cl_group cl_group;
 typedef struct {
@@ -579,6 +580,9 @@ typedef struct {
     uint64_t direct_reads;       /* batched reads the copy engine wrote into a registered client buffer            */
     uint64_t launches;           /* kernel launches of the batched route                                           */
     uint64_t errors;             /* calls that ended with a runtime error                                          */
+    uint64_t last_queue_us;      /* the last call: everything staged and queued after ... us                       */
+    uint64_t last_arrive_us;     /*                the last sub-batch had arrived and was handed to the copy threads */
+    uint64_t last_total_us;      /*                returned                                                         */
 } cl_group_stats;
 cl_group   *cl_group_make(cl_device *const *devs, size_t n_devs, const char *const *keys, const char *const *vals, size_t n_kwargs);
 void        cl_group_unmake(cl_group *g);

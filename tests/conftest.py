@@ -56,7 +56,13 @@ def _install_abort_trace():
             faulthandler.enable()                 # (first: ours chains to the handler it finds)
         out = os.environ.get("CL_ABRT_TRACE_FILE", os.path.join(ROOT, "gpurun_out", "abrt_trace.txt"))
         os.makedirs(os.path.dirname(out), exist_ok=True)
-        ctypes.CDLL(lib).abrt_trace_install(out.encode())   # (under pytest fd 2 is a capture file that dies with the process)
+        tr = ctypes.CDLL(lib)
+        tr.abrt_trace_install(out.encode())                 # (under pytest fd 2 is a capture file that dies with the process)
+        # ... followed by the product library's own record of what it did with host memory it does not own (registrations,
+        # releases, copies: clhip_debug_ops_dump), so that a GPU fault address on the host heap can be set against it
+        from cariboulite_amd import hip
+        tr.abrt_trace_set_dump.argtypes = [ctypes.c_void_p]
+        tr.abrt_trace_set_dump(ctypes.cast(hip.lib().clhip_debug_ops_dump, ctypes.c_void_p))
     except Exception as e:                        # a diagnostic must never fail a session
         print("abort trace not installed:", e, file=sys.stderr)
 

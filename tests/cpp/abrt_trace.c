@@ -12,6 +12,8 @@
 #include <sys/syscall.h>
 
 static struct sigaction g_prev;
+static void (*g_dump)(int fd);      /* libcariboulite_hip.so's clhip_debug_ops_dump (write(2) only): the library's last 256 registrations,
+                                     * releases and copies of host memory it does not own -- what a fault address on the host heap is set against */
 static int g_fd = -1;       /* a file of our own: under pytest fd 2 is a capture file that dies with the process */
 
 static void put(const char *s) { if (write(2, s, strlen(s)) < 0) { } if (g_fd >= 0 && write(g_fd, s, strlen(s)) < 0) { } }
@@ -30,11 +32,14 @@ static void on_abrt(int sig, siginfo_t *info, void *ctx)
     backtrace_symbols_fd(frames, n, 2);
     if (g_fd >= 0) { backtrace_symbols_fd(frames, n, g_fd); fsync(g_fd); }
     put("==== end of native stack ====\n");
+    if (g_dump) { g_dump(2); if (g_fd >= 0) { g_dump(g_fd); fsync(g_fd); } }
     if (g_prev.sa_flags & SA_SIGINFO) { if (g_prev.sa_sigaction) { g_prev.sa_sigaction(sig, info, ctx); return; } }
     else if (g_prev.sa_handler != SIG_DFL && g_prev.sa_handler != SIG_IGN) { g_prev.sa_handler(sig); return; }
     signal(SIGABRT, SIG_DFL);
     raise(SIGABRT);
 }
+
+void abrt_trace_set_dump(void (*fn)(int)) { g_dump = fn; }
 
 int abrt_trace_install(const char *path)
 {
