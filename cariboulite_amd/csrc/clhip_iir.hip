@@ -642,7 +642,7 @@ struct IirRailArgs {
     const double *state_in;
     double *state_out;
     unsigned int *overrun;                 // the object's pinned host word (device address)
-    int poll_bound, dbg, n_classes, dynamic, prio;
+    int poll_bound, n_classes, dynamic, prio;
     int in_sh0, in_sh1, in_width;          // where the two rails sit in an input word: CS16 {0, 16, 16}; raw SMI words {17, 1, 13} (S1G) / {1, 17, 13} (HiF)
     unsigned long long *stamps;            // diagnostics (CLHIP_IIR_STAMPS=1): [RL_STAMP_WAVES][RL_STAMP_TILES][RL_STAMP_PHASES] of s_memrealtime
 };
@@ -889,9 +889,9 @@ __global__ __launch_bounds__(64, RL_WAVES) void iir_rail_kernel(const IirRailArg
             RL_STAMP(1);
 #pragma unroll
             for (int k = 0; k < D; k++) v[k] = 0.0;
-            if (!(A.dbg & 4)) rail_segment_fir<D, SEG>(v, iir_sm + m * PITCH, G, sh, A.in_width);
+            rail_segment_fir<D, SEG>(v, iir_sm + m * PITCH, G, sh, A.in_width);
             RL_STAMP(2);
-            if (!(A.dbg & 8)) {
+            {
                 // Kogge-Stone over the 32 segments of the rail: v_m <- v_m + P^(2^d) v_(m - 2^d)
 #pragma unroll 1
                 for (int d = 0; d < 5; d++) {
@@ -904,7 +904,7 @@ __global__ __launch_bounds__(64, RL_WAVES) void iir_rail_kernel(const IirRailArg
             RL_STAMP(3);
         };
         auto publish = [&](long b, int t, const double (&v)[D]) {
-            if ((t >> 1) == RL_SEGS - 1 && !(A.dbg & 32)) {
+            if ((t >> 1) == RL_SEGS - 1) {
                 unsigned long long *mine = A.agg + ((s * A.n_tiles + b) * 2 + (t & 1)) * D;
 #pragma unroll
                 for (int k = 0; k < D; k++)
@@ -968,7 +968,7 @@ __global__ __launch_bounds__(64, RL_WAVES) void iir_rail_kernel(const IirRailArg
 #pragma unroll
                 for (int k = 0; k < D; k++) a[k] = 0.0;
                 // (the carried state is read like an aggregate that is already there: one code path, one wait)
-                bool pending = want && !(A.dbg & 1);
+                bool pending = want;
                 const unsigned long long *theirs = j >= 0 ? A.agg + ((s * A.n_tiles + j) * 2 + rail) * D
                                                           : (const unsigned long long *)(A.state_in + s * 2 * IIR_MAX_DIM + rail * IIR_MAX_DIM);
                 int guard = 0;
@@ -1037,10 +1037,7 @@ __global__ __launch_bounds__(64, RL_WAVES) void iir_rail_kernel(const IirRailArg
             // waves per SIMD the other waves cover the round trip, and the D (D + 2) registers are free during the wait.
             // Four biquads take the rows in two halves (80 registers of table entries would not fit beside the state).
             double z[D];
-            if (A.dbg & 16) {
-#pragma unroll
-                for (int r = 0; r < D; r++) z[r] = v[r] + cv[r];
-            } else {
+            {
                 const gdouble_t *pt = (const gdouble_t *)&tab->ptab[0][0] + m;
                 constexpr int RCH = NS < 4 ? D : D / 2;
 #pragma unroll
@@ -1076,7 +1073,7 @@ __global__ __launch_bounds__(64, RL_WAVES) void iir_rail_kernel(const IirRailArg
             if constexpr (PF) rail_tile_issue<SEG>(sin + bn * TILE, have_next && tile_whole(bn), raw, t);
             RL_STAMP(8);
             const long seg = b * RL_SEGS + m;
-            if (seg < A.n_seg && !(A.dbg & 2)) {
+            if (seg < A.n_seg) {
                 if (tile0 + TILE <= A.n) rail_recursion<NS, SEG, true, B121>(A.c, x, SEG, z, sh, A.in_width, rail);
                 else {
                     const long cnt = A.n - seg * SEG < SEG ? A.n - seg * SEG : SEG;
@@ -1093,7 +1090,7 @@ __global__ __launch_bounds__(64, RL_WAVES) void iir_rail_kernel(const IirRailArg
             for (int k = 0; k < D; k++) zend[k] = __shfl(z[k], 2 * (RL_SEGS - 1) + rail, 64);
             RL_STAMP(9);
             __syncthreads();
-            if (!(A.dbg & 64)) rail_tile_store<SEG>(xout, whole, A.n - tile0, iir_sm, t);
+            rail_tile_store<SEG>(xout, whole, A.n - tile0, iir_sm, t);
             __syncthreads();                                           // the rows are free for the next tile
             RL_STAMP(10);
         }
@@ -1150,11 +1147,7 @@ static const int kRailSegs[3] = {16, 32, 64};
 // is orders of magnitude above the bound.  (1e-18 until round 3: H = 2 tiles for the reference's 50 kHz filter at
 // 64-sample segments where 1e-12 gives 1 -- one prologue tile per chunk instead of two, 3 % of the run time.)  0 = no such H
 // within RL_HMAX, or the cascade's l1 gain lets 32768 x it pass 2^30 (the kernel's v_cvt_i32_f32 equals cvttss2si's low half only for |y| < 2^31).
-static double iir_horizon_eps()
-{
-    static const double eps = getenv("CLHIP_IIR_HORIZON_EPS") ? atof(getenv("CLHIP_IIR_HORIZON_EPS")) : 1e-12;     // experiment knob
-    return eps > 0 ? eps : 1e-12;
-}
+static double iir_horizon_eps() { return 1e-12; }
 
 static void iir_rail_tab_build(int dim, const double *F, int seg, const double *smax, bool bounded, IirRailTab *tb)
 {
@@ -1319,8 +1312,6 @@ static int iir_resident_waves(iir_rail_fn fn, int seg)
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64, RL_SEGS * (seg + 4) * 4) != hipSuccess || per_cu < 1) per_cu = 1;
     if (per_cu > 4) per_cu -= per_cu % 4;                        // the same number of waves on each of the CU's four SIMDs
-    static const int env = getenv("CLHIP_IIR_WG_PER_CU") ? atoi(getenv("CLHIP_IIR_WG_PER_CU")) : 0;   // experiment knob
-    if (env > 0 && env < per_cu) per_cu = env;
     cache.push_back({device, fn, cus * per_cu});
     return cus * per_cu;
 }
@@ -1394,9 +1385,9 @@ extern "C" clhip_iir *clhip_iir_create(const double *h_sos, int n_stages, int n_
     }
     // tests force the give-up path with -1; the default bound is ~0.1 s of polling, after which the call is rolled back
     // and repeated on the scan path (a launch that moves at all never gets there: see the kernel's header)
-    f->poll_bound = getenv("CLHIP_IIR_POLL_BOUND") ? atoi(getenv("CLHIP_IIR_POLL_BOUND")) : (1 << 16);
-    f->seg_force = getenv("CLHIP_IIR_SEG") ? atoi(getenv("CLHIP_IIR_SEG")) : 0;           // experiment knobs
-    f->dynamic = getenv("CLHIP_IIR_DYNAMIC") ? atoi(getenv("CLHIP_IIR_DYNAMIC")) : 1;
+    f->poll_bound = 1 << 16;
+    f->seg_force = 0;                    // (clhip_iir_set_shape: tests force every segment length and both tile orders)
+    f->dynamic = 1;
     f->force_scan = getenv("CLHIP_IIR_ONEPASS") && atoi(getenv("CLHIP_IIR_ONEPASS")) == 0;   // A/B: the four-kernel scan for everything
     if (getenv("CLHIP_IIR_STAMPS") && atoi(getenv("CLHIP_IIR_STAMPS"))) {
         f->d_stamps = (unsigned long long *)clhip_malloc(sizeof(unsigned long long) * (RL_STAMP_WAVES * RL_STAMP_TILES * RL_STAMP_PHASES + 3 * RL_STAMP_ALLWAVES));
@@ -1418,6 +1409,7 @@ extern "C" size_t clhip_iir_debug_stamps(clhip_iir *f, unsigned long long *h_out
 }
 
 extern "C" void clhip_iir_set_poll_bound(clhip_iir *f, int polls) { if (f) f->poll_bound = polls; }
+extern "C" void clhip_iir_set_shape(clhip_iir *f, int seg, int dynamic) { if (f) { f->seg_force = seg == 16 || seg == 32 || seg == 64 ? seg : 0; f->dynamic = dynamic != 0; } }
 
 // The filter's MEMORY in samples: after that many samples nothing a state could have held is left above the single-pass
 // kernel's bound (1e-12 absolute for full-scale int16 input: iir_rail_tab_build).  A filter that starts from rest that far
@@ -1564,8 +1556,8 @@ static int iir_run_impl(clhip_iir *f, const int16_t *d_in, int16_t *d_out, size_
         const int resident = iir_resident_waves(fn, seg);
         // a wave takes CHUNKS of consecutive tiles of one stream: as many as share the launch evenly over the resident
         // waves (one native batch: 1; 2^26 samples: 8), so that only a chunk's first tile looks at other waves' work
-        static const int chunk_env = getenv("CLHIP_IIR_CHUNK") ? atoi(getenv("CLHIP_IIR_CHUNK")) : 0;        // experiment knob
-        long chunk = chunk_env > 0 ? chunk_env : (long)clhip_div_up((size_t)(n_tiles * f->n_streams), (size_t)resident);
+        // (round 3, 2^26 samples: chunks of 4 / 16 tiles instead of 8 lose -- 0.252 / 0.248 against 0.233 ms -- as do 12 or 8 waves per CU)
+        long chunk = (long)clhip_div_up((size_t)(n_tiles * f->n_streams), (size_t)resident);
         if (chunk > n_tiles) chunk = n_tiles;
         const long chunks_per_stream = (long)clhip_div_up((size_t)n_tiles, (size_t)chunk);
         const long total = chunks_per_stream * f->n_streams;
@@ -1573,7 +1565,6 @@ static int iir_run_impl(clhip_iir *f, const int16_t *d_in, int16_t *d_out, size_
         const unsigned grid = (unsigned)(total < resident ? total : resident);
         int nc = RL_CLASSES;
         while ((unsigned)nc > grid) nc >>= 1;
-        static const int dbg = getenv("CLHIP_IIR_DBG") ? atoi(getenv("CLHIP_IIR_DBG")) : 0;          // timing ablations only (results invalid)
         IirRailArgs a;
         a.G = &f->pe->dev->G[0][0]; a.tab = &f->pe->dev->rail[shape]; a.c = plan.coef;
         a.in = (const uint32_t *)d_in; a.out = (uint32_t *)d_out;
@@ -1583,13 +1574,10 @@ static int iir_run_impl(clhip_iir *f, const int16_t *d_in, int16_t *d_out, size_
         a.ctl = f->d_ctl;
         a.agg = f->d_agg[f->acur]; a.agg_other = f->d_agg[f->acur ^ 1]; a.other_words = (long)f->dirty[f->acur ^ 1];
         a.state_in = st_in; a.state_out = st_out;
-        a.overrun = f->d_over; a.poll_bound = f->poll_bound; a.dbg = dbg; a.n_classes = nc; a.dynamic = f->dynamic;
+        a.overrun = f->d_over; a.poll_bound = f->poll_bound; a.n_classes = nc; a.dynamic = f->dynamic;
         a.stamps = f->d_stamps;
         a.in_sh0 = in_sh0; a.in_sh1 = in_sh1; a.in_width = in_width;
-        static const int prio_env = getenv("CLHIP_IIR_PRIO") ? atoi(getenv("CLHIP_IIR_PRIO")) : 1;       // A/B: 0 = every wave at priority 0
-        a.prio = prio_env && chunk > 1;
-        static const int verbose = getenv("CLHIP_IIR_VERBOSE") ? atoi(getenv("CLHIP_IIR_VERBOSE")) : 0;
-        if (verbose) fprintf(stderr, "clhip_iir_run: seg %d tiles %ld chunk %ld chunks %ld grid %u (resident %d) classes %d horizon %d dynamic %d\n", seg, n_tiles * f->n_streams, chunk, total, grid, resident, nc, a.horizon, a.dynamic);
+        a.prio = chunk > 1;                    // a wave lowers its priority as it advances through its chunk (the four waves of a SIMD finish 32 instead of 96 us apart: -4 %)
         hipLaunchKernelGGL(fn, dim3(grid), dim3(64), RL_SEGS * (seg + 4) * 4, s, a);
         CLHIP_CHECK_LAUNCH();
         f->dirty[f->acur] = words > f->dirty[f->acur] ? words : f->dirty[f->acur];

@@ -1345,8 +1345,6 @@ static int launch_pipe(PipeArgs &a, hipStream_t s)
             // queue mode: exactly what is resident (the tile queue keeps every worker busy to the end);
             // static striding: 4x oversubscribed, queued workgroups back-fill as residents finish
             if (a.queue_k == 0) per_cu *= 4;
-            const char *e = getenv("CLHIP_WG_PER_CU");
-            if (e && atoi(e) > 0) per_cu = atoi(e);
             resident_on[slot] = cus * per_cu;
         }
         resident = resident_on[slot];
@@ -1423,8 +1421,8 @@ static long run_impl(clhip_rx_pipe *p, int first, int count, unsigned long long 
     // ahead: 1 against 2 on four boxes 0.8926 / 0.8966, 0.919 / 0.925, 0.8953 / 0.8988, 0.8950 / 0.8976 ms (every pair in that
     // order), config 4 2.448 / 2.455 -- but one per 11.9 ns for config 3 (FM demod: 4 bytes out per sample, short tiles), past
     // it: 0.8164 against 0.7790 ms.  So: one tile per ticket for the two resampling shapes that were measured, two otherwise.
-    static const int queue_k_env = getenv("CLHIP_QUEUE_K") ? atoi(getenv("CLHIP_QUEUE_K")) : -1;
-    a.queue_k = queue_k_env >= 0 ? queue_k_env : ((p->fused_id == 0 || p->fused_id == 2) ? 1 : 2);
+    // (static striding over a 4x oversubscribed grid -- queue_k = 0 -- measured 0.898-0.934 ms against 0.893: profiles/r03/c2_grid_sweep.txt)
+    a.queue_k = (p->fused_id == 0 || p->fused_id == 2) ? 1 : 2;
     a.in_scale = in_kind == CL_PIPE_IN_CF32 ? 1.0f : 4096.0f;
     a.fir = in_kind == CL_PIPE_IN_CF32 ? p->d_fir : p->d_fir_int;
     const float *ffa_taps = in_kind == CL_PIPE_IN_CF32 ? p->d_ffa : p->d_ffa_int;
@@ -1444,7 +1442,6 @@ static long run_impl(clhip_rx_pipe *p, int first, int count, unsigned long long 
         a.b_out_lo = d_out; a.b_out_hi = (unsigned char *)d_out + ((size_t)(count - 1) * out_stride + n_out) * ob;
     }
 #endif
-    if (getenv("CLHIP_DEBUG_NOSTORE")) a.n_out = 0;     // timing ablation only: every store masked off
     bool fused_done = false;
     if (uses_fused_at(p, nt, in_kind)) {
         int rc = -1;

@@ -295,13 +295,15 @@ __global__ __launch_bounds__(FM_BLOCK) void tx_fm_fused_kernel(
 //
 // Phase is kept in TURNS (fp64): phi_t[n] = phi_t[n-1] + (kf/fs) m[n].  v_fract_f64 wraps it, and
 // v_sin_f32 / v_cos_f32 take turns directly, so a phasor costs fract + cvt + two transcendental ops.
-//   pass A  fm_super_sum_kernel : fp64 sum of one superblock (TXQ_SB messages) per workgroup
-//   pass B  fm_super_scan_kernel: exclusive scan of the superblock sums (one workgroup per stream)
-//   pass C  tx_fm_fast_kernel   : one workgroup per superblock walks it in sub-blocks of TXQ_SUB
-//           messages with a running fp64 offset; each lane owns PER consecutive messages (local
-//           fp64 prefix, wave scan by shuffles), writes its phasors to a padded LDS row, then computes
-//           PER*L/M outputs from an 8-row-sample-overlapping register window with the polyphase taps
-//           in SGPRs (compile-time phases), quantises, packs and stores 16-byte pieces.
+// One workgroup per superblock of TXQ_NSUB sub-blocks (tx_fm_chain_kernel; small calls: one sub-block per workgroup,
+// tx_fm_chain1_kernel): the superblock's fp64 sum, a decoupled look-back over the sums before it, then its sub-blocks of
+// TXQ_SUB messages with a running fp64 offset; each lane owns PER consecutive messages (local fp64 prefix, wave scan by
+// DPP), writes its phasors to a padded LDS row, then computes PER*L/M outputs from an 8-row-sample-overlapping register
+// window with the polyphase taps in SGPRs (compile-time phases), quantises, packs and stores 16-byte pieces.
+// (Round 3 built and measured around this: a three-launch form (sums, scan, fused), messages kept in registers / in LDS
+// between the two passes, a register prefetch of the next sub-block, stores transposed through LDS, four look-back words
+// per lane, a barrier-free sub-block loop, a two-role launch of summers and workers -- DESIGN.md section 8 has the numbers;
+// none was faster and none is here any more.)
 // LDS rows: PER samples (8 B each) + 16 B pad -> lane pitch 112 B at PER = 12: ds_write_b128 /
 // ds_read_b128 are conflict-free.  Row -1 holds the 8 samples before the sub-block.
 // ---------------------------------------------------------------------------
@@ -309,15 +311,6 @@ __global__ __launch_bounds__(FM_BLOCK) void tx_fm_fused_kernel(
 #define TXQ_NT 256                         // lanes per workgroup.  Config 5 through the chain kernel, one box (round 3): 64 lanes x 12 / 24 sub-blocks
 #endif                                     // 0.43-0.50 ms, 128 x 6 / 12: 0.29 / 0.39, 256 x 6: 0.269-0.277, 512 x 3 / 4 / 6: 0.32 / 0.31 / 0.31, 1024 x 3: 0.37
                                            // -- barriers are not what it waits for: smaller workgroups mean more look-back words per message
-// TXQ_KEEP=1 (compile-time experiment): the superblock's messages stay in registers between the sum pass and the
-// sub-block loop, so the stream is read once -- 147 / 179 / 234 VGPRs at 3 / 4 / 6 sub-blocks instead of 85, and
-// 0.295 / 0.318 / 0.284 ms on config 5 against 0.268 with the re-read: occupancy, which hides the look-back, is worth more
-// TXQ_KEEP=2: the superblock's messages wait in LDS instead (4 bytes per message: 48 KB at four sub-blocks, beside the
-// 29 KB of phasor rows: two workgroups per CU as before), so the stream is read from memory once -- see the table at
-// TXQ_NSUB for what it costs
-#ifndef TXQ_KEEP
-#define TXQ_KEEP 0
-#endif
 // sub-blocks per superblock (round 2, look-back in front of the arithmetic): 4 -> 0.290 ms, 5 -> 0.276, 6 -> 0.268, 7 -> 0.276,
 // 8 -> 0.274 (config 5, 2^27 messages); round 3, at five waves per SIMD (96 VGPRs: 7 and 8 sub-blocks spill): 4 -> 0.281, 5 -> 0.277,
 // 6 -> 0.270, 7 -> 0.288-0.298, 8 -> 0.326 (tools/bench_tx.py, one box)
@@ -328,20 +321,6 @@ __global__ __launch_bounds__(FM_BLOCK) void tx_fm_fused_kernel(
 #define TXQ_CHAIN_WAVES 4                  // waves per SIMD the chain kernel's register budget is cut for.  5 (96 VGPRs) was round 3's first choice; with the
 #endif                                     // interior superblocks on a path of their own (tx_chain_work<C, true>) the sum pass wants its 18-24 loads in flight
                                            // at once, which 96 registers cannot hold without spilling: 4 waves (109 VGPRs, no spills) 0.2447 ms against 0.2487 at 5
-#ifndef TXQ_PREFETCH
-#define TXQ_PREFETCH 0                     // 1: the chain kernel requests sub-block sb + 1's messages before it works sub-block sb: 12 registers more, 122 VGPRs
-                                           // = four waves per SIMD; config 5, one box: 0.267-0.272 ms without (five waves), 0.274-0.282 with (four), 0.277-0.282
-                                           // without at four waves, 0.39 with at five (spills): the fifth wave hides what the prefetch would
-#endif
-#ifndef TXQ_ABL
-#define TXQ_ABL 0                          // timing ablations of the chain kernel (results invalid; tools/tx_ablations.sh): 1 = the sum pass reads sub-block 0 only,
-#endif                                     // 2 = the sub-block loop reads no messages, 4 = no output stores, 8 = no look-back
-#ifndef TXQ_CARRY
-#define TXQ_CARRY 1                        // interior superblocks: sub-block 0's messages stay in registers from the sum pass to its arithmetic, and
-#endif                                     // sub-block 1's are requested before the look-back instead of after it (0: round 3's first form)
-#ifndef TXQ_P1_REVERSE
-#define TXQ_P1_REVERSE 1                   // the sum pass walks the superblock backwards: the second pass then starts on the most recently read lines (-4 % HBM reads, -1 % time)
-#endif
 typedef __attribute__((address_space(4))) float tx_cfloat_t;
 typedef f32x4 __attribute__((aligned(4))) f32x4_a4;      // 16-byte global access at dword alignment (unaligned mode)
 typedef u32x4 __attribute__((aligned(4))) u32x4_a4;
@@ -350,10 +329,7 @@ typedef u32x4 __attribute__((aligned(4))) u32x4_a4;
 // then row_bcast:15 (rows 1 and 3 take the totals of rows 0 and 2) and row_bcast:31 (rows 2 and 3 take the total of the
 // lower half).  Six steps of two v_mov_dpp and one v_add_f64 -- no LDS round trip; the shuffle form (__shfl_up = two
 // ds_bpermute_b32 per step and a select) was 0.7 us of a sub-block's 3.3 in the config-5 kernel's dependent chain.
-// Lanes a step does not reach add +0.0.  TXQ_DPP_SCAN=0: the shuffle form.
-#ifndef TXQ_DPP_SCAN
-#define TXQ_DPP_SCAN 1
-#endif
+// Lanes a step does not reach add +0.0.
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_take_f64(double v)
 {
@@ -364,7 +340,6 @@ __device__ __forceinline__ double dpp_take_f64(double v)
 }
 __device__ __forceinline__ double wave_inclusive_scan_f64(double v)
 {
-#if TXQ_DPP_SCAN
     v += dpp_take_f64<0x111, 0xF>(v);          // row_shr:1
     v += dpp_take_f64<0x112, 0xF>(v);          // row_shr:2
     v += dpp_take_f64<0x114, 0xF>(v);          // row_shr:4
@@ -372,15 +347,6 @@ __device__ __forceinline__ double wave_inclusive_scan_f64(double v)
     v += dpp_take_f64<0x142, 0xA>(v);          // row_bcast:15 -> rows 1, 3
     v += dpp_take_f64<0x143, 0xC>(v);          // row_bcast:31 -> rows 2, 3
     return v;
-#else
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const double up = __shfl_up(v, o, 64);
-        if (lane >= o) v += up;
-    }
-    return v;
-#endif
 }
 
 template <int L_, int M_, int KP_> struct TxCfg {
@@ -401,81 +367,9 @@ __device__ __forceinline__ f32x2 phasor_turns(double t)
     return o;
 }
 
-// Index space of passes A and C: VIRTUAL message index i' = i + phi, phi = n0 mod M, so that i' = 0 sits on
+// Index space of the config-5 kernels: VIRTUAL message index i' = i + phi, phi = n0 mod M, so that i' = 0 sits on
 // polyphase phase 0 whatever the call's start; the phi virtual messages before the call carry no phase
 // increment (their phasors come from the history) and the outputs they own were emitted by the previous call.
-template <class C>
-__global__ __launch_bounds__(TXQ_NT) void fm_super_sum_kernel(const float *__restrict__ m, long m_stride, size_t nv, int phi,
-                                                              double wt, double *__restrict__ ssum, long n_super)
-{
-    __shared__ double sh[TXQ_NT / 64];
-    const float *mm = m + (long)blockIdx.y * m_stride - phi;          // indexed by i'
-    const size_t base = (size_t)blockIdx.x * C::SB;
-    double s = 0.0;
-    if (base >= (size_t)phi && base + C::SB <= nv) {
-#pragma unroll 4
-        for (int i = 0; i < C::SB / 4 / TXQ_NT; i++) {
-            const f32x4 v = *(const f32x4_a4 *)(mm + base + 4 * ((size_t)i * TXQ_NT + threadIdx.x));
-            s += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
-        }
-    } else {
-        for (size_t j = base + threadIdx.x; j < nv && j < base + C::SB; j += TXQ_NT) s += j >= (size_t)phi ? (double)mm[j] : 0.0;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = 0.0;
-        for (int k = 0; k < TXQ_NT / 64; k++) t += sh[k];
-        ssum[(long)blockIdx.y * n_super + blockIdx.x] = t * wt;
-    }
-}
-
-// exclusive scan in turns, each offset wrapped to [0,1); phase_in / phase_new are radians in (-pi, pi].
-// One workgroup per stream walks the sums in tiles of 8192 staged through LDS (coalesced both ways): lane-local
-// serial scan of 32 entries from LDS, wave scan by shuffles, 4 wave totals, a running carry between tiles.
-#define SCAN_TILE 8192
-__global__ __launch_bounds__(256) void fm_super_scan_kernel(double *__restrict__ ssum, long n_super,
-                                                            const double *__restrict__ phase_in,
-                                                            double *__restrict__ phase_new)
-{
-    __shared__ double tile[SCAN_TILE + SCAN_TILE / 32];           // one pad per 32 entries: lane chunks on distinct banks
-    __shared__ double wsum[4];
-    double *b = ssum + (long)blockIdx.x * n_super;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    double carry = phase_in[blockIdx.x] * (1.0 / TWO_PI);
-    for (long t0 = 0; t0 < n_super; t0 += SCAN_TILE) {
-        const int cnt = (int)(n_super - t0 < SCAN_TILE ? n_super - t0 : SCAN_TILE);
-#pragma unroll 8
-        for (int i = t; i < SCAN_TILE; i += 256) tile[i + i / 32] = i < cnt ? b[t0 + i] : 0.0;
-        __syncthreads();
-        double *mine = tile + t * 33;
-        double run = 0.0;
-#pragma unroll 8
-        for (int k = 0; k < 32; k++) { const double v = mine[k]; mine[k] = run; run += v; }      // exclusive within the lane
-        double incl = run;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const double up = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += up;
-        }
-        if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
-        double base = carry, total = 0.0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) { const double v = wsum[k]; total += v; if (k < wave) base += v; }
-        base += incl - run;
-#pragma unroll 8
-        for (int k = 0; k < 32; k++) { const double v = base + mine[k]; mine[k] = v - floor(v); }
-        __syncthreads();
-#pragma unroll 8
-        for (int i = t; i < SCAN_TILE; i += 256) if (i < cnt) b[t0 + i] = tile[i + i / 32];
-        carry += total; carry -= floor(carry);
-        __syncthreads();
-    }
-    if (t == 0) phase_new[blockIdx.x] = wrap_pi(TWO_PI * (carry - rint(carry)));
-}
 
 // (int16_t)(f * 4096.0f) as the x86-64 reference build does it (cvttss2si, low 16 bits): v_cvt_i32_f32
 // saturates where cvttss2si returns 0x80000000, which only changes the low half for f >= 2^31; NaN gives 0 on both
@@ -500,39 +394,14 @@ __device__ unsigned long long g_tx_stamps[TX_STAMP_WGS * TX_STAMP_N];
 #else
 #define TXS(i) do { } while (0)
 #endif
-// Interior stores of one sub-block, every store instruction 1 KiB-contiguous.  A lane owns NOUT consecutive packed words
-// (32 bytes at NOUT = 8): stored directly, an instruction writes 16 bytes of every 32 -- half of each 128-byte line, the
-// other half by the next instruction.  Instead the wave's 2 KiB go through LDS (the wave's OWN phasor rows, whose window
-// reads this wave has behind it; its last row, which the next wave's first lane and the hand-over of the tail still
-// read, is left alone) and come back lane-contiguous.  16 bytes of padding per 8 lanes keep both directions conflict-free.
-#ifndef TXQ_STORE_T
-#define TXQ_STORE_T 0                      // 1: through LDS as described; config 5, one box: 0.2665-0.2720 ms with, 0.2663-0.2690 without -- the
-                                           // stores' shape is not what this kernel waits for, and the transposes cost registers (the prefetch build spills with them)
-#endif
 template <class C>
-__device__ __forceinline__ void tx_store_words(unsigned char *rows, const uint32_t (&wd)[C::NOUT], uint32_t *wp)
+__device__ __forceinline__ void tx_store_words(const uint32_t (&wd)[C::NOUT], uint32_t *wp)
 {
-    constexpr int NOUT = C::NOUT;
-    if constexpr (TXQ_STORE_T && NOUT == 8 && 63 * C::ROW >= 64 * 32 + 8 * 16) {
-        const int t = threadIdx.x, lane = t & 63;
-        unsigned char *reg = rows + ((t & ~63) + 1) * C::ROW;              // rows of this wave's lanes 0 .. 62
-        unsigned char *mine = reg + lane * 32 + (lane >> 3) * 16;
-        *(u32x4 *)mine = u32x4{wd[0], wd[1], wd[2], wd[3]};
-        *(u32x4 *)(mine + 16) = u32x4{wd[4], wd[5], wd[6], wd[7]};
-        uint32_t *wave_wp = wp - lane * NOUT;                                // (uniform per wave: lane 0's first word)
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int piece = j * 64 + lane, owner = piece >> 1;
-            const u32x4 v = *(const u32x4 *)(reg + owner * 32 + (owner >> 3) * 16 + (piece & 1) * 16);
-            *(u32x4_a4 *)(wave_wp + 4 * piece) = v;
-        }
-    } else {
-#pragma unroll
-        for (int q = 0; q < NOUT / 4; q++) { const u32x4 v = {wd[4 * q], wd[4 * q + 1], wd[4 * q + 2], wd[4 * q + 3]}; *(u32x4_a4 *)(wp + 4 * q) = v; }
-    }
+    for (int q = 0; q < C::NOUT / 4; q++) { const u32x4 v = {wd[4 * q], wd[4 * q + 1], wd[4 * q + 2], wd[4 * q + 3]}; *(u32x4_a4 *)(wp + 4 * q) = v; }
 }
 
-// One sub-block of tx_fm_fast_kernel.  CHECKED = false: every message and every output of the sub-block is inside
+// One sub-block in the absolute frame (its start phase known).  CHECKED = false: every message and every output of the sub-block is inside
 // the call (workgroup-uniform), so there is not a single bounds test or divergent branch in it.
 template <class C, bool CHECKED>
 __device__ __forceinline__ void tx_load_msgs(const float *mm, size_t n, int phi, size_t tb, float (&mv)[C::PER])
@@ -650,7 +519,7 @@ __device__ __forceinline__ double tx_fast_subblock(const float (&mv)[C::PER], si
     const long j0 = (long)(tb / M) * L - skip;                 // tb is a multiple of M; the first `skip` outputs are not ours
     uint32_t *wp = words_s + j0;
     if (!CHECKED) {
-        if (!(TXQ_ABL & 4) || n_out < 0) tx_store_words<C>(rows, wd, wp);
+        tx_store_words<C>(wd, wp);
     } else if (j0 >= 0 && j0 + NOUT <= n_out) {
 #pragma unroll
         for (int q = 0; q < NOUT / 4; q++) { const u32x4 v = {wd[4 * q], wd[4 * q + 1], wd[4 * q + 2], wd[4 * q + 3]}; *(u32x4_a4 *)(wp + 4 * q) = v; }
@@ -668,57 +537,6 @@ __device__ __forceinline__ double tx_fast_subblock(const float (&mv)[C::PER], si
     __syncthreads();
     if (t < HS) *(f32x2 *)(rows + 8 * (PER - HS + t)) = keep;
     return off;
-}
-
-template <class C>
-__global__ __launch_bounds__(TXQ_NT, 2) void tx_fm_fast_kernel(
-    const float *__restrict__ m, long m_stride, size_t n, int phi, int skip, double wt, const double *__restrict__ soff,
-    long n_super, const f32x2 *__restrict__ hist_in, f32x2 *__restrict__ hist_out, const float *__restrict__ rs_dev,
-    long n_out, int pack_mode, uint32_t *__restrict__ words, long w_stride, f32x2 *__restrict__ tap, long tap_stride)
-{
-    constexpr int KP = C::KP, PER = C::PER, ROW = C::ROW, HS = C::HSLOT, H = KP - 1;
-    __shared__ __attribute__((aligned(16))) unsigned char rows[(TXQ_NT + 1) * ROW];   // row r at (r + 1) * ROW
-    __shared__ double sh[TXQ_NT / 64 + 1];
-    const int s = blockIdx.y, t = threadIdx.x;
-    const float *mm = m + (long)s * m_stride - phi;                   // indexed by the virtual message index; n = virtual count
-    const size_t sbase = (size_t)blockIdx.x * C::SB;
-    const tx_cfloat_t *__restrict__ rs = (const tx_cfloat_t *)rs_dev;
-    double off = soff[(long)s * n_super + blockIdx.x];           // phase (turns) after message sbase-1
-
-    // the HS samples before the superblock -> tail of row -1
-    if (t < HS) {
-        const int k = t + 1;                                       // message sbase - k
-        f32x2 hv = {0.f, 0.f};
-        if (k <= H) {
-            if (sbase >= (size_t)k) {
-                double ph = off;
-                for (int i = 1; i < k; i++) ph -= wt * (double)mm[sbase - i];
-                hv = phasor_turns(ph);
-            } else {                                               // sbase == 0: real message -k - phi
-                const long idx = (long)H - k - phi;
-                if (idx >= 0) hv = hist_in[(long)s * H + idx];
-            }
-        }
-        *(f32x2 *)(rows + 8 * (PER - k)) = hv;
-    }
-    uint32_t *words_s = words + (long)s * w_stride;
-    f32x2 *tap_s = tap ? tap + (long)s * tap_stride : nullptr;
-    for (int sb = 0; sb < TXQ_NSUB; sb++) {
-        const size_t base = sbase + (size_t)sb * C::SUB;          // workgroup-uniform
-        if (base >= n) break;
-        // interior: all messages are real and inside the call, all outputs are ours, and the stream does not
-        // end here (the sub-block holding the last message also writes the history for the next call)
-        float mv[PER];
-        if (base > 0 && base + C::SUB < n) {
-            tx_load_msgs<C, false>(mm, n, phi, base + (size_t)t * PER, mv);
-            off = tx_fast_subblock<C, false>(mv, n, phi, skip, wt, off, base, rows, sh, hist_in + (long)s * H,
-                                             hist_out + (long)s * H, rs, n_out, pack_mode, words_s, tap_s);
-        } else {
-            tx_load_msgs<C, true>(mm, n, phi, base + (size_t)t * PER, mv);
-            off = tx_fast_subblock<C, true>(mv, n, phi, skip, wt, off, base, rows, sh, hist_in + (long)s * H,
-                                            hist_out + (long)s * H, rs, n_out, pack_mode, words_s, tap_s);
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------
@@ -740,11 +558,7 @@ struct TxLookBack {
     int poll_bound;                  // polls of one predecessor word before giving up
 };
 #define TXLB_MASK 0xFFFFFFFFFFFFull
-#ifndef TXLB_W
-#define TXLB_W 1                            // look-back words per lane and round.  4 was built to make the ~150-word window one round trip instead of
-                                           // three and is SLOWER (config 5: 0.299 against 0.248 ms at five waves, 0.312 against 0.239 at four; the look-back phase
-                                           // 6.8 us against 5.1): the words are read past the XCD's L2 (agent scope), a round's cost is the number of requests
-#endif
+#define TXLB_W 1
 __device__ __forceinline__ unsigned long long txlb_fix(double turns)
 {
     const double f = turns - floor(turns);
@@ -764,7 +578,7 @@ __device__ __forceinline__ unsigned long long txlb_fix(double turns)
 template <class C>
 __device__ __forceinline__ double tx_unit_compute(const float *mm, size_t n, int phi, double wt, double start, size_t base, bool interior,
                                                   unsigned char *rows, double *sh, const f32x2 *hist_in_s, const tx_cfloat_t *__restrict__ rs,
-                                                  f32x2 (&o)[C::NOUT], const float *lds_msgs = nullptr, const float *pre_regs = nullptr)
+                                                  f32x2 (&o)[C::NOUT], const float *pre_regs = nullptr)
 {
     constexpr int L = C::L, M = C::M, KP = C::KP, PER = C::PER, NOUT = C::NOUT, ROW = C::ROW, HS = C::HSLOT, H = KP - 1;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -774,12 +588,6 @@ __device__ __forceinline__ double tx_unit_compute(const float *mm, size_t n, int
     if (pre_regs) {                                                // (inlined: the caller's registers)
 #pragma unroll
         for (int k = 0; k < PER; k++) mv[k] = pre_regs[k];
-    } else if (lds_msgs) {
-#pragma unroll
-        for (int q = 0; q < PER / 4; q++) {
-            const f32x4 v = *(const f32x4 *)(lds_msgs + t * PER + 4 * q);
-            mv[4 * q] = v.x; mv[4 * q + 1] = v.y; mv[4 * q + 2] = v.z; mv[4 * q + 3] = v.w;
-        }
     } else if (interior) tx_load_msgs<C, false>(mm, n, phi, tb, mv); else tx_load_msgs<C, true>(mm, n, phi, tb, mv);
     double c[PER], run = 0.0;
 #pragma unroll
@@ -874,7 +682,7 @@ __device__ __forceinline__ void tx_unit_emit(f32x2 (&o)[C::NOUT], const f32x2 ro
     const long j0 = (long)(tb / M) * L - skip;                 // tb is a multiple of M; the first `skip` outputs are not ours
     uint32_t *wp = words_s + j0;
     if (interior) {                                            // (workgroup-uniform)
-        if (!(TXQ_ABL & 4) || n_out < 0) tx_store_words<C>(rows, wd, wp);
+        tx_store_words<C>(wd, wp);
     } else if (j0 >= 0 && j0 + NOUT <= n_out) {
 #pragma unroll
         for (int q = 0; q < NOUT / 4; q++) { const u32x4 v = {wd[4 * q], wd[4 * q + 1], wd[4 * q + 2], wd[4 * q + 3]}; *(u32x4_a4 *)(wp + 4 * q) = v; }
@@ -892,9 +700,8 @@ __device__ __forceinline__ void tx_unit_emit(f32x2 (&o)[C::NOUT], const f32x2 ro
 // after the last message before unit b.  Bounded polls; an overrun raises *lb.err and carries on with a made-up word.
 __device__ __forceinline__ unsigned long long tx_look_back(const TxLookBack &lb, const unsigned long long *st, long b, unsigned long long pin, int lane)
 {
-    // TXLB_W words per lane and round, all requested at once: the window back to the nearest finished prefix is ~150 words
-    // in the steady state of config 5 (a workgroup publishes its prefix ~11 us after its sum, and 14 workgroups start per
-    // microsecond), which at one word per lane was three dependent round trips to L2 (tools/tx_phase_stamps.py: 5.1 us).
+    // one word per lane and round: the window back to the nearest finished prefix is ~150 words in the steady state of config 5
+    // (three dependent round trips past the XCD's L2, tools/tx_phase_stamps.py: 5.1 us; four words per lane and round were slower)
     const unsigned long long e = (unsigned long long)lb.epoch << 48;
     unsigned long long acc = 0;
     long j0 = b - 1;
@@ -961,28 +768,19 @@ __device__ __forceinline__ void tx_chain_work(
     // aggregate of the superblock; the messages are read again from L2 / Infinity Cache by the sub-block loop
     // (keeping 48 of them per lane in registers would cost two waves of occupancy, and occupancy hides the look-back)
     double part = 0.0;
-    constexpr bool CARRY = INT && TXQ_CARRY && !TXQ_KEEP && !TXQ_PREFETCH && !TXQ_ABL;
-    float mv0[PER], mv1[PER];                                      // CARRY: sub-block 0's messages from the sum pass; sub-block 1's, requested early
-    float kept[TXQ_KEEP == 1 ? TXQ_NSUB : 1][PER];                // TXQ_KEEP = 1: the superblock's messages stay in registers
-    extern __shared__ __attribute__((aligned(16))) float kept_lds[];   // TXQ_KEEP = 2: in LDS, [sub-block][lane][PER]
+    constexpr bool CARRY = INT;                                    // interior superblocks: sub-block 0's messages stay in registers from the sum pass to
+    float mv0[PER], mv1[PER];                                      // its arithmetic, and sub-block 1's are requested before the look-back instead of after it
 #pragma unroll
     for (int sbr = 0; sbr < TXQ_NSUB; sbr++) {
-        const int sb = TXQ_P1_REVERSE ? TXQ_NSUB - 1 - sbr : sbr;   // last sub-block first: the second pass then starts on the most recently read lines
+        const int sb = TXQ_NSUB - 1 - sbr;                          // last sub-block first: the second pass then starts on the most recently read lines (-4 % HBM reads)
         const size_t tb = sbase + (size_t)sb * C::SUB + (size_t)t * PER;
         float mv[PER];
-        if ((TXQ_ABL & 1) && sb > 0) {
-#pragma unroll
-            for (int k = 0; k < PER; k++) mv[k] = 0.f;
-        } else if (INT) tx_load_msgs_u<C>(mm + (sbase + (size_t)sb * C::SUB), (unsigned)t * PER, mv);
+        if (INT) tx_load_msgs_u<C>(mm + (sbase + (size_t)sb * C::SUB), (unsigned)t * PER, mv);
         else if (interior) tx_load_msgs<C, false>(mm, n, phi, tb, mv);
         else tx_load_msgs<C, true>(mm, n, phi, tb, mv);
         double r = 0.0;
 #pragma unroll
-        for (int k = 0; k < PER; k++) { r = __builtin_fma((double)mv[k], wt, r); if (TXQ_KEEP == 1) kept[sb][k] = mv[k]; if (CARRY && sb == 0) mv0[k] = mv[k]; }
-        if (TXQ_KEEP == 2) {
-#pragma unroll
-            for (int q = 0; q < PER / 4; q++) *(f32x4 *)(kept_lds + (sb * TXQ_NT + t) * PER + 4 * q) = f32x4{mv[4 * q], mv[4 * q + 1], mv[4 * q + 2], mv[4 * q + 3]};
-        }
+        for (int k = 0; k < PER; k++) { r = __builtin_fma((double)mv[k], wt, r); if (CARRY && sb == 0) mv0[k] = mv[k]; }
         part += r;
     }
 #pragma unroll
@@ -1012,12 +810,12 @@ __device__ __forceinline__ void tx_chain_work(
     f32x2 o0[C::NOUT];
     const bool int0 = INT || (sbase > 0 && sbase + C::SUB < n);
     const double tot0 = tx_unit_compute<C>(mm, n, phi, wt, b == 0 ? pin_turns : 0.0, sbase, int0, rows, sh, hist_in + (long)s * H, rs, o0,
-                                           TXQ_KEEP == 2 ? kept_lds : nullptr, CARRY ? mv0 : nullptr);
+                                           CARRY ? mv0 : nullptr);
     if (CARRY) tx_load_msgs_u<C>(mm + (sbase + (size_t)C::SUB), (unsigned)t * PER, mv1);   // in flight across the look-back
     TXS(3);
     if (wave == 0) {
         const unsigned long long pin = txlb_fix(pin_turns);
-        const unsigned long long acc = (b > 0 && !(TXQ_ABL & 8)) ? tx_look_back(lb, st, b, pin, lane) : pin;
+        const unsigned long long acc = b > 0 ? tx_look_back(lb, st, b, pin, lane) : pin;
         if (lane == 0) {
             const unsigned long long inc = (acc + mine) & TXLB_MASK;
             __hip_atomic_store(st + b, (2ull << 62) | e | inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1044,275 +842,27 @@ __device__ __forceinline__ void tx_chain_work(
     double off = off0 + tot0;
     off -= floor(off);
     TXS(5);
-#if TXQ_PREFETCH && !TXQ_KEEP
-    // the messages of sub-block sb + 1 are requested before sub-block sb is worked (12 registers more per lane)
-    float mvn[PER];
-    {
-        const size_t base1 = sbase + (size_t)C::SUB;
-        if (INT) tx_load_msgs_u<C>(mm + base1, (unsigned)t * PER, mvn);
-        else if (base1 < n) {
-            if (base1 > 0 && base1 + C::SUB < n) tx_load_msgs<C, false>(mm, n, phi, base1 + (size_t)t * PER, mvn);
-            else tx_load_msgs<C, true>(mm, n, phi, base1 + (size_t)t * PER, mvn);
-        }
-    }
 #pragma unroll
     for (int sb = 1; sb < TXQ_NSUB; sb++) {
         const size_t base = sbase + (size_t)sb * C::SUB;          // workgroup-uniform
         if (!INT && base >= n) break;
         float mv[PER];
-#pragma unroll
-        for (int k = 0; k < PER; k++) mv[k] = mvn[k];
-        const size_t basen = base + (size_t)C::SUB;
-        if (sb + 1 < TXQ_NSUB && INT) tx_load_msgs_u<C>(mm + basen, (unsigned)t * PER, mvn);
-        else if (sb + 1 < TXQ_NSUB && basen < n) {
-            if (basen + C::SUB < n) tx_load_msgs<C, false>(mm, n, phi, basen + (size_t)t * PER, mvn);
-            else tx_load_msgs<C, true>(mm, n, phi, basen + (size_t)t * PER, mvn);
-        }
-        if (INT || (base > 0 && base + C::SUB < n))
-            off = tx_fast_subblock<C, false>(mv, n, phi, skip, wt, off, base, rows, sh, hist_in + (long)s * H,
-                                             hist_out + (long)s * H, rs, n_out, pack_mode, words_s, tap_s);
-        else
-            off = tx_fast_subblock<C, true>(mv, n, phi, skip, wt, off, base, rows, sh, hist_in + (long)s * H,
-                                            hist_out + (long)s * H, rs, n_out, pack_mode, words_s, tap_s);
-    }
-#else
-#pragma unroll
-    for (int sb = 1; sb < TXQ_NSUB; sb++) {
-        const size_t base = sbase + (size_t)sb * C::SUB;          // workgroup-uniform
-        if (!INT && base >= n) break;
-        float mv[PER];
-        if (TXQ_KEEP == 1) {
-#pragma unroll
-            for (int k = 0; k < PER; k++) mv[k] = kept[sb][k];
-        } else if (TXQ_KEEP == 2) {
-#pragma unroll
-            for (int q = 0; q < PER / 4; q++) {
-                const f32x4 v = *(const f32x4 *)(kept_lds + (sb * TXQ_NT + t) * PER + 4 * q);
-                mv[4 * q] = v.x; mv[4 * q + 1] = v.y; mv[4 * q + 2] = v.z; mv[4 * q + 3] = v.w;
-            }
-        }
-        if (TXQ_ABL & 2) {
-#pragma unroll
-            for (int k = 0; k < PER; k++) mv[k] = __builtin_bit_cast(float, 0x3C000000 + ((t * PER + k) << 8));
-        }
         if (CARRY && sb == 1) {
 #pragma unroll
             for (int k = 0; k < PER; k++) mv[k] = mv1[k];
         }
         if (INT || (base > 0 && base + C::SUB < n)) {
-            if (!TXQ_KEEP && !(TXQ_ABL & 2) && !(CARRY && sb == 1)) {
+            if (!(CARRY && sb == 1)) {
                 if (INT) tx_load_msgs_u<C>(mm + base, (unsigned)t * PER, mv);
                 else tx_load_msgs<C, false>(mm, n, phi, base + (size_t)t * PER, mv);
             }
             off = tx_fast_subblock<C, false>(mv, n, phi, skip, wt, off, base, rows, sh, hist_in + (long)s * H,
                                              hist_out + (long)s * H, rs, n_out, pack_mode, words_s, tap_s, stamp_id, sb == 3);
         } else {
-            if (!TXQ_KEEP && !(TXQ_ABL & 2)) tx_load_msgs<C, true>(mm, n, phi, base + (size_t)t * PER, mv);
+            tx_load_msgs<C, true>(mm, n, phi, base + (size_t)t * PER, mv);
             off = tx_fast_subblock<C, true>(mv, n, phi, skip, wt, off, base, rows, sh, hist_in + (long)s * H,
                                             hist_out + (long)s * H, rs, n_out, pack_mode, words_s, tap_s);
         }
-        TXS(5 + sb);
-    }
-#endif
-}
-
-// ---------------------------------------------------------------------------
-// Interior superblocks without a barrier in the sub-block loop (TXQ_FREE=1).  tools/tx_phase_stamps.py: a sub-block is a
-// chain of dependent steps -- messages land, prefix + wave scan, BARRIER (the waves' totals), phasors -> LDS, BARRIER (the
-// lane before a wave's first is in the wave before), window reads, resample, pack, store, BARRIER (the tail for the next
-// sub-block) -- 3.3 us against 0.64 us of VALU issue, and the four waves of a workgroup walk it in lock step.  All three
-// barriers exchange things a wave can have by itself: (1) the sum pass keeps every wave's total of every sub-block in a
-// small LDS table, so a wave's phase offset inside any sub-block is a sum over that table; (2) the seven samples before a
-// wave's first message are seven phasors the wave makes itself, from seven messages it loads through the scalar unit (the
-// address is wave-uniform) and the same offset; (3) with that nothing is handed from one sub-block to the next.  Each wave
-// owns 65 LDS rows (row -1 + its 64 lanes); after the look-back the four waves of a workgroup never wait for each other.
-// ---------------------------------------------------------------------------
-#ifndef TXQ_FREE
-#define TXQ_FREE 0                         // measured, not the default: the sub-block loop drops from 3.3 to 2.5 us per sub-block, but the sum pass that now
-#endif                                     // also makes the table of wave totals takes 11.6 us instead of 7.7 and the look-back 6.5 instead of 4.7:
-                                           // 0.250 ms against 0.2425 on config 5 (tools/tx_variants.sh, one box; all 35 TX tests pass with it)
-template <class C>
-__device__ __forceinline__ void tx_wave_compute(const float (&mv)[C::PER], const float *__restrict__ wp /* the wave's first message */,
-                                                double wt, double woff, unsigned char *wr, const tx_cfloat_t *__restrict__ rs,
-                                                f32x2 (&o)[C::NOUT])
-{
-    constexpr int L = C::L, M = C::M, KP = C::KP, PER = C::PER, NOUT = C::NOUT, ROW = C::ROW, HS = C::HSLOT, H = KP - 1;
-    const int lane = threadIdx.x & 63;
-    unsigned char *myrow = wr + (lane + 1) * ROW;
-    float tm[H];                                                   // the H messages before the wave's first (wave-uniform: scalar loads)
-#pragma unroll
-    for (int j = 0; j < H; j++) tm[j] = wp[-1 - j];
-    double c[PER], run = 0.0;
-#pragma unroll
-    for (int k = 0; k < PER; k++) { run = __builtin_fma((double)mv[k], wt, run); c[k] = run; }
-    const double incl = wave_inclusive_scan_f64(run);
-    const double excl = woff + (incl - run);
-#pragma unroll
-    for (int k = 0; k < PER; k += 2) {
-        const f32x2 a = phasor_turns(excl + c[k]), b = phasor_turns(excl + c[k + 1]);
-        *(f32x4 *)(myrow + 8 * k) = f32x4{a.x, a.y, b.x, b.y};
-    }
-    if (lane < HS) {                                               // sample (first - k), k = lane + 1, into the tail of the wave's row -1
-        const int k = lane + 1;
-        double ph = woff;
-#pragma unroll
-        for (int i = 1; i < H; i++) if (i < k) ph -= wt * (double)tm[i - 1];
-        const f32x2 hv = k <= H ? phasor_turns(ph) : f32x2{0.f, 0.f};
-        *(f32x2 *)(wr + 8 * (PER - k)) = hv;
-    }
-    // Same wave: the LDS performs its operations in order, no s_barrier.  But the COMPILER may move a load above a store it
-    // can prove not to overlap for this thread -- and the row a lane reads next was written by ANOTHER lane: a fence at
-    // wavefront scope (no instruction on this target beyond the ordering) pins the reads behind the writes; the same again
-    // at the end of the window reads, for the next sub-block's writes.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    f32x2 x[HS + PER];
-#pragma unroll
-    for (int k = 0; k < HS; k += 2) {
-        const f32x4 q = *(const f32x4 *)(myrow - ROW + 8 * (PER - HS + k));
-        x[k] = q.xy; x[k + 1] = q.zw;
-    }
-#pragma unroll
-    for (int k = 0; k < PER; k += 2) {
-        const f32x4 q = *(const f32x4 *)(myrow + 8 * k);
-        x[HS + k] = q.xy; x[HS + k + 1] = q.zw;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    float tp[KP * L];
-#pragma unroll
-    for (int i = 0; i < KP * L; i++) tp[i] = rs[i];
-#pragma unroll
-    for (int u = 0; u < NOUT; u++) {
-        const int bq = (u * M) / L, p = (u * M) % L;
-        f32x2 acc = {0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < KP; i++) acc += x[HS + bq - i] * tp[p + i * L];
-        o[u] = acc;
-    }
-}
-
-template <class C>
-__device__ __forceinline__ void tx_wave_store(const f32x2 (&o)[C::NOUT], size_t tb, int skip, int pack_mode, uint32_t *words_s, f32x2 *tap_s)
-{
-    constexpr int L = C::L, M = C::M, NOUT = C::NOUT;
-    uint32_t wd[NOUT];
-#pragma unroll
-    for (int u = 0; u < NOUT; u++) wd[u] = tx_pack_word(CL_TX_DOCUMENTED, tx_f2i16_bounded(o[u].x), tx_f2i16_bounded(o[u].y));   // (the taps carry the 4096)
-    if (pack_mode == CL_TX_AS_WRITTEN) {
-#pragma unroll
-        for (int u = 0; u < NOUT; u++) wd[u] = tx_pack_word(CL_TX_AS_WRITTEN, 0, 0);
-    }
-    const long j0 = (long)(tb / M) * L - skip;
-    uint32_t *wp = words_s + j0;
-#pragma unroll
-    for (int q = 0; q < NOUT / 4; q++) { const u32x4 v = {wd[4 * q], wd[4 * q + 1], wd[4 * q + 2], wd[4 * q + 3]}; *(u32x4_a4 *)(wp + 4 * q) = v; }
-    if (tap_s) {
-#pragma unroll
-        for (int u = 0; u < NOUT; u++) tap_s[j0 + u] = o[u] * (1.0f / 4096.0f);   // exact
-    }
-}
-
-template <class C>
-__device__ __forceinline__ void tx_chain_free(
-    const float *__restrict__ mm, int skip, double wt, const TxLookBack &lb, long n_super, int s, long b,
-    size_t sbase, const double *__restrict__ phase_in, double *__restrict__ phase_new, const tx_cfloat_t *__restrict__ rs,
-    int pack_mode, uint32_t *__restrict__ words, long w_stride, f32x2 *__restrict__ tap, long tap_stride,
-    unsigned char *rows, double (*wsum)[TXQ_NT / 64], double &sh_off)
-{
-    constexpr int PER = C::PER, ROW = C::ROW, NW = TXQ_NT / 64;
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    unsigned char *wr = rows + (size_t)wave * 65 * ROW;
-    const unsigned stamp_id = (unsigned)b; (void)stamp_id;
-    TXS(0);
-    // sum pass: every wave's total of every sub-block
-    float mv0[PER], mv1[PER];
-#pragma unroll
-    for (int sbr = 0; sbr < TXQ_NSUB; sbr++) {
-        const int sb = TXQ_P1_REVERSE ? TXQ_NSUB - 1 - sbr : sbr;
-        float mv[PER];
-        tx_load_msgs_u<C>(mm + (sbase + (size_t)sb * C::SUB), (unsigned)t * PER, mv);
-        double r = 0.0;
-#pragma unroll
-        for (int k = 0; k < PER; k++) { r = __builtin_fma((double)mv[k], wt, r); if (sb == 0) mv0[k] = mv[k]; }
-        // the wave's total as a scalar (lane 63 of the scan), stored by every lane alike: no branch, so that the loop stays one
-        // basic block and the compiler keeps all the sub-blocks' loads in flight together (with `if (lane == 63)` around the
-        // store it issued them one sub-block at a time: eight round trips, 15.6 us instead of 7.7)
-        const unsigned long long wb = __builtin_bit_cast(unsigned long long, wave_inclusive_scan_f64(r));
-        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)wb, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(wb >> 32), 63);
-        wsum[sb][wave] = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-    }
-    __syncthreads();
-    TXS(1);
-    unsigned long long *st = lb.st + (long)s * n_super;
-    const unsigned long long e = (unsigned long long)lb.epoch << 48;
-    const double pin_turns = phase_in[s] * (1.0 / TWO_PI);
-    unsigned long long mine = 0;
-    if (wave == 0) {
-        double total = 0.0;
-#pragma unroll
-        for (int sb = 0; sb < TXQ_NSUB; sb++)
-#pragma unroll
-            for (int k = 0; k < NW; k++) total += wsum[sb][k];
-        mine = txlb_fix(total);
-        if (lane == 0) __hip_atomic_store(st + b, (1ull << 62) | e | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    TXS(2);
-    uint32_t *words_s = words + (long)s * w_stride;
-    f32x2 *tap_s = tap ? tap + (long)s * tap_stride : nullptr;
-    const size_t wfirst = sbase + (size_t)wave * 64 * PER;         // the wave's first message of sub-block 0
-    // sub-block 0, relative to the superblock's start; its outputs wait for the look-back
-    f32x2 o0[C::NOUT];
-    {
-        double woff = 0.0;
-#pragma unroll
-        for (int k = 0; k < NW; k++) if (k < wave) woff += wsum[0][k];
-        tx_wave_compute<C>(mv0, mm + wfirst, wt, woff, wr, rs, o0);
-    }
-    tx_load_msgs_u<C>(mm + (sbase + (size_t)C::SUB), (unsigned)t * PER, mv1);   // in flight across the look-back
-    TXS(3);
-    if (wave == 0) {
-        const unsigned long long pin = txlb_fix(pin_turns);
-        const unsigned long long acc = (b > 0 && !(TXQ_ABL & 8)) ? tx_look_back(lb, st, b, pin, lane) : pin;
-        if (lane == 0) {
-            const unsigned long long inc = (acc + mine) & TXLB_MASK;
-            __hip_atomic_store(st + b, (2ull << 62) | e | inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            sh_off = (double)acc * (1.0 / 281474976710656.0);     // phase (turns) after message sbase-1
-            if (b == n_super - 1) {
-                const double it = (double)inc * (1.0 / 281474976710656.0);
-                phase_new[s] = wrap_pi(TWO_PI * (it - rint(it)));
-            }
-        }
-    }
-    __syncthreads();                                               // the last time the workgroup's waves meet
-    TXS(4);
-    double off = sh_off;
-    {
-        const f32x2 rot = phasor_turns(off);
-#pragma unroll
-        for (int u = 0; u < C::NOUT; u++)
-            o0[u] = f32x2{__builtin_fmaf(o0[u].x, rot.x, -o0[u].y * rot.y), __builtin_fmaf(o0[u].x, rot.y, o0[u].y * rot.x)};
-        tx_wave_store<C>(o0, sbase + (size_t)t * PER, skip, pack_mode, words_s, tap_s);
-    }
-    TXS(5);
-#pragma unroll
-    for (int sb = 1; sb < TXQ_NSUB; sb++) {
-        double tot = 0.0, before = 0.0;                            // of the previous sub-block / of the waves before this one
-#pragma unroll
-        for (int k = 0; k < NW; k++) { tot += wsum[sb - 1][k]; if (k < wave) before += wsum[sb][k]; }
-        off += tot; off -= floor(off);
-        const size_t base = sbase + (size_t)sb * C::SUB;
-        float mv[PER];
-        if (sb == 1) {
-#pragma unroll
-            for (int k = 0; k < PER; k++) mv[k] = mv1[k];
-        } else tx_load_msgs_u<C>(mm + base, (unsigned)t * PER, mv);
-        f32x2 o[C::NOUT];
-        tx_wave_compute<C>(mv, mm + (base + (size_t)wave * 64 * PER), wt, off + before, wr, rs, o);
-        tx_wave_store<C>(o, base + (size_t)t * PER, skip, pack_mode, words_s, tap_s);
         TXS(5 + sb);
     }
 }
@@ -1325,9 +875,8 @@ __global__ __launch_bounds__(TXQ_NT, TXQ_CHAIN_WAVES) void tx_fm_chain_kernel(
     long n_out, int pack_mode, uint32_t *__restrict__ words, long w_stride, f32x2 *__restrict__ tap, long tap_stride)
 {
     constexpr int ROW = C::ROW;
-    __shared__ __attribute__((aligned(16))) unsigned char rows[(TXQ_NT + TXQ_NT / 64) * ROW];   // (the barrier-free path: 65 rows per wave)
+    __shared__ __attribute__((aligned(16))) unsigned char rows[(TXQ_NT + 1) * ROW];   // row r at (r + 1) * ROW
     __shared__ double sh[TXQ_NT / 64 + 1];
-    __shared__ double wsum[TXQ_NSUB][TXQ_NT / 64];
     __shared__ double sh_off;
     __shared__ unsigned int sh_ticket;
     const int t = threadIdx.x;
@@ -1350,289 +899,16 @@ __global__ __launch_bounds__(TXQ_NT, TXQ_CHAIN_WAVES) void tx_fm_chain_kernel(
     const float *mm = m + (long)s * m_stride - phi;
     const size_t sbase = (size_t)b * C::SB;
     const tx_cfloat_t *__restrict__ rs = (const tx_cfloat_t *)rs_dev;
-    if (sbase > 0 && sbase + C::SB < n) {                          // workgroup-uniform
-        if (TXQ_FREE && !TXQ_KEEP && !TXQ_PREFETCH && !(TXQ_ABL & 7))
-            tx_chain_free<C>(mm, skip, wt, lb, n_super, s, b, sbase, phase_in, phase_new, rs, pack_mode, words, w_stride, tap, tap_stride,
-                             rows, wsum, sh_off);
-        else
-            tx_chain_work<C, true>(mm, n, phi, skip, wt, lb, n_super, s, b, sbase, phase_in, phase_new, hist_in, hist_out, rs, n_out, pack_mode,
-                                   words, w_stride, tap, tap_stride, rows, sh, sh_off);
-    }
+    if (sbase > 0 && sbase + C::SB < n)                            // workgroup-uniform
+        tx_chain_work<C, true>(mm, n, phi, skip, wt, lb, n_super, s, b, sbase, phase_in, phase_new, hist_in, hist_out, rs, n_out, pack_mode,
+                               words, w_stride, tap, tap_stride, rows, sh, sh_off);
     else
         tx_chain_work<C, false>(mm, n, phi, skip, wt, lb, n_super, s, b, sbase, phase_in, phase_new, hist_in, hist_out, rs, n_out, pack_mode,
                                 words, w_stride, tap, tap_stride, rows, sh, sh_off);
 }
 
 // ---------------------------------------------------------------------------
-// Two roles in one launch (CLHIP_TX_CHAIN=4).  tools/tx_phase_stamps.py on the chain kernel: of a workgroup's 42 us per
-// superblock, 8 are the sum pass (loads in flight, nothing to compute), 5 the look-back (the nearest finished prefix is
-// ~150 superblocks back, because a workgroup publishes its prefix 10 us after its sum) and 6 the detour of the first
-// sub-block (worked before its phase is known, rotated afterwards); the sub-block loop itself is 3.3 us per sub-block.
-// Here the first n_sum workgroups of the grid are SUMMERS: persistent, they walk the superblocks in order, n_sum apart,
-// and publish each one's aggregate (state 1) -- memory-bound work that needs no look-back and stays `ahead` superblocks in
-// front of the chain at most (it waits for the prefix of superblock T - ahead), so that what it has pulled through the
-// Infinity Cache is still there when the workers read it again.  Every other workgroup is a WORKER for one superblock, in
-// dispatch order: it requests its first sub-block's messages, takes its aggregate from the word its summer wrote, looks
-// back (the aggregates are all there and prefixes are published within a round trip of a worker's start: one round of 64
-// words), publishes its prefix and runs ALL its sub-blocks in the absolute frame (tx_fast_subblock, as the three-launch
-// variant does).  Forward progress: the summers are dispatched first and never leave; a worker waits for its summer and
-// for older workers only; a summer waits for older workers only, and that wait is a throttle -- when its (bounded) poll
-// runs out it simply carries on.  Every other poll is bounded as in the chain kernel and reports through *lb.err.
-// ---------------------------------------------------------------------------
-// A summer streams.  Its unit of work is a CHUNK of TXS_CH sub-blocks (six 16-byte loads per lane at TXS_CH = 2); three
-// chunk buffers rotate, so that two chunks -- 24 KB per workgroup each -- are on their way while the third is added up,
-// across superblock boundaries.  Summers take the INTERIOR superblocks only (every message inside the call: no bounds
-// tests); a stream's first and last superblocks are summed by their own workers.  Everything about "which superblock"
-// is workgroup-uniform and lives in scalar registers (32-bit, through readfirstlane: the compiler's division sequences are
-// vector code, and an address that has been through one would cost a register pair per load in flight).
-#ifndef TXS_CH
-#define TXS_CH 2
-#endif
-template <class C>
-__device__ __forceinline__ void tx_summer_issue(const float *ub, int q0, float (&mv)[TXS_CH][C::PER])
-{
-#pragma unroll
-    for (int q = 0; q < TXS_CH; q++) tx_load_msgs_u<C>(ub + (size_t)(q0 + q) * C::SUB, (unsigned)threadIdx.x * C::PER, mv[q]);
-}
-template <class C>
-__device__ __forceinline__ double tx_summer_reduce(const float (&mv)[TXS_CH][C::PER], double wt)
-{
-    double part = 0.0;
-#pragma unroll
-    for (int q = 0; q < TXS_CH; q++) {
-        double r = 0.0;
-#pragma unroll
-        for (int k = 0; k < C::PER; k++) r = __builtin_fma((double)mv[q][k], wt, r);
-        part += r;
-    }
-    return part;
-}
-
-template <class C>
-__device__ __forceinline__ void tx_roles_summer(const float *__restrict__ m, long m_stride, size_t n, int phi, double wt, const TxLookBack &lb,
-                                                long n_super, int n_streams, unsigned id, int n_sum, int ahead, double *sh)
-{
-    static_assert(TXQ_NSUB % TXS_CH == 0, "whole chunks per superblock");
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const unsigned total = (unsigned)(n_super * n_streams), ns = (unsigned)n_streams;
-    const unsigned long long e = (unsigned long long)lb.epoch << 48;
-    auto stream_of = [&](unsigned T) -> unsigned { return ns == 1 ? 0u : (unsigned)__builtin_amdgcn_readfirstlane(T % ns); };
-    auto block_of = [&](unsigned T) -> unsigned { return ns == 1 ? T : (unsigned)__builtin_amdgcn_readfirstlane(T / ns); };
-    auto interior = [&](unsigned T) { const size_t sb0 = (size_t)block_of(T) * C::SB; return sb0 > 0 && sb0 + C::SB < n; };
-    auto base_of = [&](unsigned T) { return m + (long)stream_of(T) * m_stride - phi + (size_t)block_of(T) * C::SB; };
-    auto next_super = [&](unsigned T) { unsigned Tn = T + (unsigned)n_sum; while (Tn < total && !interior(Tn)) Tn += (unsigned)n_sum; return Tn; };
-    unsigned T0 = id;
-    while (T0 < total && !interior(T0)) T0 += (unsigned)n_sum;
-    if (T0 >= total) return;
-    // issue cursor (Ti, qi, ub) runs two chunks ahead of the reduce cursor (Tr, qr)
-    unsigned Ti = T0, Tr = T0;
-    int qi = 0, qr = 0;
-    const float *ub = base_of(Ti);
-    double part = 0.0;
-    auto advance_issue = [&]() {
-        qi += TXS_CH;
-        if (qi >= TXQ_NSUB) {
-            qi = 0;
-            Ti = next_super(Ti);
-            if (Ti < total) {
-                if (Ti >= (unsigned)ahead) {                       // throttle (not a dependency): the chain has reached Ti - ahead
-                    if (t == 0) {
-                        const unsigned Tw = Ti - (unsigned)ahead;
-                        const unsigned long long *wp = lb.st + (long)stream_of(Tw) * n_super + block_of(Tw);
-                        int guard = 0;
-                        unsigned long long w;
-                        do {
-                            w = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if (((w >> 48) & 0x3FFF) == lb.epoch && (w >> 62) >= 2) break;
-                            __builtin_amdgcn_s_sleep(8);
-                        } while (++guard <= lb.poll_bound);
-                    }
-                    __syncthreads();
-                }
-                ub = base_of(Ti);
-            }
-        }
-    };
-    auto advance_reduce = [&]() {                                  // a chunk has been added to `part`
-        qr += TXS_CH;
-        if (qr >= TXQ_NSUB) {                                      // the superblock is complete: publish its aggregate
-            double v = part;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-            if (lane == 0) sh[wave] = v;
-            __syncthreads();
-            if (t == 0) {
-                double tot = 0.0;
-#pragma unroll
-                for (int k = 0; k < TXQ_NT / 64; k++) tot += sh[k];
-                __hip_atomic_store(lb.st + (long)stream_of(Tr) * n_super + block_of(Tr), (1ull << 62) | e | txlb_fix(tot), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-            }
-            __syncthreads();                                       // sh[] is free again
-            part = 0.0;
-            qr = 0;
-            Tr = next_super(Tr);
-        }
-    };
-    float A[TXS_CH][C::PER], B[TXS_CH][C::PER], Cc[TXS_CH][C::PER];
-    tx_summer_issue<C>(ub, qi, A); advance_issue();
-    if (Ti < total) { tx_summer_issue<C>(ub, qi, B); advance_issue(); }
-    while (true) {
-        if (Ti < total) { tx_summer_issue<C>(ub, qi, Cc); advance_issue(); }
-        part += tx_summer_reduce<C>(A, wt); advance_reduce();
-        if (Tr >= total) break;
-        if (Ti < total) { tx_summer_issue<C>(ub, qi, A); advance_issue(); }
-        part += tx_summer_reduce<C>(B, wt); advance_reduce();
-        if (Tr >= total) break;
-        if (Ti < total) { tx_summer_issue<C>(ub, qi, B); advance_issue(); }
-        part += tx_summer_reduce<C>(Cc, wt); advance_reduce();
-        if (Tr >= total) break;
-    }
-}
-
-template <class C, bool INT>
-__device__ __forceinline__ void tx_roles_worker(
-    const float *__restrict__ mm, size_t n, int phi, int skip, double wt, const TxLookBack &lb, long n_super, int s, long b,
-    size_t sbase, const double *__restrict__ phase_in, double *__restrict__ phase_new,
-    const f32x2 *__restrict__ hist_in, f32x2 *__restrict__ hist_out, const tx_cfloat_t *__restrict__ rs,
-    long n_out, int pack_mode, uint32_t *__restrict__ words, long w_stride, f32x2 *__restrict__ tap, long tap_stride,
-    unsigned char *rows, double *sh, double &sh_off)
-{
-    constexpr int KP = C::KP, PER = C::PER, HS = C::HSLOT, H = KP - 1;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    float mv0[PER];                                                // the first sub-block's messages: in flight across the look-back
-    if (INT) tx_load_msgs_u<C>(mm + sbase, (unsigned)t * PER, mv0);
-    else tx_load_msgs<C, true>(mm, n, phi, sbase + (size_t)t * PER, mv0);
-    unsigned long long *st = lb.st + (long)s * n_super;
-    const unsigned long long e = (unsigned long long)lb.epoch << 48;
-    const double pin_turns = phase_in[s] * (1.0 / TWO_PI);
-    if (!INT) {                                                    // a stream's first / last superblock: nobody sums it for us
-        double part = 0.0;
-        for (int sb = 0; sb < TXQ_NSUB; sb++) {
-            float mv[PER];
-            tx_load_msgs<C, true>(mm, n, phi, sbase + (size_t)sb * C::SUB + (size_t)t * PER, mv);
-#pragma unroll
-            for (int k = 0; k < PER; k++) part = __builtin_fma((double)mv[k], wt, part);
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);
-        if (lane == 0) sh[wave] = part;
-        __syncthreads();
-        if (t == 0) {
-            double tot = 0.0;
-#pragma unroll
-            for (int k = 0; k < TXQ_NT / 64; k++) tot += sh[k];
-            __hip_atomic_store(st + b, (1ull << 62) | e | txlb_fix(tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();                                           // sh[] is free again
-    }
-    if (wave == 0) {
-        unsigned long long w;
-        int guard = 0;
-        do {                                                       // this superblock's aggregate, from its summer
-            w = __hip_atomic_load(st + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (++guard > lb.poll_bound) { *lb.err = 1; w = (1ull << 62) | e; }
-        } while (((w >> 48) & 0x3FFF) != lb.epoch || (w >> 62) == 0);
-        const unsigned long long mine = w & TXLB_MASK;
-        const unsigned long long pin = txlb_fix(pin_turns);
-        const unsigned long long acc = b > 0 ? tx_look_back(lb, st, b, pin, lane) : pin;
-        if (lane == 0) {
-            const unsigned long long inc = (acc + mine) & TXLB_MASK;
-            __hip_atomic_store(st + b, (2ull << 62) | e | inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            sh_off = (double)acc * (1.0 / 281474976710656.0);     // phase (turns) after message sbase-1
-            if (b == n_super - 1) {
-                const double it = (double)inc * (1.0 / 281474976710656.0);
-                phase_new[s] = wrap_pi(TWO_PI * (it - rint(it)));
-            }
-        }
-    }
-    __syncthreads();
-    double off = b == 0 ? pin_turns : sh_off;
-    if (t < HS) {                                                  // the HS samples before the superblock -> tail of row -1
-        const int k = t + 1;                                       // message sbase - k
-        f32x2 hv = {0.f, 0.f};
-        if (k <= H) {
-            if (sbase >= (size_t)k) {
-                double ph = off;
-                for (int i = 1; i < k; i++) ph -= wt * (double)mm[sbase - i];
-                hv = phasor_turns(ph);
-            } else {                                               // sbase == 0: real message -k - phi
-                const long idx = (long)H - k - phi;
-                if (idx >= 0) hv = hist_in[(long)s * H + idx];
-            }
-        }
-        *(f32x2 *)(rows + 8 * (PER - k)) = hv;
-    }
-    uint32_t *words_s = words + (long)s * w_stride;
-    f32x2 *tap_s = tap ? tap + (long)s * tap_stride : nullptr;
-#pragma unroll
-    for (int sb = 0; sb < TXQ_NSUB; sb++) {
-        const size_t base = sbase + (size_t)sb * C::SUB;          // workgroup-uniform
-        if (!INT && base >= n) break;
-        float mv[PER];
-        if (sb == 0) {
-#pragma unroll
-            for (int k = 0; k < PER; k++) mv[k] = mv0[k];
-        }
-        if (INT || (base > 0 && base + C::SUB < n)) {
-            if (sb > 0) {
-                if (INT) tx_load_msgs_u<C>(mm + base, (unsigned)t * PER, mv);
-                else tx_load_msgs<C, false>(mm, n, phi, base + (size_t)t * PER, mv);
-            }
-            off = tx_fast_subblock<C, false>(mv, n, phi, skip, wt, off, base, rows, sh, hist_in + (long)s * H,
-                                             hist_out + (long)s * H, rs, n_out, pack_mode, words_s, tap_s);
-        } else {
-            if (sb > 0) tx_load_msgs<C, true>(mm, n, phi, base + (size_t)t * PER, mv);
-            off = tx_fast_subblock<C, true>(mv, n, phi, skip, wt, off, base, rows, sh, hist_in + (long)s * H,
-                                            hist_out + (long)s * H, rs, n_out, pack_mode, words_s, tap_s);
-        }
-    }
-}
-
-template <class C>
-__global__ __launch_bounds__(TXQ_NT, TXQ_CHAIN_WAVES) void tx_fm_roles_kernel(
-    const float *__restrict__ m, long m_stride, size_t n, int phi, int skip, double wt, TxLookBack lb, long n_super,
-    int n_streams, const double *__restrict__ phase_in, double *__restrict__ phase_new,
-    const f32x2 *__restrict__ hist_in, f32x2 *__restrict__ hist_out, const float *__restrict__ rs_dev,
-    long n_out, int pack_mode, uint32_t *__restrict__ words, long w_stride, f32x2 *__restrict__ tap, long tap_stride,
-    int n_sum, int ahead)
-{
-    __shared__ __attribute__((aligned(16))) unsigned char rows[(TXQ_NT + 1) * C::ROW];
-    __shared__ double sh[TXQ_NT / 64 + 1];
-    __shared__ double sh_off;
-    __shared__ unsigned int sh_ticket;
-    // Who is who: by blockIdx (workgroups are dispatched in index order, so the summers are the first to run and every
-    // worker's predecessors have at least been dispatched), or -- lb.ticket != NULL, after an overrun -- by ticket: the
-    // first n_sum workgroups to START are the summers and a worker's predecessors are running, whatever the dispatch order.
-    if (lb.ticket) {
-        if (threadIdx.x == 0) sh_ticket = atomicAdd(lb.ticket, 1u) - lb.ticket_base;
-        __syncthreads();
-    }
-    const unsigned int id = __builtin_amdgcn_readfirstlane(lb.ticket ? sh_ticket : blockIdx.x);
-    if (id < (unsigned)n_sum) {                                    // workgroup-uniform
-        tx_roles_summer<C>(m, m_stride, n, phi, wt, lb, n_super, n_streams, id, n_sum, ahead, sh);
-        return;
-    }
-    const unsigned int T = id - (unsigned)n_sum;
-    if (T >= (unsigned)(n_super * n_streams)) {                    // never index past the launch's superblocks, and never silently
-        if (threadIdx.x == 0) *lb.err = 1;
-        return;
-    }
-    const int s = (int)(T % (unsigned)n_streams);
-    const long b = (long)(T / (unsigned)n_streams);
-    const float *mm = m + (long)s * m_stride - phi;
-    const size_t sbase = (size_t)b * C::SB;
-    const tx_cfloat_t *__restrict__ rs = (const tx_cfloat_t *)rs_dev;
-    if (sbase > 0 && sbase + C::SB < n)                            // workgroup-uniform
-        tx_roles_worker<C, true>(mm, n, phi, skip, wt, lb, n_super, s, b, sbase, phase_in, phase_new, hist_in, hist_out, rs, n_out, pack_mode,
-                                 words, w_stride, tap, tap_stride, rows, sh, sh_off);
-    else
-        tx_roles_worker<C, false>(mm, n, phi, skip, wt, lb, n_super, s, b, sbase, phase_in, phase_new, hist_in, hist_out, rs, n_out, pack_mode,
-                                  words, w_stride, tap, tap_stride, rows, sh, sh_off);
-}
-
-// ---------------------------------------------------------------------------
-// Single read, one sub-block per workgroup (CLHIP_TX_CHAIN=3; measured, not the default).  The look-back unit is ONE
+// Single read, one sub-block per workgroup: the kernel of calls up to 2^22 messages (clhip_tx_pipe_run picks by size).  The look-back unit is ONE
 // sub-block of 256 x PER messages, the whole of which a workgroup holds in registers and LDS: every message is read
 // from memory once, the unit's sum is published at once and its look-back stands BEHIND its own arithmetic.  Correct
 // and traffic-minimal, but a look-back per 3072 messages costs more than it saves: 0.394 ms on config 5 against 0.269
@@ -1928,36 +1204,22 @@ extern "C" long clhip_tx_pipe_run(clhip_tx_pipe *p, int in_kind, const void *d_i
     p->last_stream = s; p->last_stream_valid = true;
     const f32x2 *x = (const f32x2 *)d_in;
     long x_stride = (long)in_stride;
-    static const int tx_fast = getenv("CLHIP_TX_FAST") ? atoi(getenv("CLHIP_TX_FAST")) : 1;
-    if (tx_fast && p->q_bounded && in_kind == CL_TXPIPE_IN_FM_MESSAGE && p->L == TxCfgC5::L && p->M == TxCfgC5::M &&
+    if (p->q_bounded && in_kind == CL_TXPIPE_IN_FM_MESSAGE && p->L == TxCfgC5::L && p->M == TxCfgC5::M &&
         p->n_rs == TxCfgC5::KP * TxCfgC5::L && (((uintptr_t)d_in) & 3) == 0) {
-        // config 5 instantiation (see tx_fm_fast_kernel), in the virtual index space i' = i + phi
+        // config 5 instantiation, in the virtual index space i' = i + phi
         typedef TxCfgC5 C;
         const int phi = (int)(p->n_total % (unsigned long long)p->M), skip = (phi * p->L + p->M - 1) / p->M;
         const size_t nv = n_in + (size_t)phi;
         const long n_super = (long)clhip_div_up(nv, (size_t)C::SB);
-        const size_t wsn = (size_t)(n_super + 2) * p->n_streams + 8;
-        if (wsn > p->ws_cap) {
-            clhip_free(p->ws);
-            p->ws = (double *)clhip_malloc(sizeof(double) * wsn);
-            p->ws_cap = p->ws ? wsn : 0;
-            if (!p->ws) return -1;
-        }
         const double wt = p->w * (1.0 / TWO_PI);
-        dim3 grid((unsigned)n_super, p->n_streams);
-        // By size unless CLHIP_TX_CHAIN forces one: calls of up to 2^22 messages take the one-sub-block-per-workgroup kernel (3) --
-        // an MTU is 43 workgroups there and 6 superblocks of 8 sequential sub-blocks in the chain kernel: 7.4 us against 17
-        // (tools/bench_tx.py: 2^20 8.4 / 17.6, 2^21 10.9 / 18.2, 2^22 17.7 / 20.9, 2^23 30.5 / 25.9, 2^24 55 / 38) -- larger ones (1).
-        static const int tx_chain_env = getenv("CLHIP_TX_CHAIN") ? atoi(getenv("CLHIP_TX_CHAIN")) : -1;
-        const int tx_chain = tx_chain_env >= 0 ? tx_chain_env : ((size_t)nv * (size_t)p->n_streams <= ((size_t)1 << 22) ? 3 : 1);
-        // 1 (default): single launch, superblocks of TXQ_NSUB sub-blocks, the look-back behind the first sub-block's
-        // arithmetic (tx_fm_chain_kernel); 3: single launch, single read, one sub-block per workgroup (tx_fm_chain1_kernel:
-        // measured slower); 4: single launch, summers + workers (tx_fm_roles_kernel: measured equal at best -- 0.249 ms with
-        // 192 summers against 0.245, and time ~ 1 / summers below that: the bytes that have to be in flight to stream the
-        // messages at HBM latency cost the same share of the machine whoever holds them); 0: three launches
+        // By size: calls of up to 2^22 messages take the one-sub-block-per-workgroup kernel -- an MTU is 43 workgroups there and 6
+        // superblocks of 8 sequential sub-blocks in the chain kernel: 7.4 us against 17 (tools/bench_tx.py: 2^20 8.4 / 17.6, 2^21 10.9 /
+        // 18.2, 2^22 17.7 / 20.9, 2^23 30.5 / 25.9, 2^24 55 / 38) -- larger ones the chain kernel (superblocks of TXQ_NSUB sub-blocks, the
+        // look-back behind the first sub-block's arithmetic).  Both are single launches with a single look-back.
+        const bool one_sub = (size_t)nv * (size_t)p->n_streams <= ((size_t)1 << 22);
         const long n_units = (long)clhip_div_up(nv, (size_t)C::SUB);
-        if (tx_chain) {
-            const long n_lb = tx_chain == 3 ? n_units : n_super;   // look-back words per stream
+        {
+            const long n_lb = one_sub ? n_units : n_super;        // look-back words per stream
             const size_t need = (size_t)n_lb * p->n_streams;
             if (need > p->lb_cap || !p->lb_ticket) {
                 clhip_free(p->lb_st);
@@ -1988,9 +1250,8 @@ extern "C" long clhip_tx_pipe_run(clhip_tx_pipe *p, int in_kind, const void *d_i
             // every workgroup's first load).  Correctness does not rest on that order: the poll is bounded, an
             // overrun is reported by clhip_tx_pipe_status() for the SAME call with the pipe rolled back, and from
             // then on this pipe takes tickets (every predecessor then belongs to a running workgroup that waits only
-            // for ITS predecessors: the look-back ends whatever the dispatch order).  CLHIP_TX_TICKET=1 / 0 force either.
-            static const int ticket_env = getenv("CLHIP_TX_TICKET") ? atoi(getenv("CLHIP_TX_TICKET")) : -1;
-            const int use_ticket = ticket_env >= 0 ? ticket_env : (p->force_ticket ? 1 : 0);
+            // for ITS predecessors: the look-back ends whatever the dispatch order).
+            const int use_ticket = p->force_ticket ? 1 : 0;
             if (*(volatile int *)p->lb_err) {                       // raised by an earlier launch nobody asked about
                 clhip_set_error("clhip_tx_pipe_run: a look-back poll overran in an earlier call and clhip_tx_pipe_status() "
                                 "was not consulted; output of that call is invalid");
@@ -2003,33 +1264,16 @@ extern "C" long clhip_tx_pipe_run(clhip_tx_pipe *p, int in_kind, const void *d_i
             TxLookBack lb = {p->lb_st, use_ticket ? p->lb_ticket : nullptr, p->ticket_total, p->epoch, p->lb_err_dev, bound};
             const unsigned n_wg = (unsigned)(n_lb * p->n_streams);
             double *phase_new = p->d_phase2 + (size_t)(p->pcur ^ 1) * p->n_streams;   // the other half: late workgroups still read d_phase
-            if (tx_chain == 4) {
-                // summers + workers in one launch
-                static const int sum_env = getenv("CLHIP_TX_SUMMERS") ? atoi(getenv("CLHIP_TX_SUMMERS")) : 192;
-                static const int ahead_env = getenv("CLHIP_TX_AHEAD") ? atoi(getenv("CLHIP_TX_AHEAD")) : 1024;
-                const int n_sum = (int)(n_wg < (unsigned)sum_env ? n_wg : (unsigned)sum_env);
-                const int ahead = ahead_env > 4 * n_sum ? ahead_env : 4 * n_sum;    // (a throttle shorter than the summers' own stride would stall them on workers that wait for them)
-                hipLaunchKernelGGL(tx_fm_roles_kernel<C>, dim3(n_wg + (unsigned)n_sum), dim3(TXQ_NT), 0, s, (const float *)d_in, (long)in_stride, nv, phi,
-                                   skip, wt, lb, n_super, p->n_streams, (const double *)p->d_phase, phase_new, p->hist[p->cur],
-                                   p->hist[p->cur ^ 1], p->d_rs_q, (long)n_out, p->pack_mode, (uint32_t *)d_bytes,
-                                   (long)(out_stride_bytes / 4), (f32x2 *)d_iq_tap, (long)iq_tap_stride, n_sum, ahead);
-                if (use_ticket) p->ticket_total += (unsigned)n_sum;     // (+ n_wg below)
-            } else if (tx_chain == 3)
+            if (one_sub)
                 hipLaunchKernelGGL(tx_fm_chain1_kernel<C>, dim3(n_wg), dim3(TXQ_NT), 0, s, (const float *)d_in, (long)in_stride, nv, phi,
                                    skip, wt, lb, n_units, p->n_streams, (const double *)p->d_phase, phase_new, p->hist[p->cur],
                                    p->hist[p->cur ^ 1], p->d_rs_q, (long)n_out, p->pack_mode, (uint32_t *)d_bytes,
                                    (long)(out_stride_bytes / 4), (f32x2 *)d_iq_tap, (long)iq_tap_stride);
-            else {
-                constexpr size_t keep_bytes = TXQ_KEEP == 2 ? sizeof(float) * TXQ_NSUB * C::SUB : 0;
-                if (keep_bytes) {
-                    static const hipError_t attr = hipFuncSetAttribute((const void *)tx_fm_chain_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)keep_bytes);
-                    if (attr != hipSuccess) { clhip_set_error("clhip_tx_pipe_run: cannot reserve %zu bytes of LDS", keep_bytes); return -1; }
-                }
-                hipLaunchKernelGGL(tx_fm_chain_kernel<C>, dim3(n_wg), dim3(TXQ_NT), keep_bytes, s, (const float *)d_in, (long)in_stride, nv, phi,
+            else
+                hipLaunchKernelGGL(tx_fm_chain_kernel<C>, dim3(n_wg), dim3(TXQ_NT), 0, s, (const float *)d_in, (long)in_stride, nv, phi,
                                    skip, wt, lb, n_super, p->n_streams, (const double *)p->d_phase, phase_new, p->hist[p->cur],
                                    p->hist[p->cur ^ 1], p->d_rs_q, (long)n_out, p->pack_mode, (uint32_t *)d_bytes,
                                    (long)(out_stride_bytes / 4), (f32x2 *)d_iq_tap, (long)iq_tap_stride);
-            }
             if (use_ticket) p->ticket_total += n_wg;               // the device counter moves only when tickets are taken
             CLHIP_CHECK_LAUNCH();
             p->pcur ^= 1; p->d_phase = phase_new;
@@ -2037,18 +1281,6 @@ extern "C" long clhip_tx_pipe_run(clhip_tx_pipe *p, int in_kind, const void *d_i
             p->n_total += n_in;
             return (long)n_out;
         }
-        double *phase_new = p->ws + (size_t)n_super * p->n_streams;
-        hipLaunchKernelGGL(fm_super_sum_kernel<C>, grid, dim3(TXQ_NT), 0, s, (const float *)d_in, (long)in_stride, nv, phi, wt,
-                           p->ws, n_super);
-        hipLaunchKernelGGL(fm_super_scan_kernel, dim3(p->n_streams), dim3(256), 0, s, p->ws, n_super, p->d_phase, phase_new);
-        hipLaunchKernelGGL(tx_fm_fast_kernel<C>, grid, dim3(TXQ_NT), 0, s, (const float *)d_in, (long)in_stride, nv, phi, skip, wt,
-                           p->ws, n_super, p->hist[p->cur], p->hist[p->cur ^ 1], p->d_rs_q, (long)n_out, p->pack_mode,
-                           (uint32_t *)d_bytes, (long)(out_stride_bytes / 4), (f32x2 *)d_iq_tap, (long)iq_tap_stride);
-        CLHIP_CHECK(hipMemcpyAsync(p->d_phase, phase_new, sizeof(double) * p->n_streams, hipMemcpyDeviceToDevice, s));
-        CLHIP_CHECK_LAUNCH();
-        p->cur ^= 1;
-        p->n_total += n_in;
-        return (long)n_out;
     }
     if (in_kind == CL_TXPIPE_IN_FM_MESSAGE && H <= TXF_HMAX - 1) {
         // fused path: block sums -> block scan -> phasor + resample + quantise + pack in one kernel

@@ -65,7 +65,8 @@ struct cl_group {
     void *s_in, *s_k, *s_out;
     void **ev; size_t n_ev;               /* 3 per sub-batch */
     copy_pool pool;
-    uint8_t **reg_base; uint8_t **reg_dev; size_t *reg_len;   /* per member: a client buffer registered with the GPU (cl_group_register_buffers) */
+    uint8_t **reg_base; size_t *reg_len; size_t n_reg;   /* page ranges of client buffers registered with the GPU (cl_group_register_buffers), merged where they touch */
+    uint8_t *has_reg;                                     /* per member: it has a registered buffer */
     cl_group_stats stats;
     char err[256];
 };
@@ -218,7 +219,7 @@ void cl_group_unmake(cl_group *g)
     for (size_t i = 0; i < g->n_ev; i++) clhip_event_destroy(g->ev[i]);
     clhip_stream_destroy(g->s_in); clhip_stream_destroy(g->s_k); clhip_stream_destroy(g->s_out);
     free(g->ev); free(g->lane); free(g->dev); free(g->lane_of); free(g->row_of);
-    free(g->reg_base); free(g->reg_dev); free(g->reg_len);
+    free(g->reg_base); free(g->reg_len); free(g->has_reg);
     free(g);
 }
 
@@ -246,9 +247,9 @@ cl_group *cl_group_make(cl_device *const *devs, size_t n, const char *const *key
     g->dev = (cl_device **)calloc(n, sizeof *g->dev);
     g->lane_of = (int *)calloc(n, sizeof(int)); g->row_of = (int *)calloc(n, sizeof(int));
     g->lane = (lane_t *)calloc(n, sizeof *g->lane);
-    g->reg_base = (uint8_t **)calloc(n, sizeof *g->reg_base); g->reg_dev = (uint8_t **)calloc(n, sizeof *g->reg_dev);
-    g->reg_len = (size_t *)calloc(n, sizeof *g->reg_len);
-    if (!g->dev || !g->lane_of || !g->row_of || !g->lane || !g->reg_base || !g->reg_dev || !g->reg_len) { cl_group_unmake(g); return NULL; }
+    g->reg_base = (uint8_t **)calloc(n, sizeof *g->reg_base);
+    g->reg_len = (size_t *)calloc(n, sizeof *g->reg_len); g->has_reg = (uint8_t *)calloc(n, 1);
+    if (!g->dev || !g->lane_of || !g->row_of || !g->lane || !g->reg_base || !g->reg_len || !g->has_reg) { cl_group_unmake(g); return NULL; }
     memcpy(g->dev, devs, n * sizeof *g->dev);
     const char *sub = kwget(keys, vals, n_kwargs, "SUBBATCH"), *ct = kwget(keys, vals, n_kwargs, "COPY_THREADS");
     g->sub = sub && atoi(sub) > 0 ? atoi(sub) : 4;     /* profiles/r04/group_sweep_*.txt: 2 / 4 / 8 / 16 -> 3275 / 3400 / 3100 / 2700 Msamples/s (FIR64 + 3/2, 32 streams) */
@@ -330,37 +331,50 @@ int cl_group_register_buffers(cl_group *g, void *const *buffs, size_t bytes_each
     if (!g || !buffs || !bytes_each) return -1;
     clhip_set_device(g->device);
     cl_group_unregister_buffers(g);
+    /* registrations are whole pages and neighbouring heap buffers share pages: ranges that touch are registered as one */
+    const uintptr_t pg = 4096;
     for (size_t i = 0; i < g->n; i++) {
-        const uintptr_t pg = 4096, lo = (uintptr_t)buffs[i] & ~(pg - 1), hi = ((uintptr_t)buffs[i] + bytes_each + pg - 1) & ~(pg - 1);
-        uint8_t *d = (uint8_t *)clhip_host_register((void *)lo, hi - lo);
-        if (!d) {
-            cl_seterr(g->err, sizeof g->err, "cl_group_register_buffers: buffer %zu could not be registered (%s)", i, clhip_last_error());
-            cl_group_unregister_buffers(g);
+        uintptr_t lo = (uintptr_t)buffs[i] & ~(pg - 1), hi = ((uintptr_t)buffs[i] + bytes_each + pg - 1) & ~(pg - 1);
+        for (size_t k = 0; k < g->n_reg; k++) {
+            const uintptr_t b0 = (uintptr_t)g->reg_base[k], b1 = b0 + g->reg_len[k];
+            if (lo > b1 || hi < b0) continue;                      /* (adjacent ranges merge too: fewer registrations) */
+            if (b0 < lo) lo = b0;
+            if (b1 > hi) hi = b1;
+            g->reg_base[k] = g->reg_base[g->n_reg - 1]; g->reg_len[k] = g->reg_len[g->n_reg - 1]; g->n_reg--;
+            k = (size_t)-1;
+        }
+        g->reg_base[g->n_reg] = (uint8_t *)lo; g->reg_len[g->n_reg] = hi - lo; g->n_reg++;
+    }
+    for (size_t k = 0; k < g->n_reg; k++)
+        if (!clhip_host_register(g->reg_base[k], g->reg_len[k])) {
+            cl_seterr(g->err, sizeof g->err, "cl_group_register_buffers: %zu bytes at %p could not be registered (%s)", g->reg_len[k], (void *)g->reg_base[k],
+                      clhip_last_error());
+            for (size_t q = 0; q < k; q++) clhip_host_unregister(g->reg_base[q]);
+            g->n_reg = 0;
             return -1;
         }
-        g->reg_base[i] = (uint8_t *)lo; g->reg_len[i] = hi - lo; g->reg_dev[i] = d;
-    }
+    memset(g->has_reg, 1, g->n);
     return 0;
 }
 
 void cl_group_unregister_buffers(cl_group *g)
 {
-    if (!g || !g->reg_base) return;
+    if (!g || !g->reg_base || !g->n_reg) return;
     clhip_set_device(g->device);
-    int any = 0;
-    for (size_t i = 0; i < g->n; i++) any |= g->reg_base[i] != NULL;
-    if (!any) return;
     if (g->s_out) clhip_stream_sync(g->s_out);          /* nothing may still be writing them */
-    for (size_t i = 0; i < g->n; i++) {
-        if (g->reg_base[i]) clhip_host_unregister(g->reg_base[i]);
-        g->reg_base[i] = NULL; g->reg_dev[i] = NULL; g->reg_len[i] = 0;
-    }
+    if (g->s_k) clhip_stream_sync(g->s_k);
+    for (size_t k = 0; k < g->n_reg; k++) clhip_host_unregister(g->reg_base[k]);
+    g->n_reg = 0;
+    memset(g->has_reg, 0, g->n);
 }
 
 static int registered(const cl_group *g, int m, const void *p, size_t bytes)
 {
     const uint8_t *q = (const uint8_t *)p;
-    return g->reg_base[m] && q >= g->reg_base[m] && q + bytes <= g->reg_base[m] + g->reg_len[m];
+    if (!g->has_reg[m]) return 0;
+    for (size_t k = 0; k < g->n_reg; k++)
+        if (q >= g->reg_base[k] && q + bytes <= g->reg_base[k] + g->reg_len[k]) return 1;
+    return 0;
 }
 
 /* ------------------------------------------------------------------------------------------- the call */
@@ -487,7 +501,7 @@ int cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems, int *r
              * buffer, which the copy engine fills from the device buffer */
             int mapped = g->sink_mapped;
             for (int r = a; r < e && mapped; r++)
-                if (l->fast[r] && g->reg_base[l->member[r]]) mapped = 0;
+                if (l->fast[r] && g->has_reg[l->member[r]]) mapped = 0;
             uint8_t *outb = mapped ? l->m_out : l->d_out;
             if (!hard && l->route == ROUTE_PIPE) {
                 /* maximal runs of neighbouring batched rows: one fused launch each, straight from the raw words */

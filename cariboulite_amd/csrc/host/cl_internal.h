@@ -156,7 +156,7 @@ struct cl_stream {
     void *h_conv; size_t h_conv_cap;     /* pinned host mirror */
     int zero_copy;                       /* kwarg ZEROCOPY=1: client buffers are registered with the GPU and written by the last kernel */
     struct { uint8_t *base, *dev; size_t len; } zc[CL_ZC_SLOTS];
-    int zc_n, zc_next;
+    int zc_n;
     cl_dsp_cfg dsp;
     clhip_rx_pipe *rx_pipe;
     clhip_tx_pipe *tx_pipe;

@@ -351,162 +351,230 @@ int cl_getDigitalFilter(const cl_device *dev) { return dev->stream->filter_type;
 /* ------------------------------------------------------------------- RX path */
 static size_t fmt_bytes(int fmt) { return fmt == CL_FORMAT_CF32 ? 8 : fmt == CL_FORMAT_CF64 ? 16 : fmt == CL_FORMAT_CS8 ? 2 : 4; }
 
-/* Stream::Read + Stream::ReadSamples(int16*)  CaribouliteStream.cpp:260-301:
- * native read (errors squashed to 0) then the optional IIR, result left on the device */
-static int read_native_device(cl_stream *st, size_t n, int *aligned, long timeout_us)
+/* A read is   SOURCE -> STAGES -> SINK   with one epilogue (synchronise, verdicts, deliver or redo once):
+ *
+ *   SOURCE  Stream::Read (CaribouliteStream.cpp:260-279): the call's native samples, on the device.  Either the RAW WORDS of a call
+ *           that is one read() the host has seen to be in sync (caribou_smi_find_buffer_offset returns 0 exactly when the first
+ *           four words carry the pattern, caribou_smi.c:235-292, and the staged bytes are in pinned host memory) -- nothing has
+ *           been launched, the read's verdict arrives with the epilogue's synchronisation -- or INT16 SAMPLES, complete: the
+ *           chunk loop with its re-syncs, extrapolated samples, untouched slots and "-3" (cl_smi_read_device*), or what the
+ *           ASYNC reader thread queued in the device ring.
+ *   STAGES  Stream::ReadSamples* (:282-367) + the extension stages of setupStream's kwargs: [IIR] ->
+ *           [/4096 conversion | FIR -> L/M or FM demod | nothing].  From raw words the first stage's own input conversion is the
+ *           13-bit field extraction of caribou_smi_rx_data_analyze (:338-378): unpack + format conversion in one launch, the IIR
+ *           fed from words, the fused pipe.
+ *   SINK    where the last stage stores and how that reaches the client's buffer (below).
+ *
+ * The reference's dispatch is one switch over the format (CaribouliteStream.cpp:370-382); so is this one. */
+typedef struct {
+    int n;                        /* samples of the call (read_so_far); <= 0: nothing to deliver */
+    const uint8_t *d_words;       /* raw words of a one-read() in-sync call, ready on hs -- or NULL */
+    const int16_t *d_cs16;        /* native int16 samples, complete -- or NULL */
+    void *hs;                     /* the HIP stream the stages are queued on */
+    int pending;                  /* cl_smi_ra_finish is the epilogue's synchronisation (it carries the read's verdict) */
+} cl_source;
+
+static int source_acquire(cl_device *dev, cl_stream *st, size_t n, long timeout_us, cl_source *src)
 {
-    cl_smi *smi = st->dev->smi;
+    cl_smi *smi = dev->smi;
+    memset(src, 0, sizeof *src);
     if (st->use_async) {
-        /* Stream::Read with USE_ASYNC: rx_queue->get(buffer, num_samples, timeout_us)  :262-263.  The popped samples
-         * move device-to-device into the consumer's linear buffer (the claimed span stays this call's until get_end --
-         * the reader thread's puts go on meanwhile, only one that would have to displace these very elements waits),
-         * and every later stage reads them there. */
+        /* Stream::Read with USE_ASYNC: rx_queue->get(buffer, num_samples, timeout_us)  :262-263.  The popped samples move
+         * device-to-device into the consumer's linear buffer (the claimed span stays this call's until get_end -- the reader
+         * thread's puts go on meanwhile, only one that would have to displace these very elements waits) */
+        src->hs = st->astream;
         if (cl_ensure((void **)&st->d_aiq, &st->aiq_cap, n + 8, 4, 0)) return 0;
         cl_ring_span sp;
         const size_t claimed = cl_ring_get_begin(st->rx_queue, n, (int)timeout_us, &sp);
-        if (aligned) *aligned = 0;
         if (!claimed) return 0;
-        int bad;
-        if (st->format == CL_FORMAT_CS16 && st->filter_type == CL_DIGFILT_NONE) {
-            /* no device stage follows: the ring's slots go straight to the pinned mirror (*aligned = 2 tells the caller) */
-            bad = cl_ensure((void **)&st->h_conv, &st->h_conv_cap, claimed * 4 + 64, 1, 1);
-            uint8_t *base = (uint8_t *)cl_ring_storage(st->rx_queue), *dst = (uint8_t *)st->h_conv;
-            for (int k = 0; k < 2 && !bad; k++) {
-                if (!sp.len[k]) continue;
-                bad = clhip_memcpy_d2h(dst, base + 4 * sp.pos[k], 4 * sp.len[k], st->astream);
-                dst += 4 * sp.len[k];
-            }
-            if (aligned) *aligned = 2;
-        } else
-            bad = ring_span_copy(st->rx_queue, &sp, st->d_aiq, 0, st->astream);
-        bad = bad || clhip_stream_sync(st->astream);
+        const int bad = ring_span_copy(st->rx_queue, &sp, st->d_aiq, 0, st->astream) || clhip_stream_sync(st->astream);
         cl_ring_get_end(st->rx_queue, claimed);
         if (bad) return 0;
-        return (int)claimed;
+        src->n = (int)claimed; src->d_cs16 = st->d_aiq;
+        return src->n;
     }
-    /* up to one native batch per call (what every client of the reference asks for): the chunk-at-a-time reader,
-     * which has the NEXT batch's bytes on their way to the device while this one is analysed and copied out */
+    src->hs = smi->stream;
     int ret;
-    if (n <= st->mtu_size) { ret = cl_smi_read_device_ra(smi, st->dev->channel, n, NULL); if (aligned) *aligned = 0; }
-    else ret = cl_smi_read_device(smi, st->dev->channel, n, 0, aligned);
+    if (n <= st->mtu_size) {
+        /* up to one native batch (what every client of the reference asks for): the chunk-at-a-time reader, which has the NEXT
+         * batch's bytes on their way to the device while this one is worked on */
+        smi->want_words = 1;
+        const long expect = cl_smi_ra_launch(smi, dev->channel, n, NULL);
+        if (smi->fast_used && expect > 0) {
+            src->n = (int)expect; src->d_words = smi->fast_words; src->pending = 1;
+            return src->n;
+        }
+        ret = (expect < 0 || !smi->ra_pending) ? (int)expect : cl_smi_ra_finish(smi);
+    } else
+        ret = cl_smi_read_device(smi, dev->channel, n, 0, NULL);
     if (ret < 0) {
         if (ret == CL_SMI_ERR_IO) printf("reader thread failed to read SMI!\n");    /* :270 */
         ret = 0;                                                                    /* :266-276 */
     }
+    src->n = ret; src->d_cs16 = smi->d_iq;
     return ret;
 }
 
-/* Stream::ReadSamples(int16*)  CaribouliteStream.cpp:291-298: the selected low-pass over all `n` slots of the native
- * read exactly as the reference loop runs (slots it leaves untouched after a re-sync hold stale samples there too).
- * Out of place -- d_raw keeps the unfiltered samples, st->d_filt takes the result -- so that a call the single-pass
- * kernel gave up on can be made again.  Asynchronous on hs; the verdict is clhip_iir_status() after the synchronise. */
-static const int16_t *filter_native(cl_stream *st, const int16_t *d_raw, size_t n, void *hs, int16_t *d_dst)
-{
-    if (st->filter_type == CL_DIGFILT_NONE) return d_raw;
-    if (!d_dst) {
-        if (cl_ensure((void **)&st->d_filt, &st->filt_cap, n + 8, 4, 0)) return NULL;
-        d_dst = st->d_filt;
-    }
-    if (clhip_iir_run(st->iir[st->filter_type - 1], d_raw, d_dst, n, n, hs)) return NULL;
-    return d_dst;
-}
-
-/* ---- where the LAST device stage of a read stores its results, and how they reach the client's (pageable) buffer ----
+/* ---- SINK: where the LAST device stage of a read stores its results, and how they reach the client's (pageable) buffer ----
  * Host wall time of one native batch, launch to samples in the client's buffer (tools/microbench/ingest_shape.hip,
  * profiles/r03/ingest_shape.txt; 4 / 8 / 12 output bytes per sample):
- *   CL_SINK_CLIENT  the client's buffer itself, registered with the GPU on first use (stream kwarg ZEROCOPY=1: the client
- *                   promises that a buffer it has passed stays mapped while the stream exists) -- the kernel's stores cross
- *                   PCIe themselves, nothing is left to do after the synchronisation: 29 / 39 / 48 us;
- *   CL_SINK_MIRROR  the stream's mapped pinned mirror, memcpy into the client's buffer after the synchronisation: 48 / 80 /
- *                   107 us (the memcpy reads lines the device has just written: 12 us per 512 KiB, three times its warm rate);
- *   CL_SINK_STAGED  a device buffer, copied by the copy engine into the pageable buffer before the synchronisation:
- *                   58 / 91 / 65 us -- above 1 MiB the runtime pins the target in place instead of bouncing it, which
- *                   is why this WAS the route for outputs larger than that (now only with CL_READ_STAGED=1);
- *   CL_SINK_BOUNCE  a device buffer, copied by the copy engine into the stream's pinned mirror before the synchronisation
- *                   and from there by memcpy: the route for outputs above the mirror route's limit -- 1 MiB until the end of
- *                   round 3, when FIR64 + 3/2 (1.5 MiB) was measured on both: 127-130 us here, 116-117 through the mapped
- *                   mirror; the limit is 4 MiB now (CL_MIRROR_MAX_KB), above every MTU-sized output.  (Round 3's first form handed the client's
- *                   pageable buffer to the runtime -- CL_SINK_STAGED -- which pins such a target in place from 1 MiB up:
- *                   77-81 us for FIR64 + 3/2 against 120 here, and the mechanism behind the GPU page faults on host heap
- *                   addresses of DESIGN.md section 7.  Whoever wants the copy engine in his own buffers says so: ZEROCOPY=1.) */
-enum { CL_SINK_CLIENT, CL_SINK_MIRROR, CL_SINK_STAGED, CL_SINK_BOUNCE };
-static size_t mirror_max_bytes(void)
-{
-    static size_t v;                                               /* A/B: CL_MIRROR_MAX_KB (default below) */
-    if (!v) v = getenv("CL_MIRROR_MAX_KB") ? (size_t)atol(getenv("CL_MIRROR_MAX_KB")) << 10 : (size_t)4 << 20;
-    return v;
-}
-#define CL_MIRROR_MAX_BYTES mirror_max_bytes()
-typedef struct { int kind; void *d_dst; void *bounce; } cl_sink;
+ *   CL_SINK_CLIENT  the client's buffer itself, REGISTERED by the client (cl_stream_register_buffer on a ZEROCOPY=1 stream): the
+ *                   kernel's stores cross PCIe themselves, nothing is left to do after the synchronisation: 29 / 39 / 48 us;
+ *   CL_SINK_MIRROR  the stream's mapped pinned mirror, memcpy into the client's buffer after the synchronisation: 48 / 80 / 107 us
+ *                   (up to 4 MiB: above every MTU-sized output; FIR64 + 3/2 = 1.5 MiB: 116-117 us against 127-130 through BOUNCE);
+ *   CL_SINK_BOUNCE  a device buffer, copied by the copy engine into the stream's pinned mirror before the synchronisation and from
+ *                   there by memcpy: outputs above the mirror route's limit (CS16 calls of many native batches).
+ * The library never hands memory it does not own to the runtime's copy engine or registers it behind the client's back (DESIGN.md
+ * section 7: the runtime's in-place pinning of pageable copies >= 1 MiB ended test sessions with GPU page faults on host heap
+ * addresses). */
+enum { CL_SINK_CLIENT, CL_SINK_MIRROR, CL_SINK_BOUNCE };
+#define CL_MIRROR_MAX_BYTES ((size_t)4 << 20)
+typedef struct { int kind; void *d_dst; } cl_sink;
 
-static void *mirror_for(cl_stream *st, size_t bytes)
-{
-    if (cl_ensure((void **)&st->h_conv, &st->h_conv_cap, bytes + 64, 1, 1)) return NULL;
-    return clhip_host_device_ptr(st->h_conv);
-}
-
-/* ZEROCOPY=1: the address kernels use for the client's buffer (registering the pages it covers on first sight; a small
- * table, oldest entry dropped first), or NULL: not asked for, misaligned for the 16-byte stores, or the runtime refused
- * (e.g. the range overlaps an older registration only in part) -- the caller then takes one of the other routes. */
-static void zc_drop_all(cl_stream *st)
-{
-    for (int i = 0; i < st->zc_n; i++) clhip_host_unregister(st->zc[i].base);
-    st->zc_n = st->zc_next = 0;
-}
-
+/* ZEROCOPY=1 + cl_stream_register_buffer: the address kernels use for a client pointer inside a registered buffer, or NULL (not
+ * asked for, not registered, misaligned for the 16-byte stores): the caller then takes the mirror */
 static void *client_device_addr(cl_stream *st, void *out, size_t bytes)
 {
     if (!st->zero_copy || !bytes || ((uintptr_t)out & 15)) return NULL;
     uint8_t *p = (uint8_t *)out;
     for (int i = 0; i < st->zc_n; i++)
         if (p >= st->zc[i].base && p + bytes <= st->zc[i].base + st->zc[i].len) return st->zc[i].dev + (p - st->zc[i].base);
-    const uintptr_t pg = 4096, lo = (uintptr_t)p & ~(pg - 1), hi = ((uintptr_t)p + bytes + pg - 1) & ~(pg - 1);
-    int slot = st->zc_n;
-    if (slot == CL_ZC_SLOTS) { slot = st->zc_next; st->zc_next = (st->zc_next + 1) % CL_ZC_SLOTS; clhip_host_unregister(st->zc[slot].base); st->zc[slot].len = 0; }
-    uint8_t *dev = (uint8_t *)clhip_host_register((void *)lo, hi - lo);
-    if (!dev) {
-        if (slot < st->zc_n) { st->zc[slot] = st->zc[st->zc_n - 1]; st->zc_n--; st->zc_next = 0; }   /* the evicted entry is gone */
-        return NULL;
+    return NULL;
+}
+
+static void zc_drop_all(cl_stream *st)
+{
+    for (int i = 0; i < st->zc_n; i++) clhip_host_unregister(st->zc[i].base);
+    st->zc_n = 0;
+}
+
+/* Explicit registration of a client buffer with the GPU for a ZEROCOPY=1 stream: readStream calls whose buffs[0] lies inside a
+ * registered buffer have their last kernel store into it directly.  The registration covers the pages around [p, p + bytes) and
+ * stands until cl_stream_unregister_buffers, the next setupStream or the device's end -- the client keeps the buffer allocated
+ * that long.  At most CL_ZC_SLOTS buffers; a full table refuses (no eviction: registrations never churn in steady state).
+ * 0, or -1 (cl_device_last_error). */
+int cl_stream_register_buffer(cl_device *dev, cl_stream *st, void *p, size_t bytes)
+{
+    if (!dev || !st || !p || !bytes) return -1;
+    if (!st->zero_copy) { cl_seterr(dev->err, sizeof dev->err, "cl_stream_register_buffer: the stream was not set up with ZEROCOPY=1"); return -1; }
+    clhip_set_device(dev->smi->device);
+    const uintptr_t pg = 4096;
+    uintptr_t lo = (uintptr_t)p & ~(pg - 1), hi = ((uintptr_t)p + bytes + pg - 1) & ~(pg - 1);
+    /* registrations are whole pages, and buffers that come from one heap share pages with their neighbours: a new buffer whose
+     * pages touch a registered range is registered together with it, as one range (this is set-up time, not the data path:
+     * the stream's device work is waited for before the older registration is replaced) */
+    for (int i = 0; i < st->zc_n; i++) {
+        const uintptr_t b0 = (uintptr_t)st->zc[i].base, b1 = b0 + st->zc[i].len;
+        if (lo >= b1 || hi <= b0) continue;
+        if (lo >= b0 && hi <= b1) return 0;                        /* inside a registered range already */
+        clhip_stream_sync(dev->smi->stream);
+        if (st->astream) clhip_stream_sync(st->astream);
+        clhip_host_unregister(st->zc[i].base);
+        if (b0 < lo) lo = b0;
+        if (b1 > hi) hi = b1;
+        st->zc[i] = st->zc[--st->zc_n];
+        i = -1;                                                    /* the grown range may touch another one */
     }
-    st->zc[slot].base = (uint8_t *)lo; st->zc[slot].len = hi - lo; st->zc[slot].dev = dev;
-    if (slot == st->zc_n) st->zc_n++;
+    if (st->zc_n == CL_ZC_SLOTS) { cl_seterr(dev->err, sizeof dev->err, "cl_stream_register_buffer: %d buffers are registered already", CL_ZC_SLOTS); return -1; }
+    uint8_t *d = (uint8_t *)clhip_host_register((void *)lo, hi - lo);
+    if (!d) { cl_seterr(dev->err, sizeof dev->err, "cl_stream_register_buffer: %s", clhip_last_error()); return -1; }
+    st->zc[st->zc_n].base = (uint8_t *)lo; st->zc[st->zc_n].len = hi - lo; st->zc[st->zc_n].dev = d;
+    st->zc_n++;
     st->stats.zero_copy_registrations++;
-    return dev + ((uintptr_t)p - lo);
+    return 0;
+}
+
+void cl_stream_unregister_buffers(cl_device *dev, cl_stream *st)
+{
+    if (!dev || !st) return;
+    clhip_set_device(dev->smi->device);
+    clhip_stream_sync(dev->smi->stream);               /* nothing may still be storing into them */
+    if (st->astream) clhip_stream_sync(st->astream);
+    zc_drop_all(st);
 }
 
 static int sink_open(cl_stream *st, void *out, size_t bytes, cl_sink *sk)
 {
     sk->d_dst = client_device_addr(st, out, bytes);
     if (sk->d_dst) { sk->kind = CL_SINK_CLIENT; return 0; }
-    if (bytes <= CL_MIRROR_MAX_BYTES) {
-        sk->d_dst = mirror_for(st, bytes);
-        if (!st->h_conv) return -1;
-        if (sk->d_dst) { sk->kind = CL_SINK_MIRROR; return 0; }
-    }
-    if (cl_ensure(&st->d_conv, &st->conv_cap, bytes + 64, 1, 0)) return -1;
-    sk->d_dst = st->d_conv;
-    static int staged = -1;                                        /* A/B: CL_READ_STAGED=1 = the runtime copies into the client's buffer */
-    if (staged < 0) staged = getenv("CL_READ_STAGED") ? atoi(getenv("CL_READ_STAGED")) != 0 : 0;
-    if (staged) { sk->kind = CL_SINK_STAGED; return 0; }
     if (cl_ensure((void **)&st->h_conv, &st->h_conv_cap, bytes + 64, 1, 1)) return -1;
-    sk->kind = CL_SINK_BOUNCE; sk->bounce = st->h_conv;
+    if (bytes <= CL_MIRROR_MAX_BYTES && (sk->d_dst = clhip_host_device_ptr(st->h_conv)) != NULL) { sk->kind = CL_SINK_MIRROR; return 0; }
+    if (cl_ensure(&st->d_conv, &st->conv_cap, bytes + 64, 1, 0)) return -1;
+    sk->d_dst = st->d_conv; sk->kind = CL_SINK_BOUNCE;
     return 0;
 }
 
 /* before the synchronisation (hs = the stream the last stage was queued on) ... */
-static int sink_queue(const cl_sink *sk, void *out, size_t bytes, void *hs)
+static int sink_queue(cl_stream *st, const cl_sink *sk, size_t bytes, void *hs)
 {
-    if (!bytes) return 0;
-    if (sk->kind == CL_SINK_STAGED) return clhip_memcpy_d2h(out, sk->d_dst, bytes, hs);
-    if (sk->kind == CL_SINK_BOUNCE) return clhip_memcpy_d2h(sk->bounce, sk->d_dst, bytes, hs);
-    return 0;
+    return bytes && sk->kind == CL_SINK_BOUNCE ? clhip_memcpy_d2h(st->h_conv, sk->d_dst, bytes, hs) : 0;
 }
 
 /* ... and after it, once the call is known to deliver */
 static void sink_deliver(cl_stream *st, const cl_sink *sk, void *out, size_t bytes)
 {
-    if (sk->kind == CL_SINK_MIRROR || sk->kind == CL_SINK_BOUNCE) memcpy(out, st->h_conv, bytes);
     if (sk->kind == CL_SINK_CLIENT) st->stats.zero_copy_reads++;
+    else memcpy(out, st->h_conv, bytes);
+}
+
+/* Stream::ReadSamples(int16*)  CaribouliteStream.cpp:291-298: the selected low-pass over all `n` slots of the native read
+ * exactly as the reference loop runs (slots it leaves untouched after a re-sync hold stale samples there too).  Out of place --
+ * the source keeps the unfiltered samples -- so that a call the single-pass kernel gave up on can be made again.  Asynchronous
+ * on hs; the verdict is clhip_iir_status() after the synchronise.  d_dst NULL: into st->d_filt. */
+static const int16_t *filter_source(cl_device *dev, cl_stream *st, const cl_source *src, int16_t *d_dst)
+{
+    cl_smi *smi = dev->smi;
+    const size_t n = (size_t)src->n;
+    clhip_iir *flt = st->iir[st->filter_type - 1];
+    if (!d_dst) {
+        if (cl_ensure((void **)&st->d_filt, &st->filt_cap, n + 8, 4, 0)) return NULL;
+        d_dst = st->d_filt;
+    }
+    const int16_t *d_raw = src->d_cs16;
+    if (src->d_words) {
+        /* the raw words of the read() go straight into the filter launch: the 13-bit field extraction is the filter's own input
+         * conversion -- no unpack launch, no int16 intermediate.  Only when the filter is on its scan path (it has overrun before,
+         * or its memory is too long for the single-pass kernel: -2) are the words unpacked first. */
+        const int rc = clhip_iir_run_smi(flt, dev->channel, src->d_words, d_dst, n, n, src->hs);
+        if (rc == 0) return d_dst;
+        if (rc != -2 || clhip_smi_unpack_aligned(dev->channel, src->d_words, n * 4, CL_FORMAT_CS16, smi->d_iq, NULL, src->hs)) return NULL;
+        smi->prev_words = NULL;                            /* (the persistent int16 buffer is current now) */
+        d_raw = smi->d_iq;
+    }
+    return clhip_iir_run(flt, d_raw, d_dst, n, n, src->hs) ? NULL : d_dst;
+}
+
+/* queue the call's stages on src->hs, the last one storing into the sink; *got = elements the call yields.  0 or -1 */
+static int stages_queue(cl_device *dev, cl_stream *st, const cl_source *src, const cl_sink *sk, long *got)
+{
+    cl_smi *smi = dev->smi;
+    const size_t n = (size_t)src->n;
+    const int filt = st->filter_type != CL_DIGFILT_NONE;
+    *got = src->n;
+    if (st->rx_pipe) {
+        /* extension stages where a client of readStream(CF32) would apply them */
+        const int16_t *d_f = filt ? filter_source(dev, st, src, NULL) : src->d_cs16;
+        if (filt && !d_f) return -1;
+        *got = d_f ? clhip_rx_pipe_run(st->rx_pipe, CL_PIPE_IN_CS16, d_f, 0, n, sk->d_dst, 0, src->hs)
+                   : clhip_rx_pipe_run(st->rx_pipe, CL_PIPE_IN_SMI_WORDS, src->d_words, 0, n, sk->d_dst, 0, src->hs);   /* one fused launch from the raw words */
+        return *got < 0 ? -1 : 0;
+    }
+    if (st->format == CL_FORMAT_CS16) {                    /* :282-301 */
+        if (filt) return filter_source(dev, st, src, (int16_t *)sk->d_dst) ? 0 : -1;
+        if (src->d_words) {                                /* unpack straight into the sink and the persistent int16 buffer */
+            smi->prev_words = NULL;
+            return clhip_smi_unpack_aligned(dev->channel, src->d_words, n * 4, CL_FORMAT_CS16, sk->d_dst, smi->d_iq, src->hs) ? -1 : 0;
+        }
+        return 0;                                          /* nothing to launch: the epilogue copies the slots the reference writes */
+    }
+    /* :304-367: every one of the n slots is converted, stale ones included */
+    if (!filt && src->d_words) {                           /* one launch: unpack in the client's format into the sink, int16 pairs into the persistent buffer */
+        smi->prev_words = NULL;
+        return clhip_smi_unpack_aligned(dev->channel, src->d_words, n * 4, st->format, sk->d_dst, smi->d_iq, src->hs) ? -1 : 0;
+    }
+    const int16_t *d_f = filt ? filter_source(dev, st, src, NULL) : src->d_cs16;
+    if (!d_f) return -1;
+    return clhip_convert_from_cs16(d_f, n, st->format, sk->d_dst, src->hs) ? -1 : 0;
 }
 
 /* after the synchronise: 0 = the filtered samples are good (or no filter ran); 1 = the call overran -- the filter's state
@@ -519,36 +587,77 @@ static int filter_overran(cl_device *dev, cl_stream *st)
     return 1;
 }
 
-static int read_stream(cl_device *dev, cl_stream *st, void *const *buffs, size_t numElems, long timeoutUs);
-int cl_stream_read(cl_device *dev, cl_stream *st, void *const *buffs, size_t numElems, long timeoutUs) { return read_stream(dev, st, buffs, numElems, timeoutUs); }
-
-/* A/B switch CL_READ_FAST=0: no one-launch unpack of a read() the host has seen to be in sync (search + unpack + offset
- * read-back for every call, as for the calls that do not qualify) */
-static int read_fast_enabled(void)
+/* Stream::ReadSamplesGen  CaribouliteStream.cpp:370-382 */
+static int read_stream(cl_device *dev, cl_stream *st, void *const *buffs, size_t numElems, long timeoutUs)
 {
-    static int on = -1;
-    if (on < 0) on = getenv("CL_READ_FAST") ? atoi(getenv("CL_READ_FAST")) != 0 : 1;
-    return on;
-}
-
-int cl_stream_read_native(cl_device *dev, cl_stream *st, size_t n, long timeout_us, const int16_t **d_iq)
-{
+    if (st->native_dir != CL_SOAPY_SDR_RX) return CL_SOAPY_SDR_NOT_SUPPORTED;       /* :248-251 */
     cl_smi *smi = dev->smi;
-    int aligned = 0;
-    const int res = read_native_device(st, n, &aligned, timeout_us);
-    if (res <= 0) return res;
-    if (st->use_async && aligned == 2) return 0;        /* (plain CS16 went to the pinned mirror: not a device-side caller's route) */
-    const int16_t *d_raw = st->use_async ? st->d_aiq : smi->d_iq;
-    void *hs = st->use_async ? st->astream : smi->stream;
-    for (int attempt = 0;; attempt++) {                 /* a call the single-pass kernel gave up on is made again, once */
-        const int16_t *d_f = filter_native(st, d_raw, (size_t)res, hs, NULL);
-        if (!d_f || clhip_stream_sync(hs)) return 0;
-        if (!filter_overran(dev, st)) { *d_iq = d_f; return res; }
+    clhip_set_device(smi->device);
+    void *out = buffs[0];
+    if (st->format != CL_FORMAT_CS16 && numElems > st->mtu_size) numElems = st->mtu_size;   /* :306,328,351; CS16 is not clamped (:282-301) */
+    if (!numElems) return 0;
+    cl_source src;
+    if (source_acquire(dev, st, numElems, timeoutUs, &src) <= 0) return 0;
+    const size_t n = (size_t)src.n;
+    const int plain_cs16 = st->format == CL_FORMAT_CS16 && !st->rx_pipe && st->filter_type == CL_DIGFILT_NONE;
+    if (plain_cs16 && !src.d_words && !st->use_async)
+        /* no device stage behind the read: exactly the slots the reference writes (caribou_smi.c:344-389) go to the client */
+        return cl_smi_copy_out(smi, (cl_sample_complex_int16 *)out, NULL, -1) ? 0 : src.n;
+    const size_t ob = st->rx_pipe ? (st->dsp.demod_fm ? 4 : 8) : fmt_bytes(st->format);
+    const size_t max_out = (st->rx_pipe ? clhip_rx_pipe_out_count(st->rx_pipe, n) : n) * ob;
+    cl_sink sk;
+    if (sink_open(st, out, max_out, &sk)) { if (src.pending) cl_smi_ra_finish(smi); return 0; }
+    for (int attempt = 0;; attempt++) {
+        long got = 0;
+        int bad = stages_queue(dev, st, &src, &sk, &got);
+        if (!bad && plain_cs16 && !src.d_words)            /* (ASYNC: the ring's samples are the output) */
+            bad = clhip_memcpy_d2h(sk.kind == CL_SINK_CLIENT ? out : st->h_conv, src.d_cs16, n * 4, src.hs);
+        else if (!bad) bad = sink_queue(st, &sk, (size_t)(got > 0 ? got : 0) * ob, src.hs);
+        /* the one synchronisation; with it the verdict of the read() whose words the stages took (host-certain: in sync) */
+        int fr = src.n;
+        if (src.pending) { fr = cl_smi_ra_finish(smi); src.pending = 0; }
+        else if (clhip_stream_sync(src.hs)) fr = CL_SMI_ERR_IO;
+        if (bad) { clhip_stream_sync(src.hs); fr = CL_SMI_ERR_IO; }
+        if (fr == CL_SMI_ERR_IO) printf("reader thread failed to read SMI!\n");    /* :270 */
+        if (fr <= 0) return 0;                                                      /* :266-276 */
+        if (!filter_overran(dev, st)) {
+            if (got <= 0) return 0;
+            sink_deliver(st, &sk, out, (size_t)got * ob);
+            return (int)got;
+        }
+        /* the single-pass filter kernel gave up: its state is back where it was and the object is on the scan path; whatever ran
+         * behind it ran on invalid samples: undone, and the stages are queued again, once */
+        if (st->rx_pipe) clhip_rx_pipe_rollback(st->rx_pipe);
         if (attempt) return 0;
     }
 }
 
-/* Stream::ReadSamplesGen  CaribouliteStream.cpp:370-382 */
+int cl_stream_read(cl_device *dev, cl_stream *st, void *const *buffs, size_t numElems, long timeoutUs) { return read_stream(dev, st, buffs, numElems, timeoutUs); }
+
+/* Stream::Read + Stream::ReadSamples(int16*) with the result left on the DEVICE, complete (cl_group.c: a group's pipe slot runs
+ * from them) */
+int cl_stream_read_native(cl_device *dev, cl_stream *st, size_t n, long timeout_us, const int16_t **d_iq)
+{
+    cl_smi *smi = dev->smi;
+    cl_source src;
+    if (st->use_async) { if (source_acquire(dev, st, n, timeout_us, &src) <= 0) return 0; }
+    else {
+        /* int16 samples wanted: the chunk loop proper (it also brings the persistent buffer up to date first) */
+        int ret = n <= st->mtu_size ? cl_smi_read_device_ra(smi, dev->channel, n, NULL) : cl_smi_read_device(smi, dev->channel, n, 0, NULL);
+        if (ret < 0) { if (ret == CL_SMI_ERR_IO) printf("reader thread failed to read SMI!\n"); ret = 0; }
+        if (ret <= 0) return 0;
+        memset(&src, 0, sizeof src);
+        src.n = ret; src.d_cs16 = smi->d_iq; src.hs = smi->stream;
+    }
+    if (st->filter_type == CL_DIGFILT_NONE) { *d_iq = src.d_cs16; return src.n; }
+    for (int attempt = 0;; attempt++) {                 /* a call the single-pass kernel gave up on is made again, once */
+        const int16_t *d_f = filter_source(dev, st, &src, NULL);
+        if (!d_f || clhip_stream_sync(src.hs)) return 0;
+        if (!filter_overran(dev, st)) { *d_iq = d_f; return src.n; }
+        if (attempt) return 0;
+    }
+}
+
 int cl_readStream(cl_device *dev, cl_stream *st, void *const *buffs, size_t numElems, int *flags, long long *timeNs, long timeoutUs)
 {
     (void)flags; (void)timeNs;                         /* never written; timeoutUs only matters in ASYNC mode */
@@ -568,216 +677,6 @@ unsigned long cl_stream_iir_overruns(const cl_stream *st) { return st ? (unsigne
 void cl_stream_set_iir_poll_bound(cl_stream *st, int polls)
 {
     if (st) for (int i = 0; i < 3; i++) clhip_iir_set_poll_bound(st->iir[i], polls);
-}
-
-static int read_stream(cl_device *dev, cl_stream *st, void *const *buffs, size_t numElems, long timeoutUs)
-{
-    if (st->native_dir != CL_SOAPY_SDR_RX) return CL_SOAPY_SDR_NOT_SUPPORTED;       /* :248-251 */
-    cl_smi *smi = dev->smi;
-    clhip_set_device(smi->device);
-    void *out = buffs[0];
-    static int single_sync = -1;
-    /* A/B switch: 0 = analysis and copy-out synchronised separately; 1 = one synchronisation, every format through the
-     * pinned mirror; 2 (default) = one synchronisation, converted formats copied straight into the client's buffer
-     * (all of their slots are written anyway; measured 134 -> 108 us per CF32 batch), CS16 through the mirror (only the
-     * slots the reference writes may be touched, and which those are is known after the synchronisation) */
-    if (single_sync < 0) single_sync = getenv("CL_READ_SINGLE_SYNC") ? atoi(getenv("CL_READ_SINGLE_SYNC")) : 2;
-    if (single_sync && !st->use_async && !st->rx_pipe && st->filter_type == CL_DIGFILT_NONE && numElems && numElems <= st->mtu_size) {
-        /* One native batch, no state-carrying stage behind the read: everything the call needs is queued on the seam's
-         * stream behind the chunk analysis -- the conversion kernel (every slot, stale ones included, :304-367) and
-         * the device-to-host copy into the pinned mirror -- so the call pays ONE synchronisation; the verdict of the
-         * last read() arrives with it and a failed read simply discards what was queued.  Host side: CS16 copies
-         * exactly the slots the reference writes (caribou_smi.c:344-389), the other formats all of them. */
-        const size_t eb = fmt_bytes(st->format);
-        cl_sink sk;
-        if (sink_open(st, out, numElems * eb, &sk) ||
-            cl_ensure((void **)&st->h_conv, &st->h_conv_cap, numElems * eb + 64, 1, 1) ||
-            (st->format != CL_FORMAT_CS16 && cl_ensure(&st->d_conv, &st->conv_cap, numElems * 16 + 64, 1, 0)))
-            return 0;
-        if (sk.kind == CL_SINK_STAGED || sk.kind == CL_SINK_BOUNCE) { sk.d_dst = st->d_conv; sk.bounce = st->h_conv; }   /* (the line above may have moved them) */
-        /* the short cut: a call that is one read() the host can see to be in sync is unpacked by ONE launch, in the
-         * client's format, straight into the sink (cl_smi_ra_launch): no search launch, no offset read-back, no conversion
-         * launch; what is left here is the one synchronisation and the sink's own last step */
-        smi->fast_out = read_fast_enabled() ? sk.d_dst : NULL;
-        smi->fast_format = st->format;
-        const long expect = cl_smi_ra_launch(smi, dev->channel, numElems, NULL);
-        smi->fast_out = NULL;
-        if (smi->fast_used) {
-            const int bad = expect > 0 ? sink_queue(&sk, out, (size_t)expect * eb, smi->stream) : 0;
-            int fr = cl_smi_ra_finish(smi);
-            if (bad) fr = CL_SMI_ERR_IO;
-            if (fr == CL_SMI_ERR_IO) printf("reader thread failed to read SMI!\n");      /* :270 */
-            if (fr <= 0) return 0;
-            sink_deliver(st, &sk, out, (size_t)fr * eb);
-            return fr;
-        }
-        /* the staged bytes are in pinned host memory: when every chunk of the call starts with the sync pattern the
-         * call WILL deliver `expect` samples into every slot (offset 0 <=> those four words), so the device-to-host
-         * copy may target the client's buffer itself.  Otherwise it goes to the pinned mirror and the client's
-         * buffer is written after the verdict: nothing on a failed read, for CS16 only the slots the reference writes. */
-        const int direct = single_sync == 2 && smi->ra_certain;
-        void *dst = direct ? out : st->h_conv;
-        int ret;
-        if (expect > 0 && smi->ra_pending) {
-            int bad;
-            if (st->format == CL_FORMAT_CS16) bad = clhip_memcpy_d2h(dst, smi->d_iq, (size_t)expect * 4, smi->stream);
-            else bad = clhip_convert_from_cs16(smi->d_iq, (size_t)expect, st->format, st->d_conv, smi->stream) ||
-                       clhip_memcpy_d2h(dst, st->d_conv, (size_t)expect * eb, smi->stream);
-            ret = cl_smi_ra_finish(smi);
-            if (bad) ret = CL_SMI_ERR_IO;
-        } else {                                           /* nothing pending, or the loop ended on an earlier read() */
-            ret = expect < 0 ? (int)expect : (smi->ra_pending ? cl_smi_ra_finish(smi) : (int)expect);
-            dst = st->h_conv;
-            if (ret > 0) {
-                int bad;
-                if (st->format == CL_FORMAT_CS16) bad = clhip_memcpy_d2h(dst, smi->d_iq, (size_t)ret * 4, smi->stream);
-                else bad = clhip_convert_from_cs16(smi->d_iq, (size_t)ret, st->format, st->d_conv, smi->stream) ||
-                           clhip_memcpy_d2h(dst, st->d_conv, (size_t)ret * eb, smi->stream);
-                if (bad || clhip_stream_sync(smi->stream)) ret = CL_SMI_ERR_IO;
-            }
-        }
-        if (ret == CL_SMI_ERR_IO) printf("reader thread failed to read SMI!\n");    /* :270 */
-        if (ret <= 0) return 0;                                                     /* :266-276 */
-        if (dst == out) return ret;
-        if (st->format != CL_FORMAT_CS16) { memcpy(out, st->h_conv, (size_t)ret * eb); return ret; }
-        for (size_t i = 0; i < smi->n_chunks; i++) {
-            const cl_chunk *c = &smi->chunks[i];
-            const size_t shortening = c->offs > 0 ? (size_t)(c->offs / 4 + 1) : 0;
-            const size_t nn = (c->len - 4 * shortening) / 4, n_iq = nn + (shortening > 0 && nn >= 2 ? 1 : 0);
-            memcpy((uint8_t *)out + 4 * c->slot0, (const uint8_t *)st->h_conv + 4 * c->slot0, 4 * n_iq);
-        }
-        return ret;
-    }
-    if (st->format == CL_FORMAT_CS16) {                /* :282-301, no MTU clamp */
-        int aligned = 0;
-        int res;
-        if (read_fast_enabled() && !st->use_async && st->filter_type != CL_DIGFILT_NONE && numElems && numElems <= st->mtu_size) {
-            /* One native batch through the low-pass: when the call is one read() the host can see to be in sync, the
-             * unpack launch and the filter launch are queued back to back and the call pays ONE synchronisation (the
-             * read's verdict arrives with it); the filter stores straight into the sink. */
-            /* ... and the unpack is the filter's own input conversion (clhip_iir_run_smi): the raw words of the read() go
-             * straight into the filter launch -- no unpack launch, no int16 intermediate.  Only when the filter is on its
-             * scan path (it has overrun before, or its memory is too long for the single-pass kernel) are the words
-             * unpacked first. */
-            smi->fast_out = CL_FAST_WORDS_ONLY;
-            const long expect = cl_smi_ra_launch(smi, dev->channel, numElems, NULL);
-            smi->fast_out = NULL;
-            if (smi->fast_used && expect > 0) {
-                cl_sink sk;
-                clhip_iir *flt = st->iir[st->filter_type - 1];
-                int bad = sink_open(st, out, (size_t)expect * 4, &sk);
-                int unpacked = 0;
-                if (!bad) {
-                    const int rc = clhip_iir_run_smi(flt, dev->channel, smi->fast_words, (int16_t *)sk.d_dst, (size_t)expect, (size_t)expect, smi->stream);
-                    if (rc == -2) {
-                        unpacked = 1;
-                        bad = clhip_smi_unpack_aligned(dev->channel, smi->fast_words, (size_t)expect * 4, CL_FORMAT_CS16, smi->d_iq, NULL, smi->stream) ||
-                              !filter_native(st, smi->d_iq, (size_t)expect, smi->stream, (int16_t *)sk.d_dst);
-                    } else bad = rc != 0;
-                }
-                bad = bad || sink_queue(&sk, out, (size_t)expect * 4, smi->stream);
-                int fr = cl_smi_ra_finish(smi);                              /* the synchronisation */
-                if (bad) fr = CL_SMI_ERR_IO;
-                if (fr == CL_SMI_ERR_IO) printf("reader thread failed to read SMI!\n");    /* :270 */
-                if (fr <= 0) return 0;
-                if (filter_overran(dev, st)) {                               /* made again, once, on the scan path (from int16 samples) */
-                    if ((!unpacked && clhip_smi_unpack_aligned(dev->channel, smi->fast_words, (size_t)fr * 4, CL_FORMAT_CS16, smi->d_iq, NULL, smi->stream)) ||
-                        !filter_native(st, smi->d_iq, (size_t)fr, smi->stream, (int16_t *)sk.d_dst) ||
-                        sink_queue(&sk, out, (size_t)fr * 4, smi->stream) || clhip_stream_sync(smi->stream) || filter_overran(dev, st))
-                        return 0;
-                }
-                sink_deliver(st, &sk, out, (size_t)fr * 4);
-                return fr;
-            }
-            res = (expect < 0 || !smi->ra_pending) ? (int)expect : cl_smi_ra_finish(smi);
-            if (res < 0) {
-                if (res == CL_SMI_ERR_IO) printf("reader thread failed to read SMI!\n");   /* :270 */
-                res = 0;                                                                    /* :266-276 */
-            }
-        } else
-            res = read_native_device(st, numElems, &aligned, timeoutUs);
-        if (res <= 0) return res;
-        if (st->use_async && aligned == 2) {        /* the ring's slots went straight to the pinned mirror */
-            memcpy(out, st->h_conv, (size_t)res * 4);
-            return res;
-        }
-        if (!st->use_async && st->filter_type == CL_DIGFILT_NONE) { if (cl_smi_copy_out(smi, (cl_sample_complex_int16 *)out, NULL, -1)) return 0; return res; }
-        /* the filter (or, ASYNC without one, nothing) is the last device stage: its results go straight into the sink */
-        void *hs = st->use_async ? st->astream : smi->stream;
-        const int16_t *d_raw = st->use_async ? st->d_aiq : smi->d_iq;
-        cl_sink sk;
-        if (sink_open(st, out, (size_t)res * 4, &sk)) return 0;
-        for (int attempt = 0;; attempt++) {          /* a call the single-pass kernel gave up on is made again, once */
-            const int filt = st->filter_type != CL_DIGFILT_NONE;
-            const int16_t *d_f = filter_native(st, d_raw, (size_t)res, hs, filt ? (int16_t *)sk.d_dst : NULL);
-            if (!d_f) return 0;
-            if (!filt ? clhip_memcpy_d2h(sk.kind == CL_SINK_MIRROR || sk.kind == CL_SINK_BOUNCE ? st->h_conv : out, d_f, (size_t)res * 4, hs)
-                      : sink_queue(&sk, out, (size_t)res * 4, hs)) return 0;
-            if (clhip_stream_sync(hs)) return 0;
-            if (!filter_overran(dev, st)) break;
-            if (attempt) return 0;
-        }
-        sink_deliver(st, &sk, out, (size_t)res * 4);
-        return res;
-    }
-    if (numElems > st->mtu_size) numElems = st->mtu_size;                          /* :306,328,351 */
-    if (st->rx_pipe && !st->use_async && st->filter_type == CL_DIGFILT_NONE) {
-        /* extension stages straight from the staged raw words: no int16 intermediate, one fused launch, the sync
-         * verdict checked on the device; re-sync / "-3" as caribou_smi_read has them (clhip_rx_pipe_run_smi) */
-        const size_t ob = st->dsp.demod_fm ? 4 : 8, max_out = clhip_rx_pipe_out_count(st->rx_pipe, numElems) * ob;
-        cl_sink sk;
-        if (sink_open(st, out, max_out, &sk) || cl_ensure(&st->d_conv, &st->conv_cap, max_out + 64, 1, 0)) return 0;
-        long got = 0;
-        /* a call the host can see to be in sync stores its outputs straight into the client's registered buffer or the mapped
-         * mirror; any other call (and every output larger than the mirror route pays for) leaves them on the device and
-         * copies them into the client's buffer under the pipe call's own synchronisation, once it is known to deliver */
-        const int held = sk.kind == CL_SINK_STAGED || sk.kind == CL_SINK_BOUNCE;   /* outputs stay on the device until the call is known to deliver */
-        const int ret = cl_smi_read_pipe_device(smi, dev->channel, numElems, st->rx_pipe, st->d_conv, &got,
-                                                sk.kind == CL_SINK_BOUNCE ? st->h_conv : out, held ? NULL : sk.d_dst);
-        if (ret == CL_SMI_ERR_IO) printf("reader thread failed to read SMI!\n");    /* :270 */
-        if (ret <= 0 || got <= 0) return 0;                                         /* :266-276 */
-        if (sk.kind == CL_SINK_BOUNCE) memcpy(out, st->h_conv, (size_t)got * ob);   /* (the copy engine wrote the pinned mirror) */
-        else if (!held && smi->pipe_out_used == sk.d_dst) sink_deliver(st, &sk, out, (size_t)got * ob);
-        return (int)got;
-    }
-    int aligned = 0;
-    int res = read_native_device(st, numElems, &aligned, timeoutUs);
-    if (res <= 0) return res;
-    const size_t n = (size_t)res;
-    const int16_t *d_raw = st->use_async ? st->d_aiq : smi->d_iq;      /* the native samples of this call */
-    void *hs = st->use_async ? st->astream : smi->stream;
-    if (st->filter_type != CL_DIGFILT_NONE) aligned = 0;              /* filtered samples: the fused raw-word path no longer applies */
-    /* everything behind the native read is queued on one stream and synchronised once; if the filter's verdict then says
-     * the single-pass kernel gave up, its state is already back where it was: the stages are queued again, once */
-    const size_t ob = st->rx_pipe ? (st->dsp.demod_fm ? 4 : 8) : fmt_bytes(st->format);
-    const size_t max_out = (st->rx_pipe ? clhip_rx_pipe_out_count(st->rx_pipe, n) : n) * ob;
-    cl_sink sk;                                                       /* the last stage stores straight into the sink */
-    if (sink_open(st, out, max_out, &sk)) return 0;
-    for (int attempt = 0;; attempt++) {
-        const int16_t *d_iq = filter_native(st, d_raw, n, hs, NULL);
-        if (!d_iq) return 0;
-        long got;
-        if (st->rx_pipe) {
-            /* extension stages where a client of readStream(CF32) would apply them */
-            if (aligned)   /* every chunk in sync: one fused launch straight from the raw SMI words */
-                got = clhip_rx_pipe_run(st->rx_pipe, CL_PIPE_IN_SMI_WORDS, smi->d_bytes, 0, n, sk.d_dst, 0, hs);
-            else           /* re-synchronised, IIR-filtered or popped from the ring: from the native int16 samples */
-                got = clhip_rx_pipe_run(st->rx_pipe, CL_PIPE_IN_CS16, d_iq, 0, n, sk.d_dst, 0, hs);
-            if (got < 0) return 0;
-        } else {
-            /* :304-367: every one of the `res` slots is converted, stale ones included */
-            if (clhip_convert_from_cs16(d_iq, n, st->format, sk.d_dst, hs)) return 0;
-            got = res;
-        }
-        if (sink_queue(&sk, out, (size_t)got * ob, hs)) return 0;
-        if (clhip_stream_sync(hs)) return 0;
-        if (!filter_overran(dev, st)) {
-            sink_deliver(st, &sk, out, (size_t)got * ob);
-            return (int)got;
-        }
-        if (st->rx_pipe) clhip_rx_pipe_rollback(st->rx_pipe);         /* the pipe ran on invalid samples: undo it too */
-        if (attempt) return 0;
-    }
 }
 
 /* ------------------------------------------------------------------- TX path */
@@ -823,9 +722,11 @@ static int write_stream(cl_device *dev, cl_stream *st, const void *const *buffs,
      * every input several times. */
     const void *d_in = n * ib <= cl_write_mapped_max() && !(st->tx_pipe && !st->dsp.mod_fm) ? clhip_host_device_ptr(smi->h_txin) : NULL;
     uint8_t *d_room = d_in ? (uint8_t *)cl_fifo_device_ptr(&smi->tx, room) : NULL;
+    /* (every exit behind a queued copy or launch synchronises first -- `fail`: the kernels read smi->h_txin and store into the FIFO's
+     * reserved room, both of which the next call may move or overwrite) */
     if (!d_room) {
         d_in = st->d_conv;
-        if (clhip_memcpy_h2d(st->d_conv, smi->h_txin, n * ib, smi->stream)) return 0;
+        if (clhip_memcpy_h2d(st->d_conv, smi->h_txin, n * ib, smi->stream)) goto fail;
     }
     uint8_t *d_words = d_room ? d_room : smi->d_bytes;
     size_t n_packed = n;
@@ -839,17 +740,17 @@ static int write_stream(cl_device *dev, cl_stream *st, const void *const *buffs,
             if (st->dsp.mod_fm) {
                 /* the I rail as a dense message, taken on the device behind the samples (d_conv holds 16 bytes per element) */
                 float *d_msg = (float *)st->d_conv + 2 * n;
-                if (clhip_take_i_rail((const float *)d_in, n, d_msg, smi->stream)) return 0;
+                if (clhip_take_i_rail((const float *)d_in, n, d_msg, smi->stream)) goto fail;
                 got = clhip_tx_pipe_run(st->tx_pipe, CL_TXPIPE_IN_FM_MESSAGE, d_msg, 0, n, d_words, 0, NULL, 0, smi->stream);
             } else
                 got = clhip_tx_pipe_run(st->tx_pipe, CL_TXPIPE_IN_CF32, d_in, 0, n, d_words, 0, NULL, 0, smi->stream);
-            if (got < 0) return 0;
+            if (got < 0) goto fail;
             n_packed = (size_t)got;
         } else {
             /* :199-244 and caribou_smi.c:684-717 on the same sample, one launch */
-            if (clhip_convert_pack(d_in, st->format, n, smi->tx_mode, d_words, smi->stream)) return 0;
+            if (clhip_convert_pack(d_in, st->format, n, smi->tx_mode, d_words, smi->stream)) goto fail;
         }
-        if (n_packed && ((!d_room && clhip_memcpy_d2h(room, smi->d_bytes, 4 * n_packed, smi->stream)) || clhip_stream_sync(smi->stream))) return 0;
+        if (n_packed && ((!d_room && clhip_memcpy_d2h(room, smi->d_bytes, 4 * n_packed, smi->stream)) || clhip_stream_sync(smi->stream))) goto fail;
         /* the modulator's verdict on this very call: invalid words never reach the fd (squashed to 0 like every
          * write error, CaribouliteStream.cpp:185-194) */
         if (!st->tx_pipe || clhip_tx_pipe_status(st->tx_pipe) == 0) break;
@@ -859,4 +760,7 @@ static int write_stream(cl_device *dev, cl_stream *st, const void *const *buffs,
     }
     cl_smi_tx_commit(smi, 4 * n_packed);
     return (int)n;      /* elements consumed from the caller's buffer */
+fail:
+    clhip_stream_sync(smi->stream);
+    return 0;
 }

@@ -69,6 +69,7 @@ _SIGS = {
     "clhip_iir_set_state": (C.c_int, [C.c_void_p, C.c_void_p]),
     "clhip_iir_get_state": (C.c_int, [C.c_void_p, C.c_void_p]),
     "clhip_iir_set_poll_bound": (None, [C.c_void_p, C.c_int]),
+    "clhip_iir_set_shape": (None, [C.c_void_p, C.c_int, C.c_int]),
     "clhip_iir_on_scan_path": (C.c_int, [C.c_void_p]),
     "clhip_iir_debug_stamps": (C.c_size_t, [C.c_void_p, C.c_void_p]),
     "clhip_iir_memory_samples": (C.c_size_t, [C.c_void_p]),

@@ -81,6 +81,8 @@ _SIGS = {
     "cl_getNativeStreamFormat": (C.c_char_p, [C.c_void_p, C.c_int, C.c_size_t, C.POINTER(C.c_double)]),
     "cl_setupStream": (C.c_void_p, [C.c_void_p, C.c_int, C.c_char_p, C.c_void_p, C.c_size_t,
                                     C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_size_t]),
+    "cl_stream_register_buffer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "cl_stream_unregister_buffers": (None, [C.c_void_p, C.c_void_p]),
     "cl_closeStream": (None, [C.c_void_p, C.c_void_p]),
     "cl_getStreamMTU": (C.c_size_t, [C.c_void_p, C.c_void_p]),
     "cl_activateStream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_size_t]),
@@ -297,6 +299,16 @@ class Device:
 
     def lastError(self):
         return lib().cl_device_last_error(self.h).decode()
+
+    def registerStreamBuffer(self, st, buf):
+        """ZEROCOPY=1 streams: `buf` (a numpy array the caller keeps alive) may be written by the last kernel of a read"""
+        if lib().cl_stream_register_buffer(self.h, st, buf.ctypes.data, buf.nbytes) != 0:
+            raise RuntimeError(self.lastError())
+        self._zc_bufs = getattr(self, "_zc_bufs", []) + [buf]
+
+    def unregisterStreamBuffers(self, st):
+        lib().cl_stream_unregister_buffers(self.h, st)
+        self._zc_bufs = []
 
     def closeStream(self, st):
         lib().cl_closeStream(self.h, st)

@@ -244,6 +244,9 @@ int    clhip_iir_get_state(clhip_iir *f, double *h_state);
  * for several GPUs need a halo of this length, not a state hand-off.  0 = longer than the single-pass kernel's horizon. */
 size_t clhip_iir_memory_samples(const clhip_iir *f);
 void   clhip_iir_set_poll_bound(clhip_iir *f, int polls);   /* test hook: -1 forces every poll to give up */
+/* test hook: force the single-pass kernel's segment length (16 / 32 / 64 samples per lane; 0 = by the call's size) and its tile order
+ * (1 = chunks by atomic ticket, the default; 0 = a rank per wave) */
+void   clhip_iir_set_shape(clhip_iir *f, int seg, int dynamic);
 int    clhip_iir_on_scan_path(const clhip_iir *f);           /* 1 once an overrun (or CLHIP_IIR_ONEPASS=0) has switched it */
 /* diagnostics (objects created under CLHIP_IIR_STAMPS=1): per-phase time stamps of the last single-pass launch,
  * [64 waves][16 tiles][12 phases] of the 100 MHz real-time counter; returns the word count (0: not enabled) */
@@ -515,15 +518,21 @@ const char *cl_getNativeStreamFormat(const cl_device *dev, int direction, size_t
 /* setupStream :100-139 -- NULL + cl_device_last_error() where the reference throws.
  * Extension kwargs (SURVEY.md section 5 "Config / flags"): FIR=<ntaps>:<cutoff_hz>,
  * RESAMP=<L>/<M>, DEMOD=FM, MOD=FM:<kf_hz>; ASYNC=1 enables the reader thread + ring of the reference's
- * compiled-out USE_ASYNC path (CaribouliteStream.cpp:11,16-49,70-75); ZEROCOPY=1 (RX) registers the buffers the client
- * passes to readStream with the GPU on first sight (up to 8, 16-byte aligned) so that the last kernel of a read stores
- * into them directly -- the client promises that such a buffer stays mapped until the stream is set up again or the
- * device is closed (a user-pointer mapping of the client's pages: the same mechanism as the runtime's in-place pinning the
- * copy helpers above avoid -- meant for buffers the client allocates once and keeps, not for a heap that churns);
+ * compiled-out USE_ASYNC path (CaribouliteStream.cpp:11,16-49,70-75); ZEROCOPY=1 (RX) lets the client REGISTER buffers
+ * of its own with the GPU (cl_stream_register_buffer below): a readStream whose buffs[0] lies inside a registered buffer has its
+ * last kernel store into it directly; any other pointer takes the default route (the stream's pinned mirror + memcpy).  Nothing
+ * is ever registered behind the client's back (round 3 registered "on first sight" and evicted: a user-pointer mapping of heap
+ * pages the client may since have freed -- the same family of effects as the runtime's in-place pinning);
  * defaults = reference behaviour. */
 cl_stream *cl_setupStream(cl_device *dev, int direction, const char *format,
                           const size_t *channels, size_t n_channels,
                           const char *const *keys, const char *const *vals, size_t n_kwargs);
+/* ZEROCOPY=1 streams: register [p, p + bytes) (the pages around it) with the GPU until _unregister_buffers, the next setupStream
+ * or the device's end -- the client keeps the buffer allocated that long.  At most 8 buffers per stream; a full table refuses
+ * (no eviction: registrations never churn in steady state).  0, or -1 + cl_device_last_error.  _unregister_buffers waits for the
+ * stream's device work first. */
+int    cl_stream_register_buffer(cl_device *dev, cl_stream *stream, void *p, size_t bytes);
+void   cl_stream_unregister_buffers(cl_device *dev, cl_stream *stream);
 void   cl_closeStream(cl_device *dev, cl_stream *stream);                         /* :147-150 */
 size_t cl_getStreamMTU(const cl_device *dev, cl_stream *stream);                  /* :162-165 */
 int    cl_activateStream(cl_device *dev, cl_stream *stream, int flags,
@@ -545,7 +554,7 @@ typedef struct {
     uint64_t write_calls, elements_written;  /* writeStream calls / elements they consumed                             */
     uint64_t writes_empty;                   /* writeStream calls that returned 0                                      */
     uint64_t tx_overruns;                    /* writes whose modulator look-back gave up and was repeated in ticket order */
-    uint64_t zero_copy_registrations;        /* ZEROCOPY=1: client buffers registered with the GPU so far                */
+    uint64_t zero_copy_registrations;        /* ZEROCOPY=1: client buffers registered with the GPU so far (cl_stream_register_buffer) */
     uint64_t zero_copy_reads;                /* ZEROCOPY=1: reads whose last kernel stored into the client's buffer itself */
 } cl_stream_stats;
 void   cl_getStreamStats(const cl_device *dev, const cl_stream *stream, cl_stream_stats *out);

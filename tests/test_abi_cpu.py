@@ -119,3 +119,34 @@ def test_cpp_api_library_exports_the_reference_method_names():
               "CaribouLiteRadio::WriteSamples(std::complex<float>*", "CaribouLiteRadio::WriteSamples(std::complex<short>*",
               "CaribouLiteRadio::StartReceiving(", "CaribouLiteRadio::StopReceiving()", "CaribouLiteRadio::GetNativeMtuSample()"):
         assert m in out, m
+
+
+def test_host_memory_operation_ring_and_its_signal_safe_dump(tmp_path):
+    """clhip_debug_ops / _ops_dump (what the SIGABRT tracer of the test sessions prints): registrations are noted whether or not
+    they succeed -- without a GPU they fail, which is what makes this testable here -- oldest first, at most 256, and the text dump
+    uses write(2) only."""
+    import ctypes as C
+    from cariboulite_amd import hip
+
+    class Rec(C.Structure):
+        _fields_ = [("seq", C.c_uint64), ("op", C.c_uint32), ("pad", C.c_uint32), ("base", C.c_uint64), ("len", C.c_uint64)]
+    L = hip.lib()
+    recs = (Rec * 300)()
+    n0 = L.clhip_debug_ops(recs, 300)
+    buf = np.zeros(1 << 16, np.uint8)
+    L.clhip_host_register.restype = C.c_void_p
+    for k in range(300):
+        assert not L.clhip_host_register(C.c_void_p(buf.ctypes.data + 4096 * (k % 8)), C.c_size_t(4096 + k))
+    n = L.clhip_debug_ops(recs, 300)
+    assert n == 256 and n0 <= 256
+    seqs = [recs[k].seq for k in range(n)]
+    assert seqs == sorted(seqs) and seqs[-1] - seqs[0] == 255
+    assert all(recs[k].op == 2 for k in range(n))                                           # CLHIP_OP_REGISTER_FAILED
+    assert recs[n - 1].len == 4096 + 299 and recs[n - 1].base == buf.ctypes.data + 4096 * (299 % 8)
+    out = tmp_path / "dump.txt"
+    fd = os.open(str(out), os.O_WRONLY | os.O_CREAT)
+    L.clhip_debug_ops_dump(fd)
+    os.close(fd)
+    lines = out.read_text().splitlines()
+    assert lines[0].startswith("[clhip] host-memory operations") and len(lines) == 257
+    assert lines[-1].split()[1] == "register-failed" and lines[-1].split()[3] == "+0x%x" % (4096 + 299)

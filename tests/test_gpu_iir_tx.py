@@ -485,7 +485,7 @@ def test_iir_overrun_is_reported_rolled_back_and_repaired(G, orc):
 
 @pytest.mark.parametrize("seg", [16, 32, 64])
 @pytest.mark.parametrize("dynamic", [1, 0])
-def test_iir_every_segment_length_and_tile_order(G, orc, seg, dynamic, monkeypatch):
+def test_iir_every_segment_length_and_tile_order(G, orc, seg, dynamic):
     """The single-pass kernel's three segment lengths (16 / 32 / 64 samples per lane, picked from the call's size) and
     both tile orders (a ticket per tile / a rank per wave), forced here: three streams, a ragged tail, a second call
     from the carried state, the narrowest reference filter where its horizon fits (fc = 10 kHz at 16-sample segments
@@ -494,13 +494,12 @@ def test_iir_every_segment_length_and_tile_order(G, orc, seg, dynamic, monkeypat
         pytest.skip("the A/B switch in force replaces the single-pass kernel")
     import torch
     from cariboulite_amd import hip
-    monkeypatch.setenv("CLHIP_IIR_SEG", str(seg))
-    monkeypatch.setenv("CLHIP_IIR_DYNAMIC", str(dynamic))
     rng = np.random.default_rng(seg + dynamic)
     ns, n1, n2 = 3, 70 * 32 * seg + 3 * seg + 5, 9 * 32 * seg + 17
     x = rng.integers(-4096, 4096, size=(ns, n1 + n2, 2), dtype=np.int16)
     for fc in (50e3, 25e3, 10e3):
         f = hip.IIR(_sos5(orc.IIR(6, 4e6, fc)), ns)
+        hip.lib().clhip_iir_set_shape(f.h, seg, dynamic)
         d = torch.from_numpy(x.copy()).to(G.DEV)
         f.run(d, n1, stride=n1 + n2)
         f.run(d[:, n1:], n2, stride=n1 + n2)
@@ -661,7 +660,7 @@ def test_two_large_iir_launches_share_the_gpu(G, orc):
     """Two filters, each on its own HIP stream, each launch large enough to want every resident wave of the chip, in
     flight together (round-2 review: 'no test runs two IIR streams at once').  Chunks are taken by ticket, so a wave only
     ever waits for chunks whose owners are already running: neither launch can starve the other, whatever share of the
-    chip each gets.  Each object's verdict is its own; a launch that did give up (static assignment, CLHIP_IIR_DYNAMIC=0)
+    chip each gets.  Each object's verdict is its own; a launch that did give up (static assignment: clhip_iir_set_shape(f, 0, 0))
     is repaired by finish() and still has to be right."""
     import torch
     from cariboulite_amd import hip

@@ -764,13 +764,12 @@ def test_seam_and_stream_counters(S, orc):
 
 
 def test_zero_copy_streams_deliver_what_the_default_route_delivers(S, orc):
-    """ZEROCOPY=1: the client's buffers are registered with the GPU and written by the last kernel of the read.  Same
-    samples as the default route, for every format, through the IIR, through the fused stages, with a re-synchronising
-    and a lost batch in between (those calls fall back to the mirror: the client's buffer sees nothing of a failed read),
-    with an unaligned and a ninth buffer (table eviction)."""
+    """ZEROCOPY=1 + cl_stream_register_buffer: buffers the client has REGISTERED are written by the last kernel of the read.  Same
+    samples as the default route, for every format, through the IIR, through the fused stages, with a re-synchronising and a lost
+    batch in between (the client's buffer sees nothing of a failed read); a pointer that is not registered -- or not 16-byte
+    aligned -- takes the default route; the table holds eight buffers and refuses a ninth (no eviction); nothing is registered
+    unless the client asks."""
     from cariboulite_amd import synth
-    # (the A/B switches that turn the one-launch route off leave the samples alone and the zero-copy counters at zero)
-    one_launch = os.environ.get("CL_READ_FAST", "1") != "0" and os.environ.get("CL_READ_SINGLE_SYNC", "2") != "0"
     t = load_golden("taps.npz")
     b, i, q = synth.smi_stream_bytes(4 * MTU, 0, stream=21)
     iq = np.stack([i, q], 1)
@@ -783,9 +782,11 @@ def test_zero_copy_streams_deliver_what_the_default_route_delivers(S, orc):
         garbage = np.zeros(4 * MTU, np.uint8)
         sdr.feedSmiBytes(np.concatenate([b[: 4 * MTU], shifted, garbage, b[8 * MTU:]]))
         bufs = [np.full((MTU + 4, 2), 77, dt) for _ in range(2)]
+        for x in bufs:
+            sdr.registerStreamBuffer(rx, x)
         assert sdr.readStream(rx, [bufs[0]], MTU).ret == MTU
         assert np.array_equal(bufs[0][:MTU], conv(iq[:MTU])) and (bufs[0][MTU:] == 77).all()
-        assert sdr.readStream(rx, [bufs[1]], MTU).ret == MTU                # re-sync at byte 6: not the one-launch route
+        assert sdr.readStream(rx, [bufs[1]], MTU).ret == MTU                # re-sync at byte 6: not a one-read() in-sync call
         _, want, _ = orc.rx_data_analyze(0, shifted)
         if dt == np.int16:
             assert np.array_equal(bufs[1][:MTU - 2], want[:MTU - 2])
@@ -798,33 +799,56 @@ def test_zero_copy_streams_deliver_what_the_default_route_delivers(S, orc):
             assert sdr.readStream(rx, [bufs[k]], MTU).ret == MTU
             assert np.array_equal(bufs[k][:MTU], conv(iq[(2 + k) * MTU:(3 + k) * MTU]))
         st = sdr.streamStats(rx)
-        assert not one_launch or (st["zero_copy_registrations"] == 2 and st["zero_copy_reads"] == 3), st
+        # CS16 re-synchronised reads copy slot by slot (only what the reference writes): not a kernel's store; the others are
+        assert st["zero_copy_registrations"] == 2 and st["zero_copy_reads"] == (3 if dt == np.int16 else 4), st
         sdr.close()
-    # an odd address (not 16-byte aligned) takes the default route; nine buffers cycle through the table of eight
+    # nothing is registered behind the client's back; an odd address takes the default route; the table of eight refuses a ninth
     sdr = S.Device(dict(driver="Cariboulite", channel="S1G"))
     rx = sdr.setupStream(S.SOAPY_SDR_RX, S.SOAPY_SDR_CS16, args={"ZEROCOPY": "1"})
-    raw = np.zeros(4 * MTU + 64, np.uint8)
-    off = (-raw.ctypes.data) % 16 + 4
-    odd = raw[off: off + 4 * MTU].view(np.int16).reshape(-1, 2)
+    plain = np.zeros((MTU, 2), np.int16)
+    sdr.feedSmiBytes(b[: 4 * MTU])
+    assert sdr.readStream(rx, [plain], MTU).ret == MTU and np.array_equal(plain, iq[:MTU])
+    assert sdr.streamStats(rx)["zero_copy_reads"] == 0 and sdr.streamStats(rx)["zero_copy_registrations"] == 0
+    # ten page-aligned slots two pages apart inside ONE allocation: their page ranges never touch (ranges that do are registered
+    # together, as one -- neighbouring heap buffers share pages), so the table's count is the number of buffers
+    slot_b = 4 * MTU + 8192
+    big = np.zeros(10 * slot_b + 4096, np.uint8)
+    a0 = (-big.ctypes.data) % 4096
+    slots = [big[a0 + k * slot_b: a0 + k * slot_b + 4 * MTU + 64] for k in range(10)]
+    raw = slots[0]
+    odd = raw[4: 4 + 4 * MTU].view(np.int16).reshape(-1, 2)              # 4 bytes off the 16-byte grid
+    sdr.registerStreamBuffer(rx, raw)
     sdr.feedSmiBytes(b[: 4 * MTU])
     assert sdr.readStream(rx, [odd], MTU).ret == MTU and np.array_equal(odd, iq[:MTU])
     assert sdr.streamStats(rx)["zero_copy_reads"] == 0
-    many = [np.zeros((MTU, 2), np.int16) for _ in range(9)]
+    many = [x[: 4 * MTU].view(np.int16).reshape(-1, 2) for x in slots[1:]]
+    for m in many[:7]:
+        sdr.registerStreamBuffer(rx, m)
+    sdr.registerStreamBuffer(rx, many[3])                                # inside a registered range already: nothing to do
+    with pytest.raises(RuntimeError, match="8 buffers are registered already"):
+        sdr.registerStreamBuffer(rx, many[8])
     for rep in range(2):
         for k, m in enumerate(many):
             sdr.feedSmiBytes(b[4 * MTU * (k % 4): 4 * MTU * (k % 4 + 1)])
             assert sdr.readStream(rx, [m], MTU).ret == MTU and np.array_equal(m, iq[(k % 4) * MTU:(k % 4 + 1) * MTU])
     st = sdr.streamStats(rx)
-    assert not one_launch or (st["zero_copy_reads"] == 18 and st["zero_copy_registrations"] >= 10), st
+    assert st["zero_copy_reads"] == 14 and st["zero_copy_registrations"] == 8, st     # many[7], many[8]: the default route
+    sdr.unregisterStreamBuffers(rx)
+    sdr.feedSmiBytes(b[: 4 * MTU])
+    assert sdr.readStream(rx, [many[0]], MTU).ret == MTU and sdr.streamStats(rx)["zero_copy_reads"] == 14
+    with pytest.raises(RuntimeError, match="not set up with ZEROCOPY=1"):
+        d2 = S.Device(dict(driver="Cariboulite", channel="S1G"))
+        d2.registerStreamBuffer(d2.setupStream(S.SOAPY_SDR_RX, S.SOAPY_SDR_CS16), many[0])
     # the IIR and the fused stages as last kernels
-    sdr.setupStream(S.SOAPY_SDR_RX, S.SOAPY_SDR_CS16, args={"ZEROCOPY": "1"})
+    rx = sdr.setupStream(S.SOAPY_SDR_RX, S.SOAPY_SDR_CS16, args={"ZEROCOPY": "1"})
     ref = S.Device(dict(driver="Cariboulite", channel="S1G"))
     rr = ref.setupStream(S.SOAPY_SDR_RX, S.SOAPY_SDR_CS16)
     for d in (sdr, ref):
         d.setBandwidth(S.SOAPY_SDR_RX, 0, 100e3)
         d.feedSmiBytes(b)
-    zc0 = sdr.streamStats(rx)["zero_copy_reads"]
     o1, o2 = np.zeros((MTU, 2), np.int16), np.zeros((MTU, 2), np.int16)
+    sdr.registerStreamBuffer(rx, o1)
+    zc0 = sdr.streamStats(rx)["zero_copy_reads"]
     for k in range(4):
         assert sdr.readStream(rx, [o1], MTU).ret == MTU and ref.readStream(rr, [o2], MTU).ret == MTU
         assert np.array_equal(o1, o2)
@@ -836,11 +860,13 @@ def test_zero_copy_streams_deliver_what_the_default_route_delivers(S, orc):
     x = orc.cs16_to_cf32(iq)
     fir, rs = orc.FIR(t["fir64_c2"]), orc.Resampler(t["rs_3_2"], 3, 2)
     out = np.zeros((MTU * 3 // 2, 2), np.float32)
+    sdr.registerStreamBuffer(rx, out)
+    zc1 = sdr.streamStats(rx)["zero_copy_reads"]
     for k in range(2):
         assert sdr.readStream(rx, [out], MTU).ret == MTU * 3 // 2
         want = rs.f64(fir.f64(x[k * MTU:(k + 1) * MTU]))
         assert np.max(np.abs(out - want)) <= 1e-5 * np.max(np.abs(want))
-    assert sdr.streamStats(rx)["zero_copy_reads"] == zc0 + 6
+    assert sdr.streamStats(rx)["zero_copy_reads"] == zc1 + 2
     sdr.close()
 
 

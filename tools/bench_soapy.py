@@ -32,7 +32,7 @@ for name, fmt, dt, width, args, bw in (
         ("cs16_iir", S.SOAPY_SDR_CS16, np.int16, 2, None, 100e3),
         ("cf32_fir64_rs_3_2", S.SOAPY_SDR_CF32, np.float32, 2, {"FIR": "64:1000000", "RESAMP": "3/2"}, None),
         ("cs16_async_ring", S.SOAPY_SDR_CS16, np.int16, 2, {"ASYNC": "1"}, None),
-        # ZEROCOPY=1: the client's buffer is registered with the GPU, the last kernel of the read stores into it
+        # ZEROCOPY=1 + registerStreamBuffer: the client's buffer is registered with the GPU, the last kernel of the read stores into it
         ("zc_cs16", S.SOAPY_SDR_CS16, np.int16, 2, {"ZEROCOPY": "1"}, None),
         ("zc_cf32", S.SOAPY_SDR_CF32, np.float32, 2, {"ZEROCOPY": "1"}, None),
         ("zc_cs16_iir", S.SOAPY_SDR_CS16, np.int16, 2, {"ZEROCOPY": "1"}, 100e3),
@@ -45,6 +45,8 @@ for name, fmt, dt, width, args, bw in (
         sdr.setBandwidth(S.SOAPY_SDR_RX, 0, bw)
     sdr.activateStream(rx)
     buf = np.zeros((2 * MTU, width), dt)
+    if args and args.get("ZEROCOPY") == "1":
+        sdr.registerStreamBuffer(rx, buf)          # explicit since round 4: nothing is registered behind the client's back
     t_feed = t_read = 0.0
     got = 0
     for rep in range(9 if (args and "ASYNC" in args) else 3):

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Per-workload evidence, on the GPU box:  tools/collect_workload_profiles.sh <outdir> <workload>...
 #   <outdir>/<wl>_bench.json          bench.py --workload <wl>  (default K/W)
-#   <outdir>/<wl>_kernel_stats.csv    rocprofv3 --kernel-trace --stats of the same command
+#   <outdir>/<wl>_kernel_stats.csv    rocprofv3 --kernel-trace --stats of the same command (ALL launches: settle + warm-up included)
+#   <outdir>/<wl>_kernel_timed.json   the same trace, the TIMED launches only (tools/kernel_trace_timed.py): the bench line's clock
 #   <outdir>/<wl>_pmc.json            HBM bytes per step from two separate --pmc passes (FETCH_SIZE, WRITE_SIZE)
 # Copy the files into profiles/rNN/ afterwards (gpurun_out/ is scratch).
 set -e
@@ -17,6 +18,9 @@ for WL in "$@"; do
   python3 bench.py --workload $WL $EXTRA --no-cpu > $OUT/${WL}_bench.json 2> $OUT/${WL}_bench.err
   rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/${WL}_prof -o run -- python3 bench.py --workload $WL $EXTRA --no-cpu > /dev/null 2> $OUT/${WL}_prof.err
   find $OUT/${WL}_prof -name "*kernel_stats.csv" -exec cp {} $OUT/${WL}_kernel_stats.csv \;
+  # bench.py's defaults: 40 settle + 30 warm-up steps in front of 100 timed ones (c2: + 10 launches with per-launch events behind them)
+  DT=170; if [ "$WL" = "c2" ]; then DT=180; fi
+  python3 tools/kernel_trace_timed.py $OUT/${WL}_kernel_timed.json $OUT/${WL}_prof 70 100 $DT > /dev/null
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/$OUT/${WL}_pmc_fetch -o run -- python3 bench.py --workload $WL $EXTRA --steps $PS --warmup $PW --settle $PSETTLE --no-cpu > /dev/null 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/$OUT/${WL}_pmc_write -o run -- python3 bench.py --workload $WL $EXTRA --steps $PS --warmup $PW --settle $PSETTLE --no-cpu > /dev/null 2>&1
   T=$TOTAL; if [ "$WL" = "c2" ]; then T=$((TOTAL+10)); fi   # c2 adds an untimed pass of min(steps, 10) launches with per-launch events
