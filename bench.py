@@ -68,6 +68,11 @@ def parse():
                          "per GPU (weak scaling), same JSON shape with their own algorithmic bytes")
     ap.add_argument("--streams", type=int, default=256, help="c4 only: total streams (32 = the share of one GPU of the 8-GPU job)")
     ap.add_argument("--fanout", action="store_true", help="c4 only: rank 0 holds all raw buffers and scatters them over xGMI first")
+    ap.add_argument("--pcie", action="store_true",
+                    help="c2 only: the PCIe-INCLUSIVE figure instead of the headline one -- host SMI bytes in, host CF32 samples out, "
+                         "--pcie-streams Soapy devices of one GPU read through cl_group_readStream (one MTU per stream and step); "
+                         "roofline.bound = \"pcie\" against the box's own concurrent H2D + D2H ceiling.  Never the headline `value`.")
+    ap.add_argument("--pcie-streams", type=int, default=32)
     ap.add_argument("--print-launch", action="store_true",
                     help="with --gpus N > 1 and no WORLD_SIZE: print the launcher command this process would start, and exit")
     return ap.parse_args()
@@ -148,6 +153,87 @@ def pmc_traffic(workload):
             except Exception:
                 pass
     return None, None
+
+
+def bench_pcie(a, world, rank, dev, dist, red_dev, arch, taps):
+    """Config 2's stages at the drop-in boundary, PCIe included: every rank feeds --pcie-streams Soapy devices of its GPU with host
+    SMI bytes (cl_smi_feed_bytes: their pinned FIFOs stand where /dev/smi's kfifo stands) and reads them through cl_group_readStream
+    into pageable numpy buffers, one MTU per stream and step (soapy_api/CaribouliteStreamFunctions.cpp:239-254 x N devices,
+    SoapyCariboulite.cpp:46-69).  Same JSON shape as the headline line; the roof is the PCIe link, measured on this box in this
+    run (tools/microbench/pcie_duplex: the same bytes in and out on two streams, pinned memory, copy engine)."""
+    from cariboulite_amd import soapy as S, synth, shard
+    MTU, NB = NATIVE_CHUNK_SAMPLES, 4 * NATIVE_CHUNK_SAMPLES
+    n, K, W = a.pcie_streams, a.steps, a.warmup
+    devs = []
+    for i in range(n):
+        d = S.Device(dict(driver="Cariboulite", channel="S1G" if i % 2 == 0 else "HiF", gpu=str(dev.index or 0)))
+        d.activateStream(d.setupStream(S.SOAPY_SDR_RX, S.SOAPY_SDR_CF32, args={"FIR": "64:1000000", "RESAMP": "3/2"}))
+        devs.append(d)
+    grp = S.Group(devs)
+    bufs = [np.zeros((MTU * 3 // 2 + 8, 2), np.float32) for _ in range(n)]
+    words = [synth.smi_stream_bytes((K + W) * MTU, i % 2, stream=1000 * rank + i)[0] for i in range(min(n, 4))]
+    for i, d in enumerate(devs):
+        d.feedSmiBytes(words[i % len(words)])
+
+    def step():
+        nd, rets = grp.readStream(bufs, MTU)
+        assert nd == n, (nd, grp.lastError())
+
+    for _ in range(W):
+        step()
+    dt = shard.timed_steps(step, K, sync_fn=torch.cuda.synchronize, dist=dist, device=red_dev)
+    st = grp.stats()
+    got0 = bufs[0][: MTU * 3 // 2].copy()
+    grp.close()
+    for d in devs:
+        d.close()
+    if rank == 0:
+        value = world * n * MTU * K / dt / 1e6
+        res = {"metric": "Msamples/s through unpack+FIR(64)+resample(3/2) pipe, host bytes in -> host samples out (PCIe-inclusive)",
+               "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": K, "warmup": W,
+               "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"config 2's stages at the Soapy boundary: {n} streams per GPU (S1G + HiF), one MTU = {MTU} samples per stream and step "
+                                      f"through cl_group_readStream, host SMI bytes in (pinned FIFOs), CF32 samples out into pageable buffers",
+                          "streams_per_gpu": n, "arch": arch, "group": {k: st[k] for k in ("batched_reads", "single_reads", "launches", "errors")},
+                          "parallelism": f"{world} independent group(s), no data-path collective"}}
+        exe = os.path.join(ROOT, "tools", "microbench", "pcie_duplex")
+        sh = None
+        if os.path.exists(exe):
+            try:
+                o = subprocess.run([exe, str(n * NB >> 20), str(n * MTU * 12 >> 20)], capture_output=True, text=True, timeout=120, check=True).stdout
+                sh = json.loads(o[o.index("{"):])["shape"]
+            except Exception:
+                sh = None
+        per_gpu = value / world
+        if sh:
+            peak = n * MTU / (sh["duplex_ms"] * 1e-3) / 1e6
+            res["roofline"] = {"bound": "pcie", "achieved": round(per_gpu, 1), "peak": round(peak, 1), "unit": "Msamples/s per GPU", "frac": round(per_gpu / peak, 4),
+                               "achieved_GBs": round(16.0 * per_gpu / 1e3, 2), "peak_GBs": round(16.0 * peak / 1e3, 2), "traffic": None,
+                               "peak_note": f"measured here: {sh['in_MiB']} MiB H2D + {sh['out_MiB']} MiB D2H queued together on two HIP streams (pinned memory, copy engine) "
+                                            f"take {sh['duplex_ms']:.3f} ms; alone {sh['h2d_GBs']} / {sh['d2h_GBs']} GB/s",
+                               "kernel": "rx_pipe_fused_kernel over sub-batches of 4 streams, stores into the mapped pinned mirror",
+                               "algorithmic_bytes_per_sample": 16.0}
+        else:
+            res["roofline"] = {"bound": "pcie", "achieved": round(per_gpu, 1), "peak": None, "unit": "Msamples/s per GPU", "frac": None, "traffic": None,
+                               "peak_note": "tools/microbench/pcie_duplex not built: __graft_entry__.build() compiles it"}
+        if world == 1 and not a.no_cpu:
+            n_cpu = 1 << 24
+            dwords = torch.from_numpy(np.tile(words[0][: min(words[0].size, 4 * n_cpu)], -(-4 * n_cpu // words[0].size))[: 4 * n_cpu].view(np.int32).copy())
+            cb, cpu_out = cpu_baseline(taps, dwords, a.cpu_seconds)
+            res["cpu_baseline"] = cb
+            res["gpu_over_cpu"] = round(value / cb["value"], 2)
+            # parity of the delivered samples: stream 0's last batch against the oracle's pipe over the same stream (carried state included)
+            from oracle import oracle as orc
+            fir, rs = orc.FIR(taps["fir64_c2"]), orc.Resampler(taps["rs_3_2"], 3, 2)
+            want = None
+            for k in range(K + W):
+                _, iq, _ = orc.smi_read(0, words[0][k * NB:(k + 1) * NB], MTU, NB)
+                want = rs.f64(fir.f64(orc.cs16_to_cf32(iq[:MTU])))
+            res["max_abs_diff_vs_oracle_last_batch"] = float(np.max(np.abs(got0[: want.shape[0]] - want)))
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 def bench_c4(a, world, rank, dev, dist, red_dev, arch, taps):
@@ -330,6 +416,12 @@ def main():
     from cariboulite_amd import hip, synth
     arch = hip.require_gpu()
     taps = np.load(os.path.join(ROOT, "tests", "golden", "taps.npz"))
+    if a.pcie:
+        if a.workload != "c2":
+            raise SystemExit("--pcie is config 2's stages at the Soapy boundary: --workload c2")
+        if a.steps == 100 and a.warmup == 30:
+            a.steps, a.warmup = 40, 10                  # (every step's bytes are queued in the members' pinned FIFOs beforehand: 512 KiB per stream and step)
+        return bench_pcie(a, world, rank, dev, dist, red_dev, arch, taps)
     if a.workload == "c4":
         return bench_c4(a, world, rank, dev, dist, red_dev, arch, taps)
     if a.workload != "c2":

@@ -123,6 +123,21 @@ def build_fanout(force=False, verbose=False):
     return FANOUT_LIB
 
 
+PCIE_PROBE = os.path.join(ROOT, "tools", "microbench", "pcie_duplex")
+
+
+def build_pcie_probe(force=False, verbose=False):
+    """tools/microbench/pcie_duplex: the box's concurrent H2D + D2H ceiling, which bench.py --pcie and tools/bench_group.py price
+    the stream group against (a measuring tool, not part of the product libraries)."""
+    src = PCIE_PROBE + ".hip"
+    if force or _newer(PCIE_PROBE, [src]):
+        cmd = [_hipcc(), "-O3", "-mavx2", "-w", f"--offload-arch={ARCH}", src, "-o", PCIE_PROBE, "-lpthread"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return PCIE_PROBE
+
+
 def build_all(force=False, verbose=False):
     build_hip(force, verbose)
     build_host(force, verbose)
@@ -134,6 +149,11 @@ def build_all(force=False, verbose=False):
         # the data path; cariboulite_amd.fanout raises ImportError when someone asks for the missing library
         import warnings
         warnings.warn(f"libcariboulite_fanout.so not built ({e}); the RCCL fan-out is unavailable")
+    try:
+        build_pcie_probe(force, verbose)
+    except (subprocess.CalledProcessError, OSError) as e:
+        import warnings
+        warnings.warn(f"tools/microbench/pcie_duplex not built ({e}); bench.py --pcie reports no roof")
 
 
 if __name__ == "__main__":

@@ -649,7 +649,8 @@ struct IirRailArgs {
 #define RL_STAMP_WAVES 64
 #define RL_STAMP_TILES 16
 #define RL_STAMP_PHASES 12
-#define RL_STAMP_ALLWAVES 8192             // behind the phase table: [wave][start, end, tiles done]
+#define RL_STAMP_ALLWAVES 8192             // behind the phase table: [wave][start, end, tiles done | HW_ID | XCC_ID, ticks spent polling for first-tile aggregates, first chunk | class << 32]
+#define RL_STAMP_WORDS 5
 #define RL_STAMP(p) do { if (A.stamps && blockIdx.x < RL_STAMP_WAVES && it < RL_STAMP_TILES && t0 == 0) \
         A.stamps[((size_t)blockIdx.x * RL_STAMP_TILES + it) * RL_STAMP_PHASES + (p)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 
@@ -830,12 +831,17 @@ __global__ __launch_bounds__(64, RL_WAVES) void iir_rail_kernel(const IirRailArg
     for (long i = (long)blockIdx.x * 64 + t0; i < A.other_words; i += (long)gridDim.x * 64) A.agg_other[i] = IIR_SENTINEL;
 
     if (A.stamps && t0 == 0 && blockIdx.x < RL_STAMP_ALLWAVES)
-        A.stamps[(size_t)RL_STAMP_WAVES * RL_STAMP_TILES * RL_STAMP_PHASES + 3 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+        A.stamps[(size_t)RL_STAMP_WAVES * RL_STAMP_TILES * RL_STAMP_PHASES + RL_STAMP_WORDS * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
     unsigned int tk = 0;
     if (t0 == 0) tk = atomicAdd(A.ctl + cls * RL_CTL_STRIDE, 1u);
     // (a ticket beyond the launch's chunks saturates: more tickets than chunks are only ever taken by waves on their way out)
     unsigned T = rail_tile_of(cls, NC, (unsigned)__builtin_amdgcn_readfirstlane((int)tk), total);
     const unsigned NW = gridDim.x;
+    // (diagnostics; written at once so that nothing of it stays live: this kernel has no scalar register to spare)
+    if (A.stamps && t0 == 0 && blockIdx.x < RL_STAMP_ALLWAVES) {
+        A.stamps[(size_t)RL_STAMP_WAVES * RL_STAMP_TILES * RL_STAMP_PHASES + RL_STAMP_WORDS * blockIdx.x + 3] = 0;
+        A.stamps[(size_t)RL_STAMP_WAVES * RL_STAMP_TILES * RL_STAMP_PHASES + RL_STAMP_WORDS * blockIdx.x + 4] = (unsigned long long)T | ((unsigned long long)cls << 32);
+    }
     constexpr bool PF = RL_PREFETCH && NS < 4;      // (four biquads: the start-state phase needs the registers)
     int it = -1;
     while (T < total) {
@@ -972,6 +978,8 @@ __global__ __launch_bounds__(64, RL_WAVES) void iir_rail_kernel(const IirRailArg
                 const unsigned long long *theirs = j >= 0 ? A.agg + ((s * A.n_tiles + j) * 2 + rail) * D
                                                           : (const unsigned long long *)(A.state_in + s * 2 * IIR_MAX_DIM + rail * IIR_MAX_DIM);
                 int guard = 0;
+                if (A.stamps && t0 == 0 && blockIdx.x < RL_STAMP_ALLWAVES)      // ticks spent polling: -start here, +end behind the loop
+                    A.stamps[(size_t)RL_STAMP_WAVES * RL_STAMP_TILES * RL_STAMP_PHASES + RL_STAMP_WORDS * blockIdx.x + 3] -= __builtin_amdgcn_s_memrealtime();
                 while (__any(pending)) {
                     if (pending) {
                         // the D stores land in any order: take all of them every time and check each (one round trip through
@@ -1000,6 +1008,8 @@ __global__ __launch_bounds__(64, RL_WAVES) void iir_rail_kernel(const IirRailArg
                     }
                     if (__any(pending)) __builtin_amdgcn_s_sleep(2);
                 }
+                if (A.stamps && t0 == 0 && blockIdx.x < RL_STAMP_ALLWAVES)
+                    A.stamps[(size_t)RL_STAMP_WAVES * RL_STAMP_TILES * RL_STAMP_PHASES + RL_STAMP_WORDS * blockIdx.x + 3] += __builtin_amdgcn_s_memrealtime();
                 RL_STAMP(5);
                 if (H <= RL_HORNER_MAX) {
                     // cv = a_0 + Q (a_1 + Q (a_2 + ...)), the pair's vector broadcast by one shuffle per word
@@ -1097,12 +1107,13 @@ __global__ __launch_bounds__(64, RL_WAVES) void iir_rail_kernel(const IirRailArg
         T = A.dynamic ? rail_tile_of(cls, NC, (unsigned)__builtin_amdgcn_readfirstlane((int)tkn), total) : T + NW;
     }
     if (A.stamps && t0 == 0 && blockIdx.x < RL_STAMP_ALLWAVES) {
-        A.stamps[(size_t)RL_STAMP_WAVES * RL_STAMP_TILES * RL_STAMP_PHASES + 3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+        A.stamps[(size_t)RL_STAMP_WAVES * RL_STAMP_TILES * RL_STAMP_PHASES + RL_STAMP_WORDS * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
         // steps done | HW_ID (wave, SIMD, CU, SH, SE: where the wave ran) << 16 | XCC_ID << 48   (tools/iir_wave_balance.py)
         const unsigned hw = __builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (0 << 6) | (31 << 11));
         const unsigned xcc = __builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | (31 << 11));
-        A.stamps[(size_t)RL_STAMP_WAVES * RL_STAMP_TILES * RL_STAMP_PHASES + 3 * blockIdx.x + 2] =
+        A.stamps[(size_t)RL_STAMP_WAVES * RL_STAMP_TILES * RL_STAMP_PHASES + RL_STAMP_WORDS * blockIdx.x + 2] =
             (unsigned long long)(it + 1) | ((unsigned long long)hw << 16) | ((unsigned long long)(xcc & 0xF) << 48);
+
     }
     // the last wave out puts the counters back for the next launch
     if (t0 == 0) {
@@ -1390,8 +1401,8 @@ extern "C" clhip_iir *clhip_iir_create(const double *h_sos, int n_stages, int n_
     f->dynamic = 1;
     f->force_scan = getenv("CLHIP_IIR_ONEPASS") && atoi(getenv("CLHIP_IIR_ONEPASS")) == 0;   // A/B: the four-kernel scan for everything
     if (getenv("CLHIP_IIR_STAMPS") && atoi(getenv("CLHIP_IIR_STAMPS"))) {
-        f->d_stamps = (unsigned long long *)clhip_malloc(sizeof(unsigned long long) * (RL_STAMP_WAVES * RL_STAMP_TILES * RL_STAMP_PHASES + 3 * RL_STAMP_ALLWAVES));
-        if (f->d_stamps) (void)hipMemset(f->d_stamps, 0, sizeof(unsigned long long) * (RL_STAMP_WAVES * RL_STAMP_TILES * RL_STAMP_PHASES + 3 * RL_STAMP_ALLWAVES));
+        f->d_stamps = (unsigned long long *)clhip_malloc(sizeof(unsigned long long) * (RL_STAMP_WAVES * RL_STAMP_TILES * RL_STAMP_PHASES + RL_STAMP_WORDS * RL_STAMP_ALLWAVES));
+        if (f->d_stamps) (void)hipMemset(f->d_stamps, 0, sizeof(unsigned long long) * (RL_STAMP_WAVES * RL_STAMP_TILES * RL_STAMP_PHASES + RL_STAMP_WORDS * RL_STAMP_ALLWAVES));
     }
     return f;
 }
@@ -1402,7 +1413,7 @@ extern "C" clhip_iir *clhip_iir_create(const double *h_sos, int n_stages, int n_
 extern "C" size_t clhip_iir_debug_stamps(clhip_iir *f, unsigned long long *h_out)
 {
     if (!f || !f->d_stamps) return 0;
-    const size_t nw = (size_t)RL_STAMP_WAVES * RL_STAMP_TILES * RL_STAMP_PHASES + 3 * RL_STAMP_ALLWAVES;
+    const size_t nw = (size_t)RL_STAMP_WAVES * RL_STAMP_TILES * RL_STAMP_PHASES + RL_STAMP_WORDS * RL_STAMP_ALLWAVES;
     if (f->last_valid) (void)hipStreamSynchronize(f->last_stream);
     if (h_out && hipMemcpy(h_out, f->d_stamps, sizeof(unsigned long long) * nw, hipMemcpyDeviceToHost) != hipSuccess) return 0;
     return nw;

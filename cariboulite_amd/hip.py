@@ -333,13 +333,14 @@ class IIR:
         return bool(lib().clhip_iir_on_scan_path(self.h))
 
     def debug_stamps(self):
-        """([64 waves][16 tiles][12 phases] stamps, [8192 waves][start, end, tiles]) of the last launch (CLHIP_IIR_STAMPS=1), or None"""
+        """([64 waves][16 tiles][12 phases] stamps, [8192 waves][start, end, tiles | HW_ID << 16 | XCC_ID << 48, ticks spent polling,
+        first chunk | class << 32]) of the last launch (CLHIP_IIR_STAMPS=1), or None"""
         n = lib().clhip_iir_debug_stamps(self.h, None)
         if not n:
             return None
         out = np.zeros(n, dtype=np.uint64)
         lib().clhip_iir_debug_stamps(self.h, out.ctypes.data)
-        return out[:64 * 16 * 12].reshape(64, 16, 12), out[64 * 16 * 12:].reshape(-1, 3)
+        return out[:64 * 16 * 12].reshape(64, 16, 12), out[64 * 16 * 12:].reshape(-1, 5)
 
     @property
     def state(self):
