@@ -8,7 +8,7 @@
  * that cannot take the batched route takes its own device's single-stream route, here, inside the call), while the
  * streams that are in sync -- the normal case -- share launches and cross PCIe as a pipeline:
  *
- *     sub-batch b (SUB streams):  FIFO bytes --copy engine--> d_in rows        stream s_in,  event in[b]
+ *     sub-batch b (SUB streams):  FIFO bytes --copy engine--> d_in rows        streams s_in[row mod K], events in[b][k]
  *                                 one launch over the rows (fused pipe / unpack) stream s_k,   event k[b]
  *                                 d_out rows --copy engine--> pinned mirror      stream s_out, event out[b]
  *                                 mirror rows --memcpy pool--> the clients' (pageable) buffers
@@ -62,7 +62,11 @@ struct cl_group {
     int n_lanes; lane_t *lane;
     int sub;                              /* streams per sub-batch */
     int sink_mapped;                      /* kwarg SINK: "mapped" (default) = the sub-batch's kernel stores into the mapped pinned mirror itself; "copy" = device buffer + copy engine */
-    void *s_in, *s_k, *s_out;
+#define GRP_MAX_IN 8
+    void *s_in[GRP_MAX_IN], *s_k, *s_out; /* ingest streams taken in turn by the members' copies: a copy's fixed cost (~10 us between two copies of one
+                                           * stream, rocprofv3 trace: profiles/r04/group_call_timeline_cs16.txt) overlaps the transfer of its neighbour's */
+    int n_in;                             /* kwarg INGEST_STREAMS: 1 .. 8 (default 2) */
+    int ev_per;                           /* events per sub-batch: n_in (in) + 1 (launched) + 1 (out) */
     void **ev; size_t n_ev;               /* 3 per sub-batch */
     copy_pool pool;
     uint8_t **reg_base; size_t *reg_len; size_t n_reg;   /* page ranges of client buffers registered with the GPU (cl_group_register_buffers), merged where they touch */
@@ -210,14 +214,15 @@ void cl_group_unmake(cl_group *g)
 {
     if (!g) return;
     clhip_set_device(g->device);
-    if (g->s_in) clhip_stream_sync(g->s_in);
+    for (int k = 0; k < GRP_MAX_IN; k++) if (g->s_in[k]) clhip_stream_sync(g->s_in[k]);
     if (g->s_k) clhip_stream_sync(g->s_k);
     if (g->s_out) clhip_stream_sync(g->s_out);
     pool_stop(&g->pool);
     cl_group_unregister_buffers(g);
     for (int i = 0; i < g->n_lanes; i++) lane_free(&g->lane[i]);
     for (size_t i = 0; i < g->n_ev; i++) clhip_event_destroy(g->ev[i]);
-    clhip_stream_destroy(g->s_in); clhip_stream_destroy(g->s_k); clhip_stream_destroy(g->s_out);
+    for (int k = 0; k < GRP_MAX_IN; k++) clhip_stream_destroy(g->s_in[k]);
+    clhip_stream_destroy(g->s_k); clhip_stream_destroy(g->s_out);
     free(g->ev); free(g->lane); free(g->dev); free(g->lane_of); free(g->row_of);
     free(g->reg_base); free(g->reg_len); free(g->has_reg);
     free(g);
@@ -253,9 +258,12 @@ cl_group *cl_group_make(cl_device *const *devs, size_t n, const char *const *key
     memcpy(g->dev, devs, n * sizeof *g->dev);
     const char *sub = kwget(keys, vals, n_kwargs, "SUBBATCH"), *ct = kwget(keys, vals, n_kwargs, "COPY_THREADS");
     g->sub = sub && atoi(sub) > 0 ? atoi(sub) : 4;     /* profiles/r04/group_sweep_*.txt: 2 / 4 / 8 / 16 -> 3275 / 3400 / 3100 / 2700 Msamples/s (FIR64 + 3/2, 32 streams) */
+    const char *is = kwget(keys, vals, n_kwargs, "INGEST_STREAMS");
+    g->n_in = is && atoi(is) >= 1 && atoi(is) <= GRP_MAX_IN ? atoi(is) : 2;     /* tools/group_ab.py, medians of 9 interleaved reps: CS16 4989 / 6508 / 5443 Msamples/s at 1 / 2 / 4, FIR64 + 3/2 3116 / 3131 / 2854 */
+    g->ev_per = g->n_in + 2;
     const char *sk = kwget(keys, vals, n_kwargs, "SINK");
     g->sink_mapped = !(sk && !strcmp(sk, "copy"));
-    int threads = ct ? atoi(ct) : 4;
+    int threads = ct ? atoi(ct) : 2;                     /* tools/group_ab.py (interleaved medians, FIR64 + 3/2 x 32): 0 / 1 / 2 / 3 / 4 / 8 threads -> 2099 / 2556 / 3158 / 3034 / 2925 / 2783 Msamples/s */
     if (threads < 0) threads = 0;
     if (threads > 16) threads = 16;
     /* lanes: members of one channel type with one stream configuration, in the caller's order */
@@ -294,7 +302,8 @@ cl_group *cl_group_make(cl_device *const *devs, size_t n, const char *const *key
             l->elem_bytes = fmt_bytes(l->format);
             l->out_stride = l->in_stride / 4;            /* clhip_smi_unpack: sample k of chunk c lands in slot c * stride / 4 + k */
         }
-        const size_t in_bytes = (size_t)l->n * l->in_stride + 256, out_bytes = (size_t)l->n * l->out_stride * l->elem_bytes + 256;
+        const size_t out_bytes = (size_t)l->n * l->out_stride * l->elem_bytes + 256;
+        const size_t in_bytes = (size_t)l->n * l->in_stride + 256;
         l->d_in[0] = (uint8_t *)clhip_malloc(in_bytes); l->d_in[1] = (uint8_t *)clhip_malloc(in_bytes);
         l->d_out = (uint8_t *)clhip_malloc(out_bytes); l->h_out = (uint8_t *)clhip_host_alloc(out_bytes);
         l->h_offs = (int32_t *)clhip_host_alloc(sizeof(int32_t) * (size_t)l->n + 64);
@@ -310,10 +319,12 @@ cl_group *cl_group_make(cl_device *const *devs, size_t n, const char *const *key
         }
         n_sub += ((size_t)l->n + (size_t)g->sub - 1) / (size_t)g->sub;
     }
-    g->s_in = clhip_stream_create(); g->s_k = clhip_stream_create(); g->s_out = clhip_stream_create();
-    g->n_ev = 3 * n_sub;
+    for (int k = 0; k < g->n_in; k++) g->s_in[k] = clhip_stream_create();
+    g->s_k = clhip_stream_create(); g->s_out = clhip_stream_create();
+    g->n_ev = (size_t)g->ev_per * n_sub;
     g->ev = (void **)calloc(g->n_ev, sizeof(void *));
-    int bad = !g->s_in || !g->s_k || !g->s_out || !g->ev;
+    int bad = !g->s_k || !g->s_out || !g->ev;
+    for (int k = 0; k < g->n_in; k++) bad |= !g->s_in[k];
     for (size_t i = 0; !bad && i < g->n_ev; i++) bad = !(g->ev[i] = clhip_event_create());
     if (bad || pool_start(&g->pool, threads, 16 * n + 64)) { cl_seterr(g_make_err, sizeof g_make_err, "cl_group_make: streams / events / threads"); cl_group_unmake(g); return NULL; }
     return g;
@@ -383,7 +394,7 @@ static int registered(const cl_group *g, int m, const void *p, size_t bytes)
  * bytes are in pinned host memory, so the host knows before the device has looked); they are staged and their copy to the
  * lane's row is queued while they cannot move.  Everything else -- short, ragged or slipped reads, bytes given back earlier,
  * reader threads, the IIR, debug modes -- is the single-stream route's business. */
-static int try_stage(cl_group *g, lane_t *l, int row, size_t want)
+static int try_stage(cl_group *g, lane_t *l, int row, size_t want, void *s_in)
 {
     cl_device *dev = g->dev[l->member[row]];
     cl_stream *st = dev->stream;
@@ -396,10 +407,10 @@ static int try_stage(cl_group *g, lane_t *l, int row, size_t want)
     int ok = 0;
     pthread_mutex_lock(&smi->fifo_mu);
     if (!cl_fifo_front_len(&smi->rx) && smi->rx.len >= want) {
-        smi->rx.dma_stream[1] = g->s_in;                       /* a feeder that has to move the buffer waits for this copy first */
+        smi->rx.dma_stream[1] = s_in;                          /* a feeder that has to move the buffer waits for this copy first */
         const size_t got = cl_fifo_stage(&smi->rx, want, &src);
         if (got == want && cl_smi_head_in_sync(src, got) &&
-            clhip_memcpy_h2d(l->d_in[l->cur_in] + (size_t)row * l->in_stride, src, got, g->s_in) == 0) ok = 1;
+            clhip_memcpy_h2d(l->d_in[l->cur_in] + (size_t)row * l->in_stride, src, got, s_in) == 0) ok = 1;
         else if (got) cl_fifo_unstage(&smi->rx, got);
     }
     pthread_mutex_unlock(&smi->fifo_mu);
@@ -485,16 +496,19 @@ int cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems, int *r
         if (l->pipe && clhip_rx_pipe_epoch_begin(l->pipe)) { hard = 1; break; }
         for (int a = 0; a < l->n && !hard; a += g->sub, b++) {
             const int e = a + g->sub < l->n ? a + g->sub : l->n;
-            void *ev_in = g->ev[3 * b], *ev_k = g->ev[3 * b + 1], *ev_out = g->ev[3 * b + 2];
+            void **ev_in = g->ev + (size_t)g->ev_per * b, *ev_k = ev_in[g->n_in], *ev_out = ev_in[g->n_in + 1];
+            unsigned used = 0;                                 /* ingest streams this sub-batch's copies were queued on */
             int any = 0;
             for (int r = a; r < e; r++) {
-                l->fast[r] = (uint8_t)try_stage(g, l, r, want);
+                l->fast[r] = (uint8_t)try_stage(g, l, r, want, g->s_in[r % g->n_in]);
+                if (l->fast[r]) used |= 1u << (r % g->n_in);
                 l->len[r] = l->fast[r] ? want : 0;
                 l->got[r] = 0;
                 any |= l->fast[r];
             }
             if (!any) { if (clhip_event_record(ev_out, g->s_out)) hard = 1; continue; }
-            hard = clhip_event_record(ev_in, g->s_in) || clhip_stream_wait_event(g->s_k, ev_in);
+            for (int k = 0; k < g->n_in && !hard; k++)
+                if (used >> k & 1) hard = clhip_event_record(ev_in[k], g->s_in[k]) || clhip_stream_wait_event(g->s_k, ev_in[k]);
             uint8_t *in = l->d_in[l->cur_in];
             /* where the sub-batch's launch stores: the mapped pinned mirror itself (its stores cross PCIe as the kernel produces them --
              * no second hop, no copy-engine call: tools/microbench/pcie_duplex.hip) unless one of its rows has a registered client
@@ -552,13 +566,13 @@ int cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems, int *r
         lane_t *l = &g->lane[k];
         for (int a = 0; a < l->n; a += g->sub, b++) {
             const int e = a + g->sub < l->n ? a + g->sub : l->n;
-            const int arrived = b < n_queued && !hard && clhip_event_sync(g->ev[3 * b + 2]) == 0;
+            const int arrived = b < n_queued && !hard && clhip_event_sync(g->ev[(size_t)g->ev_per * b + g->n_in + 1]) == 0;
             for (int r = a; r < e; r++) {
                 if (!l->fast[r]) continue;
                 const int m = l->member[r];
                 cl_device *dev = g->dev[m];
                 if (!arrived) {                                    /* a runtime error: nothing is delivered, nothing is consumed */
-                    clhip_stream_sync(g->s_in);
+                    for (int k = 0; k < g->n_in; k++) clhip_stream_sync(g->s_in[k]);
                     pthread_mutex_lock(&dev->smi->fifo_mu);
                     cl_fifo_unstage(&dev->smi->rx, l->len[r]);
                     pthread_mutex_unlock(&dev->smi->fifo_mu);
@@ -594,7 +608,8 @@ int cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems, int *r
     }
     pool_drain(&g->pool);
     if (hard) {
-        clhip_stream_sync(g->s_in); clhip_stream_sync(g->s_k); clhip_stream_sync(g->s_out);
+        for (int k = 0; k < g->n_in; k++) clhip_stream_sync(g->s_in[k]);
+        clhip_stream_sync(g->s_k); clhip_stream_sync(g->s_out);
         if (!g->err[0]) cl_seterr(g->err, sizeof g->err, "cl_group_readStream: %s", clhip_last_error());
         g->stats.errors++;
         return -1;

@@ -578,8 +578,9 @@ void   cl_stream_set_iir_poll_bound(cl_stream *stream, int polls);
  * Make the group AFTER cl_setupStream of every member (RX); members are grouped by channel type and stream configuration
  * (format, FIR / RESAMP / DEMOD kwargs); a group with extension stages owns their state (one n-stream pipe per
  * configuration), so its members are read through the group from then on.  kwargs: SUBBATCH=<streams per launch> (4),
- * COPY_THREADS=<n> (4; 0 = the caller copies), SINK=copy (the sub-batch's outputs leave through
- * a device buffer and the copy engine instead of being stored into the mapped pinned mirror by the kernel itself).  Returns the number of streams that delivered (> 0 elements), or -1 on a
+ * COPY_THREADS=<n> (2; 0 = the caller copies), SINK=copy (the sub-batch's outputs leave through
+ * a device buffer and the copy engine instead of being stored into the mapped pinned mirror by the kernel itself),
+ * INGEST_STREAMS=<1 .. 8> (HIP streams the members' copies in take turns on; 2).  Returns the number of streams that delivered (> 0 elements), or -1 on a
  * runtime error (cl_group_last_error; NULL group = the last cl_group_make failure). */
 typedef struct cl_group cl_group;
 typedef struct {

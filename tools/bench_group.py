@@ -68,7 +68,7 @@ def run_case(name, a):
         bufs = [np.zeros(shape, dt) for _ in range(n)]
         grp = None
         if mode != "one_by_one":
-            grp = S.Group(devs, {"SUBBATCH": str(a.sub), "COPY_THREADS": str(a.threads), "SINK": a.sink})
+            grp = S.Group(devs, {"SUBBATCH": str(a.sub), "COPY_THREADS": str(a.threads), "SINK": a.sink, "INGEST_STREAMS": str(a.ingest)})
             if mode == "registered":
                 grp.registerBuffers(bufs)
         best, got_total = None, 0
@@ -113,8 +113,9 @@ def main():
     ap.add_argument("--calls", type=int, default=12)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--sub", type=int, default=4)
-    ap.add_argument("--threads", type=int, default=4)
+    ap.add_argument("--threads", type=int, default=2)
     ap.add_argument("--sink", default="mapped", choices=["mapped", "copy"])
+    ap.add_argument("--ingest", type=int, default=2, help="ingest HIP streams (1 .. 8)")
     ap.add_argument("--cases", default="cf32_fir64_rs_3_2,cs16,cf32")
     ap.add_argument("--modes", default="default,registered,one_by_one")
     ap.add_argument("--only", default=None, help="(internal) one case in this process")
@@ -123,7 +124,7 @@ def main():
         print(json.dumps({a.only: run_case(a.only, a)}))
         return 0
     # one fresh process per case: what a call costs must not depend on what the process registered or freed before
-    out = {"streams": a.streams, "calls": a.calls, "subbatch": a.sub, "copy_threads": a.threads, "sink": a.sink,
+    out = {"streams": a.streams, "calls": a.calls, "subbatch": a.sub, "copy_threads": a.threads, "sink": a.sink, "ingest_streams": a.ingest,
            "runtime_env": {"GPU_PINNED_MIN_XFER_SIZE": os.environ.get("GPU_PINNED_MIN_XFER_SIZE", "(unset: the runtime's default)")}}
     for c in a.cases.split(","):
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--only", c] + [x for x in sys.argv[1:]], capture_output=True, text=True)
