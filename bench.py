@@ -169,7 +169,8 @@ def bench_pcie(a, world, rank, dev, dist, red_dev, arch, taps):
         d = S.Device(dict(driver="Cariboulite", channel="S1G" if i % 2 == 0 else "HiF", gpu=str(dev.index or 0)))
         d.activateStream(d.setupStream(S.SOAPY_SDR_RX, S.SOAPY_SDR_CF32, args={"FIR": "64:1000000", "RESAMP": "3/2"}))
         devs.append(d)
-    grp = S.Group(devs)
+    # (every step's bytes are queued beforehand: room for all of them in the group's pinned slab, so that the members' FIFOs stay in it)
+    grp = S.Group(devs, {"SLAB_MB": str(((K + W) * NB >> 20) + 1)})
     bufs = [np.zeros((MTU * 3 // 2 + 8, 2), np.float32) for _ in range(n)]
     words = [synth.smi_stream_bytes((K + W) * MTU, i % 2, stream=1000 * rank + i)[0] for i in range(min(n, 4))]
     for i, d in enumerate(devs):
@@ -195,7 +196,7 @@ def bench_pcie(a, world, rank, dev, dist, red_dev, arch, taps):
                "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"config 2's stages at the Soapy boundary: {n} streams per GPU (S1G + HiF), one MTU = {MTU} samples per stream and step "
                                       f"through cl_group_readStream, host SMI bytes in (pinned FIFOs), CF32 samples out into pageable buffers",
-                          "streams_per_gpu": n, "arch": arch, "group": {k: st[k] for k in ("batched_reads", "single_reads", "launches", "errors")},
+                          "streams_per_gpu": n, "arch": arch, "group": {k: st[k] for k in ("batched_reads", "single_reads", "launches", "copies_2d", "errors")},
                           "parallelism": f"{world} independent group(s), no data-path collective"}}
         exe = os.path.join(ROOT, "tools", "microbench", "pcie_duplex")
         sh = None

@@ -52,6 +52,7 @@ typedef struct {
     int32_t *h_offs; int32_t *d_offs;     /* ROUTE_PLAIN: per row 0 (unpack) / -1 (skip), mapped pinned */
     uint8_t *m_out;                       /* the device's address of h_out (mapped pinned): kernels may store into the mirror themselves */
     uint8_t *fast; size_t *len; long *got;   /* per call */
+    uint8_t **src;                        /* per call and row: where the staged batch lies in the member's pinned FIFO */
     cl_dsp_cfg dsp;
 } lane_t;
 
@@ -71,6 +72,8 @@ struct cl_group {
     copy_pool pool;
     uint8_t **reg_base; size_t *reg_len; size_t n_reg;   /* page ranges of client buffers registered with the GPU (cl_group_register_buffers), merged where they touch */
     uint8_t *has_reg;                                     /* per member: it has a registered buffer */
+    uint8_t *slab; size_t slab_slice;     /* ONE pinned allocation the members' byte FIFOs live in, a slice each, lane after lane in row order: batches
+                                           * of neighbouring rows that lie at the same offset of their slices are `slab_slice` apart -- one 2-D copy */
     cl_group_stats stats;
     char err[256];
 };
@@ -206,7 +209,7 @@ static void lane_free(lane_t *l)
     if (l->pipe) clhip_rx_pipe_destroy(l->pipe);
     clhip_free(l->d_in[0]); clhip_free(l->d_in[1]); clhip_free(l->d_out);
     clhip_host_free(l->h_out); clhip_host_free(l->h_offs);
-    free(l->member); free(l->prev_len); free(l->fast); free(l->len); free(l->got);
+    free(l->member); free(l->prev_len); free(l->fast); free(l->len); free(l->got); free(l->src);
     memset(l, 0, sizeof *l);
 }
 
@@ -219,6 +222,15 @@ void cl_group_unmake(cl_group *g)
     if (g->s_out) clhip_stream_sync(g->s_out);
     pool_stop(&g->pool);
     cl_group_unregister_buffers(g);
+    if (g->slab) {                                             /* the members' FIFOs move out before the slab goes */
+        for (size_t i = 0; i < g->n; i++) {
+            cl_smi *smi = g->dev[i]->smi;
+            pthread_mutex_lock(&smi->fifo_mu);
+            if (smi->rx.external && smi->rx.data >= g->slab && smi->rx.data < g->slab + g->n * g->slab_slice) cl_fifo_leave(&smi->rx);
+            pthread_mutex_unlock(&smi->fifo_mu);
+        }
+        clhip_host_free(g->slab);
+    }
     for (int i = 0; i < g->n_lanes; i++) lane_free(&g->lane[i]);
     for (size_t i = 0; i < g->n_ev; i++) clhip_event_destroy(g->ev[i]);
     for (int k = 0; k < GRP_MAX_IN; k++) clhip_stream_destroy(g->s_in[k]);
@@ -312,7 +324,8 @@ cl_group *cl_group_make(cl_device *const *devs, size_t n, const char *const *key
         l->prev_len = (size_t *)calloc((size_t)l->n, sizeof(size_t));
         l->fast = (uint8_t *)calloc((size_t)l->n, 1); l->len = (size_t *)calloc((size_t)l->n, sizeof(size_t));
         l->got = (long *)calloc((size_t)l->n, sizeof(long));
-        if (!l->d_in[0] || !l->d_in[1] || !l->d_out || !l->h_out || !l->h_offs || !l->d_offs || !l->m_out || !l->prev_len || !l->fast || !l->len || !l->got) {
+        l->src = (uint8_t **)calloc((size_t)l->n, sizeof(uint8_t *));
+        if (!l->d_in[0] || !l->d_in[1] || !l->d_out || !l->h_out || !l->h_offs || !l->d_offs || !l->m_out || !l->prev_len || !l->fast || !l->len || !l->got || !l->src) {
             cl_seterr(g_make_err, sizeof g_make_err, "cl_group_make: buffers for %d streams could not be allocated", l->n);
             cl_group_unmake(g);
             return NULL;
@@ -321,6 +334,23 @@ cl_group *cl_group_make(cl_device *const *devs, size_t n, const char *const *key
     }
     for (int k = 0; k < g->n_in; k++) g->s_in[k] = clhip_stream_create();
     g->s_k = clhip_stream_create(); g->s_out = clhip_stream_create();
+    {
+        /* kwarg SLAB_MB: MiB of pinned FIFO room per member (default 8 = sixteen native batches; 0 = the members keep their own
+         * buffers and every batch comes in by a copy of its own) */
+        const char *sm = kwget(keys, vals, n_kwargs, "SLAB_MB");
+        const size_t mb = sm ? (size_t)atol(sm) : 8;
+        g->slab_slice = mb << 20;
+        g->slab = mb ? (uint8_t *)clhip_host_alloc(g->n * g->slab_slice) : NULL;
+        size_t slot = 0;
+        for (int k = 0; g->slab && k < g->n_lanes; k++)
+            for (int r = 0; r < g->lane[k].n; r++, slot++) {
+                cl_smi *smi = g->dev[g->lane[k].member[r]]->smi;
+                cl_smi_readahead_cancel(smi);
+                pthread_mutex_lock(&smi->fifo_mu);
+                if (!cl_fifo_front_len(&smi->rx)) cl_fifo_adopt(&smi->rx, g->slab + slot * g->slab_slice, g->slab_slice);   /* (too full: stays where it is) */
+                pthread_mutex_unlock(&smi->fifo_mu);
+            }
+    }
     g->n_ev = (size_t)g->ev_per * n_sub;
     g->ev = (void **)calloc(g->n_ev, sizeof(void *));
     int bad = !g->s_k || !g->s_out || !g->ev;
@@ -399,22 +429,49 @@ static int try_stage(cl_group *g, lane_t *l, int row, size_t want, void *s_in)
     cl_device *dev = g->dev[l->member[row]];
     cl_stream *st = dev->stream;
     cl_smi *smi = dev->smi;
+    l->src[row] = NULL;
     if (st->use_async || st->filter_type != CL_DIGFILT_NONE || smi->debug_mode != CL_SMI_DEBUG_NONE || st->native_dir != CL_SOAPY_SDR_RX) return 0;
     if (st->format != l->format || !want || (want & 15) || want > smi->native_batch_len || (smi->max_read && smi->max_read < want)) return 0;
     if (l->route == ROUTE_PIPE && clhip_rx_pipe_stream_total(l->pipe, row) % (2ull * (unsigned long long)l->down)) return 0;   /* (off polyphase phase 0: generic kernels, one by one) */
     cl_smi_readahead_cancel(smi);                              /* what a single-stream call staged ahead is pending again */
     uint8_t *src = NULL;
-    int ok = 0;
     pthread_mutex_lock(&smi->fifo_mu);
     if (!cl_fifo_front_len(&smi->rx) && smi->rx.len >= want) {
         smi->rx.dma_stream[1] = s_in;                          /* a feeder that has to move the buffer waits for this copy first */
         const size_t got = cl_fifo_stage(&smi->rx, want, &src);
-        if (got == want && cl_smi_head_in_sync(src, got) &&
-            clhip_memcpy_h2d(l->d_in[l->cur_in] + (size_t)row * l->in_stride, src, got, s_in) == 0) ok = 1;
-        else if (got) cl_fifo_unstage(&smi->rx, got);
+        if (got == want && cl_smi_head_in_sync(src, got)) {
+            l->src[row] = src;
+            return 1;                                          /* NOTE: with the member's FIFO lock HELD -- the bytes must not move before the
+                                                                * copy that reads them is queued (copies_queue releases it) */
+        }
+        if (got) cl_fifo_unstage(&smi->rx, got);
     }
     pthread_mutex_unlock(&smi->fifo_mu);
-    return ok;
+    return 0;
+}
+
+/* Queue the copies in of the staged rows [a, e) and let their FIFOs go again.  Neighbouring rows whose batches lie one slab slice
+ * apart (members that are fed and read in step, the normal case) travel as ONE 2-D copy; any other row by a copy of its own.  A row
+ * whose copy cannot be queued is unstaged and leaves the batched route.  Returns 0, or -1 on a runtime error. */
+static int copies_queue(cl_group *g, lane_t *l, int a, int e, size_t want, void *s_in)
+{
+    int rc = 0, r = a;
+    while (r < e) {
+        if (!l->fast[r]) { r++; continue; }
+        int r1 = r + 1;
+        while (g->slab && r1 < e && l->fast[r1] && l->src[r1] == l->src[r] + (size_t)(r1 - r) * g->slab_slice) r1++;
+        uint8_t *dst = l->d_in[l->cur_in] + (size_t)r * l->in_stride;
+        const int bad = r1 - r > 1 ? clhip_memcpy2d_h2d(dst, l->in_stride, l->src[r], g->slab_slice, want, (size_t)(r1 - r), s_in)
+                                   : clhip_memcpy_h2d(dst, l->src[r], want, s_in);
+        if (r1 - r > 1) g->stats.copies_2d++;
+        for (int q = r; q < r1; q++) {
+            cl_smi *smi = g->dev[l->member[q]]->smi;
+            if (bad) { cl_fifo_unstage(&smi->rx, want); l->fast[q] = 0; rc = -1; }
+            pthread_mutex_unlock(&smi->fifo_mu);
+        }
+        r = r1;
+    }
+    return rc;
 }
 
 static void confirm_staged(cl_smi *smi, size_t n)
@@ -499,13 +556,14 @@ int cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems, int *r
             void **ev_in = g->ev + (size_t)g->ev_per * b, *ev_k = ev_in[g->n_in], *ev_out = ev_in[g->n_in + 1];
             unsigned used = 0;                                 /* ingest streams this sub-batch's copies were queued on */
             int any = 0;
+            void *s_in = g->s_in[b % (size_t)g->n_in];          /* the sub-batches take turns on the ingest streams */
             for (int r = a; r < e; r++) {
-                l->fast[r] = (uint8_t)try_stage(g, l, r, want, g->s_in[r % g->n_in]);
-                if (l->fast[r]) used |= 1u << (r % g->n_in);
-                l->len[r] = l->fast[r] ? want : 0;
+                l->fast[r] = (uint8_t)try_stage(g, l, r, want, s_in);
                 l->got[r] = 0;
-                any |= l->fast[r];
             }
+            if (copies_queue(g, l, a, e, want, s_in)) hard = 1;
+            for (int r = a; r < e; r++) { l->len[r] = l->fast[r] ? want : 0; any |= l->fast[r]; }
+            if (any) used |= 1u << (b % (size_t)g->n_in);
             if (!any) { if (clhip_event_record(ev_out, g->s_out)) hard = 1; continue; }
             for (int k = 0; k < g->n_in && !hard; k++)
                 if (used >> k & 1) hard = clhip_event_record(ev_in[k], g->s_in[k]) || clhip_stream_wait_event(g->s_k, ev_in[k]);

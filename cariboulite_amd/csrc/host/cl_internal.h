@@ -28,12 +28,16 @@ typedef struct {
     uint8_t *data;
     size_t cap, keep, head, len;
     int pinned;                  /* hipHostMalloc'ed */
+    int external;                /* `data` is a slice of memory somebody else owns (a stream group's pinned slab): never freed here; a FIFO that
+                                  * outgrows it moves into a buffer of its own */
     void *dma_stream[2];         /* streams whose copies read FIFO memory in place (waited for before the buffer moves) */
     uint8_t *front;              /* front stash: [front_head, front_cap) are pending bytes OLDER than everything in `data` */
     size_t front_cap, front_head;
 } cl_fifo;
 
 void   cl_fifo_free(cl_fifo *f);
+int    cl_fifo_adopt(cl_fifo *f, uint8_t *slice, size_t cap);   /* move the (pinned) FIFO's bytes into `slice` and live there from now on (0 / -1: does not fit) */
+int    cl_fifo_leave(cl_fifo *f);                               /* the reverse: into a buffer of its own (0 / -1) */
 uint8_t *cl_fifo_reserve(cl_fifo *f, size_t n);              /* room for n more bytes at the tail (may move the buffer) */
 void   cl_fifo_commit(cl_fifo *f, size_t n);
 int    cl_fifo_push(cl_fifo *f, const uint8_t *src, size_t n);

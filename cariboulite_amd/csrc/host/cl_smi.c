@@ -19,6 +19,7 @@ void cl_seterr(char *dst, size_t n, const char *fmt, ...)
 /* ------------------------------------------------------------------ FIFO */
 void cl_fifo_free(cl_fifo *f)
 {
+    if (f->external) f->data = NULL;
     if (f->pinned) clhip_host_free(f->data); else free(f->data);
     free(f->front);
     memset(f, 0, sizeof *f);
@@ -40,7 +41,8 @@ uint8_t *cl_fifo_reserve(cl_fifo *f, size_t n)
             uint8_t *p = f->pinned ? (uint8_t *)clhip_host_alloc(cap) : (uint8_t *)malloc(cap);
             if (!p) return NULL;
             if (live) memcpy(p, f->data + f->keep, live);
-            if (f->pinned) clhip_host_free(f->data); else free(f->data);
+            if (f->external) f->external = 0;                                /* (outgrew the slice it was lent: a buffer of its own from here on) */
+            else if (f->pinned) clhip_host_free(f->data); else free(f->data);
             f->data = p; f->cap = cap;
         }
         f->head -= f->keep; f->keep = 0;
@@ -49,6 +51,36 @@ uint8_t *cl_fifo_reserve(cl_fifo *f, size_t n)
 }
 
 void cl_fifo_commit(cl_fifo *f, size_t n) { f->len += n; }
+
+/* Under the owner's lock, with no reservation open: live bytes (staged-unconfirmed + pending) move to the front of `slice`. */
+int cl_fifo_adopt(cl_fifo *f, uint8_t *slice, size_t cap)
+{
+    const size_t live = f->head - f->keep + f->len;
+    if (!f->pinned || live > cap) return -1;
+    for (int k = 0; k < 2; k++)
+        if (f->dma_stream[k]) clhip_stream_sync(f->dma_stream[k]);
+    if (live) memcpy(slice, f->data + f->keep, live);
+    if (!f->external) clhip_host_free(f->data);
+    f->data = slice; f->cap = cap; f->external = 1;
+    f->head -= f->keep; f->keep = 0;
+    return 0;
+}
+
+int cl_fifo_leave(cl_fifo *f)
+{
+    if (!f->external) return 0;
+    const size_t live = f->head - f->keep + f->len;
+    size_t cap = (size_t)1 << 20;
+    while (cap < live) cap *= 2;
+    for (int k = 0; k < 2; k++)
+        if (f->dma_stream[k]) clhip_stream_sync(f->dma_stream[k]);
+    uint8_t *p = (uint8_t *)clhip_host_alloc(cap);
+    if (!p) return -1;
+    if (live) memcpy(p, f->data + f->keep, live);
+    f->data = p; f->cap = cap; f->external = 0;
+    f->head -= f->keep; f->keep = 0;
+    return 0;
+}
 
 int cl_fifo_push(cl_fifo *f, const uint8_t *src, size_t n)
 {

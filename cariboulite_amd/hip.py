@@ -46,6 +46,7 @@ _SIGS = {
     "clhip_event_record": (C.c_int, [C.c_void_p, C.c_void_p]),
     "clhip_event_elapsed_ms": (C.c_float, [C.c_void_p, C.c_void_p]),
     "clhip_stream_wait_event": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "clhip_memcpy2d_h2d": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]),
     "clhip_event_sync": (C.c_int, [C.c_void_p]),
     "clhip_debug_ops": (C.c_size_t, [C.c_void_p, C.c_size_t]),
     "clhip_debug_ops_dump": (None, [C.c_int]),

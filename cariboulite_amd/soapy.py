@@ -392,10 +392,10 @@ class Group:
         return lib().cl_group_last_error(self.h).decode()
 
     def stats(self):
-        out = (C.c_uint64 * 9)()
+        out = (C.c_uint64 * 10)()
         lib().cl_group_getStats(self.h, out)
-        return dict(zip(("calls", "batched_reads", "single_reads", "direct_reads", "launches", "errors", "last_queue_us", "last_arrive_us",
-                         "last_total_us"), [int(v) for v in out]))
+        return dict(zip(("calls", "batched_reads", "single_reads", "direct_reads", "launches", "errors", "copies_2d", "last_queue_us",
+                         "last_arrive_us", "last_total_us"), [int(v) for v in out]))
 
     def close(self):
         if getattr(self, "h", None) and _lib is not None:

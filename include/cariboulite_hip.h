@@ -100,6 +100,9 @@ void        clhip_host_unregister(void *h_ptr);
 int         clhip_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream);
 int         clhip_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream);
 int         clhip_memcpy_d2d(void *d_dst, const void *d_src, size_t bytes, void *stream);
+/* `height` rows of `width` bytes from page-locked host memory (rows h_pitch apart) to device rows d_pitch apart in ONE copy-engine
+ * operation (what a stream group does with its members' batches when they lie at one stride in its pinned slab); refuses pageable memory */
+int         clhip_memcpy2d_h2d(void *d_dst, size_t d_pitch, const void *h_src, size_t h_pitch, size_t width, size_t height, void *stream);
 /* Diagnostics: the last 256 things this library asked the runtime to do with host memory it does not own -- registrations,
  * releases, copies above one piece (what kind of memory it found) -- so that a GPU page fault on a host address can be set
  * against them.  _ops copies the ring (oldest first), _ops_dump writes it as text with write(2) only (callable from a signal
@@ -580,7 +583,10 @@ void   cl_stream_set_iir_poll_bound(cl_stream *stream, int polls);
  * configuration), so its members are read through the group from then on.  kwargs: SUBBATCH=<streams per launch> (4),
  * COPY_THREADS=<n> (2; 0 = the caller copies), SINK=copy (the sub-batch's outputs leave through
  * a device buffer and the copy engine instead of being stored into the mapped pinned mirror by the kernel itself),
- * INGEST_STREAMS=<1 .. 8> (HIP streams the members' copies in take turns on; 2).  Returns the number of streams that delivered (> 0 elements), or -1 on a
+ * INGEST_STREAMS=<1 .. 8> (HIP streams the sub-batches' copies in take turns on; 2), SLAB_MB=<MiB> (pinned FIFO room per member
+ * in the group's ONE slab, 8: the members' byte FIFOs live there from cl_group_make to cl_group_unmake, a slice each, so that the
+ * batches of members that are fed and read in step lie one stride apart and travel as one 2-D copy per sub-batch; a FIFO that
+ * outgrows its slice moves into a buffer of its own and its batches come in by copies of their own; 0 = no slab).  Returns the number of streams that delivered (> 0 elements), or -1 on a
  * runtime error (cl_group_last_error; NULL group = the last cl_group_make failure). */
 typedef struct cl_group cl_group;
 typedef struct {
@@ -590,6 +596,7 @@ typedef struct {
     uint64_t direct_reads;       /* batched reads the copy engine wrote into a registered client buffer            */
     uint64_t launches;           /* kernel launches of the batched route                                           */
     uint64_t errors;             /* calls that ended with a runtime error                                          */
+    uint64_t copies_2d;          /* copies in that carried several members' batches at once (one slab stride apart) */
     uint64_t last_queue_us;      /* the last call: everything staged and queued after ... us                       */
     uint64_t last_arrive_us;     /*                the last sub-batch had arrived and was handed to the copy threads */
     uint64_t last_total_us;      /*                returned                                                         */
