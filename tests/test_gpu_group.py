@@ -224,3 +224,115 @@ def test_group_make_refuses_what_it_cannot_read(S):
     assert g.readStream([buf], MTU) == (0, [0])           # nothing pending: every member times out like the lone device
     assert g.readStream([buf], 0) == (0, [0])
     g.close(); d0.close(); d1.close()
+
+
+def test_the_groups_slab_members_in_step_out_of_step_outgrown_and_released(S, orc):
+    """The members' byte FIFOs live in the group's ONE pinned slab (a slice each): batches of members fed and read in step lie one
+    stride apart and come in as one 2-D copy per sub-batch; a member that is out of step (it was fed an extra half batch once) comes
+    in by a copy of its own from then on; a FIFO fed more than its slice holds moves into a buffer of its own without losing a byte;
+    and when the group goes the FIFOs move out of the slab with what they hold -- the lone device reads it."""
+    n = 8
+    devs, sts = make_devices(S, n, S.SOAPY_SDR_CS16, None, lambda i: "S1G")
+    grp = S.Group(devs, {"SLAB_MB": "2", "SUBBATCH": "4"})
+    bufs = sentinel_buffers(n, (MTU + 2, 2), np.int16)
+    streams = [np.concatenate([batch_bytes(i, c, 0) for c in range(12)]) for i in range(n)]
+    want = [orc.smi_read(0, streams[i], 12 * MTU, NB)[1] for i in range(n)]
+    pos = [0] * n                      # bytes of each stream fed so far
+    got = [0] * n                      # samples of each stream read so far
+
+    def feed(i, nbytes):
+        devs[i].feedSmiBytes(streams[i][pos[i]: pos[i] + nbytes]); pos[i] += nbytes
+
+    def read_all(expect):
+        delivered, rets = grp.readStream(bufs, MTU)
+        assert rets == expect, (rets, expect)
+        for i, r in enumerate(rets):
+            assert np.array_equal(bufs[i][:r], want[i][got[i]: got[i] + r]), i
+            got[i] += r
+    # in step: two sub-batches of four, each ONE 2-D copy
+    for c in range(2):
+        for i in range(n):
+            feed(i, NB)
+        read_all([MTU] * n)
+    assert grp.stats()["copies_2d"] == 4
+    # member 5 is fed half a batch more: its batches no longer lie on the others' stride
+    for i in range(n):
+        feed(i, NB + (NB // 2 if i == 5 else 0))
+    read_all([MTU] * n)
+    c2d = grp.stats()["copies_2d"]
+    assert c2d == 4 + 2                                    # rows 0-3 as one; 4 | 5 | 6-7: the pair 6-7 still as one
+    for i in range(n):
+        feed(i, NB)
+    read_all([MTU] * n)
+    # member 2 is fed 3 MiB at once: more than its 2 MiB slice holds -> a buffer of its own, nothing lost, still read by the group
+    feed(2, 6 * NB)
+    for i in range(n):
+        if i != 2:
+            feed(i, NB)
+    read_all([MTU] * n)
+    for k in range(2):
+        for i in range(n):
+            if i != 2:
+                feed(i, NB)
+        read_all([MTU] * n)
+    assert grp.stats()["errors"] == 0 and grp.stats()["single_reads"] == 0
+    # the group goes; what the FIFOs hold moves out of the slab with them
+    for i in range(n):
+        if i != 2:
+            feed(i, NB)
+    pend = [d.pendingSmiBytes() for d in devs]
+    grp.close()
+    assert [d.pendingSmiBytes() for d in devs] == pend
+    for i in range(n):
+        r = devs[i].readStream(sts[i], [bufs[i]], MTU).ret
+        assert r == MTU and np.array_equal(bufs[i][:MTU], want[i][got[i]: got[i] + MTU]), i
+    for d in devs:
+        d.close()
+
+
+def test_feeder_threads_race_the_group(S, orc):
+    """One feeder thread per member pushes the next batch the moment its FIFO runs dry while the group reads: a batch is staged under
+    the member's FIFO lock and its copy in is queued before the lock is released, a feeder that has to compact or move a FIFO waits
+    for the ingest stream first -- every stream must come out as the oracle's analysis of the bytes that were fed, in order."""
+    import threading
+    import time
+    n, n_batches = 6, 24
+    devs, sts = make_devices(S, n, S.SOAPY_SDR_CF32, None, lambda i: "S1G" if i % 2 else "HiF")
+    grp = S.Group(devs, {"SLAB_MB": "1", "SUBBATCH": "4"})      # 1 MiB slices: two batches -- compaction and outgrowing happen
+    data = [np.concatenate([batch_bytes(i, c, 0 if i % 2 else 1) for c in range(n_batches)]) for i in range(n)]
+    stop = threading.Event()
+
+    def feeder(i):
+        k = 0
+        while k < n_batches and not stop.is_set():
+            if devs[i].pendingSmiBytes() <= (NB if i % 3 == 0 else 0):      # some keep a batch in reserve: FIFOs at different fill levels
+                devs[i].feedSmiBytes(data[i][k * NB:(k + 1) * NB]); k += 1
+            else:
+                time.sleep(0)
+
+    ths = [threading.Thread(target=feeder, args=(i,)) for i in range(n)]
+    for t in ths:
+        t.start()
+    got = [[] for _ in range(n)]
+    bufs = [np.zeros((MTU, 2), np.float32) for _ in range(n)]
+    try:
+        deadline = time.time() + 120
+        while min(len(g_) for g_ in got) < n_batches and time.time() < deadline:
+            _, rets = grp.readStream(bufs, MTU)
+            for i, r in enumerate(rets):
+                if r > 0:
+                    assert r == MTU
+                    got[i].append(bufs[i].copy())
+    finally:
+        stop.set()
+        for t in ths:
+            t.join(timeout=30)
+    for i in range(n):
+        assert len(got[i]) == n_batches, (i, len(got[i]))
+        ch = 0 if i % 2 else 1
+        want = orc.cs16_to_cf32(orc.smi_read(ch, data[i], n_batches * MTU, NB)[1][: n_batches * MTU])
+        assert np.array_equal(np.concatenate(got[i]), want), i
+    assert grp.stats()["errors"] == 0
+    grp.close()
+    for d in devs:
+        d.close()
