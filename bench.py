@@ -18,7 +18,9 @@ no data-path collective (weak scaling); the only collectives are the timing
 barrier and the max-over-ranks reduction.
 
 --workload c1|c3|c4|c5|iir|tags times the other configs of BASELINE.json (the a6 IIR, the pps tag compaction) through the same contract;
-the default (c2) is the headline metric.
+the default (c2) is the headline metric.  --pcie prints the PCIe-INCLUSIVE companion of the headline line in the same JSON shape
+(host SMI bytes in, host samples out, --pcie-streams Soapy devices per GPU through cl_group_readStream; roofline.bound "pcie"
+against the ceiling measured in the same run): reported beside the headline, never instead of it.
 
 One JSON line on rank 0.  `roofline` prices the fused kernel against HBM
 (16 algorithmic bytes per input sample: 4 read + 12 written); `cpu_baseline`

@@ -372,9 +372,12 @@ typedef struct {
     const int16_t *d_cs16;        /* native int16 samples, complete -- or NULL */
     void *hs;                     /* the HIP stream the stages are queued on */
     int pending;                  /* cl_smi_ra_finish is the epilogue's synchronisation (it carries the read's verdict) */
+    int host_filled;              /* ASYNC, plain CS16: the ring's elements are already on their way to the sink's host side (no device stage follows) */
+    size_t ring_claimed;          /* ASYNC: elements of the ring claimed by this call; the copy out of them is queued on hs, the claim ends
+                                   * (cl_ring_get_end) once hs has been synchronised -- the epilogue's one synchronisation */
 } cl_source;
 
-static int source_acquire(cl_device *dev, cl_stream *st, size_t n, long timeout_us, cl_source *src)
+static int source_acquire(cl_device *dev, cl_stream *st, size_t n, long timeout_us, void *ring_host_dst, cl_source *src)
 {
     cl_smi *smi = dev->smi;
     memset(src, 0, sizeof *src);
@@ -387,10 +390,26 @@ static int source_acquire(cl_device *dev, cl_stream *st, size_t n, long timeout_
         cl_ring_span sp;
         const size_t claimed = cl_ring_get_begin(st->rx_queue, n, (int)timeout_us, &sp);
         if (!claimed) return 0;
-        const int bad = ring_span_copy(st->rx_queue, &sp, st->d_aiq, 0, st->astream) || clhip_stream_sync(st->astream);
-        cl_ring_get_end(st->rx_queue, claimed);
-        if (bad) return 0;
-        src->n = (int)claimed; src->d_cs16 = st->d_aiq;
+        int bad = 0;
+        if (ring_host_dst) {
+            /* no device stage follows (plain CS16): the ring's slots go straight to the sink's host side, no device-to-device hop */
+            uint8_t *base = (uint8_t *)cl_ring_storage(st->rx_queue), *dst = (uint8_t *)ring_host_dst;
+            for (int k = 0; k < 2 && !bad; k++) {
+                if (!sp.len[k]) continue;
+                bad = clhip_memcpy_d2h(dst, base + 4 * sp.pos[k], 4 * sp.len[k], st->astream);
+                dst += 4 * sp.len[k];
+            }
+            src->host_filled = 1;
+        } else {
+            bad = ring_span_copy(st->rx_queue, &sp, st->d_aiq, 0, st->astream);
+            src->d_cs16 = st->d_aiq;
+        }
+        if (bad) {
+            clhip_stream_sync(st->astream);
+            cl_ring_get_end(st->rx_queue, claimed);
+            return 0;
+        }
+        src->n = (int)claimed; src->ring_claimed = claimed;
         return src->n;
     }
     src->hs = smi->stream;
@@ -413,6 +432,15 @@ static int source_acquire(cl_device *dev, cl_stream *st, size_t n, long timeout_
     }
     src->n = ret; src->d_cs16 = smi->d_iq;
     return ret;
+}
+
+/* hs has been synchronised (or is, here): the ring elements an ASYNC call claimed are the reader thread's again */
+static void source_release(cl_stream *st, cl_source *src, int synced)
+{
+    if (!src->ring_claimed) return;
+    if (!synced) clhip_stream_sync(src->hs);
+    cl_ring_get_end(st->rx_queue, src->ring_claimed);
+    src->ring_claimed = 0;
 }
 
 /* ---- SINK: where the LAST device stage of a read stores its results, and how they reach the client's (pageable) buffer ----
@@ -596,28 +624,38 @@ static int read_stream(cl_device *dev, cl_stream *st, void *const *buffs, size_t
     void *out = buffs[0];
     if (st->format != CL_FORMAT_CS16 && numElems > st->mtu_size) numElems = st->mtu_size;   /* :306,328,351; CS16 is not clamped (:282-301) */
     if (!numElems) return 0;
-    cl_source src;
-    if (source_acquire(dev, st, numElems, timeoutUs, &src) <= 0) return 0;
-    const size_t n = (size_t)src.n;
     const int plain_cs16 = st->format == CL_FORMAT_CS16 && !st->rx_pipe && st->filter_type == CL_DIGFILT_NONE;
+    cl_source src;
+    cl_sink sk;
+    int sink_ready = 0;
+    void *ring_dst = NULL;
+    if (plain_cs16 && st->use_async) {                     /* the ring's samples ARE the output: the sink comes first */
+        if (sink_open(st, out, numElems * 4, &sk)) return 0;
+        sink_ready = 1;
+        ring_dst = sk.kind == CL_SINK_CLIENT ? out : (void *)st->h_conv;
+    }
+    if (source_acquire(dev, st, numElems, timeoutUs, ring_dst, &src) <= 0) return 0;
+    const size_t n = (size_t)src.n;
     if (plain_cs16 && !src.d_words && !st->use_async)
         /* no device stage behind the read: exactly the slots the reference writes (caribou_smi.c:344-389) go to the client */
         return cl_smi_copy_out(smi, (cl_sample_complex_int16 *)out, NULL, -1) ? 0 : src.n;
     const size_t ob = st->rx_pipe ? (st->dsp.demod_fm ? 4 : 8) : fmt_bytes(st->format);
     const size_t max_out = (st->rx_pipe ? clhip_rx_pipe_out_count(st->rx_pipe, n) : n) * ob;
-    cl_sink sk;
-    if (sink_open(st, out, max_out, &sk)) { if (src.pending) cl_smi_ra_finish(smi); return 0; }
+    if (!sink_ready && sink_open(st, out, max_out, &sk)) { if (src.pending) cl_smi_ra_finish(smi); source_release(st, &src, 0); return 0; }
     for (int attempt = 0;; attempt++) {
         long got = 0;
-        int bad = stages_queue(dev, st, &src, &sk, &got);
-        if (!bad && plain_cs16 && !src.d_words)            /* (ASYNC: the ring's samples are the output) */
-            bad = clhip_memcpy_d2h(sk.kind == CL_SINK_CLIENT ? out : st->h_conv, src.d_cs16, n * 4, src.hs);
-        else if (!bad) bad = sink_queue(st, &sk, (size_t)(got > 0 ? got : 0) * ob, src.hs);
+        int bad = 0;
+        if (src.host_filled) got = src.n;                  /* (ASYNC, plain CS16: already on its way to the sink's host side) */
+        else {
+            bad = stages_queue(dev, st, &src, &sk, &got);
+            if (!bad) bad = sink_queue(st, &sk, (size_t)(got > 0 ? got : 0) * ob, src.hs);
+        }
         /* the one synchronisation; with it the verdict of the read() whose words the stages took (host-certain: in sync) */
         int fr = src.n;
         if (src.pending) { fr = cl_smi_ra_finish(smi); src.pending = 0; }
         else if (clhip_stream_sync(src.hs)) fr = CL_SMI_ERR_IO;
         if (bad) { clhip_stream_sync(src.hs); fr = CL_SMI_ERR_IO; }
+        source_release(st, &src, 1);
         if (fr == CL_SMI_ERR_IO) printf("reader thread failed to read SMI!\n");    /* :270 */
         if (fr <= 0) return 0;                                                      /* :266-276 */
         if (!filter_overran(dev, st)) {
@@ -640,7 +678,7 @@ int cl_stream_read_native(cl_device *dev, cl_stream *st, size_t n, long timeout_
 {
     cl_smi *smi = dev->smi;
     cl_source src;
-    if (st->use_async) { if (source_acquire(dev, st, n, timeout_us, &src) <= 0) return 0; }
+    if (st->use_async) { if (source_acquire(dev, st, n, timeout_us, NULL, &src) <= 0) return 0; source_release(st, &src, 0); }
     else {
         /* int16 samples wanted: the chunk loop proper (it also brings the persistent buffer up to date first) */
         int ret = n <= st->mtu_size ? cl_smi_read_device_ra(smi, dev->channel, n, NULL) : cl_smi_read_device(smi, dev->channel, n, 0, NULL);
