@@ -75,6 +75,10 @@ def parse():
                          "--pcie-streams Soapy devices of one GPU read through cl_group_readStream (one MTU per stream and step); "
                          "roofline.bound = \"pcie\" against the box's own concurrent H2D + D2H ceiling.  Never the headline `value`.")
     ap.add_argument("--pcie-streams", type=int, default=32)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed even at world size 1 (under torch.distributed.run --nproc-per-node 1): the "
+                         "RCCL calls of the N > 1 path -- init with a device id, barrier, max-reduction on a device tensor, destroy -- "
+                         "on a one-GPU box")
     ap.add_argument("--print-launch", action="store_true",
                     help="with --gpus N > 1 and no WORLD_SIZE: print the launcher command this process would start, and exit")
     return ap.parse_args()
@@ -394,7 +398,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist, red_dev = None, dev
-    if world > 1:
+    if world > 1 or (a.force_dist and "RANK" in os.environ):
         import torch.distributed as dist
         if a.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)   # RCCL; used only for barrier + max

@@ -652,6 +652,21 @@ int cl_smi_restore_prev_words(cl_smi *dev, int channel)
     return clhip_smi_unpack_aligned(channel, w, n, CL_FORMAT_CS16, dev->d_iq, NULL, dev->stream) || clhip_stream_sync(dev->stream) ? -1 : 0;
 }
 
+/* A runtime error inside the loop, behind a staged read(): everything queued is waited for, the read() in hand (`got` bytes, the
+ * oldest staged ones) counts as consumed -- like a read() whose analysis failed, caribou_smi.c:665-668 -- and what was staged ahead
+ * of it is pending again: the FIFO is never left with bytes that are neither consumed nor pending. */
+static long ra_fail(cl_smi *dev, size_t got)
+{
+    clhip_stream_sync(dev->stream);
+    if (dev->cstream) clhip_stream_sync(dev->cstream);
+    cl_smi_readahead_cancel(dev);
+    pthread_mutex_lock(&dev->fifo_mu);
+    cl_fifo_confirm(&dev->rx, got);
+    pthread_mutex_unlock(&dev->fifo_mu);
+    dev->ra_pending = 0;
+    return smi_count(dev, CL_SMI_ERR_IO);
+}
+
 long cl_smi_ra_launch(cl_smi *dev, int channel, size_t length_samples, int16_t *d_iq)
 {
     clhip_set_device(dev->device);
@@ -716,7 +731,7 @@ long cl_smi_ra_launch(cl_smi *dev, int channel, size_t length_samples, int16_t *
              * (caribou_smi.c:235-292) without asking the device, every slot written.  No launch here at all: the caller's
              * own first kernel reads the raw words (dev->fast_words, ready on dev->stream) -- the unpack in the client's
              * format, the IIR's input conversion, the fused pipe -- and cl_smi_ra_finish is the call's one synchronisation. */
-            if (clhip_stream_wait_event(dev->stream, dev->ev_copied[slot])) return CL_SMI_ERR_IO;
+            if (clhip_stream_wait_event(dev->stream, dev->ev_copied[slot])) return ra_fail(dev, got);
             dev->fast_words = dev->d_slot[slot];
             dev->prev_words = dev->d_slot[slot]; dev->prev_words_len = got;   /* (a caller that writes dev->d_iq itself clears this) */
             dev->h_offs[0] = 0;
@@ -726,12 +741,12 @@ long cl_smi_ra_launch(cl_smi *dev, int channel, size_t length_samples, int16_t *
             dev->ra_pending = 1; dev->ra_samples = got / CL_BYTES_PER_SAMPLE;
             return (long)dev->ra_samples;
         }
-        if (own && read_so_far == 0 && cl_smi_restore_prev_words(dev, channel)) return CL_SMI_ERR_IO;
+        if (own && read_so_far == 0 && cl_smi_restore_prev_words(dev, channel)) return ra_fail(dev, got);
         if (clhip_stream_wait_event(dev->stream, dev->ev_copied[slot]) ||
             clhip_smi_find_offsets(dev->d_slot[slot], got, nb, nb, 1, dev->d_offs, dev->stream) ||
             clhip_smi_unpack(channel, dev->d_slot[slot], got, nb, nb, 1, dev->d_offs, CL_FORMAT_CS16, d_iq + 2 * read_so_far, NULL, dev->stream) ||
             clhip_memcpy_d2h(dev->h_offs, dev->d_offs, 4, dev->stream))
-            return CL_SMI_ERR_IO;
+            return ra_fail(dev, got);
         cl_chunk *c = &dev->chunks[dev->n_chunks];             /* published (n_chunks++) once its verdict is in */
         c->stage_off = 0; c->len = got; c->slot0 = read_so_far; c->offs = 0;
         read_so_far += got / CL_BYTES_PER_SAMPLE;              /* :677 */
@@ -740,7 +755,7 @@ long cl_smi_ra_launch(cl_smi *dev, int channel, size_t length_samples, int16_t *
             dev->ra_pending = 1; dev->ra_samples = read_so_far;
             return (long)read_so_far;
         }
-        if (clhip_stream_sync(dev->stream)) return CL_SMI_ERR_IO;
+        if (clhip_stream_sync(dev->stream)) return ra_fail(dev, got);
         const int v = ra_chunk_verdict(dev);
         if (v) return v;
     }
@@ -753,7 +768,7 @@ int cl_smi_ra_finish(cl_smi *dev)
 {
     if (!dev->ra_pending) return 0;
     dev->ra_pending = 0;
-    if (clhip_stream_sync(dev->stream)) return smi_count(dev, CL_SMI_ERR_IO);
+    if (clhip_stream_sync(dev->stream)) return (int)ra_fail(dev, dev->chunks[dev->n_chunks].len);
     const int v = ra_chunk_verdict(dev);
     if (v) return v;
     dev->stat_samples += dev->ra_samples;

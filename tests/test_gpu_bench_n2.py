@@ -39,3 +39,21 @@ def test_two_ranks_headline_workload():
 def test_two_ranks_sharded_config4():
     d = _run(["--workload", "c4", "--streams", "6", "--log2-samples", "17"])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["streams_per_gpu"] == 3
+
+
+@pytest.mark.gpu
+def test_rccl_calls_of_the_n_gt_1_path_at_world_size_one():
+    """The driver's N = 2, 4, 8 runs use the nccl (= RCCL) backend: init_process_group with a device id, barrier, the max-reduction on
+    a DEVICE tensor, destroy.  Two ranks cannot share one GPU under RCCL, so those calls run here at world size 1 under
+    torch.distributed.run (--force-dist), everything else of the line as at N = 1."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--dist-backend", "nccl",
+                        "--steps", "3", "--warmup", "1", "--settle", "1", "--no-cpu", "--log2-samples", "20"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0

@@ -339,3 +339,70 @@ def test_time_sliced_single_stream_equals_one_pipe(G, orc):
         assert pos == n_out
         torch.cuda.synchronize()
         assert torch.equal(got, ref), world
+
+
+def test_streams_of_one_pipe_advance_independently(G, orc):
+    """clhip_rx_pipe_epoch_begin / _run_range / _epoch_end (what cl_group_readStream launches through): the streams of ONE 5-stream
+    pipe driven by range runs -- all together, in two runs around a skipped stream, one alone from int16 samples, with different
+    input counts -- equal five single-stream pipes driven with the same inputs bit for bit, call after call; a skipped stream keeps
+    its state; a range over streams on different polyphase phases is refused, and so is the whole-pipe call once the streams have
+    drifted apart."""
+    import torch
+    from cariboulite_amd import hip, synth
+    t = load_golden("taps.npz")
+    ns, n = 5, 3 * 4096 + 40
+    multi = hip.RxPipe(ns, 0, t["fir64_c2"], t["rs_3_2"], 3, 2, hip.PIPE_OUT_IQ)
+    lone = [hip.RxPipe(1, 0, t["fir64_c2"], t["rs_3_2"], 3, 2, hip.PIPE_OUT_IQ) for _ in range(ns)]
+    stride_in, stride_out = n + 16, n * 3 // 2 + 32
+    def words(call):
+        return torch.stack([torch.from_numpy(np.concatenate([synth.smi_stream_bytes(n, 0, stream=50 + s, n0=call * n)[0], np.zeros(64, np.uint8)]).view(np.int32).copy()) for s in range(ns)]).to(G.DEV)
+    def cs16_of(w_row, count):
+        o = torch.zeros((count + 2, 2), dtype=torch.int16, device=G.DEV)
+        offs = torch.zeros(1, dtype=torch.int32, device=G.DEV)
+        hip.smi_unpack(0, w_row, 4 * count, 4 * count, 4 * count, 1, offs, hip.FORMAT_CS16, o)
+        return o
+    # call plans: list of (first, count, kind, n_in); streams not named are skipped in that call
+    plans = [[(0, 5, "words", n)],
+             [(0, 2, "words", n), (3, 2, "words", n)],                      # stream 2 skipped
+             [(0, 1, "words", n), (1, 1, "cs16", n), (2, 3, "words", n)],
+             [(0, 5, "words", n)],
+             [(0, 4, "words", n), (4, 1, "words", 2 * 1024)],                # stream 4 takes fewer inputs: still phase 0 (a multiple of 4)
+             [(0, 5, "words", n)]]
+    for call, plan in enumerate(plans):
+        w = words(call)
+        assert w.shape[1] >= stride_in
+        out = torch.full((ns, stride_out, 2), float("nan"), dtype=torch.float32, device=G.DEV)
+        ref = torch.full((ns, stride_out, 2), float("nan"), dtype=torch.float32, device=G.DEV)
+        multi.epoch_begin()
+        for first, count, kind, n_in in plan:
+            if kind == "words":
+                got = multi.run_range(first, count, hip.PIPE_IN_SMI_WORDS, w[first], w.shape[1], n_in, out[first], stride_out)
+            else:
+                got = multi.run_range(first, count, hip.PIPE_IN_CS16, cs16_of(w[first], n_in), 0, n_in, out[first], stride_out)
+            for s in range(first, first + count):
+                assert got == lone[s].out_count(n_in)
+                if kind == "words":
+                    assert lone[s].run(hip.PIPE_IN_SMI_WORDS, w[s], 0, n_in, ref[s], 0) == got
+                else:
+                    assert lone[s].run(hip.PIPE_IN_CS16, cs16_of(w[s], n_in), 0, n_in, ref[s], 0) == got
+        multi.epoch_end()
+        torch.cuda.synchronize()
+        assert out.cpu().numpy().tobytes() == ref.cpu().numpy().tobytes(), call      # NaN where nothing was written, on both sides
+    assert [multi.stream_total(s) for s in range(ns)] == [6 * n, 6 * n, 5 * n, 6 * n, 5 * n + 2048]
+    # drifted apart: the whole-pipe call refuses; a range over two phase classes refuses; an epoch cannot be opened twice
+    w = words(9)
+    out = torch.zeros((ns, stride_out, 2), dtype=torch.float32, device=G.DEV)
+    with pytest.raises(RuntimeError, match="no longer move as one"):
+        multi.run(hip.PIPE_IN_SMI_WORDS, w, w.shape[1], n, out, stride_out)
+    multi.epoch_begin()
+    with pytest.raises(RuntimeError):
+        multi.epoch_begin()
+    assert multi.run_range(0, 1, hip.PIPE_IN_SMI_WORDS, w[0], 0, 6, out[0], 0) == 9        # 6 inputs: stream 0 is now off the others' phase class (6 mod 4)
+    with pytest.raises(RuntimeError, match="already ran"):
+        multi.run_range(0, 2, hip.PIPE_IN_SMI_WORDS, w[0], w.shape[1], n, out[0], stride_out)
+    multi.epoch_end()
+    multi.epoch_begin()
+    with pytest.raises(RuntimeError, match="different polyphase phases"):
+        multi.run_range(0, 2, hip.PIPE_IN_SMI_WORDS, w[0], w.shape[1], n, out[0], stride_out)
+    multi.epoch_end()
+    torch.cuda.synchronize()
