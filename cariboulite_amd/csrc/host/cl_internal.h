@@ -36,7 +36,7 @@ typedef struct {
 } cl_fifo;
 
 void   cl_fifo_free(cl_fifo *f);
-int    cl_fifo_adopt(cl_fifo *f, uint8_t *slice, size_t cap);   /* move the (pinned) FIFO's bytes into `slice` and live there from now on (0 / -1: does not fit) */
+int    cl_fifo_adopt(cl_fifo *f, uint8_t *slice, size_t cap);   /* move the FIFO's bytes into `slice` (memory of the FIFO's own kind: pinned for a pinned FIFO) and live there from now on (0 / -1: does not fit) */
 int    cl_fifo_leave(cl_fifo *f);                               /* the reverse: into a buffer of its own (0 / -1) */
 uint8_t *cl_fifo_reserve(cl_fifo *f, size_t n);              /* room for n more bytes at the tail (may move the buffer) */
 void   cl_fifo_commit(cl_fifo *f, size_t n);

@@ -56,11 +56,11 @@ void cl_fifo_commit(cl_fifo *f, size_t n) { f->len += n; }
 int cl_fifo_adopt(cl_fifo *f, uint8_t *slice, size_t cap)
 {
     const size_t live = f->head - f->keep + f->len;
-    if (!f->pinned || live > cap) return -1;
+    if (live > cap) return -1;
     for (int k = 0; k < 2; k++)
         if (f->dma_stream[k]) clhip_stream_sync(f->dma_stream[k]);
     if (live) memcpy(slice, f->data + f->keep, live);
-    if (!f->external) clhip_host_free(f->data);
+    if (!f->external) { if (f->pinned) clhip_host_free(f->data); else free(f->data); }
     f->data = slice; f->cap = cap; f->external = 1;
     f->head -= f->keep; f->keep = 0;
     return 0;
@@ -74,7 +74,7 @@ int cl_fifo_leave(cl_fifo *f)
     while (cap < live) cap *= 2;
     for (int k = 0; k < 2; k++)
         if (f->dma_stream[k]) clhip_stream_sync(f->dma_stream[k]);
-    uint8_t *p = (uint8_t *)clhip_host_alloc(cap);
+    uint8_t *p = f->pinned ? (uint8_t *)clhip_host_alloc(cap) : (uint8_t *)malloc(cap);
     if (!p) return -1;
     if (live) memcpy(p, f->data + f->keep, live);
     f->data = p; f->cap = cap; f->external = 0;

@@ -31,8 +31,27 @@ static void fifo_fuzz(void)
     cl_fifo f; memset(&f, 0, sizeof f);
     uint8_t counter = 0, tmp[5000];
     uint8_t *last_stage = NULL; size_t last_stage_n = 0;
+    uint8_t *slices[4096]; int n_slices = 0, adoptions = 0, outgrown = 0;     /* memory lent to the FIFO (a stream group's slab): the FIFO never frees it */
     for (int it = 0; it < 200000; it++) {
         const uint32_t op = rnd() % 100;
+        if (it % 97 == 0 && n_slices < 4096) {
+            /* the FIFO moves into a slice somebody else owns (cl_group.c: the group's pinned slab) -- with staged bytes, pending bytes, a
+             * front stash, whatever it holds -- or back out into a buffer of its own; either way not a byte changes */
+            const int was_external = f.external;
+            if (was_external && (rnd() & 1)) { assert(cl_fifo_leave(&f) == 0 && !f.external); }
+            else {
+                const size_t live = f.head - f.keep + f.len, cap = live + rnd() % 6000;
+                uint8_t *sl = (uint8_t *)malloc(cap ? cap : 1);
+                slices[n_slices++] = sl;
+                assert(cl_fifo_adopt(&f, sl, cap) == 0 && f.external && f.data == sl);
+                adoptions++;
+            }
+            last_stage = NULL;
+            assert(cl_fifo_pending(&f) == m_len - m_staged && f.head - f.keep == m_staged);
+            if (m_staged) assert(memcmp(f.data + f.keep, model, m_staged) == 0);
+            if (f.len) assert(memcmp(f.data + f.head, model + m_staged + cl_fifo_front_len(&f), f.len) == 0);
+        }
+        const int ext_before = f.external;
         if (op < 35) {                                          /* push / reserve+commit */
             size_t n = rnd() % (m_len > 200000 ? 50 : 3000);     /* keep the backlog bounded */
             for (size_t k = 0; k < n; k++) tmp[k] = counter++;
@@ -89,8 +108,11 @@ static void fifo_fuzz(void)
         }
         assert(cl_fifo_pending(&f) == m_len - m_staged && f.head - f.keep == m_staged && f.head + f.len <= f.cap);
         assert(!(m_staged && cl_fifo_front_len(&f)));           /* staged bytes and a front stash never coexist */
+        if (ext_before && !f.external) outgrown++;              /* a push found the lent slice too small: the FIFO has a buffer of its own again */
     }
-    cl_fifo_free(&f);
+    assert(adoptions > 500 && outgrown > 50);
+    cl_fifo_free(&f);                                           /* (must not free a slice it was lent) */
+    for (int k = 0; k < n_slices; k++) free(slices[k]);
     free(m_base); m_base = model = NULL; m_len = m_cap = m_staged = m_off = 0;
 }
 

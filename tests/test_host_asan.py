@@ -38,3 +38,21 @@ def test_ring_span_calls_two_threads_under_tsan(tmp_path):
     env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1:exitcode=66")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0 and "ring tsan harness ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_group_copy_pool_under_tsan(tmp_path):
+    """the stream group's last hop (cl_group.c: copy threads + the calling thread draining one queue, non-temporal stores) under
+    ThreadSanitizer: ragged rows, an overflowing queue, 0 / 1 / 3 workers, every byte checked after every drain"""
+    from cariboulite_amd import _build
+    _build.build_all()
+    pkg = os.path.join(ROOT, "cariboulite_amd")
+    host = os.path.join(pkg, "csrc", "host")
+    exe = str(tmp_path / "group_pool_tsan")
+    cmd = ["gcc", "-std=gnu11", "-O1", "-g", "-fsanitize=thread", "-fno-omit-frame-pointer",
+           os.path.join(ROOT, "tests", "cpp", "test_group_pool_tsan.c"), os.path.join(host, "cl_smi.c"), os.path.join(host, "cl_soapy.c"), os.path.join(host, "cl_ring.c"),
+           "-I", host, "-I", os.path.join(ROOT, "include"), "-L", pkg, "-lcariboulite_hip", f"-Wl,-rpath,{pkg}", "-lpthread", "-lm", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1:exitcode=66")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "group pool tsan harness ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
