@@ -226,6 +226,8 @@ void cl_group_unmake(cl_group *g)
         for (size_t i = 0; i < g->n; i++) {
             cl_smi *smi = g->dev[i]->smi;
             pthread_mutex_lock(&smi->fifo_mu);
+            /* (a producer that holds an uncommitted reservation is writing into the slice: its commit is waited for) */
+            while (smi->rx.external && smi->rx.reserved) pthread_cond_wait(&smi->fifo_fed, &smi->fifo_mu);
             if (smi->rx.external && smi->rx.data >= g->slab && smi->rx.data < g->slab + g->n * g->slab_slice) cl_fifo_leave(&smi->rx);
             pthread_mutex_unlock(&smi->fifo_mu);
         }

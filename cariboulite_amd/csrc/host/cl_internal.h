@@ -28,6 +28,7 @@ typedef struct {
     uint8_t *data;
     size_t cap, keep, head, len;
     int pinned;                  /* hipHostMalloc'ed */
+    int reserved;                /* a producer holds a pointer from cl_smi_feed_reserve it has not committed yet: nobody else may move `data` */
     int external;                /* `data` is a slice of memory somebody else owns (a stream group's pinned slab): never freed here; a FIFO that
                                   * outgrows it moves into a buffer of its own */
     void *dma_stream[2];         /* streams whose copies read FIFO memory in place (waited for before the buffer moves) */

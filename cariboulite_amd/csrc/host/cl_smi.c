@@ -56,7 +56,7 @@ void cl_fifo_commit(cl_fifo *f, size_t n) { f->len += n; }
 int cl_fifo_adopt(cl_fifo *f, uint8_t *slice, size_t cap)
 {
     const size_t live = f->head - f->keep + f->len;
-    if (live > cap) return -1;
+    if (live > cap || f->reserved) return -1;               /* (a producer is writing into the buffer through a pointer it was handed) */
     for (int k = 0; k < 2; k++)
         if (f->dma_stream[k]) clhip_stream_sync(f->dma_stream[k]);
     if (live) memcpy(slice, f->data + f->keep, live);
@@ -69,6 +69,7 @@ int cl_fifo_adopt(cl_fifo *f, uint8_t *slice, size_t cap)
 int cl_fifo_leave(cl_fifo *f)
 {
     if (!f->external) return 0;
+    if (f->reserved) return -1;
     const size_t live = f->head - f->keep + f->len;
     size_t cap = (size_t)1 << 20;
     while (cap < live) cap *= 2;
@@ -222,6 +223,7 @@ uint8_t *cl_smi_feed_reserve(cl_smi *dev, size_t n)
     clhip_set_device(dev->device);
     pthread_mutex_lock(&dev->fifo_mu);
     uint8_t *p = cl_fifo_reserve(&dev->rx, n);
+    dev->rx.reserved = p != NULL;
     pthread_mutex_unlock(&dev->fifo_mu);
     return p;
 }
@@ -230,6 +232,7 @@ int cl_smi_feed_commit(cl_smi *dev, size_t n)
 {
     pthread_mutex_lock(&dev->fifo_mu);
     cl_fifo_commit(&dev->rx, n);
+    dev->rx.reserved = 0;
     pthread_cond_broadcast(&dev->fifo_fed);
     pthread_mutex_unlock(&dev->fifo_mu);
     return 0;
@@ -377,12 +380,14 @@ long cl_smi_feed_fd(cl_smi *dev, int fd, size_t max_bytes)
         uint8_t *slot = cl_smi_feed_reserve(dev, want);        /* read() lands in pinned memory the DMA engine reads from */
         if (!slot) return -1;
         ssize_t r = read(fd, slot, want);
-        if (r < 0) {
-            if (errno == EINTR) continue;
-            if (errno == EAGAIN || errno == EWOULDBLOCK) break;
+        if (r <= 0) {
+            const int e = errno;
+            cl_smi_feed_commit(dev, 0);                        /* (the reservation ends whatever read() said) */
+            if (r == 0) break;
+            if (e == EINTR) continue;
+            if (e == EAGAIN || e == EWOULDBLOCK) break;
             return -1;
         }
-        if (r == 0) break;
         cl_smi_feed_commit(dev, (size_t)r);
         total += (size_t)r;
     }

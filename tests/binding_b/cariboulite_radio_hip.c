@@ -102,6 +102,7 @@ int cariboulite_radio_read_samples(cariboulite_radio_state_st *radio, cariboulit
         read_so_far += (size_t)ret / CARIBOU_SMI_BYTES_PER_SAMPLE;        /* :677 */
         left -= (size_t)ret;                                   /* :678 */
     }
+    cl_smi_feed_commit(g_smi, 0);                              /* (a reservation the loop left open -- time-out, error -- ends here) */
     pthread_mutex_unlock(&g_io);
     if (rc == -1) fprintf(stderr, "SMI reading operation failed\n");           /* cariboulite_radio.c:1276-1283 */
     else if (rc == -3) fprintf(stderr, "SMI data synchronization failed\n");
