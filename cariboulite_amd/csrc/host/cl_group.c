@@ -45,13 +45,17 @@ typedef struct {
     int n; int *member;                   /* indices into the group's device table */
     clhip_rx_pipe *pipe;                  /* ROUTE_PIPE */
     size_t in_stride;                     /* bytes per row of d_in */
-    uint8_t *d_in[2]; int cur_in;         /* raw words of this call / of the call before it */
-    size_t *prev_len;                     /* per row: bytes the PREVIOUS call put into d_in[cur_in ^ 1] on the batched route (0: none) */
+    uint8_t *d_in[3]; int cur_in, prev_in, next_in;   /* raw words of this call / of the call before it / read ahead for the next one (rotating) */
+    size_t *primed; unsigned *primed_epoch;   /* per row: bytes of the NEXT call's batch already staged in the member's FIFO and copied to d_in[next_in]
+                                               * (0: none), and the member seam's foreign_epoch then -- a reader of the seam's own that came in between bumps it */
+    void *ev_primed;                      /* behind the read-ahead's copies */
+    size_t *prev_len;                     /* per row: bytes the PREVIOUS call put into d_in[prev_in] on the batched route (0: none) */
     size_t out_stride;                    /* elements per row of d_out / h_out */
     uint8_t *d_out, *h_out;
     int32_t *h_offs; int32_t *d_offs;     /* ROUTE_PLAIN: per row 0 (unpack) / -1 (skip), mapped pinned */
     uint8_t *m_out;                       /* the device's address of h_out (mapped pinned): kernels may store into the mirror themselves */
     uint8_t *fast; size_t *len; long *got;   /* per call */
+    uint8_t *ahead_mark; size_t want;      /* per call: rows staged for the read-ahead; the call's bytes per batch */
     uint8_t **src;                        /* per call and row: where the staged batch lies in the member's pinned FIFO */
     cl_dsp_cfg dsp;
 } lane_t;
@@ -62,6 +66,7 @@ struct cl_group {
     int *lane_of, *row_of;                /* member -> lane / row */
     int n_lanes; lane_t *lane;
     int sub;                              /* streams per sub-batch */
+    int readahead;                        /* kwarg READAHEAD: 1 (default) = behind a call's launches the NEXT call's batches are staged and copied in */
     int sink_mapped;                      /* kwarg SINK: "mapped" (default) = the sub-batch's kernel stores into the mapped pinned mirror itself; "copy" = device buffer + copy engine */
 #define GRP_MAX_IN 8
     void *s_in[GRP_MAX_IN], *s_k, *s_out; /* ingest streams taken in turn by the members' copies: a copy's fixed cost (~10 us between two copies of one
@@ -207,9 +212,10 @@ static int same_dsp(const cl_dsp_cfg *a, const cl_dsp_cfg *b)
 static void lane_free(lane_t *l)
 {
     if (l->pipe) clhip_rx_pipe_destroy(l->pipe);
-    clhip_free(l->d_in[0]); clhip_free(l->d_in[1]); clhip_free(l->d_out);
+    clhip_free(l->d_in[0]); clhip_free(l->d_in[1]); clhip_free(l->d_in[2]); clhip_free(l->d_out);
+    clhip_event_destroy(l->ev_primed); free(l->primed); free(l->primed_epoch);
     clhip_host_free(l->h_out); clhip_host_free(l->h_offs);
-    free(l->member); free(l->prev_len); free(l->fast); free(l->len); free(l->got); free(l->src);
+    free(l->member); free(l->prev_len); free(l->fast); free(l->len); free(l->got); free(l->src); free(l->ahead_mark);
     memset(l, 0, sizeof *l);
 }
 
@@ -222,6 +228,7 @@ void cl_group_unmake(cl_group *g)
     if (g->s_out) clhip_stream_sync(g->s_out);
     pool_stop(&g->pool);
     cl_group_unregister_buffers(g);
+    for (size_t i = 0; i < g->n; i++) cl_smi_foreign_cancel(g->dev[i]->smi);      /* what was read ahead is pending again */
     if (g->slab) {                                             /* the members' FIFOs move out before the slab goes */
         for (size_t i = 0; i < g->n; i++) {
             cl_smi *smi = g->dev[i]->smi;
@@ -275,6 +282,7 @@ cl_group *cl_group_make(cl_device *const *devs, size_t n, const char *const *key
     const char *is = kwget(keys, vals, n_kwargs, "INGEST_STREAMS");
     g->n_in = is && atoi(is) >= 1 && atoi(is) <= GRP_MAX_IN ? atoi(is) : 2;     /* tools/group_ab.py, medians of 9 interleaved reps: CS16 4989 / 6508 / 5443 Msamples/s at 1 / 2 / 4, FIR64 + 3/2 3116 / 3131 / 2854 */
     g->ev_per = g->n_in + 2;
+    { const char *ra = kwget(keys, vals, n_kwargs, "READAHEAD"); g->readahead = ra ? atoi(ra) != 0 : 1; }
     const char *sk = kwget(keys, vals, n_kwargs, "SINK");
     g->sink_mapped = !(sk && !strcmp(sk, "copy"));
     int threads = ct ? atoi(ct) : 2;                     /* tools/group_ab.py (interleaved medians, FIR64 + 3/2 x 32): 0 / 1 / 2 / 3 / 4 / 8 threads -> 2099 / 2556 / 3158 / 3034 / 2925 / 2783 Msamples/s */
@@ -318,7 +326,10 @@ cl_group *cl_group_make(cl_device *const *devs, size_t n, const char *const *key
         }
         const size_t out_bytes = (size_t)l->n * l->out_stride * l->elem_bytes + 256;
         const size_t in_bytes = (size_t)l->n * l->in_stride + 256;
-        l->d_in[0] = (uint8_t *)clhip_malloc(in_bytes); l->d_in[1] = (uint8_t *)clhip_malloc(in_bytes);
+        l->d_in[0] = (uint8_t *)clhip_malloc(in_bytes); l->d_in[1] = (uint8_t *)clhip_malloc(in_bytes); l->d_in[2] = (uint8_t *)clhip_malloc(in_bytes);
+        l->cur_in = 0; l->prev_in = 1; l->next_in = 2;
+        l->primed = (size_t *)calloc((size_t)l->n, sizeof(size_t)); l->primed_epoch = (unsigned *)calloc((size_t)l->n, sizeof(unsigned));
+        l->ev_primed = clhip_event_create();
         l->d_out = (uint8_t *)clhip_malloc(out_bytes); l->h_out = (uint8_t *)clhip_host_alloc(out_bytes);
         l->h_offs = (int32_t *)clhip_host_alloc(sizeof(int32_t) * (size_t)l->n + 64);
         l->d_offs = l->h_offs ? (int32_t *)clhip_host_device_ptr(l->h_offs) : NULL;
@@ -327,7 +338,8 @@ cl_group *cl_group_make(cl_device *const *devs, size_t n, const char *const *key
         l->fast = (uint8_t *)calloc((size_t)l->n, 1); l->len = (size_t *)calloc((size_t)l->n, sizeof(size_t));
         l->got = (long *)calloc((size_t)l->n, sizeof(long));
         l->src = (uint8_t **)calloc((size_t)l->n, sizeof(uint8_t *));
-        if (!l->d_in[0] || !l->d_in[1] || !l->d_out || !l->h_out || !l->h_offs || !l->d_offs || !l->m_out || !l->prev_len || !l->fast || !l->len || !l->got || !l->src) {
+        l->ahead_mark = (uint8_t *)calloc((size_t)l->n, 1);
+        if (!l->d_in[0] || !l->d_in[1] || !l->d_in[2] || !l->primed || !l->primed_epoch || !l->ev_primed || !l->d_out || !l->h_out || !l->h_offs || !l->d_offs || !l->m_out || !l->prev_len || !l->fast || !l->len || !l->got || !l->src || !l->ahead_mark) {
             cl_seterr(g_make_err, sizeof g_make_err, "cl_group_make: buffers for %d streams could not be allocated", l->n);
             cl_group_unmake(g);
             return NULL;
@@ -426,43 +438,66 @@ static int registered(const cl_group *g, int m, const void *p, size_t bytes)
  * bytes are in pinned host memory, so the host knows before the device has looked); they are staged and their copy to the
  * lane's row is queued while they cannot move.  Everything else -- short, ragged or slipped reads, bytes given back earlier,
  * reader threads, the IIR, debug modes -- is the single-stream route's business. */
-static int try_stage(cl_group *g, lane_t *l, int row, size_t want, void *s_in)
+/* may member `row` take the batched route at all in this call? */
+static int qualifies(const cl_group *g, const lane_t *l, int row, size_t want)
 {
-    cl_device *dev = g->dev[l->member[row]];
-    cl_stream *st = dev->stream;
-    cl_smi *smi = dev->smi;
-    l->src[row] = NULL;
+    const cl_device *dev = g->dev[l->member[row]];
+    const cl_stream *st = dev->stream;
+    const cl_smi *smi = dev->smi;
     if (st->use_async || st->filter_type != CL_DIGFILT_NONE || smi->debug_mode != CL_SMI_DEBUG_NONE || st->native_dir != CL_SOAPY_SDR_RX) return 0;
     if (st->format != l->format || !want || (want & 15) || want > smi->native_batch_len || (smi->max_read && smi->max_read < want)) return 0;
-    if (l->route == ROUTE_PIPE && clhip_rx_pipe_stream_total(l->pipe, row) % (2ull * (unsigned long long)l->down)) return 0;   /* (off polyphase phase 0: generic kernels, one by one) */
-    cl_smi_readahead_cancel(smi);                              /* what a single-stream call staged ahead is pending again */
+    return 1;
+}
+
+/* stage member `row`'s next `want` pending bytes in place if they are one in-sync batch: l->src[row] says where they lie.  Returns 1
+ * with the member's FIFO lock HELD -- the bytes must not move before the copy that reads them is queued (copies_queue releases it) */
+static int stage_row(cl_group *g, lane_t *l, int row, size_t want, void *s_in, int slot)
+{
+    cl_smi *smi = g->dev[l->member[row]]->smi;
     uint8_t *src = NULL;
+    l->src[row] = NULL;
     pthread_mutex_lock(&smi->fifo_mu);
     if (!cl_fifo_front_len(&smi->rx) && smi->rx.len >= want) {
-        smi->rx.dma_stream[1] = s_in;                          /* a feeder that has to move the buffer waits for this copy first */
+        smi->rx.dma_stream[slot] = s_in;                       /* a feeder that has to move the buffer waits for this copy first */
         const size_t got = cl_fifo_stage(&smi->rx, want, &src);
-        if (got == want && cl_smi_head_in_sync(src, got)) {
-            l->src[row] = src;
-            return 1;                                          /* NOTE: with the member's FIFO lock HELD -- the bytes must not move before the
-                                                                * copy that reads them is queued (copies_queue releases it) */
-        }
+        if (got == want && cl_smi_head_in_sync(src, got)) { l->src[row] = src; return 1; }
         if (got) cl_fifo_unstage(&smi->rx, got);
     }
     pthread_mutex_unlock(&smi->fifo_mu);
     return 0;
 }
 
+/* 2 = the batch was read ahead by the previous call (staged in the FIFO, copied to d_in[cur_in]): nothing to do here;
+ * 1 = staged now, its copy still to be queued (FIFO lock held); 0 = not on the batched route in this call */
+static int try_stage(cl_group *g, lane_t *l, int row, size_t want, void *s_in)
+{
+    cl_smi *smi = g->dev[l->member[row]]->smi;
+    const int ok = qualifies(g, l, row, want) &&
+                   !(l->route == ROUTE_PIPE && clhip_rx_pipe_stream_total(l->pipe, row) % (2ull * (unsigned long long)l->down));   /* (off polyphase phase 0: generic kernels, one by one) */
+    l->src[row] = NULL;
+    if (l->primed[row]) {
+        const int intact = smi->foreign_ahead == l->primed[row] && smi->foreign_epoch == l->primed_epoch[row];
+        const size_t had = l->primed[row];
+        l->primed[row] = 0;
+        if (intact && ok && had == want) { smi->foreign_ahead = 0; return 2; }    /* the read-ahead is this call's batch now: staged, the oldest unconfirmed bytes */
+        if (intact) cl_smi_foreign_cancel(smi);                 /* another length, or off the batched route: pending again, in order */
+    }
+    if (!ok) return 0;
+    cl_smi_readahead_cancel(smi);                              /* what a single-stream call staged ahead is pending again */
+    return stage_row(g, l, row, want, s_in, 1);
+}
+
 /* Queue the copies in of the staged rows [a, e) and let their FIFOs go again.  Neighbouring rows whose batches lie one slab slice
  * apart (members that are fed and read in step, the normal case) travel as ONE 2-D copy; any other row by a copy of its own.  A row
  * whose copy cannot be queued is unstaged and leaves the batched route.  Returns 0, or -1 on a runtime error. */
-static int copies_queue(cl_group *g, lane_t *l, int a, int e, size_t want, void *s_in)
+static int copies_queue(cl_group *g, lane_t *l, uint8_t *d_buf, int a, int e, size_t want, void *s_in)
 {
     int rc = 0, r = a;
     while (r < e) {
-        if (!l->fast[r]) { r++; continue; }
+        if (!l->fast[r] || !l->src[r]) { r++; continue; }     /* (not batched, or read ahead by the call before) */
         int r1 = r + 1;
-        while (g->slab && r1 < e && l->fast[r1] && l->src[r1] == l->src[r] + (size_t)(r1 - r) * g->slab_slice) r1++;
-        uint8_t *dst = l->d_in[l->cur_in] + (size_t)r * l->in_stride;
+        while (g->slab && r1 < e && l->fast[r1] && l->src[r1] && l->src[r1] == l->src[r] + (size_t)(r1 - r) * g->slab_slice) r1++;
+        uint8_t *dst = d_buf + (size_t)r * l->in_stride;
         const int bad = r1 - r > 1 ? clhip_memcpy2d_h2d(dst, l->in_stride, l->src[r], g->slab_slice, want, (size_t)(r1 - r), s_in)
                                    : clhip_memcpy_h2d(dst, l->src[r], want, s_in);
         if (r1 - r > 1) g->stats.copies_2d++;
@@ -503,7 +538,7 @@ static int single_member(cl_group *g, lane_t *l, int row, void *out, size_t numE
     if (l->prev_len[row] && (l->route == ROUTE_PIPE || st->format != CL_FORMAT_CS16)) {
         const size_t pl = l->prev_len[row];
         if (cl_ensure((void **)&smi->d_iq, &smi->iq_cap, pl / 4 + 8, 4, 0) ||
-            clhip_smi_unpack_aligned(l->channel, l->d_in[l->cur_in ^ 1] + (size_t)row * l->in_stride, pl, CL_FORMAT_CS16, smi->d_iq, NULL, smi->stream))
+            clhip_smi_unpack_aligned(l->channel, l->d_in[l->prev_in] + (size_t)row * l->in_stride, pl, CL_FORMAT_CS16, smi->d_iq, NULL, smi->stream))
             return 0;
         smi->prev_words = NULL;
     }
@@ -551,21 +586,29 @@ int cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems, int *r
         /* CS16 is not clamped to the MTU by the reference (CaribouliteStream.cpp:282-301): longer calls are chunk loops, one by one */
         const size_t n_el = l->format == CL_FORMAT_CS16 && l->route == ROUTE_PLAIN ? numElems : (numElems > mtu ? mtu : numElems);
         const size_t want = n_el <= mtu ? n_el * 4 : 0;
-        l->cur_in ^= 1;
+        { const int p = l->prev_in; l->prev_in = l->cur_in; l->cur_in = l->next_in; l->next_in = p; }   /* what was read ahead is this call's input */
+        l->want = want;
         if (l->pipe && clhip_rx_pipe_epoch_begin(l->pipe)) { hard = 1; break; }
+        int waits_primed = 0;
         for (int a = 0; a < l->n && !hard; a += g->sub, b++) {
             const int e = a + g->sub < l->n ? a + g->sub : l->n;
             void **ev_in = g->ev + (size_t)g->ev_per * b, *ev_k = ev_in[g->n_in], *ev_out = ev_in[g->n_in + 1];
             unsigned used = 0;                                 /* ingest streams this sub-batch's copies were queued on */
             int any = 0;
             void *s_in = g->s_in[b % (size_t)g->n_in];          /* the sub-batches take turns on the ingest streams */
+            int from_ahead = 0;
             for (int r = a; r < e; r++) {
-                l->fast[r] = (uint8_t)try_stage(g, l, r, want, s_in);
+                const int how = try_stage(g, l, r, want, s_in);
+                l->fast[r] = (uint8_t)(how != 0);
+                from_ahead |= how == 2; g->stats.ahead_reads += how == 2;
                 l->got[r] = 0;
             }
-            if (copies_queue(g, l, a, e, want, s_in)) hard = 1;
-            for (int r = a; r < e; r++) { l->len[r] = l->fast[r] ? want : 0; any |= l->fast[r]; }
-            if (any) used |= 1u << (b % (size_t)g->n_in);
+            if (copies_queue(g, l, l->d_in[l->cur_in], a, e, want, s_in)) hard = 1;
+            if (from_ahead && !waits_primed) { hard = hard || clhip_stream_wait_event(g->s_k, l->ev_primed); waits_primed = 1; }
+            for (int r = a; r < e; r++) {
+                l->len[r] = l->fast[r] ? want : 0; any |= l->fast[r];
+                if (l->fast[r] && l->src[r]) used |= 1u << (b % (size_t)g->n_in);      /* (a copy was queued in this call) */
+            }
             if (!any) { if (clhip_event_record(ev_out, g->s_out)) hard = 1; continue; }
             for (int k = 0; k < g->n_in && !hard; k++)
                 if (used >> k & 1) hard = clhip_event_record(ev_in[k], g->s_in[k]) || clhip_stream_wait_event(g->s_k, ev_in[k]);
@@ -618,6 +661,31 @@ int cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems, int *r
             hard = hard || clhip_event_record(ev_out, g->s_out);
         }
     }
+    /* ---- read-ahead: behind this call's launches, the NEXT call's batches of the rows that are on the batched route -- staged in the
+     * members' FIFOs (the newest staged bytes: cl_smi_foreign_cancel gives them back if anybody else reads that seam first) and copied to
+     * d_in[next_in], whole lanes at a time where the members are in step.  The next call then starts with its launches. */
+    for (int k = 0; g->readahead && k < g->n_lanes && !hard; k++) {
+        lane_t *l = &g->lane[k];
+        void *s_p = g->s_in[(size_t)k % (size_t)g->n_in];
+        int any = 0;
+        uint8_t *keep_fast = l->fast;                          /* (copies_queue walks l->fast: the rows staged for the read-ahead, for the moment) */
+        l->fast = l->ahead_mark;
+        for (int r = 0; r < l->n; r++) {
+            l->ahead_mark[r] = keep_fast[r] && l->want && stage_row(g, l, r, l->want, s_p, 2) ? 1 : 0;
+            any |= l->ahead_mark[r];
+        }
+        if (any) {
+            if (copies_queue(g, l, l->d_in[l->next_in], 0, l->n, l->want, s_p)) hard = 1;
+            for (int r = 0; r < l->n; r++) {
+                if (!l->ahead_mark[r]) continue;              /* (a row whose copy could not be queued was unstaged and unmarked) */
+                cl_smi *smi = g->dev[l->member[r]]->smi;
+                smi->foreign_ahead = l->want;
+                l->primed[r] = l->want; l->primed_epoch[r] = smi->foreign_epoch;
+            }
+            hard = hard || clhip_event_record(l->ev_primed, s_p);
+        }
+        l->fast = keep_fast;
+    }
     clock_gettime(CLOCK_MONOTONIC, &t1);
     /* ---- pass 2: as the sub-batches arrive, their bytes are consumed for good and their rows go to the clients */
     const size_t n_queued = b;
@@ -633,6 +701,7 @@ int cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems, int *r
                 cl_device *dev = g->dev[m];
                 if (!arrived) {                                    /* a runtime error: nothing is delivered, nothing is consumed */
                     for (int k = 0; k < g->n_in; k++) clhip_stream_sync(g->s_in[k]);
+                    if (l->primed[r]) { cl_smi_foreign_cancel(dev->smi); l->primed[r] = 0; }     /* (newest staged bytes first) */
                     pthread_mutex_lock(&dev->smi->fifo_mu);
                     cl_fifo_unstage(&dev->smi->rx, l->len[r]);
                     pthread_mutex_unlock(&dev->smi->fifo_mu);

@@ -24,6 +24,7 @@
  * moves it: bytes a reader gives back that do not fit in front of `head` go to the FRONT STASH, a second small buffer
  * only the consumer touches, which pop drains first and the in-place readers step around (they take the copying route
  * while it holds anything). */
+#define CL_FIFO_DMA_STREAMS 3
 typedef struct {
     uint8_t *data;
     size_t cap, keep, head, len;
@@ -31,7 +32,8 @@ typedef struct {
     int reserved;                /* a producer holds a pointer from cl_smi_feed_reserve it has not committed yet: nobody else may move `data` */
     int external;                /* `data` is a slice of memory somebody else owns (a stream group's pinned slab): never freed here; a FIFO that
                                   * outgrows it moves into a buffer of its own */
-    void *dma_stream[2];         /* streams whose copies read FIFO memory in place (waited for before the buffer moves) */
+    void *dma_stream[CL_FIFO_DMA_STREAMS];   /* streams whose copies read FIFO memory in place (waited for before the buffer moves): the seam's
+                                  * own, a stream group's copy of the current batch, the group's read-ahead */
     uint8_t *front;              /* front stash: [front_head, front_cap) are pending bytes OLDER than everything in `data` */
     size_t front_cap, front_head;
 } cl_fifo;
@@ -99,6 +101,10 @@ struct cl_smi {
     uint8_t *d_slot[CL_RA_SLOTS]; size_t slot_cap;   /* device side of the read-ahead; the host side is the pinned RX FIFO itself */
     struct { int valid, slot, head_ok; size_t len; } ahead;
     int next_slot;
+    /* bytes a stream GROUP has staged ahead for its NEXT call (cl_group.c: their copy to the device is already queued): the newest staged
+     * bytes of the FIFO.  Every entry of the seam's own readers gives them back first (cl_smi_foreign_cancel) and bumps the epoch, so that
+     * the group can tell that its read-ahead is void */
+    size_t foreign_ahead; unsigned foreign_epoch;
     int ra_pending; size_t ra_samples;     /* between cl_smi_ra_launch and cl_smi_ra_finish */
     size_t inplace_len;                    /* bytes of a one-read() call staged in place on `stream`: confirmed once that stream has been synchronised */
     /* cl_smi_ra_launch's short cut for a call that is ONE read() the host has seen to be in sync: set want_words before the
@@ -122,6 +128,7 @@ int cl_smi_read_device_ra(cl_smi *dev, int channel, size_t length_samples, int16
 long cl_smi_ra_launch(cl_smi *dev, int channel, size_t length_samples, int16_t *d_iq);   /* its two halves: the caller may queue */
 int cl_smi_ra_finish(cl_smi *dev);                                                      /* work on the seam's stream in between */
 void cl_smi_readahead_cancel(cl_smi *dev);
+void cl_smi_foreign_cancel(cl_smi *dev);                 /* a group's read-ahead on this seam is given back (pending again) */
 int cl_smi_head_in_sync(const uint8_t *chunk, size_t len);   /* offs == 0 decided on the host from the staged bytes */
 /* poll(POLLIN, timeout) on the injected byte stream: returns 1 when bytes are pending (at once or within timeout_us) */
 int cl_smi_wait_bytes(cl_smi *dev, long timeout_us);     /* bytes staged ahead go back to the front of the FIFO */

@@ -31,7 +31,7 @@ uint8_t *cl_fifo_reserve(cl_fifo *f, size_t n)
     if (f->len == 0 && f->keep == f->head) f->keep = f->head = 0;          /* empty: start over at the front */
     if (f->head + f->len + n > f->cap) {
         const size_t live = f->head - f->keep + f->len;                      /* staged-unconfirmed + pending */
-        for (int k = 0; k < 2; k++)                                          /* copies may still be reading this memory in place */
+        for (int k = 0; k < CL_FIFO_DMA_STREAMS; k++)                                          /* copies may still be reading this memory in place */
             if (f->dma_stream[k]) clhip_stream_sync(f->dma_stream[k]);
         if (live + n <= f->cap && f->keep) {                                /* compact */
             memmove(f->data, f->data + f->keep, live);
@@ -57,7 +57,7 @@ int cl_fifo_adopt(cl_fifo *f, uint8_t *slice, size_t cap)
 {
     const size_t live = f->head - f->keep + f->len;
     if (live > cap || f->reserved) return -1;               /* (a producer is writing into the buffer through a pointer it was handed) */
-    for (int k = 0; k < 2; k++)
+    for (int k = 0; k < CL_FIFO_DMA_STREAMS; k++)
         if (f->dma_stream[k]) clhip_stream_sync(f->dma_stream[k]);
     if (live) memcpy(slice, f->data + f->keep, live);
     if (!f->external) { if (f->pinned) clhip_host_free(f->data); else free(f->data); }
@@ -73,7 +73,7 @@ int cl_fifo_leave(cl_fifo *f)
     const size_t live = f->head - f->keep + f->len;
     size_t cap = (size_t)1 << 20;
     while (cap < live) cap *= 2;
-    for (int k = 0; k < 2; k++)
+    for (int k = 0; k < CL_FIFO_DMA_STREAMS; k++)
         if (f->dma_stream[k]) clhip_stream_sync(f->dma_stream[k]);
     uint8_t *p = f->pinned ? (uint8_t *)clhip_host_alloc(cap) : (uint8_t *)malloc(cap);
     if (!p) return -1;
@@ -258,13 +258,13 @@ int cl_smi_wait_bytes(cl_smi *dev, long timeout_us)
     if (until.tv_nsec >= 1000000000L) { until.tv_sec++; until.tv_nsec -= 1000000000L; }
     pthread_mutex_lock(&dev->fifo_mu);
     int expired = 0;
-    while (cl_fifo_pending(&dev->rx) == 0 && !dev->ahead.valid && !expired)
+    while (cl_fifo_pending(&dev->rx) == 0 && !dev->ahead.valid && !dev->foreign_ahead && !expired)
         expired = pthread_cond_timedwait(&dev->fifo_fed, &dev->fifo_mu, &until) != 0;
-    const int ready = cl_fifo_pending(&dev->rx) != 0 || dev->ahead.valid;
+    const int ready = cl_fifo_pending(&dev->rx) != 0 || dev->ahead.valid || dev->foreign_ahead;
     pthread_mutex_unlock(&dev->fifo_mu);
     return ready;
 }
-size_t cl_smi_pending_bytes(const cl_smi *dev) { return cl_fifo_pending(&dev->rx) + (dev->ahead.valid ? dev->ahead.len : 0); }   /* staged ahead = still pending */
+size_t cl_smi_pending_bytes(const cl_smi *dev) { return cl_fifo_pending(&dev->rx) + (dev->ahead.valid ? dev->ahead.len : 0) + dev->foreign_ahead; }   /* staged ahead = still pending */
 void   cl_smi_set_max_read(cl_smi *dev, size_t m) { dev->max_read = m; }
 /* The TX FIFO has one producer (the write calls: reserve, fill by DMA or kernel, commit) and one consumer (the drain calls),
  * which may be two threads: its bookkeeping moves under fifo_mu; the bytes of an open reservation lie behind everything a pop
@@ -604,8 +604,19 @@ static size_t ra_stage(cl_smi *dev, int slot, size_t want, int *in_sync)
     return bad ? 0 : got;
 }
 
+void cl_smi_foreign_cancel(cl_smi *dev)
+{
+    if (!dev->foreign_ahead) return;
+    pthread_mutex_lock(&dev->fifo_mu);
+    cl_fifo_unstage(&dev->rx, dev->foreign_ahead);             /* the newest staged bytes: still in place, pending again */
+    pthread_mutex_unlock(&dev->fifo_mu);
+    dev->foreign_ahead = 0;
+    dev->foreign_epoch++;
+}
+
 void cl_smi_readahead_cancel(cl_smi *dev)
 {
+    cl_smi_foreign_cancel(dev);
     if (!dev->ahead.valid) return;
     pthread_mutex_lock(&dev->fifo_mu);
     cl_fifo_unstage(&dev->rx, dev->ahead.len);                 /* still in place: pending again */
@@ -676,6 +687,7 @@ long cl_smi_ra_launch(cl_smi *dev, int channel, size_t length_samples, int16_t *
 {
     clhip_set_device(dev->device);
     const size_t nb = dev->native_batch_len;
+    cl_smi_foreign_cancel(dev);                                /* (a group's read-ahead: this reader comes first) */
     const int want_words = dev->want_words;
     dev->want_words = 0;
     dev->ra_pending = 0;

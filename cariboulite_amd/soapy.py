@@ -231,6 +231,9 @@ class Device:
     def pendingSmiBytes(self):
         return lib().cl_smi_pending_bytes(self.smi)
 
+    def flushSmiFifo(self):
+        return lib().cl_smi_flush_fifo(self.smi)
+
     def setMaxRead(self, n):
         lib().cl_smi_set_max_read(self.smi, n)
 
@@ -392,10 +395,10 @@ class Group:
         return lib().cl_group_last_error(self.h).decode()
 
     def stats(self):
-        out = (C.c_uint64 * 10)()
+        out = (C.c_uint64 * 11)()
         lib().cl_group_getStats(self.h, out)
         return dict(zip(("calls", "batched_reads", "single_reads", "direct_reads", "launches", "errors", "copies_2d", "last_queue_us",
-                         "last_arrive_us", "last_total_us"), [int(v) for v in out]))
+                         "last_arrive_us", "last_total_us", "ahead_reads"), [int(v) for v in out]))
 
     def close(self):
         if getattr(self, "h", None) and _lib is not None:

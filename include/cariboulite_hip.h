@@ -586,7 +586,10 @@ void   cl_stream_set_iir_poll_bound(cl_stream *stream, int polls);
  * INGEST_STREAMS=<1 .. 8> (HIP streams the sub-batches' copies in take turns on; 2), SLAB_MB=<MiB> (pinned FIFO room per member
  * in the group's ONE slab, 8: the members' byte FIFOs live there from cl_group_make to cl_group_unmake, a slice each, so that the
  * batches of members that are fed and read in step lie one stride apart and travel as one 2-D copy per sub-batch; a FIFO that
- * outgrows its slice moves into a buffer of its own and its batches come in by copies of their own; 0 = no slab).  Returns the number of streams that delivered (> 0 elements), or -1 on a
+ * outgrows its slice moves into a buffer of its own and its batches come in by copies of their own; 0 = no slab), READAHEAD=<0|1>
+ * (1: behind a call's launches the members' NEXT batches, where they are pending already, are staged in their FIFOs and copied in, so
+ * that the next call starts with its launches; such bytes count as pending until that call takes them, and any other reader of
+ * the member's device -- its own readStream, a flush, a call with another numElems -- finds them pending, in order).  Returns the number of streams that delivered (> 0 elements), or -1 on a
  * runtime error (cl_group_last_error; NULL group = the last cl_group_make failure). */
 typedef struct cl_group cl_group;
 typedef struct {
@@ -600,6 +603,7 @@ typedef struct {
     uint64_t last_queue_us;      /* the last call: everything staged and queued after ... us                       */
     uint64_t last_arrive_us;     /*                the last sub-batch had arrived and was handed to the copy threads */
     uint64_t last_total_us;      /*                returned                                                         */
+    uint64_t ahead_reads;        /* batched reads whose batch the call BEFORE had already staged and copied in (READAHEAD) */
 } cl_group_stats;
 cl_group   *cl_group_make(cl_device *const *devs, size_t n_devs, const char *const *keys, const char *const *vals, size_t n_kwargs);
 void        cl_group_unmake(cl_group *g);
