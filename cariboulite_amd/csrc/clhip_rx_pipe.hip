@@ -1550,6 +1550,21 @@ extern "C" long clhip_rx_pipe_run_range(clhip_rx_pipe *p, int first, int count, 
     return n_out;
 }
 
+// A range run of the OPEN epoch is taken back for stream s (the caller read ahead of its client and the client went another way):
+// the stream counts as not run -- its history of the epoch before is untouched (ping-pong), what the run wrote for the next epoch is
+// overwritten by a later run of this epoch or by epoch_end's copy across -- and its input counter is rewound.  Work queued behind it
+// on the same HIP stream sees the right order.
+extern "C" int clhip_rx_pipe_unrun_stream(clhip_rx_pipe *p, int s, size_t n_in)
+{
+    if (!p || !p->epoch_open || s < 0 || s >= p->n_streams || !p->ran[s] || p->nt_s[s] < n_in) {
+        clhip_set_error("clhip_rx_pipe_unrun_stream: stream %d has no run of the open epoch to take back", s);
+        return -1;
+    }
+    p->ran[s] = 0;
+    p->nt_s[s] -= n_in;
+    return 0;
+}
+
 extern "C" int clhip_rx_pipe_epoch_end(clhip_rx_pipe *p, void *stream)
 {
     if (!p || !p->epoch_open) { clhip_set_error("clhip_rx_pipe_epoch_end: no epoch open"); return -1; }

@@ -16,6 +16,12 @@
  * so that sub-batch b + 1 comes in and sub-batch b - 1 leaves while b computes, and the last hop (which one thread cannot
  * do at PCIe rate: profiles/r04/pcie_duplex.json) is spread over a few threads with non-temporal stores.
  *
+ * Calls overlap as well (READAHEAD): before a call waits for its own results it stages the members' NEXT batches in their
+ * FIFOs, copies them in and (READAHEAD=2) launches over them into the second of two mirrors -- the next call finds its results
+ * computed or on their way and the GPU never waits for the host between two calls.  Bytes read ahead stay the members' (staged,
+ * counted as pending, given back to any other reader of the seam: cl_smi_foreign_cancel); a run made ahead is taken back when
+ * its client goes another way (clhip_rx_pipe_unrun_stream).
+ *
  * State: a lane of the group (members with one channel type and one stream configuration) owns ONE n-stream RX pipe whose
  * streams advance independently (clhip_rx_pipe_epoch_begin / _run_range / _epoch_end); formats without extension stages
  * are stateless behind the unpack.  What the single-stream route keeps for the reference's "untouched slots" (the
@@ -51,9 +57,16 @@ typedef struct {
     void *ev_primed;                      /* behind the read-ahead's copies */
     size_t *prev_len;                     /* per row: bytes the PREVIOUS call put into d_in[prev_in] on the batched route (0: none) */
     size_t out_stride;                    /* elements per row of d_out / h_out */
-    uint8_t *d_out, *h_out;
-    int32_t *h_offs; int32_t *d_offs;     /* ROUTE_PLAIN: per row 0 (unpack) / -1 (skip), mapped pinned */
-    uint8_t *m_out;                       /* the device's address of h_out (mapped pinned): kernels may store into the mirror themselves */
+    uint8_t *d_out;
+    uint8_t *h_out[2], *m_out[2]; int cur_m;   /* two pinned mirrors (this call's results / the next call's, computed ahead) and the device's addresses of
+                                               * them (mapped pinned): kernels may store into a mirror themselves */
+    int32_t *h_offs[4]; int32_t *d_offs[4];    /* ROUTE_PLAIN: per row 0 (unpack) / -1 (skip), mapped pinned: one table per (event set, launched ahead | in the
+                                               * call) -- a launch reads its table when it RUNS */
+    uint8_t *done_ahead; long *ahead_got;      /* per row: the previous call launched over the batch it read ahead, results in h_out[cur_m ^ 1] then; elements */
+    uint8_t *direct;                           /* per call and row: the copy engine wrote the client's registered buffer */
+    int epoch_open;                            /* the pipe's epoch of the NEXT call was opened by the read-ahead */
+    int set;                                   /* this call's event set (0 / 1) */
+    size_t sub0; int queued;                   /* the lane's first sub-batch among the group's; sub-batches queued in this call */
     uint8_t *fast; size_t *len; long *got;   /* per call */
     uint8_t *ahead_mark; size_t want;      /* per call: rows staged for the read-ahead; the call's bytes per batch */
     uint8_t **src;                        /* per call and row: where the staged batch lies in the member's pinned FIFO */
@@ -66,14 +79,16 @@ struct cl_group {
     int *lane_of, *row_of;                /* member -> lane / row */
     int n_lanes; lane_t *lane;
     int sub;                              /* streams per sub-batch */
-    int readahead;                        /* kwarg READAHEAD: 1 (default) = behind a call's launches the NEXT call's batches are staged and copied in */
+    int readahead;                        /* kwarg READAHEAD: 0 = none; 1 = before a call waits for its results the NEXT call's batches are staged and copied in;
+                                           * 2 (default) = ... and launched over, into the second mirror */
+    size_t n_sub;                         /* sub-batches over all lanes */
     int sink_mapped;                      /* kwarg SINK: "mapped" (default) = the sub-batch's kernel stores into the mapped pinned mirror itself; "copy" = device buffer + copy engine */
 #define GRP_MAX_IN 8
     void *s_in[GRP_MAX_IN], *s_k, *s_out; /* ingest streams taken in turn by the members' copies: a copy's fixed cost (~10 us between two copies of one
                                            * stream, rocprofv3 trace: profiles/r04/group_call_timeline_cs16.txt) overlaps the transfer of its neighbour's */
     int n_in;                             /* kwarg INGEST_STREAMS: 1 .. 8 (default 2) */
     int ev_per;                           /* events per sub-batch: n_in (in) + 1 (launched) + 1 (out) */
-    void **ev; size_t n_ev;               /* 3 per sub-batch */
+    void **ev; size_t n_ev;               /* ev_per per sub-batch and set */
     copy_pool pool;
     uint8_t **reg_base; size_t *reg_len; size_t n_reg;   /* page ranges of client buffers registered with the GPU (cl_group_register_buffers), merged where they touch */
     uint8_t *has_reg;                                     /* per member: it has a registered buffer */
@@ -209,12 +224,15 @@ static int same_dsp(const cl_dsp_cfg *a, const cl_dsp_cfg *b)
            !memcmp(a->rs, b->rs, sizeof(float) * (size_t)a->n_rs);
 }
 
+static void ahead_cancel_all(cl_group *g);
+
 static void lane_free(lane_t *l)
 {
     if (l->pipe) clhip_rx_pipe_destroy(l->pipe);
     clhip_free(l->d_in[0]); clhip_free(l->d_in[1]); clhip_free(l->d_in[2]); clhip_free(l->d_out);
     clhip_event_destroy(l->ev_primed); free(l->primed); free(l->primed_epoch);
-    clhip_host_free(l->h_out); clhip_host_free(l->h_offs);
+    clhip_host_free(l->h_out[0]); clhip_host_free(l->h_out[1]); clhip_host_free(l->h_offs[0]);
+    free(l->done_ahead); free(l->ahead_got); free(l->direct);
     free(l->member); free(l->prev_len); free(l->fast); free(l->len); free(l->got); free(l->src); free(l->ahead_mark);
     memset(l, 0, sizeof *l);
 }
@@ -228,7 +246,7 @@ void cl_group_unmake(cl_group *g)
     if (g->s_out) clhip_stream_sync(g->s_out);
     pool_stop(&g->pool);
     cl_group_unregister_buffers(g);
-    for (size_t i = 0; i < g->n; i++) cl_smi_foreign_cancel(g->dev[i]->smi);      /* what was read ahead is pending again */
+    ahead_cancel_all(g);                                       /* what was read ahead is pending again */
     if (g->slab) {                                             /* the members' FIFOs move out before the slab goes */
         for (size_t i = 0; i < g->n; i++) {
             cl_smi *smi = g->dev[i]->smi;
@@ -282,9 +300,11 @@ cl_group *cl_group_make(cl_device *const *devs, size_t n, const char *const *key
     const char *is = kwget(keys, vals, n_kwargs, "INGEST_STREAMS");
     g->n_in = is && atoi(is) >= 1 && atoi(is) <= GRP_MAX_IN ? atoi(is) : 2;     /* tools/group_ab.py, medians of 9 interleaved reps: CS16 4989 / 6508 / 5443 Msamples/s at 1 / 2 / 4, FIR64 + 3/2 3116 / 3131 / 2854 */
     g->ev_per = g->n_in + 2;
-    { const char *ra = kwget(keys, vals, n_kwargs, "READAHEAD"); g->readahead = ra ? atoi(ra) != 0 : 1; }
     const char *sk = kwget(keys, vals, n_kwargs, "SINK");
     g->sink_mapped = !(sk && !strcmp(sk, "copy"));
+    { const char *ra = kwget(keys, vals, n_kwargs, "READAHEAD"); g->readahead = ra ? atoi(ra) : 2; }
+    if (g->readahead < 0 || g->readahead > 2) g->readahead = 2;
+    if (g->readahead == 2 && !g->sink_mapped) g->readahead = 1;     /* (results ahead are stored into the second mirror by the launches themselves) */
     int threads = ct ? atoi(ct) : 2;                     /* tools/group_ab.py (interleaved medians, FIR64 + 3/2 x 32): 0 / 1 / 2 / 3 / 4 / 8 threads -> 2099 / 2556 / 3158 / 3034 / 2925 / 2783 Msamples/s */
     if (threads < 0) threads = 0;
     if (threads > 16) threads = 16;
@@ -330,16 +350,25 @@ cl_group *cl_group_make(cl_device *const *devs, size_t n, const char *const *key
         l->cur_in = 0; l->prev_in = 1; l->next_in = 2;
         l->primed = (size_t *)calloc((size_t)l->n, sizeof(size_t)); l->primed_epoch = (unsigned *)calloc((size_t)l->n, sizeof(unsigned));
         l->ev_primed = clhip_event_create();
-        l->d_out = (uint8_t *)clhip_malloc(out_bytes); l->h_out = (uint8_t *)clhip_host_alloc(out_bytes);
-        l->h_offs = (int32_t *)clhip_host_alloc(sizeof(int32_t) * (size_t)l->n + 64);
-        l->d_offs = l->h_offs ? (int32_t *)clhip_host_device_ptr(l->h_offs) : NULL;
-        l->m_out = l->h_out ? (uint8_t *)clhip_host_device_ptr(l->h_out) : NULL;
+        l->d_out = (uint8_t *)clhip_malloc(out_bytes);
+        l->h_out[0] = (uint8_t *)clhip_host_alloc(out_bytes);
+        l->h_out[1] = g->readahead == 2 ? (uint8_t *)clhip_host_alloc(out_bytes) : NULL;
+        const size_t offs_each = ((size_t)l->n + 15) & ~(size_t)15;
+        l->h_offs[0] = (int32_t *)clhip_host_alloc(sizeof(int32_t) * 4 * offs_each);
+        for (int q = 0; q < 4; q++) {
+            l->h_offs[q] = l->h_offs[0] ? l->h_offs[0] + (size_t)q * offs_each : NULL;
+            l->d_offs[q] = l->h_offs[0] ? (int32_t *)clhip_host_device_ptr(l->h_offs[q]) : NULL;
+        }
+        for (int q = 0; q < 2; q++) l->m_out[q] = l->h_out[q] ? (uint8_t *)clhip_host_device_ptr(l->h_out[q]) : NULL;
+        l->done_ahead = (uint8_t *)calloc((size_t)l->n, 1); l->ahead_got = (long *)calloc((size_t)l->n, sizeof(long));
+        l->direct = (uint8_t *)calloc((size_t)l->n, 1);
+        l->sub0 = n_sub;
         l->prev_len = (size_t *)calloc((size_t)l->n, sizeof(size_t));
         l->fast = (uint8_t *)calloc((size_t)l->n, 1); l->len = (size_t *)calloc((size_t)l->n, sizeof(size_t));
         l->got = (long *)calloc((size_t)l->n, sizeof(long));
         l->src = (uint8_t **)calloc((size_t)l->n, sizeof(uint8_t *));
         l->ahead_mark = (uint8_t *)calloc((size_t)l->n, 1);
-        if (!l->d_in[0] || !l->d_in[1] || !l->d_in[2] || !l->primed || !l->primed_epoch || !l->ev_primed || !l->d_out || !l->h_out || !l->h_offs || !l->d_offs || !l->m_out || !l->prev_len || !l->fast || !l->len || !l->got || !l->src || !l->ahead_mark) {
+        if (!l->d_in[0] || !l->d_in[1] || !l->d_in[2] || !l->primed || !l->primed_epoch || !l->ev_primed || !l->d_out || !l->h_out[0] || (g->readahead == 2 && !l->h_out[1]) || !l->h_offs[0] || !l->d_offs[0] || !l->m_out[0] || !l->done_ahead || !l->ahead_got || !l->direct || !l->prev_len || !l->fast || !l->len || !l->got || !l->src || !l->ahead_mark) {
             cl_seterr(g_make_err, sizeof g_make_err, "cl_group_make: buffers for %d streams could not be allocated", l->n);
             cl_group_unmake(g);
             return NULL;
@@ -365,7 +394,8 @@ cl_group *cl_group_make(cl_device *const *devs, size_t n, const char *const *key
                 pthread_mutex_unlock(&smi->fifo_mu);
             }
     }
-    g->n_ev = (size_t)g->ev_per * n_sub;
+    g->n_sub = n_sub;
+    g->n_ev = 2 * (size_t)g->ev_per * n_sub;                  /* two sets: this call's, and the one the launches made ahead record into */
     g->ev = (void **)calloc(g->n_ev, sizeof(void *));
     int bad = !g->s_k || !g->s_out || !g->ev;
     for (int k = 0; k < g->n_in; k++) bad |= !g->s_in[k];
@@ -377,6 +407,21 @@ cl_group *cl_group_make(cl_device *const *devs, size_t n, const char *const *key
 size_t cl_group_size(const cl_group *g) { return g ? g->n : 0; }
 void cl_group_getStats(const cl_group *g, cl_group_stats *out) { if (out) { if (g) *out = g->stats; else memset(out, 0, sizeof *out); } }
 
+/* everything read or computed ahead is given back: the bytes are pending in the members' FIFOs again, the runs are taken back */
+static void ahead_cancel_all(cl_group *g)
+{
+    for (int k = 0; k < g->n_lanes; k++) {
+        lane_t *l = &g->lane[k];
+        for (int r = 0; r < l->n; r++) {
+            if (!l->primed || !l->primed[r]) continue;
+            cl_smi *smi = g->dev[l->member[r]]->smi;
+            if (smi->foreign_ahead == l->primed[r] && smi->foreign_epoch == l->primed_epoch[r]) cl_smi_foreign_cancel(smi);
+            if (l->done_ahead[r] && l->pipe) clhip_rx_pipe_unrun_stream(l->pipe, r, l->primed[r] / 4);
+            l->primed[r] = 0; l->done_ahead[r] = 0;
+        }
+    }
+}
+
 /* Client buffers the members' outputs may be written into by the copy engine directly (no pinned mirror, no memcpy): one
  * buffer per member, registered with the GPU HERE, explicitly, for as long as the registration stands -- the client keeps them
  * allocated until cl_group_unregister_buffers / cl_group_unmake.  A call whose buffs[i] lies inside member i's registered
@@ -385,6 +430,7 @@ int cl_group_register_buffers(cl_group *g, void *const *buffs, size_t bytes_each
 {
     if (!g || !buffs || !bytes_each) return -1;
     clhip_set_device(g->device);
+    ahead_cancel_all(g);                                       /* (results computed ahead lie in the mirror: the next call decides afresh) */
     cl_group_unregister_buffers(g);
     /* registrations are whole pages and neighbouring heap buffers share pages: ranges that touch are registered as one */
     const uintptr_t pg = 4096;
@@ -416,6 +462,7 @@ void cl_group_unregister_buffers(cl_group *g)
 {
     if (!g || !g->reg_base || !g->n_reg) return;
     clhip_set_device(g->device);
+    ahead_cancel_all(g);
     if (g->s_out) clhip_stream_sync(g->s_out);          /* nothing may still be writing them */
     if (g->s_k) clhip_stream_sync(g->s_k);
     for (size_t k = 0; k < g->n_reg; k++) clhip_host_unregister(g->reg_base[k]);
@@ -467,22 +514,33 @@ static int stage_row(cl_group *g, lane_t *l, int row, size_t want, void *s_in, i
     return 0;
 }
 
-/* 2 = the batch was read ahead by the previous call (staged in the FIFO, copied to d_in[cur_in]): nothing to do here;
+static int on_phase_0(const lane_t *l, int row)
+{
+    /* (off polyphase phase 0 the pipe runs its generic kernels: such streams go one by one) */
+    return l->route != ROUTE_PIPE || clhip_rx_pipe_stream_total(l->pipe, row) % (2ull * (unsigned long long)l->down) == 0;
+}
+
+/* 3 = the previous call read this batch ahead AND launched over it: its results are in the current mirror (or on their way);
+ * 2 = the previous call read it ahead (staged in the FIFO, copied to d_in[cur_in]): to be launched over;
  * 1 = staged now, its copy still to be queued (FIFO lock held); 0 = not on the batched route in this call */
 static int try_stage(cl_group *g, lane_t *l, int row, size_t want, void *s_in)
 {
     cl_smi *smi = g->dev[l->member[row]]->smi;
-    const int ok = qualifies(g, l, row, want) &&
-                   !(l->route == ROUTE_PIPE && clhip_rx_pipe_stream_total(l->pipe, row) % (2ull * (unsigned long long)l->down));   /* (off polyphase phase 0: generic kernels, one by one) */
-    l->src[row] = NULL;
     if (l->primed[row]) {
         const int intact = smi->foreign_ahead == l->primed[row] && smi->foreign_epoch == l->primed_epoch[row];
         const size_t had = l->primed[row];
-        l->primed[row] = 0;
-        if (intact && ok && had == want) { smi->foreign_ahead = 0; return 2; }    /* the read-ahead is this call's batch now: staged, the oldest unconfirmed bytes */
+        const int was_done = l->done_ahead[row];
+        l->primed[row] = 0; l->done_ahead[row] = 0; l->src[row] = NULL;
+        /* (a run made ahead has advanced the stream's counter already: its phase was checked when it was made) */
+        if (intact && had == want && qualifies(g, l, row, want) && (was_done || on_phase_0(l, row))) {
+            smi->foreign_ahead = 0;                            /* this call's batch now: staged, the oldest unconfirmed bytes */
+            return was_done ? 3 : 2;
+        }
         if (intact) cl_smi_foreign_cancel(smi);                 /* another length, or off the batched route: pending again, in order */
+        if (was_done && l->pipe) clhip_rx_pipe_unrun_stream(l->pipe, row, had / 4);
     }
-    if (!ok) return 0;
+    l->src[row] = NULL;
+    if (!qualifies(g, l, row, want) || !on_phase_0(l, row)) return 0;
     cl_smi_readahead_cancel(smi);                              /* what a single-stream call staged ahead is pending again */
     return stage_row(g, l, row, want, s_in, 1);
 }
@@ -552,7 +610,7 @@ static int single_member(cl_group *g, lane_t *l, int row, void *out, size_t numE
     const int16_t *d_iq = NULL;
     const int res = cl_stream_read_native(dev, st, numElems, timeoutUs, &d_iq);
     if (res <= 0 || !d_iq) return 0;
-    uint8_t *d_row = l->d_out + (size_t)row * l->out_stride * l->elem_bytes, *h_row = l->h_out + (size_t)row * l->out_stride * l->elem_bytes;
+    uint8_t *d_row = l->d_out + (size_t)row * l->out_stride * l->elem_bytes, *h_row = l->h_out[l->cur_m] + (size_t)row * l->out_stride * l->elem_bytes;
     const long got = clhip_rx_pipe_run_range(l->pipe, row, 1, CL_PIPE_IN_CS16, d_iq, 0, (size_t)res, d_row, 0, g->s_k);
     if (got < 0) { cl_seterr(g->err, sizeof g->err, "cl_group_readStream: %s", clhip_last_error()); return 0; }
     if (got == 0) return 0;
@@ -566,6 +624,40 @@ static int single_member(cl_group *g, lane_t *l, int row, void *out, size_t numE
     return (int)got;
 }
 
+static void **ev_of(const cl_group *g, const lane_t *l, int set, int a)
+{
+    return g->ev + ((size_t)set * g->n_sub + l->sub0 + (size_t)(a / g->sub)) * (size_t)g->ev_per;
+}
+
+/* The launches of one sub-batch over the rows [a, e) marked in `run` (maximal runs of neighbours: one fused launch each / one unpack
+ * launch with the other rows masked), from the raw words in `in` into `outb` (both row-strided); got[r] = elements per marked row. */
+static int launch_rows(cl_group *g, lane_t *l, int a, int e, const uint8_t *run, size_t want, uint8_t *in, uint8_t *outb, int offs_table, long *got)
+{
+    if (l->route == ROUTE_PIPE) {
+        int r = a;
+        while (r < e) {
+            if (!run[r]) { r++; continue; }
+            int r1 = r + 1;
+            while (r1 < e && run[r1]) r1++;
+            const long n = clhip_rx_pipe_run_range(l->pipe, r, r1 - r, CL_PIPE_IN_SMI_WORDS, in + (size_t)r * l->in_stride, l->in_stride / 4, want / 4,
+                                                   outb + (size_t)r * l->out_stride * l->elem_bytes, l->out_stride, g->s_k);
+            if (n < 0) return -1;
+            for (int q = r; q < r1; q++) got[q] = n;
+            g->stats.launches++;
+            r = r1;
+        }
+        return 0;
+    }
+    /* caribou_smi_rx_data_analyze at offset 0 + the format conversion, one launch over the sub-batch's rows (a row that is not
+     * marked has offset -1: the kernel writes nothing for it) */
+    int any = 0;
+    for (int r = a; r < e; r++) { l->h_offs[offs_table][r] = run[r] ? 0 : -1; if (run[r]) { got[r] = (long)(want / 4); any = 1; } }
+    if (!any) return 0;
+    g->stats.launches++;
+    return clhip_smi_unpack(l->channel, in + (size_t)a * l->in_stride, (size_t)(e - a - 1) * l->in_stride + want, l->in_stride, want, e - a,
+                            l->d_offs[offs_table] + a, l->format, outb + (size_t)a * l->out_stride * l->elem_bytes, NULL, g->s_k);
+}
+
 int cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems, int *rets, long timeoutUs)
 {
     if (!g || !buffs || !rets) return -1;
@@ -574,12 +666,11 @@ int cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems, int *r
     g->stats.calls++;
     for (size_t i = 0; i < g->n; i++) rets[i] = 0;
     if (!numElems) return 0;
-    for (int k = 0; k < g->n_lanes; k++) memset(g->lane[k].fast, 0, (size_t)g->lane[k].n);
+    for (int k = 0; k < g->n_lanes; k++) { memset(g->lane[k].fast, 0, (size_t)g->lane[k].n); g->lane[k].queued = 0; }
     int hard = 0;
-    size_t b = 0;                                              /* sub-batch counter over all lanes */
     struct timespec t0, t1, t2, t3;
     clock_gettime(CLOCK_MONOTONIC, &t0);
-    /* ---- pass 1: stage, copy in, launch, copy out -- everything queued, nothing waited for */
+    /* ---- pass 1: what the previous call did not do ahead -- stage, copy in, launch, copy out: everything queued, nothing waited for */
     for (int k = 0; k < g->n_lanes && !hard; k++) {
         lane_t *l = &g->lane[k];
         const size_t mtu = CL_NATIVE_MTU_SAMPLES;
@@ -587,121 +678,147 @@ int cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems, int *r
         const size_t n_el = l->format == CL_FORMAT_CS16 && l->route == ROUTE_PLAIN ? numElems : (numElems > mtu ? mtu : numElems);
         const size_t want = n_el <= mtu ? n_el * 4 : 0;
         { const int p = l->prev_in; l->prev_in = l->cur_in; l->cur_in = l->next_in; l->next_in = p; }   /* what was read ahead is this call's input */
+        if (g->readahead == 2) { l->cur_m ^= 1; l->set ^= 1; }   /* ... and what was computed ahead went to this mirror, behind these events */
         l->want = want;
-        if (l->pipe && clhip_rx_pipe_epoch_begin(l->pipe)) { hard = 1; break; }
+        if (l->pipe && !l->epoch_open && clhip_rx_pipe_epoch_begin(l->pipe)) { hard = 1; break; }
+        l->epoch_open = 1;
         int waits_primed = 0;
-        for (int a = 0; a < l->n && !hard; a += g->sub, b++) {
+        uint8_t *in = l->d_in[l->cur_in];
+        for (int a = 0; a < l->n && !hard; a += g->sub) {
             const int e = a + g->sub < l->n ? a + g->sub : l->n;
-            void **ev_in = g->ev + (size_t)g->ev_per * b, *ev_k = ev_in[g->n_in], *ev_out = ev_in[g->n_in + 1];
-            unsigned used = 0;                                 /* ingest streams this sub-batch's copies were queued on */
-            int any = 0;
+            void **ev_in = ev_of(g, l, l->set, a), *ev_k = ev_in[g->n_in], *ev_out = ev_in[g->n_in + 1];
+            const size_t b = l->sub0 + (size_t)(a / g->sub);
             void *s_in = g->s_in[b % (size_t)g->n_in];          /* the sub-batches take turns on the ingest streams */
-            int from_ahead = 0;
+            int from_ahead = 0, any_run = 0, any_copy = 0;
+            l->queued++;
             for (int r = a; r < e; r++) {
                 const int how = try_stage(g, l, r, want, s_in);
                 l->fast[r] = (uint8_t)(how != 0);
-                from_ahead |= how == 2; g->stats.ahead_reads += how == 2;
-                l->got[r] = 0;
+                l->ahead_mark[r] = (uint8_t)(how == 1 || how == 2);      /* (here: rows to launch over in this call) */
+                from_ahead |= how == 2;
+                g->stats.ahead_reads += how >= 2;
+                l->got[r] = how == 3 ? l->ahead_got[r] : 0;
+                l->direct[r] = 0;
             }
-            if (copies_queue(g, l, l->d_in[l->cur_in], a, e, want, s_in)) hard = 1;
-            if (from_ahead && !waits_primed) { hard = hard || clhip_stream_wait_event(g->s_k, l->ev_primed); waits_primed = 1; }
+            if (copies_queue(g, l, in, a, e, want, s_in)) hard = 1;     /* (a row whose copy cannot be queued leaves the batched route: fast = 0) */
             for (int r = a; r < e; r++) {
-                l->len[r] = l->fast[r] ? want : 0; any |= l->fast[r];
-                if (l->fast[r] && l->src[r]) used |= 1u << (b % (size_t)g->n_in);      /* (a copy was queued in this call) */
+                l->ahead_mark[r] = (uint8_t)(l->ahead_mark[r] && l->fast[r]);
+                l->len[r] = l->fast[r] ? want : 0;
+                any_run |= l->ahead_mark[r];
+                any_copy |= l->ahead_mark[r] && l->src[r] != NULL;
             }
-            if (!any) { if (clhip_event_record(ev_out, g->s_out)) hard = 1; continue; }
-            for (int k = 0; k < g->n_in && !hard; k++)
-                if (used >> k & 1) hard = clhip_event_record(ev_in[k], g->s_in[k]) || clhip_stream_wait_event(g->s_k, ev_in[k]);
-            uint8_t *in = l->d_in[l->cur_in];
+            if (!any_run) continue;                            /* nothing to launch: the results are there (behind the event the previous call recorded), or there are none */
+            if (from_ahead && !waits_primed) { hard = hard || clhip_stream_wait_event(g->s_k, l->ev_primed); waits_primed = 1; }
+            if (any_copy && !hard) hard = clhip_event_record(ev_in[0], s_in) || clhip_stream_wait_event(g->s_k, ev_in[0]);
             /* where the sub-batch's launch stores: the mapped pinned mirror itself (its stores cross PCIe as the kernel produces them --
              * no second hop, no copy-engine call: tools/microbench/pcie_duplex.hip) unless one of its rows has a registered client
              * buffer, which the copy engine fills from the device buffer */
             int mapped = g->sink_mapped;
             for (int r = a; r < e && mapped; r++)
                 if (l->fast[r] && g->has_reg[l->member[r]]) mapped = 0;
-            uint8_t *outb = mapped ? l->m_out : l->d_out;
-            if (!hard && l->route == ROUTE_PIPE) {
-                /* maximal runs of neighbouring batched rows: one fused launch each, straight from the raw words */
-                int r = a;
-                while (r < e && !hard) {
-                    if (!l->fast[r]) { r++; continue; }
-                    int r1 = r + 1;
-                    while (r1 < e && l->fast[r1]) r1++;
-                    const long got = clhip_rx_pipe_run_range(l->pipe, r, r1 - r, CL_PIPE_IN_SMI_WORDS, in + (size_t)r * l->in_stride, l->in_stride / 4, want / 4,
-                                                             outb + (size_t)r * l->out_stride * l->elem_bytes, l->out_stride, g->s_k);
-                    if (got < 0) hard = 1;
-                    for (int q = r; q < r1; q++) l->got[q] = got;
-                    g->stats.launches++;
-                    r = r1;
-                }
-            } else if (!hard) {
-                /* caribou_smi_rx_data_analyze at offset 0 + the format conversion, one launch over the sub-batch's rows (a row
-                 * off the batched route has offset -1: the kernel writes nothing for it) */
-                for (int r = a; r < e; r++) { l->h_offs[r] = l->fast[r] ? 0 : -1; l->got[r] = l->fast[r] ? (long)(want / 4) : 0; }
-                hard = clhip_smi_unpack(l->channel, in + (size_t)a * l->in_stride, (size_t)(e - a - 1) * l->in_stride + want, l->in_stride, want, e - a,
-                                        l->d_offs + a, l->format, outb + (size_t)a * l->out_stride * l->elem_bytes, NULL, g->s_k);
-                g->stats.launches++;
-            }
+            uint8_t *outb = mapped ? l->m_out[l->cur_m] : l->d_out;
+            if (!hard && launch_rows(g, l, a, e, l->ahead_mark, want, in, outb, 2 * l->set + 1, l->got)) hard = 1;
             if (mapped) { hard = hard || clhip_event_record(ev_out, g->s_k); continue; }     /* "arrived" = the launch has ended */
             hard = hard || clhip_event_record(ev_k, g->s_k) || clhip_stream_wait_event(g->s_out, ev_k);
-            /* out: rows whose client buffer is registered leave for it directly; the others as one block into the mirror */
-            int lo = -1, hi = -1;
-            for (int r = a; r < e && !hard; r++) {
-                if (!l->fast[r] || l->got[r] <= 0) continue;
+            /* out: rows whose client buffer is registered leave for it directly; the others in blocks of neighbours into the mirror */
+            for (int r = a; r < e && !hard; ) {
+                if (!l->ahead_mark[r] || l->got[r] <= 0) { r++; continue; }
                 const size_t bytes = (size_t)l->got[r] * l->elem_bytes;
-                if (registered(g, l->member[r], buffs[l->member[r]], bytes))
+                if (registered(g, l->member[r], buffs[l->member[r]], bytes)) {
                     hard = clhip_memcpy_d2h(buffs[l->member[r]], l->d_out + (size_t)r * l->out_stride * l->elem_bytes, bytes, g->s_out);
-                else { if (lo < 0) lo = r; hi = r; }
-            }
-            if (!hard && lo >= 0) {
-                const size_t o = (size_t)lo * l->out_stride * l->elem_bytes;
-                const size_t bytes = (size_t)(hi - lo) * l->out_stride * l->elem_bytes + (size_t)l->got[hi] * l->elem_bytes;
-                hard = clhip_memcpy_d2h(l->h_out + o, l->d_out + o, bytes, g->s_out);
+                    l->direct[r] = 1; r++;
+                    continue;
+                }
+                int hi = r;
+                while (hi + 1 < e && l->ahead_mark[hi + 1] && l->got[hi + 1] > 0 &&
+                       !registered(g, l->member[hi + 1], buffs[l->member[hi + 1]], (size_t)l->got[hi + 1] * l->elem_bytes)) hi++;
+                const size_t o = (size_t)r * l->out_stride * l->elem_bytes;
+                hard = clhip_memcpy_d2h(l->h_out[l->cur_m] + o, l->d_out + o, (size_t)(hi - r) * l->out_stride * l->elem_bytes + (size_t)l->got[hi] * l->elem_bytes, g->s_out);
+                r = hi + 1;
             }
             hard = hard || clhip_event_record(ev_out, g->s_out);
         }
     }
-    /* ---- read-ahead: behind this call's launches, the NEXT call's batches of the rows that are on the batched route -- staged in the
-     * members' FIFOs (the newest staged bytes: cl_smi_foreign_cancel gives them back if anybody else reads that seam first) and copied to
-     * d_in[next_in], whole lanes at a time where the members are in step.  The next call then starts with its launches. */
+    /* ---- pass 2: the members off the batched route, one by one, through their own devices; then the pipes' epochs end */
+    for (int k = 0; k < g->n_lanes; k++) {
+        lane_t *l = &g->lane[k];
+        if (!l->queued) continue;                              /* (a runtime error before this lane's turn: its state stands) */
+        for (int r = 0; r < l->n; r++) {
+            if (l->fast[r]) continue;
+            const int m = l->member[r];
+            rets[m] = hard ? 0 : single_member(g, l, r, buffs[m], numElems, timeoutUs);
+            count_read(g->dev[m]->stream, rets[m]);
+        }
+        if (l->pipe && l->epoch_open && clhip_rx_pipe_epoch_end(l->pipe, g->s_k)) hard = 1;
+        l->epoch_open = 0;
+    }
+    /* ---- ahead: before this call waits for its own results, the NEXT call's batches of the rows on the batched route -- staged in the
+     * members' FIFOs (the newest staged bytes: cl_smi_foreign_cancel gives them back if anybody else reads that seam first), copied to
+     * d_in[next_in], whole lanes at a time where the members are in step, and (READAHEAD=2) launched over into the other mirror: the
+     * GPU goes on while the host hands this call's results out, and the next call finds its own computed. */
     for (int k = 0; g->readahead && k < g->n_lanes && !hard; k++) {
         lane_t *l = &g->lane[k];
         void *s_p = g->s_in[(size_t)k % (size_t)g->n_in];
         int any = 0;
-        uint8_t *keep_fast = l->fast;                          /* (copies_queue walks l->fast: the rows staged for the read-ahead, for the moment) */
+        if (!l->queued || !l->want) continue;
+        uint8_t *keep_fast = l->fast;                          /* (copies_queue walks l->fast: the rows staged ahead, for the moment) */
         l->fast = l->ahead_mark;
         for (int r = 0; r < l->n; r++) {
-            l->ahead_mark[r] = keep_fast[r] && l->want && stage_row(g, l, r, l->want, s_p, 2) ? 1 : 0;
+            l->ahead_mark[r] = keep_fast[r] && qualifies(g, l, r, l->want) && stage_row(g, l, r, l->want, s_p, 2) ? 1 : 0;
             any |= l->ahead_mark[r];
         }
-        if (any) {
-            if (copies_queue(g, l, l->d_in[l->next_in], 0, l->n, l->want, s_p)) hard = 1;
-            for (int r = 0; r < l->n; r++) {
-                if (!l->ahead_mark[r]) continue;              /* (a row whose copy could not be queued was unstaged and unmarked) */
-                cl_smi *smi = g->dev[l->member[r]]->smi;
-                smi->foreign_ahead = l->want;
-                l->primed[r] = l->want; l->primed_epoch[r] = smi->foreign_epoch;
-            }
-            hard = hard || clhip_event_record(l->ev_primed, s_p);
-        }
+        if (any && copies_queue(g, l, l->d_in[l->next_in], 0, l->n, l->want, s_p)) hard = 1;
         l->fast = keep_fast;
+        if (!any) continue;
+        for (int r = 0; r < l->n; r++) {
+            if (!l->ahead_mark[r]) continue;                  /* (a row whose copy could not be queued was unstaged and unmarked) */
+            cl_smi *smi = g->dev[l->member[r]]->smi;
+            smi->foreign_ahead = l->want;
+            l->primed[r] = l->want; l->primed_epoch[r] = smi->foreign_epoch;
+        }
+        hard = hard || clhip_event_record(l->ev_primed, s_p);
+        if (g->readahead < 2 || hard) continue;
+        /* the launches: sub-batch by sub-batch like the call's own, into the OTHER mirror, behind the OTHER event set; sub-batches
+         * with a registered client buffer among their members wait for the call (the copy engine needs the client's pointer) */
+        if (l->pipe) { if (clhip_rx_pipe_epoch_begin(l->pipe)) { hard = 1; break; } l->epoch_open = 1; }
+        int waited = 0;
+        for (int a = 0; a < l->n && !hard; a += g->sub) {
+            const int e = a + g->sub < l->n ? a + g->sub : l->n;
+            int run = 0;
+            for (int r = a; r < e; r++) {
+                if (g->has_reg[l->member[r]]) { run = 0; break; }
+                l->done_ahead[r] = (uint8_t)(l->ahead_mark[r] && on_phase_0(l, r));
+                run |= l->done_ahead[r];
+            }
+            if (!run) { for (int r = a; r < e; r++) l->done_ahead[r] = 0; continue; }
+            if (!waited) { hard = clhip_stream_wait_event(g->s_k, l->ev_primed); waited = 1; }
+            if (!hard && launch_rows(g, l, a, e, l->done_ahead, l->want, l->d_in[l->next_in], l->m_out[l->cur_m ^ 1], 2 * (l->set ^ 1), l->ahead_got)) hard = 1;
+            hard = hard || clhip_event_record(ev_of(g, l, l->set ^ 1, a)[g->n_in + 1], g->s_k);
+        }
     }
     clock_gettime(CLOCK_MONOTONIC, &t1);
-    /* ---- pass 2: as the sub-batches arrive, their bytes are consumed for good and their rows go to the clients */
-    const size_t n_queued = b;
-    b = 0;
+    /* ---- pass 3: as the sub-batches arrive, their bytes are consumed for good and their rows go to the clients */
     for (int k = 0; k < g->n_lanes; k++) {
         lane_t *l = &g->lane[k];
-        for (int a = 0; a < l->n; a += g->sub, b++) {
+        int sb = 0;
+        for (int a = 0; a < l->n; a += g->sub, sb++) {
             const int e = a + g->sub < l->n ? a + g->sub : l->n;
-            const int arrived = b < n_queued && !hard && clhip_event_sync(g->ev[(size_t)g->ev_per * b + g->n_in + 1]) == 0;
+            int any = 0;
+            for (int r = a; r < e; r++) any |= l->fast[r];
+            if (!any) continue;
+            const int arrived = sb < l->queued && !hard && clhip_event_sync(ev_of(g, l, l->set, a)[g->n_in + 1]) == 0;
+            if (!arrived) hard = 1;
             for (int r = a; r < e; r++) {
                 if (!l->fast[r]) continue;
                 const int m = l->member[r];
                 cl_device *dev = g->dev[m];
                 if (!arrived) {                                    /* a runtime error: nothing is delivered, nothing is consumed */
-                    for (int k = 0; k < g->n_in; k++) clhip_stream_sync(g->s_in[k]);
-                    if (l->primed[r]) { cl_smi_foreign_cancel(dev->smi); l->primed[r] = 0; }     /* (newest staged bytes first) */
+                    for (int q = 0; q < g->n_in; q++) clhip_stream_sync(g->s_in[q]);
+                    if (l->primed[r]) {                            /* (the newest staged bytes first) */
+                        cl_smi_foreign_cancel(dev->smi);
+                        if (l->done_ahead[r] && l->pipe) clhip_rx_pipe_unrun_stream(l->pipe, r, l->primed[r] / 4);
+                        l->primed[r] = 0; l->done_ahead[r] = 0;
+                    }
                     pthread_mutex_lock(&dev->smi->fifo_mu);
                     cl_fifo_unstage(&dev->smi->rx, l->len[r]);
                     pthread_mutex_unlock(&dev->smi->fifo_mu);
@@ -714,8 +831,8 @@ int cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems, int *r
                 dev->smi->prev_words = NULL;                       /* (the lane's previous raw words stand in for them) */
                 l->prev_len[r] = l->len[r];
                 const size_t bytes = (size_t)l->got[r] * l->elem_bytes;
-                if (!registered(g, m, buffs[m], bytes))
-                    pool_submit(&g->pool, (uint8_t *)buffs[m], l->h_out + (size_t)r * l->out_stride * l->elem_bytes, bytes);
+                if (!l->direct[r])
+                    pool_submit(&g->pool, (uint8_t *)buffs[m], l->h_out[l->cur_m] + (size_t)r * l->out_stride * l->elem_bytes, bytes);
                 else g->stats.direct_reads++;
                 rets[m] = (int)l->got[r];
                 g->stats.batched_reads++;
@@ -724,22 +841,14 @@ int cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems, int *r
         }
     }
     clock_gettime(CLOCK_MONOTONIC, &t2);
-    /* ---- pass 3: the members off the batched route, one by one (while the pool still copies) */
-    for (int k = 0; k < g->n_lanes; k++) {
-        lane_t *l = &g->lane[k];
-        for (int r = 0; r < l->n; r++) {
-            if (l->fast[r]) continue;
-            const int m = l->member[r];
-            rets[m] = hard ? 0 : single_member(g, l, r, buffs[m], numElems, timeoutUs);
-            count_read(g->dev[m]->stream, rets[m]);
-        }
-        if (l->pipe && clhip_rx_pipe_epoch_end(l->pipe, g->s_k)) hard = 1;
-    }
     pool_drain(&g->pool);
     if (hard) {
         for (int k = 0; k < g->n_in; k++) clhip_stream_sync(g->s_in[k]);
         clhip_stream_sync(g->s_k); clhip_stream_sync(g->s_out);
         if (!g->err[0]) cl_seterr(g->err, sizeof g->err, "cl_group_readStream: %s", clhip_last_error());
+        ahead_cancel_all(g);
+        for (int k = 0; k < g->n_lanes; k++)
+            if (g->lane[k].pipe && g->lane[k].epoch_open) { clhip_rx_pipe_epoch_end(g->lane[k].pipe, g->s_k); g->lane[k].epoch_open = 0; }
         g->stats.errors++;
         return -1;
     }

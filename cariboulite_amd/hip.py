@@ -90,6 +90,7 @@ _SIGS = {
     "clhip_rx_pipe_epoch_begin": (C.c_int, [C.c_void_p]),
     "clhip_rx_pipe_run_range": (C.c_long, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
     "clhip_rx_pipe_epoch_end": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "clhip_rx_pipe_unrun_stream": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t]),
     "clhip_rx_pipe_out_count_stream": (C.c_size_t, [C.c_void_p, C.c_int, C.c_size_t]),
     "clhip_rx_pipe_stream_total": (C.c_ulonglong, [C.c_void_p, C.c_int]),
     "clhip_rx_pipe_set_host_sink": (None, [C.c_void_p, C.c_void_p]),
@@ -265,6 +266,9 @@ class RxPipe:
 
     def epoch_end(self, stream=None):
         _check(lib().clhip_rx_pipe_epoch_end(self.h, stream if stream is not None else current_stream()), "clhip_rx_pipe_epoch_end")
+
+    def unrun_stream(self, s, n_in):
+        _check(lib().clhip_rx_pipe_unrun_stream(self.h, s, n_in), "clhip_rx_pipe_unrun_stream")
 
     def out_count_stream(self, s, n_in):
         return lib().clhip_rx_pipe_out_count_stream(self.h, s, n_in)

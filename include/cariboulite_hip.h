@@ -302,6 +302,7 @@ int    clhip_rx_pipe_epoch_begin(clhip_rx_pipe *p);
 long   clhip_rx_pipe_run_range(clhip_rx_pipe *p, int first, int count, int in_kind, const void *d_in, size_t in_stride_elems,
                                size_t n_in, void *d_out, size_t out_stride_elems, void *stream);
 int    clhip_rx_pipe_epoch_end(clhip_rx_pipe *p, void *stream);
+int    clhip_rx_pipe_unrun_stream(clhip_rx_pipe *p, int s, size_t n_in);   /* take back stream s's range run of the OPEN epoch (n_in inputs): it may run again, or not at all */
 size_t clhip_rx_pipe_out_count_stream(const clhip_rx_pipe *p, int s, size_t n_in);
 unsigned long long clhip_rx_pipe_stream_total(const clhip_rx_pipe *p, int s);   /* inputs stream s has consumed */
 /* diagnostic: route config 2 through the s_memtime-stamped build (tools/phase_stamps.py); NULL = off */

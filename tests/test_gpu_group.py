@@ -56,7 +56,7 @@ def same(a, b):
 
 
 def run_script(S, n, fmt, args, dtype, out_shape, script, n_calls, channel_of=lambda i: "S1G" if i % 3 else "HiF", group_args=None,
-               num_elems=MTU, register=False):
+               num_elems=MTU, register=False, deep=False):
     """`script[(call, stream)]` = how that stream's batch of that call is damaged: ("slip", k) | ("lost",) | ("short", bytes) | ("none",).
     Runs the same byte streams through a group and through n lone devices; returns per call (group rets, single rets)."""
     gdevs, _ = make_devices(S, n, fmt, args, channel_of)
@@ -68,20 +68,9 @@ def run_script(S, n, fmt, args, dtype, out_shape, script, n_calls, channel_of=la
         grp.registerBuffers(gb)
     log = []
     for c in range(n_calls):
-        for i in range(n):
-            ch = 0 if channel_of(i) == "S1G" else 1
-            b = batch_bytes(i, c, ch)
-            what = script.get((c, i), ("good",))
-            if what[0] == "slip":
-                b = slipped(b, what[1])
-            elif what[0] == "lost":
-                b[:] = 0
-            elif what[0] == "short":
-                b = b[: what[1]]
-            elif what[0] == "none":
-                b = b[:0]
-            if b.size:
-                gdevs[i].feedSmiBytes(b); sdevs[i].feedSmiBytes(b)
+        for i in range(n if not (deep and c) else 0):      # (deep: every call's bytes are fed before the first call -- the group reads and computes ahead)
+            for cc in (range(n_calls) if deep else (c,)):
+                feed_one(S, gdevs, sdevs, i, cc, channel_of, script)
         for x in gb + sb:
             x[...] = np.nan if np.issubdtype(dtype, np.floating) else SENT if dtype == np.int16 else -86
         delivered, rets = grp.readStream(gb, num_elems)
@@ -92,6 +81,26 @@ def run_script(S, n, fmt, args, dtype, out_shape, script, n_calls, channel_of=la
             assert same(gb[i], sb[i]), f"call {c} stream {i} ({script.get((c, i), ('good',))}): group and lone device differ"
             assert gdevs[i].pendingSmiBytes() == sdevs[i].pendingSmiBytes(), (c, i)
         log.append((rets, [x.copy() for x in gb]))
+    return finish_script(grp, gdevs, sdevs, n, log)
+
+
+def feed_one(S, gdevs, sdevs, i, c, channel_of, script):
+    ch = 0 if channel_of(i) == "S1G" else 1
+    b = batch_bytes(i, c, ch)
+    what = script.get((c, i), ("good",))
+    if what[0] == "slip":
+        b = slipped(b, what[1])
+    elif what[0] == "lost":
+        b[:] = 0
+    elif what[0] == "short":
+        b = b[: what[1]]
+    elif what[0] == "none":
+        b = b[:0]
+    if b.size:
+        gdevs[i].feedSmiBytes(b); sdevs[i].feedSmiBytes(b)
+
+
+def finish_script(grp, gdevs, sdevs, n, log):
     gstats = [gdevs[i].smiStats() for i in range(n)]
     sstats = [sdevs[i].smiStats() for i in range(n)]
     for i in range(n):
@@ -338,14 +347,15 @@ def test_feeder_threads_race_the_group(S, orc):
         d.close()
 
 
-@pytest.mark.parametrize("readahead,staged", [("1", True), ("1", False), ("0", True)])
+@pytest.mark.parametrize("readahead,staged", [("2", True), ("2", False), ("1", True), ("1", False), ("0", True)])
 def test_read_ahead_between_calls_is_invisible(S, orc, readahead, staged):
-    """READAHEAD=1 (the default): behind a call's launches the group stages the members' NEXT batches in their FIFOs and copies them
-    in, so with FIFOs that hold several batches a call finds its input on the device already.  Whatever happens between two calls --
-    another numElems, a member read through its own device, a member flushed, a low-pass selected on one, a batch ahead that is out
-    of sync, the group closed with batches read ahead -- every stream delivers what its lone device delivers from the same bytes,
-    and counts the same bytes pending after every step."""
-    n, depth = 6, 10
+    """READAHEAD=1: before a call waits for its results the group stages the members' NEXT batches in their FIFOs and copies them in;
+    READAHEAD=2 (the default): ... and launches over them into its second mirror, so with FIFOs that hold several batches a call
+    finds its results computed.  Whatever happens between two calls -- another numElems, a member read through its own device, a
+    member flushed, a low-pass selected on one, client buffers registered and released, a batch ahead that is out of sync, the
+    group closed with batches read ahead -- every stream delivers what its lone device delivers from the same bytes, and counts
+    the same bytes pending after every step."""
+    n, depth = 6, 14
     args = {"FIR": "64:1000000", "RESAMP": "3/2"} if staged else None
     full = MTU * 3 // 2 if staged else MTU
     gdevs, gsts = make_devices(S, n, S.SOAPY_SDR_CF32, args, lambda i: "S1G" if i % 2 else "HiF")
@@ -383,7 +393,9 @@ def test_read_ahead_between_calls_is_invisible(S, orc, readahead, staged):
     assert both(MTU) == [full] * n                          # call 0: staged and copied in the call; batch 1 read ahead behind it
     assert both(MTU) == [full] * n                          # call 1: from the read-ahead
     st = grp.stats()
-    assert st["ahead_reads"] == (n if readahead == "1" else 0), st
+    assert st["ahead_reads"] == (n if readahead != "0" else 0), st
+    if readahead == "2":
+        assert st["launches"] == 3 * 4                          # call 0's own, and what calls 0 and 1 launched ahead: two lanes of 3 rows = 4 sub-batches
     # member 2 is read through its own device between two group calls: it gets batch 2 (which the group had read ahead), the group
     # batch 3.  (Plain formats only: the FIR's and the resampler's history of a member live in the group's pipe, not in its device's.)
     if not staged:
@@ -399,9 +411,15 @@ def test_read_ahead_between_calls_is_invisible(S, orc, readahead, staged):
     gdevs[5].setBandwidth(S.SOAPY_SDR_RX, 0, 100e3); sdevs[5].setBandwidth(S.SOAPY_SDR_RX, 0, 100e3)
     for k in range(4):
         both(MTU)                                           # ... over member 4's slipped and member 1's lost batch
+    # client buffers are registered while results computed ahead lie in the mirror, and released again
+    grp.registerBuffers(gb)
+    both(MTU); both(MTU)
+    assert grp.stats()["direct_reads"] > 0
+    grp.unregisterBuffers()
+    both(MTU); both(MTU)
     assert grp.stats()["errors"] == 0
-    if readahead == "1":
-        assert grp.stats()["ahead_reads"] > st["ahead_reads"]
+    if readahead != "0":
+        assert grp.stats()["ahead_reads"] > st["ahead_reads"] + 2 * n
     # closed with batches read ahead: they are pending on the devices, which read on alone
     pend = [d.pendingSmiBytes() for d in gdevs]
     assert pend == [d.pendingSmiBytes() for d in sdevs] and max(pend) > 0
@@ -415,3 +433,17 @@ def test_read_ahead_between_calls_is_invisible(S, orc, readahead, staged):
         check()
     for d in gdevs + sdevs:
         d.close()
+
+
+@pytest.mark.parametrize("fmt,dtype,args,shape", [("CF32", np.float32, {"FIR": "64:1000000", "RESAMP": "3/2"}, (MTU * 3 // 2 + 8, 2)),
+                                                   ("CS16", np.int16, None, (MTU + 2, 2)),
+                                                   ("CF32", np.float32, {"FIR": "64:100000", "DEMOD": "FM"}, (MTU + 8,))])
+def test_32_streams_with_every_batch_pending_beforehand(S, fmt, dtype, args, shape):
+    """The FIFOs hold ALL the calls' bytes before the first call (a client that reads slower than its boards deliver): the group reads
+    and computes every next batch ahead -- over slipped and lost batches, a short one and a missing one in the middle of the streams
+    (behind which the members' batches are out of step with their neighbours') -- and still every stream equals its lone device call
+    for call, in output, return value, pending bytes and counters."""
+    n, calls = 32, 7
+    script = {(1, 3): ("slip", 3), (2, 17): ("slip", 6), (2, 9): ("lost",), (3, 5): ("short", NB // 2), (3, 21): ("none",), (4, 30): ("slip", 9)}
+    log, st = run_script(S, n, getattr(S, "SOAPY_SDR_" + fmt), args, dtype, shape, script, calls, deep=True)
+    assert st["errors"] == 0 and st["ahead_reads"] >= (calls - 3) * (n - 6), st

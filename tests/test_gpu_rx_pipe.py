@@ -406,3 +406,46 @@ def test_streams_of_one_pipe_advance_independently(G, orc):
         multi.run_range(0, 2, hip.PIPE_IN_SMI_WORDS, w[0], w.shape[1], n, out[0], stride_out)
     multi.epoch_end()
     torch.cuda.synchronize()
+
+
+def test_a_range_run_of_the_open_epoch_can_be_taken_back(G, orc):
+    """clhip_rx_pipe_unrun_stream (what a stream group does with results it computed ahead of a client who then went another way): in
+    an epoch all four streams run; the run of stream 1 is taken back and made again with OTHER input, that of stream 2 is taken back
+    and not made again -- afterwards every stream continues exactly like a lone pipe that was given what finally counted."""
+    import torch
+    from cariboulite_amd import hip, synth
+    t = load_golden("taps.npz")
+    ns, n = 4, 2 * 4096
+    multi = hip.RxPipe(ns, 0, t["fir64_c2"], t["rs_3_2"], 3, 2, hip.PIPE_OUT_IQ)
+    lone = [hip.RxPipe(1, 0, t["fir64_c2"], t["rs_3_2"], 3, 2, hip.PIPE_OUT_IQ) for _ in range(ns)]
+    stride_out = n * 3 // 2 + 32
+    def words(call):
+        return torch.stack([torch.from_numpy(np.concatenate([synth.smi_stream_bytes(n, 0, stream=70 + s, n0=call * n)[0], np.zeros(64, np.uint8)]).view(np.int32).copy()) for s in range(ns)]).to(G.DEV)
+    def epoch(w_multi, counted, unrun=(), rerun=None):
+        """counted[s] = the words row stream s finally consumed in this epoch (None: nothing)"""
+        out = torch.full((ns, stride_out, 2), float("nan"), dtype=torch.float32, device=G.DEV)
+        ref = torch.full((ns, stride_out, 2), float("nan"), dtype=torch.float32, device=G.DEV)
+        multi.epoch_begin()
+        multi.run_range(0, ns, hip.PIPE_IN_SMI_WORDS, w_multi[0], w_multi.shape[1], n, out[0], stride_out)
+        for s in unrun:
+            multi.unrun_stream(s, n)
+            out[s] = float("nan")
+        if rerun is not None:
+            s, row = rerun
+            multi.run_range(s, 1, hip.PIPE_IN_SMI_WORDS, row, 0, n, out[s], 0)
+        multi.epoch_end()
+        for s in range(ns):
+            if counted[s] is not None:
+                lone[s].run(hip.PIPE_IN_SMI_WORDS, counted[s], 0, n, ref[s], 0)
+        torch.cuda.synchronize()
+        assert out.cpu().numpy().tobytes() == ref.cpu().numpy().tobytes()
+    w0, w1, w2, other = words(0), words(1), words(2), words(7)
+    epoch(w0, [w0[s] for s in range(ns)])
+    epoch(w1, [w1[0], other[1], None, w1[3]], unrun=(1, 2), rerun=(1, other[1]))
+    assert [multi.stream_total(s) for s in range(ns)] == [2 * n, 2 * n, n, 2 * n]
+    epoch(w2, [w2[s] for s in range(ns)])                  # ... and all of them go on from the state that counted
+    multi.epoch_begin()
+    with pytest.raises(RuntimeError, match="no run of the open epoch"):
+        multi.unrun_stream(0, n)
+    multi.epoch_end()
+    torch.cuda.synchronize()
