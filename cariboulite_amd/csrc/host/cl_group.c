@@ -49,6 +49,7 @@ typedef struct {
     size_t elem_bytes;                    /* bytes per output element */
     int up, down;
     int n; int *member;                   /* indices into the group's device table */
+    int sub;                              /* streams per sub-batch */
     clhip_rx_pipe *pipe;                  /* ROUTE_PIPE */
     size_t in_stride;                     /* bytes per row of d_in */
     uint8_t *d_in[3]; int cur_in, prev_in, next_in;   /* raw words of this call / of the call before it / read ahead for the next one (rotating) */
@@ -78,7 +79,7 @@ struct cl_group {
     size_t n; cl_device **dev;
     int *lane_of, *row_of;                /* member -> lane / row */
     int n_lanes; lane_t *lane;
-    int sub;                              /* streams per sub-batch */
+    int sub;                              /* kwarg SUBBATCH: streams per sub-batch for every lane (0: by the lane's output size, cl_group_make) */
     int readahead;                        /* kwarg READAHEAD: 0 = none; 1 = before a call waits for its results the NEXT call's batches are staged and copied in;
                                            * 2 (default) = ... and launched over, into the second mirror */
     size_t n_sub;                         /* sub-batches over all lanes */
@@ -296,7 +297,7 @@ cl_group *cl_group_make(cl_device *const *devs, size_t n, const char *const *key
     if (!g->dev || !g->lane_of || !g->row_of || !g->lane || !g->reg_base || !g->reg_len || !g->has_reg) { cl_group_unmake(g); return NULL; }
     memcpy(g->dev, devs, n * sizeof *g->dev);
     const char *sub = kwget(keys, vals, n_kwargs, "SUBBATCH"), *ct = kwget(keys, vals, n_kwargs, "COPY_THREADS");
-    g->sub = sub && atoi(sub) > 0 ? atoi(sub) : 4;     /* profiles/r04/group_sweep_*.txt: 2 / 4 / 8 / 16 -> 3275 / 3400 / 3100 / 2700 Msamples/s (FIR64 + 3/2, 32 streams) */
+    g->sub = sub && atoi(sub) > 0 ? atoi(sub) : 0;     /* 0: by the lane's route (below) */
     const char *is = kwget(keys, vals, n_kwargs, "INGEST_STREAMS");
     g->n_in = is && atoi(is) >= 1 && atoi(is) <= GRP_MAX_IN ? atoi(is) : 2;     /* tools/group_ab.py, medians of 9 interleaved reps: CS16 4989 / 6508 / 5443 Msamples/s at 1 / 2 / 4, FIR64 + 3/2 3116 / 3131 / 2854 */
     g->ev_per = g->n_in + 2;
@@ -373,7 +374,11 @@ cl_group *cl_group_make(cl_device *const *devs, size_t n, const char *const *key
             cl_group_unmake(g);
             return NULL;
         }
-        n_sub += ((size_t)l->n + (size_t)g->sub - 1) / (size_t)g->sub;
+        /* streams per launch.  Interleaved A/B with results computed ahead (profiles/r04/group_ab_subbatch_results_ahead.txt), 4 / 8 / 16:
+         * FIR64 + 3/2 (1.5 MiB out per stream) 3994 / 3872 / 3859 Msamples/s; CS16 (0.5 MiB) 9874 / 10396 / 10119, FIR64 + FM demod (0.5 MiB)
+         * 9489 / 10269 / 10343, CF32 (1 MiB) 5773 / 6034 / 6050 -- short launches (43 us for four CS16 streams) lie 6 ... 10 us apart */
+        l->sub = g->sub ? g->sub : l->out_stride * l->elem_bytes >= ((size_t)3 << 19) ? 4 : 8;
+        n_sub += ((size_t)l->n + (size_t)l->sub - 1) / (size_t)l->sub;
     }
     for (int k = 0; k < g->n_in; k++) g->s_in[k] = clhip_stream_create();
     g->s_k = clhip_stream_create(); g->s_out = clhip_stream_create();
@@ -626,7 +631,7 @@ static int single_member(cl_group *g, lane_t *l, int row, void *out, size_t numE
 
 static void **ev_of(const cl_group *g, const lane_t *l, int set, int a)
 {
-    return g->ev + ((size_t)set * g->n_sub + l->sub0 + (size_t)(a / g->sub)) * (size_t)g->ev_per;
+    return g->ev + ((size_t)set * g->n_sub + l->sub0 + (size_t)(a / l->sub)) * (size_t)g->ev_per;
 }
 
 /* The launches of one sub-batch over the rows [a, e) marked in `run` (maximal runs of neighbours: one fused launch each / one unpack
@@ -684,10 +689,10 @@ int cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems, int *r
         l->epoch_open = 1;
         int waits_primed = 0;
         uint8_t *in = l->d_in[l->cur_in];
-        for (int a = 0; a < l->n && !hard; a += g->sub) {
-            const int e = a + g->sub < l->n ? a + g->sub : l->n;
+        for (int a = 0; a < l->n && !hard; a += l->sub) {
+            const int e = a + l->sub < l->n ? a + l->sub : l->n;
             void **ev_in = ev_of(g, l, l->set, a), *ev_k = ev_in[g->n_in], *ev_out = ev_in[g->n_in + 1];
-            const size_t b = l->sub0 + (size_t)(a / g->sub);
+            const size_t b = l->sub0 + (size_t)(a / l->sub);
             void *s_in = g->s_in[b % (size_t)g->n_in];          /* the sub-batches take turns on the ingest streams */
             int from_ahead = 0, any_run = 0, any_copy = 0;
             l->queued++;
@@ -782,8 +787,8 @@ int cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems, int *r
          * with a registered client buffer among their members wait for the call (the copy engine needs the client's pointer) */
         if (l->pipe) { if (clhip_rx_pipe_epoch_begin(l->pipe)) { hard = 1; break; } l->epoch_open = 1; }
         int waited = 0;
-        for (int a = 0; a < l->n && !hard; a += g->sub) {
-            const int e = a + g->sub < l->n ? a + g->sub : l->n;
+        for (int a = 0; a < l->n && !hard; a += l->sub) {
+            const int e = a + l->sub < l->n ? a + l->sub : l->n;
             int run = 0;
             for (int r = a; r < e; r++) {
                 if (g->has_reg[l->member[r]]) { run = 0; break; }
@@ -801,8 +806,8 @@ int cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems, int *r
     for (int k = 0; k < g->n_lanes; k++) {
         lane_t *l = &g->lane[k];
         int sb = 0;
-        for (int a = 0; a < l->n; a += g->sub, sb++) {
-            const int e = a + g->sub < l->n ? a + g->sub : l->n;
+        for (int a = 0; a < l->n; a += l->sub, sb++) {
+            const int e = a + l->sub < l->n ? a + l->sub : l->n;
             int any = 0;
             for (int r = a; r < e; r++) any |= l->fast[r];
             if (!any) continue;

@@ -581,16 +581,19 @@ void   cl_stream_set_iir_poll_bound(cl_stream *stream, int polls);
  * route inside the same call.
  * Make the group AFTER cl_setupStream of every member (RX); members are grouped by channel type and stream configuration
  * (format, FIR / RESAMP / DEMOD kwargs); a group with extension stages owns their state (one n-stream pipe per
- * configuration), so its members are read through the group from then on.  kwargs: SUBBATCH=<streams per launch> (4),
+ * configuration), so its members are read through the group from then on.  kwargs: SUBBATCH=<streams per launch> (4 where a stream delivers 1.5 MiB or more per call, else 8),
  * COPY_THREADS=<n> (2; 0 = the caller copies), SINK=copy (the sub-batch's outputs leave through
  * a device buffer and the copy engine instead of being stored into the mapped pinned mirror by the kernel itself),
  * INGEST_STREAMS=<1 .. 8> (HIP streams the sub-batches' copies in take turns on; 2), SLAB_MB=<MiB> (pinned FIFO room per member
  * in the group's ONE slab, 8: the members' byte FIFOs live there from cl_group_make to cl_group_unmake, a slice each, so that the
  * batches of members that are fed and read in step lie one stride apart and travel as one 2-D copy per sub-batch; a FIFO that
- * outgrows its slice moves into a buffer of its own and its batches come in by copies of their own; 0 = no slab), READAHEAD=<0|1>
- * (1: behind a call's launches the members' NEXT batches, where they are pending already, are staged in their FIFOs and copied in, so
- * that the next call starts with its launches; such bytes count as pending until that call takes them, and any other reader of
- * the member's device -- its own readStream, a flush, a call with another numElems -- finds them pending, in order).  Returns the number of streams that delivered (> 0 elements), or -1 on a
+ * outgrows its slice moves into a buffer of its own and its batches come in by copies of their own; 0 = no slab), READAHEAD=<0|1|2>
+ * (2, the default: before a call waits for its own results, the members' NEXT batches -- where they are pending already and in sync --
+ * are staged in their FIFOs, copied in and launched over into a second pinned mirror, so that the next call finds its results
+ * computed and the GPU does not wait for the host between two calls; 1: staged and copied in only; 0: nothing ahead.  Bytes read
+ * ahead count as pending until that call takes them, and any other reader of the member's device -- its own readStream, a flush, a
+ * call with another numElems -- finds them pending, in order; a run made ahead of a client who then goes another way is taken
+ * back).  Returns the number of streams that delivered (> 0 elements), or -1 on a
  * runtime error (cl_group_last_error; NULL group = the last cl_group_make failure). */
 typedef struct cl_group cl_group;
 typedef struct {

@@ -68,7 +68,10 @@ def run_case(name, a):
         bufs = [np.zeros(shape, dt) for _ in range(n)]
         grp = None
         if mode != "one_by_one":
-            grp = S.Group(devs, {"SUBBATCH": str(a.sub), "COPY_THREADS": str(a.threads), "SINK": a.sink, "INGEST_STREAMS": str(a.ingest)})
+            kw = {"COPY_THREADS": str(a.threads), "SINK": a.sink, "INGEST_STREAMS": str(a.ingest)}
+            if a.sub:
+                kw["SUBBATCH"] = str(a.sub)                # (0: the group's default for the lane's route)
+            grp = S.Group(devs, kw)
             if mode == "registered":
                 grp.registerBuffers(bufs)
         best, got_total = None, 0
@@ -112,7 +115,7 @@ def main():
     ap.add_argument("--streams", type=int, default=32)
     ap.add_argument("--calls", type=int, default=12)
     ap.add_argument("--reps", type=int, default=3)
-    ap.add_argument("--sub", type=int, default=4)
+    ap.add_argument("--sub", type=int, default=0)
     ap.add_argument("--threads", type=int, default=2)
     ap.add_argument("--sink", default="mapped", choices=["mapped", "copy"])
     ap.add_argument("--ingest", type=int, default=2, help="ingest HIP streams (1 .. 8)")

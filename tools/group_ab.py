@@ -11,7 +11,8 @@ MTU = 131072
 case, reps, K = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 axes = [(a.split("=")[0], a.split("=")[1].split(",")) for a in sys.argv[4:]]
 fmt, dt, width, args = {"cs16": ("CS16", np.int16, 2, None), "cf32": ("CF32", np.float32, 2, None),
-                        "c2": ("CF32", np.float32, 2, {"FIR": "64:1000000", "RESAMP": "3/2"})}[case]
+                        "c2": ("CF32", np.float32, 2, {"FIR": "64:1000000", "RESAMP": "3/2"}),
+                        "fm": ("CF32", np.float32, 1, {"FIR": "64:100000", "DEMOD": "FM"})}[case]
 n = 32
 words = [synth.smi_stream_bytes(K * MTU, i % 2, stream=i)[0] for i in range(4)]
 cfgs = []
@@ -22,7 +23,7 @@ for combo in itertools.product(*[v for _, v in axes]):
         d = S.Device(dict(driver="Cariboulite", channel="S1G" if i % 2 == 0 else "HiF"))
         d.activateStream(d.setupStream(S.SOAPY_SDR_RX, fmt, args=args))
         devs.append(d)
-    cfgs.append((kw, devs, S.Group(devs, kw), [np.zeros((MTU * 3 // 2 + 8, width), dt) for _ in range(n)], []))
+    cfgs.append((kw, devs, S.Group(devs, kw), [np.zeros((MTU * 3 // 2 + 8, width) if width > 1 else (MTU * 3 // 2 + 8,), dt) for _ in range(n)], []))
 for rep in range(reps + 1):
     for kw, devs, grp, bufs, times in cfgs:
         for i, d in enumerate(devs):
