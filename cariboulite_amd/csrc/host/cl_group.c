@@ -83,6 +83,7 @@ struct cl_group {
     int readahead;                        /* kwarg READAHEAD: 0 = none; 1 = before a call waits for its results the NEXT call's batches are staged and copied in;
                                            * 2 (default) = ... and launched over, into the second mirror */
     size_t n_sub;                         /* sub-batches over all lanes */
+    int stale;                            /* work made ahead has just been given up: it is waited for before anything takes its place (settle) */
     int sink_mapped;                      /* kwarg SINK: "mapped" (default) = the sub-batch's kernel stores into the mapped pinned mirror itself; "copy" = device buffer + copy engine */
 #define GRP_MAX_IN 8
     void *s_in[GRP_MAX_IN], *s_k, *s_out; /* ingest streams taken in turn by the members' copies: a copy's fixed cost (~10 us between two copies of one
@@ -121,8 +122,9 @@ __attribute__((target("avx2"))) static void copy_stream_avx2(uint8_t *dst, const
 
 static void copy_out(uint8_t *dst, const uint8_t *src, size_t n)
 {
-    static int avx2 = -1;
-    if (avx2 < 0) avx2 = __builtin_cpu_supports("avx2") ? 1 : 0;
+    static int avx2_known = -1;                             /* (several threads may find out at once: the same answer, stored atomically) */
+    int avx2 = __atomic_load_n(&avx2_known, __ATOMIC_RELAXED);
+    if (avx2 < 0) { avx2 = __builtin_cpu_supports("avx2") ? 1 : 0; __atomic_store_n(&avx2_known, avx2, __ATOMIC_RELAXED); }
     if (avx2 && n >= 4096) copy_stream_avx2(dst, src, n); else memcpy(dst, src, n);
 }
 
@@ -412,6 +414,17 @@ cl_group *cl_group_make(cl_device *const *devs, size_t n, const char *const *key
 size_t cl_group_size(const cl_group *g) { return g ? g->n : 0; }
 void cl_group_getStats(const cl_group *g, cl_group_stats *out) { if (out) { if (g) *out = g->stats; else memset(out, 0, sizeof *out); } }
 
+/* Work made ahead that nobody will use -- a copy into an input row, a launch that reads that row and an offsets table and writes a
+ * mirror row -- may still be queued when its row is staged, copied and launched over afresh, or when the buffers come round again.
+ * Giving up work made ahead is rare (the client went another way): the streams are simply drained before anything takes its place. */
+static void settle(cl_group *g)
+{
+    if (!g->stale) return;
+    for (int k = 0; k < g->n_in; k++) if (g->s_in[k]) clhip_stream_sync(g->s_in[k]);
+    if (g->s_k) clhip_stream_sync(g->s_k);
+    g->stale = 0;
+}
+
 /* everything read or computed ahead is given back: the bytes are pending in the members' FIFOs again, the runs are taken back */
 static void ahead_cancel_all(cl_group *g)
 {
@@ -423,8 +436,10 @@ static void ahead_cancel_all(cl_group *g)
             if (smi->foreign_ahead == l->primed[r] && smi->foreign_epoch == l->primed_epoch[r]) cl_smi_foreign_cancel(smi);
             if (l->done_ahead[r] && l->pipe) clhip_rx_pipe_unrun_stream(l->pipe, r, l->primed[r] / 4);
             l->primed[r] = 0; l->done_ahead[r] = 0;
+            g->stale = 1;
         }
     }
+    settle(g);
 }
 
 /* Client buffers the members' outputs may be written into by the copy engine directly (no pinned mirror, no memcpy): one
@@ -539,10 +554,13 @@ static int try_stage(cl_group *g, lane_t *l, int row, size_t want, void *s_in)
         /* (a run made ahead has advanced the stream's counter already: its phase was checked when it was made) */
         if (intact && had == want && qualifies(g, l, row, want) && (was_done || on_phase_0(l, row))) {
             smi->foreign_ahead = 0;                            /* this call's batch now: staged, the oldest unconfirmed bytes */
+            cl_smi_ahead_note(smi);
             return was_done ? 3 : 2;
         }
         if (intact) cl_smi_foreign_cancel(smi);                 /* another length, or off the batched route: pending again, in order */
         if (was_done && l->pipe) clhip_rx_pipe_unrun_stream(l->pipe, row, had / 4);
+        g->stale = 1;
+        settle(g);
     }
     l->src[row] = NULL;
     if (!qualifies(g, l, row, want) || !on_phase_0(l, row)) return 0;
@@ -778,7 +796,7 @@ int cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems, int *r
         for (int r = 0; r < l->n; r++) {
             if (!l->ahead_mark[r]) continue;                  /* (a row whose copy could not be queued was unstaged and unmarked) */
             cl_smi *smi = g->dev[l->member[r]]->smi;
-            smi->foreign_ahead = l->want;
+            smi->foreign_ahead = l->want; cl_smi_ahead_note(smi);
             l->primed[r] = l->want; l->primed_epoch[r] = smi->foreign_epoch;
         }
         hard = hard || clhip_event_record(l->ev_primed, s_p);
@@ -823,6 +841,7 @@ int cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems, int *r
                         cl_smi_foreign_cancel(dev->smi);
                         if (l->done_ahead[r] && l->pipe) clhip_rx_pipe_unrun_stream(l->pipe, r, l->primed[r] / 4);
                         l->primed[r] = 0; l->done_ahead[r] = 0;
+                        g->stale = 1;
                     }
                     pthread_mutex_lock(&dev->smi->fifo_mu);
                     cl_fifo_unstage(&dev->smi->rx, l->len[r]);
@@ -852,6 +871,7 @@ int cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems, int *r
         clhip_stream_sync(g->s_k); clhip_stream_sync(g->s_out);
         if (!g->err[0]) cl_seterr(g->err, sizeof g->err, "cl_group_readStream: %s", clhip_last_error());
         ahead_cancel_all(g);
+        g->stale = 0;                                      /* (everything was drained above) */
         for (int k = 0; k < g->n_lanes; k++)
             if (g->lane[k].pipe && g->lane[k].epoch_open) { clhip_rx_pipe_epoch_end(g->lane[k].pipe, g->s_k); g->lane[k].epoch_open = 0; }
         g->stats.errors++;

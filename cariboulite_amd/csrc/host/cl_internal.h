@@ -105,6 +105,7 @@ struct cl_smi {
      * bytes of the FIFO.  Every entry of the seam's own readers gives them back first (cl_smi_foreign_cancel) and bumps the epoch, so that
      * the group can tell that its read-ahead is void */
     size_t foreign_ahead; unsigned foreign_epoch;
+    size_t ahead_bytes;          /* (atomic) what the consumer holds staged ahead, its own read-ahead + a group's: cl_smi_pending_bytes counts it, from any thread */
     int ra_pending; size_t ra_samples;     /* between cl_smi_ra_launch and cl_smi_ra_finish */
     size_t inplace_len;                    /* bytes of a one-read() call staged in place on `stream`: confirmed once that stream has been synchronised */
     /* cl_smi_ra_launch's short cut for a call that is ONE read() the host has seen to be in sync: set want_words before the
@@ -128,7 +129,8 @@ int cl_smi_read_device_ra(cl_smi *dev, int channel, size_t length_samples, int16
 long cl_smi_ra_launch(cl_smi *dev, int channel, size_t length_samples, int16_t *d_iq);   /* its two halves: the caller may queue */
 int cl_smi_ra_finish(cl_smi *dev);                                                      /* work on the seam's stream in between */
 void cl_smi_readahead_cancel(cl_smi *dev);
-void cl_smi_foreign_cancel(cl_smi *dev);                 /* a group's read-ahead on this seam is given back (pending again) */
+void cl_smi_foreign_cancel(cl_smi *dev);
+void cl_smi_ahead_note(cl_smi *dev);     /* after every change of ahead / foreign_ahead */                 /* a group's read-ahead on this seam is given back (pending again) */
 int cl_smi_head_in_sync(const uint8_t *chunk, size_t len);   /* offs == 0 decided on the host from the staged bytes */
 /* poll(POLLIN, timeout) on the injected byte stream: returns 1 when bytes are pending (at once or within timeout_us) */
 int cl_smi_wait_bytes(cl_smi *dev, long timeout_us);     /* bytes staged ahead go back to the front of the FIFO */

@@ -258,13 +258,29 @@ int cl_smi_wait_bytes(cl_smi *dev, long timeout_us)
     if (until.tv_nsec >= 1000000000L) { until.tv_sec++; until.tv_nsec -= 1000000000L; }
     pthread_mutex_lock(&dev->fifo_mu);
     int expired = 0;
-    while (cl_fifo_pending(&dev->rx) == 0 && !dev->ahead.valid && !dev->foreign_ahead && !expired)
+    while (cl_fifo_pending(&dev->rx) == 0 && !__atomic_load_n(&dev->ahead_bytes, __ATOMIC_RELAXED) && !expired)
         expired = pthread_cond_timedwait(&dev->fifo_fed, &dev->fifo_mu, &until) != 0;
-    const int ready = cl_fifo_pending(&dev->rx) != 0 || dev->ahead.valid || dev->foreign_ahead;
+    const int ready = cl_fifo_pending(&dev->rx) != 0 || __atomic_load_n(&dev->ahead_bytes, __ATOMIC_RELAXED);
     pthread_mutex_unlock(&dev->fifo_mu);
     return ready;
 }
-size_t cl_smi_pending_bytes(const cl_smi *dev) { return cl_fifo_pending(&dev->rx) + (dev->ahead.valid ? dev->ahead.len : 0) + dev->foreign_ahead; }   /* staged ahead = still pending */
+
+/* Any thread may ask (a feeder pacing itself, a monitor): the FIFO's counters are read under its lock, what the consumer has staged
+ * ahead of its client -- still pending as far as anybody outside can tell -- from a word the consumer publishes. */
+size_t cl_smi_pending_bytes(const cl_smi *dev)
+{
+    cl_smi *d = (cl_smi *)dev;
+    pthread_mutex_lock(&d->fifo_mu);
+    const size_t n = cl_fifo_pending(&d->rx);
+    pthread_mutex_unlock(&d->fifo_mu);
+    return n + __atomic_load_n(&d->ahead_bytes, __ATOMIC_RELAXED);
+}
+
+/* the consumer publishes what it holds staged ahead (its own read-ahead + a stream group's) after every change */
+void cl_smi_ahead_note(cl_smi *dev)
+{
+    __atomic_store_n(&dev->ahead_bytes, (dev->ahead.valid ? dev->ahead.len : 0) + dev->foreign_ahead, __ATOMIC_RELAXED);
+}
 void   cl_smi_set_max_read(cl_smi *dev, size_t m) { dev->max_read = m; }
 /* The TX FIFO has one producer (the write calls: reserve, fill by DMA or kernel, commit) and one consumer (the drain calls),
  * which may be two threads: its bookkeeping moves under fifo_mu; the bytes of an open reservation lie behind everything a pop
@@ -607,21 +623,27 @@ static size_t ra_stage(cl_smi *dev, int slot, size_t want, int *in_sync)
 void cl_smi_foreign_cancel(cl_smi *dev)
 {
     if (!dev->foreign_ahead) return;
+    /* (the group's copy of these bytes may still be reading them: once they are pending again somebody else consumes them and a feeder
+     * may write over them -- the stale copy is waited for first; giving up a read-ahead is rare) */
+    if (dev->rx.dma_stream[2]) clhip_stream_sync(dev->rx.dma_stream[2]);
     pthread_mutex_lock(&dev->fifo_mu);
     cl_fifo_unstage(&dev->rx, dev->foreign_ahead);             /* the newest staged bytes: still in place, pending again */
     pthread_mutex_unlock(&dev->fifo_mu);
     dev->foreign_ahead = 0;
     dev->foreign_epoch++;
+    cl_smi_ahead_note(dev);
 }
 
 void cl_smi_readahead_cancel(cl_smi *dev)
 {
     cl_smi_foreign_cancel(dev);
     if (!dev->ahead.valid) return;
+    if (dev->cstream) clhip_stream_sync(dev->cstream);          /* (the copy that is reading them, as above) */
     pthread_mutex_lock(&dev->fifo_mu);
     cl_fifo_unstage(&dev->rx, dev->ahead.len);                 /* still in place: pending again */
     pthread_mutex_unlock(&dev->fifo_mu);
     dev->ahead.valid = 0;
+    cl_smi_ahead_note(dev);
 }
 
 /* caribou_smi_read's chunk loop (caribou_smi.c:643-679) for a reader thread: chunk k is analysed on the seam's
@@ -724,6 +746,7 @@ long cl_smi_ra_launch(cl_smi *dev, int channel, size_t length_samples, int16_t *
         size_t got; int slot, head_ok = 0;
         if (dev->ahead.valid) {
             slot = dev->ahead.slot; got = dev->ahead.len; head_ok = dev->ahead.head_ok; dev->ahead.valid = 0;
+            cl_smi_ahead_note(dev);
             if (got > want) {                                  /* staged for a longer read than this one: the tail is pending again */
                 pthread_mutex_lock(&dev->fifo_mu);
                 cl_fifo_unstage(&dev->rx, got - want);         /* (the newest staged bytes: nothing was staged behind them) */
@@ -742,7 +765,7 @@ long cl_smi_ra_launch(cl_smi *dev, int channel, size_t length_samples, int16_t *
         const size_t rest = left - got, want_next = rest ? (rest < cap_read ? rest : cap_read) : cap_read;
         int ahead_ok = 0;
         const size_t a = ra_stage(dev, slot_next, want_next, &ahead_ok);
-        if (a) { dev->ahead.valid = 1; dev->ahead.slot = slot_next; dev->ahead.len = a; dev->ahead.head_ok = ahead_ok; }
+        if (a) { dev->ahead.valid = 1; dev->ahead.slot = slot_next; dev->ahead.len = a; dev->ahead.head_ok = ahead_ok; cl_smi_ahead_note(dev); }
         if (want_words && own && read_so_far == 0 && got == left && head_ok && !(got & 15)) {
             /* The call is this one read(), and the host has seen the sync pattern on its first four words: offset 0
              * (caribou_smi.c:235-292) without asking the device, every slot written.  No launch here at all: the caller's

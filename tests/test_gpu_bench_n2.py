@@ -42,6 +42,16 @@ def test_two_ranks_sharded_config4():
 
 
 @pytest.mark.gpu
+def test_two_ranks_at_the_soapy_boundary():
+    """--pcie: each rank owns a stream group of its own (8 Soapy devices here), feeds it host bytes and reads host samples; the
+    line's value is both ranks' samples over the max-over-ranks time."""
+    d = _run(["--pcie", "--pcie-streams", "8"])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["roofline"]["bound"] == "pcie"
+    assert d["config"]["streams_per_gpu"] == 8 and d["config"]["group"]["errors"] == 0 and d["config"]["group"]["single_reads"] == 0
+    assert abs(d["value"] - 2 * 8 * 131072 / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 1e-2
+
+
+@pytest.mark.gpu
 def test_rccl_calls_of_the_n_gt_1_path_at_world_size_one():
     """The driver's N = 2, 4, 8 runs use the nccl (= RCCL) backend: init_process_group with a device id, barrier, the max-reduction on
     a DEVICE tensor, destroy.  Two ranks cannot share one GPU under RCCL, so those calls run here at world size 1 under

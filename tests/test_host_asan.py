@@ -4,6 +4,8 @@ AddressSanitizer + UBSan on the CPU build, driven by random op sequences against
 import os
 import subprocess
 
+import pytest
+
 from conftest import ROOT
 
 
@@ -56,3 +58,24 @@ def test_group_copy_pool_under_tsan(tmp_path):
     env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1:exitcode=66")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "group pool tsan harness ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.parametrize("sanitizer", ["thread", "address,undefined"])
+def test_stream_group_host_side_over_a_threaded_hip_model(tmp_path, sanitizer):
+    """cl_group.c + cl_smi.c + cl_soapy.c over tests/cpp/hip_mock/clhip_mock.c, a CPU model of the clhip_* layer in which every HIP
+    stream is a thread: what the group queues (copies out of the members' FIFOs, launches that read offset tables and write the
+    mirrors, the next call's batches read and computed AHEAD) runs concurrently with the caller, with a feeder thread per member and
+    with the copy threads, while the client reads members through their own devices, asks for half batches and registers / releases
+    its buffers in between.  ThreadSanitizer: a host write under queued work is a race; AddressSanitizer: a buffer freed or
+    overrun under queued work.  Every delivered sample is checked against what was fed (tests/cpp/test_group_mock.c)."""
+    host = os.path.join(ROOT, "cariboulite_amd", "csrc", "host")
+    exe = str(tmp_path / "group_mock")
+    cmd = ["gcc", "-std=gnu11", "-O1", "-g", f"-fsanitize={sanitizer}", "-fno-omit-frame-pointer",
+           os.path.join(ROOT, "tests", "cpp", "test_group_mock.c"), os.path.join(ROOT, "tests", "cpp", "hip_mock", "clhip_mock.c"),
+           os.path.join(ROOT, "oracle", "cl_oracle.c")] + [os.path.join(host, f) for f in ("cl_group.c", "cl_smi.c", "cl_soapy.c", "cl_ring.c")] + \
+          ["-I", host, "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "oracle"), "-lpthread", "-lm", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1:exitcode=66", ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="halt_on_error=1")
+    r = subprocess.run([exe, "30" if sanitizer == "thread" else "40"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "group mock harness ok" in r.stdout, r.stdout[-2000:] + r.stderr[-6000:]
