@@ -158,7 +158,7 @@ struct cl_stream {
     cl_device *dev;
     int format;                  /* CL_FORMAT_*                                 */
     int native_dir;              /* CL_SOAPY_SDR_RX / TX (setInnerStreamType)    */
-    int stream_active;
+    int stream_active;                     /* (atomic: read by the reader thread) */
     size_t mtu_size;
     int filter_type;             /* CL_DIGFILT_*                                 */
     double sos[3][15];           /* filt20 / filt50 / filt100: 3 biquads x {b0,b1,b2,a1,a2} */
@@ -181,7 +181,7 @@ struct cl_stream {
     int use_async;
     cl_ring *rx_queue;
     pthread_t reader_thread;
-    volatile int reader_thread_running;
+    int reader_thread_running;             /* (atomic: the client's thread and the reader thread) */
     int16_t *d_native1;                  /* interm_native_buffer1 of the reference, on the device (reader thread's) */
     void *astream;                       /* consumer-side HIP stream and linear CS16 device buffer: the reader */
     int16_t *d_aiq; size_t aiq_cap;      /* thread owns the cl_smi ones */

@@ -83,8 +83,8 @@ static void *reader_thread_fn(void *arg)
 {
     cl_stream *st = (cl_stream *)arg;
     cl_smi *smi = st->dev->smi;
-    while (st->reader_thread_running) {
-        if (!st->stream_active) { cl_smi_readahead_cancel(smi); usleep(10000); continue; }   /* :24-28 */
+    while (__atomic_load_n(&st->reader_thread_running, __ATOMIC_ACQUIRE)) {
+        if (!__atomic_load_n(&st->stream_active, __ATOMIC_ACQUIRE)) { cl_smi_readahead_cancel(smi); usleep(10000); continue; }   /* :24-28 */
         /* cariboulite_radio_read_samples(radio, interm_native_buffer1, ..., mtu_size)  :30-33, then
          * rx_queue->put(interm_native_buffer1, ret)  :44 -- the put's device-to-device copy is queued behind the
          * analysis on the seam's stream, so the two cost one synchronisation; a read that then turns out to have
@@ -121,8 +121,8 @@ static void zc_drop_all(cl_stream *st);
 
 static void stream_stop_async(cl_stream *st)
 {
-    if (st->reader_thread_running) {
-        st->reader_thread_running = 0;
+    if (__atomic_load_n(&st->reader_thread_running, __ATOMIC_ACQUIRE)) {
+        __atomic_store_n(&st->reader_thread_running, 0, __ATOMIC_RELEASE);
         pthread_join(st->reader_thread, NULL);
     }
     if (st->rx_queue) { cl_ring_destroy(st->rx_queue); st->rx_queue = NULL; }
@@ -298,7 +298,7 @@ cl_stream *cl_setupStream(cl_device *dev, int direction, const char *format, con
                                            dev->smi->tx_mode);
         if (!st->tx_pipe) { cl_seterr(dev->err, sizeof dev->err, "setupStream: %s", clhip_last_error()); return NULL; }
     }
-    st->stream_active = 0;                             /* :137 activate_channel(..., false) */
+    __atomic_store_n(&st->stream_active, 0, __ATOMIC_RELEASE);   /* :137 activate_channel(..., false); (the reader thread reads the flag) */
     stream_stop_async(st);
     clhip_stream_sync(dev->smi->stream);
     zc_drop_all(st);
@@ -312,24 +312,24 @@ cl_stream *cl_setupStream(cl_device *dev, int direction, const char *format, con
         st->astream = clhip_stream_create();
         if (!st->rx_queue || !st->d_native1 || !st->astream) { cl_seterr(dev->err, sizeof dev->err, "setupStream: ASYNC allocation failed"); return NULL; }
         st->use_async = 1;
-        st->reader_thread_running = 1;
-        if (pthread_create(&st->reader_thread, NULL, reader_thread_fn, st)) { st->reader_thread_running = 0; return NULL; }
+        __atomic_store_n(&st->reader_thread_running, 1, __ATOMIC_RELEASE);
+        if (pthread_create(&st->reader_thread, NULL, reader_thread_fn, st)) { __atomic_store_n(&st->reader_thread_running, 0, __ATOMIC_RELEASE); return NULL; }
     }
     return st;
 }
 
-void   cl_closeStream(cl_device *dev, cl_stream *stream) { (void)dev; if (stream) stream->stream_active = 0; }   /* :147-150 */
+void   cl_closeStream(cl_device *dev, cl_stream *stream) { (void)dev; if (stream) __atomic_store_n(&stream->stream_active, 0, __ATOMIC_RELEASE); }   /* :147-150 */
 size_t cl_getStreamMTU(const cl_device *dev, cl_stream *stream) { (void)stream; return cl_radio_get_native_mtu_size_samples(dev->radio); }
 int    cl_activateStream(cl_device *dev, cl_stream *stream, int flags, long long timeNs, size_t numElems)
 {
     (void)dev; (void)flags; (void)timeNs; (void)numElems;
-    stream->stream_active = 1;                         /* :191; the 20 ms settle sleep is modem hardware */
+    __atomic_store_n(&stream->stream_active, 1, __ATOMIC_RELEASE);   /* :191; the 20 ms settle sleep is modem hardware */
     return 0;
 }
 int    cl_deactivateStream(cl_device *dev, cl_stream *stream, int flags, long long timeNs)
 {
     (void)dev; (void)flags; (void)timeNs;
-    stream->stream_active = 0;
+    __atomic_store_n(&stream->stream_active, 0, __ATOMIC_RELEASE);
     return 0;
 }
 

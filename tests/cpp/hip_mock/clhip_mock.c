@@ -12,7 +12,8 @@
  * The "kernels" compute with the oracle (oracle/cl_oracle.c: orc_find_buffer_offset, orc_rx_data_analyze, orc_cs16_to_*): the RX
  * unpack family exactly; the RX pipe as a two-tap stand-in with the real pipe's STATE contract (ping-pong history, per-stream
  * input counters, epochs of range runs, unrun) -- y[n] = i[n]/4096 + i[n-1]/8192, q[n]/4096 -- so that a run made twice, not at
- * all, or from the wrong history shows in the output.  IIR, TX and the debug modes are not modelled (the calls fail loudly). */
+ * all, or from the wrong history shows in the output; TX without a modulator (conversion + pack).  IIR, the TX modulator pipe and the
+ * debug modes are not modelled (the calls fail loudly). */
 #include <pthread.h>
 #include <stdarg.h>
 #include <stdint.h>
@@ -402,8 +403,28 @@ int clhip_iir_run_smi(clhip_iir *f, int ch, const uint8_t *w, int16_t *o, size_t
 int clhip_iir_status(clhip_iir *f) { (void)f; return 0; }
 void clhip_iir_set_poll_bound(clhip_iir *f, int polls) { (void)f; (void)polls; }
 int clhip_smi_debug_analyze(int mode, const uint8_t *b, size_t n, uint32_t last, int32_t *res, void *s) { (void)mode; (void)b; (void)n; (void)last; (void)res; (void)s; set_err("clhip_mock: no debug modes"); return -1; }
-int clhip_smi_pack(int mode, const int16_t *iq, size_t n, uint8_t *b, void *s) { (void)mode; (void)iq; (void)n; (void)b; (void)s; set_err("clhip_mock: no TX"); return -1; }
-int clhip_convert_pack(const void *in, int fmt, size_t n, int mode, uint8_t *b, void *s) { (void)in; (void)fmt; (void)n; (void)mode; (void)b; (void)s; set_err("clhip_mock: no TX"); return -1; }
+/* TX without a modulator: the conversion loop (CaribouliteStream.cpp:199-244) and caribou_smi_generate_data (caribou_smi.c:684-717) */
+static void job_pack(job *j)
+{
+    const size_t n = j->z[0]; const int fmt = (int)j->i[0], mode = (int)j->i[1];
+    int16_t *iq = (int16_t *)malloc(4 * n + 4);
+    if (fmt == CL_FORMAT_CF32) orc_cf32_to_cs16((const float *)j->p[0], iq, n);
+    else if (fmt == CL_FORMAT_CF64) orc_cf64_to_cs16((const double *)j->p[0], iq, n);
+    else if (fmt == CL_FORMAT_CS8) orc_cs8_to_cs16((const int8_t *)j->p[0], iq, n);
+    else memcpy(iq, j->p[0], 4 * n);
+    orc_generate_data(mode, iq, n, (uint8_t *)j->p[1]);
+    free(iq);
+}
+int clhip_smi_pack(int mode, const int16_t *iq, size_t n, uint8_t *b, void *s)
+{
+    job *j = new_job(job_pack); j->p[0] = (void *)iq; j->p[1] = b; j->z[0] = n; j->i[0] = CL_FORMAT_CS16; j->i[1] = mode;
+    return enqueue(s, j);
+}
+int clhip_convert_pack(const void *in, int fmt, size_t n, int mode, uint8_t *b, void *s)
+{
+    job *j = new_job(job_pack); j->p[0] = (void *)in; j->p[1] = b; j->z[0] = n; j->i[0] = fmt; j->i[1] = mode;
+    return enqueue(s, j);
+}
 int clhip_take_i_rail(const float *in, size_t n, float *out, void *s) { (void)in; (void)n; (void)out; (void)s; set_err("clhip_mock: no TX"); return -1; }
 clhip_tx_pipe *clhip_tx_pipe_create(int n_streams, double kf, double fs, const float *rs, int n_rs, int up, int down, int mode)
 { (void)n_streams; (void)kf; (void)fs; (void)rs; (void)n_rs; (void)up; (void)down; (void)mode; set_err("clhip_mock: no TX"); return NULL; }

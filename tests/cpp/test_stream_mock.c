@@ -1,0 +1,192 @@
+/* CPU-only sanitizer harness for the single-stream host paths (cariboulite_amd/csrc/host/cl_soapy.c, cl_smi.c, cl_ring.c) over the
+ * threaded model of the HIP layer (tests/cpp/hip_mock/clhip_mock.c: every HIP stream a thread).  Built twice by
+ * tests/test_host_asan.py (-fsanitize=thread; -fsanitize=address,undefined).  No GPU.  Three parts, each with a producer thread
+ * racing the client:
+ *   A  readStream with ASYNC=1 (reader thread -> device ring -> client; CaribouliteStream.cpp:16-49,262-263), CS16 and CF32;
+ *   B  readStream on the calling thread with the seam's read-ahead, CF32, plain and into a registered buffer (ZEROCOPY=1), with a
+ *      flush in between;
+ *   C  writeStream CS16 / CF32 (conversion + caribou_smi_generate_data into the pinned TX FIFO) against a drainer thread.
+ * Sample n of a stream carries n in its 24 payload bits, so every delivered block names its own place in the stream: blocks must be
+ * contiguous inside and strictly ascending across calls (an overwrite-oldest ring may skip, never repeat or reorder). */
+#include <assert.h>
+#include <pthread.h>
+#include <sched.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#include "cariboulite_hip.h"
+#include "cl_oracle.h"
+
+#define MTU 131072u
+#define NB (4u * MTU)
+
+static void sample_of(uint64_t g, int *I, int *Q) { *I = (int)(g & 0xFFF) - 2048; *Q = (int)((g >> 12) & 0xFFF) - 2048; }
+static uint64_t index_of(int I, int Q) { return (uint64_t)(I + 2048) | ((uint64_t)(Q + 2048) << 12); }
+
+static void words_of(uint64_t g0, size_t n, uint8_t *out)                /* S1G layout: I in the high field (caribou_smi.c:338-359) */
+{
+    for (size_t k = 0; k < n; k++) {
+        int I, Q; sample_of(g0 + k, &I, &Q);
+        const uint32_t w = 0x80004000u | (((uint32_t)I & 0x1FFF) << 17) | (((uint32_t)Q & 0x1FFF) << 1);
+        memcpy(out + 4 * k, &w, 4);
+    }
+}
+
+typedef struct { cl_smi *smi; uint64_t total; size_t max_pending; volatile int stop; } feed_arg;
+static void *feeder(void *arg)
+{
+    feed_arg *a = (feed_arg *)arg;
+    uint8_t *piece = (uint8_t *)malloc(NB);
+    uint32_t r = 4242u;
+    uint64_t g = 0;
+    while (g < a->total && !a->stop) {
+        if (cl_smi_pending_bytes(a->smi) >= a->max_pending) { sched_yield(); usleep(20); continue; }
+        r = r * 1664525u + 1013904223u;
+        size_t n = MTU >> ((r >> 20) % 3);
+        if (g + n > a->total) n = (size_t)(a->total - g);
+        words_of(g, n, piece);
+        if (cl_smi_feed_bytes(a->smi, piece, 4 * n)) abort();
+        g += n;
+    }
+    free(piece);
+    return NULL;
+}
+
+/* a delivered block: contiguous, starting at or behind `*next`; returns 0 and moves *next behind it */
+static int block_ok(const void *buf, int is_f32, size_t n, uint64_t *next, int may_skip)
+{
+    uint64_t g0 = 0;
+    for (size_t k = 0; k < n; k++) {
+        int I, Q;
+        if (is_f32) { I = (int)(((const float *)buf)[2 * k] * 4096.0f); Q = (int)(((const float *)buf)[2 * k + 1] * 4096.0f); }
+        else { I = ((const int16_t *)buf)[2 * k]; Q = ((const int16_t *)buf)[2 * k + 1]; }
+        const uint64_t g = index_of(I, Q);
+        if (!k) { g0 = g; if (g < *next || (!may_skip && g != *next)) { fprintf(stderr, "block starts at %llu, expected %s%llu\n", (unsigned long long)g, may_skip ? ">= " : "", (unsigned long long)*next); return -1; } }
+        else if (g != g0 + k) { fprintf(stderr, "sample %zu of the block is %llu, not %llu\n", k, (unsigned long long)g, (unsigned long long)(g0 + k)); return -1; }
+    }
+    if (n) *next = g0 + n;
+    return 0;
+}
+
+static cl_device *make_device(const char *fmt, int dir, const char *const *sk, const char *const *sv, size_t nk, cl_stream **st)
+{
+    const char *dk[] = {"driver", "channel"}, *dv[] = {"Cariboulite", "S1G"};
+    cl_device *d = cl_device_make(dk, dv, 2);
+    assert(d);
+    *st = cl_setupStream(d, dir, fmt, NULL, 0, sk, sv, nk);
+    if (!*st) { fprintf(stderr, "setupStream: %s\n", cl_device_last_error(d)); abort(); }
+    assert(cl_activateStream(d, *st, 0, 0, 0) == 0);
+    return d;
+}
+
+static int part_a(const char *fmt, int n_mtus)
+{
+    cl_stream *st; const char *sk[] = {"ASYNC"}, *sv[] = {"1"};
+    cl_device *d = make_device(fmt, CL_SOAPY_SDR_RX, sk, sv, 1, &st);
+    feed_arg fa = {cl_device_smi(d), (uint64_t)n_mtus * MTU, 2 * NB, 0};
+    pthread_t th; pthread_create(&th, NULL, feeder, &fa);
+    const int f32 = !strcmp(fmt, "CF32");
+    void *buf = malloc((MTU + 16) * 8);
+    uint64_t next = 0, delivered = 0; long calls = 0, empty = 0;
+    while (next < fa.total && calls < 100000) {
+        void *b[1] = {buf};
+        const size_t num = calls % 5 == 4 ? MTU / 2 : MTU;
+        const int r = cl_readStream(d, st, b, num, NULL, NULL, 20000);
+        calls++;
+        if (r < 0) { fprintf(stderr, "readStream: %d\n", r); return -1; }
+        if (!r) { empty++; continue; }
+        if (block_ok(buf, f32, (size_t)r, &next, 1)) return -1;
+        delivered += (uint64_t)r;
+    }
+    fa.stop = 1; pthread_join(th, NULL);
+    cl_device_unmake(d); free(buf);
+    printf("A %s: %llu of %llu samples delivered in %ld calls (%ld empty)\n", fmt, (unsigned long long)delivered, (unsigned long long)fa.total, calls, empty);
+    return next == fa.total && delivered * 10 >= fa.total * 5 ? 0 : -1;      /* (the ring overwrites its oldest when the client is late: at least half must arrive) */
+}
+
+static int part_b(int n_mtus)
+{
+    cl_stream *st; const char *sk[] = {"ZEROCOPY"}, *sv[] = {"1"};
+    cl_device *d = make_device("CF32", CL_SOAPY_SDR_RX, sk, sv, 1, &st);
+    cl_smi *smi = cl_device_smi(d);
+    feed_arg fa = {smi, (uint64_t)n_mtus * MTU, 3 * NB, 0};
+    pthread_t th; pthread_create(&th, NULL, feeder, &fa);
+    float *reg = (float *)malloc((MTU + 16) * 8), *plain = (float *)malloc((MTU + 16) * 8);
+    assert(cl_stream_register_buffer(d, st, reg, (MTU + 16) * 8) == 0);
+    uint64_t next = 0; long calls = 0, flushed = 0;
+    while (next < fa.total && calls < 100000) {
+        void *b[1] = {calls & 1 ? (void *)reg : (void *)plain};
+        const size_t num = calls % 7 == 6 ? MTU / 4 : MTU;
+        const int r = cl_readStream(d, st, b, num, NULL, NULL, 1000);
+        calls++;
+        assert(r >= 0);
+        if (block_ok(b[0], 1, (size_t)r, &next, flushed > 0)) return -1;
+        if (calls == 9) { cl_smi_flush_fifo(smi); flushed = 1; }         /* what is pending (and what was staged ahead) is dropped: the stream skips */
+        if (!r) { sched_yield(); usleep(50); }
+    }
+    fa.stop = 1; pthread_join(th, NULL);
+    cl_stream_stats ss; cl_getStreamStats(d, st, &ss);
+    cl_device_unmake(d); free(reg); free(plain);
+    printf("B: %ld calls, %llu zero-copy reads\n", calls, (unsigned long long)ss.zero_copy_reads);
+    return next == fa.total && ss.zero_copy_reads > 2 ? 0 : -1;
+}
+
+typedef struct { cl_smi *smi; uint64_t total; int bad; } drain_arg;
+static void *drainer(void *arg)
+{
+    drain_arg *a = (drain_arg *)arg;
+    uint8_t *got = (uint8_t *)malloc(NB), *want = (uint8_t *)malloc(NB);
+    int16_t *iq = (int16_t *)malloc(NB);
+    uint64_t g = 0;
+    while (g < a->total && !a->bad) {
+        const size_t n = cl_smi_drain_bytes(a->smi, got, NB);
+        if (!n) { sched_yield(); usleep(20); continue; }
+        assert(n % 4 == 0);
+        for (size_t k = 0; k < n / 4; k++) { int I, Q; sample_of(g + k, &I, &Q); iq[2 * k] = (int16_t)I; iq[2 * k + 1] = (int16_t)Q; }
+        orc_generate_data(ORC_TX_DOCUMENTED, iq, n / 4, want);
+        if (memcmp(got, want, n)) { fprintf(stderr, "TX bytes differ behind sample %llu\n", (unsigned long long)g); a->bad = 1; }
+        g += n / 4;
+    }
+    free(got); free(want); free(iq);
+    return NULL;
+}
+
+static int part_c(const char *fmt, int n_mtus)
+{
+    cl_stream *st;
+    cl_device *d = make_device(fmt, CL_SOAPY_SDR_TX, NULL, NULL, 0, &st);
+    cl_smi_set_tx_mode(cl_device_smi(d), CL_TX_DOCUMENTED);
+    drain_arg da = {cl_device_smi(d), (uint64_t)n_mtus * MTU, 0};
+    pthread_t th; pthread_create(&th, NULL, drainer, &da);
+    const int f32 = !strcmp(fmt, "CF32");
+    void *buf = malloc(MTU * 8);
+    uint64_t g = 0; long calls = 0;
+    while (g < da.total && !da.bad) {
+        const size_t num = calls % 3 == 2 ? MTU / 2 : MTU;
+        for (size_t k = 0; k < num; k++) {
+            int I, Q; sample_of(g + k, &I, &Q);
+            if (f32) { ((float *)buf)[2 * k] = (float)I / 4096.0f; ((float *)buf)[2 * k + 1] = (float)Q / 4096.0f; }
+            else { ((int16_t *)buf)[2 * k] = (int16_t)I; ((int16_t *)buf)[2 * k + 1] = (int16_t)Q; }
+        }
+        const void *b[1] = {buf};
+        const int r = cl_writeStream(d, st, b, num, NULL, 0, 1000);
+        calls++;
+        if (r != (int)num) { fprintf(stderr, "writeStream: %d (%s)\n", r, cl_device_last_error(d)); da.bad = 1; break; }
+        g += (uint64_t)r;
+    }
+    pthread_join(th, NULL);
+    cl_device_unmake(d); free(buf);
+    printf("C %s: %ld calls\n", fmt, calls);
+    return da.bad ? -1 : 0;
+}
+
+int main(int argc, char **argv)
+{
+    const int n = argc > 1 ? atoi(argv[1]) : 24;
+    if (part_a("CS16", n) || part_a("CF32", n) || part_b(n) || part_c("CS16", n) || part_c("CF32", n)) { fprintf(stderr, "stream mock harness FAILED\n"); return 1; }
+    printf("stream mock harness ok\n");
+    return 0;
+}

@@ -79,3 +79,22 @@ def test_stream_group_host_side_over_a_threaded_hip_model(tmp_path, sanitizer):
     env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1:exitcode=66", ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="halt_on_error=1")
     r = subprocess.run([exe, "30" if sanitizer == "thread" else "40"], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and "group mock harness ok" in r.stdout, r.stdout[-2000:] + r.stderr[-6000:]
+
+
+@pytest.mark.parametrize("sanitizer", ["thread", "address,undefined"])
+def test_single_stream_host_paths_over_a_threaded_hip_model(tmp_path, sanitizer):
+    """readStream with ASYNC=1 (reader thread -> device ring -> client), readStream on the calling thread with the seam's read-ahead
+    (plain and into a registered ZEROCOPY buffer, with a flush in between) and writeStream CS16 / CF32 into the pinned TX FIFO, each
+    racing a producer / drainer thread, over the threaded model of the HIP layer (tests/cpp/test_stream_mock.c); every delivered
+    block names its own place in the stream: contiguous inside, strictly ascending across calls."""
+    host = os.path.join(ROOT, "cariboulite_amd", "csrc", "host")
+    exe = str(tmp_path / "stream_mock")
+    cmd = ["gcc", "-std=gnu11", "-O1", "-g", f"-fsanitize={sanitizer}", "-fno-omit-frame-pointer",
+           os.path.join(ROOT, "tests", "cpp", "test_stream_mock.c"), os.path.join(ROOT, "tests", "cpp", "hip_mock", "clhip_mock.c"),
+           os.path.join(ROOT, "oracle", "cl_oracle.c")] + [os.path.join(host, f) for f in ("cl_group.c", "cl_smi.c", "cl_soapy.c", "cl_ring.c")] + \
+          ["-I", host, "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "oracle"), "-lpthread", "-lm", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1:exitcode=66", ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="halt_on_error=1")
+    r = subprocess.run([exe, "40"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "stream mock harness ok" in r.stdout, r.stdout[-2000:] + r.stderr[-6000:]
