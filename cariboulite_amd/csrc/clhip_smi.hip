@@ -520,6 +520,55 @@ extern "C" int clhip_convert_pack(const void *d_in, int format, size_t n, int mo
     return 0;
 }
 
+// The same for up to CLHIP_PACK_ROWS streams in one launch (a stream group's writeStream): row r converts in[r] into out[r], the rows
+// being wherever they are -- the clients' samples in one pinned or device buffer, the packed words in the members' TX FIFOs.
+struct PackRows { const void *in[CLHIP_PACK_ROWS]; uint32_t *out[CLHIP_PACK_ROWS]; };
+
+template <int FMT>
+__global__ __launch_bounds__(256) void convert_pack_rows_kernel(int mode, PackRows rows, size_t n)
+{
+    const typename OutElem<FMT>::type *__restrict__ in = (const typename OutElem<FMT>::type *)rows.in[blockIdx.y];
+    uint32_t *__restrict__ out = rows.out[blockIdx.y];
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if ((((uintptr_t)out) & 15) == 0) {
+        const size_t n4 = n / 4;
+        for (size_t j = k; j < n4; j += step) {
+            u32x4 r;
+#pragma unroll
+            for (int t = 0; t < 4; t++) r[t] = pack_tx_word(mode, sample_to_cs16<FMT>(in[4 * j + t]));
+            ((u32x4 *)out)[j] = r;
+        }
+        for (size_t j = 4 * n4 + k; j < n; j += step) out[j] = pack_tx_word(mode, sample_to_cs16<FMT>(in[j]));
+    } else {
+        for (size_t j = k; j < n; j += step) out[j] = pack_tx_word(mode, sample_to_cs16<FMT>(in[j]));
+    }
+}
+
+extern "C" int clhip_convert_pack_rows(const void *const *d_in_rows, int format, size_t n, int n_rows, int mode, uint8_t *const *d_bytes_rows, void *stream)
+{
+    if (n == 0 || n_rows == 0) return 0;
+    if (!d_in_rows || !d_bytes_rows || n_rows < 0 || n_rows > CLHIP_PACK_ROWS) { clhip_set_error("clhip_convert_pack_rows: 1 .. %d rows", CLHIP_PACK_ROWS); return -1; }
+    PackRows rows;
+    for (int r = 0; r < CLHIP_PACK_ROWS; r++) {
+        rows.in[r] = r < n_rows ? d_in_rows[r] : nullptr; rows.out[r] = r < n_rows ? (uint32_t *)d_bytes_rows[r] : nullptr;
+        if (r < n_rows && (!rows.in[r] || !rows.out[r] || (((uintptr_t)rows.out[r]) & 3))) { clhip_set_error("clhip_convert_pack_rows: bad row %d", r); return -1; }
+    }
+    unsigned gx = (unsigned)clhip_div_up(clhip_div_up(n, 4), 256);
+    if (gx > 2048) gx = 2048;
+    const dim3 grid(gx, (unsigned)n_rows);
+    hipStream_t s = (hipStream_t)stream;
+    switch (format) {
+    case CL_FORMAT_CS16: hipLaunchKernelGGL(convert_pack_rows_kernel<CL_FORMAT_CS16>, grid, dim3(256), 0, s, mode, rows, n); break;
+    case CL_FORMAT_CF32: hipLaunchKernelGGL(convert_pack_rows_kernel<CL_FORMAT_CF32>, grid, dim3(256), 0, s, mode, rows, n); break;
+    case CL_FORMAT_CS8: hipLaunchKernelGGL(convert_pack_rows_kernel<CL_FORMAT_CS8>, grid, dim3(256), 0, s, mode, rows, n); break;
+    case CL_FORMAT_CF64: hipLaunchKernelGGL(convert_pack_rows_kernel<CL_FORMAT_CF64>, grid, dim3(256), 0, s, mode, rows, n); break;
+    default: clhip_set_error("clhip_convert_pack_rows: unknown format %d", format); return -1;
+    }
+    CLHIP_CHECK_LAUNCH();
+    return 0;
+}
+
 // the I rail of interleaved CF32 as a dense fp32 message (the FM modulator's input: SURVEY.md a13 "if given I/Q, use I")
 __global__ __launch_bounds__(256) void take_i_rail_kernel(const f32x2 *__restrict__ in, size_t n, float *__restrict__ out)
 {

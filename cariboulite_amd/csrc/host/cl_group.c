@@ -32,7 +32,7 @@
 
 #include "cl_internal.h"
 
-enum { ROUTE_PIPE = 1, ROUTE_PLAIN = 2 };
+enum { ROUTE_PIPE = 1, ROUTE_PLAIN = 2, ROUTE_TX_PLAIN = 3, ROUTE_TX_SINGLE = 4 };
 
 typedef struct { uint8_t *dst; const uint8_t *src; size_t bytes; } copy_job;
 
@@ -72,10 +72,13 @@ typedef struct {
     uint8_t *ahead_mark; size_t want;      /* per call: rows staged for the read-ahead; the call's bytes per batch */
     uint8_t **src;                        /* per call and row: where the staged batch lies in the member's pinned FIFO */
     cl_dsp_cfg dsp;
+    /* a TX group's lane (cl_group_writeStream): the clients' samples, row by row, in pinned memory and on the device */
+    uint8_t *tx_h_in, *tx_d_in; size_t tx_row;
 } lane_t;
 
 struct cl_group {
     int device;
+    int dir;                              /* CL_SOAPY_SDR_RX: a group to read through; CL_SOAPY_SDR_TX: to write through (boards are half duplex: one stream per device) */
     size_t n; cl_device **dev;
     int *lane_of, *row_of;                /* member -> lane / row */
     int n_lanes; lane_t *lane;
@@ -235,6 +238,7 @@ static void lane_free(lane_t *l)
     clhip_free(l->d_in[0]); clhip_free(l->d_in[1]); clhip_free(l->d_in[2]); clhip_free(l->d_out);
     clhip_event_destroy(l->ev_primed); free(l->primed); free(l->primed_epoch);
     clhip_host_free(l->h_out[0]); clhip_host_free(l->h_out[1]); clhip_host_free(l->h_offs[0]);
+    clhip_host_free(l->tx_h_in); clhip_free(l->tx_d_in);
     free(l->done_ahead); free(l->ahead_got); free(l->direct);
     free(l->member); free(l->prev_len); free(l->fast); free(l->len); free(l->got); free(l->src); free(l->ahead_mark);
     memset(l, 0, sizeof *l);
@@ -284,11 +288,12 @@ cl_group *cl_group_make(cl_device *const *devs, size_t n, const char *const *key
         }
         for (size_t j = 0; j < i; j++)
             if (devs[j] == devs[i]) { cl_seterr(g_make_err, sizeof g_make_err, "cl_group_make: device %zu appears twice", i); return NULL; }
-        if (devs[i]->stream->native_dir != CL_SOAPY_SDR_RX) { cl_seterr(g_make_err, sizeof g_make_err, "cl_group_make: device %zu is not set up for RX", i); return NULL; }
+        if (devs[i]->stream->native_dir != devs[0]->stream->native_dir) { cl_seterr(g_make_err, sizeof g_make_err, "cl_group_make: device %zu is set up for the other direction (a group reads or writes)", i); return NULL; }
     }
     cl_group *g = (cl_group *)calloc(1, sizeof *g);
     if (!g) return NULL;
     g->device = devs[0]->smi->device;
+    g->dir = devs[0]->stream->native_dir;
     clhip_set_device(g->device);
     g->n = n;
     g->dev = (cl_device **)calloc(n, sizeof *g->dev);
@@ -317,13 +322,14 @@ cl_group *cl_group_make(cl_device *const *devs, size_t n, const char *const *key
         int li = -1;
         for (int k = 0; k < g->n_lanes && li < 0; k++) {
             const cl_stream *s0 = devs[g->lane[k].member[0]]->stream;
-            if (g->lane[k].channel == devs[i]->channel && s0->format == st->format && same_dsp(&s0->dsp, &st->dsp)) li = k;
+            if (g->dir == CL_SOAPY_SDR_TX) { if (s0->format == st->format && !s0->dsp.enabled && !st->dsp.enabled) li = k; }      /* (the TX words do not depend on the channel type) */
+            else if (g->lane[k].channel == devs[i]->channel && s0->format == st->format && same_dsp(&s0->dsp, &st->dsp)) li = k;
         }
         if (li < 0) {
             li = g->n_lanes++;
             lane_t *l = &g->lane[li];
             l->channel = devs[i]->channel; l->format = st->format; l->dsp = st->dsp;
-            l->route = st->dsp.enabled ? ROUTE_PIPE : ROUTE_PLAIN;
+            l->route = g->dir == CL_SOAPY_SDR_TX ? (st->dsp.enabled ? ROUTE_TX_SINGLE : ROUTE_TX_PLAIN) : st->dsp.enabled ? ROUTE_PIPE : ROUTE_PLAIN;
             l->member = (int *)calloc(n, sizeof(int));
             if (!l->member) { cl_group_unmake(g); return NULL; }
         }
@@ -335,6 +341,19 @@ cl_group *cl_group_make(cl_device *const *devs, size_t n, const char *const *key
     for (int k = 0; k < g->n_lanes; k++) {
         lane_t *l = &g->lane[k];
         const size_t nb = CL_NATIVE_BATCH_LEN, mtu = CL_NATIVE_MTU_SAMPLES;
+        if (g->dir == CL_SOAPY_SDR_TX) {
+            l->sub = g->sub && g->sub <= CLHIP_PACK_ROWS ? g->sub : CLHIP_PACK_ROWS;
+            l->sub0 = n_sub;
+            n_sub += ((size_t)l->n + (size_t)l->sub - 1) / (size_t)l->sub;
+            l->fast = (uint8_t *)calloc((size_t)l->n, 1); l->src = (uint8_t **)calloc((size_t)l->n, sizeof(uint8_t *));
+            if (!l->fast || !l->src) { cl_group_unmake(g); return NULL; }
+            if (l->route != ROUTE_TX_PLAIN) continue;
+            l->elem_bytes = fmt_bytes(l->format);
+            l->tx_row = mtu * l->elem_bytes + 256;
+            l->tx_h_in = (uint8_t *)clhip_host_alloc((size_t)l->n * l->tx_row); l->tx_d_in = (uint8_t *)clhip_malloc((size_t)l->n * l->tx_row);
+            if (!l->tx_h_in || !l->tx_d_in) { cl_seterr(g_make_err, sizeof g_make_err, "cl_group_make: buffers for %d TX streams could not be allocated", l->n); cl_group_unmake(g); return NULL; }
+            continue;
+        }
         l->in_stride = nb + 256;
         l->up = l->dsp.enabled ? l->dsp.up : 1; l->down = l->dsp.enabled ? l->dsp.down : 1;
         if (l->route == ROUTE_PIPE) {
@@ -390,7 +409,7 @@ cl_group *cl_group_make(cl_device *const *devs, size_t n, const char *const *key
         const char *sm = kwget(keys, vals, n_kwargs, "SLAB_MB");
         const size_t mb = sm ? (size_t)atol(sm) : 8;
         g->slab_slice = mb << 20;
-        g->slab = mb ? (uint8_t *)clhip_host_alloc(g->n * g->slab_slice) : NULL;
+        g->slab = mb && g->dir == CL_SOAPY_SDR_RX ? (uint8_t *)clhip_host_alloc(g->n * g->slab_slice) : NULL;
         size_t slot = 0;
         for (int k = 0; g->slab && k < g->n_lanes; k++)
             for (int r = 0; r < g->lane[k].n; r++, slot++) {
@@ -684,6 +703,7 @@ static int launch_rows(cl_group *g, lane_t *l, int a, int e, const uint8_t *run,
 int cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems, int *rets, long timeoutUs)
 {
     if (!g || !buffs || !rets) return -1;
+    if (g->dir != CL_SOAPY_SDR_RX) { cl_seterr(g->err, sizeof g->err, "cl_group_readStream: the group's devices are set up for TX"); return -1; }
     clhip_set_device(g->device);
     g->err[0] = 0;
     g->stats.calls++;
@@ -876,6 +896,128 @@ int cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems, int *r
             if (g->lane[k].pipe && g->lane[k].epoch_open) { clhip_rx_pipe_epoch_end(g->lane[k].pipe, g->s_k); g->lane[k].epoch_open = 0; }
         g->stats.errors++;
         return -1;
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t3);
+    g->stats.last_queue_us = (uint64_t)((t1.tv_sec - t0.tv_sec) * 1000000L + (t1.tv_nsec - t0.tv_nsec) / 1000);
+    g->stats.last_arrive_us = (uint64_t)((t2.tv_sec - t0.tv_sec) * 1000000L + (t2.tv_nsec - t0.tv_nsec) / 1000);
+    g->stats.last_total_us = (uint64_t)((t3.tv_sec - t0.tv_sec) * 1000000L + (t3.tv_nsec - t0.tv_nsec) / 1000);
+    int delivered = 0;
+    for (size_t i = 0; i < g->n; i++) delivered += rets[i] > 0;
+    return delivered;
+}
+
+/* ------------------------------------------------------------------------------------------- the write call
+ * N writeStream calls as one (Stream::WriteSamplesGen, CaribouliteStream.cpp:199-258, over caribou_smi_write, caribou_smi.c:720-762):
+ * rets[i] is what cl_writeStream(devs[i], ..., &buffs[i], numElems) returns, and when the call returns the packed words of every
+ * member are in its TX FIFO behind what was there.  Members without a modulator share launches, up to eight streams each:
+ *
+ *     sub-batch b:  clients' samples --copy threads--> pinned rows --copy engine--> device rows     stream s_in[b mod K]
+ *                   one launch converts and packs (caribou_smi_generate_data) every row and stores the words straight into the room
+ *                   reserved in each member's pinned TX FIFO                                          stream s_k
+ *
+ * so the host copies sub-batch b + 1 while b crosses PCIe both ways.  A member with a modulator (MOD=FM, RESAMP), a CS16 call above
+ * one MTU (the reference does not clamp those) or a member whose pack mode differs from its sub-batch's takes its own device's
+ * writeStream, here, inside the call. */
+int cl_group_writeStream(cl_group *g, const void *const *buffs, size_t numElems, int *rets, long timeoutUs)
+{
+    if (!g || !buffs || !rets) return -1;
+    if (g->dir != CL_SOAPY_SDR_TX) { cl_seterr(g->err, sizeof g->err, "cl_group_writeStream: the group's devices are set up for RX"); return -1; }
+    clhip_set_device(g->device);
+    g->err[0] = 0;
+    g->stats.calls++;
+    for (size_t i = 0; i < g->n; i++) rets[i] = 0;
+    if (!numElems) return 0;
+    const size_t mtu = CL_NATIVE_MTU_SAMPLES;
+    int hard = 0;
+    struct timespec t0, t1, t2, t3;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    /* ---- pass 1: room in the FIFOs, the clients' samples to the device, the launches -- everything queued, nothing waited for */
+    for (int k = 0; k < g->n_lanes && !hard; k++) {
+        lane_t *l = &g->lane[k];
+        memset(l->fast, 0, (size_t)l->n);
+        l->queued = 0;
+        if (l->route != ROUTE_TX_PLAIN) continue;
+        const size_t n_el = l->format != CL_FORMAT_CS16 && numElems > mtu ? mtu : numElems;      /* :201,217,234; CS16 is not clamped (:182-196) */
+        if (n_el > mtu) continue;                              /* (a chunk loop of its own, member by member) */
+        l->want = n_el;
+        for (int a = 0; a < l->n && !hard; a += l->sub) {
+            const int e = a + l->sub < l->n ? a + l->sub : l->n;
+            void **ev = ev_of(g, l, 0, a);
+            const size_t b = l->sub0 + (size_t)(a / l->sub);
+            void *s_in = g->s_in[b % (size_t)g->n_in];
+            const void *in_rows[CLHIP_PACK_ROWS]; uint8_t *out_rows[CLHIP_PACK_ROWS];
+            int n_rows = 0, mode = -1, lo = -1, hi = -1;
+            l->queued++;
+            for (int r = a; r < e; r++) {
+                cl_device *dev = g->dev[l->member[r]];
+                const cl_stream *st = dev->stream;
+                if (st->native_dir != CL_SOAPY_SDR_TX || st->format != l->format || st->tx_pipe || !buffs[l->member[r]]) continue;
+                if (mode < 0) mode = dev->smi->tx_mode;
+                if (dev->smi->tx_mode != mode) continue;
+                /* caribou_smi_write's chunk loop appends native-batch pieces of one contiguous array (caribou_smi.c:738-759): the array,
+                 * packed into the room behind what the FIFO holds, committed once the launch is known to have run */
+                uint8_t *room = cl_smi_tx_reserve(dev->smi, 4 * n_el + 64);
+                uint8_t *d_room = room ? (uint8_t *)cl_fifo_device_ptr(&dev->smi->tx, room) : NULL;
+                if (!d_room) continue;
+                l->fast[r] = 1; l->src[r] = room;
+                pool_submit(&g->pool, l->tx_h_in + (size_t)r * l->tx_row, (const uint8_t *)buffs[l->member[r]], n_el * l->elem_bytes);
+                in_rows[n_rows] = l->tx_d_in + (size_t)r * l->tx_row; out_rows[n_rows] = d_room; n_rows++;
+                if (lo < 0) lo = r;
+                hi = r;
+            }
+            if (!n_rows) continue;
+            pool_drain(&g->pool);                              /* (the previous sub-batch is crossing PCIe meanwhile) */
+            hard = clhip_memcpy_h2d(l->tx_d_in + (size_t)lo * l->tx_row, l->tx_h_in + (size_t)lo * l->tx_row, (size_t)(hi - lo) * l->tx_row + n_el * l->elem_bytes, s_in) ||
+                   clhip_event_record(ev[0], s_in) || clhip_stream_wait_event(g->s_k, ev[0]) ||
+                   clhip_convert_pack_rows(in_rows, l->format, n_el, n_rows, mode, out_rows, g->s_k) ||
+                   clhip_event_record(ev[g->n_in + 1], g->s_k);
+            g->stats.launches++;
+        }
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    /* ---- pass 2: as the sub-batches' launches end, their words are the FIFOs' */
+    for (int k = 0; k < g->n_lanes; k++) {
+        lane_t *l = &g->lane[k];
+        int sb = 0;
+        for (int a = 0; a < l->n; a += l->sub, sb++) {
+            const int e = a + l->sub < l->n ? a + l->sub : l->n;
+            int any = 0;
+            for (int r = a; r < e; r++) any |= l->fast[r];
+            if (!any) continue;
+            const int arrived = sb < l->queued && !hard && clhip_event_sync(ev_of(g, l, 0, a)[g->n_in + 1]) == 0;
+            if (!arrived) hard = 1;
+            for (int r = a; r < e; r++) {
+                if (!l->fast[r]) continue;
+                cl_device *dev = g->dev[l->member[r]];
+                cl_stream *st = dev->stream;
+                st->stats.write_calls++;
+                if (!arrived) { l->fast[r] = 2; st->stats.writes_empty++; continue; }     /* nothing was committed: the FIFO is as it was (a write error is 0 elements, :185-194) */
+                cl_smi_tx_commit(dev->smi, 4 * l->want);
+                if (l->format == CL_FORMAT_CS16) dev->smi->stat_written += l->want;          /* (caribou_smi_write counts; the conversions' callers do not) */
+                rets[l->member[r]] = (int)l->want;
+                st->stats.elements_written += l->want;
+                g->stats.batched_reads++;
+            }
+        }
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t2);
+    if (hard) {
+        for (int k = 0; k < g->n_in; k++) clhip_stream_sync(g->s_in[k]);
+        clhip_stream_sync(g->s_k);
+        cl_seterr(g->err, sizeof g->err, "cl_group_writeStream: %s", clhip_last_error());
+        g->stats.errors++;
+        return -1;
+    }
+    /* ---- pass 3: the members off the batched route, through their own devices */
+    for (int k = 0; k < g->n_lanes; k++) {
+        lane_t *l = &g->lane[k];
+        for (int r = 0; r < l->n; r++) {
+            if (l->fast[r]) continue;
+            const int m = l->member[r];
+            const void *const b1[1] = {buffs[m]};
+            rets[m] = buffs[m] ? cl_writeStream(g->dev[m], g->dev[m]->stream, b1, numElems, NULL, 0, timeoutUs) : 0;
+            g->stats.single_reads++;
+        }
     }
     clock_gettime(CLOCK_MONOTONIC, &t3);
     g->stats.last_queue_us = (uint64_t)((t1.tv_sec - t0.tv_sec) * 1000000L + (t1.tv_nsec - t0.tv_nsec) / 1000);

@@ -59,6 +59,7 @@ _SIGS = {
     "clhip_smi_debug_analyze": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p]),
     "clhip_smi_pack": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "clhip_convert_pack": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]),
+    "clhip_convert_pack_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "clhip_take_i_rail": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "clhip_sync_tags_ws_bytes": (C.c_size_t, [C.c_size_t]),
     "clhip_sync_tags": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),

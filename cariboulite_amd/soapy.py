@@ -101,6 +101,7 @@ _SIGS = {
     "cl_group_unmake": (None, [C.c_void_p]),
     "cl_group_size": (C.c_size_t, [C.c_void_p]),
     "cl_group_readStream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t, C.POINTER(C.c_int), C.c_long]),
+    "cl_group_writeStream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t, C.POINTER(C.c_int), C.c_long]),
     "cl_group_last_error": (C.c_char_p, [C.c_void_p]),
     "cl_group_getStats": (None, [C.c_void_p, C.c_void_p]),
     "cl_group_register_buffers": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t]),
@@ -382,6 +383,16 @@ class Group:
                 self._ptrs[i] = b.ctypes.data
             self._last_buffs = tuple(buffs)         # (held: the identity test above stands for the addresses)
         n = lib().cl_group_readStream(self.h, self._ptrs, numElems, self._rets, timeoutUs)
+        return n, list(self._rets)
+
+    def writeStream(self, buffs, numElems, timeoutUs=100000):
+        """a group of TX devices: (members that consumed elements, [ret per member])"""
+        last = getattr(self, "_last_buffs", ())
+        if len(last) != len(buffs) or any(x is not y for x, y in zip(last, buffs)):
+            for i, b in enumerate(buffs):
+                self._ptrs[i] = b.ctypes.data
+            self._last_buffs = tuple(buffs)
+        n = lib().cl_group_writeStream(self.h, self._ptrs, numElems, self._rets, timeoutUs)
         return n, list(self._rets)
 
     def registerBuffers(self, buffs):

@@ -198,6 +198,10 @@ int clhip_convert_to_cs16(const void *d_in, int format, size_t n_samples, int16_
  * caribou_smi_generate_data (caribou_smi.c:684-717) -- in one launch; bit-identical to clhip_convert_to_cs16 + clhip_smi_pack.
  * d_bytes: 4-byte aligned, 4 * n_samples bytes.  mode = CL_TX_DOCUMENTED / CL_TX_AS_WRITTEN. */
 int clhip_convert_pack(const void *d_in, int format, size_t n_samples, int mode, uint8_t *d_bytes, void *stream);
+/* ... for up to CLHIP_PACK_ROWS streams in one launch (cl_group_writeStream): row r converts n_samples from d_in_rows[r] into
+ * d_bytes_rows[r] (host arrays of device-visible addresses, read at the call). */
+#define CLHIP_PACK_ROWS 8
+int clhip_convert_pack_rows(const void *const *d_in_rows, int format, size_t n_samples, int n_rows, int mode, uint8_t *const *d_bytes_rows, void *stream);
 /* The I rail of interleaved CF32 samples as a dense fp32 message: what Stream::WriteSamples would hand an FM modulator
  * ("if given I/Q, use I"), taken on the device instead of in a host loop. */
 int clhip_take_i_rail(const float *d_cf32, size_t n_samples, float *d_msg, void *stream);
@@ -613,6 +617,14 @@ cl_group   *cl_group_make(cl_device *const *devs, size_t n_devs, const char *con
 void        cl_group_unmake(cl_group *g);
 size_t      cl_group_size(const cl_group *g);
 int         cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems, int *rets, long timeoutUs);
+/* A group of devices set up for TX (boards are half duplex, Cariboulite.hpp:60: a group reads or writes): N cl_writeStream calls as
+ * one -- rets[i] is what cl_writeStream(devs[i], stream_i, &buffs[i], numElems, ...) returns, and on return every member's packed
+ * words are in its TX FIFO behind what it held (Stream::WriteSamplesGen, CaribouliteStream.cpp:199-258, over caribou_smi_write,
+ * caribou_smi.c:720-762).  Members without a modulator share launches of up to eight streams (conversion + caribou_smi_generate_data,
+ * words stored straight into the room reserved in each pinned FIFO) while the next sub-batch's samples are copied in; a member with
+ * MOD / RESAMP kwargs, or a CS16 call above one MTU, takes its own device's writeStream inside the call.  Returns the number of
+ * members that consumed elements, or -1 (cl_group_last_error).  cl_group_getStats: batched_reads / single_reads count the writes. */
+int         cl_group_writeStream(cl_group *g, const void *const *buffs, size_t numElems, int *rets, long timeoutUs);
 const char *cl_group_last_error(const cl_group *g);
 void        cl_group_getStats(const cl_group *g, cl_group_stats *out);
 /* Explicit zero-copy: one client buffer per member (bytes_each long), registered with the GPU here and kept registered until

@@ -420,6 +420,15 @@ int clhip_smi_pack(int mode, const int16_t *iq, size_t n, uint8_t *b, void *s)
     job *j = new_job(job_pack); j->p[0] = (void *)iq; j->p[1] = b; j->z[0] = n; j->i[0] = CL_FORMAT_CS16; j->i[1] = mode;
     return enqueue(s, j);
 }
+int clhip_convert_pack_rows(const void *const *in_rows, int fmt, size_t n, int n_rows, int mode, uint8_t *const *out_rows, void *s)
+{
+    if (n_rows < 0 || n_rows > CLHIP_PACK_ROWS) { set_err("clhip_convert_pack_rows: 1 .. 8 rows"); return -1; }
+    for (int r = 0; r < n_rows; r++) {                    /* (the addresses are read at the call; the rows run one after the other on the stream) */
+        job *j = new_job(job_pack); j->p[0] = (void *)in_rows[r]; j->p[1] = out_rows[r]; j->z[0] = n; j->i[0] = fmt; j->i[1] = mode;
+        enqueue(s, j);
+    }
+    return 0;
+}
 int clhip_convert_pack(const void *in, int fmt, size_t n, int mode, uint8_t *b, void *s)
 {
     job *j = new_job(job_pack); j->p[0] = (void *)in; j->p[1] = b; j->z[0] = n; j->i[0] = fmt; j->i[1] = mode;

@@ -5,7 +5,8 @@
  *   A  readStream with ASYNC=1 (reader thread -> device ring -> client; CaribouliteStream.cpp:16-49,262-263), CS16 and CF32;
  *   B  readStream on the calling thread with the seam's read-ahead, CF32, plain and into a registered buffer (ZEROCOPY=1), with a
  *      flush in between;
- *   C  writeStream CS16 / CF32 (conversion + caribou_smi_generate_data into the pinned TX FIFO) against a drainer thread.
+ *   C  writeStream CS16 / CF32 (conversion + caribou_smi_generate_data into the pinned TX FIFO) against a drainer thread;
+ *   D  cl_group_writeStream over eleven TX devices, a drainer thread per member.
  * Sample n of a stream carries n in its 24 payload bits, so every delivered block names its own place in the stream: blocks must be
  * contiguous inside and strictly ascending across calls (an overwrite-oldest ring may skip, never repeat or reorder). */
 #include <assert.h>
@@ -134,7 +135,7 @@ static int part_b(int n_mtus)
     return next == fa.total && ss.zero_copy_reads > 2 ? 0 : -1;
 }
 
-typedef struct { cl_smi *smi; uint64_t total; int bad; } drain_arg;
+typedef struct { cl_smi *smi; volatile uint64_t total; volatile int bad; } drain_arg;
 static void *drainer(void *arg)
 {
     drain_arg *a = (drain_arg *)arg;
@@ -183,10 +184,56 @@ static int part_c(const char *fmt, int n_mtus)
     return da.bad ? -1 : 0;
 }
 
+/* D: a group of TX devices (cl_group_writeStream: copy threads -> pinned rows -> device rows -> one launch per sub-batch that stores into
+ * the room reserved in every member's TX FIFO) against one drainer thread per member */
+#define N_TX 11
+static int part_d(const char *fmt, int n_mtus)
+{
+    cl_device *d[N_TX]; cl_stream *st[N_TX]; drain_arg da[N_TX]; pthread_t th[N_TX];
+    for (int i = 0; i < N_TX; i++) {
+        d[i] = make_device(fmt, CL_SOAPY_SDR_TX, NULL, NULL, 0, &st[i]);
+        cl_smi_set_tx_mode(cl_device_smi(d[i]), CL_TX_DOCUMENTED);
+        da[i] = (drain_arg){cl_device_smi(d[i]), (uint64_t)n_mtus * MTU, 0};
+    }
+    const char *gk[] = {"COPY_THREADS"}, *gv[] = {"2"};
+    cl_group *grp = cl_group_make(d, N_TX, gk, gv, 1);
+    if (!grp) { fprintf(stderr, "cl_group_make: %s\n", cl_group_last_error(NULL)); return -1; }
+    for (int i = 0; i < N_TX; i++) pthread_create(&th[i], NULL, drainer, &da[i]);
+    const int f32 = !strcmp(fmt, "CF32");
+    void *buf = malloc(MTU * 8);                                    /* (every member is written the same samples: one buffer) */
+    const void *bufs[N_TX]; int rets[N_TX];
+    for (int i = 0; i < N_TX; i++) bufs[i] = buf;
+    uint64_t g = 0; long calls = 0; int bad = 0;
+    while (g < da[0].total && !bad) {
+        const size_t num = calls % 3 == 2 ? MTU / 2 : MTU;
+        for (size_t k = 0; k < num; k++) {
+            int I, Q; sample_of(g + k, &I, &Q);
+            if (f32) { ((float *)buf)[2 * k] = (float)I / 4096.0f; ((float *)buf)[2 * k + 1] = (float)Q / 4096.0f; }
+            else { ((int16_t *)buf)[2 * k] = (int16_t)I; ((int16_t *)buf)[2 * k + 1] = (int16_t)Q; }
+        }
+        const int nd = cl_group_writeStream(grp, bufs, num, rets, 1000);
+        calls++;
+        if (nd != N_TX) { fprintf(stderr, "cl_group_writeStream: %d (%s)\n", nd, cl_group_last_error(grp)); bad = 1; break; }
+        for (int i = 0; i < N_TX; i++) if (rets[i] != (int)num) bad = 1;
+        for (int i = 0; i < N_TX; i++) bad |= da[i].bad;
+        g += num;
+    }
+    if (bad) for (int i = 0; i < N_TX; i++) da[i].total = 0;         /* (let the drainers go) */
+    for (int i = 0; i < N_TX; i++) { pthread_join(th[i], NULL); bad |= da[i].bad; }
+    cl_group_stats gs; cl_group_getStats(grp, &gs);
+    cl_group_unmake(grp);
+    for (int i = 0; i < N_TX; i++) cl_device_unmake(d[i]);
+    free(buf);
+    printf("D %s: %ld calls, %llu batched writes, %llu launches\n", fmt, calls, (unsigned long long)gs.batched_reads, (unsigned long long)gs.launches);
+    return bad || gs.errors || gs.single_reads ? -1 : 0;
+}
+
 int main(int argc, char **argv)
 {
     const int n = argc > 1 ? atoi(argv[1]) : 24;
-    if (part_a("CS16", n) || part_a("CF32", n) || part_b(n) || part_c("CS16", n) || part_c("CF32", n)) { fprintf(stderr, "stream mock harness FAILED\n"); return 1; }
+    if (part_a("CS16", n) || part_a("CF32", n) || part_b(n) || part_c("CS16", n) || part_c("CF32", n) || part_d("CS16", n / 2) || part_d("CF32", n / 2)) {
+        fprintf(stderr, "stream mock harness FAILED\n"); return 1;
+    }
     printf("stream mock harness ok\n");
     return 0;
 }

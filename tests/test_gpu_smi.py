@@ -183,6 +183,44 @@ def test_convert_pack_in_one_launch_equals_the_two_steps_and_the_oracle(orc, fmt
             assert np.array_equal(got[mis:mis + 4 * n], orc.generate_data(to16(host), mode))
 
 
+@pytest.mark.parametrize("fmt_name", ["CS16", "CF32", "CF64", "CS8"])
+def test_convert_pack_rows_equals_the_single_row_launch_row_by_row(orc, fmt_name):
+    """clhip_convert_pack_rows (a stream group's writeStream: up to 8 streams per launch, rows wherever they are): every row's bytes
+    equal the oracle's (CaribouliteStream.cpp:199-244 + caribou_smi.c:684-717), rows scattered and one of them only 4-byte aligned,
+    nothing written between or behind the rows; 0 rows and more than 8 are refused / empty."""
+    import ctypes as C
+    import torch
+    from cariboulite_amd import hip
+    rng = np.random.default_rng(5)
+    fmt = getattr(hip, "FORMAT_" + fmt_name)
+    for n, rows in ((131072, 8), (1023, 3), (4, 1)):
+        if fmt_name == "CS16":
+            host = rng.integers(-32768, 32768, (rows, n, 2)).astype(np.int16); to16 = lambda a: a
+        elif fmt_name == "CF32":
+            host = ((rng.random((rows, n, 2)) - 0.5) * 20).astype(np.float32); to16 = orc.cf32_to_cs16
+        elif fmt_name == "CF64":
+            host = (rng.random((rows, n, 2)) - 0.5) * 20; to16 = orc.cf64_to_cs16
+        else:
+            host = rng.integers(-128, 128, (rows, n, 2)).astype(np.int8); to16 = orc.cs8_to_cs16
+        d_in = torch.from_numpy(host.copy()).to("cuda:0")
+        pitch = 4 * n + 64
+        raw = torch.full((rows * pitch + 64,), 0xEE, dtype=torch.uint8, device="cuda:0")
+        order = list(rng.permutation(rows))                          # row r's words land in slot order[r]
+        offs = [int(order[r]) * pitch + (4 if r == 1 else 0) for r in range(rows)]
+        ins = (C.c_void_p * rows)(*[d_in[r].data_ptr() for r in range(rows)])
+        outs = (C.c_void_p * rows)(*[raw.data_ptr() + offs[r] for r in range(rows)])
+        assert hip.lib().clhip_convert_pack_rows(ins, fmt, n, rows, hip.TX_DOCUMENTED, outs, hip.current_stream()) == 0
+        torch.cuda.synchronize()
+        got = raw.cpu().numpy()
+        mask = np.ones(got.size, bool)
+        for r in range(rows):
+            assert np.array_equal(got[offs[r]: offs[r] + 4 * n], orc.generate_data(to16(host[r]), hip.TX_DOCUMENTED)), (n, r)
+            mask[offs[r]: offs[r] + 4 * n] = False
+        assert (got[mask] == 0xEE).all()
+    assert hip.lib().clhip_convert_pack_rows(ins, fmt, 4, 0, hip.TX_DOCUMENTED, outs, hip.current_stream()) == 0
+    assert hip.lib().clhip_convert_pack_rows(ins, fmt, 4, 9, hip.TX_DOCUMENTED, outs, hip.current_stream()) != 0
+
+
 def test_take_i_rail():
     import torch
     from cariboulite_amd import hip

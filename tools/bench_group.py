@@ -40,9 +40,66 @@ def pcie_shape(in_mib, out_mib):
         return None
 
 
+TX_CASES = {"tx_cs16": ("CS16", "int16", 4), "tx_cf32": ("CF32", "float32", 8)}
+
+
+def run_tx_case(name, a):
+    """cl_group_writeStream: the clients' samples (pageable) in, packed SMI words in the members' pinned TX FIFOs out (drained between
+    the timed repetitions), against the same devices written one by one."""
+    import numpy as np
+    from cariboulite_amd import soapy as S
+    fmt, dt, in_b = TX_CASES[name]
+    n, K = a.streams, a.calls
+    rng = np.random.default_rng(5)
+    res = {}
+    for mode in ("default", "one_by_one"):
+        devs, sts = [], []
+        for i in range(n):
+            d = S.Device(dict(driver="Cariboulite", channel="S1G" if i % 2 == 0 else "HiF"))
+            sts.append(d.setupStream(S.SOAPY_SDR_TX, fmt))
+            d.activateStream(sts[-1])
+            devs.append(d)
+        bufs = [(rng.integers(-4096, 4096, (MTU, 2)).astype(np.int16) if fmt == "CS16" else (rng.random((MTU, 2), dtype=np.float32) - 0.5)) for _ in range(n)]
+        kw = {"COPY_THREADS": str(a.threads), "INGEST_STREAMS": str(a.ingest)}
+        if a.sub:
+            kw["SUBBATCH"] = str(a.sub)
+        grp = S.Group(devs, kw) if mode == "default" else None
+        best = None
+        for rep in range(a.reps + 1):
+            t0 = time.perf_counter()
+            for k in range(K):
+                if grp is not None:
+                    nd, rets = grp.writeStream(bufs, MTU)
+                    assert nd == n, (k, nd, grp.lastError())
+                else:
+                    for i in range(n):
+                        assert devs[i].writeStream(sts[i], [bufs[i]], MTU).ret == MTU
+            dt_s = time.perf_counter() - t0
+            for d in devs:
+                assert d.drainSmiBytes().size == K * MTU * 4
+            if rep and (best is None or dt_s < best):
+                best = dt_s
+        res[mode] = {"msps_in": round(n * K * MTU / best / 1e6, 1), "ms_per_group_call": round(best / K * 1e3, 4), "us_per_stream_call": round(best / K / n * 1e6, 2)}
+        if grp is not None:
+            res[mode]["stats"] = grp.stats()
+            grp.close()
+        for d in devs:
+            d.close()
+    in_mib, out_mib = n * MTU * in_b >> 20, n * MTU * 4 >> 20
+    sh = pcie_shape(in_mib, out_mib)
+    if sh:
+        ceiling = n * MTU / (sh["duplex_ms"] * 1e-3) / 1e6
+        res["roofline"] = {"bound": "pcie", "unit": "Msamples/s", "peak": round(ceiling, 1),
+                           "peak_note": f"{in_mib} MiB H2D and {out_mib} MiB D2H queued together on two streams, pinned memory, copy engine: {sh['duplex_ms']:.3f} ms",
+                           **{f"frac_{m}": round(res[m]["msps_in"] / ceiling, 3) for m in ("default", "one_by_one")}}
+    return res
+
+
 def run_case(name, a):
     import numpy as np
     from cariboulite_amd import soapy as S, synth
+    if name in TX_CASES:
+        return run_tx_case(name, a)
     fmt, dt, width, args, out_b = CASES[name]
     n, K = a.streams, a.calls
     words = [synth.smi_stream_bytes(K * MTU, i % 2, stream=i)[0] for i in range(min(n, 4))]      # a few distinct streams, reused
