@@ -150,7 +150,7 @@ def cpu_baseline(taps, d_words, budget_s):
 def pmc_traffic(workload):
     """HBM bytes per step measured with rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections;
     tools/collect_workload_profiles.sh) and committed under profiles/: (bytes, source) or (None, None)."""
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         f = os.path.join(ROOT, "profiles", rnd, f"{workload}_pmc.json")
         if os.path.exists(f):
             try:

@@ -5,12 +5,14 @@
  * -fsanitize=thread (a host write under queued work is a race) and -fsanitize=address,undefined (a buffer freed or overrun under
  * queued work).  No GPU.
  *
- * Eight devices, two lanes (CS16 on S1G without stages; CF32 on HiF behind the mock's stand-in pipe, whose output depends on the
+ * Eight devices (+ one, below), two lanes (CS16 on S1G without stages; CF32 on HiF behind the mock's stand-in pipe, whose output depends on the
  * pipe's history and therefore on every run being made exactly once and in order).  The feeders push pieces of a quarter, half or
  * whole batch and let the FIFOs run between empty and four batches deep, so calls find anything from nothing to several batches
  * pending: full batches (batched route, read and computed ahead), short reads (the members' own devices).  Between group calls the
  * client reads a member through its own device, asks for half batches, registers and releases its buffers.  Every sample every
- * stream delivers is checked against the sequence that was fed: nothing lost, nothing twice, nothing out of order. */
+ * stream delivers is checked against the sequence that was fed: nothing lost, nothing twice, nothing out of order.  A ninth stream (in
+ * the plain lane) is fed damage -- batches that start six junk bytes late, batches without any sync word -- so that the re-sync and
+ * "-3" paths of its own device run inside the group's calls, next to the others; its samples are not checked, its neighbours' are. */
 #include <assert.h>
 #include <pthread.h>
 #include <sched.h>
@@ -22,14 +24,15 @@
 
 #include "cariboulite_hip.h"
 
-#define N_DEV 8
+#define N_DEV 9
+#define N_GOOD 8          /* streams 0 .. 7 are checked sample by sample; stream 8 is fed DAMAGE */
 #define MTU 131072u
 #define NB (4u * MTU)
 
 static int n_batches = 20;
 static cl_device *dev[N_DEV]; static cl_stream *st[N_DEV]; static cl_smi *smi[N_DEV];
-static int chan_of(int i) { return i < N_DEV / 2 ? CL_CHANNEL_S1G : CL_CHANNEL_HIF; }
-static int piped(int i) { return i >= N_DEV / 2; }
+static int chan_of(int i) { return i < N_GOOD / 2 || i == N_GOOD ? CL_CHANNEL_S1G : CL_CHANNEL_HIF; }
+static int piped(int i) { return i >= N_GOOD / 2 && i < N_GOOD; }
 
 static void sample_of(int i, uint64_t g, int *I, int *Q)
 {
@@ -81,6 +84,11 @@ static void *feeder(void *arg)
         size_t n = MTU >> ((r >> 20) % 3);                             /* a whole, half or quarter batch */
         if (g + n > total) n = (size_t)(total - g);
         words_of(i, g, n, piece);
+        if (i == N_GOOD && n == MTU) {                                  /* the damaged stream: every third whole batch slipped, every fifth lost */
+            const uint64_t b = g / MTU;
+            if (b % 3 == 1) { memmove(piece + 6, piece, 4 * n - 6); memset(piece, 0x11, 6); }
+            else if (b % 5 == 2) memset(piece, 0, 4 * n);
+        }
         if (cl_smi_feed_bytes(smi[i], piece, 4 * n)) { fprintf(stderr, "feed failed\n"); abort(); }
         g += n;
     }
@@ -115,11 +123,11 @@ int main(int argc, char **argv)
     int is_registered = 0;
     for (;; iter++) {
         int done = 1;
-        for (int i = 0; i < N_DEV; i++) done &= pos[i] == total;
+        for (int i = 0; i < N_GOOD; i++) done &= pos[i] == total;
         if (done) break;
         if (iter > 200000) { fprintf(stderr, "no progress\n"); g_stop = 1; return 1; }
         if (iter % 5 == 2) {                                           /* a member read through its own device between two group calls */
-            const int i = (int)(iter / 5) % (N_DEV / 2);
+            const int i = (int)(iter / 5) % (N_GOOD / 2);
             void *b[1] = {bufs[i]};
             const int r = cl_readStream(dev[i], st[i], b, MTU, NULL, NULL, 1000);
             assert(r >= 0);
@@ -134,24 +142,26 @@ int main(int argc, char **argv)
         if (nd < 0) { fprintf(stderr, "cl_group_readStream: %s\n", cl_group_last_error(grp)); g_stop = 1; return 1; }
         for (int i = 0; i < N_DEV; i++) {
             assert(rets[i] >= 0 && (size_t)rets[i] <= num);
-            if (check(i, pos[i], (size_t)rets[i], bufs[i])) { g_stop = 1; return 1; }
+            if (i < N_GOOD && check(i, pos[i], (size_t)rets[i], bufs[i])) { g_stop = 1; return 1; }
             pos[i] += (uint64_t)rets[i];
         }
         if (!nd) { sched_yield(); usleep(50); }
     }
+    g_stop = 1;                                                        /* (the damaged stream's feeder may still be waiting for room) */
     for (int i = 0; i < N_DEV; i++) pthread_join(th[i], NULL);
+    cl_smi_flush_fifo(smi[N_GOOD]);
     if (is_registered) cl_group_unregister_buffers(grp);
     cl_group_stats gs; cl_group_getStats(grp, &gs);
 
     /* the group goes with batches read and computed ahead: they are the devices' again, pending, in order */
     uint8_t *three = (uint8_t *)malloc(3 * NB);
-    for (int i = 0; i < N_DEV; i++) { words_of(i, pos[i], 3 * MTU, three); assert(cl_smi_feed_bytes(smi[i], three, 3 * NB) == 0); }
+    for (int i = 0; i < N_GOOD; i++) { words_of(i, pos[i], 3 * MTU, three); assert(cl_smi_feed_bytes(smi[i], three, 3 * NB) == 0); }
     free(three);
-    assert(cl_group_readStream(grp, bufs, MTU, rets, 1000) == N_DEV);
-    for (int i = 0; i < N_DEV; i++) { assert(rets[i] == (int)MTU && check(i, pos[i], MTU, bufs[i]) == 0); pos[i] += MTU; }
-    for (int i = 0; i < N_DEV; i++) assert(cl_smi_pending_bytes(smi[i]) == 2 * NB);
+    assert(cl_group_readStream(grp, bufs, MTU, rets, 1000) == N_GOOD);
+    for (int i = 0; i < N_GOOD; i++) { assert(rets[i] == (int)MTU && check(i, pos[i], MTU, bufs[i]) == 0); pos[i] += MTU; }
+    for (int i = 0; i < N_GOOD; i++) assert(cl_smi_pending_bytes(smi[i]) == 2 * NB);
     cl_group_unmake(grp);
-    for (int i = 0; i < N_DEV; i++) {
+    for (int i = 0; i < N_GOOD; i++) {
         assert(cl_smi_pending_bytes(smi[i]) == 2 * NB);
         if (piped(i)) continue;                                        /* (a lone device's pipe starts from rest: not the group's history) */
         for (int c = 0; c < 2; c++) {
