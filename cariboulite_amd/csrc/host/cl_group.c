@@ -65,6 +65,7 @@ typedef struct {
                                                * call) -- a launch reads its table when it RUNS */
     uint8_t *done_ahead; long *ahead_got;      /* per row: the previous call launched over the batch it read ahead, results in h_out[cur_m ^ 1] then; elements */
     uint8_t *direct;                           /* per call and row: the copy engine wrote the client's registered buffer */
+    cl_read_ctx *ctx;                          /* per call and row: a one-by-one member's read in flight (lanes without extension stages) */
     int epoch_open;                            /* the pipe's epoch of the NEXT call was opened by the read-ahead */
     int set;                                   /* this call's event set (0 / 1) */
     size_t sub0; int queued;                   /* the lane's first sub-batch among the group's; sub-batches queued in this call */
@@ -239,7 +240,7 @@ static void lane_free(lane_t *l)
     clhip_event_destroy(l->ev_primed); free(l->primed); free(l->primed_epoch);
     clhip_host_free(l->h_out[0]); clhip_host_free(l->h_out[1]); clhip_host_free(l->h_offs[0]);
     clhip_host_free(l->tx_h_in); clhip_free(l->tx_d_in);
-    free(l->done_ahead); free(l->ahead_got); free(l->direct);
+    free(l->done_ahead); free(l->ahead_got); free(l->direct); free(l->ctx);
     free(l->member); free(l->prev_len); free(l->fast); free(l->len); free(l->got); free(l->src); free(l->ahead_mark);
     memset(l, 0, sizeof *l);
 }
@@ -384,13 +385,14 @@ cl_group *cl_group_make(cl_device *const *devs, size_t n, const char *const *key
         for (int q = 0; q < 2; q++) l->m_out[q] = l->h_out[q] ? (uint8_t *)clhip_host_device_ptr(l->h_out[q]) : NULL;
         l->done_ahead = (uint8_t *)calloc((size_t)l->n, 1); l->ahead_got = (long *)calloc((size_t)l->n, sizeof(long));
         l->direct = (uint8_t *)calloc((size_t)l->n, 1);
+        l->ctx = (cl_read_ctx *)calloc((size_t)l->n, sizeof(cl_read_ctx));
         l->sub0 = n_sub;
         l->prev_len = (size_t *)calloc((size_t)l->n, sizeof(size_t));
         l->fast = (uint8_t *)calloc((size_t)l->n, 1); l->len = (size_t *)calloc((size_t)l->n, sizeof(size_t));
         l->got = (long *)calloc((size_t)l->n, sizeof(long));
         l->src = (uint8_t **)calloc((size_t)l->n, sizeof(uint8_t *));
         l->ahead_mark = (uint8_t *)calloc((size_t)l->n, 1);
-        if (!l->d_in[0] || !l->d_in[1] || !l->d_in[2] || !l->primed || !l->primed_epoch || !l->ev_primed || !l->d_out || !l->h_out[0] || (g->readahead == 2 && !l->h_out[1]) || !l->h_offs[0] || !l->d_offs[0] || !l->m_out[0] || !l->done_ahead || !l->ahead_got || !l->direct || !l->prev_len || !l->fast || !l->len || !l->got || !l->src || !l->ahead_mark) {
+        if (!l->d_in[0] || !l->d_in[1] || !l->d_in[2] || !l->primed || !l->primed_epoch || !l->ev_primed || !l->d_out || !l->h_out[0] || (g->readahead == 2 && !l->h_out[1]) || !l->h_offs[0] || !l->d_offs[0] || !l->m_out[0] || !l->done_ahead || !l->ahead_got || !l->direct || !l->ctx || !l->prev_len || !l->fast || !l->len || !l->got || !l->src || !l->ahead_mark) {
             cl_seterr(g_make_err, sizeof g_make_err, "cl_group_make: buffers for %d streams could not be allocated", l->n);
             cl_group_unmake(g);
             return NULL;
@@ -644,8 +646,9 @@ static int single_member(cl_group *g, lane_t *l, int row, void *out, size_t numE
     }
     l->prev_len[row] = 0;
     if (l->route == ROUTE_PLAIN || st->format != l->format || st->native_dir != CL_SOAPY_SDR_RX) {
-        void *const b[1] = {out};
-        return cl_stream_read(dev, st, b, numElems, timeoutUs);
+        /* queued only: the caller runs every such member's first half before the first second half (cl_stream_read_end) */
+        cl_stream_read_begin(dev, st, out, numElems, timeoutUs, &l->ctx[row]);
+        return -1000;
     }
     /* pipe lane: Stream::Read (+ the low-pass) leaves the native samples on the device, the group's pipe slot runs from them */
     if (numElems > st->mtu_size) numElems = st->mtu_size;                        /* CaribouliteStream.cpp:306,328,351 */
@@ -786,10 +789,15 @@ int cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems, int *r
     for (int k = 0; k < g->n_lanes; k++) {
         lane_t *l = &g->lane[k];
         if (!l->queued) continue;                              /* (a runtime error before this lane's turn: its state stands) */
-        for (int r = 0; r < l->n; r++) {
+        for (int r = 0; r < l->n; r++) {                      /* first halves: everything queued on the members' own streams, nothing waited for */
             if (l->fast[r]) continue;
             const int m = l->member[r];
             rets[m] = hard ? 0 : single_member(g, l, r, buffs[m], numElems, timeoutUs);
+        }
+        for (int r = 0; r < l->n; r++) {                      /* second halves: synchronise, verdicts, deliver */
+            if (l->fast[r]) continue;
+            const int m = l->member[r];
+            if (rets[m] == -1000) rets[m] = cl_stream_read_end(g->dev[m], g->dev[m]->stream, &l->ctx[r]);
             count_read(g->dev[m]->stream, rets[m]);
         }
         if (l->pipe && l->epoch_open && clhip_rx_pipe_epoch_end(l->pipe, g->s_k)) hard = 1;

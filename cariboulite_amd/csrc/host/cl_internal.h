@@ -197,6 +197,27 @@ struct cl_device {
 
 
 /* Stream::ReadSamplesGen (CaribouliteStream.cpp:370-382) without the call counters: what cl_readStream runs */
+/* a read in flight (cl_soapy.c: SOURCE -> STAGES -> SINK) */
+typedef struct {
+    int n;                        /* samples of the call (read_so_far); <= 0: nothing to deliver */
+    const uint8_t *d_words;       /* raw words of a one-read() in-sync call, ready on hs -- or NULL */
+    const int16_t *d_cs16;        /* native int16 samples, complete -- or NULL */
+    void *hs;                     /* the HIP stream the stages are queued on */
+    int pending;                  /* cl_smi_ra_finish is the epilogue's synchronisation (it carries the read's verdict) */
+    int host_filled;              /* ASYNC, plain CS16: the ring's elements are already on their way to the sink's host side (no device stage follows) */
+    size_t ring_claimed;          /* ASYNC: elements of the ring claimed by this call; the copy out of them is queued on hs, the claim ends
+                                   * (cl_ring_get_end) once hs has been synchronised -- the epilogue's one synchronisation */
+} cl_source;
+typedef struct { int kind; void *d_dst; } cl_sink;
+typedef struct {
+    cl_source src; cl_sink sk;
+    void *out; size_t ob;         /* the client's buffer; bytes per output element */
+    long got; int bad;            /* outputs the stages yield; something could not be queued */
+    int open;                     /* _begin queued work that _end has to wait for */
+    int ret;                      /* the call's result where it was known at once (nothing pending, wrong direction, a plain CS16 chunk loop) */
+} cl_read_ctx;
+int cl_stream_read_begin(cl_device *dev, cl_stream *st, void *out, size_t numElems, long timeoutUs, cl_read_ctx *c);   /* 1: _end has work to wait for */
+int cl_stream_read_end(cl_device *dev, cl_stream *st, cl_read_ctx *c);                                               /* the call's return value */
 int cl_stream_read(cl_device *dev, cl_stream *st, void *const *buffs, size_t numElems, long timeoutUs);
 /* Stream::Read + Stream::ReadSamples(int16*) (CaribouliteStream.cpp:260-301) with the result left on the DEVICE, complete:
  * *d_iq = the call's native samples (through the selected low-pass, overrun redo included).  Returns what Stream::Read returns

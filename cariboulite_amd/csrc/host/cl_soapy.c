@@ -366,16 +366,7 @@ static size_t fmt_bytes(int fmt) { return fmt == CL_FORMAT_CF32 ? 8 : fmt == CL_
  *   SINK    where the last stage stores and how that reaches the client's buffer (below).
  *
  * The reference's dispatch is one switch over the format (CaribouliteStream.cpp:370-382); so is this one. */
-typedef struct {
-    int n;                        /* samples of the call (read_so_far); <= 0: nothing to deliver */
-    const uint8_t *d_words;       /* raw words of a one-read() in-sync call, ready on hs -- or NULL */
-    const int16_t *d_cs16;        /* native int16 samples, complete -- or NULL */
-    void *hs;                     /* the HIP stream the stages are queued on */
-    int pending;                  /* cl_smi_ra_finish is the epilogue's synchronisation (it carries the read's verdict) */
-    int host_filled;              /* ASYNC, plain CS16: the ring's elements are already on their way to the sink's host side (no device stage follows) */
-    size_t ring_claimed;          /* ASYNC: elements of the ring claimed by this call; the copy out of them is queued on hs, the claim ends
-                                   * (cl_ring_get_end) once hs has been synchronised -- the epilogue's one synchronisation */
-} cl_source;
+/* (cl_source: cl_internal.h) */
 
 static int source_acquire(cl_device *dev, cl_stream *st, size_t n, long timeout_us, void *ring_host_dst, cl_source *src)
 {
@@ -457,7 +448,7 @@ static void source_release(cl_stream *st, cl_source *src, int synced)
  * addresses). */
 enum { CL_SINK_CLIENT, CL_SINK_MIRROR, CL_SINK_BOUNCE };
 #define CL_MIRROR_MAX_BYTES ((size_t)4 << 20)
-typedef struct { int kind; void *d_dst; } cl_sink;
+/* (cl_sink: cl_internal.h) */
 
 /* ZEROCOPY=1 + cl_stream_register_buffer: the address kernels use for a client pointer inside a registered buffer, or NULL (not
  * asked for, not registered, misaligned for the 16-byte stores): the caller then takes the mirror */
@@ -615,59 +606,84 @@ static int filter_overran(cl_device *dev, cl_stream *st)
     return 1;
 }
 
-/* Stream::ReadSamplesGen  CaribouliteStream.cpp:370-382 */
-static int read_stream(cl_device *dev, cl_stream *st, void *const *buffs, size_t numElems, long timeoutUs)
+/* Stream::ReadSamplesGen  CaribouliteStream.cpp:370-382, in two halves: _begin acquires the source (the read() of the call: a FIFO pop
+ * or the reader thread's ring) and QUEUES everything behind it -- analysis, low-pass, stages, the way out -- on the source's stream;
+ * _end synchronises, takes the verdicts (the read()'s, the filter's: a call the single-pass kernel gave up on is queued again, once)
+ * and delivers.  cl_readStream is the two back to back; a stream group runs the _begin of all its one-by-one members before the
+ * first _end, so that their chains cross PCIe and run together instead of one after the other. */
+int cl_stream_read_begin(cl_device *dev, cl_stream *st, void *out, size_t numElems, long timeoutUs, cl_read_ctx *c)
 {
-    if (st->native_dir != CL_SOAPY_SDR_RX) return CL_SOAPY_SDR_NOT_SUPPORTED;       /* :248-251 */
+    memset(c, 0, sizeof *c);
+    c->out = out;
+    if (st->native_dir != CL_SOAPY_SDR_RX) { c->ret = CL_SOAPY_SDR_NOT_SUPPORTED; return 0; }       /* :248-251 */
     cl_smi *smi = dev->smi;
     clhip_set_device(smi->device);
-    void *out = buffs[0];
     if (st->format != CL_FORMAT_CS16 && numElems > st->mtu_size) numElems = st->mtu_size;   /* :306,328,351; CS16 is not clamped (:282-301) */
     if (!numElems) return 0;
     const int plain_cs16 = st->format == CL_FORMAT_CS16 && !st->rx_pipe && st->filter_type == CL_DIGFILT_NONE;
-    cl_source src;
-    cl_sink sk;
     int sink_ready = 0;
     void *ring_dst = NULL;
     if (plain_cs16 && st->use_async) {                     /* the ring's samples ARE the output: the sink comes first */
-        if (sink_open(st, out, numElems * 4, &sk)) return 0;
+        if (sink_open(st, out, numElems * 4, &c->sk)) return 0;
         sink_ready = 1;
-        ring_dst = sk.kind == CL_SINK_CLIENT ? out : (void *)st->h_conv;
+        ring_dst = c->sk.kind == CL_SINK_CLIENT ? out : (void *)st->h_conv;
     }
-    if (source_acquire(dev, st, numElems, timeoutUs, ring_dst, &src) <= 0) return 0;
-    const size_t n = (size_t)src.n;
-    if (plain_cs16 && !src.d_words && !st->use_async)
+    if (source_acquire(dev, st, numElems, timeoutUs, ring_dst, &c->src) <= 0) return 0;
+    const size_t n = (size_t)c->src.n;
+    if (plain_cs16 && !c->src.d_words && !st->use_async) {
         /* no device stage behind the read: exactly the slots the reference writes (caribou_smi.c:344-389) go to the client */
-        return cl_smi_copy_out(smi, (cl_sample_complex_int16 *)out, NULL, -1) ? 0 : src.n;
-    const size_t ob = st->rx_pipe ? (st->dsp.demod_fm ? 4 : 8) : fmt_bytes(st->format);
-    const size_t max_out = (st->rx_pipe ? clhip_rx_pipe_out_count(st->rx_pipe, n) : n) * ob;
-    if (!sink_ready && sink_open(st, out, max_out, &sk)) { if (src.pending) cl_smi_ra_finish(smi); source_release(st, &src, 0); return 0; }
+        c->ret = cl_smi_copy_out(smi, (cl_sample_complex_int16 *)out, NULL, -1) ? 0 : c->src.n;
+        return 0;
+    }
+    c->ob = st->rx_pipe ? (st->dsp.demod_fm ? 4 : 8) : fmt_bytes(st->format);
+    const size_t max_out = (st->rx_pipe ? clhip_rx_pipe_out_count(st->rx_pipe, n) : n) * c->ob;
+    if (!sink_ready && sink_open(st, out, max_out, &c->sk)) { if (c->src.pending) cl_smi_ra_finish(smi); source_release(st, &c->src, 0); return 0; }
+    if (c->src.host_filled) c->got = c->src.n;             /* (ASYNC, plain CS16: already on its way to the sink's host side) */
+    else {
+        c->bad = stages_queue(dev, st, &c->src, &c->sk, &c->got);
+        if (!c->bad) c->bad = sink_queue(st, &c->sk, (size_t)(c->got > 0 ? c->got : 0) * c->ob, c->src.hs);
+    }
+    c->open = 1;
+    return 1;
+}
+
+int cl_stream_read_end(cl_device *dev, cl_stream *st, cl_read_ctx *c)
+{
+    if (!c->open) return c->ret;
+    cl_smi *smi = dev->smi;
+    clhip_set_device(smi->device);
+    c->open = 0;
     for (int attempt = 0;; attempt++) {
-        long got = 0;
-        int bad = 0;
-        if (src.host_filled) got = src.n;                  /* (ASYNC, plain CS16: already on its way to the sink's host side) */
-        else {
-            bad = stages_queue(dev, st, &src, &sk, &got);
-            if (!bad) bad = sink_queue(st, &sk, (size_t)(got > 0 ? got : 0) * ob, src.hs);
+        if (attempt) {                                     /* (the stages again, behind a filter that is on its scan path now) */
+            c->got = 0;
+            c->bad = stages_queue(dev, st, &c->src, &c->sk, &c->got);
+            if (!c->bad) c->bad = sink_queue(st, &c->sk, (size_t)(c->got > 0 ? c->got : 0) * c->ob, c->src.hs);
         }
         /* the one synchronisation; with it the verdict of the read() whose words the stages took (host-certain: in sync) */
-        int fr = src.n;
-        if (src.pending) { fr = cl_smi_ra_finish(smi); src.pending = 0; }
-        else if (clhip_stream_sync(src.hs)) fr = CL_SMI_ERR_IO;
-        if (bad) { clhip_stream_sync(src.hs); fr = CL_SMI_ERR_IO; }
-        source_release(st, &src, 1);
+        int fr = c->src.n;
+        if (c->src.pending) { fr = cl_smi_ra_finish(smi); c->src.pending = 0; }
+        else if (clhip_stream_sync(c->src.hs)) fr = CL_SMI_ERR_IO;
+        if (c->bad) { clhip_stream_sync(c->src.hs); fr = CL_SMI_ERR_IO; }
+        source_release(st, &c->src, 1);
         if (fr == CL_SMI_ERR_IO) printf("reader thread failed to read SMI!\n");    /* :270 */
         if (fr <= 0) return 0;                                                      /* :266-276 */
         if (!filter_overran(dev, st)) {
-            if (got <= 0) return 0;
-            sink_deliver(st, &sk, out, (size_t)got * ob);
-            return (int)got;
+            if (c->got <= 0) return 0;
+            sink_deliver(st, &c->sk, c->out, (size_t)c->got * c->ob);
+            return (int)c->got;
         }
         /* the single-pass filter kernel gave up: its state is back where it was and the object is on the scan path; whatever ran
          * behind it ran on invalid samples: undone, and the stages are queued again, once */
         if (st->rx_pipe) clhip_rx_pipe_rollback(st->rx_pipe);
         if (attempt) return 0;
     }
+}
+
+static int read_stream(cl_device *dev, cl_stream *st, void *const *buffs, size_t numElems, long timeoutUs)
+{
+    cl_read_ctx c;
+    cl_stream_read_begin(dev, st, buffs[0], numElems, timeoutUs, &c);
+    return cl_stream_read_end(dev, st, &c);
 }
 
 int cl_stream_read(cl_device *dev, cl_stream *st, void *const *buffs, size_t numElems, long timeoutUs) { return read_stream(dev, st, buffs, numElems, timeoutUs); }

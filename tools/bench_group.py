@@ -25,6 +25,9 @@ CASES = {
     "cf32": ("CF32", "float32", 2, None, 8.0),
     "cf32_fir64_rs_3_2": ("CF32", "float32", 2, {"FIR": "64:1000000", "RESAMP": "3/2"}, 12.0),
     "cf32_fir64_fm_demod": ("CF32", "float32", 1, {"FIR": "64:100000", "DEMOD": "FM"}, 4.0),
+    # the reference's own low-pass selected on every member (setBandwidth 100 kHz: Butterworth-6, CaribouliteStream.cpp:282-301): such
+    # members are read through their own devices inside the group call, their chains queued together
+    "cs16_iir": ("CS16", "int16", 2, None, 4.0, 100e3),
 }
 
 
@@ -100,7 +103,8 @@ def run_case(name, a):
     from cariboulite_amd import soapy as S, synth
     if name in TX_CASES:
         return run_tx_case(name, a)
-    fmt, dt, width, args, out_b = CASES[name]
+    fmt, dt, width, args, out_b = CASES[name][:5]
+    bw = CASES[name][5] if len(CASES[name]) > 5 else None
     n, K = a.streams, a.calls
     words = [synth.smi_stream_bytes(K * MTU, i % 2, stream=i)[0] for i in range(min(n, 4))]      # a few distinct streams, reused
     res = {}
@@ -112,6 +116,8 @@ def run_case(name, a):
         for i in range(n):
             d = S.Device(dict(driver="Cariboulite", channel="S1G" if i % 2 == 0 else "HiF"))
             sts.append(d.setupStream(S.SOAPY_SDR_RX, fmt, args=args))
+            if bw:
+                d.setBandwidth(S.SOAPY_SDR_RX, 0, bw)
             d.activateStream(sts[-1])
             devs.append(d)
         return devs, sts
