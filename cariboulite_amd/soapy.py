@@ -209,6 +209,10 @@ class Device:
         self.smi = lib().cl_device_smi(self.h)
 
     def close(self):
+        grp = getattr(self, "_group", None)
+        grp = grp() if grp is not None else None
+        if grp is not None:
+            grp.close()                             # (a group holds its members' seams: it goes first, they are ordinary devices again)
         if getattr(self, "h", None):
             lib().cl_device_unmake(self.h)
             self.h = None
@@ -375,6 +379,9 @@ class Group:
             raise RuntimeError(lib().cl_group_last_error(None).decode())
         self._rets = (C.c_int * len(self.devices))()
         self._ptrs = (C.c_void_p * len(self.devices))()
+        import weakref
+        for d in self.devices:
+            d._group = weakref.ref(self)
 
     def readStream(self, buffs, numElems, timeoutUs=100000):
         last = getattr(self, "_last_buffs", ())
@@ -417,6 +424,8 @@ class Group:
     def close(self):
         if getattr(self, "h", None) and _lib is not None:
             _lib.cl_group_unmake(self.h)
+            for d in getattr(self, "devices", ()):
+                d._group = None
         self.h = None
 
     __del__ = close

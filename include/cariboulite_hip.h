@@ -614,7 +614,7 @@ typedef struct {
     uint64_t ahead_reads;        /* batched reads whose batch the call BEFORE had already staged and copied in (READAHEAD) */
 } cl_group_stats;
 cl_group   *cl_group_make(cl_device *const *devs, size_t n_devs, const char *const *keys, const char *const *vals, size_t n_kwargs);
-void        cl_group_unmake(cl_group *g);
+void        cl_group_unmake(cl_group *g);                     /* BEFORE cl_device_unmake of any member: the group holds the members' seams (their FIFOs live in its slab) */
 size_t      cl_group_size(const cl_group *g);
 int         cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems, int *rets, long timeoutUs);
 /* A group of devices set up for TX (boards are half duplex, Cariboulite.hpp:60: a group reads or writes): N cl_writeStream calls as

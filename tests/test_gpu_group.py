@@ -235,6 +235,21 @@ def test_group_make_refuses_what_it_cannot_read(S):
     g.close(); d0.close(); d1.close()
 
 
+def test_a_member_closed_first_takes_its_group_with_it(S):
+    """(the Python face) closing a member while its group stands closes the group first: the group holds the members' seams"""
+    devs, sts = make_devices(S, 3, S.SOAPY_SDR_CS16, None, lambda i: "S1G")
+    grp = S.Group(devs)
+    for d in devs:
+        d.feedSmiBytes(batch_bytes(0, 0, 0))
+    bufs = sentinel_buffers(3, (MTU + 2, 2), np.int16)
+    assert grp.readStream(bufs, MTU)[0] == 3
+    devs[1].close()
+    assert grp.h is None
+    assert devs[0].readStream(sts[0], [bufs[0]], MTU).ret == 0        # an ordinary device again (nothing pending)
+    for d in devs:
+        d.close()
+
+
 def test_the_groups_slab_members_in_step_out_of_step_outgrown_and_released(S, orc):
     """The members' byte FIFOs live in the group's ONE pinned slab (a slice each): batches of members fed and read in step lie one
     stride apart and come in as one 2-D copy per sub-batch; a member that is out of step (it was fed an extra half batch once) comes
