@@ -56,7 +56,6 @@ typedef struct {
     size_t *primed; unsigned *primed_epoch;   /* per row: bytes of the NEXT call's batch already staged in the member's FIFO and copied to d_in[next_in]
                                                * (0: none), and the member seam's foreign_epoch then -- a reader of the seam's own that came in between bumps it */
     void *ev_primed;                      /* behind the read-ahead's copies */
-    size_t *prev_len;                     /* per row: bytes the PREVIOUS call put into d_in[prev_in] on the batched route (0: none) */
     size_t out_stride;                    /* elements per row of d_out / h_out */
     uint8_t *d_out;
     uint8_t *h_out[2], *m_out[2]; int cur_m;   /* two pinned mirrors (this call's results / the next call's, computed ahead) and the device's addresses of
@@ -241,7 +240,7 @@ static void lane_free(lane_t *l)
     clhip_host_free(l->h_out[0]); clhip_host_free(l->h_out[1]); clhip_host_free(l->h_offs[0]);
     clhip_host_free(l->tx_h_in); clhip_free(l->tx_d_in);
     free(l->done_ahead); free(l->ahead_got); free(l->direct); free(l->ctx);
-    free(l->member); free(l->prev_len); free(l->fast); free(l->len); free(l->got); free(l->src); free(l->ahead_mark);
+    free(l->member); free(l->fast); free(l->len); free(l->got); free(l->src); free(l->ahead_mark);
     memset(l, 0, sizeof *l);
 }
 
@@ -255,6 +254,8 @@ void cl_group_unmake(cl_group *g)
     pool_stop(&g->pool);
     cl_group_unregister_buffers(g);
     ahead_cancel_all(g);                                       /* what was read ahead is pending again */
+    for (int k = 0; k < g->n_lanes; k++)                       /* raw words standing in for a seam's persistent buffer: unpacked now, the lane's buffers go */
+        for (int r = 0; g->lane[k].d_in[0] && r < g->lane[k].n; r++) cl_smi_restore_prev_words(g->dev[g->lane[k].member[r]]->smi, g->lane[k].channel);
     if (g->slab) {                                             /* the members' FIFOs move out before the slab goes */
         for (size_t i = 0; i < g->n; i++) {
             cl_smi *smi = g->dev[i]->smi;
@@ -387,12 +388,11 @@ cl_group *cl_group_make(cl_device *const *devs, size_t n, const char *const *key
         l->direct = (uint8_t *)calloc((size_t)l->n, 1);
         l->ctx = (cl_read_ctx *)calloc((size_t)l->n, sizeof(cl_read_ctx));
         l->sub0 = n_sub;
-        l->prev_len = (size_t *)calloc((size_t)l->n, sizeof(size_t));
         l->fast = (uint8_t *)calloc((size_t)l->n, 1); l->len = (size_t *)calloc((size_t)l->n, sizeof(size_t));
         l->got = (long *)calloc((size_t)l->n, sizeof(long));
         l->src = (uint8_t **)calloc((size_t)l->n, sizeof(uint8_t *));
         l->ahead_mark = (uint8_t *)calloc((size_t)l->n, 1);
-        if (!l->d_in[0] || !l->d_in[1] || !l->d_in[2] || !l->primed || !l->primed_epoch || !l->ev_primed || !l->d_out || !l->h_out[0] || (g->readahead == 2 && !l->h_out[1]) || !l->h_offs[0] || !l->d_offs[0] || !l->m_out[0] || !l->done_ahead || !l->ahead_got || !l->direct || !l->ctx || !l->prev_len || !l->fast || !l->len || !l->got || !l->src || !l->ahead_mark) {
+        if (!l->d_in[0] || !l->d_in[1] || !l->d_in[2] || !l->primed || !l->primed_epoch || !l->ev_primed || !l->d_out || !l->h_out[0] || (g->readahead == 2 && !l->h_out[1]) || !l->h_offs[0] || !l->d_offs[0] || !l->m_out[0] || !l->done_ahead || !l->ahead_got || !l->direct || !l->ctx || !l->fast || !l->len || !l->got || !l->src || !l->ahead_mark) {
             cl_seterr(g_make_err, sizeof g_make_err, "cl_group_make: buffers for %d streams could not be allocated", l->n);
             cl_group_unmake(g);
             return NULL;
@@ -627,24 +627,15 @@ static void count_read(cl_stream *st, int ret)
 }
 
 /* A member off the batched route: its own device's single-stream call, with the group's pipe slot standing where the
- * device's own pipe would.  Before it, the persistent native buffer of its seam is brought up to date from the raw words of
- * the previous (batched) call, so that a re-sync finds in the slots it leaves untouched what the reference's
- * interm_native_buffer would hold (caribou_smi.c:382-389, CaribouliteStream.cpp:304-367). */
+ * device's own pipe would.  (What a re-sync finds in the slots it leaves untouched -- the reference's interm_native_buffer,
+ * caribou_smi.c:382-389, CaribouliteStream.cpp:304-367 -- is the seam's business: the batched route leaves it the raw words of
+ * the member's last batch, pass 3.) */
 static int single_member(cl_group *g, lane_t *l, int row, void *out, size_t numElems, long timeoutUs)
 {
     const int m = l->member[row];
     cl_device *dev = g->dev[m];
     cl_stream *st = dev->stream;
-    cl_smi *smi = dev->smi;
     g->stats.single_reads++;
-    if (l->prev_len[row] && (l->route == ROUTE_PIPE || st->format != CL_FORMAT_CS16)) {
-        const size_t pl = l->prev_len[row];
-        if (cl_ensure((void **)&smi->d_iq, &smi->iq_cap, pl / 4 + 8, 4, 0) ||
-            clhip_smi_unpack_aligned(l->channel, l->d_in[l->prev_in] + (size_t)row * l->in_stride, pl, CL_FORMAT_CS16, smi->d_iq, NULL, smi->stream))
-            return 0;
-        smi->prev_words = NULL;
-    }
-    l->prev_len[row] = 0;
     if (l->route == ROUTE_PLAIN || st->format != l->format || st->native_dir != CL_SOAPY_SDR_RX) {
         /* queued only: the caller runs every such member's first half before the first second half (cl_stream_read_end) */
         cl_stream_read_begin(dev, st, out, numElems, timeoutUs, &l->ctx[row]);
@@ -874,14 +865,18 @@ int cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems, int *r
                     pthread_mutex_lock(&dev->smi->fifo_mu);
                     cl_fifo_unstage(&dev->smi->rx, l->len[r]);
                     pthread_mutex_unlock(&dev->smi->fifo_mu);
-                    l->fast[r] = 0; l->prev_len[r] = 0;
+                    l->fast[r] = 0;
                     count_read(dev->stream, 0);
                     continue;
                 }
                 confirm_staged(dev->smi, l->len[r]);
                 dev->smi->stat_samples += (uint64_t)(l->len[r] / 4);
-                dev->smi->prev_words = NULL;                       /* (the lane's previous raw words stand in for them) */
-                l->prev_len[r] = l->len[r];
+                /* the seam's persistent int16 buffer (the slots a re-synchronised read() leaves untouched keep what the call before
+                 * left there, caribou_smi.c:382-389) was not written: this call's raw words stand in for it, where they lie -- the lane
+                 * rotates three input buffers, a row is only written again in a call that reads it again and moves this pointer -- and
+                 * the seam unpacks them the first time it needs the samples (cl_smi_restore_prev_words); a read through the member's
+                 * own device in between overrides them like any other read */
+                if (cl_smi_set_prev_words(dev->smi, l->channel, l->d_in[l->cur_in] + (size_t)r * l->in_stride, l->len[r])) hard = 1;
                 const size_t bytes = (size_t)l->got[r] * l->elem_bytes;
                 if (!l->direct[r])
                     pool_submit(&g->pool, (uint8_t *)buffs[m], l->h_out[l->cur_m] + (size_t)r * l->out_stride * l->elem_bytes, bytes);

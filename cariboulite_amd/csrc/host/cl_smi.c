@@ -690,6 +690,16 @@ int cl_smi_restore_prev_words(cl_smi *dev, int channel)
     return clhip_smi_unpack_aligned(channel, w, n, CL_FORMAT_CS16, dev->d_iq, NULL, dev->stream) || clhip_stream_sync(dev->stream) ? -1 : 0;
 }
 
+/* `w` (len bytes of raw words, in sync, on the device) stand in for the persistent buffer from now on.  The buffer is an OVERLAY of
+ * every call so far -- a call writes the slots of its own length, the slots behind them keep what longer calls left there -- so words
+ * that are shorter than the ones they replace may only do so once those have been unpacked. */
+int cl_smi_set_prev_words(cl_smi *dev, int channel, const uint8_t *w, size_t len)
+{
+    if (dev->prev_words && dev->prev_words_len > len && cl_smi_restore_prev_words(dev, channel)) return -1;
+    dev->prev_words = w; dev->prev_words_len = len;
+    return 0;
+}
+
 /* A runtime error inside the loop, behind a staged read(): everything queued is waited for, the read() in hand (`got` bytes, the
  * oldest staged ones) counts as consumed -- like a read() whose analysis failed, caribou_smi.c:665-668 -- and what was staged ahead
  * of it is pending again: the FIFO is never left with bytes that are neither consumed nor pending. */
@@ -744,6 +754,22 @@ long cl_smi_ra_launch(cl_smi *dev, int channel, size_t length_samples, int16_t *
     while (left) {
         const size_t want = left < cap_read ? left : cap_read;
         size_t got; int slot, head_ok = 0;
+        if (dev->ahead.valid && dev->ahead.len < want) {
+            /* staged ahead when the FIFO held less than this read() asks for: if more has arrived since, the read() of the call
+             * (caribou_smi.c:655: as many bytes as there are, up to len) would return more than what was staged -- and where a
+             * read() ends decides where the next one looks for the sync pattern.  Staged again, now. */
+            pthread_mutex_lock(&dev->fifo_mu);
+            const int more = cl_fifo_pending(&dev->rx) != 0;
+            pthread_mutex_unlock(&dev->fifo_mu);
+            if (more) {
+                if (dev->cstream) clhip_stream_sync(dev->cstream);
+                pthread_mutex_lock(&dev->fifo_mu);
+                cl_fifo_unstage(&dev->rx, dev->ahead.len);
+                pthread_mutex_unlock(&dev->fifo_mu);
+                dev->ahead.valid = 0;
+                cl_smi_ahead_note(dev);
+            }
+        }
         if (dev->ahead.valid) {
             slot = dev->ahead.slot; got = dev->ahead.len; head_ok = dev->ahead.head_ok; dev->ahead.valid = 0;
             cl_smi_ahead_note(dev);
@@ -773,7 +799,7 @@ long cl_smi_ra_launch(cl_smi *dev, int channel, size_t length_samples, int16_t *
              * format, the IIR's input conversion, the fused pipe -- and cl_smi_ra_finish is the call's one synchronisation. */
             if (clhip_stream_wait_event(dev->stream, dev->ev_copied[slot])) return ra_fail(dev, got);
             dev->fast_words = dev->d_slot[slot];
-            dev->prev_words = dev->d_slot[slot]; dev->prev_words_len = got;   /* (a caller that writes dev->d_iq itself clears this) */
+            if (cl_smi_set_prev_words(dev, channel, dev->d_slot[slot], got)) return ra_fail(dev, got);   /* (a caller that writes dev->d_iq itself clears this) */
             dev->h_offs[0] = 0;
             dev->fast_used = 1;
             cl_chunk *c = &dev->chunks[dev->n_chunks];

@@ -213,9 +213,9 @@ class Device:
         grp = grp() if grp is not None else None
         if grp is not None:
             grp.close()                             # (a group holds its members' seams: it goes first, they are ordinary devices again)
-        if getattr(self, "h", None):
-            lib().cl_device_unmake(self.h)
-            self.h = None
+        if getattr(self, "h", None) and _lib is not None:  # (at interpreter shutdown the module's globals may be gone already)
+            _lib.cl_device_unmake(self.h)
+        self.h = None
 
     __del__ = close
 

@@ -462,3 +462,85 @@ def test_32_streams_with_every_batch_pending_beforehand(S, fmt, dtype, args, sha
     script = {(1, 3): ("slip", 3), (2, 17): ("slip", 6), (2, 9): ("lost",), (3, 5): ("short", NB // 2), (3, 21): ("none",), (4, 30): ("slip", 9)}
     log, st = run_script(S, n, getattr(S, "SOAPY_SDR_" + fmt), args, dtype, shape, script, calls, deep=True)
     assert st["errors"] == 0 and st["ahead_reads"] >= (calls - 3) * (n - 6), st
+
+
+@pytest.mark.parametrize("seed,staged", [(1, True), (2, True), (3, False), (4, False), (5, True), (6, False), (7, True), (8, False), (9, False), (10, True)])
+def test_random_walk_against_lone_devices(S, seed, staged):
+    """A seeded random walk over everything a client can do between and in group calls -- feed whole / half / damaged / no batches to
+    some members, ask for a whole or half MTU, read a member through its own device (plain lanes), flush one, switch a low-pass on or
+    off, register / release buffers -- with eight streams whose FIFOs run several batches deep (work is made ahead and given up all
+    the time).  After every step every stream equals its lone device: output, return value, pending bytes."""
+    rng = np.random.default_rng(seed)
+    n = 8
+    args = {"FIR": "64:1000000", "RESAMP": "3/2"} if staged else None
+    full = MTU * 3 // 2 if staged else MTU
+    chan = lambda i: "S1G" if i % 2 else "HiF"
+    gdevs, gsts = make_devices(S, n, S.SOAPY_SDR_CF32, args, chan)
+    sdevs, ssts = make_devices(S, n, S.SOAPY_SDR_CF32, args, chan)
+    grp = S.Group(gdevs, {"SUBBATCH": "2", "SLAB_MB": "4"})
+    gb, sb = sentinel_buffers(n, (full + 8, 2), np.float32), sentinel_buffers(n, (full + 8, 2), np.float32)
+    fed = [0] * n                                          # batches fed per stream so far
+
+    def feed(i, how):
+        ch = 0 if chan(i) == "S1G" else 1
+        b = batch_bytes(i, fed[i], ch); fed[i] += 1
+        hist[i].append(str(how))
+        if how == "slip":
+            b = slipped(b, int(rng.integers(1, 9)))
+        elif how == "lost":
+            b[:] = 0
+        elif how == "half":
+            b = b[: NB // 2]
+        gdevs[i].feedSmiBytes(b); sdevs[i].feedSmiBytes(b)
+
+    hist = [[] for _ in range(n)]                          # what was fed to / done with every stream, for the failure message
+
+    def compare(where):
+        for i in range(n):
+            if not same(gb[i], sb[i]):
+                a, b = gb[i].reshape(-1), sb[i].reshape(-1)
+                d = np.flatnonzero(~((a == b) | (np.isnan(a) & np.isnan(b))))
+                raise AssertionError(f"{where} stream {i}: {d.size} values differ, first at {d[0]} ({a[d[0]]} vs {b[d[0]]}), last at {d[-1]}; "
+                                     f"history {hist[i][-12:]}; rets so far {where}")
+            assert gdevs[i].pendingSmiBytes() == sdevs[i].pendingSmiBytes(), (where, i)
+
+    registered = False
+    for step in range(36):
+        for i in range(n):                                 # keep most FIFOs two to four batches deep
+            while gdevs[i].pendingSmiBytes() < int(rng.integers(1, 4)) * NB:
+                feed(i, rng.choice(["good"] * 12 + ["slip", "lost", "half"]))
+        op = rng.choice(["call"] * 5 + ["half", "lone", "flush", "filter", "register"])
+        for x in gb + sb:
+            x[...] = np.nan
+        if op == "lone" and not staged:
+            i = int(rng.integers(0, n))
+            assert gdevs[i].readStream(gsts[i], [gb[i]], MTU).ret == sdevs[i].readStream(ssts[i], [sb[i]], MTU).ret
+            compare(("lone", step))
+        elif op == "flush":
+            i = int(rng.integers(0, n))
+            assert gdevs[i].flushSmiFifo() == sdevs[i].flushSmiFifo() == 0
+            hist[i].append("flush")
+        elif op == "filter":
+            i = int(rng.integers(0, n)); bw = float(rng.choice([100e3, 1e6]))
+            gdevs[i].setBandwidth(S.SOAPY_SDR_RX, 0, bw); sdevs[i].setBandwidth(S.SOAPY_SDR_RX, 0, bw)
+            hist[i].append(f"bw{bw:g}")
+        elif op == "register":
+            if registered:
+                grp.unregisterBuffers()
+            else:
+                grp.registerBuffers(gb)
+            registered = not registered
+        num = MTU // 2 if op == "half" else MTU
+        for x in gb + sb:
+            x[...] = np.nan
+        _, rets = grp.readStream(gb, num)
+        srets = [sdevs[i].readStream(ssts[i], [sb[i]], num).ret for i in range(n)]
+        for i in range(n):
+            hist[i].append(f"<{op}:{num}:{rets[i]}>")
+        assert rets == srets, (step, op, rets, srets)
+        compare((str(op), step))
+    st = grp.stats()
+    assert st["errors"] == 0 and st["ahead_reads"] > 40 and st["single_reads"] > 5, st
+    grp.close()
+    for d in gdevs + sdevs:
+        d.close()
