@@ -205,6 +205,7 @@ typedef struct {
     const int16_t *d_cs16;        /* native int16 samples, complete -- or NULL */
     void *hs;                     /* the HIP stream the stages are queued on */
     int pending;                  /* cl_smi_ra_finish is the epilogue's synchronisation (it carries the read's verdict) */
+    int err;                      /* the chunk loop's error where the call delivers nothing (CL_SMI_ERR_*); 0 otherwise */
     int host_filled;              /* ASYNC, plain CS16: the ring's elements are already on their way to the sink's host side (no device stage follows) */
     size_t ring_claimed;          /* ASYNC: elements of the ring claimed by this call; the copy out of them is queued on hs, the claim ends
                                    * (cl_ring_get_end) once hs has been synchronised -- the epilogue's one synchronisation */

@@ -419,6 +419,7 @@ static int source_acquire(cl_device *dev, cl_stream *st, size_t n, long timeout_
         ret = cl_smi_read_device(smi, dev->channel, n, 0, NULL);
     if (ret < 0) {
         if (ret == CL_SMI_ERR_IO) printf("reader thread failed to read SMI!\n");    /* :270 */
+        src->err = ret;
         ret = 0;                                                                    /* :266-276 */
     }
     src->n = ret; src->d_cs16 = smi->d_iq;
@@ -628,7 +629,12 @@ int cl_stream_read_begin(cl_device *dev, cl_stream *st, void *out, size_t numEle
         sink_ready = 1;
         ring_dst = c->sk.kind == CL_SINK_CLIENT ? out : (void *)st->h_conv;
     }
-    if (source_acquire(dev, st, numElems, timeoutUs, ring_dst, &c->src) <= 0) return 0;
+    if (source_acquire(dev, st, numElems, timeoutUs, ring_dst, &c->src) <= 0) {
+        /* CS16 is read straight into the client's buffer (:282-301): what the chunk loop wrote before the read() that found no sync
+         * ("-3", caribou_smi.c:665-668) is in it, although the call reports 0 elements */
+        if (plain_cs16 && !st->use_async && c->src.err == CL_SMI_ERR_SYNC) cl_smi_copy_out(smi, (cl_sample_complex_int16 *)out, NULL, -1);
+        return 0;
+    }
     const size_t n = (size_t)c->src.n;
     if (plain_cs16 && !c->src.d_words && !st->use_async) {
         /* no device stage behind the read: exactly the slots the reference writes (caribou_smi.c:344-389) go to the client */

@@ -100,6 +100,16 @@ def smi_read(channel, stream_bytes, length_samples, native_batch_len=NATIVE_BATC
     return ret, iq, meta
 
 
+def smi_read_pos(channel, stream_bytes, length_samples, native_batch_len=NATIVE_BATCH_LEN, max_read=0, fill=-21846):
+    """smi_read, and how many bytes of the source the chunk loop consumed (caribou_smi.c:643-679: every read() it issued, the one whose
+    analysis failed included) -- what a model of a sequence of calls over one byte FIFO needs"""
+    b = np.ascontiguousarray(stream_bytes, dtype=np.uint8)
+    src = _Src(b.ctypes.data if b.size else None, b.size, 0, max_read)
+    iq = np.full((length_samples + 2, 2), fill, dtype=np.int16)
+    ret = lib().orc_smi_read(C.byref(src), int(channel), _p(iq, C.c_int16), None, C.c_size_t(length_samples), C.c_size_t(native_batch_len))
+    return ret, iq, int(src.pos)
+
+
 # ---------------------------------------------------------------- TX integer
 def generate_data(iq, mode=TX_DOCUMENTED):
     iq = np.ascontiguousarray(iq, dtype=np.int16).reshape(-1, 2)

@@ -1,0 +1,111 @@
+"""-m gpu: one Soapy device against a MODEL of the reference over a random walk -- the lone device is what the stream group's tests
+compare against, so it is itself held against the reference's semantics for SEQUENCES of calls over one byte stream, which the
+scripted tests (one batch fed per call) cannot reach:
+
+  * /dev/smi is a byte FIFO: a read() returns as many bytes as there are, up to the length asked for (caribou_smi.c:466-492,655), so
+    where one read() ends decides where the next one looks for the sync pattern;
+  * caribou_smi_read's chunk loop (caribou_smi.c:632-682: the oracle's orc_smi_read, run here over exactly the bytes that are
+    pending at the call): re-syncs, the extrapolated sample, the slots it leaves untouched, "-3" with the failing read() consumed,
+    short counts when the FIFO runs dry, ragged byte counts behind slipped batches;
+  * Stream::ReadSamples (CaribouliteStream.cpp:282-367): CS16 goes straight into the client's buffer (only the slots the chunk loop
+    writes change), every other format converts ALL n slots of the Stream's persistent intermediate buffer -- an overlay of every
+    call so far -- and any error is 0 elements with the client's buffer untouched (:266-276).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+NB, MTU, SENT = 524288, 131072, -21846
+
+
+@pytest.fixture(scope="module")
+def S():
+    import torch
+    from cariboulite_amd import hip, soapy
+    assert torch.cuda.is_available() and hip.require_gpu().startswith("gfx950")
+    return soapy
+
+
+class RefDevice:
+    """the reference's Stream over a byte FIFO (the model)"""
+
+    def __init__(self, orc, ch, fmt):
+        self.orc, self.ch, self.fmt = orc, ch, fmt
+        self.fifo = np.zeros(0, np.uint8)
+        self.interm = np.zeros((8 * MTU + 2, 2), np.int16)      # interm_native_buffer (the formats that convert); zero-initialised like ours
+
+    def feed(self, b):
+        self.fifo = np.concatenate([self.fifo, b])
+
+    def pending(self):
+        return self.fifo.size
+
+    def flush(self):
+        self.fifo = self.fifo[:0]
+
+    def read(self, client, num):
+        """Stream::ReadSamplesGen into `client` (a numpy buffer the caller keeps between calls); returns the element count"""
+        n = num if self.fmt == "CS16" else min(num, MTU)
+        if n == 0:
+            return 0
+        ret, iq, pos = self.orc.smi_read_pos(self.ch, self.fifo[: 4 * n], n, NB, fill=SENT)
+        self.fifo = self.fifo[pos:]
+        touched = (iq != SENT).any(axis=1)
+        if self.fmt == "CS16":
+            client[: n + 2][touched] = iq[touched]              # the chunk loop writes the client's buffer itself, failed calls included
+            return ret if ret > 0 else 0
+        self.interm[: n + 2][touched] = iq[touched]
+        if ret <= 0:
+            return 0
+        conv = {"CF32": self.orc.cs16_to_cf32, "CF64": self.orc.cs16_to_cf64, "CS8": self.orc.cs16_to_cs8}[self.fmt]
+        client[:ret] = conv(self.interm[:ret])                  # (:304-367: the count the chunk loop returned, stale slots included)
+        return ret
+
+
+@pytest.mark.parametrize("seed,fmt", [(1, "CS16"), (2, "CF32"), (3, "CS16"), (4, "CF32"), (5, "CS8"), (6, "CF64"), (7, "CF32"), (8, "CS16"),
+                                      (9, "CS16"), (10, "CF32"), (11, "CS16"), (12, "CF32"), (13, "CS16"), (14, "CS8"), (15, "CF32"), (16, "CS16")])
+def test_one_device_against_the_reference_model(S, orc, seed, fmt):
+    from cariboulite_amd import synth
+    rng = np.random.default_rng(100 + seed)
+    ch = seed % 2
+    dev = S.Device(dict(driver="Cariboulite", channel="S1G" if ch == 0 else "HiF"))
+    st = dev.setupStream(S.SOAPY_SDR_RX, fmt)
+    dev.activateStream(st)
+    ref = RefDevice(orc, ch, fmt)
+    dt = {"CS16": np.int16, "CF32": np.float32, "CF64": np.float64, "CS8": np.int8}[fmt]
+    rows = 2 * MTU + 16
+    got, want = np.zeros((rows, 2), dt), np.zeros((rows, 2), dt)        # the client's buffers persist across calls (CS16: untouched slots)
+    fed = 0
+    stats = dict(resync=0, lost=0, short=0, ragged=0, multi=0)
+    for step in range(60):
+        while ref.pending() < int(rng.integers(0, 4)) * NB:
+            how = rng.choice(["good"] * 10 + ["slip", "lost", "half", "quarter"])
+            b = synth.smi_stream_bytes(MTU, ch, stream=300 + seed, n0=fed * MTU)[0].copy(); fed += 1
+            if how == "slip":
+                k = int(rng.integers(1, 9))
+                b = np.concatenate([((np.arange(k, dtype=np.uint8) * 7 + 3) & 0x3F), b[: b.size - (k if rng.integers(0, 2) else 0)]])
+                stats["resync"] += 1; stats["ragged"] += b.size % 4 != 0
+            elif how == "lost":
+                b[:] = 0; stats["lost"] += 1
+            elif how == "half":
+                b = b[: NB // 2]
+            elif how == "quarter":
+                b = b[: NB // 4]
+            dev.feedSmiBytes(b); ref.feed(b)
+        if rng.integers(0, 12) == 0:
+            dev.flushSmiFifo(); ref.flush()
+        choices = [MTU] * 6 + [MTU // 2, 1000, 4, MTU - 4]
+        if fmt == "CS16":
+            choices += [MTU + 4096, 2 * MTU]                    # CS16 is not clamped to the MTU: chunk loops of several read()s
+        num = int(rng.choice(choices))
+        r_dev = dev.readStream(st, [got], num).ret
+        r_ref = ref.read(want, num)
+        assert r_dev == r_ref, (step, num, r_dev, r_ref, dev.pendingSmiBytes(), ref.pending())
+        assert dev.pendingSmiBytes() == ref.pending(), (step, num)
+        if not np.array_equal(got, want):
+            d = np.flatnonzero((got != want).any(axis=1))
+            raise AssertionError(f"step {step} num {num} ret {r_dev}: {d.size} slots differ, first {d[0]} ({got[d[0]]} vs {want[d[0]]}), last {d[-1]}")
+        stats["short"] += 0 < r_dev < min(num, MTU if fmt != "CS16" else num)
+        stats["multi"] += num > MTU
+    assert stats["resync"] + stats["lost"] >= 2, stats             # (the walk went where it is meant to go)
+    dev.close()
