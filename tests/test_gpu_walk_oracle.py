@@ -109,3 +109,63 @@ def test_one_device_against_the_reference_model(S, orc, seed, fmt):
         stats["multi"] += num > MTU
     assert stats["resync"] + stats["lost"] >= 2, stats             # (the walk went where it is meant to go)
     dev.close()
+
+
+@pytest.mark.parametrize("seed,stages", [(21, "rs32"), (22, "fm"), (23, "rs32"), (24, "rs32"), (25, "fm"), (26, "rs32")])
+def test_one_device_with_extension_stages_against_the_model(S, orc, seed, stages):
+    """The same walk with the extension stages behind the read (FIR64 -> 3/2 polyphase, FIR64 -> FM demod):
+    the model runs the oracle's float64 FIR / resampler / demodulator, state carried from call to call, over the n slots of the
+    persistent buffer a successful call converts; a call that delivers nothing leaves the state alone.  Counts must be equal (the
+    resampler's phase moves with every odd length), values within 1e-5 of the stage's peak (atan2 where the phasor is not small)."""
+    from conftest import load_golden
+    from cariboulite_amd import synth
+    t = load_golden("taps.npz")
+    rng = np.random.default_rng(seed)
+    ch = seed % 2
+    args = {"FIR": "64:1000000", "RESAMP": "3/2"} if stages == "rs32" else {"FIR": "64:100000", "DEMOD": "FM"}
+    dev = S.Device(dict(driver="Cariboulite", channel="S1G" if ch == 0 else "HiF"))
+    st = dev.setupStream(S.SOAPY_SDR_RX, "CF32", args=args)
+    dev.activateStream(st)
+    ref = RefDevice(orc, ch, "CF32")
+    fir = orc.FIR(t["fir64_c2"] if stages == "rs32" else t["fir64_c3"])
+    rs = orc.Resampler(t["rs_3_2"], 3, 2) if stages == "rs32" else None
+    fm_prev = None
+    n_rows = MTU * 3 // 2 + 16
+    got = np.zeros((n_rows, 2) if stages == "rs32" else (n_rows,), np.float32)
+    tmp = np.zeros((MTU + 16, 2), np.float32)
+    fed, delivered = 0, 0
+    for step in range(40):
+        while ref.pending() < int(rng.integers(0, 4)) * NB:
+            how = rng.choice(["good"] * 10 + ["slip", "lost", "half"])
+            b = synth.smi_stream_bytes(MTU, ch, stream=400 + seed, n0=fed * MTU)[0].copy(); fed += 1
+            if how == "slip":
+                k = int(rng.integers(1, 9))
+                b = np.concatenate([((np.arange(k, dtype=np.uint8) * 7 + 3) & 0x3F), b[: b.size - k]])
+            elif how == "lost":
+                b[:] = 0
+            elif how == "half":
+                b = b[: NB // 2]
+            dev.feedSmiBytes(b); ref.feed(b)
+        num = int(rng.choice([MTU] * 6 + [MTU // 2, 1000, 1001, 6, MTU - 3]))
+        got[...] = np.nan
+        r_dev = dev.readStream(st, [got], num).ret
+        r = ref.read(tmp, num)                                      # CF32 of the persistent buffer's first r slots (0: nothing delivered)
+        assert dev.pendingSmiBytes() == ref.pending(), (step, num)
+        if r <= 0:
+            assert r_dev == 0 and np.isnan(got).all(), (step, num, r_dev)
+            continue
+        z = fir.f64(tmp[:r])
+        if stages == "rs32":
+            want = rs.f64(z)
+            assert r_dev == want.shape[0], (step, num, r, r_dev, want.shape)
+            assert np.max(np.abs(got[:r_dev] - want)) <= 1e-5 * max(np.max(np.abs(want)), 1e-3), (step, num, r)
+        else:
+            want, fm_prev = orc.fm_demod_f64(z, fm_prev)
+            assert r_dev == r, (step, num, r, r_dev)
+            mag = np.hypot(z[:, 0], z[:, 1]); ok = mag > 0.02; ok[1:] &= ok[:-1]; ok[0] = False
+            d = np.abs(got[:r] - want); d = np.minimum(d, 2 * np.pi - d)
+            assert (not ok.any()) or np.max(d[ok]) <= 1e-4, (step, num, float(np.max(d[ok])))
+        assert np.isnan(got[r_dev:]).all()
+        delivered += 1
+    assert delivered >= 20
+    dev.close()
