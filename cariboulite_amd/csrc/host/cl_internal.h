@@ -123,6 +123,7 @@ struct cl_smi {
 int cl_smi_read_device(cl_smi *dev, int channel, size_t length_samples, int want_meta, int *all_aligned);
 /* the same chunk loop with results in caller-owned DEVICE buffers (NULL = the seam's own / no metadata) */
 int cl_smi_read_device_to(cl_smi *dev, int channel, size_t length_samples, int16_t *d_iq, uint8_t *d_meta, int *all_aligned);
+int cl_smi_ensure_iq(cl_smi *dev, size_t samples);   /* dev->d_iq holds at least `samples` int16 pairs: zeros at first, contents kept when it grows (0 / -1) */
 int cl_smi_set_prev_words(cl_smi *dev, int channel, const uint8_t *w, size_t len);   /* raw words that stand in for dev->d_iq from now on (0 / -1) */
 int cl_smi_restore_prev_words(cl_smi *dev, int channel);   /* bring dev->d_iq up to date from the previous call's raw words (0 / -1) */
 /* the same chunk loop, one chunk at a time, with the next read() staged and copied ahead (reader threads) */

@@ -180,6 +180,23 @@ int cl_ensure(void **p, size_t *cap, size_t need, size_t elem, int pinned)
     return 0;
 }
 
+/* The seam's persistent int16 buffer (it stands where the Stream's interm_native_buffer stands: an overlay of every call so far --
+ * a re-synchronised read() leaves slots untouched, caribou_smi.c:382-389): starts as zeros, and growing keeps what it holds. */
+int cl_smi_ensure_iq(cl_smi *dev, size_t samples)
+{
+    if (samples <= dev->iq_cap) return 0;
+    size_t ncap = dev->iq_cap ? dev->iq_cap : CL_NATIVE_MTU_SAMPLES + 8;
+    while (ncap < samples) ncap *= 2;
+    int16_t *np = (int16_t *)clhip_malloc(ncap * 4);
+    if (!np) return -1;
+    int bad = clhip_memset(np, 0, ncap * 4, dev->stream);
+    if (!bad && dev->d_iq) bad = clhip_memcpy_d2d(np, dev->d_iq, dev->iq_cap * 4, dev->stream);
+    if (clhip_stream_sync(dev->stream) || bad) { clhip_free(np); return -1; }
+    clhip_free(dev->d_iq);
+    dev->d_iq = np; dev->iq_cap = ncap;
+    return 0;
+}
+
 /* ----------------------------------------------------------- init / close */
 cl_smi *cl_smi_init(int device)
 {
@@ -447,7 +464,7 @@ long cl_smi_drain_to_fd(cl_smi *dev, int fd, size_t max_bytes)
 /* --------------------------------------------------------------- RX path */
 int cl_smi_read_device(cl_smi *dev, int channel, size_t length_samples, int want_meta, int *all_aligned)
 {
-    if (cl_ensure((void **)&dev->d_iq, &dev->iq_cap, length_samples + 8, 4, 0) ||
+    if (cl_smi_ensure_iq(dev, length_samples + 8) ||
         (want_meta && cl_ensure((void **)&dev->d_meta, &dev->meta_cap, length_samples + 8, 1, 0)))
         return CL_SMI_ERR_IO;
     return cl_smi_read_device_to(dev, channel, length_samples, dev->d_iq, want_meta ? dev->d_meta : NULL, all_aligned);
@@ -685,7 +702,7 @@ int cl_smi_restore_prev_words(cl_smi *dev, int channel)
     const uint8_t *w = dev->prev_words;
     const size_t n = dev->prev_words_len;
     dev->prev_words = NULL;
-    if (cl_ensure((void **)&dev->d_iq, &dev->iq_cap, n / 4 + 8, 4, 0)) return -1;
+    if (cl_smi_ensure_iq(dev, n / 4 + 8)) return -1;
     /* (synchronised: the copy stream may stage into that slot as soon as this call moves on) */
     return clhip_smi_unpack_aligned(channel, w, n, CL_FORMAT_CS16, dev->d_iq, NULL, dev->stream) || clhip_stream_sync(dev->stream) ? -1 : 0;
 }
@@ -737,7 +754,7 @@ long cl_smi_ra_launch(cl_smi *dev, int channel, size_t length_samples, int16_t *
     }
     const int own = !d_iq;                                     /* results in the seam's persistent int16 buffer */
     if (own) {
-        if (cl_ensure((void **)&dev->d_iq, &dev->iq_cap, length_samples + 8, 4, 0)) return CL_SMI_ERR_IO;
+        if (cl_smi_ensure_iq(dev, length_samples + 8)) return CL_SMI_ERR_IO;
         d_iq = dev->d_iq;
     }
     if (cl_ensure((void **)&dev->d_offs, &dev->offs_cap, 4, 4, 0) || cl_ensure((void **)&dev->h_offs, &dev->h_offs_cap, 4, 4, 1))
@@ -916,7 +933,7 @@ static int smi_write_core(cl_smi *dev, const cl_sample_complex_int16 *h_buffer, 
     clhip_set_device(dev->device);
     size_t left = length_samples * CL_BYTES_PER_SAMPLE, written_so_far = 0;
     if (length_samples == 0) return 0;
-    if ((h_buffer && cl_ensure((void **)&dev->d_iq, &dev->iq_cap, length_samples + 8, 4, 0)) ||
+    if ((h_buffer && cl_smi_ensure_iq(dev, length_samples + 8)) ||
         cl_ensure((void **)&dev->d_bytes, &dev->bytes_cap, left + 256, 1, 0))
         return CL_SMI_ERR_IO;
     /* the chunk loop only slices the same contiguous arrays (len &= ~3 never bites: 4 B/sample), so

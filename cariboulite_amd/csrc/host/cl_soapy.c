@@ -311,6 +311,8 @@ cl_stream *cl_setupStream(cl_device *dev, int direction, const char *format, con
         st->d_native1 = (int16_t *)clhip_malloc(sizeof(cl_sample_complex_int16) * (st->mtu_size + 8));
         st->astream = clhip_stream_create();
         if (!st->rx_queue || !st->d_native1 || !st->astream) { cl_seterr(dev->err, sizeof dev->err, "setupStream: ASYNC allocation failed"); return NULL; }
+        /* (interm_native_buffer1: the slots a re-synchronised read() leaves untouched keep what the read before left -- zeros at first) */
+        if (clhip_memset(st->d_native1, 0, sizeof(cl_sample_complex_int16) * (st->mtu_size + 8), st->astream) || clhip_stream_sync(st->astream)) return NULL;
         st->use_async = 1;
         __atomic_store_n(&st->reader_thread_running, 1, __ATOMIC_RELEASE);
         if (pthread_create(&st->reader_thread, NULL, reader_thread_fn, st)) { __atomic_store_n(&st->reader_thread_running, 0, __ATOMIC_RELEASE); return NULL; }
@@ -767,7 +769,7 @@ static int write_stream(cl_device *dev, cl_stream *st, const void *const *buffs,
     if (numElems == 0) return 0;
     const size_t n = numElems, ib = fmt_bytes(st->format);
     if (cl_ensure(&st->d_conv, &st->conv_cap, n * 16 + 64, 1, 0) ||
-        cl_ensure((void **)&smi->d_iq, &smi->iq_cap, n + 8, 4, 0) ||
+        cl_smi_ensure_iq(smi, n + 8) ||
         cl_ensure((void **)&smi->d_bytes, &smi->bytes_cap, 4 * n * (size_t)(st->tx_pipe ? st->dsp.up : 1) + 256, 1, 0))
         return 0;
     /* the client's samples reach the device through a pinned buffer of ours (see smi_write_core) */
