@@ -120,3 +120,51 @@ def test_a_group_reads_or_writes(S):
     g = S.Group([rx])
     assert g.writeStream([buf], MTU)[0] == -1 and "RX" in g.lastError()
     g.close(); rx.close(); tx.close()
+
+
+@pytest.mark.parametrize("seed,fmt", [(1, "CS16"), (2, "CF32"), (3, "CS8"), (4, "CF64"), (5, "CF32"), (6, "CS16")])
+def test_random_walk_of_writes_against_lone_devices_and_the_oracle(S, orc, seed, fmt):
+    """A seeded walk: nine TX members, every call another length (whole MTUs, ragged, tiny, above the MTU), now and then a member
+    written through its own device between two group calls, a pack mode switched, the FIFOs drained at random moments or left to
+    pile up -- after every drain every member's bytes equal its lone twin's and the oracle's conversion + pack of what was written."""
+    from cariboulite_amd import hip
+    rng = np.random.default_rng(700 + seed)
+    n = 9
+    gdevs, gsts = make_tx(S, n, fmt)
+    sdevs, ssts = make_tx(S, n, fmt)
+    grp = S.Group(gdevs)
+    to16 = {"CS16": lambda a: a, "CF32": orc.cf32_to_cs16, "CF64": orc.cf64_to_cs16, "CS8": orc.cs8_to_cs16}[fmt]
+    mode = [hip.TX_DOCUMENTED] * n
+    want = [[] for _ in range(n)]
+    for step in range(30):
+        op = rng.choice(["call"] * 6 + ["lone", "mode", "drain"])
+        if op == "lone":
+            i = int(rng.integers(0, n)); num = int(rng.choice([MTU, 777]))
+            b = samples(rng, fmt, num)
+            assert gdevs[i].writeStream(gsts[i], [b], num).ret == sdevs[i].writeStream(ssts[i], [b], num).ret == num
+            want[i].append(orc.generate_data(to16(b), mode[i]))
+        elif op == "mode":
+            i = int(rng.integers(0, n)); mode[i] = hip.TX_AS_WRITTEN if mode[i] == hip.TX_DOCUMENTED else hip.TX_DOCUMENTED
+            gdevs[i].setTxMode(mode[i]); sdevs[i].setTxMode(mode[i])
+        elif op == "drain":
+            for i in range(n):
+                g, s = gdevs[i].drainSmiBytes(), sdevs[i].drainSmiBytes()
+                w = np.concatenate(want[i]) if want[i] else np.zeros(0, np.uint8)
+                assert g.tobytes() == s.tobytes() == w.tobytes(), (step, i, g.size, s.size, w.size)
+                want[i] = []
+        num = int(rng.choice([MTU] * 4 + [MTU - 1, 1000, 3, MTU + 5000]))
+        bufs = [samples(rng, fmt, num) for _ in range(n)]
+        nd, rets = grp.writeStream(bufs, num)
+        srets = [sdevs[i].writeStream(ssts[i], [bufs[i]], num).ret for i in range(n)]
+        took = num if fmt == "CS16" else min(num, MTU)
+        assert rets == srets == [took] * n and nd == n, (step, num, rets, srets)
+        for i in range(n):
+            want[i].append(orc.generate_data(to16(bufs[i][:took]), mode[i]))
+    for i in range(n):
+        g, s = gdevs[i].drainSmiBytes(), sdevs[i].drainSmiBytes()
+        assert g.tobytes() == s.tobytes() == np.concatenate(want[i]).tobytes(), i
+    st = grp.stats()
+    assert st["errors"] == 0 and st["batched_reads"] > 50
+    grp.close()
+    for d in gdevs + sdevs:
+        d.close()
