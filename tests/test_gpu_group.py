@@ -509,9 +509,12 @@ def test_random_walk_against_lone_devices(S, seed, staged):
         for i in range(n):                                 # keep most FIFOs two to four batches deep
             while gdevs[i].pendingSmiBytes() < int(rng.integers(1, 4)) * NB:
                 feed(i, rng.choice(["good"] * 12 + ["slip", "lost", "half"]))
-        op = rng.choice(["call"] * 5 + ["half", "lone", "flush", "filter", "register"])
+        op = rng.choice(["call"] * 5 + ["half", "lone", "flush", "filter", "register", "maxread"])
         for x in gb + sb:
             x[...] = np.nan
+        if op == "maxread":                                # one member's driver hands out shorter read()s from now on (or whole ones again)
+            i = int(rng.integers(0, n)); m = int(rng.choice([0, NB // 2, 100000]))
+            gdevs[i].setMaxRead(m); sdevs[i].setMaxRead(m); hist[i].append(f"maxread{m}")
         if op == "lone" and not staged:
             i = int(rng.integers(0, n))
             assert gdevs[i].readStream(gsts[i], [gb[i]], MTU).ret == sdevs[i].readStream(ssts[i], [sb[i]], MTU).ret

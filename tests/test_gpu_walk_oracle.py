@@ -33,6 +33,7 @@ class RefDevice:
         self.orc, self.ch, self.fmt = orc, ch, fmt
         self.fifo = np.zeros(0, np.uint8)
         self.interm = np.zeros((8 * MTU + 2, 2), np.int16)      # interm_native_buffer (the formats that convert); zero-initialised like ours
+        self.max_read = 0                                       # a driver that hands out at most this many bytes per read() (0: no limit)
 
     def feed(self, b):
         self.fifo = np.concatenate([self.fifo, b])
@@ -48,7 +49,7 @@ class RefDevice:
         n = num if self.fmt == "CS16" else min(num, MTU)
         if n == 0:
             return 0
-        ret, iq, pos = self.orc.smi_read_pos(self.ch, self.fifo[: 4 * n], n, NB, fill=SENT)
+        ret, iq, pos = self.orc.smi_read_pos(self.ch, self.fifo[: 4 * n], n, NB, max_read=self.max_read, fill=SENT)
         self.fifo = self.fifo[pos:]
         touched = (iq != SENT).any(axis=1)
         if self.fmt == "CS16":
@@ -94,6 +95,9 @@ def test_one_device_against_the_reference_model(S, orc, seed, fmt):
             dev.feedSmiBytes(b); ref.feed(b)
         if rng.integers(0, 12) == 0:
             dev.flushSmiFifo(); ref.flush()
+        if rng.integers(0, 8) == 0:                             # the driver's read() size changes: several read()s per call, ragged ones too
+            ref.max_read = int(rng.choice([0, 0, NB // 2, 100000, 4098, 65536 + 2]))
+            dev.setMaxRead(ref.max_read)
         choices = [MTU] * 6 + [MTU // 2, 1000, 4, MTU - 4]
         if fmt == "CS16":
             choices += [MTU + 4096, 2 * MTU]                    # CS16 is not clamped to the MTU: chunk loops of several read()s
