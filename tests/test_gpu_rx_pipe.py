@@ -449,3 +449,43 @@ def test_a_range_run_of_the_open_epoch_can_be_taken_back(G, orc):
         multi.unrun_stream(0, n)
     multi.epoch_end()
     torch.cuda.synchronize()
+
+
+def test_outputs_do_not_depend_on_input_kind_chunking_or_what_lies_behind_the_input(G):
+    """Three properties the host side relies on when it decides HOW a call's samples reach the pipe (one read() or several, raw words
+    or int16 samples, a buffer that ends with the call or a FIFO slot with the next batch behind it): the fused kernels' outputs are
+    bit-identical (a) from raw words and from the int16 samples unpacked from them, (b) in one run and in two runs that split the
+    input anywhere (a multiple of 2 M), (c) whatever the words behind the run's last input are."""
+    import torch
+    from cariboulite_amd import hip, synth
+    t = load_golden("taps.npz")
+    n = 131072
+    b = synth.smi_stream_bytes(n + 64, 0, stream=5)[0]
+    w = torch.from_numpy(b.view(np.int32).copy()).to(G.DEV)
+    def pipe():
+        return hip.RxPipe(1, 0, t["fir64_c2"], t["rs_3_2"], 3, 2, hip.PIPE_OUT_IQ)
+    def cs16_of(wr, count):
+        o = torch.zeros((count + 2, 2), dtype=torch.int16, device=G.DEV)
+        offs = torch.zeros(1, dtype=torch.int32, device=G.DEV)
+        hip.smi_unpack(0, wr, 4 * count, 4 * count, 4 * count, 1, offs, hip.FORMAT_CS16, o)
+        return o
+    so = n * 3 // 2 + 64
+    ref = torch.zeros((so, 2), device=G.DEV)
+    g = pipe().run(hip.PIPE_IN_SMI_WORDS, w, 0, n, ref, 0)
+    out = torch.zeros((so, 2), device=G.DEV)
+    assert pipe().run(hip.PIPE_IN_CS16, cs16_of(w, n), 0, n, out, 0) == g                       # (a)
+    torch.cuda.synchronize()
+    assert torch.equal(out[:g], ref[:g])
+    for first in (n // 2, n // 4, n - 4096, 4):                                                 # (b)
+        p = pipe(); out.zero_()
+        g1 = p.run(hip.PIPE_IN_SMI_WORDS, w, 0, first, out, 0)
+        g2 = p.run(hip.PIPE_IN_SMI_WORDS, w[first:], 0, n - first, out[g1:], 0)
+        torch.cuda.synchronize()
+        assert g1 + g2 == g and torch.equal(out[:g], ref[:g]), first
+    for m in (n, 65536, 1001, n - 3):                                                           # (c)
+        wz = w.clone(); wz[m:] = 0
+        oa, ob = torch.zeros((so, 2), device=G.DEV), torch.zeros((so, 2), device=G.DEV)
+        ga = pipe().run(hip.PIPE_IN_SMI_WORDS, w, 0, m, oa, 0)
+        gb = pipe().run(hip.PIPE_IN_SMI_WORDS, wz, 0, m, ob, 0)
+        torch.cuda.synchronize()
+        assert ga == gb and torch.equal(oa[:ga], ob[:gb]), m
