@@ -173,3 +173,50 @@ def test_one_device_with_extension_stages_against_the_model(S, orc, seed, stages
         delivered += 1
     assert delivered >= 20
     dev.close()
+
+
+@pytest.mark.parametrize("seed", [31, 32, 33, 34, 35, 36])
+def test_the_lower_seam_against_orc_smi_read(S, orc, seed):
+    """caribou_smi_read itself (Binding B's seam, cariboulite_radio_read_samples is a pass-through: cariboulite_radio.c:1258-1285) with
+    the metadata plane: fresh sentinel-filled buffers every call, so every slot the chunk loop writes or leaves alone shows --
+    samples, the extrapolated one, meta[n] untouched behind a re-sync (caribou_smi.c:344-389) -- over lengths up to three MTUs,
+    read() sizes that change, damage and flushes; the return code is the chunk loop's own (-3 included)."""
+    from cariboulite_amd import synth
+    rng = np.random.default_rng(seed)
+    ch = seed % 2
+    dev = S.Device(dict(driver="Cariboulite", channel="S1G" if ch == 0 else "HiF"))
+    fifo = np.zeros(0, np.uint8)
+    fed, max_read, codes = 0, 0, set()
+    for step in range(60):
+        while fifo.size < int(rng.integers(0, 5)) * NB:
+            how = rng.choice(["good"] * 10 + ["slip", "lost", "half", "quarter"])
+            b = synth.smi_stream_bytes(MTU, ch, stream=500 + seed, n0=fed * MTU)[0].copy(); fed += 1
+            if how == "slip":
+                k = int(rng.integers(1, 9))
+                b = np.concatenate([((np.arange(k, dtype=np.uint8) * 7 + 3) & 0x3F), b[: b.size - (k if rng.integers(0, 2) else 0)]])
+            elif how == "lost":
+                b[:] = 0
+            elif how == "half":
+                b = b[: NB // 2]
+            elif how == "quarter":
+                b = b[: NB // 4]
+            dev.feedSmiBytes(b); fifo = np.concatenate([fifo, b])
+        if rng.integers(0, 8) == 0:
+            max_read = int(rng.choice([0, 0, NB // 2, 100000, 4098]))
+            dev.setMaxRead(max_read)
+        if rng.integers(0, 15) == 0:
+            dev.flushSmiFifo(); fifo = fifo[:0]
+        n = int(rng.choice([MTU] * 4 + [MTU // 2, 1000, 5, 2 * MTU, 3 * MTU, MTU + 4096]))
+        want_meta = bool(rng.integers(0, 2))
+        ret, iq, meta = dev.smiRead(ch, n, want_meta=want_meta)
+        r_ret, r_iq, r_meta = orc.smi_read(ch, fifo[: 4 * n], n, NB, max_read=max_read, want_meta=want_meta)
+        _, _, pos = orc.smi_read_pos(ch, fifo[: 4 * n], n, NB, max_read=max_read)
+        fifo = fifo[pos:]
+        assert ret == r_ret, (step, n, ret, r_ret)
+        assert dev.pendingSmiBytes() == fifo.size, (step, n)
+        assert np.array_equal(iq, r_iq), (step, n, ret, np.flatnonzero((iq != r_iq).any(axis=1))[:4])
+        if want_meta:
+            assert np.array_equal(meta, r_meta), (step, n, ret, np.flatnonzero(meta != r_meta)[:4])
+        codes.add(ret if ret < 0 else (0 if ret == 0 else 1))
+    assert 1 in codes and -3 in codes, codes
+    dev.close()
