@@ -65,6 +65,9 @@ typedef struct {
     uint8_t *done_ahead; long *ahead_got;      /* per row: the previous call launched over the batch it read ahead, results in h_out[cur_m ^ 1] then; elements */
     uint8_t *direct;                           /* per call and row: the copy engine wrote the client's registered buffer */
     cl_read_ctx *ctx;                          /* per call and row: a one-by-one member's read in flight (lanes without extension stages) */
+    /* the reference's low-pass over whole sub-batches (lanes without extension stages): one multi-stream filter object per (filter,
+     * sub-batch), made when first needed; a member's carried state lives EITHER in its stream's own objects or here (iir_own) */
+    clhip_iir **giir; int n_subs; uint8_t *iir_own; int16_t *d_f; uint8_t *sub_ft; uint8_t *how;
     int epoch_open;                            /* the pipe's epoch of the NEXT call was opened by the read-ahead */
     int set;                                   /* this call's event set (0 / 1) */
     size_t sub0; int queued;                   /* the lane's first sub-batch among the group's; sub-batches queued in this call */
@@ -86,6 +89,7 @@ struct cl_group {
     int readahead;                        /* kwarg READAHEAD: 0 = none; 1 = before a call waits for its results the NEXT call's batches are staged and copied in;
                                            * 2 (default) = ... and launched over, into the second mirror */
     size_t n_sub;                         /* sub-batches over all lanes */
+    int iir_polls; int iir_polls_set;     /* test hook (cl_group_set_iir_poll_bound): the poll bound of the group's filter objects */
     int stale;                            /* work made ahead has just been given up: it is waited for before anything takes its place (settle) */
     int sink_mapped;                      /* kwarg SINK: "mapped" (default) = the sub-batch's kernel stores into the mapped pinned mirror itself; "copy" = device buffer + copy engine */
 #define GRP_MAX_IN 8
@@ -231,6 +235,7 @@ static int same_dsp(const cl_dsp_cfg *a, const cl_dsp_cfg *b)
 }
 
 static void ahead_cancel_all(cl_group *g);
+static void iir_home(void *ctx, int member);
 
 static void lane_free(lane_t *l)
 {
@@ -240,6 +245,8 @@ static void lane_free(lane_t *l)
     clhip_host_free(l->h_out[0]); clhip_host_free(l->h_out[1]); clhip_host_free(l->h_offs[0]);
     clhip_host_free(l->tx_h_in); clhip_free(l->tx_d_in);
     free(l->done_ahead); free(l->ahead_got); free(l->direct); free(l->ctx);
+    for (int i = 0; l->giir && i < 3 * l->n_subs; i++) clhip_iir_destroy(l->giir[i]);
+    free(l->giir); free(l->iir_own); free(l->sub_ft); free(l->how); clhip_free(l->d_f);
     free(l->member); free(l->fast); free(l->len); free(l->got); free(l->src); free(l->ahead_mark);
     memset(l, 0, sizeof *l);
 }
@@ -254,6 +261,10 @@ void cl_group_unmake(cl_group *g)
     pool_stop(&g->pool);
     cl_group_unregister_buffers(g);
     ahead_cancel_all(g);                                       /* what was read ahead is pending again */
+    for (size_t i = 0; g->lane_of && i < g->n; i++) {          /* the filters' carried state goes back to the streams' own objects */
+        cl_stream *st = g->dev[i]->stream;
+        if (st->iir_home_ctx == g) { iir_home(g, (int)i); st->iir_home = NULL; st->iir_home_ctx = NULL; }
+    }
     for (int k = 0; k < g->n_lanes; k++)                       /* raw words standing in for a seam's persistent buffer: unpacked now, the lane's buffers go */
         for (int r = 0; g->lane[k].d_in[0] && r < g->lane[k].n; r++) cl_smi_restore_prev_words(g->dev[g->lane[k].member[r]]->smi, g->lane[k].channel);
     if (g->slab) {                                             /* the members' FIFOs move out before the slab goes */
@@ -387,12 +398,13 @@ cl_group *cl_group_make(cl_device *const *devs, size_t n, const char *const *key
         l->done_ahead = (uint8_t *)calloc((size_t)l->n, 1); l->ahead_got = (long *)calloc((size_t)l->n, sizeof(long));
         l->direct = (uint8_t *)calloc((size_t)l->n, 1);
         l->ctx = (cl_read_ctx *)calloc((size_t)l->n, sizeof(cl_read_ctx));
+        l->how = (uint8_t *)calloc((size_t)l->n, 1);
         l->sub0 = n_sub;
         l->fast = (uint8_t *)calloc((size_t)l->n, 1); l->len = (size_t *)calloc((size_t)l->n, sizeof(size_t));
         l->got = (long *)calloc((size_t)l->n, sizeof(long));
         l->src = (uint8_t **)calloc((size_t)l->n, sizeof(uint8_t *));
         l->ahead_mark = (uint8_t *)calloc((size_t)l->n, 1);
-        if (!l->d_in[0] || !l->d_in[1] || !l->d_in[2] || !l->primed || !l->primed_epoch || !l->ev_primed || !l->d_out || !l->h_out[0] || (g->readahead == 2 && !l->h_out[1]) || !l->h_offs[0] || !l->d_offs[0] || !l->m_out[0] || !l->done_ahead || !l->ahead_got || !l->direct || !l->ctx || !l->fast || !l->len || !l->got || !l->src || !l->ahead_mark) {
+        if (!l->d_in[0] || !l->d_in[1] || !l->d_in[2] || !l->primed || !l->primed_epoch || !l->ev_primed || !l->d_out || !l->h_out[0] || (g->readahead == 2 && !l->h_out[1]) || !l->h_offs[0] || !l->d_offs[0] || !l->m_out[0] || !l->done_ahead || !l->ahead_got || !l->direct || !l->ctx || !l->how || !l->fast || !l->len || !l->got || !l->src || !l->ahead_mark) {
             cl_seterr(g_make_err, sizeof g_make_err, "cl_group_make: buffers for %d streams could not be allocated", l->n);
             cl_group_unmake(g);
             return NULL;
@@ -402,6 +414,17 @@ cl_group *cl_group_make(cl_device *const *devs, size_t n, const char *const *key
          * 9489 / 10269 / 10343, CF32 (1 MiB) 5773 / 6034 / 6050 -- short launches (43 us for four CS16 streams) lie 6 ... 10 us apart */
         l->sub = g->sub ? g->sub : l->out_stride * l->elem_bytes >= ((size_t)3 << 19) ? 4 : 8;
         n_sub += ((size_t)l->n + (size_t)l->sub - 1) / (size_t)l->sub;
+        l->n_subs = (l->n + l->sub - 1) / l->sub;
+        if (l->route == ROUTE_PLAIN) {
+            l->giir = (clhip_iir **)calloc((size_t)3 * (size_t)l->n_subs, sizeof(clhip_iir *)); l->iir_own = (uint8_t *)calloc((size_t)3 * (size_t)l->n, 1);
+            l->sub_ft = (uint8_t *)calloc((size_t)l->n_subs, 1);
+            l->d_f = (int16_t *)clhip_malloc((size_t)l->n * l->out_stride * 4 + 256);
+            if (!l->giir || !l->iir_own || !l->sub_ft || !l->d_f) { cl_seterr(g_make_err, sizeof g_make_err, "cl_group_make: filter buffers"); cl_group_unmake(g); return NULL; }
+            for (int r = 0; r < l->n; r++) {
+                cl_stream *st = g->dev[l->member[r]]->stream;
+                st->iir_home = iir_home; st->iir_home_ctx = g; st->iir_home_member = l->member[r];
+            }
+        }
     }
     for (int k = 0; k < g->n_in; k++) g->s_in[k] = clhip_stream_create();
     g->s_k = clhip_stream_create(); g->s_out = clhip_stream_create();
@@ -526,13 +549,93 @@ static int registered(const cl_group *g, int m, const void *p, size_t bytes)
  * bytes are in pinned host memory, so the host knows before the device has looked); they are staged and their copy to the
  * lane's row is queued while they cannot move.  Everything else -- short, ragged or slipped reads, bytes given back earlier,
  * reader threads, the IIR, debug modes -- is the single-stream route's business. */
+/* ---- the reference's low-pass over whole sub-batches ----
+ * Stream::ReadSamples(int16*) (CaribouliteStream.cpp:282-301) runs the selected Butterworth over every sample of the read on the
+ * client's thread; a sub-batch whose members all have the SAME filter selected and are all in sync goes through ONE multi-stream filter
+ * launch fed from the raw words (clhip_iir_run_smi).  The carried state of a member's three filters persists for the life of its
+ * Stream and is not reset when the selection changes (:84-91,127-141): it is moved, not copied -- into the group's object when the
+ * member first takes the batched filter route, back into the stream's own object the moment that object is about to be used
+ * (cl_soapy.c: filter_source calls iir_home) or the group goes. */
+static int giir_index(const lane_t *l, int row, int ft) { return (ft - 1) * l->n_subs + row / l->sub; }
+
+static void iir_home(void *ctx, int member)
+{
+    cl_group *g = (cl_group *)ctx;
+    lane_t *l = &g->lane[g->lane_of[member]];
+    const int row = g->row_of[member];
+    if (!l->iir_own) return;
+    for (int ft = 1; ft <= 3; ft++) {
+        if (!l->iir_own[3 * row + ft - 1]) continue;
+        clhip_iir *obj = l->giir[giir_index(l, row, ft)];
+        const int a = row / l->sub * l->sub, cnt = (a + l->sub < l->n ? a + l->sub : l->n) - a;
+        double *st = (double *)malloc(sizeof(double) * 16 * (size_t)cnt);
+        if (st && obj && clhip_iir_get_state(obj, st) == 0) clhip_iir_set_state(g->dev[member]->stream->iir[ft - 1], st + 16 * (row - a));
+        free(st);
+        l->iir_own[3 * row + ft - 1] = 0;
+    }
+}
+
+/* the filter object of sub-batch [a, e) for filter `ft`, holding the carried state of all its members (NULL: a runtime error) */
+static clhip_iir *giir_get(cl_group *g, lane_t *l, int a, int e, int ft)
+{
+    clhip_iir **slot = &l->giir[giir_index(l, a, ft)];
+    if (!*slot) {
+        *slot = clhip_iir_create(g->dev[l->member[a]]->stream->sos[ft - 1], 3, e - a);
+        if (!*slot) return NULL;
+        if (g->iir_polls_set) clhip_iir_set_poll_bound(*slot, g->iir_polls);
+    }
+    int need = 0;
+    for (int r = a; r < e; r++) need |= !l->iir_own[3 * r + ft - 1];
+    if (need) {
+        double *st = (double *)malloc(sizeof(double) * 16 * (size_t)(e - a));
+        if (!st || clhip_iir_get_state(*slot, st)) { free(st); return NULL; }
+        for (int r = a; r < e; r++) {
+            if (l->iir_own[3 * r + ft - 1]) continue;
+            if (clhip_iir_get_state(g->dev[l->member[r]]->stream->iir[ft - 1], st + 16 * (r - a))) { free(st); return NULL; }
+            l->iir_own[3 * r + ft - 1] = 1;
+        }
+        const int bad = clhip_iir_set_state(*slot, st);
+        free(st);
+        if (bad) return NULL;
+    }
+    return *slot;
+}
+
+void cl_group_set_iir_poll_bound(cl_group *g, int polls)
+{
+    if (!g) return;
+    g->iir_polls = polls; g->iir_polls_set = 1;
+    for (int k = 0; k < g->n_lanes; k++)
+        for (int i = 0; g->lane[k].giir && i < 3 * g->lane[k].n_subs; i++) clhip_iir_set_poll_bound(g->lane[k].giir[i], polls);
+}
+
+/* the filter launch(es) of sub-batch [a, e): raw words in `in` rows -> filtered samples in the lane's format in `outb` rows (the mapped
+ * mirror); redo = the scan path after an overrun (or an object that is on it): unpack, filter, convert */
+static int giir_launch(cl_group *g, lane_t *l, clhip_iir *obj, int a, int e, size_t want, uint8_t *in, uint8_t *outb, int offs_table)
+{
+    const size_t n = want / 4, stride = l->out_stride;
+    int16_t *mirror16 = (int16_t *)(outb + (size_t)a * stride * l->elem_bytes), *f16 = l->d_f + 2 * (size_t)a * stride;
+    int16_t *dst = l->format == CL_FORMAT_CS16 ? mirror16 : f16;
+    int rc = clhip_iir_run_smi(obj, l->channel, in + (size_t)a * l->in_stride, dst, stride, n, g->s_k);
+    if (rc == -2) {
+        for (int r = a; r < e; r++) l->h_offs[offs_table][r] = 0;
+        rc = clhip_smi_unpack(l->channel, in + (size_t)a * l->in_stride, (size_t)(e - a - 1) * l->in_stride + want, l->in_stride, want, e - a,
+                              l->d_offs[offs_table] + a, CL_FORMAT_CS16, f16, NULL, g->s_k) ||
+             clhip_iir_run(obj, f16, dst, stride, n, g->s_k);
+    }
+    if (rc) return -1;
+    g->stats.launches++;
+    if (dst == f16) return clhip_convert_from_cs16(f16, (size_t)(e - a - 1) * stride + n, l->format, outb + (size_t)a * stride * l->elem_bytes, g->s_k);
+    return 0;
+}
+
 /* may member `row` take the batched route at all in this call? */
-static int qualifies(const cl_group *g, const lane_t *l, int row, size_t want)
+static int qualifies(const cl_group *g, const lane_t *l, int row, size_t want, int allow_filter)
 {
     const cl_device *dev = g->dev[l->member[row]];
     const cl_stream *st = dev->stream;
     const cl_smi *smi = dev->smi;
-    if (st->use_async || st->filter_type != CL_DIGFILT_NONE || smi->debug_mode != CL_SMI_DEBUG_NONE || st->native_dir != CL_SOAPY_SDR_RX) return 0;
+    if (st->use_async || (st->filter_type != CL_DIGFILT_NONE && !allow_filter) || smi->debug_mode != CL_SMI_DEBUG_NONE || st->native_dir != CL_SOAPY_SDR_RX) return 0;
     if (st->format != l->format || !want || (want & 15) || want > smi->native_batch_len || (smi->max_read && smi->max_read < want)) return 0;
     return 1;
 }
@@ -564,7 +667,7 @@ static int on_phase_0(const lane_t *l, int row)
 /* 3 = the previous call read this batch ahead AND launched over it: its results are in the current mirror (or on their way);
  * 2 = the previous call read it ahead (staged in the FIFO, copied to d_in[cur_in]): to be launched over;
  * 1 = staged now, its copy still to be queued (FIFO lock held); 0 = not on the batched route in this call */
-static int try_stage(cl_group *g, lane_t *l, int row, size_t want, void *s_in)
+static int try_stage(cl_group *g, lane_t *l, int row, size_t want, void *s_in, int allow_filter)
 {
     cl_smi *smi = g->dev[l->member[row]]->smi;
     if (l->primed[row]) {
@@ -573,9 +676,10 @@ static int try_stage(cl_group *g, lane_t *l, int row, size_t want, void *s_in)
         const int was_done = l->done_ahead[row];
         l->primed[row] = 0; l->done_ahead[row] = 0; l->src[row] = NULL;
         /* (a run made ahead has advanced the stream's counter already: its phase was checked when it was made) */
-        if (intact && had == want && qualifies(g, l, row, want) && (was_done || on_phase_0(l, row))) {
+        if (intact && had == want && qualifies(g, l, row, want, allow_filter) && (was_done || on_phase_0(l, row))) {
             smi->foreign_ahead = 0;                            /* this call's batch now: staged, the oldest unconfirmed bytes */
             cl_smi_ahead_note(smi);
+            if (was_done && allow_filter) { g->stale = 1; settle(g); return 2; }     /* (computed ahead WITHOUT the low-pass that has been selected since: only the input stands) */
             return was_done ? 3 : 2;
         }
         if (intact) cl_smi_foreign_cancel(smi);                 /* another length, or off the batched route: pending again, in order */
@@ -584,7 +688,7 @@ static int try_stage(cl_group *g, lane_t *l, int row, size_t want, void *s_in)
         settle(g);
     }
     l->src[row] = NULL;
-    if (!qualifies(g, l, row, want) || !on_phase_0(l, row)) return 0;
+    if (!qualifies(g, l, row, want, allow_filter) || !on_phase_0(l, row)) return 0;
     cl_smi_readahead_cancel(smi);                              /* what a single-stream call staged ahead is pending again */
     return stage_row(g, l, row, want, s_in, 1);
 }
@@ -728,8 +832,18 @@ int cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems, int *r
             void *s_in = g->s_in[b % (size_t)g->n_in];          /* the sub-batches take turns on the ingest streams */
             int from_ahead = 0, any_run = 0, any_copy = 0;
             l->queued++;
+            /* the sub-batch's low-pass: the same one selected on every member (and no registered buffers: the mirror route) -> one filter
+             * launch over the sub-batch; members with a filter in a mixed sub-batch go through their own devices */
+            int ft = 0;
+            if (l->route == ROUTE_PLAIN && g->sink_mapped) {
+                ft = g->dev[l->member[a]]->stream->filter_type;
+                for (int r = a; r < e; r++)
+                    if (g->dev[l->member[r]]->stream->filter_type != ft || g->has_reg[l->member[r]]) ft = 0;
+            }
+            if (l->sub_ft) l->sub_ft[a / l->sub] = 0;
             for (int r = a; r < e; r++) {
-                const int how = try_stage(g, l, r, want, s_in);
+                const int how = try_stage(g, l, r, want, s_in, ft > 0);
+                l->how[r] = (uint8_t)how;
                 l->fast[r] = (uint8_t)(how != 0);
                 l->ahead_mark[r] = (uint8_t)(how == 1 || how == 2);      /* (here: rows to launch over in this call) */
                 from_ahead |= how == 2;
@@ -737,7 +851,23 @@ int cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems, int *r
                 l->got[r] = how == 3 ? l->ahead_got[r] : 0;
                 l->direct[r] = 0;
             }
+            if (ft > 0) {                                      /* all of them or none: a member that is short, out of sync or off the route sends everybody home */
+                int all = 1;
+                for (int r = a; r < e; r++) all &= l->how[r] == 1 || l->how[r] == 2;
+                if (!all) {
+                    for (int r = a; r < e; r++) {
+                        if (!l->fast[r]) continue;
+                        cl_smi *smi = g->dev[l->member[r]]->smi;
+                        if (l->how[r] != 1) pthread_mutex_lock(&smi->fifo_mu);       /* (staged just now: the lock is still held) */
+                        cl_fifo_unstage(&smi->rx, want);
+                        pthread_mutex_unlock(&smi->fifo_mu);
+                        l->fast[r] = 0; l->ahead_mark[r] = 0; l->src[r] = NULL;
+                    }
+                    ft = 0;
+                }
+            }
             if (copies_queue(g, l, in, a, e, want, s_in)) hard = 1;     /* (a row whose copy cannot be queued leaves the batched route: fast = 0) */
+            if (ft > 0) for (int r = a; r < e; r++) if (!l->fast[r]) hard = 1;   /* (a copy that could not be queued inside a filter sub-batch: a runtime error) */
             for (int r = a; r < e; r++) {
                 l->ahead_mark[r] = (uint8_t)(l->ahead_mark[r] && l->fast[r]);
                 l->len[r] = l->fast[r] ? want : 0;
@@ -754,6 +884,12 @@ int cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems, int *r
             for (int r = a; r < e && mapped; r++)
                 if (l->fast[r] && g->has_reg[l->member[r]]) mapped = 0;
             uint8_t *outb = mapped ? l->m_out[l->cur_m] : l->d_out;
+            if (!hard && ft > 0) {
+                clhip_iir *obj = giir_get(g, l, a, e, ft);
+                if (!obj || giir_launch(g, l, obj, a, e, want, in, outb, 2 * l->set + 1)) hard = 1;
+                for (int r = a; r < e; r++) l->got[r] = (long)(want / 4);
+                l->sub_ft[a / l->sub] = (uint8_t)ft;
+            } else
             if (!hard && launch_rows(g, l, a, e, l->ahead_mark, want, in, outb, 2 * l->set + 1, l->got)) hard = 1;
             if (mapped) { hard = hard || clhip_event_record(ev_out, g->s_k); continue; }     /* "arrived" = the launch has ended */
             hard = hard || clhip_event_record(ev_k, g->s_k) || clhip_stream_wait_event(g->s_out, ev_k);
@@ -806,7 +942,7 @@ int cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems, int *r
         uint8_t *keep_fast = l->fast;                          /* (copies_queue walks l->fast: the rows staged ahead, for the moment) */
         l->fast = l->ahead_mark;
         for (int r = 0; r < l->n; r++) {
-            l->ahead_mark[r] = keep_fast[r] && qualifies(g, l, r, l->want) && stage_row(g, l, r, l->want, s_p, 2) ? 1 : 0;
+            l->ahead_mark[r] = keep_fast[r] && qualifies(g, l, r, l->want, l->route == ROUTE_PLAIN) && stage_row(g, l, r, l->want, s_p, 2) ? 1 : 0;
             any |= l->ahead_mark[r];
         }
         if (any && copies_queue(g, l, l->d_in[l->next_in], 0, l->n, l->want, s_p)) hard = 1;
@@ -828,7 +964,7 @@ int cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems, int *r
             const int e = a + l->sub < l->n ? a + l->sub : l->n;
             int run = 0;
             for (int r = a; r < e; r++) {
-                if (g->has_reg[l->member[r]]) { run = 0; break; }
+                if (g->has_reg[l->member[r]] || g->dev[l->member[r]]->stream->filter_type != CL_DIGFILT_NONE) { run = 0; break; }     /* (the copy engine needs the client's pointer; a filter run cannot be taken back) */
                 l->done_ahead[r] = (uint8_t)(l->ahead_mark[r] && on_phase_0(l, r));
                 run |= l->done_ahead[r];
             }
@@ -848,12 +984,25 @@ int cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems, int *r
             int any = 0;
             for (int r = a; r < e; r++) any |= l->fast[r];
             if (!any) continue;
-            const int arrived = sb < l->queued && !hard && clhip_event_sync(ev_of(g, l, l->set, a)[g->n_in + 1]) == 0;
+            int arrived = sb < l->queued && !hard && clhip_event_sync(ev_of(g, l, l->set, a)[g->n_in + 1]) == 0;
+            int filter_failed = 0;
+            if (arrived && l->sub_ft && l->sub_ft[sb]) {
+                /* the filter launch's verdict (clhip_iir_status): a single-pass launch that gave up has its state back where it was and
+                 * the object on its scan path -- the sub-batch is filtered again, once, here (CaribouliteStream.cpp has no such case:
+                 * its loop cannot fail; a second failure delivers 0 elements like any read error, :266-276) */
+                clhip_iir *obj = l->giir[giir_index(l, a, l->sub_ft[sb])];
+                if (clhip_iir_status(obj)) {
+                    for (int r = a; r < e; r++) g->dev[l->member[r]]->stream->stats.iir_overruns++;
+                    if (giir_launch(g, l, obj, a, e, l->want, l->d_in[l->cur_in], l->m_out[l->cur_m], 2 * l->set + 1) || clhip_stream_sync(g->s_k)) arrived = 0;
+                    else if (clhip_iir_status(obj)) filter_failed = 1;
+                }
+            }
             if (!arrived) hard = 1;
             for (int r = a; r < e; r++) {
                 if (!l->fast[r]) continue;
                 const int m = l->member[r];
                 cl_device *dev = g->dev[m];
+                if (filter_failed) l->got[r] = 0;                  /* (consumed, nothing delivered) */
                 if (!arrived) {                                    /* a runtime error: nothing is delivered, nothing is consumed */
                     for (int q = 0; q < g->n_in; q++) clhip_stream_sync(g->s_in[q]);
                     if (l->primed[r]) {                            /* (the newest staged bytes first) */

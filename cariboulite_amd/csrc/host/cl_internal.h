@@ -164,6 +164,9 @@ struct cl_stream {
     size_t mtu_size;
     int filter_type;             /* CL_DIGFILT_*                                 */
     double sos[3][15];           /* filt20 / filt50 / filt100: 3 biquads x {b0,b1,b2,a1,a2} */
+    /* a stream group may hold the carried state of this stream's filters in multi-stream objects of its own: before the stream's own
+     * objects are used (or its filters destroyed) the group hands the state back */
+    void (*iir_home)(void *ctx, int member); void *iir_home_ctx; int iir_home_member;
     clhip_iir *iir[3];           /* filt20 / filt50 / filt100 (CaribouliteStream.hpp:124-131): state per filter, I and Q rails, never
                                   * reset, not even when the selection changes (CaribouliteStream.cpp:127-141) */
     int16_t *d_filt; size_t filt_cap;    /* the filtered samples: the IIR runs out of place, so a call can be repeated */

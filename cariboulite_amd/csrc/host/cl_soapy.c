@@ -547,6 +547,7 @@ static const int16_t *filter_source(cl_device *dev, cl_stream *st, const cl_sour
 {
     cl_smi *smi = dev->smi;
     const size_t n = (size_t)src->n;
+    if (st->iir_home) st->iir_home(st->iir_home_ctx, st->iir_home_member);     /* (a stream group hands the filters' state back first) */
     clhip_iir *flt = st->iir[st->filter_type - 1];
     if (!d_dst) {
         if (cl_ensure((void **)&st->d_filt, &st->filt_cap, n + 8, 4, 0)) return NULL;

@@ -581,8 +581,10 @@ void   cl_stream_set_iir_poll_bound(cl_stream *stream, int polls);
  * launch per sub-batch (the fused unpack + FIR + resample / demod kernel over several streams, or the unpack in the
  * stream format), while the sub-batch before it is on its way back and the one behind it on its way in (three HIP
  * streams), and the last hop into the clients' pageable buffers is shared by COPY_THREADS threads.  A stream that cannot take
- * that route (a slipped or lost chunk, a short read, the IIR, ASYNC=1, a debug mode) takes its own device's single-stream
- * route inside the same call.
+ * that route (a slipped or lost chunk, a short read, ASYNC=1, a debug mode) takes its own device's single-stream
+ * route inside the same call.  The reference's low-pass (cl_setBandwidth below 160 kHz) is batched too where a whole sub-batch of a
+ * lane without extension stages has the same filter selected: one multi-stream filter launch fed from the raw words; the filters'
+ * carried state moves between the members' own objects and the group's as the members change routes (never copied, never reset).
  * Make the group AFTER cl_setupStream of every member (RX); members are grouped by channel type and stream configuration
  * (format, FIR / RESAMP / DEMOD kwargs); a group with extension stages owns their state (one n-stream pipe per
  * configuration), so its members are read through the group from then on.  kwargs: SUBBATCH=<streams per launch> (4 where a stream delivers 1.5 MiB or more per call, else 8),
@@ -627,6 +629,7 @@ int         cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems
 int         cl_group_writeStream(cl_group *g, const void *const *buffs, size_t numElems, int *rets, long timeoutUs);
 const char *cl_group_last_error(const cl_group *g);
 void        cl_group_getStats(const cl_group *g, cl_group_stats *out);
+void        cl_group_set_iir_poll_bound(cl_group *g, int polls);      /* test hook: clhip_iir_set_poll_bound for the group's own filter objects */
 /* Explicit zero-copy: one client buffer per member (bytes_each long), registered with the GPU here and kept registered until
  * _unregister_buffers / cl_group_unmake -- the client keeps them allocated that long.  A call whose buffs[i] lies inside
  * member i's registered buffer has the copy engine write it directly (no pinned mirror, no memcpy); any other pointer takes

@@ -547,3 +547,93 @@ def test_random_walk_against_lone_devices(S, seed, staged):
     grp.close()
     for d in gdevs + sdevs:
         d.close()
+
+
+@pytest.mark.parametrize("fmt,dtype", [("CS16", np.int16), ("CF32", np.float32)])
+def test_the_low_pass_over_whole_sub_batches(S, orc, fmt, dtype):
+    """setBandwidth below 160 kHz on EVERY member (Cariboulite.cpp:395-417: the Butterworth-6 of CaribouliteStream.cpp:282-301): a
+    sub-batch whose members all have the same filter selected goes through ONE multi-stream filter launch fed from the raw words --
+    and every stream still equals its lone device bit for bit (the filter's fp64 state carried from call to call), through: another
+    filter selected on everybody, one member switched off (its sub-batch falls apart: those members go through their own devices and
+    take their filters' state with them), a member read through its own device between two calls, a damaged batch, the filter on
+    again (the state comes back), the group closed (the state goes home: the lone devices read on in step)."""
+    n = 12
+    chan = lambda i: "S1G"
+    gdevs, gsts = make_devices(S, n, getattr(S, "SOAPY_SDR_" + fmt), None, chan)
+    sdevs, ssts = make_devices(S, n, getattr(S, "SOAPY_SDR_" + fmt), None, chan)
+    def bw_all(bw, who=range(n)):
+        for i in who:
+            gdevs[i].setBandwidth(S.SOAPY_SDR_RX, 0, bw); sdevs[i].setBandwidth(S.SOAPY_SDR_RX, 0, bw)
+    bw_all(100e3)
+    grp = S.Group(gdevs, {"SUBBATCH": "4"})
+    gb, sb = sentinel_buffers(n, (MTU + 2, 2), dtype), sentinel_buffers(n, (MTU + 2, 2), dtype)
+    fed = [0]
+    def step(script=None, expect_single=None):
+        c = fed[0]; fed[0] += 1
+        for i in range(n):
+            b = batch_bytes(i, c, 0)
+            if script and script.get(i) == "slip":
+                b = slipped(b, 4)
+            gdevs[i].feedSmiBytes(b); sdevs[i].feedSmiBytes(b)
+        s0 = grp.stats()["single_reads"]
+        _, rets = grp.readStream(gb, MTU)
+        srets = [sdevs[i].readStream(ssts[i], [sb[i]], MTU).ret for i in range(n)]
+        assert rets == srets == [MTU] * n, (c, rets, srets)
+        for i in range(n):
+            assert same(gb[i], sb[i]), (c, i)
+        if expect_single is not None:
+            assert grp.stats()["single_reads"] - s0 == expect_single, (c, grp.stats())
+    step(expect_single=0); step(expect_single=0)            # three filter launches per call, nobody through its own device
+    assert grp.stats()["launches"] == 2 * 3
+    bw_all(20e3); step(expect_single=0); bw_all(100e3); step(expect_single=0)   # the 100 kHz filter continues from where it was (state is per filter)
+    bw_all(1e6, [5]); step(expect_single=3)                 # member 5 without a filter: rows 4, 6, 7 go through their own devices, 5 batched alone
+    step(expect_single=3)
+    for x in (gb[6], sb[6]):
+        x[...] = 0
+    assert gdevs[6].readStream(gsts[6], [gb[6]], MTU).ret == sdevs[6].readStream(ssts[6], [sb[6]], MTU).ret == 0   # (nothing pending: a read through the device itself)
+    c = fed[0]
+    b = batch_bytes(6, 900, 0); gdevs[6].feedSmiBytes(b); sdevs[6].feedSmiBytes(b)
+    assert gdevs[6].readStream(gsts[6], [gb[6]], MTU).ret == sdevs[6].readStream(ssts[6], [sb[6]], MTU).ret == MTU
+    assert same(gb[6], sb[6])
+    bw_all(100e3, [5]); step(expect_single=0)               # whole again: the states move back into the group's object
+    step(script={9: "slip"}, expect_single=4)               # a slipped batch in member 9: its sub-batch goes home for this call
+    step(expect_single=0)                                   # (the slipped batch was a whole read(): everybody is whole and in step again)
+    grp.close()
+    for c in range(2):
+        for i in range(n):
+            b = batch_bytes(i, 50 + c, 0)
+            gdevs[i].feedSmiBytes(b); sdevs[i].feedSmiBytes(b)
+        for i in range(n):
+            assert gdevs[i].readStream(gsts[i], [gb[i]], MTU).ret == sdevs[i].readStream(ssts[i], [sb[i]], MTU).ret
+            assert same(gb[i], sb[i]), ("after the group", c, i)
+    for d in gdevs + sdevs:
+        d.close()
+
+
+def test_a_group_filter_launch_that_gives_up_is_made_again(S):
+    """the single-pass filter kernel's bounded polls (clhip_iir_set_poll_bound(-1): every poll gives up): the sub-batch's launch reports
+    an overrun, its state is back where it was, the group filters the sub-batch again on the scan path inside the same call -- same
+    samples as the lone devices, whose own objects go through the same repair; the members' iir_overruns counters move"""
+    n = 4
+    gdevs, gsts = make_devices(S, n, S.SOAPY_SDR_CS16, None, lambda i: "HiF")
+    sdevs, ssts = make_devices(S, n, S.SOAPY_SDR_CS16, None, lambda i: "HiF")
+    for d in gdevs + sdevs:
+        d.setBandwidth(S.SOAPY_SDR_RX, 0, 50e3)
+    grp = S.Group(gdevs)
+    gb, sb = sentinel_buffers(n, (MTU + 2, 2), np.int16), sentinel_buffers(n, (MTU + 2, 2), np.int16)
+    for c in range(3):
+        if c == 1:
+            grp.setIirPollBound(-1)
+        for i in range(n):
+            b = batch_bytes(i, c, 1)
+            gdevs[i].feedSmiBytes(b); sdevs[i].feedSmiBytes(b)
+        _, rets = grp.readStream(gb, MTU)
+        srets = [sdevs[i].readStream(ssts[i], [sb[i]], MTU).ret for i in range(n)]
+        assert rets == srets == [MTU] * n
+        for i in range(n):
+            assert same(gb[i], sb[i]), (c, i)
+    assert [gdevs[i].streamStats(gsts[i])["iir_overruns"] for i in range(n)] == [1] * n
+    assert grp.stats()["single_reads"] == 0 and grp.stats()["errors"] == 0
+    grp.close()
+    for d in gdevs + sdevs:
+        d.close()
