@@ -464,8 +464,9 @@ def test_32_streams_with_every_batch_pending_beforehand(S, fmt, dtype, args, sha
     assert st["errors"] == 0 and st["ahead_reads"] >= (calls - 3) * (n - 6), st
 
 
-@pytest.mark.parametrize("seed,staged", [(1, True), (2, True), (3, False), (4, False), (5, True), (6, False), (7, True), (8, False), (9, False), (10, True)])
-def test_random_walk_against_lone_devices(S, seed, staged):
+@pytest.mark.parametrize("seed,staged,filters", [(1, True, 0), (2, True, 0), (3, False, 0), (4, False, 0), (5, True, 0), (6, False, 0), (7, True, 0), (8, False, 0), (9, False, 0),
+                                                 (10, True, 0), (11, False, 1), (12, False, 1), (13, False, 1), (14, True, 1)])
+def test_random_walk_against_lone_devices(S, seed, staged, filters):
     """A seeded random walk over everything a client can do between and in group calls -- feed whole / half / damaged / no batches to
     some members, ask for a whole or half MTU, read a member through its own device (plain lanes), flush one, switch a low-pass on or
     off, register / release buffers -- with eight streams whose FIFOs run several batches deep (work is made ahead and given up all
@@ -509,12 +510,16 @@ def test_random_walk_against_lone_devices(S, seed, staged):
         for i in range(n):                                 # keep most FIFOs two to four batches deep
             while gdevs[i].pendingSmiBytes() < int(rng.integers(1, 4)) * NB:
                 feed(i, rng.choice(["good"] * 12 + ["slip", "lost", "half"]))
-        op = rng.choice(["call"] * 5 + ["half", "lone", "flush", "filter", "register", "maxread"])
+        op = rng.choice(["call"] * 5 + ["half", "lone", "flush", "filter", "register", "maxread"] + ["filter_all"] * (2 * filters))
         for x in gb + sb:
             x[...] = np.nan
         if op == "maxread":                                # one member's driver hands out shorter read()s from now on (or whole ones again)
             i = int(rng.integers(0, n)); m = int(rng.choice([0, NB // 2, 100000]))
             gdevs[i].setMaxRead(m); sdevs[i].setMaxRead(m); hist[i].append(f"maxread{m}")
+        if op == "filter_all":                             # the same low-pass on everybody (lanes without stages: whole sub-batches through one filter launch), or off
+            bw = float(rng.choice([100e3, 50e3, 1e6]))
+            for i in range(n):
+                gdevs[i].setBandwidth(S.SOAPY_SDR_RX, 0, bw); sdevs[i].setBandwidth(S.SOAPY_SDR_RX, 0, bw); hist[i].append(f"bw{bw:g}")
         if op == "lone" and not staged:
             i = int(rng.integers(0, n))
             assert gdevs[i].readStream(gsts[i], [gb[i]], MTU).ret == sdevs[i].readStream(ssts[i], [sb[i]], MTU).ret
@@ -543,7 +548,7 @@ def test_random_walk_against_lone_devices(S, seed, staged):
         assert rets == srets, (step, op, rets, srets)
         compare((str(op), step))
     st = grp.stats()
-    assert st["errors"] == 0 and st["ahead_reads"] > 40 and st["single_reads"] > 5, st
+    assert st["errors"] == 0 and st["single_reads"] > 5 and (filters or st["ahead_reads"] > 40), st
     grp.close()
     for d in gdevs + sdevs:
         d.close()
