@@ -1639,6 +1639,18 @@ extern "C" int clhip_iir_status(clhip_iir *f)
     return -1;
 }
 
+// The last call is taken back (a caller that filtered ahead of its client, who then went another way): its stream must have been
+// synchronised.  The carried state is again what it was before that call; a verdict that call left behind is consumed.
+// 0, or -1 when there is no call to take back.
+extern "C" int clhip_iir_unrun(clhip_iir *f)
+{
+    if (!f) return -1;
+    if (clhip_iir_status(f) != 0) return 0;               // it had overrun: status has put the state back already
+    if (!f->can_undo) { clhip_set_error("clhip_iir_unrun: no call to take back"); return -1; }
+    f->cur = f->undo_cur; f->can_undo = false;
+    return 0;
+}
+
 // Synchronise, ask, and repair: 0 = good; 1 = the call overran and has been made again on the scan path (d_out holds
 // the right samples now, the state has advanced once); -1 = overran in place (the input is gone: state restored,
 // the caller re-produces the input and calls again) or a runtime error.

@@ -68,6 +68,8 @@ typedef struct {
     /* the reference's low-pass over whole sub-batches (lanes without extension stages): one multi-stream filter object per (filter,
      * sub-batch), made when first needed; a member's carried state lives EITHER in its stream's own objects or here (iir_own) */
     clhip_iir **giir; int n_subs; uint8_t *iir_own; int16_t *d_f; uint8_t *sub_ft; uint8_t *how;
+    uint8_t *ahead_ft;                         /* per sub-batch: the filter of a filter launch made AHEAD (its results in the other mirror; 0: none) */
+    uint8_t *sub_verdict;                      /* per call and sub-batch: 0 = its filter launch has not been asked yet; 1 = good; 2 = gave up twice (nothing to deliver); 3 = runtime error */
     int epoch_open;                            /* the pipe's epoch of the NEXT call was opened by the read-ahead */
     int set;                                   /* this call's event set (0 / 1) */
     size_t sub0; int queued;                   /* the lane's first sub-batch among the group's; sub-batches queued in this call */
@@ -235,6 +237,9 @@ static int same_dsp(const cl_dsp_cfg *a, const cl_dsp_cfg *b)
 }
 
 static void ahead_cancel_all(cl_group *g);
+static void settle(cl_group *g);
+static void giir_ahead_drop(cl_group *g, lane_t *l, int sb);
+static void **ev_of(const cl_group *g, const lane_t *l, int set, int a);
 static void iir_home(void *ctx, int member);
 
 static void lane_free(lane_t *l)
@@ -246,7 +251,7 @@ static void lane_free(lane_t *l)
     clhip_host_free(l->tx_h_in); clhip_free(l->tx_d_in);
     free(l->done_ahead); free(l->ahead_got); free(l->direct); free(l->ctx);
     for (int i = 0; l->giir && i < 3 * l->n_subs; i++) clhip_iir_destroy(l->giir[i]);
-    free(l->giir); free(l->iir_own); free(l->sub_ft); free(l->how); clhip_free(l->d_f);
+    free(l->giir); free(l->iir_own); free(l->sub_ft); free(l->ahead_ft); free(l->sub_verdict); free(l->how); clhip_free(l->d_f);
     free(l->member); free(l->fast); free(l->len); free(l->got); free(l->src); free(l->ahead_mark);
     memset(l, 0, sizeof *l);
 }
@@ -417,9 +422,9 @@ cl_group *cl_group_make(cl_device *const *devs, size_t n, const char *const *key
         l->n_subs = (l->n + l->sub - 1) / l->sub;
         if (l->route == ROUTE_PLAIN) {
             l->giir = (clhip_iir **)calloc((size_t)3 * (size_t)l->n_subs, sizeof(clhip_iir *)); l->iir_own = (uint8_t *)calloc((size_t)3 * (size_t)l->n, 1);
-            l->sub_ft = (uint8_t *)calloc((size_t)l->n_subs, 1);
+            l->sub_ft = (uint8_t *)calloc((size_t)l->n_subs, 1); l->ahead_ft = (uint8_t *)calloc((size_t)l->n_subs, 1); l->sub_verdict = (uint8_t *)calloc((size_t)l->n_subs, 1);
             l->d_f = (int16_t *)clhip_malloc((size_t)l->n * l->out_stride * 4 + 256);
-            if (!l->giir || !l->iir_own || !l->sub_ft || !l->d_f) { cl_seterr(g_make_err, sizeof g_make_err, "cl_group_make: filter buffers"); cl_group_unmake(g); return NULL; }
+            if (!l->giir || !l->iir_own || !l->sub_ft || !l->ahead_ft || !l->sub_verdict || !l->d_f) { cl_seterr(g_make_err, sizeof g_make_err, "cl_group_make: filter buffers"); cl_group_unmake(g); return NULL; }
             for (int r = 0; r < l->n; r++) {
                 cl_stream *st = g->dev[l->member[r]]->stream;
                 st->iir_home = iir_home; st->iir_home_ctx = g; st->iir_home_member = l->member[r];
@@ -484,6 +489,8 @@ static void ahead_cancel_all(cl_group *g)
         }
     }
     settle(g);
+    for (int k = 0; k < g->n_lanes; k++)
+        for (int sb = 0; g->lane[k].ahead_ft && sb < g->lane[k].n_subs; sb++) giir_ahead_drop(g, &g->lane[k], sb);
 }
 
 /* Client buffers the members' outputs may be written into by the copy engine directly (no pinned mirror, no memcpy): one
@@ -558,12 +565,25 @@ static int registered(const cl_group *g, int m, const void *p, size_t bytes)
  * (cl_soapy.c: filter_source calls iir_home) or the group goes. */
 static int giir_index(const lane_t *l, int row, int ft) { return (ft - 1) * l->n_subs + row / l->sub; }
 
+/* a filter launch made ahead over sub-batch `sb` is given up: waited for, its object's state put back, its rows' results forgotten
+ * (what was READ ahead stands: the rows are launched over in the call) */
+static void giir_ahead_drop(cl_group *g, lane_t *l, int sb)
+{
+    if (!l->ahead_ft || !l->ahead_ft[sb]) return;
+    g->stale = 1; settle(g);
+    clhip_iir_unrun(l->giir[(l->ahead_ft[sb] - 1) * l->n_subs + sb]);
+    l->ahead_ft[sb] = 0;
+    const int a = sb * l->sub, e = a + l->sub < l->n ? a + l->sub : l->n;
+    for (int r = a; r < e; r++) l->done_ahead[r] = 0;
+}
+
 static void iir_home(void *ctx, int member)
 {
     cl_group *g = (cl_group *)ctx;
     lane_t *l = &g->lane[g->lane_of[member]];
     const int row = g->row_of[member];
     if (!l->iir_own) return;
+    giir_ahead_drop(g, l, row / l->sub);                       /* (a filter launch made ahead has advanced the state: taken back first) */
     for (int ft = 1; ft <= 3; ft++) {
         if (!l->iir_own[3 * row + ft - 1]) continue;
         clhip_iir *obj = l->giir[giir_index(l, row, ft)];
@@ -629,6 +649,28 @@ static int giir_launch(cl_group *g, lane_t *l, clhip_iir *obj, int a, int e, siz
     return 0;
 }
 
+/* The verdict of the filter launch over THIS call's batch of sub-batch [a, e) (clhip_iir_status behind its event): a single-pass launch
+ * that gave up has its state back where it was and the object on its scan path -- the sub-batch is filtered again, once, here
+ * (CaribouliteStream.cpp has no such case: its loop cannot fail; a second failure delivers 0 elements like any read error,
+ * :266-276).  Asked once per call -- before the object is launched over the NEXT batch (one call in flight per object: a launch
+ * behind one that gave up would start from its garbage), or when the sub-batch's rows are handed out.  1 / 2 / 3 as sub_verdict. */
+static int giir_verdict(cl_group *g, lane_t *l, int a, int e)
+{
+    const int sb = a / l->sub;
+    if (l->sub_verdict[sb]) return l->sub_verdict[sb];
+    int v = 1;
+    if (clhip_event_sync(ev_of(g, l, l->set, a)[g->n_in + 1])) v = 3;
+    else {
+        clhip_iir *obj = l->giir[giir_index(l, a, l->sub_ft[sb])];
+        if (clhip_iir_status(obj)) {
+            for (int r = a; r < e; r++) g->dev[l->member[r]]->stream->stats.iir_overruns++;
+            if (giir_launch(g, l, obj, a, e, l->want, l->d_in[l->cur_in], l->m_out[l->cur_m], 2 * l->set + 1) || clhip_stream_sync(g->s_k)) v = 3;
+            else if (clhip_iir_status(obj)) v = 2;
+        }
+    }
+    return l->sub_verdict[sb] = (uint8_t)v;
+}
+
 /* may member `row` take the batched route at all in this call? */
 static int qualifies(const cl_group *g, const lane_t *l, int row, size_t want, int allow_filter)
 {
@@ -679,7 +721,7 @@ static int try_stage(cl_group *g, lane_t *l, int row, size_t want, void *s_in, i
         if (intact && had == want && qualifies(g, l, row, want, allow_filter) && (was_done || on_phase_0(l, row))) {
             smi->foreign_ahead = 0;                            /* this call's batch now: staged, the oldest unconfirmed bytes */
             cl_smi_ahead_note(smi);
-            if (was_done && allow_filter) { g->stale = 1; settle(g); return 2; }     /* (computed ahead WITHOUT the low-pass that has been selected since: only the input stands) */
+            if (was_done && allow_filter && !(l->ahead_ft && l->ahead_ft[row / l->sub])) { g->stale = 1; settle(g); return 2; }   /* (computed ahead WITHOUT the low-pass that has been selected since: only the input stands) */
             return was_done ? 3 : 2;
         }
         if (intact) cl_smi_foreign_cancel(smi);                 /* another length, or off the batched route: pending again, in order */
@@ -840,7 +882,7 @@ int cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems, int *r
                 for (int r = a; r < e; r++)
                     if (g->dev[l->member[r]]->stream->filter_type != ft || g->has_reg[l->member[r]]) ft = 0;
             }
-            if (l->sub_ft) l->sub_ft[a / l->sub] = 0;
+            if (l->sub_ft) { l->sub_ft[a / l->sub] = 0; l->sub_verdict[a / l->sub] = 0; }
             for (int r = a; r < e; r++) {
                 const int how = try_stage(g, l, r, want, s_in, ft > 0);
                 l->how[r] = (uint8_t)how;
@@ -851,7 +893,21 @@ int cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems, int *r
                 l->got[r] = how == 3 ? l->ahead_got[r] : 0;
                 l->direct[r] = 0;
             }
-            if (ft > 0) {                                      /* all of them or none: a member that is short, out of sync or off the route sends everybody home */
+            int filtered_ahead = 0;
+            if (l->ahead_ft && l->ahead_ft[a / l->sub]) {
+                /* the previous call filtered this sub-batch ahead: good for this call if the same filter is still selected on everybody and
+                 * every row's batch is still the one it read ahead -- otherwise the launch is taken back (the state it advanced), the rows
+                 * that are still theirs keep their input */
+                int all3 = ft == l->ahead_ft[a / l->sub];
+                for (int r = a; r < e; r++) all3 &= l->how[r] == 3;
+                if (all3) { filtered_ahead = 1; l->ahead_ft[a / l->sub] = 0; }
+                else {
+                    giir_ahead_drop(g, l, a / l->sub);
+                    for (int r = a; r < e; r++)
+                        if (l->how[r] == 3) { l->how[r] = 2; l->ahead_mark[r] = 1; l->got[r] = 0; from_ahead = 1; }
+                }
+            }
+            if (ft > 0 && !filtered_ahead) {                   /* all of them or none: a member that is short, out of sync or off the route sends everybody home */
                 int all = 1;
                 for (int r = a; r < e; r++) all &= l->how[r] == 1 || l->how[r] == 2;
                 if (!all) {
@@ -868,6 +924,7 @@ int cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems, int *r
             }
             if (copies_queue(g, l, in, a, e, want, s_in)) hard = 1;     /* (a row whose copy cannot be queued leaves the batched route: fast = 0) */
             if (ft > 0) for (int r = a; r < e; r++) if (!l->fast[r]) hard = 1;   /* (a copy that could not be queued inside a filter sub-batch: a runtime error) */
+            if (filtered_ahead) l->sub_ft[a / l->sub] = (uint8_t)ft;                /* (nothing to launch; its verdict is asked with the others', pass 3) */
             for (int r = a; r < e; r++) {
                 l->ahead_mark[r] = (uint8_t)(l->ahead_mark[r] && l->fast[r]);
                 l->len[r] = l->fast[r] ? want : 0;
@@ -962,14 +1019,25 @@ int cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems, int *r
         int waited = 0;
         for (int a = 0; a < l->n && !hard; a += l->sub) {
             const int e = a + l->sub < l->n ? a + l->sub : l->n;
-            int run = 0;
+            int run = 0, ft = l->route == ROUTE_PLAIN ? g->dev[l->member[a]]->stream->filter_type : 0, whole = 1;
             for (int r = a; r < e; r++) {
-                if (g->has_reg[l->member[r]] || g->dev[l->member[r]]->stream->filter_type != CL_DIGFILT_NONE) { run = 0; break; }     /* (the copy engine needs the client's pointer; a filter run cannot be taken back) */
+                cl_stream *st = g->dev[l->member[r]]->stream;
+                if (g->has_reg[l->member[r]] || st->filter_type != ft || (l->route != ROUTE_PLAIN && st->filter_type != CL_DIGFILT_NONE)) { run = 0; whole = 0; break; }   /* (the copy engine needs the client's pointer; a mixed sub-batch waits for the call) */
                 l->done_ahead[r] = (uint8_t)(l->ahead_mark[r] && on_phase_0(l, r));
-                run |= l->done_ahead[r];
+                run |= l->done_ahead[r]; whole &= l->done_ahead[r];
             }
+            if (ft > 0 && !whole) run = 0;                     /* (a filter launch is over the whole sub-batch or not at all) */
             if (!run) { for (int r = a; r < e; r++) l->done_ahead[r] = 0; continue; }
             if (!waited) { hard = clhip_stream_wait_event(g->s_k, l->ev_primed); waited = 1; }
+            if (ft > 0) {
+                if (l->sub_ft[a / l->sub] && giir_verdict(g, l, a, e) == 3) hard = 1;      /* (this call's launch over the same object, first) */
+                clhip_iir *obj = hard ? NULL : giir_get(g, l, a, e, ft);
+                if (!obj || giir_launch(g, l, obj, a, e, l->want, l->d_in[l->next_in], l->m_out[l->cur_m ^ 1], 2 * (l->set ^ 1))) hard = 1;
+                for (int r = a; r < e; r++) l->ahead_got[r] = (long)(l->want / 4);
+                l->ahead_ft[a / l->sub] = (uint8_t)ft;
+                hard = hard || clhip_event_record(ev_of(g, l, l->set ^ 1, a)[g->n_in + 1], g->s_k);
+                continue;
+            }
             if (!hard && launch_rows(g, l, a, e, l->done_ahead, l->want, l->d_in[l->next_in], l->m_out[l->cur_m ^ 1], 2 * (l->set ^ 1), l->ahead_got)) hard = 1;
             hard = hard || clhip_event_record(ev_of(g, l, l->set ^ 1, a)[g->n_in + 1], g->s_k);
         }
@@ -984,19 +1052,12 @@ int cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems, int *r
             int any = 0;
             for (int r = a; r < e; r++) any |= l->fast[r];
             if (!any) continue;
-            int arrived = sb < l->queued && !hard && clhip_event_sync(ev_of(g, l, l->set, a)[g->n_in + 1]) == 0;
-            int filter_failed = 0;
-            if (arrived && l->sub_ft && l->sub_ft[sb]) {
-                /* the filter launch's verdict (clhip_iir_status): a single-pass launch that gave up has its state back where it was and
-                 * the object on its scan path -- the sub-batch is filtered again, once, here (CaribouliteStream.cpp has no such case:
-                 * its loop cannot fail; a second failure delivers 0 elements like any read error, :266-276) */
-                clhip_iir *obj = l->giir[giir_index(l, a, l->sub_ft[sb])];
-                if (clhip_iir_status(obj)) {
-                    for (int r = a; r < e; r++) g->dev[l->member[r]]->stream->stats.iir_overruns++;
-                    if (giir_launch(g, l, obj, a, e, l->want, l->d_in[l->cur_in], l->m_out[l->cur_m], 2 * l->set + 1) || clhip_stream_sync(g->s_k)) arrived = 0;
-                    else if (clhip_iir_status(obj)) filter_failed = 1;
-                }
-            }
+            int arrived, filter_failed = 0;
+            if (l->sub_ft && l->sub_ft[sb] && sb < l->queued && !hard) {
+                const int v = giir_verdict(g, l, a, e);
+                arrived = v != 3; filter_failed = v == 2;
+            } else
+                arrived = sb < l->queued && !hard && clhip_event_sync(ev_of(g, l, l->set, a)[g->n_in + 1]) == 0;
             if (!arrived) hard = 1;
             for (int r = a; r < e; r++) {
                 if (!l->fast[r]) continue;

@@ -68,6 +68,7 @@ _SIGS = {
     "clhip_iir_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]),
     "clhip_iir_status": (C.c_int, [C.c_void_p]),
     "clhip_iir_finish": (C.c_int, [C.c_void_p]),
+    "clhip_iir_unrun": (C.c_int, [C.c_void_p]),
     "clhip_iir_set_state": (C.c_int, [C.c_void_p, C.c_void_p]),
     "clhip_iir_get_state": (C.c_int, [C.c_void_p, C.c_void_p]),
     "clhip_iir_set_poll_bound": (None, [C.c_void_p, C.c_int]),
@@ -327,6 +328,10 @@ class IIR:
     def finish(self):
         """synchronise + verdict + repeat on the scan path when the call was out of place: 0 good, 1 repaired, -1 failed"""
         return lib().clhip_iir_finish(self.h)
+
+    def unrun(self):
+        """take the last run back (after a synchronise): the carried state is what it was before it"""
+        return lib().clhip_iir_unrun(self.h)
 
     def set_poll_bound(self, polls):
         lib().clhip_iir_set_poll_bound(self.h, int(polls))

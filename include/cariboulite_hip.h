@@ -243,6 +243,8 @@ int    clhip_iir_status(clhip_iir *f);
  * good now, the state has advanced once); -1 = overran with d_out == d_in (the input is gone: state restored, the
  * caller re-produces the input and calls again), or a runtime error */
 int    clhip_iir_finish(clhip_iir *f);
+/* take the LAST call back (its stream synchronised): the carried state is what it was before it; 0 / -1 (no call to take back) */
+int    clhip_iir_unrun(clhip_iir *f);
 /* carried state: 16 doubles per stream (NULL = rest); both synchronise with the last call */
 int    clhip_iir_set_state(clhip_iir *f, const double *h_state);
 int    clhip_iir_get_state(clhip_iir *f, double *h_state);

@@ -401,6 +401,7 @@ void clhip_iir_destroy(clhip_iir *f) { free(f); }
 int clhip_iir_run(clhip_iir *f, const int16_t *a, int16_t *b, size_t c, size_t d, void *s) { (void)f; (void)a; (void)b; (void)c; (void)d; (void)s; set_err("clhip_mock: no IIR"); return -1; }
 int clhip_iir_run_smi(clhip_iir *f, int ch, const uint8_t *w, int16_t *o, size_t a, size_t b, void *s) { (void)f; (void)ch; (void)w; (void)o; (void)a; (void)b; (void)s; set_err("clhip_mock: no IIR"); return -1; }
 int clhip_iir_status(clhip_iir *f) { (void)f; return 0; }
+int clhip_iir_unrun(clhip_iir *f) { (void)f; return 0; }
 int clhip_iir_set_state(clhip_iir *f, const double *h) { (void)f; (void)h; return 0; }
 int clhip_iir_get_state(clhip_iir *f, double *h) { (void)f; memset(h, 0, 16 * sizeof(double)); return 0; }
 void clhip_iir_set_poll_bound(clhip_iir *f, int polls) { (void)f; (void)polls; }

@@ -734,3 +734,30 @@ def test_tx_pipe_calls_on_either_side_of_the_kernel_choice_equal_one_shot(G, orc
     # moves 1e-7-sized roundings around: 3e-4 of the samples with the one-sub-block kernel on both sides, CLHIP_TX_CHAIN=3)
     assert float((d != 0).float().mean()) < 1e-3, float((d != 0).float().mean())
     assert torch.equal(got.view(-1, 4)[:, 0] & 0xE0, want.view(-1, 4)[:, 0] & 0xE0)
+
+
+def test_iir_last_call_can_be_taken_back(G, orc):
+    """clhip_iir_unrun (a stream group that filtered ahead of a client who then went another way): run A, run B, take B back, run C --
+    the outputs of C equal those of an object that ran A and C only, bit for bit, on both launch paths; with nothing to take back it
+    refuses."""
+    import torch
+    from cariboulite_amd import hip, synth
+    n, ns = 131072, 3
+    sos = _sos5(orc.IIR(6, 4e6, 50e3))
+    x = [torch.from_numpy(np.stack([np.stack(synth.smi_stream_bytes(n, 0, stream=60 + 3 * k + s)[1:], 1).astype(np.int16) for s in range(ns)])).to(G.DEV) for k in range(3)]
+    for onepass in (True, False):
+        f, ref = hip.IIR(sos, ns), hip.IIR(sos, ns)
+        if not onepass:
+            for o in (f, ref):
+                o.set_poll_bound(-1); y = x[0].clone(); o.run(y, n, stride=n); torch.cuda.synchronize(); assert o.status() == -1     # (now on the scan path)
+        a1, a2 = x[0].clone(), x[0].clone()
+        f.run(a1, n, stride=n); ref.run(a2, n, stride=n)
+        b = x[1].clone(); f.run(b, n, stride=n)
+        torch.cuda.synchronize()
+        assert f.status() == 0 and f.unrun() == 0
+        c1, c2 = x[2].clone(), x[2].clone()
+        f.run(c1, n, stride=n); ref.run(c2, n, stride=n)
+        torch.cuda.synchronize()
+        assert f.status() == 0 and ref.status() == 0
+        assert torch.equal(a1, a2) and torch.equal(c1, c2), onepass
+        assert f.unrun() == 0 and f.unrun() != 0                    # one level
