@@ -78,7 +78,8 @@ typedef struct {
     uint8_t **src;                        /* per call and row: where the staged batch lies in the member's pinned FIFO */
     cl_dsp_cfg dsp;
     /* a TX group's lane (cl_group_writeStream): the clients' samples, row by row, in pinned memory and on the device */
-    uint8_t *tx_h_in, *tx_d_in; size_t tx_row;
+    uint8_t *tx_h_in, *tx_d_in; size_t tx_row;      /* two sets of rows each: this call's and the previous call's (still in flight) */
+    uint8_t *tx_pend; int tx_pend_set; size_t tx_pend_want;   /* per row: words launched over and not committed yet (write-behind) */
 } lane_t;
 
 struct cl_group {
@@ -92,6 +93,7 @@ struct cl_group {
                                            * 2 (default) = ... and launched over, into the second mirror */
     size_t n_sub;                         /* sub-batches over all lanes */
     int iir_polls; int iir_polls_set;     /* test hook (cl_group_set_iir_poll_bound): the poll bound of the group's filter objects */
+    pthread_mutex_t tx_mu; int tx_mu_ok; int tx_pending;      /* a TX group: the call and the members' seams' call-backs (any thread) */
     int stale;                            /* work made ahead has just been given up: it is waited for before anything takes its place (settle) */
     int sink_mapped;                      /* kwarg SINK: "mapped" (default) = the sub-batch's kernel stores into the mapped pinned mirror itself; "copy" = device buffer + copy engine */
 #define GRP_MAX_IN 8
@@ -237,6 +239,8 @@ static int same_dsp(const cl_dsp_cfg *a, const cl_dsp_cfg *b)
 }
 
 static void ahead_cancel_all(cl_group *g);
+static void tx_settle_hook(void *ctx, int member);
+static void tx_finish(cl_group *g);
 static void settle(cl_group *g);
 static void giir_ahead_drop(cl_group *g, lane_t *l, int sb);
 static void **ev_of(const cl_group *g, const lane_t *l, int set, int a);
@@ -248,7 +252,7 @@ static void lane_free(lane_t *l)
     clhip_free(l->d_in[0]); clhip_free(l->d_in[1]); clhip_free(l->d_in[2]); clhip_free(l->d_out);
     clhip_event_destroy(l->ev_primed); free(l->primed); free(l->primed_epoch);
     clhip_host_free(l->h_out[0]); clhip_host_free(l->h_out[1]); clhip_host_free(l->h_offs[0]);
-    clhip_host_free(l->tx_h_in); clhip_free(l->tx_d_in);
+    clhip_host_free(l->tx_h_in); clhip_free(l->tx_d_in); free(l->tx_pend);
     free(l->done_ahead); free(l->ahead_got); free(l->direct); free(l->ctx);
     for (int i = 0; l->giir && i < 3 * l->n_subs; i++) clhip_iir_destroy(l->giir[i]);
     free(l->giir); free(l->iir_own); free(l->sub_ft); free(l->ahead_ft); free(l->sub_verdict); free(l->how); clhip_free(l->d_f);
@@ -260,6 +264,13 @@ void cl_group_unmake(cl_group *g)
 {
     if (!g) return;
     clhip_set_device(g->device);
+    if (g->tx_mu_ok) {                                         /* a TX group: what is in flight lands, the members' seams stop calling back */
+        pthread_mutex_lock(&g->tx_mu);
+        tx_finish(g);
+        for (size_t i = 0; g->dev && i < g->n; i++)
+            if (g->dev[i] && g->dev[i]->smi->tx_settle_ctx == g) { g->dev[i]->smi->tx_settle = NULL; g->dev[i]->smi->tx_settle_ctx = NULL; }
+        pthread_mutex_unlock(&g->tx_mu);
+    }
     for (int k = 0; k < GRP_MAX_IN; k++) if (g->s_in[k]) clhip_stream_sync(g->s_in[k]);
     if (g->s_k) clhip_stream_sync(g->s_k);
     if (g->s_out) clhip_stream_sync(g->s_out);
@@ -289,6 +300,7 @@ void cl_group_unmake(cl_group *g)
     clhip_stream_destroy(g->s_k); clhip_stream_destroy(g->s_out);
     free(g->ev); free(g->lane); free(g->dev); free(g->lane_of); free(g->row_of);
     free(g->reg_base); free(g->reg_len); free(g->has_reg);
+    if (g->tx_mu_ok) pthread_mutex_destroy(&g->tx_mu);
     free(g);
 }
 
@@ -312,6 +324,7 @@ cl_group *cl_group_make(cl_device *const *devs, size_t n, const char *const *key
     if (!g) return NULL;
     g->device = devs[0]->smi->device;
     g->dir = devs[0]->stream->native_dir;
+    { pthread_mutexattr_t at; pthread_mutexattr_init(&at); pthread_mutexattr_settype(&at, PTHREAD_MUTEX_RECURSIVE); pthread_mutex_init(&g->tx_mu, &at); pthread_mutexattr_destroy(&at); g->tx_mu_ok = 1; }
     clhip_set_device(g->device);
     g->n = n;
     g->dev = (cl_device **)calloc(n, sizeof *g->dev);
@@ -368,8 +381,13 @@ cl_group *cl_group_make(cl_device *const *devs, size_t n, const char *const *key
             if (l->route != ROUTE_TX_PLAIN) continue;
             l->elem_bytes = fmt_bytes(l->format);
             l->tx_row = mtu * l->elem_bytes + 256;
-            l->tx_h_in = (uint8_t *)clhip_host_alloc((size_t)l->n * l->tx_row); l->tx_d_in = (uint8_t *)clhip_malloc((size_t)l->n * l->tx_row);
-            if (!l->tx_h_in || !l->tx_d_in) { cl_seterr(g_make_err, sizeof g_make_err, "cl_group_make: buffers for %d TX streams could not be allocated", l->n); cl_group_unmake(g); return NULL; }
+            l->tx_h_in = (uint8_t *)clhip_host_alloc(2 * (size_t)l->n * l->tx_row); l->tx_d_in = (uint8_t *)clhip_malloc(2 * (size_t)l->n * l->tx_row);
+            l->tx_pend = (uint8_t *)calloc((size_t)l->n, 1);
+            for (int r = 0; r < l->n; r++) {
+                cl_smi *smi = g->dev[l->member[r]]->smi;
+                smi->tx_settle = tx_settle_hook; smi->tx_settle_ctx = g; smi->tx_settle_member = l->member[r];
+            }
+            if (!l->tx_h_in || !l->tx_d_in || !l->tx_pend) { cl_seterr(g_make_err, sizeof g_make_err, "cl_group_make: buffers for %d TX streams could not be allocated", l->n); cl_group_unmake(g); return NULL; }
             continue;
         }
         l->in_stride = nb + 256;
@@ -1121,30 +1139,70 @@ int cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems, int *r
 
 /* ------------------------------------------------------------------------------------------- the write call
  * N writeStream calls as one (Stream::WriteSamplesGen, CaribouliteStream.cpp:199-258, over caribou_smi_write, caribou_smi.c:720-762):
- * rets[i] is what cl_writeStream(devs[i], ..., &buffs[i], numElems) returns, and when the call returns the packed words of every
- * member are in its TX FIFO behind what was there.  Members without a modulator share launches, up to eight streams each:
+ * rets[i] is what cl_writeStream(devs[i], ..., &buffs[i], numElems) returns, and the packed words of every member land in its TX FIFO
+ * behind what was there.  Members without a modulator share launches, up to eight streams each:
  *
- *     sub-batch b:  clients' samples --copy threads--> pinned rows --copy engine--> device rows     stream s_in[b mod K]
- *                   one launch converts and packs (caribou_smi_generate_data) every row and stores the words straight into the room
- *                   reserved in each member's pinned TX FIFO                                          stream s_k
+ *     A  sub-batch b:  clients' samples --copy threads--> pinned rows --copy engine--> device rows           stream s_in[b mod K]
+ *     B  the PREVIOUS call's launches are waited for, its words committed to the members' FIFOs
+ *     C  room is reserved in every member's pinned TX FIFO; one launch per sub-batch converts and packs (caribou_smi_generate_data)
+ *        every row and stores the words straight into the rooms                                               stream s_k
  *
- * so the host copies sub-batch b + 1 while b crosses PCIe both ways.  A member with a modulator (MOD=FM, RESAMP), a CS16 call above
- * one MTU (the reference does not clamp those) or a member whose pack mode differs from its sub-batch's takes its own device's
- * writeStream, here, inside the call. */
+ * The call returns with C queued (WRITE-BEHIND by one call: this call's copies in cross PCIe while the previous call's launches store
+ * out, and the next call's host copies run while this one's launches do).  Nobody can tell: the members' seams call back
+ * (tx_settle) before anything of theirs looks at or adds to a TX FIFO -- cl_smi_drain_bytes / _drain_to_fd from any thread, a
+ * write through a member's own device -- and the group finishes what it has in flight first; so does cl_group_unmake.  (What a
+ * client cannot be told any more is a runtime error of launches it was already told about: the next call reports it.)
+ * A member with a modulator (MOD=FM, RESAMP), a CS16 call above one MTU (the reference does not clamp those) or a member whose pack
+ * mode differs from its sub-batch's takes its own device's writeStream, here, inside the call. */
+static void tx_finish(cl_group *g)
+{
+    if (!g->tx_pending) return;
+    g->tx_pending = 0;
+    for (int k = 0; k < g->n_lanes; k++) {
+        lane_t *l = &g->lane[k];
+        if (l->route != ROUTE_TX_PLAIN) continue;
+        for (int a = 0; a < l->n; a += l->sub) {
+            const int e = a + l->sub < l->n ? a + l->sub : l->n;
+            int any = 0;
+            for (int r = a; r < e; r++) any |= l->tx_pend[r];
+            if (!any) continue;
+            const int ok = clhip_event_sync(ev_of(g, l, l->tx_pend_set, a)[g->n_in + 1]) == 0;
+            for (int r = a; r < e; r++) {
+                if (!l->tx_pend[r]) continue;
+                l->tx_pend[r] = 0;
+                if (ok) cl_smi_tx_commit(g->dev[l->member[r]]->smi, 4 * l->tx_pend_want);
+            }
+            if (!ok) { cl_seterr(g->err, sizeof g->err, "cl_group_writeStream: launches of the previous call failed (%s): their words are lost", clhip_last_error()); g->stats.errors++; }
+        }
+    }
+}
+
+/* a member's seam is about to look at or add to its TX FIFO (any thread) */
+static void tx_settle_hook(void *ctx, int member)
+{
+    cl_group *g = (cl_group *)ctx;
+    (void)member;
+    pthread_mutex_lock(&g->tx_mu);
+    tx_finish(g);
+    pthread_mutex_unlock(&g->tx_mu);
+}
+
 int cl_group_writeStream(cl_group *g, const void *const *buffs, size_t numElems, int *rets, long timeoutUs)
 {
     if (!g || !buffs || !rets) return -1;
     if (g->dir != CL_SOAPY_SDR_TX) { cl_seterr(g->err, sizeof g->err, "cl_group_writeStream: the group's devices are set up for RX"); return -1; }
     clhip_set_device(g->device);
+    pthread_mutex_lock(&g->tx_mu);
+    const uint64_t errors_before = g->stats.errors;
     g->err[0] = 0;
     g->stats.calls++;
     for (size_t i = 0; i < g->n; i++) rets[i] = 0;
-    if (!numElems) return 0;
+    if (!numElems) { pthread_mutex_unlock(&g->tx_mu); return 0; }
     const size_t mtu = CL_NATIVE_MTU_SAMPLES;
     int hard = 0;
     struct timespec t0, t1, t2, t3;
     clock_gettime(CLOCK_MONOTONIC, &t0);
-    /* ---- pass 1: room in the FIFOs, the clients' samples to the device, the launches -- everything queued, nothing waited for */
+    /* ---- A: the clients' samples to the device (the previous call's launches are storing their words meanwhile) */
     for (int k = 0; k < g->n_lanes && !hard; k++) {
         lane_t *l = &g->lane[k];
         memset(l->fast, 0, (size_t)l->n);
@@ -1153,13 +1211,14 @@ int cl_group_writeStream(cl_group *g, const void *const *buffs, size_t numElems,
         const size_t n_el = l->format != CL_FORMAT_CS16 && numElems > mtu ? mtu : numElems;      /* :201,217,234; CS16 is not clamped (:182-196) */
         if (n_el > mtu) continue;                              /* (a chunk loop of its own, member by member) */
         l->want = n_el;
+        l->set ^= 1;                                           /* pinned rows, device rows and events of this call: the other set is the previous call's, still in flight */
+        uint8_t *h_in = l->tx_h_in + (size_t)l->set * l->n * l->tx_row, *d_in = l->tx_d_in + (size_t)l->set * l->n * l->tx_row;
         for (int a = 0; a < l->n && !hard; a += l->sub) {
             const int e = a + l->sub < l->n ? a + l->sub : l->n;
-            void **ev = ev_of(g, l, 0, a);
+            void **ev = ev_of(g, l, l->set, a);
             const size_t b = l->sub0 + (size_t)(a / l->sub);
             void *s_in = g->s_in[b % (size_t)g->n_in];
-            const void *in_rows[CLHIP_PACK_ROWS]; uint8_t *out_rows[CLHIP_PACK_ROWS];
-            int n_rows = 0, mode = -1, lo = -1, hi = -1;
+            int mode = -1, lo = -1, hi = -1;
             l->queued++;
             for (int r = a; r < e; r++) {
                 cl_device *dev = g->dev[l->member[r]];
@@ -1167,61 +1226,71 @@ int cl_group_writeStream(cl_group *g, const void *const *buffs, size_t numElems,
                 if (st->native_dir != CL_SOAPY_SDR_TX || st->format != l->format || st->tx_pipe || !buffs[l->member[r]]) continue;
                 if (mode < 0) mode = dev->smi->tx_mode;
                 if (dev->smi->tx_mode != mode) continue;
-                /* caribou_smi_write's chunk loop appends native-batch pieces of one contiguous array (caribou_smi.c:738-759): the array,
-                 * packed into the room behind what the FIFO holds, committed once the launch is known to have run */
-                uint8_t *room = cl_smi_tx_reserve(dev->smi, 4 * n_el + 64);
-                uint8_t *d_room = room ? (uint8_t *)cl_fifo_device_ptr(&dev->smi->tx, room) : NULL;
-                if (!d_room) continue;
-                l->fast[r] = 1; l->src[r] = room;
-                pool_submit(&g->pool, l->tx_h_in + (size_t)r * l->tx_row, (const uint8_t *)buffs[l->member[r]], n_el * l->elem_bytes);
-                in_rows[n_rows] = l->tx_d_in + (size_t)r * l->tx_row; out_rows[n_rows] = d_room; n_rows++;
+                l->fast[r] = 1;
+                pool_submit(&g->pool, h_in + (size_t)r * l->tx_row, (const uint8_t *)buffs[l->member[r]], n_el * l->elem_bytes);
                 if (lo < 0) lo = r;
                 hi = r;
             }
-            if (!n_rows) continue;
-            pool_drain(&g->pool);                              /* (the previous sub-batch is crossing PCIe meanwhile) */
-            hard = clhip_memcpy_h2d(l->tx_d_in + (size_t)lo * l->tx_row, l->tx_h_in + (size_t)lo * l->tx_row, (size_t)(hi - lo) * l->tx_row + n_el * l->elem_bytes, s_in) ||
-                   clhip_event_record(ev[0], s_in) || clhip_stream_wait_event(g->s_k, ev[0]) ||
-                   clhip_convert_pack_rows(in_rows, l->format, n_el, n_rows, mode, out_rows, g->s_k) ||
-                   clhip_event_record(ev[g->n_in + 1], g->s_k);
-            g->stats.launches++;
+            if (lo < 0) continue;
+            pool_drain(&g->pool);                              /* (the previous sub-batch is on its way meanwhile) */
+            hard = clhip_memcpy_h2d(d_in + (size_t)lo * l->tx_row, h_in + (size_t)lo * l->tx_row, (size_t)(hi - lo) * l->tx_row + n_el * l->elem_bytes, s_in) ||
+                   clhip_event_record(ev[0], s_in);
         }
     }
     clock_gettime(CLOCK_MONOTONIC, &t1);
-    /* ---- pass 2: as the sub-batches' launches end, their words are the FIFOs' */
-    for (int k = 0; k < g->n_lanes; k++) {
+    /* ---- B: the previous call's words are the FIFOs' */
+    tx_finish(g);
+    clock_gettime(CLOCK_MONOTONIC, &t2);
+    /* ---- C: room in the FIFOs behind them, the launches */
+    for (int k = 0; k < g->n_lanes && !hard; k++) {
         lane_t *l = &g->lane[k];
-        int sb = 0;
-        for (int a = 0; a < l->n; a += l->sub, sb++) {
+        if (l->route != ROUTE_TX_PLAIN || !l->queued) continue;
+        uint8_t *d_in = l->tx_d_in + (size_t)l->set * l->n * l->tx_row;
+        for (int a = 0; a < l->n && !hard; a += l->sub) {
             const int e = a + l->sub < l->n ? a + l->sub : l->n;
-            int any = 0;
-            for (int r = a; r < e; r++) any |= l->fast[r];
-            if (!any) continue;
-            const int arrived = sb < l->queued && !hard && clhip_event_sync(ev_of(g, l, 0, a)[g->n_in + 1]) == 0;
-            if (!arrived) hard = 1;
+            void **ev = ev_of(g, l, l->set, a);
+            const void *in_rows[CLHIP_PACK_ROWS]; uint8_t *out_rows[CLHIP_PACK_ROWS];
+            int n_rows = 0, mode = -1;
             for (int r = a; r < e; r++) {
                 if (!l->fast[r]) continue;
-                cl_device *dev = g->dev[l->member[r]];
-                cl_stream *st = dev->stream;
-                st->stats.write_calls++;
-                if (!arrived) { l->fast[r] = 2; st->stats.writes_empty++; continue; }     /* nothing was committed: the FIFO is as it was (a write error is 0 elements, :185-194) */
-                cl_smi_tx_commit(dev->smi, 4 * l->want);
-                if (l->format == CL_FORMAT_CS16) dev->smi->stat_written += l->want;          /* (caribou_smi_write counts; the conversions' callers do not) */
-                rets[l->member[r]] = (int)l->want;
-                st->stats.elements_written += l->want;
-                g->stats.batched_reads++;
+                cl_smi *smi = g->dev[l->member[r]]->smi;
+                /* caribou_smi_write's chunk loop appends native-batch pieces of one contiguous array (caribou_smi.c:738-759): the array,
+                 * packed into the room behind what the FIFO holds, committed once the launch is known to have run */
+                uint8_t *room = cl_smi_tx_reserve_raw(smi, 4 * l->want + 64);
+                uint8_t *d_room = room ? (uint8_t *)cl_fifo_device_ptr(&smi->tx, room) : NULL;
+                if (!d_room) { l->fast[r] = 0; continue; }        /* (through its own device, below) */
+                mode = smi->tx_mode;
+                in_rows[n_rows] = d_in + (size_t)r * l->tx_row; out_rows[n_rows] = d_room; n_rows++;
             }
+            if (!n_rows) continue;
+            hard = clhip_stream_wait_event(g->s_k, ev[0]) ||
+                   clhip_convert_pack_rows(in_rows, l->format, l->want, n_rows, mode, out_rows, g->s_k) ||
+                   clhip_event_record(ev[g->n_in + 1], g->s_k);
+            g->stats.launches++;
+        }
+        if (hard) break;
+        l->tx_pend_set = l->set; l->tx_pend_want = l->want;
+        for (int r = 0; r < l->n; r++) {
+            if (!l->fast[r]) continue;
+            cl_device *dev = g->dev[l->member[r]];
+            cl_stream *st = dev->stream;
+            l->tx_pend[r] = 1; g->tx_pending = 1;
+            rets[l->member[r]] = (int)l->want;
+            st->stats.write_calls++; st->stats.elements_written += l->want;
+            if (l->format == CL_FORMAT_CS16) dev->smi->stat_written += l->want;          /* (caribou_smi_write counts; the conversions' callers do not) */
+            g->stats.batched_reads++;
         }
     }
-    clock_gettime(CLOCK_MONOTONIC, &t2);
     if (hard) {
         for (int k = 0; k < g->n_in; k++) clhip_stream_sync(g->s_in[k]);
         clhip_stream_sync(g->s_k);
+        tx_finish(g);                                          /* (what was launched and told is waited for; what was not is not committed) */
         cl_seterr(g->err, sizeof g->err, "cl_group_writeStream: %s", clhip_last_error());
         g->stats.errors++;
+        pthread_mutex_unlock(&g->tx_mu);
         return -1;
     }
-    /* ---- pass 3: the members off the batched route, through their own devices */
+    /* ---- the members off the batched route, through their own devices (their seams settle the group first: order in the FIFOs) */
     for (int k = 0; k < g->n_lanes; k++) {
         lane_t *l = &g->lane[k];
         for (int r = 0; r < l->n; r++) {
@@ -1238,5 +1307,7 @@ int cl_group_writeStream(cl_group *g, const void *const *buffs, size_t numElems,
     g->stats.last_total_us = (uint64_t)((t3.tv_sec - t0.tv_sec) * 1000000L + (t3.tv_nsec - t0.tv_nsec) / 1000);
     int delivered = 0;
     for (size_t i = 0; i < g->n; i++) delivered += rets[i] > 0;
-    return delivered;
+    const int failed_before = g->stats.errors != errors_before;      /* (the previous call's launches: reported now) */
+    pthread_mutex_unlock(&g->tx_mu);
+    return failed_before ? -1 : delivered;
 }

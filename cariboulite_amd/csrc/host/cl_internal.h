@@ -105,6 +105,8 @@ struct cl_smi {
      * bytes of the FIFO.  Every entry of the seam's own readers gives them back first (cl_smi_foreign_cancel) and bumps the epoch, so that
      * the group can tell that its read-ahead is void */
     size_t foreign_ahead; unsigned foreign_epoch;
+    /* a TX stream group holds words of this seam in flight (write-behind): called before anything looks at or adds to the TX FIFO */
+    void (*tx_settle)(void *ctx, int member); void *tx_settle_ctx; int tx_settle_member;
     size_t ahead_bytes;          /* (atomic) what the consumer holds staged ahead, its own read-ahead + a group's: cl_smi_pending_bytes counts it, from any thread */
     int ra_pending; size_t ra_samples;     /* between cl_smi_ra_launch and cl_smi_ra_finish */
     size_t inplace_len;                    /* bytes of a one-read() call staged in place on `stream`: confirmed once that stream has been synchronised */
@@ -132,6 +134,7 @@ long cl_smi_ra_launch(cl_smi *dev, int channel, size_t length_samples, int16_t *
 int cl_smi_ra_finish(cl_smi *dev);                                                      /* work on the seam's stream in between */
 void cl_smi_readahead_cancel(cl_smi *dev);
 void cl_smi_foreign_cancel(cl_smi *dev);
+uint8_t *cl_smi_tx_reserve_raw(cl_smi *dev, size_t n);   /* cl_smi_tx_reserve without the call-back (the group's own reservation) */
 void cl_smi_ahead_note(cl_smi *dev);     /* after every change of ahead / foreign_ahead */                 /* a group's read-ahead on this seam is given back (pending again) */
 int cl_smi_head_in_sync(const uint8_t *chunk, size_t len);   /* offs == 0 decided on the host from the staged bytes */
 /* poll(POLLIN, timeout) on the injected byte stream: returns 1 when bytes are pending (at once or within timeout_us) */

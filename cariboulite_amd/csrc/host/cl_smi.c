@@ -302,8 +302,23 @@ void   cl_smi_set_max_read(cl_smi *dev, size_t m) { dev->max_read = m; }
 /* The TX FIFO has one producer (the write calls: reserve, fill by DMA or kernel, commit) and one consumer (the drain calls),
  * which may be two threads: its bookkeeping moves under fifo_mu; the bytes of an open reservation lie behind everything a pop
  * can touch, and only the producer's reserve ever moves the buffer. */
+uint8_t *cl_smi_tx_reserve_raw(cl_smi *dev, size_t n)
+{
+    pthread_mutex_lock(&dev->fifo_mu);
+    uint8_t *room = cl_fifo_reserve(&dev->tx, n);
+    pthread_mutex_unlock(&dev->fifo_mu);
+    return room;
+}
+/* (a stream group may have words of this seam in flight -- launched over, not committed: it lands them before anybody else looks at
+ * or adds to the TX FIFO) */
+static void tx_settle(cl_smi *dev)
+{
+    void (*fn)(void *, int) = dev->tx_settle;
+    if (fn) fn(dev->tx_settle_ctx, dev->tx_settle_member);
+}
 uint8_t *cl_smi_tx_reserve(cl_smi *dev, size_t n)
 {
+    tx_settle(dev);
     pthread_mutex_lock(&dev->fifo_mu);
     uint8_t *room = cl_fifo_reserve(&dev->tx, n);
     pthread_mutex_unlock(&dev->fifo_mu);
@@ -317,6 +332,7 @@ void cl_smi_tx_commit(cl_smi *dev, size_t n)
 }
 static size_t tx_pop(cl_smi *dev, uint8_t *b, size_t max)
 {
+    tx_settle(dev);
     pthread_mutex_lock(&dev->fifo_mu);
     const size_t n = cl_fifo_pop(&dev->tx, b, max);
     pthread_mutex_unlock(&dev->fifo_mu);

@@ -626,8 +626,12 @@ int         cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems
  * words are in its TX FIFO behind what it held (Stream::WriteSamplesGen, CaribouliteStream.cpp:199-258, over caribou_smi_write,
  * caribou_smi.c:720-762).  Members without a modulator share launches of up to eight streams (conversion + caribou_smi_generate_data,
  * words stored straight into the room reserved in each pinned FIFO) while the next sub-batch's samples are copied in; a member with
- * MOD / RESAMP kwargs, or a CS16 call above one MTU, takes its own device's writeStream inside the call.  Returns the number of
- * members that consumed elements, or -1 (cl_group_last_error).  cl_group_getStats: batched_reads / single_reads count the writes. */
+ * MOD / RESAMP kwargs, or a CS16 call above one MTU, takes its own device's writeStream inside the call.  The call returns with the
+ * launches queued (write-behind by one call); the members' seams land what is in flight before anything looks at or adds to a TX
+ * FIFO (cl_smi_drain_bytes / _drain_to_fd from any thread, cl_writeStream on a member), so the words are there for whoever asks.  A
+ * runtime error of launches already reported as consumed is returned by the NEXT call.  No thread may be draining a member while the
+ * group is unmade.  Returns the number of members that consumed elements, or -1 (cl_group_last_error).  cl_group_getStats:
+ * batched_reads / single_reads count the writes. */
 int         cl_group_writeStream(cl_group *g, const void *const *buffs, size_t numElems, int *rets, long timeoutUs);
 const char *cl_group_last_error(const cl_group *g);
 void        cl_group_getStats(const cl_group *g, cl_group_stats *out);
