@@ -81,7 +81,7 @@ def build_host(force=False, verbose=False):
     if not srcs:
         return None
     deps = srcs + [os.path.join(INC, "cariboulite_hip.h")] + \
-        [os.path.join(hdir, f) for f in os.listdir(hdir) if f.endswith(".h")]
+        [os.path.join(hdir, f) for f in os.listdir(hdir) if f.endswith((".h", ".inc"))]
     if force or _newer(HOST_LIB, deps + [HIP_LIB]):
         cmd = ["gcc", "-O2", "-g", "-std=gnu11", "-Wall", "-Wextra", "-fPIC", "-shared", "-I", INC,
                "-o", HOST_LIB] + srcs + ["-L", PKG, "-lcariboulite_hip", "-Wl,-rpath,$ORIGIN", "-lm", "-lpthread"]

@@ -25,7 +25,10 @@
  * State: a lane of the group (members with one channel type and one stream configuration) owns ONE n-stream RX pipe whose
  * streams advance independently (clhip_rx_pipe_epoch_begin / _run_range / _epoch_end); formats without extension stages
  * are stateless behind the unpack.  What the single-stream route keeps for the reference's "untouched slots" (the
- * persistent native buffer) is rebuilt lazily from the previous call's raw words when a member leaves the batched route. */
+ * persistent native buffer) is rebuilt lazily from the previous call's raw words when a member leaves the batched route.
+ *
+ * This file: types, the copy threads, make / unmake, registered buffers.  cl_group_rx.inc: cl_group_readStream.  cl_group_tx.inc:
+ * cl_group_writeStream (a group of TX devices).  One translation unit. */
 #include <immintrin.h>
 #include <time.h>
 #include <unistd.h>
@@ -568,746 +571,6 @@ static int registered(const cl_group *g, int m, const void *p, size_t bytes)
     return 0;
 }
 
-/* ------------------------------------------------------------------------------------------- the call */
-/* Does member m's next read() qualify for the batched route?  Under its FIFO lock: `want` bytes pending as ONE in-place read()
- * whose head carries the sync pattern (caribou_smi_find_buffer_offset returns 0 exactly then, caribou_smi.c:235-292 -- the
- * bytes are in pinned host memory, so the host knows before the device has looked); they are staged and their copy to the
- * lane's row is queued while they cannot move.  Everything else -- short, ragged or slipped reads, bytes given back earlier,
- * reader threads, the IIR, debug modes -- is the single-stream route's business. */
-/* ---- the reference's low-pass over whole sub-batches ----
- * Stream::ReadSamples(int16*) (CaribouliteStream.cpp:282-301) runs the selected Butterworth over every sample of the read on the
- * client's thread; a sub-batch whose members all have the SAME filter selected and are all in sync goes through ONE multi-stream filter
- * launch fed from the raw words (clhip_iir_run_smi).  The carried state of a member's three filters persists for the life of its
- * Stream and is not reset when the selection changes (:84-91,127-141): it is moved, not copied -- into the group's object when the
- * member first takes the batched filter route, back into the stream's own object the moment that object is about to be used
- * (cl_soapy.c: filter_source calls iir_home) or the group goes. */
-static int giir_index(const lane_t *l, int row, int ft) { return (ft - 1) * l->n_subs + row / l->sub; }
-
-/* a filter launch made ahead over sub-batch `sb` is given up: waited for, its object's state put back, its rows' results forgotten
- * (what was READ ahead stands: the rows are launched over in the call) */
-static void giir_ahead_drop(cl_group *g, lane_t *l, int sb)
-{
-    if (!l->ahead_ft || !l->ahead_ft[sb]) return;
-    g->stale = 1; settle(g);
-    clhip_iir_unrun(l->giir[(l->ahead_ft[sb] - 1) * l->n_subs + sb]);
-    l->ahead_ft[sb] = 0;
-    const int a = sb * l->sub, e = a + l->sub < l->n ? a + l->sub : l->n;
-    for (int r = a; r < e; r++) l->done_ahead[r] = 0;
-}
-
-static void iir_home(void *ctx, int member)
-{
-    cl_group *g = (cl_group *)ctx;
-    lane_t *l = &g->lane[g->lane_of[member]];
-    const int row = g->row_of[member];
-    if (!l->iir_own) return;
-    giir_ahead_drop(g, l, row / l->sub);                       /* (a filter launch made ahead has advanced the state: taken back first) */
-    for (int ft = 1; ft <= 3; ft++) {
-        if (!l->iir_own[3 * row + ft - 1]) continue;
-        clhip_iir *obj = l->giir[giir_index(l, row, ft)];
-        const int a = row / l->sub * l->sub, cnt = (a + l->sub < l->n ? a + l->sub : l->n) - a;
-        double *st = (double *)malloc(sizeof(double) * 16 * (size_t)cnt);
-        if (st && obj && clhip_iir_get_state(obj, st) == 0) clhip_iir_set_state(g->dev[member]->stream->iir[ft - 1], st + 16 * (row - a));
-        free(st);
-        l->iir_own[3 * row + ft - 1] = 0;
-    }
-}
-
-/* the filter object of sub-batch [a, e) for filter `ft`, holding the carried state of all its members (NULL: a runtime error) */
-static clhip_iir *giir_get(cl_group *g, lane_t *l, int a, int e, int ft)
-{
-    clhip_iir **slot = &l->giir[giir_index(l, a, ft)];
-    if (!*slot) {
-        *slot = clhip_iir_create(g->dev[l->member[a]]->stream->sos[ft - 1], 3, e - a);
-        if (!*slot) return NULL;
-        if (g->iir_polls_set) clhip_iir_set_poll_bound(*slot, g->iir_polls);
-    }
-    int need = 0;
-    for (int r = a; r < e; r++) need |= !l->iir_own[3 * r + ft - 1];
-    if (need) {
-        double *st = (double *)malloc(sizeof(double) * 16 * (size_t)(e - a));
-        if (!st || clhip_iir_get_state(*slot, st)) { free(st); return NULL; }
-        for (int r = a; r < e; r++) {
-            if (l->iir_own[3 * r + ft - 1]) continue;
-            if (clhip_iir_get_state(g->dev[l->member[r]]->stream->iir[ft - 1], st + 16 * (r - a))) { free(st); return NULL; }
-            l->iir_own[3 * r + ft - 1] = 1;
-        }
-        const int bad = clhip_iir_set_state(*slot, st);
-        free(st);
-        if (bad) return NULL;
-    }
-    return *slot;
-}
-
-void cl_group_set_iir_poll_bound(cl_group *g, int polls)
-{
-    if (!g) return;
-    g->iir_polls = polls; g->iir_polls_set = 1;
-    for (int k = 0; k < g->n_lanes; k++)
-        for (int i = 0; g->lane[k].giir && i < 3 * g->lane[k].n_subs; i++) clhip_iir_set_poll_bound(g->lane[k].giir[i], polls);
-}
-
-/* the filter launch(es) of sub-batch [a, e): raw words in `in` rows -> filtered samples in the lane's format in `outb` rows (the mapped
- * mirror); redo = the scan path after an overrun (or an object that is on it): unpack, filter, convert */
-static int giir_launch(cl_group *g, lane_t *l, clhip_iir *obj, int a, int e, size_t want, uint8_t *in, uint8_t *outb, int offs_table)
-{
-    const size_t n = want / 4, stride = l->out_stride;
-    int16_t *mirror16 = (int16_t *)(outb + (size_t)a * stride * l->elem_bytes), *f16 = l->d_f + 2 * (size_t)a * stride;
-    int16_t *dst = l->format == CL_FORMAT_CS16 ? mirror16 : f16;
-    int rc = clhip_iir_run_smi(obj, l->channel, in + (size_t)a * l->in_stride, dst, stride, n, g->s_k);
-    if (rc == -2) {
-        for (int r = a; r < e; r++) l->h_offs[offs_table][r] = 0;
-        rc = clhip_smi_unpack(l->channel, in + (size_t)a * l->in_stride, (size_t)(e - a - 1) * l->in_stride + want, l->in_stride, want, e - a,
-                              l->d_offs[offs_table] + a, CL_FORMAT_CS16, f16, NULL, g->s_k) ||
-             clhip_iir_run(obj, f16, dst, stride, n, g->s_k);
-    }
-    if (rc) return -1;
-    g->stats.launches++;
-    if (dst == f16) return clhip_convert_from_cs16(f16, (size_t)(e - a - 1) * stride + n, l->format, outb + (size_t)a * stride * l->elem_bytes, g->s_k);
-    return 0;
-}
-
-/* The verdict of the filter launch over THIS call's batch of sub-batch [a, e) (clhip_iir_status behind its event): a single-pass launch
- * that gave up has its state back where it was and the object on its scan path -- the sub-batch is filtered again, once, here
- * (CaribouliteStream.cpp has no such case: its loop cannot fail; a second failure delivers 0 elements like any read error,
- * :266-276).  Asked once per call -- before the object is launched over the NEXT batch (one call in flight per object: a launch
- * behind one that gave up would start from its garbage), or when the sub-batch's rows are handed out.  1 / 2 / 3 as sub_verdict. */
-static int giir_verdict(cl_group *g, lane_t *l, int a, int e)
-{
-    const int sb = a / l->sub;
-    if (l->sub_verdict[sb]) return l->sub_verdict[sb];
-    int v = 1;
-    if (clhip_event_sync(ev_of(g, l, l->set, a)[g->n_in + 1])) v = 3;
-    else {
-        clhip_iir *obj = l->giir[giir_index(l, a, l->sub_ft[sb])];
-        if (clhip_iir_status(obj)) {
-            for (int r = a; r < e; r++) g->dev[l->member[r]]->stream->stats.iir_overruns++;
-            if (giir_launch(g, l, obj, a, e, l->want, l->d_in[l->cur_in], l->m_out[l->cur_m], 2 * l->set + 1) || clhip_stream_sync(g->s_k)) v = 3;
-            else if (clhip_iir_status(obj)) v = 2;
-        }
-    }
-    return l->sub_verdict[sb] = (uint8_t)v;
-}
-
-/* may member `row` take the batched route at all in this call? */
-static int qualifies(const cl_group *g, const lane_t *l, int row, size_t want, int allow_filter)
-{
-    const cl_device *dev = g->dev[l->member[row]];
-    const cl_stream *st = dev->stream;
-    const cl_smi *smi = dev->smi;
-    if (st->use_async || (st->filter_type != CL_DIGFILT_NONE && !allow_filter) || smi->debug_mode != CL_SMI_DEBUG_NONE || st->native_dir != CL_SOAPY_SDR_RX) return 0;
-    if (st->format != l->format || !want || (want & 15) || want > smi->native_batch_len || (smi->max_read && smi->max_read < want)) return 0;
-    return 1;
-}
-
-/* stage member `row`'s next `want` pending bytes in place if they are one in-sync batch: l->src[row] says where they lie.  Returns 1
- * with the member's FIFO lock HELD -- the bytes must not move before the copy that reads them is queued (copies_queue releases it) */
-static int stage_row(cl_group *g, lane_t *l, int row, size_t want, void *s_in, int slot)
-{
-    cl_smi *smi = g->dev[l->member[row]]->smi;
-    uint8_t *src = NULL;
-    l->src[row] = NULL;
-    pthread_mutex_lock(&smi->fifo_mu);
-    if (!cl_fifo_front_len(&smi->rx) && smi->rx.len >= want) {
-        smi->rx.dma_stream[slot] = s_in;                       /* a feeder that has to move the buffer waits for this copy first */
-        const size_t got = cl_fifo_stage(&smi->rx, want, &src);
-        if (got == want && cl_smi_head_in_sync(src, got)) { l->src[row] = src; return 1; }
-        if (got) cl_fifo_unstage(&smi->rx, got);
-    }
-    pthread_mutex_unlock(&smi->fifo_mu);
-    return 0;
-}
-
-static int on_phase_0(const lane_t *l, int row)
-{
-    /* (off polyphase phase 0 the pipe runs its generic kernels: such streams go one by one) */
-    return l->route != ROUTE_PIPE || clhip_rx_pipe_stream_total(l->pipe, row) % (2ull * (unsigned long long)l->down) == 0;
-}
-
-/* 3 = the previous call read this batch ahead AND launched over it: its results are in the current mirror (or on their way);
- * 2 = the previous call read it ahead (staged in the FIFO, copied to d_in[cur_in]): to be launched over;
- * 1 = staged now, its copy still to be queued (FIFO lock held); 0 = not on the batched route in this call */
-static int try_stage(cl_group *g, lane_t *l, int row, size_t want, void *s_in, int allow_filter)
-{
-    cl_smi *smi = g->dev[l->member[row]]->smi;
-    if (l->primed[row]) {
-        const int intact = smi->foreign_ahead == l->primed[row] && smi->foreign_epoch == l->primed_epoch[row];
-        const size_t had = l->primed[row];
-        const int was_done = l->done_ahead[row];
-        l->primed[row] = 0; l->done_ahead[row] = 0; l->src[row] = NULL;
-        /* (a run made ahead has advanced the stream's counter already: its phase was checked when it was made) */
-        if (intact && had == want && qualifies(g, l, row, want, allow_filter) && (was_done || on_phase_0(l, row))) {
-            smi->foreign_ahead = 0;                            /* this call's batch now: staged, the oldest unconfirmed bytes */
-            cl_smi_ahead_note(smi);
-            if (was_done && allow_filter && !(l->ahead_ft && l->ahead_ft[row / l->sub])) { g->stale = 1; settle(g); return 2; }   /* (computed ahead WITHOUT the low-pass that has been selected since: only the input stands) */
-            return was_done ? 3 : 2;
-        }
-        if (intact) cl_smi_foreign_cancel(smi);                 /* another length, or off the batched route: pending again, in order */
-        if (was_done && l->pipe) clhip_rx_pipe_unrun_stream(l->pipe, row, had / 4);
-        g->stale = 1;
-        settle(g);
-    }
-    l->src[row] = NULL;
-    if (!qualifies(g, l, row, want, allow_filter) || !on_phase_0(l, row)) return 0;
-    cl_smi_readahead_cancel(smi);                              /* what a single-stream call staged ahead is pending again */
-    return stage_row(g, l, row, want, s_in, 1);
-}
-
-/* Queue the copies in of the staged rows [a, e) and let their FIFOs go again.  Neighbouring rows whose batches lie one slab slice
- * apart (members that are fed and read in step, the normal case) travel as ONE 2-D copy; any other row by a copy of its own.  A row
- * whose copy cannot be queued is unstaged and leaves the batched route.  Returns 0, or -1 on a runtime error. */
-static int copies_queue(cl_group *g, lane_t *l, uint8_t *d_buf, int a, int e, size_t want, void *s_in)
-{
-    int rc = 0, r = a;
-    while (r < e) {
-        if (!l->fast[r] || !l->src[r]) { r++; continue; }     /* (not batched, or read ahead by the call before) */
-        int r1 = r + 1;
-        while (g->slab && r1 < e && l->fast[r1] && l->src[r1] && l->src[r1] == l->src[r] + (size_t)(r1 - r) * g->slab_slice) r1++;
-        uint8_t *dst = d_buf + (size_t)r * l->in_stride;
-        const int bad = r1 - r > 1 ? clhip_memcpy2d_h2d(dst, l->in_stride, l->src[r], g->slab_slice, want, (size_t)(r1 - r), s_in)
-                                   : clhip_memcpy_h2d(dst, l->src[r], want, s_in);
-        if (r1 - r > 1) g->stats.copies_2d++;
-        for (int q = r; q < r1; q++) {
-            cl_smi *smi = g->dev[l->member[q]]->smi;
-            if (bad) { cl_fifo_unstage(&smi->rx, want); l->fast[q] = 0; rc = -1; }
-            pthread_mutex_unlock(&smi->fifo_mu);
-        }
-        r = r1;
-    }
-    return rc;
-}
-
-static void confirm_staged(cl_smi *smi, size_t n)
-{
-    pthread_mutex_lock(&smi->fifo_mu);
-    cl_fifo_confirm(&smi->rx, n);
-    pthread_mutex_unlock(&smi->fifo_mu);
-}
-
-static void count_read(cl_stream *st, int ret)
-{
-    st->stats.read_calls++;
-    if (ret > 0) st->stats.elements_read += (uint64_t)ret; else if (ret == 0) st->stats.reads_empty++;
-}
-
-/* A member off the batched route: its own device's single-stream call, with the group's pipe slot standing where the
- * device's own pipe would.  (What a re-sync finds in the slots it leaves untouched -- the reference's interm_native_buffer,
- * caribou_smi.c:382-389, CaribouliteStream.cpp:304-367 -- is the seam's business: the batched route leaves it the raw words of
- * the member's last batch, pass 3.) */
-static int single_member(cl_group *g, lane_t *l, int row, void *out, size_t numElems, long timeoutUs)
-{
-    const int m = l->member[row];
-    cl_device *dev = g->dev[m];
-    cl_stream *st = dev->stream;
-    g->stats.single_reads++;
-    if (l->route == ROUTE_PLAIN || st->format != l->format || st->native_dir != CL_SOAPY_SDR_RX) {
-        /* queued only: the caller runs every such member's first half before the first second half (cl_stream_read_end) */
-        cl_stream_read_begin(dev, st, out, numElems, timeoutUs, &l->ctx[row]);
-        return -1000;
-    }
-    /* pipe lane: Stream::Read (+ the low-pass) leaves the native samples on the device, the group's pipe slot runs from them */
-    if (numElems > st->mtu_size) numElems = st->mtu_size;                        /* CaribouliteStream.cpp:306,328,351 */
-    const int16_t *d_iq = NULL;
-    const int res = cl_stream_read_native(dev, st, numElems, timeoutUs, &d_iq);
-    if (res <= 0 || !d_iq) return 0;
-    uint8_t *d_row = l->d_out + (size_t)row * l->out_stride * l->elem_bytes, *h_row = l->h_out[l->cur_m] + (size_t)row * l->out_stride * l->elem_bytes;
-    const long got = clhip_rx_pipe_run_range(l->pipe, row, 1, CL_PIPE_IN_CS16, d_iq, 0, (size_t)res, d_row, 0, g->s_k);
-    if (got < 0) { cl_seterr(g->err, sizeof g->err, "cl_group_readStream: %s", clhip_last_error()); return 0; }
-    if (got == 0) return 0;
-    const size_t bytes = (size_t)got * l->elem_bytes;
-    if (registered(g, m, out, bytes)) {
-        if (clhip_memcpy_d2h(out, d_row, bytes, g->s_k) || clhip_stream_sync(g->s_k)) return 0;
-    } else {
-        if (clhip_memcpy_d2h(h_row, d_row, bytes, g->s_k) || clhip_stream_sync(g->s_k)) return 0;
-        memcpy(out, h_row, bytes);
-    }
-    return (int)got;
-}
-
-static void **ev_of(const cl_group *g, const lane_t *l, int set, int a)
-{
-    return g->ev + ((size_t)set * g->n_sub + l->sub0 + (size_t)(a / l->sub)) * (size_t)g->ev_per;
-}
-
-/* The launches of one sub-batch over the rows [a, e) marked in `run` (maximal runs of neighbours: one fused launch each / one unpack
- * launch with the other rows masked), from the raw words in `in` into `outb` (both row-strided); got[r] = elements per marked row. */
-static int launch_rows(cl_group *g, lane_t *l, int a, int e, const uint8_t *run, size_t want, uint8_t *in, uint8_t *outb, int offs_table, long *got)
-{
-    if (l->route == ROUTE_PIPE) {
-        int r = a;
-        while (r < e) {
-            if (!run[r]) { r++; continue; }
-            int r1 = r + 1;
-            while (r1 < e && run[r1]) r1++;
-            const long n = clhip_rx_pipe_run_range(l->pipe, r, r1 - r, CL_PIPE_IN_SMI_WORDS, in + (size_t)r * l->in_stride, l->in_stride / 4, want / 4,
-                                                   outb + (size_t)r * l->out_stride * l->elem_bytes, l->out_stride, g->s_k);
-            if (n < 0) return -1;
-            for (int q = r; q < r1; q++) got[q] = n;
-            g->stats.launches++;
-            r = r1;
-        }
-        return 0;
-    }
-    /* caribou_smi_rx_data_analyze at offset 0 + the format conversion, one launch over the sub-batch's rows (a row that is not
-     * marked has offset -1: the kernel writes nothing for it) */
-    int any = 0;
-    for (int r = a; r < e; r++) { l->h_offs[offs_table][r] = run[r] ? 0 : -1; if (run[r]) { got[r] = (long)(want / 4); any = 1; } }
-    if (!any) return 0;
-    g->stats.launches++;
-    return clhip_smi_unpack(l->channel, in + (size_t)a * l->in_stride, (size_t)(e - a - 1) * l->in_stride + want, l->in_stride, want, e - a,
-                            l->d_offs[offs_table] + a, l->format, outb + (size_t)a * l->out_stride * l->elem_bytes, NULL, g->s_k);
-}
-
-int cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems, int *rets, long timeoutUs)
-{
-    if (!g || !buffs || !rets) return -1;
-    if (g->dir != CL_SOAPY_SDR_RX) { cl_seterr(g->err, sizeof g->err, "cl_group_readStream: the group's devices are set up for TX"); return -1; }
-    clhip_set_device(g->device);
-    g->err[0] = 0;
-    g->stats.calls++;
-    for (size_t i = 0; i < g->n; i++) rets[i] = 0;
-    if (!numElems) return 0;
-    for (int k = 0; k < g->n_lanes; k++) { memset(g->lane[k].fast, 0, (size_t)g->lane[k].n); g->lane[k].queued = 0; }
-    int hard = 0;
-    struct timespec t0, t1, t2, t3;
-    clock_gettime(CLOCK_MONOTONIC, &t0);
-    /* ---- pass 1: what the previous call did not do ahead -- stage, copy in, launch, copy out: everything queued, nothing waited for */
-    for (int k = 0; k < g->n_lanes && !hard; k++) {
-        lane_t *l = &g->lane[k];
-        const size_t mtu = CL_NATIVE_MTU_SAMPLES;
-        /* CS16 is not clamped to the MTU by the reference (CaribouliteStream.cpp:282-301): longer calls are chunk loops, one by one */
-        const size_t n_el = l->format == CL_FORMAT_CS16 && l->route == ROUTE_PLAIN ? numElems : (numElems > mtu ? mtu : numElems);
-        const size_t want = n_el <= mtu ? n_el * 4 : 0;
-        { const int p = l->prev_in; l->prev_in = l->cur_in; l->cur_in = l->next_in; l->next_in = p; }   /* what was read ahead is this call's input */
-        if (g->readahead == 2) { l->cur_m ^= 1; l->set ^= 1; }   /* ... and what was computed ahead went to this mirror, behind these events */
-        l->want = want;
-        if (l->pipe && !l->epoch_open && clhip_rx_pipe_epoch_begin(l->pipe)) { hard = 1; break; }
-        l->epoch_open = 1;
-        int waits_primed = 0;
-        uint8_t *in = l->d_in[l->cur_in];
-        for (int a = 0; a < l->n && !hard; a += l->sub) {
-            const int e = a + l->sub < l->n ? a + l->sub : l->n;
-            void **ev_in = ev_of(g, l, l->set, a), *ev_k = ev_in[g->n_in], *ev_out = ev_in[g->n_in + 1];
-            const size_t b = l->sub0 + (size_t)(a / l->sub);
-            void *s_in = g->s_in[b % (size_t)g->n_in];          /* the sub-batches take turns on the ingest streams */
-            int from_ahead = 0, any_run = 0, any_copy = 0;
-            l->queued++;
-            /* the sub-batch's low-pass: the same one selected on every member (and no registered buffers: the mirror route) -> one filter
-             * launch over the sub-batch; members with a filter in a mixed sub-batch go through their own devices */
-            int ft = 0;
-            if (l->route == ROUTE_PLAIN && g->sink_mapped) {
-                ft = g->dev[l->member[a]]->stream->filter_type;
-                for (int r = a; r < e; r++)
-                    if (g->dev[l->member[r]]->stream->filter_type != ft || g->has_reg[l->member[r]]) ft = 0;
-            }
-            if (l->sub_ft) { l->sub_ft[a / l->sub] = 0; l->sub_verdict[a / l->sub] = 0; }
-            for (int r = a; r < e; r++) {
-                const int how = try_stage(g, l, r, want, s_in, ft > 0);
-                l->how[r] = (uint8_t)how;
-                l->fast[r] = (uint8_t)(how != 0);
-                l->ahead_mark[r] = (uint8_t)(how == 1 || how == 2);      /* (here: rows to launch over in this call) */
-                from_ahead |= how == 2;
-                g->stats.ahead_reads += how >= 2;
-                l->got[r] = how == 3 ? l->ahead_got[r] : 0;
-                l->direct[r] = 0;
-            }
-            int filtered_ahead = 0;
-            if (l->ahead_ft && l->ahead_ft[a / l->sub]) {
-                /* the previous call filtered this sub-batch ahead: good for this call if the same filter is still selected on everybody and
-                 * every row's batch is still the one it read ahead -- otherwise the launch is taken back (the state it advanced), the rows
-                 * that are still theirs keep their input */
-                int all3 = ft == l->ahead_ft[a / l->sub];
-                for (int r = a; r < e; r++) all3 &= l->how[r] == 3;
-                if (all3) { filtered_ahead = 1; l->ahead_ft[a / l->sub] = 0; }
-                else {
-                    giir_ahead_drop(g, l, a / l->sub);
-                    for (int r = a; r < e; r++)
-                        if (l->how[r] == 3) { l->how[r] = 2; l->ahead_mark[r] = 1; l->got[r] = 0; from_ahead = 1; }
-                }
-            }
-            if (ft > 0 && !filtered_ahead) {                   /* all of them or none: a member that is short, out of sync or off the route sends everybody home */
-                int all = 1;
-                for (int r = a; r < e; r++) all &= l->how[r] == 1 || l->how[r] == 2;
-                if (!all) {
-                    for (int r = a; r < e; r++) {
-                        if (!l->fast[r]) continue;
-                        cl_smi *smi = g->dev[l->member[r]]->smi;
-                        if (l->how[r] != 1) pthread_mutex_lock(&smi->fifo_mu);       /* (staged just now: the lock is still held) */
-                        cl_fifo_unstage(&smi->rx, want);
-                        pthread_mutex_unlock(&smi->fifo_mu);
-                        l->fast[r] = 0; l->ahead_mark[r] = 0; l->src[r] = NULL;
-                    }
-                    ft = 0;
-                }
-            }
-            if (copies_queue(g, l, in, a, e, want, s_in)) hard = 1;     /* (a row whose copy cannot be queued leaves the batched route: fast = 0) */
-            if (ft > 0) for (int r = a; r < e; r++) if (!l->fast[r]) hard = 1;   /* (a copy that could not be queued inside a filter sub-batch: a runtime error) */
-            if (filtered_ahead) l->sub_ft[a / l->sub] = (uint8_t)ft;                /* (nothing to launch; its verdict is asked with the others', pass 3) */
-            for (int r = a; r < e; r++) {
-                l->ahead_mark[r] = (uint8_t)(l->ahead_mark[r] && l->fast[r]);
-                l->len[r] = l->fast[r] ? want : 0;
-                any_run |= l->ahead_mark[r];
-                any_copy |= l->ahead_mark[r] && l->src[r] != NULL;
-            }
-            if (!any_run) continue;                            /* nothing to launch: the results are there (behind the event the previous call recorded), or there are none */
-            if (from_ahead && !waits_primed) { hard = hard || clhip_stream_wait_event(g->s_k, l->ev_primed); waits_primed = 1; }
-            if (any_copy && !hard) hard = clhip_event_record(ev_in[0], s_in) || clhip_stream_wait_event(g->s_k, ev_in[0]);
-            /* where the sub-batch's launch stores: the mapped pinned mirror itself (its stores cross PCIe as the kernel produces them --
-             * no second hop, no copy-engine call: tools/microbench/pcie_duplex.hip) unless one of its rows has a registered client
-             * buffer, which the copy engine fills from the device buffer */
-            int mapped = g->sink_mapped;
-            for (int r = a; r < e && mapped; r++)
-                if (l->fast[r] && g->has_reg[l->member[r]]) mapped = 0;
-            uint8_t *outb = mapped ? l->m_out[l->cur_m] : l->d_out;
-            if (!hard && ft > 0) {
-                clhip_iir *obj = giir_get(g, l, a, e, ft);
-                if (!obj || giir_launch(g, l, obj, a, e, want, in, outb, 2 * l->set + 1)) hard = 1;
-                for (int r = a; r < e; r++) l->got[r] = (long)(want / 4);
-                l->sub_ft[a / l->sub] = (uint8_t)ft;
-            } else
-            if (!hard && launch_rows(g, l, a, e, l->ahead_mark, want, in, outb, 2 * l->set + 1, l->got)) hard = 1;
-            if (mapped) { hard = hard || clhip_event_record(ev_out, g->s_k); continue; }     /* "arrived" = the launch has ended */
-            hard = hard || clhip_event_record(ev_k, g->s_k) || clhip_stream_wait_event(g->s_out, ev_k);
-            /* out: rows whose client buffer is registered leave for it directly; the others in blocks of neighbours into the mirror */
-            for (int r = a; r < e && !hard; ) {
-                if (!l->ahead_mark[r] || l->got[r] <= 0) { r++; continue; }
-                const size_t bytes = (size_t)l->got[r] * l->elem_bytes;
-                if (registered(g, l->member[r], buffs[l->member[r]], bytes)) {
-                    hard = clhip_memcpy_d2h(buffs[l->member[r]], l->d_out + (size_t)r * l->out_stride * l->elem_bytes, bytes, g->s_out);
-                    l->direct[r] = 1; r++;
-                    continue;
-                }
-                int hi = r;
-                while (hi + 1 < e && l->ahead_mark[hi + 1] && l->got[hi + 1] > 0 &&
-                       !registered(g, l->member[hi + 1], buffs[l->member[hi + 1]], (size_t)l->got[hi + 1] * l->elem_bytes)) hi++;
-                const size_t o = (size_t)r * l->out_stride * l->elem_bytes;
-                hard = clhip_memcpy_d2h(l->h_out[l->cur_m] + o, l->d_out + o, (size_t)(hi - r) * l->out_stride * l->elem_bytes + (size_t)l->got[hi] * l->elem_bytes, g->s_out);
-                r = hi + 1;
-            }
-            hard = hard || clhip_event_record(ev_out, g->s_out);
-        }
-    }
-    /* ---- pass 2: the members off the batched route, one by one, through their own devices; then the pipes' epochs end */
-    for (int k = 0; k < g->n_lanes; k++) {
-        lane_t *l = &g->lane[k];
-        if (!l->queued) continue;                              /* (a runtime error before this lane's turn: its state stands) */
-        for (int r = 0; r < l->n; r++) {                      /* first halves: everything queued on the members' own streams, nothing waited for */
-            if (l->fast[r]) continue;
-            const int m = l->member[r];
-            rets[m] = hard ? 0 : single_member(g, l, r, buffs[m], numElems, timeoutUs);
-        }
-        for (int r = 0; r < l->n; r++) {                      /* second halves: synchronise, verdicts, deliver */
-            if (l->fast[r]) continue;
-            const int m = l->member[r];
-            if (rets[m] == -1000) rets[m] = cl_stream_read_end(g->dev[m], g->dev[m]->stream, &l->ctx[r]);
-            count_read(g->dev[m]->stream, rets[m]);
-        }
-        if (l->pipe && l->epoch_open && clhip_rx_pipe_epoch_end(l->pipe, g->s_k)) hard = 1;
-        l->epoch_open = 0;
-    }
-    /* ---- ahead: before this call waits for its own results, the NEXT call's batches of the rows on the batched route -- staged in the
-     * members' FIFOs (the newest staged bytes: cl_smi_foreign_cancel gives them back if anybody else reads that seam first), copied to
-     * d_in[next_in], whole lanes at a time where the members are in step, and (READAHEAD=2) launched over into the other mirror: the
-     * GPU goes on while the host hands this call's results out, and the next call finds its own computed. */
-    for (int k = 0; g->readahead && k < g->n_lanes && !hard; k++) {
-        lane_t *l = &g->lane[k];
-        void *s_p = g->s_in[(size_t)k % (size_t)g->n_in];
-        int any = 0;
-        if (!l->queued || !l->want) continue;
-        uint8_t *keep_fast = l->fast;                          /* (copies_queue walks l->fast: the rows staged ahead, for the moment) */
-        l->fast = l->ahead_mark;
-        for (int r = 0; r < l->n; r++) {
-            l->ahead_mark[r] = keep_fast[r] && qualifies(g, l, r, l->want, l->route == ROUTE_PLAIN) && stage_row(g, l, r, l->want, s_p, 2) ? 1 : 0;
-            any |= l->ahead_mark[r];
-        }
-        if (any && copies_queue(g, l, l->d_in[l->next_in], 0, l->n, l->want, s_p)) hard = 1;
-        l->fast = keep_fast;
-        if (!any) continue;
-        for (int r = 0; r < l->n; r++) {
-            if (!l->ahead_mark[r]) continue;                  /* (a row whose copy could not be queued was unstaged and unmarked) */
-            cl_smi *smi = g->dev[l->member[r]]->smi;
-            smi->foreign_ahead = l->want; cl_smi_ahead_note(smi);
-            l->primed[r] = l->want; l->primed_epoch[r] = smi->foreign_epoch;
-        }
-        hard = hard || clhip_event_record(l->ev_primed, s_p);
-        if (g->readahead < 2 || hard) continue;
-        /* the launches: sub-batch by sub-batch like the call's own, into the OTHER mirror, behind the OTHER event set; sub-batches
-         * with a registered client buffer among their members wait for the call (the copy engine needs the client's pointer) */
-        if (l->pipe) { if (clhip_rx_pipe_epoch_begin(l->pipe)) { hard = 1; break; } l->epoch_open = 1; }
-        int waited = 0;
-        for (int a = 0; a < l->n && !hard; a += l->sub) {
-            const int e = a + l->sub < l->n ? a + l->sub : l->n;
-            int run = 0, ft = l->route == ROUTE_PLAIN ? g->dev[l->member[a]]->stream->filter_type : 0, whole = 1;
-            for (int r = a; r < e; r++) {
-                cl_stream *st = g->dev[l->member[r]]->stream;
-                if (g->has_reg[l->member[r]] || st->filter_type != ft || (l->route != ROUTE_PLAIN && st->filter_type != CL_DIGFILT_NONE)) { run = 0; whole = 0; break; }   /* (the copy engine needs the client's pointer; a mixed sub-batch waits for the call) */
-                l->done_ahead[r] = (uint8_t)(l->ahead_mark[r] && on_phase_0(l, r));
-                run |= l->done_ahead[r]; whole &= l->done_ahead[r];
-            }
-            if (ft > 0 && !whole) run = 0;                     /* (a filter launch is over the whole sub-batch or not at all) */
-            if (!run) { for (int r = a; r < e; r++) l->done_ahead[r] = 0; continue; }
-            if (!waited) { hard = clhip_stream_wait_event(g->s_k, l->ev_primed); waited = 1; }
-            if (ft > 0) {
-                if (l->sub_ft[a / l->sub] && giir_verdict(g, l, a, e) == 3) hard = 1;      /* (this call's launch over the same object, first) */
-                clhip_iir *obj = hard ? NULL : giir_get(g, l, a, e, ft);
-                if (!obj || giir_launch(g, l, obj, a, e, l->want, l->d_in[l->next_in], l->m_out[l->cur_m ^ 1], 2 * (l->set ^ 1))) hard = 1;
-                for (int r = a; r < e; r++) l->ahead_got[r] = (long)(l->want / 4);
-                l->ahead_ft[a / l->sub] = (uint8_t)ft;
-                hard = hard || clhip_event_record(ev_of(g, l, l->set ^ 1, a)[g->n_in + 1], g->s_k);
-                continue;
-            }
-            if (!hard && launch_rows(g, l, a, e, l->done_ahead, l->want, l->d_in[l->next_in], l->m_out[l->cur_m ^ 1], 2 * (l->set ^ 1), l->ahead_got)) hard = 1;
-            hard = hard || clhip_event_record(ev_of(g, l, l->set ^ 1, a)[g->n_in + 1], g->s_k);
-        }
-    }
-    clock_gettime(CLOCK_MONOTONIC, &t1);
-    /* ---- pass 3: as the sub-batches arrive, their bytes are consumed for good and their rows go to the clients */
-    for (int k = 0; k < g->n_lanes; k++) {
-        lane_t *l = &g->lane[k];
-        int sb = 0;
-        for (int a = 0; a < l->n; a += l->sub, sb++) {
-            const int e = a + l->sub < l->n ? a + l->sub : l->n;
-            int any = 0;
-            for (int r = a; r < e; r++) any |= l->fast[r];
-            if (!any) continue;
-            int arrived, filter_failed = 0;
-            if (l->sub_ft && l->sub_ft[sb] && sb < l->queued && !hard) {
-                const int v = giir_verdict(g, l, a, e);
-                arrived = v != 3; filter_failed = v == 2;
-            } else
-                arrived = sb < l->queued && !hard && clhip_event_sync(ev_of(g, l, l->set, a)[g->n_in + 1]) == 0;
-            if (!arrived) hard = 1;
-            for (int r = a; r < e; r++) {
-                if (!l->fast[r]) continue;
-                const int m = l->member[r];
-                cl_device *dev = g->dev[m];
-                if (filter_failed) l->got[r] = 0;                  /* (consumed, nothing delivered) */
-                if (!arrived) {                                    /* a runtime error: nothing is delivered, nothing is consumed */
-                    for (int q = 0; q < g->n_in; q++) clhip_stream_sync(g->s_in[q]);
-                    if (l->primed[r]) {                            /* (the newest staged bytes first) */
-                        cl_smi_foreign_cancel(dev->smi);
-                        if (l->done_ahead[r] && l->pipe) clhip_rx_pipe_unrun_stream(l->pipe, r, l->primed[r] / 4);
-                        l->primed[r] = 0; l->done_ahead[r] = 0;
-                        g->stale = 1;
-                    }
-                    pthread_mutex_lock(&dev->smi->fifo_mu);
-                    cl_fifo_unstage(&dev->smi->rx, l->len[r]);
-                    pthread_mutex_unlock(&dev->smi->fifo_mu);
-                    l->fast[r] = 0;
-                    count_read(dev->stream, 0);
-                    continue;
-                }
-                confirm_staged(dev->smi, l->len[r]);
-                dev->smi->stat_samples += (uint64_t)(l->len[r] / 4);
-                /* the seam's persistent int16 buffer (the slots a re-synchronised read() leaves untouched keep what the call before
-                 * left there, caribou_smi.c:382-389) was not written: this call's raw words stand in for it, where they lie -- the lane
-                 * rotates three input buffers, a row is only written again in a call that reads it again and moves this pointer -- and
-                 * the seam unpacks them the first time it needs the samples (cl_smi_restore_prev_words); a read through the member's
-                 * own device in between overrides them like any other read */
-                if (cl_smi_set_prev_words(dev->smi, l->channel, l->d_in[l->cur_in] + (size_t)r * l->in_stride, l->len[r])) hard = 1;
-                const size_t bytes = (size_t)l->got[r] * l->elem_bytes;
-                if (!l->direct[r])
-                    pool_submit(&g->pool, (uint8_t *)buffs[m], l->h_out[l->cur_m] + (size_t)r * l->out_stride * l->elem_bytes, bytes);
-                else g->stats.direct_reads++;
-                rets[m] = (int)l->got[r];
-                g->stats.batched_reads++;
-                count_read(dev->stream, rets[m]);
-            }
-        }
-    }
-    clock_gettime(CLOCK_MONOTONIC, &t2);
-    pool_drain(&g->pool);
-    if (hard) {
-        for (int k = 0; k < g->n_in; k++) clhip_stream_sync(g->s_in[k]);
-        clhip_stream_sync(g->s_k); clhip_stream_sync(g->s_out);
-        if (!g->err[0]) cl_seterr(g->err, sizeof g->err, "cl_group_readStream: %s", clhip_last_error());
-        ahead_cancel_all(g);
-        g->stale = 0;                                      /* (everything was drained above) */
-        for (int k = 0; k < g->n_lanes; k++)
-            if (g->lane[k].pipe && g->lane[k].epoch_open) { clhip_rx_pipe_epoch_end(g->lane[k].pipe, g->s_k); g->lane[k].epoch_open = 0; }
-        g->stats.errors++;
-        return -1;
-    }
-    clock_gettime(CLOCK_MONOTONIC, &t3);
-    g->stats.last_queue_us = (uint64_t)((t1.tv_sec - t0.tv_sec) * 1000000L + (t1.tv_nsec - t0.tv_nsec) / 1000);
-    g->stats.last_arrive_us = (uint64_t)((t2.tv_sec - t0.tv_sec) * 1000000L + (t2.tv_nsec - t0.tv_nsec) / 1000);
-    g->stats.last_total_us = (uint64_t)((t3.tv_sec - t0.tv_sec) * 1000000L + (t3.tv_nsec - t0.tv_nsec) / 1000);
-    int delivered = 0;
-    for (size_t i = 0; i < g->n; i++) delivered += rets[i] > 0;
-    return delivered;
-}
-
-/* ------------------------------------------------------------------------------------------- the write call
- * N writeStream calls as one (Stream::WriteSamplesGen, CaribouliteStream.cpp:199-258, over caribou_smi_write, caribou_smi.c:720-762):
- * rets[i] is what cl_writeStream(devs[i], ..., &buffs[i], numElems) returns, and the packed words of every member land in its TX FIFO
- * behind what was there.  Members without a modulator share launches, up to eight streams each:
- *
- *     A  sub-batch b:  clients' samples --copy threads--> pinned rows --copy engine--> device rows           stream s_in[b mod K]
- *     B  the PREVIOUS call's launches are waited for, its words committed to the members' FIFOs
- *     C  room is reserved in every member's pinned TX FIFO; one launch per sub-batch converts and packs (caribou_smi_generate_data)
- *        every row and stores the words straight into the rooms                                               stream s_k
- *
- * The call returns with C queued (WRITE-BEHIND by one call: this call's copies in cross PCIe while the previous call's launches store
- * out, and the next call's host copies run while this one's launches do).  Nobody can tell: the members' seams call back
- * (tx_settle) before anything of theirs looks at or adds to a TX FIFO -- cl_smi_drain_bytes / _drain_to_fd from any thread, a
- * write through a member's own device -- and the group finishes what it has in flight first; so does cl_group_unmake.  (What a
- * client cannot be told any more is a runtime error of launches it was already told about: the next call reports it.)
- * A member with a modulator (MOD=FM, RESAMP), a CS16 call above one MTU (the reference does not clamp those) or a member whose pack
- * mode differs from its sub-batch's takes its own device's writeStream, here, inside the call. */
-static void tx_finish(cl_group *g)
-{
-    if (!g->tx_pending) return;
-    g->tx_pending = 0;
-    for (int k = 0; k < g->n_lanes; k++) {
-        lane_t *l = &g->lane[k];
-        if (l->route != ROUTE_TX_PLAIN) continue;
-        for (int a = 0; a < l->n; a += l->sub) {
-            const int e = a + l->sub < l->n ? a + l->sub : l->n;
-            int any = 0;
-            for (int r = a; r < e; r++) any |= l->tx_pend[r];
-            if (!any) continue;
-            const int ok = clhip_event_sync(ev_of(g, l, l->tx_pend_set, a)[g->n_in + 1]) == 0;
-            for (int r = a; r < e; r++) {
-                if (!l->tx_pend[r]) continue;
-                l->tx_pend[r] = 0;
-                if (ok) cl_smi_tx_commit(g->dev[l->member[r]]->smi, 4 * l->tx_pend_want);
-            }
-            if (!ok) { cl_seterr(g->err, sizeof g->err, "cl_group_writeStream: launches of the previous call failed (%s): their words are lost", clhip_last_error()); g->stats.errors++; }
-        }
-    }
-}
-
-/* a member's seam is about to look at or add to its TX FIFO (any thread) */
-static void tx_settle_hook(void *ctx, int member)
-{
-    cl_group *g = (cl_group *)ctx;
-    (void)member;
-    pthread_mutex_lock(&g->tx_mu);
-    tx_finish(g);
-    pthread_mutex_unlock(&g->tx_mu);
-}
-
-int cl_group_writeStream(cl_group *g, const void *const *buffs, size_t numElems, int *rets, long timeoutUs)
-{
-    if (!g || !buffs || !rets) return -1;
-    if (g->dir != CL_SOAPY_SDR_TX) { cl_seterr(g->err, sizeof g->err, "cl_group_writeStream: the group's devices are set up for RX"); return -1; }
-    clhip_set_device(g->device);
-    pthread_mutex_lock(&g->tx_mu);
-    const uint64_t errors_before = g->stats.errors;
-    g->err[0] = 0;
-    g->stats.calls++;
-    for (size_t i = 0; i < g->n; i++) rets[i] = 0;
-    if (!numElems) { pthread_mutex_unlock(&g->tx_mu); return 0; }
-    const size_t mtu = CL_NATIVE_MTU_SAMPLES;
-    int hard = 0;
-    struct timespec t0, t1, t2, t3;
-    clock_gettime(CLOCK_MONOTONIC, &t0);
-    /* ---- A: the clients' samples to the device (the previous call's launches are storing their words meanwhile) */
-    for (int k = 0; k < g->n_lanes && !hard; k++) {
-        lane_t *l = &g->lane[k];
-        memset(l->fast, 0, (size_t)l->n);
-        l->queued = 0;
-        if (l->route != ROUTE_TX_PLAIN) continue;
-        const size_t n_el = l->format != CL_FORMAT_CS16 && numElems > mtu ? mtu : numElems;      /* :201,217,234; CS16 is not clamped (:182-196) */
-        if (n_el > mtu) continue;                              /* (a chunk loop of its own, member by member) */
-        l->want = n_el;
-        l->set ^= 1;                                           /* pinned rows, device rows and events of this call: the other set is the previous call's, still in flight */
-        uint8_t *h_in = l->tx_h_in + (size_t)l->set * l->n * l->tx_row, *d_in = l->tx_d_in + (size_t)l->set * l->n * l->tx_row;
-        for (int a = 0; a < l->n && !hard; a += l->sub) {
-            const int e = a + l->sub < l->n ? a + l->sub : l->n;
-            void **ev = ev_of(g, l, l->set, a);
-            const size_t b = l->sub0 + (size_t)(a / l->sub);
-            void *s_in = g->s_in[b % (size_t)g->n_in];
-            int mode = -1, lo = -1, hi = -1;
-            l->queued++;
-            for (int r = a; r < e; r++) {
-                cl_device *dev = g->dev[l->member[r]];
-                const cl_stream *st = dev->stream;
-                if (st->native_dir != CL_SOAPY_SDR_TX || st->format != l->format || st->tx_pipe || !buffs[l->member[r]]) continue;
-                if (mode < 0) mode = dev->smi->tx_mode;
-                if (dev->smi->tx_mode != mode) continue;
-                l->fast[r] = 1;
-                pool_submit(&g->pool, h_in + (size_t)r * l->tx_row, (const uint8_t *)buffs[l->member[r]], n_el * l->elem_bytes);
-                if (lo < 0) lo = r;
-                hi = r;
-            }
-            if (lo < 0) continue;
-            pool_drain(&g->pool);                              /* (the previous sub-batch is on its way meanwhile) */
-            hard = clhip_memcpy_h2d(d_in + (size_t)lo * l->tx_row, h_in + (size_t)lo * l->tx_row, (size_t)(hi - lo) * l->tx_row + n_el * l->elem_bytes, s_in) ||
-                   clhip_event_record(ev[0], s_in);
-        }
-    }
-    clock_gettime(CLOCK_MONOTONIC, &t1);
-    /* ---- B: the previous call's words are the FIFOs' */
-    tx_finish(g);
-    clock_gettime(CLOCK_MONOTONIC, &t2);
-    /* ---- C: room in the FIFOs behind them, the launches */
-    for (int k = 0; k < g->n_lanes && !hard; k++) {
-        lane_t *l = &g->lane[k];
-        if (l->route != ROUTE_TX_PLAIN || !l->queued) continue;
-        uint8_t *d_in = l->tx_d_in + (size_t)l->set * l->n * l->tx_row;
-        for (int a = 0; a < l->n && !hard; a += l->sub) {
-            const int e = a + l->sub < l->n ? a + l->sub : l->n;
-            void **ev = ev_of(g, l, l->set, a);
-            const void *in_rows[CLHIP_PACK_ROWS]; uint8_t *out_rows[CLHIP_PACK_ROWS];
-            int n_rows = 0, mode = -1;
-            for (int r = a; r < e; r++) {
-                if (!l->fast[r]) continue;
-                cl_smi *smi = g->dev[l->member[r]]->smi;
-                /* caribou_smi_write's chunk loop appends native-batch pieces of one contiguous array (caribou_smi.c:738-759): the array,
-                 * packed into the room behind what the FIFO holds, committed once the launch is known to have run */
-                uint8_t *room = cl_smi_tx_reserve_raw(smi, 4 * l->want + 64);
-                uint8_t *d_room = room ? (uint8_t *)cl_fifo_device_ptr(&smi->tx, room) : NULL;
-                if (!d_room) { l->fast[r] = 0; continue; }        /* (through its own device, below) */
-                mode = smi->tx_mode;
-                in_rows[n_rows] = d_in + (size_t)r * l->tx_row; out_rows[n_rows] = d_room; n_rows++;
-            }
-            if (!n_rows) continue;
-            hard = clhip_stream_wait_event(g->s_k, ev[0]) ||
-                   clhip_convert_pack_rows(in_rows, l->format, l->want, n_rows, mode, out_rows, g->s_k) ||
-                   clhip_event_record(ev[g->n_in + 1], g->s_k);
-            g->stats.launches++;
-        }
-        if (hard) break;
-        l->tx_pend_set = l->set; l->tx_pend_want = l->want;
-        for (int r = 0; r < l->n; r++) {
-            if (!l->fast[r]) continue;
-            cl_device *dev = g->dev[l->member[r]];
-            cl_stream *st = dev->stream;
-            l->tx_pend[r] = 1; g->tx_pending = 1;
-            rets[l->member[r]] = (int)l->want;
-            st->stats.write_calls++; st->stats.elements_written += l->want;
-            if (l->format == CL_FORMAT_CS16) dev->smi->stat_written += l->want;          /* (caribou_smi_write counts; the conversions' callers do not) */
-            g->stats.batched_reads++;
-        }
-    }
-    if (hard) {
-        for (int k = 0; k < g->n_in; k++) clhip_stream_sync(g->s_in[k]);
-        clhip_stream_sync(g->s_k);
-        tx_finish(g);                                          /* (what was launched and told is waited for; what was not is not committed) */
-        cl_seterr(g->err, sizeof g->err, "cl_group_writeStream: %s", clhip_last_error());
-        g->stats.errors++;
-        pthread_mutex_unlock(&g->tx_mu);
-        return -1;
-    }
-    /* ---- the members off the batched route, through their own devices (their seams settle the group first: order in the FIFOs) */
-    for (int k = 0; k < g->n_lanes; k++) {
-        lane_t *l = &g->lane[k];
-        for (int r = 0; r < l->n; r++) {
-            if (l->fast[r]) continue;
-            const int m = l->member[r];
-            const void *const b1[1] = {buffs[m]};
-            rets[m] = buffs[m] ? cl_writeStream(g->dev[m], g->dev[m]->stream, b1, numElems, NULL, 0, timeoutUs) : 0;
-            g->stats.single_reads++;
-        }
-    }
-    clock_gettime(CLOCK_MONOTONIC, &t3);
-    g->stats.last_queue_us = (uint64_t)((t1.tv_sec - t0.tv_sec) * 1000000L + (t1.tv_nsec - t0.tv_nsec) / 1000);
-    g->stats.last_arrive_us = (uint64_t)((t2.tv_sec - t0.tv_sec) * 1000000L + (t2.tv_nsec - t0.tv_nsec) / 1000);
-    g->stats.last_total_us = (uint64_t)((t3.tv_sec - t0.tv_sec) * 1000000L + (t3.tv_nsec - t0.tv_nsec) / 1000);
-    int delivered = 0;
-    for (size_t i = 0; i < g->n; i++) delivered += rets[i] > 0;
-    const int failed_before = g->stats.errors != errors_before;      /* (the previous call's launches: reported now) */
-    pthread_mutex_unlock(&g->tx_mu);
-    return failed_before ? -1 : delivered;
-}
+/* the two calls (same translation unit: everything above is file-local) */
+#include "cl_group_rx.inc"
+#include "cl_group_tx.inc"
