@@ -55,6 +55,20 @@ def same(a, b):
     return a.shape == b.shape and a.tobytes() == b.tobytes()       # NaN sentinels included
 
 
+def same_behind_a_filter(a, b, max_count=4):
+    """Two filter objects that reach the same sample by different launch shapes (a multi-stream launch of the group, a single-stream
+    one of the lone device: which tile looks back and which carries its state along differs) hold fp64 states an ulp apart, and
+    (int16) truncation turns that into a one-LSB difference about once in 10^10 samples (the time-slice test):
+    identical, or a handful of single-LSB differences."""
+    if same(a, b):
+        return True
+    if a.shape != b.shape or not np.array_equal(np.isnan(a), np.isnan(b)):
+        return False
+    lsb = 1.0 / 4096 if np.issubdtype(a.dtype, np.floating) else 1
+    d = np.abs(np.nan_to_num(a.astype(np.float64)) - np.nan_to_num(b.astype(np.float64)))
+    return d.max() <= lsb * (1 + 1e-9) and np.count_nonzero(d) <= max_count
+
+
 def run_script(S, n, fmt, args, dtype, out_shape, script, n_calls, channel_of=lambda i: "S1G" if i % 3 else "HiF", group_args=None,
                num_elems=MTU, register=False, deep=False):
     """`script[(call, stream)]` = how that stream's batch of that call is damaged: ("slip", k) | ("lost",) | ("short", bytes) | ("none",).
@@ -211,7 +225,7 @@ def test_a_member_with_the_iir_selected_is_read_by_its_own_device(S):
         srets = [sdevs[i].readStream(ssts[i], [sb[i]], MTU).ret for i in range(n)]
         assert rets == srets == [MTU] * n
         for i in range(n):
-            assert same(gb[i], sb[i]), (c, i)
+            assert (same_behind_a_filter if i == 2 else same)(gb[i], sb[i]), (c, i)
     st = grp.stats()
     assert st["single_reads"] == calls and st["batched_reads"] == (n - 1) * calls
     grp.close()
@@ -495,10 +509,12 @@ def test_random_walk_against_lone_devices(S, seed, staged, filters):
         gdevs[i].feedSmiBytes(b); sdevs[i].feedSmiBytes(b)
 
     hist = [[] for _ in range(n)]                          # what was fed to / done with every stream, for the failure message
+    filtered = [False] * n                                 # a low-pass is selected on the stream (outputs compared up to a handful of LSBs)
 
     def compare(where):
         for i in range(n):
-            if not same(gb[i], sb[i]):
+            # (behind the extension stages one differing input sample shows in every output its FIR window reaches)
+            if not (same(gb[i], sb[i]) or (filtered[i] and same_behind_a_filter(gb[i], sb[i], 1200 if staged else 4))):
                 a, b = gb[i].reshape(-1), sb[i].reshape(-1)
                 d = np.flatnonzero(~((a == b) | (np.isnan(a) & np.isnan(b))))
                 raise AssertionError(f"{where} stream {i}: {d.size} values differ, first at {d[0]} ({a[d[0]]} vs {b[d[0]]}), last at {d[-1]}; "
@@ -520,6 +536,7 @@ def test_random_walk_against_lone_devices(S, seed, staged, filters):
             bw = float(rng.choice([100e3, 50e3, 1e6]))
             for i in range(n):
                 gdevs[i].setBandwidth(S.SOAPY_SDR_RX, 0, bw); sdevs[i].setBandwidth(S.SOAPY_SDR_RX, 0, bw); hist[i].append(f"bw{bw:g}")
+                filtered[i] = bw < 160e3
         if op == "lone" and not staged:
             i = int(rng.integers(0, n))
             assert gdevs[i].readStream(gsts[i], [gb[i]], MTU).ret == sdevs[i].readStream(ssts[i], [sb[i]], MTU).ret
@@ -531,7 +548,7 @@ def test_random_walk_against_lone_devices(S, seed, staged, filters):
         elif op == "filter":
             i = int(rng.integers(0, n)); bw = float(rng.choice([100e3, 1e6]))
             gdevs[i].setBandwidth(S.SOAPY_SDR_RX, 0, bw); sdevs[i].setBandwidth(S.SOAPY_SDR_RX, 0, bw)
-            hist[i].append(f"bw{bw:g}")
+            hist[i].append(f"bw{bw:g}"); filtered[i] = bw < 160e3
         elif op == "register":
             if registered:
                 grp.unregisterBuffers()
@@ -585,7 +602,7 @@ def test_the_low_pass_over_whole_sub_batches(S, orc, fmt, dtype):
         srets = [sdevs[i].readStream(ssts[i], [sb[i]], MTU).ret for i in range(n)]
         assert rets == srets == [MTU] * n, (c, rets, srets)
         for i in range(n):
-            assert same(gb[i], sb[i]), (c, i)
+            assert same_behind_a_filter(gb[i], sb[i]), (c, i)
         if expect_single is not None:
             assert grp.stats()["single_reads"] - s0 == expect_single, (c, grp.stats())
     step(expect_single=0); step(expect_single=0)            # three filter launches per call, nobody through its own device
@@ -599,7 +616,7 @@ def test_the_low_pass_over_whole_sub_batches(S, orc, fmt, dtype):
     c = fed[0]
     b = batch_bytes(6, 900, 0); gdevs[6].feedSmiBytes(b); sdevs[6].feedSmiBytes(b)
     assert gdevs[6].readStream(gsts[6], [gb[6]], MTU).ret == sdevs[6].readStream(ssts[6], [sb[6]], MTU).ret == MTU
-    assert same(gb[6], sb[6])
+    assert same_behind_a_filter(gb[6], sb[6])
     bw_all(100e3, [5]); step(expect_single=0)               # whole again: the states move back into the group's object
     step(script={9: "slip"}, expect_single=4)               # a slipped batch in member 9: its sub-batch goes home for this call
     step(expect_single=0)                                   # (the slipped batch was a whole read(): everybody is whole and in step again)
@@ -610,7 +627,7 @@ def test_the_low_pass_over_whole_sub_batches(S, orc, fmt, dtype):
             gdevs[i].feedSmiBytes(b); sdevs[i].feedSmiBytes(b)
         for i in range(n):
             assert gdevs[i].readStream(gsts[i], [gb[i]], MTU).ret == sdevs[i].readStream(ssts[i], [sb[i]], MTU).ret
-            assert same(gb[i], sb[i]), ("after the group", c, i)
+            assert same_behind_a_filter(gb[i], sb[i]), ("after the group", c, i)
     for d in gdevs + sdevs:
         d.close()
 
@@ -636,7 +653,7 @@ def test_a_group_filter_launch_that_gives_up_is_made_again(S):
         srets = [sdevs[i].readStream(ssts[i], [sb[i]], MTU).ret for i in range(n)]
         assert rets == srets == [MTU] * n
         for i in range(n):
-            assert same(gb[i], sb[i]), (c, i)
+            assert same_behind_a_filter(gb[i], sb[i]), (c, i)
     assert [gdevs[i].streamStats(gsts[i])["iir_overruns"] for i in range(n)] == [1] * n
     assert grp.stats()["single_reads"] == 0 and grp.stats()["errors"] == 0
     grp.close()
