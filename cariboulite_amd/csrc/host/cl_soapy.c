@@ -93,7 +93,10 @@ static void *reader_thread_fn(void *arg)
         cl_ring_span sp;
         size_t room = 0;
         int put_open = 0;
-        if (expect > 0 && smi->ra_pending) {
+        /* (only where the put displaces nothing: a read that then turns out to have failed must leave the ring as it was -- the
+         * reference puts nothing, CaribouliteStream.cpp:34-44 -- and an opened put has taken the oldest elements' slots already; a
+         * full ring's put waits for the verdict, below) */
+        if (expect > 0 && smi->ra_pending && cl_ring_size(st->rx_queue) + (size_t)expect < cl_ring_capacity(st->rx_queue)) {
             room = cl_ring_put_begin(st->rx_queue, (size_t)expect, &sp);
             put_open = 1;
             if (room && ring_span_copy(st->rx_queue, &sp, st->d_native1, 1, smi->stream)) room = 0;
@@ -349,6 +352,8 @@ void cl_setBandwidth(cl_device *dev, int direction, size_t channel, double bw)
     } else st->filter_type = CL_DIGFILT_NONE;
 }
 int cl_getDigitalFilter(const cl_device *dev) { return dev->stream->filter_type; }
+/* ASYNC=1: samples the reader thread has queued and no readStream has taken yet (rx_queue->size(), circular_buffer.h) */
+size_t cl_stream_queue_size(const cl_device *dev, const cl_stream *st) { (void)dev; return st && st->rx_queue ? cl_ring_size(st->rx_queue) : 0; }
 
 /* ------------------------------------------------------------------- RX path */
 static size_t fmt_bytes(int fmt) { return fmt == CL_FORMAT_CF32 ? 8 : fmt == CL_FORMAT_CF64 ? 16 : fmt == CL_FORMAT_CS8 ? 2 : 4; }

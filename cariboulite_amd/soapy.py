@@ -93,6 +93,7 @@ _SIGS = {
                                  C.c_longlong, C.c_long]),
     "cl_setBandwidth": (None, [C.c_void_p, C.c_int, C.c_size_t, C.c_double]),
     "cl_getDigitalFilter": (C.c_int, [C.c_void_p]),
+    "cl_stream_queue_size": (C.c_size_t, [C.c_void_p, C.c_void_p]),
     "cl_stream_iir_overruns": (C.c_ulong, [C.c_void_p]),
     "cl_getStreamStats": (None, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "cl_smi_get_stats": (None, [C.c_void_p, C.c_void_p]),
@@ -348,6 +349,9 @@ class Device:
 
     def getDigitalFilter(self):
         return lib().cl_getDigitalFilter(self.h)
+
+    def streamQueueSize(self, st):
+        return lib().cl_stream_queue_size(self.h, st)
 
     def streamStats(self, st):
         out = (C.c_uint64 * 10)()

@@ -555,6 +555,7 @@ int    cl_writeStream(cl_device *dev, cl_stream *stream, const void *const *buff
 /* setBandwidth Cariboulite.cpp:395-417: RX bw < 160 kHz selects the IIR */
 void   cl_setBandwidth(cl_device *dev, int direction, size_t channel, double bw);
 int    cl_getDigitalFilter(const cl_device *dev);
+size_t cl_stream_queue_size(const cl_device *dev, const cl_stream *stream);   /* ASYNC=1: samples queued by the reader thread and not read yet (0 without ASYNC) */
 /* counters of the stream calls (SURVEY.md section 5 "metrics"): the reference squashes every error to 0 elements
  * (CaribouliteStream.cpp:185-194,266-276) and prints; here the caller can ask what happened */
 typedef struct {

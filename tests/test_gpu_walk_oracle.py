@@ -220,3 +220,69 @@ def test_the_lower_seam_against_orc_smi_read(S, orc, seed):
         codes.add(ret if ret < 0 else (0 if ret == 0 else 1))
     assert 1 in codes and -3 in codes, codes
     dev.close()
+
+
+@pytest.mark.parametrize("seed,fmt", [(41, "CS16"), (42, "CF32"), (43, "CS16"), (44, "CF32")])
+def test_the_reader_thread_and_its_ring_against_the_model(S, orc, seed, fmt):
+    """ASYNC=1 (the reference's USE_ASYNC path, CaribouliteStream.cpp:16-49,70-75,260-279): a reader thread runs caribou_smi_read for one
+    MTU into interm_native_buffer1 and puts what it got into a ring that overwrites its oldest elements when full; readStream pops
+    whole requests.  Deterministic here because the walk feeds ONE piece (at most a native batch), waits until the reader thread has
+    taken it (the ring holds what the model says), and only then goes on: every piece is one iteration of the reader's loop -- its
+    re-syncs with interm_native_buffer1's stale slots, its "-3"s (nothing queued), short pieces -- and the ring (16 MTU: the next power
+    of two above 10) is run over its capacity on purpose."""
+    import time
+    from cariboulite_amd import synth
+    rng = np.random.default_rng(seed)
+    ch = seed % 2
+    dev = S.Device(dict(driver="Cariboulite", channel="S1G" if ch == 0 else "HiF"))
+    st = dev.setupStream(S.SOAPY_SDR_RX, fmt, args={"ASYNC": "1"})
+    dev.activateStream(st)
+    ring = orc.Ring(10 * MTU, override_write=True, block_read=True)
+    interm = np.zeros((MTU + 2, 2), np.int16)
+    dt = np.int16 if fmt == "CS16" else np.float32
+    got = np.zeros((MTU + 8, 2), dt)
+    fed, overruns, reads = 0, 0, 0
+
+    def wait_for(cond, what):
+        t0 = time.time()
+        while not cond():
+            assert time.time() - t0 < 10, what
+            time.sleep(0.0005)
+
+    for step in range(70):
+        # one piece for the reader thread
+        how = rng.choice(["good"] * 8 + ["slip", "lost", "half", "quarter"])
+        b = synth.smi_stream_bytes(MTU, ch, stream=600 + seed, n0=fed * MTU)[0].copy(); fed += 1
+        if how == "slip":
+            k = 4 * int(rng.integers(1, 3))                        # (whole words: the reader's next read() starts aligned again)
+            b = np.concatenate([((np.arange(k, dtype=np.uint8) * 7 + 3) & 0x3F), b[: b.size - k]])
+        elif how == "lost":
+            b[:] = 0
+        elif how == "half":
+            b = b[: NB // 2]
+        elif how == "quarter":
+            b = b[: NB // 4]
+        ret, iq, pos = orc.smi_read_pos(ch, b, MTU, NB, fill=SENT)
+        assert pos == b.size
+        touched = (iq != SENT).any(axis=1)
+        interm[touched] = iq[touched]
+        before = ring.size()
+        if ret > 0:
+            overruns += before + ret > ring.capacity() - 1
+            ring.put(interm[:ret].copy().view(np.uint32).reshape(-1))
+        dev.feedSmiBytes(b)
+        wait_for(lambda: dev.pendingSmiBytes() == 0 and dev.streamQueueSize(st) == ring.size(), ("the reader thread", step, how, dev.streamQueueSize(st), ring.size()))
+        # the client: now and then, whole requests only when the ring holds them
+        while ring.size() >= MTU and rng.integers(0, 3) == 0:
+            num = int(rng.choice([MTU, MTU // 2, 50000]))
+            k, want = ring.get(num)
+            assert k == num
+            r = dev.readStream(st, [got], num, timeoutUs=1_000_000).ret
+            assert r == num, (step, num, r)
+            w16 = want.view(np.int16).reshape(-1, 2)
+            exp = w16 if fmt == "CS16" else orc.cs16_to_cf32(w16)
+            assert np.array_equal(got[:num], exp), (step, num, np.flatnonzero((got[:num] != exp).any(axis=1))[:4])
+            assert dev.streamQueueSize(st) == ring.size()
+            reads += 1
+    assert overruns >= 1 and reads >= 5, (overruns, reads)
+    dev.close()
