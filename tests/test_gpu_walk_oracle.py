@@ -286,3 +286,37 @@ def test_the_reader_thread_and_its_ring_against_the_model(S, orc, seed, fmt):
             reads += 1
     assert overruns >= 1 and reads >= 5, (overruns, reads)
     dev.close()
+
+
+@pytest.mark.parametrize("seed", [51, 52, 53])
+def test_write_stream_with_the_modulator_against_the_oracle(S, orc, seed):
+    """writeStream(CF32, MOD=FM:75000, RESAMP=2/3) over a walk of call lengths (whole MTUs, every residue mod 3, tiny, above the MTU:
+    clamped): the oracle's fp64 chain -- phase accumulated from call to call, 2/3 polyphase with its history carried (SURVEY.md
+    section 8 a13) -- quantised like Stream::WriteSamples (CaribouliteStream.cpp:199-214: (int16)(f * 4096)) and parsed back from the
+    words the FPGA would see: every word within one LSB of the truncation boundary, the output count exact call by call."""
+    from conftest import load_golden
+    t = load_golden("taps.npz")
+    rng = np.random.default_rng(seed)
+    dev = S.Device(dict(driver="Cariboulite", channel="S1G"))
+    st = dev.setupStream(S.SOAPY_SDR_TX, "CF32", args={"MOD": "FM:75000", "RESAMP": "2/3"})
+    dev.activateStream(st)
+    rs = orc.Resampler(t["rs_2_3"], 2, 3)
+    phase, pos = 0.0, 0
+    for step in range(25):
+        num = int(rng.choice([MTU] * 3 + [MTU - 1, MTU - 2, 1000, 1001, 1002, 5, MTU + 3000]))
+        took = min(num, MTU)
+        msg = (0.4 * np.sin(2 * np.pi * 3e3 * (pos + np.arange(num)) / 4e6) + 0.3 * rng.standard_normal(num)).astype(np.float32)
+        buf = np.stack([msg, rng.standard_normal(num).astype(np.float32)], 1)      # (the Q rail is ignored: "if given I/Q, use I")
+        assert dev.writeStream(st, [buf], num).ret == took, (step, num)
+        iq, phase = orc.fm_mod_f64(msg[:took], 75e3, 4e6, phase)
+        want = rs.f64(iq) * 4096.0
+        by = dev.drainSmiBytes()
+        assert by.size == 4 * want.shape[0], (step, num, by.size, want.shape)
+        if want.shape[0]:
+            w = orc.fpga_tx_parse(by)
+            _, got, _ = orc.rx_data_analyze(0, (w & ~np.uint32(1 << 16)).view(np.uint8))
+            wq = ((np.trunc(want).astype(np.int64) + 4096) & 0x1FFF) - 4096
+            dd = np.abs(got[: wq.shape[0]].astype(np.int64) - wq); dd = np.minimum(dd, 8192 - dd)
+            assert dd.max() <= 1 and np.mean(dd != 0) < 2e-3, (step, num, int(dd.max()), float(np.mean(dd != 0)))
+        pos += took
+    dev.close()
