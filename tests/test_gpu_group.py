@@ -659,3 +659,41 @@ def test_a_group_filter_launch_that_gives_up_is_made_again(S):
     grp.close()
     for d in gdevs + sdevs:
         d.close()
+
+
+def test_a_member_with_a_reader_thread_is_read_through_its_ring(S):
+    """ASYNC=1 on one member (the reference's USE_ASYNC reader thread + ring, CaribouliteStream.cpp:16-49): inside the group call that
+    member pops its ring like its lone twin, the others stay batched"""
+    import time
+    n = 4
+    args_of = lambda i: {"ASYNC": "1"} if i == 2 else None
+    def make():
+        devs, sts = [], []
+        for i in range(n):
+            d = S.Device(dict(driver="Cariboulite", channel="S1G"))
+            sts.append(d.setupStream(S.SOAPY_SDR_RX, S.SOAPY_SDR_CS16, args=args_of(i)))
+            d.activateStream(sts[-1])
+            devs.append(d)
+        return devs, sts
+    gdevs, gsts = make()
+    sdevs, ssts = make()
+    grp = S.Group(gdevs)
+    gb, sb = sentinel_buffers(n, (MTU + 2, 2), np.int16), sentinel_buffers(n, (MTU + 2, 2), np.int16)
+    for c in range(4):
+        for i in range(n):
+            b = batch_bytes(i, c, 0)
+            gdevs[i].feedSmiBytes(b); sdevs[i].feedSmiBytes(b)
+        t0 = time.time()
+        while gdevs[2].streamQueueSize(gsts[2]) < MTU or sdevs[2].streamQueueSize(ssts[2]) < MTU:
+            assert time.time() - t0 < 10
+            time.sleep(0.001)
+        _, rets = grp.readStream(gb, MTU, timeoutUs=1_000_000)
+        srets = [sdevs[i].readStream(ssts[i], [sb[i]], MTU, timeoutUs=1_000_000).ret for i in range(n)]
+        assert rets == srets == [MTU] * n, (c, rets, srets)
+        for i in range(n):
+            assert same(gb[i], sb[i]), (c, i)
+    st = grp.stats()
+    assert st["single_reads"] == 4 and st["batched_reads"] == 12 and st["errors"] == 0
+    grp.close()
+    for d in gdevs + sdevs:
+        d.close()
