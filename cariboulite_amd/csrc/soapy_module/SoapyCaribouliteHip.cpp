@@ -118,6 +118,156 @@ SoapySDR::KwargsList findCaribouliteHip(const SoapySDR::Kwargs &args)
 
 SoapySDR::Device *makeCaribouliteHip(const SoapySDR::Kwargs &args) { return new CaribouliteHip(args); }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Many boards on one GPU as ONE multi-channel Soapy device: driver=CaribouliteGroup, channels="S1G,HiF,S1G,..." (one entry per
+// underlying Cariboulite device, i.e. per board and channel type).  SoapySDR's own multi-channel stream shape --
+// setupStream(dir, fmt, {0 .. N-1}) and readStream(stream, buffs[N], numElems, ...) -- which the reference declines (one channel per
+// device, Cariboulite.hpp:59) maps one-to-one onto cl_group_readStream / cl_group_writeStream: every channel is exactly the
+// reference's device for that board, all of them read (or written) in one call.  readStream returns the LARGEST count any channel
+// delivered (SoapySDR has one return value for all channels); readSetting("GROUP_RETS") gives the last call's count per channel
+// ("131072,131072,0,..."): a channel that re-synchronised or timed out says so there, exactly as its own readStream would have.
+class CaribouliteGroupHip : public SoapySDR::Device {
+    std::vector<cl_device *> devs_;
+    std::vector<cl_stream *> streams_;
+    cl_group *grp_ = nullptr;
+    SoapySDR::Kwargs group_args_;
+    mutable std::vector<int> rets_;
+
+    void drop_group() { if (grp_) { cl_group_unmake(grp_); grp_ = nullptr; } }
+
+public:
+    explicit CaribouliteGroupHip(const SoapySDR::Kwargs &args)
+    {
+        const std::string list = args.count("channels") ? args.at("channels") : "";
+        size_t pos = 0;
+        while (pos <= list.size() && !list.empty()) {
+            const size_t comma = list.find(',', pos);
+            const std::string ch = list.substr(pos, comma == std::string::npos ? std::string::npos : comma - pos);
+            SoapySDR::Kwargs one = args;
+            one.erase("channels"); one["driver"] = "Cariboulite"; one["channel"] = ch;
+            KwArrays a(one);
+            cl_device *d = cl_device_make(a.k.data(), a.v.data(), a.k.size());
+            if (!d) { for (cl_device *x : devs_) cl_device_unmake(x); throw std::runtime_error("CaribouliteGroup: channels=\"S1G,HiF,...\""); }
+            devs_.push_back(d);
+            if (comma == std::string::npos) break;
+            pos = comma + 1;
+        }
+        if (devs_.empty()) throw std::runtime_error("CaribouliteGroup: channels=\"S1G,HiF,...\"");
+        for (const auto &it : args)                          // group kwargs (SUBBATCH, COPY_THREADS, READAHEAD, ...) pass through
+            if (it.first != "driver" && it.first != "channels" && it.first != "gpu") group_args_[it.first] = it.second;
+        rets_.assign(devs_.size(), 0);
+    }
+    ~CaribouliteGroupHip() override
+    {
+        drop_group();                                        // (before its members: the group holds their seams)
+        for (cl_device *d : devs_) cl_device_unmake(d);
+    }
+
+    std::string getDriverKey() const override { return "CaribouliteGroup"; }
+    size_t getNumChannels(const int) const override { return devs_.size(); }
+    bool getFullDuplex(const int, const size_t) const override { return false; }
+    std::vector<std::string> getStreamFormats(const int dir, const size_t ch) const override
+    {
+        const char *f[8];
+        const size_t n = cl_getStreamFormats(devs_.at(ch), dir, 0, f, 8);
+        return std::vector<std::string>(f, f + n);
+    }
+    std::string getNativeStreamFormat(const int dir, const size_t ch, double &fullScale) const override
+    {
+        return cl_getNativeStreamFormat(devs_.at(ch), dir, 0, &fullScale);
+    }
+
+    // all channels, in order (an empty list means all): the group is made here, behind the members' setupStream
+    SoapySDR::Stream *setupStream(const int dir, const std::string &format, const std::vector<size_t> &channels,
+                                  const SoapySDR::Kwargs &args) override
+    {
+        if (!channels.empty()) {
+            if (channels.size() != devs_.size()) throw std::runtime_error("CaribouliteGroup: a stream spans all channels");
+            for (size_t i = 0; i < channels.size(); i++)
+                if (channels[i] != i) throw std::runtime_error("CaribouliteGroup: a stream spans all channels, in order");
+        }
+        drop_group();
+        KwArrays a(args);
+        streams_.clear();
+        const size_t zero = 0;
+        for (cl_device *d : devs_) {
+            cl_stream *s = cl_setupStream(d, dir, format.c_str(), &zero, 1, a.k.data(), a.v.data(), a.k.size());
+            if (!s) throw std::runtime_error(cl_device_last_error(d));
+            streams_.push_back(s);
+        }
+        KwArrays ga(group_args_);
+        grp_ = cl_group_make(devs_.data(), devs_.size(), ga.k.data(), ga.v.data(), ga.k.size());
+        if (!grp_) throw std::runtime_error(cl_group_last_error(nullptr));
+        return reinterpret_cast<SoapySDR::Stream *>(grp_);
+    }
+    void closeStream(SoapySDR::Stream *) override
+    {
+        for (size_t i = 0; i < streams_.size(); i++) cl_closeStream(devs_[i], streams_[i]);
+    }
+    size_t getStreamMTU(SoapySDR::Stream *) const override { return streams_.empty() ? 0 : cl_getStreamMTU(devs_[0], streams_[0]); }
+    int activateStream(SoapySDR::Stream *, const int flags, const long long timeNs, const size_t numElems) override
+    {
+        int rc = 0;
+        for (size_t i = 0; i < streams_.size(); i++) rc |= cl_activateStream(devs_[i], streams_[i], flags, timeNs, numElems);
+        return rc;
+    }
+    int deactivateStream(SoapySDR::Stream *, const int flags, const long long timeNs) override
+    {
+        int rc = 0;
+        for (size_t i = 0; i < streams_.size(); i++) rc |= cl_deactivateStream(devs_[i], streams_[i], flags, timeNs);
+        return rc;
+    }
+    int readStream(SoapySDR::Stream *, void *const *buffs, const size_t numElems, int &, long long &, const long timeoutUs) override
+    {
+        if (!grp_) return -5;
+        if (cl_group_readStream(grp_, buffs, numElems, rets_.data(), timeoutUs) < 0) return -1;      // SOAPY_SDR_TIMEOUT where the runtime failed
+        int most = 0, wrong = 0;
+        for (int r : rets_) { if (r > most) most = r; if (r < 0) wrong = r; }
+        return wrong ? wrong : most;                         // (NOT_SUPPORTED: a group set up for TX)
+    }
+    int writeStream(SoapySDR::Stream *, const void *const *buffs, const size_t numElems, int &, const long long, const long timeoutUs) override
+    {
+        if (!grp_) return -5;
+        if (cl_group_writeStream(grp_, buffs, numElems, rets_.data(), timeoutUs) < 0) return -1;
+        int most = 0, wrong = 0;
+        for (int r : rets_) { if (r > most) most = r; if (r < 0) wrong = r; }
+        return wrong ? wrong : most;
+    }
+    void setBandwidth(const int dir, const size_t ch, const double bw) override { cl_setBandwidth(devs_.at(ch), dir, 0, bw); }
+
+    std::string readSetting(const std::string &key) const override
+    {
+        std::string out;
+        if (key == "GROUP_RETS")
+            for (size_t i = 0; i < rets_.size(); i++) out += (i ? "," : "") + std::to_string(rets_[i]);
+        return out;
+    }
+    void writeSetting(const std::string &key, const std::string &value) override
+    {
+        // "SMI_FEED_PTR:<channel>" = "<host pointer>:<bytes>" (a co-located feeder per board)
+        if (key.compare(0, 13, "SMI_FEED_PTR:") == 0) {
+            const size_t ch = (size_t)std::stoul(key.substr(13));
+            unsigned long long p = 0, n = 0;
+            if (ch < devs_.size() && sscanf(value.c_str(), "%llx:%llu", &p, &n) == 2)
+                cl_smi_feed_bytes(cl_device_smi(devs_[ch]), reinterpret_cast<const uint8_t *>(p), (size_t)n);
+        }
+    }
+};
+
+SoapySDR::KwargsList findCaribouliteGroupHip(const SoapySDR::Kwargs &args)
+{
+    SoapySDR::KwargsList out;
+    if (args.count("channels")) {                            // (nothing to enumerate: the client says which boards make the group)
+        SoapySDR::Kwargs d = args;
+        d["driver"] = "CaribouliteGroup"; d["label"] = "CaribouLite-HIP group of " + args.at("channels");
+        out.push_back(d);
+    }
+    return out;
+}
+
+SoapySDR::Device *makeCaribouliteGroupHip(const SoapySDR::Kwargs &args) { return new CaribouliteGroupHip(args); }
+
 SoapySDR::Registry registerCaribouliteHip("Cariboulite", &findCaribouliteHip, &makeCaribouliteHip, SOAPY_SDR_ABI_VERSION);
+SoapySDR::Registry registerCaribouliteGroupHip("CaribouliteGroup", &findCaribouliteGroupHip, &makeCaribouliteGroupHip, SOAPY_SDR_ABI_VERSION);
 
 }   // namespace

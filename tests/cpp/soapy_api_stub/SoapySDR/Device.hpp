@@ -36,5 +36,6 @@ public:
     virtual int writeStream(Stream *, const void *const *, const size_t, int &, const long long = 0, const long = 100000) { return -5; }
     virtual void setBandwidth(const int, const size_t, const double) {}
     virtual void writeSetting(const std::string &, const std::string &) {}
+    virtual std::string readSetting(const std::string &) const { return ""; }
 };
 }   // namespace SoapySDR
