@@ -138,6 +138,10 @@ extern "C" void *clhip_host_alloc(size_t bytes)
 
 extern "C" void clhip_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
+// diagnostic: the runtime's sticky "last error" of the calling thread (consumed by the call; 0 = none).  A HIP call that fails and is
+// handled must not leave it behind -- the next kernel launch's check would report it as its own.
+extern "C" int clhip_debug_sticky_error(void) { return (int)hipGetLastError(); }
+
 // the address kernels use for pinned host memory of clhip_host_alloc (NULL when the device cannot reach it)
 extern "C" void *clhip_host_device_ptr(void *h)
 {
@@ -182,11 +186,19 @@ extern "C" void clhip_host_unregister(void *h)
 // runtime, ~1 us) is copied in pieces below the threshold: each piece goes through the runtime's own pinned staging buffers
 // and the device never touches the caller's pages.  Order on the stream is kept; pinned memory is copied in one piece.
 #define CLHIP_PAGEABLE_PIECE ((size_t)512 << 10)
-static bool clhip_host_is_pinned(const void *h)
+static bool clhip_host_byte_is_pinned(const void *h)
 {
     hipPointerAttribute_t a;
     if (hipPointerGetAttributes(&a, h) != hipSuccess) { (void)hipGetLastError(); return false; }   // unknown to the runtime: plain pageable memory
     return a.type == hipMemoryTypeHost;
+}
+// The WHOLE range, not its first byte: registrations are whole pages, so a neighbouring registration (somebody else's buffer that ends
+// in the page this one starts in) makes the head of a pageable buffer look page-locked -- a copy of the whole range then fails in the
+// runtime ("invalid argument"; found by the group's random walk: the lone devices' buffers lie next to the registered ones).
+static bool clhip_host_is_pinned(const void *h, size_t n)
+{
+    return clhip_host_byte_is_pinned(h) && clhip_host_byte_is_pinned((const uint8_t *)h + (n ? n - 1 : 0)) &&
+           clhip_host_byte_is_pinned((const uint8_t *)h + n / 2);
 }
 // what kind of copy this is, noted in the operation ring and the counters (clhip_debug_copy_counters: a test asserts that no
 // pageable range above one piece ever reaches a single hipMemcpyAsync)
@@ -196,7 +208,7 @@ static bool clhip_copy_in_pieces(const void *h, size_t n, bool h2d)
         // (small copies are staged by the runtime whatever the memory is; asking what it is would cost more than the copy's set-up)
         return false;
     }
-    const bool pinned = clhip_host_is_pinned(h);
+    const bool pinned = clhip_host_is_pinned(h, n);
     clhip_note_op(pinned ? (h2d ? CLHIP_OP_H2D_LOCKED : CLHIP_OP_D2H_LOCKED) : (h2d ? CLHIP_OP_H2D_PIECES : CLHIP_OP_D2H_PIECES), h, n);
     if (pinned) { g_copy_ctr[1].fetch_add(1, std::memory_order_relaxed); return false; }
     g_copy_ctr[0].fetch_add(1, std::memory_order_relaxed);
@@ -209,17 +221,47 @@ static void clhip_note_pageable_piece(size_t m)
     while (m > cur && !g_copy_ctr[2].compare_exchange_weak(cur, m, std::memory_order_relaxed)) {}
 }
 
+// A host range that the runtime refuses as one copy ("invalid argument"): it STRADDLES the edge of somebody's registration --
+// registrations are whole pages, so a registered buffer that ends inside a page pins the head of whatever the heap placed behind it,
+// and a copy that starts in that page and runs on into pageable memory is neither one thing nor the other to the runtime (found by
+// the stream group's random walk: the lone devices' client buffers lay right behind the group's registered ones in the heap).  Such
+// a range is walked page by page and copied in runs of one kind: page-locked runs whole, pageable runs in pieces.  Rare, hence on the
+// error path only: the normal copy costs nothing for it.
+static int clhip_copy_straddling(void *dev, void *host, size_t n, bool h2d, hipStream_t s)
+{
+    (void)hipGetLastError();
+    const uintptr_t page = 4096;
+    size_t o = 0;
+    while (o < n) {
+        const bool pinned = clhip_host_byte_is_pinned((char *)host + o);
+        size_t e = (size_t)((((uintptr_t)host + o) | (page - 1)) + 1 - (uintptr_t)host);      // the end of this byte's page
+        while (e < n && clhip_host_byte_is_pinned((char *)host + e) == pinned && (pinned || e - o < CLHIP_PAGEABLE_PIECE)) e += page;
+        if (e > n) e = n;
+        if (!pinned) clhip_note_pageable_piece(e - o);
+        CLHIP_CHECK(h2d ? hipMemcpyAsync((char *)dev + o, (char *)host + o, e - o, hipMemcpyHostToDevice, s)
+                        : hipMemcpyAsync((char *)host + o, (char *)dev + o, e - o, hipMemcpyDeviceToHost, s));
+        o = e;
+    }
+    return 0;
+}
+#define CLHIP_COPY_OR_STRADDLE(call, dev, host, n, h2d, s)                                             \
+    do {                                                                                               \
+        const hipError_t first_ = (call);                                                              \
+        if (first_ == hipErrorInvalidValue) return clhip_copy_straddling((void *)(dev), (void *)(host), (n), (h2d), (hipStream_t)(s)); \
+        CLHIP_CHECK(first_);                                                                           \
+    } while (0)
+
 extern "C" int clhip_memcpy_h2d(void *d, const void *h, size_t n, void *s)
 {
     if (clhip_copy_in_pieces(h, n, true)) {
         for (size_t o = 0; o < n; o += CLHIP_PAGEABLE_PIECE) {
             const size_t m = n - o < CLHIP_PAGEABLE_PIECE ? n - o : CLHIP_PAGEABLE_PIECE;
             clhip_note_pageable_piece(m);
-            CLHIP_CHECK(hipMemcpyAsync((char *)d + o, (const char *)h + o, m, hipMemcpyHostToDevice, (hipStream_t)s));
+            CLHIP_COPY_OR_STRADDLE(hipMemcpyAsync((char *)d + o, (const char *)h + o, m, hipMemcpyHostToDevice, (hipStream_t)s), (char *)d + o, (const char *)h + o, n - o, true, s);
         }
         return 0;
     }
-    CLHIP_CHECK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, (hipStream_t)s));
+    CLHIP_COPY_OR_STRADDLE(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, (hipStream_t)s), d, h, n, true, s);
     return 0;
 }
 extern "C" int clhip_memcpy_d2h(void *h, const void *d, size_t n, void *s)
@@ -228,11 +270,11 @@ extern "C" int clhip_memcpy_d2h(void *h, const void *d, size_t n, void *s)
         for (size_t o = 0; o < n; o += CLHIP_PAGEABLE_PIECE) {
             const size_t m = n - o < CLHIP_PAGEABLE_PIECE ? n - o : CLHIP_PAGEABLE_PIECE;
             clhip_note_pageable_piece(m);
-            CLHIP_CHECK(hipMemcpyAsync((char *)h + o, (const char *)d + o, m, hipMemcpyDeviceToHost, (hipStream_t)s));
+            CLHIP_COPY_OR_STRADDLE(hipMemcpyAsync((char *)h + o, (const char *)d + o, m, hipMemcpyDeviceToHost, (hipStream_t)s), (const char *)d + o, (char *)h + o, n - o, false, s);
         }
         return 0;
     }
-    CLHIP_CHECK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, (hipStream_t)s));
+    CLHIP_COPY_OR_STRADDLE(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, (hipStream_t)s), d, h, n, false, s);
     return 0;
 }
 // `height` rows of `width` bytes from PAGE-LOCKED host memory (rows h_pitch apart) to device rows d_pitch apart, one runtime call: the
@@ -243,7 +285,7 @@ extern "C" int clhip_memcpy_d2h(void *h, const void *d, size_t n, void *s)
 extern "C" int clhip_memcpy2d_h2d(void *d, size_t d_pitch, const void *h, size_t h_pitch, size_t width, size_t height, void *s)
 {
     if (!width || !height) return 0;
-    if (!clhip_host_is_pinned(h)) { clhip_set_error("clhip_memcpy2d_h2d: the source is not page-locked memory"); return -1; }
+    if (!clhip_host_is_pinned(h, h_pitch * (height - 1) + width)) { clhip_set_error("clhip_memcpy2d_h2d: the source is not page-locked memory"); return -1; }
     clhip_note_op(CLHIP_OP_H2D_LOCKED, h, h_pitch * (height - 1) + width);
     g_copy_ctr[1].fetch_add(1, std::memory_order_relaxed);
     CLHIP_CHECK(hipMemcpy2DAsync(d, d_pitch, h, h_pitch, width, height, hipMemcpyHostToDevice, (hipStream_t)s));

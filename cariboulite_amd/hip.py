@@ -51,6 +51,7 @@ _SIGS = {
     "clhip_debug_ops": (C.c_size_t, [C.c_void_p, C.c_size_t]),
     "clhip_debug_ops_dump": (None, [C.c_int]),
     "clhip_debug_copy_counters": (None, [C.c_void_p]),
+    "clhip_debug_sticky_error": (C.c_int, []),
     "clhip_smi_find_offsets": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]),
     "clhip_smi_unpack": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p,
                                    C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -120,6 +120,7 @@ typedef struct { uint64_t seq; uint32_t op; uint32_t pad; uint64_t base; uint64_
 size_t      clhip_debug_ops(clhip_op_record *out, size_t max);
 void        clhip_debug_ops_dump(int fd);
 void        clhip_debug_copy_counters(uint64_t out[4]);
+int         clhip_debug_sticky_error(void);          /* the runtime's pending "last error" of this thread, consumed (0: none): nothing handled may leave one behind */
 int         clhip_memset(void *d_dst, int value, size_t bytes, void *stream);
 void       *clhip_stream_create(void);
 void        clhip_stream_destroy(void *stream);

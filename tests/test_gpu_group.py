@@ -479,7 +479,7 @@ def test_32_streams_with_every_batch_pending_beforehand(S, fmt, dtype, args, sha
 
 
 @pytest.mark.parametrize("seed,staged,filters", [(1, True, 0), (2, True, 0), (3, False, 0), (4, False, 0), (5, True, 0), (6, False, 0), (7, True, 0), (8, False, 0), (9, False, 0),
-                                                 (10, True, 0), (11, False, 1), (12, False, 1), (13, False, 1), (14, True, 1)])
+                                                 (10, True, 0), (11, False, 1), (12, False, 1), (13, False, 1), (14, True, 1), (15, False, 2), (16, False, 2)])
 def test_random_walk_against_lone_devices(S, seed, staged, filters):
     """A seeded random walk over everything a client can do between and in group calls -- feed whole / half / damaged / no batches to
     some members, ask for a whole or half MTU, read a member through its own device (plain lanes), flush one, switch a low-pass on or
@@ -490,10 +490,13 @@ def test_random_walk_against_lone_devices(S, seed, staged, filters):
     args = {"FIR": "64:1000000", "RESAMP": "3/2"} if staged else None
     full = MTU * 3 // 2 if staged else MTU
     chan = lambda i: "S1G" if i % 2 else "HiF"
-    gdevs, gsts = make_devices(S, n, S.SOAPY_SDR_CF32, args, chan)
-    sdevs, ssts = make_devices(S, n, S.SOAPY_SDR_CF32, args, chan)
+    cs16 = filters == 2                                    # (seeds 15, 16: the reference's own format -- calls above one MTU are not clamped, the client's buffer is the persistent one)
+    fmt, dtype = (S.SOAPY_SDR_CS16, np.int16) if cs16 else (S.SOAPY_SDR_CF32, np.float32)
+    gdevs, gsts = make_devices(S, n, fmt, args, chan)
+    sdevs, ssts = make_devices(S, n, fmt, args, chan)
     grp = S.Group(gdevs, {"SUBBATCH": "2", "SLAB_MB": "4"})
-    gb, sb = sentinel_buffers(n, (full + 8, 2), np.float32), sentinel_buffers(n, (full + 8, 2), np.float32)
+    rows = 2 * MTU + 8 if cs16 else full + 8
+    gb, sb = sentinel_buffers(n, (rows, 2), dtype), sentinel_buffers(n, (rows, 2), dtype)
     fed = [0] * n                                          # batches fed per stream so far
 
     def feed(i, how):
@@ -526,9 +529,9 @@ def test_random_walk_against_lone_devices(S, seed, staged, filters):
         for i in range(n):                                 # keep most FIFOs two to four batches deep
             while gdevs[i].pendingSmiBytes() < int(rng.integers(1, 4)) * NB:
                 feed(i, rng.choice(["good"] * 12 + ["slip", "lost", "half"]))
-        op = rng.choice(["call"] * 5 + ["half", "lone", "flush", "filter", "register", "maxread"] + ["filter_all"] * (2 * filters))
+        op = rng.choice(["call"] * 5 + ["half", "lone", "flush", "filter", "register", "maxread"] + ["filter_all"] * (2 * (filters == 1)))
         for x in gb + sb:
-            x[...] = np.nan
+            x[...] = np.nan if not cs16 else SENT
         if op == "maxread":                                # one member's driver hands out shorter read()s from now on (or whole ones again)
             i = int(rng.integers(0, n)); m = int(rng.choice([0, NB // 2, 100000]))
             gdevs[i].setMaxRead(m); sdevs[i].setMaxRead(m); hist[i].append(f"maxread{m}")
@@ -556,13 +559,27 @@ def test_random_walk_against_lone_devices(S, seed, staged, filters):
                 grp.registerBuffers(gb)
             registered = not registered
         num = MTU // 2 if op == "half" else MTU
+        if cs16 and rng.integers(0, 6) == 0:
+            num = int(rng.choice([MTU + 4096, 2 * MTU]))    # a chunk loop of several read()s, member by member
         for x in gb + sb:
-            x[...] = np.nan
+            x[...] = np.nan if not cs16 else SENT
+        from cariboulite_amd import hip as _hip
+        assert _hip.lib().clhip_debug_sticky_error() == 0, ("a handled HIP error was left pending before the group call", step, str(op))
         _, rets = grp.readStream(gb, num)
-        srets = [sdevs[i].readStream(ssts[i], [sb[i]], num).ret for i in range(n)]
+        assert _hip.lib().clhip_debug_sticky_error() == 0, ("the group call left a handled HIP error pending", step, str(op), num)
+        srets = []
+        for i in range(n):
+            srets.append(sdevs[i].readStream(ssts[i], [sb[i]], num).ret)
+            e = _hip.lib().clhip_debug_sticky_error()
+            if e:
+                print("DIAG lone read", step, str(op), num, i, srets, "sticky", e, "hip:", _hip.last_error(), "dev:", sdevs[i].lastError(), "hist", hist[i], flush=True)
+            assert e == 0, ("a lone read left a handled HIP error pending", step, i)
         for i in range(n):
             hist[i].append(f"<{op}:{num}:{rets[i]}>")
-        assert rets == srets, (step, op, rets, srets)
+        if rets != srets:
+            from cariboulite_amd import hip
+            bad = [i for i in range(n) if rets[i] != srets[i]]
+            raise AssertionError((step, str(op), num, rets, srets, [(i, sdevs[i].lastError(), gdevs[i].lastError()) for i in bad], hip.last_error(), grp.lastError()))
         compare((str(op), step))
     st = grp.stats()
     assert st["errors"] == 0 and st["single_reads"] > 5 and (filters or st["ahead_reads"] > 40), st

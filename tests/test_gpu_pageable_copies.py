@@ -82,3 +82,45 @@ def test_no_pageable_range_above_one_piece_reaches_a_runtime_copy(tmp_path):
     kinds = {op for op, _ in res["ops"]}
     assert kinds <= {4, 5, 6, 7}, kinds                                    # no registration of anybody's memory along the way
     assert all(ln > 512 << 10 for _, ln in res["ops"])                     # (the ring notes copies above one piece only)
+
+
+@pytest.mark.gpu
+def test_a_pageable_buffer_that_starts_in_a_registered_page_is_copied_in_pieces():
+    """Registrations are whole pages: a client's registered buffer that ends in the middle of a page pins the head of whatever lies
+    behind it.  A copy to or from that neighbour -- pageable, 2 MiB -- used to be taken for page-locked by its first byte and handed
+    to the runtime whole, which refused it (found by the stream group's random walk: the lone devices' buffers lie right behind the
+    registered ones).  The WHOLE range decides now: such a copy goes in pieces, both directions, bytes intact."""
+    import numpy as np
+    import torch
+    from cariboulite_amd import hip
+    assert torch.cuda.is_available()
+    page = 4096
+    raw = np.zeros(8 * (1 << 20) + 2 * page, np.uint8)
+    base = (-raw.ctypes.data) % page                              # a page-aligned carve
+    a = raw[base: base + (1 << 20) + 100]                         # ends 100 bytes into a page ...
+    b = raw[base + (1 << 20) + 100: base + (1 << 20) + 100 + (2 << 20)]      # ... in which the pageable neighbour starts
+    assert hip.lib().clhip_host_register(a.ctypes.data, a.size)
+    try:
+        c0 = np.zeros(4, np.uint64); hip.lib().clhip_debug_copy_counters(c0.ctypes.data)
+        b[:] = np.arange(b.size, dtype=np.uint32).astype(np.uint8)
+        d = torch.zeros(b.size, dtype=torch.uint8, device="cuda:0")
+        s = hip.current_stream()
+        assert hip.lib().clhip_memcpy_h2d(d.data_ptr(), b.ctypes.data, b.size, s) == 0
+        back = np.zeros_like(b)
+        assert hip.lib().clhip_memcpy_d2h(back.ctypes.data, d.data_ptr(), b.size, s) == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(back, b) and np.array_equal(d.cpu().numpy(), b)
+        c1 = np.zeros(4, np.uint64); hip.lib().clhip_debug_copy_counters(c1.ctypes.data)
+        assert c1[0] - c0[0] >= 1 and c1[2] <= 512 << 10            # (in pieces; nothing above one piece went to the runtime in one go)
+        # ... and a copy below the piece size, which the library hands to the runtime without asking what the memory is: the runtime
+        # refuses a range that starts page-locked and ends pageable; the library then walks it page by page
+        small = b[: 300000]
+        back2 = np.zeros_like(small)
+        assert hip.lib().clhip_memcpy_d2h(back2.ctypes.data, d.data_ptr(), small.size, s) == 0
+        assert hip.lib().clhip_memcpy_h2d(d.data_ptr() + (1 << 20), small.ctypes.data, small.size, s) == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(back2, small) and np.array_equal(d[1 << 20: (1 << 20) + small.size].cpu().numpy(), small)
+        assert hip.lib().clhip_debug_sticky_error() == 0            # nothing handled is left pending for the next launch to trip over
+    finally:
+        torch.cuda.synchronize()
+        hip.lib().clhip_host_unregister(a.ctypes.data)
