@@ -69,13 +69,16 @@ def test_one_device_against_the_reference_model(S, orc, seed, fmt):
     from cariboulite_amd import synth
     rng = np.random.default_rng(100 + seed)
     ch = seed % 2
+    zc = seed % 4 == 2                                             # (seeds 2, 6, 10, 14: ZEROCOPY=1 with the client's buffer registered -- the last kernel stores into it)
     dev = S.Device(dict(driver="Cariboulite", channel="S1G" if ch == 0 else "HiF"))
-    st = dev.setupStream(S.SOAPY_SDR_RX, fmt)
+    st = dev.setupStream(S.SOAPY_SDR_RX, fmt, args={"ZEROCOPY": "1"} if zc else None)
     dev.activateStream(st)
     ref = RefDevice(orc, ch, fmt)
     dt = {"CS16": np.int16, "CF32": np.float32, "CF64": np.float64, "CS8": np.int8}[fmt]
     rows = 2 * MTU + 16
     got, want = np.zeros((rows, 2), dt), np.zeros((rows, 2), dt)        # the client's buffers persist across calls (CS16: untouched slots)
+    if zc:
+        dev.registerStreamBuffer(st, got)
     fed = 0
     stats = dict(resync=0, lost=0, short=0, ragged=0, multi=0)
     for step in range(60):
@@ -112,6 +115,8 @@ def test_one_device_against_the_reference_model(S, orc, seed, fmt):
         stats["short"] += 0 < r_dev < min(num, MTU if fmt != "CS16" else num)
         stats["multi"] += num > MTU
     assert stats["resync"] + stats["lost"] >= 2, stats             # (the walk went where it is meant to go)
+    if zc:
+        assert dev.streamStats(st)["zero_copy_reads"] >= 10
     dev.close()
 
 
