@@ -70,7 +70,7 @@ typedef struct {
     cl_read_ctx *ctx;                          /* per call and row: a one-by-one member's read in flight (lanes without extension stages) */
     /* the reference's low-pass over whole sub-batches (lanes without extension stages): one multi-stream filter object per (filter,
      * sub-batch), made when first needed; a member's carried state lives EITHER in its stream's own objects or here (iir_own) */
-    clhip_iir **giir; int n_subs; uint8_t *iir_own; int16_t *d_f; uint8_t *sub_ft; uint8_t *how;
+    clhip_iir **giir; int n_subs; uint8_t *iir_own; int16_t *d_f[2]; uint8_t *sub_ft; uint8_t *how;   /* (d_f: filtered int16 rows of this call's / the next call's set) */
     uint8_t *ahead_ft;                         /* per sub-batch: the filter of a filter launch made AHEAD (its results in the other mirror; 0: none) */
     uint8_t *sub_verdict;                      /* per call and sub-batch: 0 = its filter launch has not been asked yet; 1 = good; 2 = gave up twice (nothing to deliver); 3 = runtime error */
     int epoch_open;                            /* the pipe's epoch of the NEXT call was opened by the read-ahead */
@@ -258,7 +258,7 @@ static void lane_free(lane_t *l)
     clhip_host_free(l->tx_h_in); clhip_free(l->tx_d_in); free(l->tx_pend);
     free(l->done_ahead); free(l->ahead_got); free(l->direct); free(l->ctx);
     for (int i = 0; l->giir && i < 3 * l->n_subs; i++) clhip_iir_destroy(l->giir[i]);
-    free(l->giir); free(l->iir_own); free(l->sub_ft); free(l->ahead_ft); free(l->sub_verdict); free(l->how); clhip_free(l->d_f);
+    free(l->giir); free(l->iir_own); free(l->sub_ft); free(l->ahead_ft); free(l->sub_verdict); free(l->how); clhip_free(l->d_f[0]); clhip_free(l->d_f[1]);
     free(l->member); free(l->fast); free(l->len); free(l->got); free(l->src); free(l->ahead_mark);
     memset(l, 0, sizeof *l);
 }
@@ -444,8 +444,8 @@ cl_group *cl_group_make(cl_device *const *devs, size_t n, const char *const *key
         if (l->route == ROUTE_PLAIN) {
             l->giir = (clhip_iir **)calloc((size_t)3 * (size_t)l->n_subs, sizeof(clhip_iir *)); l->iir_own = (uint8_t *)calloc((size_t)3 * (size_t)l->n, 1);
             l->sub_ft = (uint8_t *)calloc((size_t)l->n_subs, 1); l->ahead_ft = (uint8_t *)calloc((size_t)l->n_subs, 1); l->sub_verdict = (uint8_t *)calloc((size_t)l->n_subs, 1);
-            l->d_f = (int16_t *)clhip_malloc((size_t)l->n * l->out_stride * 4 + 256);
-            if (!l->giir || !l->iir_own || !l->sub_ft || !l->ahead_ft || !l->sub_verdict || !l->d_f) { cl_seterr(g_make_err, sizeof g_make_err, "cl_group_make: filter buffers"); cl_group_unmake(g); return NULL; }
+            l->d_f[0] = (int16_t *)clhip_malloc((size_t)l->n * l->out_stride * 4 + 256); l->d_f[1] = (int16_t *)clhip_malloc((size_t)l->n * l->out_stride * 4 + 256);
+            if (!l->giir || !l->iir_own || !l->sub_ft || !l->ahead_ft || !l->sub_verdict || !l->d_f[0] || !l->d_f[1]) { cl_seterr(g_make_err, sizeof g_make_err, "cl_group_make: filter buffers"); cl_group_unmake(g); return NULL; }
             for (int r = 0; r < l->n; r++) {
                 cl_stream *st = g->dev[l->member[r]]->stream;
                 st->iir_home = iir_home; st->iir_home_ctx = g; st->iir_home_member = l->member[r];

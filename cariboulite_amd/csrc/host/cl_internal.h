@@ -83,7 +83,7 @@ struct cl_smi {
     /* the raw words of the previous call when they went straight into the caller's own kernel (which never materialises
      * int16 samples in d_iq), kept so that a re-sync in a LATER call finds in d_iq what the reference's persistent
      * intermediate buffer would hold in the slots it leaves untouched (cl_smi_restore_prev_words) */
-    const uint8_t *prev_words; size_t prev_words_len;
+    const uint8_t *prev_words; size_t prev_words_len; int prev_is_cs16;   /* (… or the int16 samples a filtered call delivered: cl_smi_set_prev_cs16) */
     int16_t *d_iq; size_t iq_cap;         /* samples */
     uint8_t *d_meta; size_t meta_cap;
     uint8_t *h_stage; size_t h_stage_cap; /* pinned host staging */
@@ -127,6 +127,7 @@ int cl_smi_read_device(cl_smi *dev, int channel, size_t length_samples, int want
 int cl_smi_read_device_to(cl_smi *dev, int channel, size_t length_samples, int16_t *d_iq, uint8_t *d_meta, int *all_aligned);
 int cl_smi_ensure_iq(cl_smi *dev, size_t samples);   /* dev->d_iq holds at least `samples` int16 pairs: zeros at first, contents kept when it grows (0 / -1) */
 int cl_smi_set_prev_words(cl_smi *dev, int channel, const uint8_t *w, size_t len);   /* raw words that stand in for dev->d_iq from now on (0 / -1) */
+int cl_smi_set_prev_cs16(cl_smi *dev, int channel, const int16_t *p, size_t n_samples);   /* int16 samples (what a filtered call delivered) that stand in for dev->d_iq */
 int cl_smi_restore_prev_words(cl_smi *dev, int channel);   /* bring dev->d_iq up to date from the previous call's raw words (0 / -1) */
 /* the same chunk loop, one chunk at a time, with the next read() staged and copied ahead (reader threads) */
 int cl_smi_read_device_ra(cl_smi *dev, int channel, size_t length_samples, int16_t *d_iq);

@@ -717,9 +717,11 @@ int cl_smi_restore_prev_words(cl_smi *dev, int channel)
     if (!dev->prev_words) return 0;
     const uint8_t *w = dev->prev_words;
     const size_t n = dev->prev_words_len;
-    dev->prev_words = NULL;
+    const int cs16 = dev->prev_is_cs16;
+    dev->prev_words = NULL; dev->prev_is_cs16 = 0;
     if (cl_smi_ensure_iq(dev, n / 4 + 8)) return -1;
     /* (synchronised: the copy stream may stage into that slot as soon as this call moves on) */
+    if (cs16) return clhip_memcpy_d2d(dev->d_iq, w, n, dev->stream) || clhip_stream_sync(dev->stream) ? -1 : 0;
     return clhip_smi_unpack_aligned(channel, w, n, CL_FORMAT_CS16, dev->d_iq, NULL, dev->stream) || clhip_stream_sync(dev->stream) ? -1 : 0;
 }
 
@@ -729,7 +731,17 @@ int cl_smi_restore_prev_words(cl_smi *dev, int channel)
 int cl_smi_set_prev_words(cl_smi *dev, int channel, const uint8_t *w, size_t len)
 {
     if (dev->prev_words && dev->prev_words_len > len && cl_smi_restore_prev_words(dev, channel)) return -1;
-    dev->prev_words = w; dev->prev_words_len = len;
+    dev->prev_words = w; dev->prev_words_len = len; dev->prev_is_cs16 = 0;
+    return 0;
+}
+
+/* The same with int16 SAMPLES (n of them, device-readable): what a call that ran the low-pass delivered.  The reference filters in
+ * place in the buffer it read into (CaribouliteStream.cpp:282-301: interm_native_buffer2, or the client's own buffer for CS16), so
+ * the slots a later re-synchronised read() leaves untouched hold FILTERED samples there -- and go through the filter again. */
+int cl_smi_set_prev_cs16(cl_smi *dev, int channel, const int16_t *p, size_t n_samples)
+{
+    if (dev->prev_words && dev->prev_words_len > 4 * n_samples && cl_smi_restore_prev_words(dev, channel)) return -1;
+    dev->prev_words = (const uint8_t *)p; dev->prev_words_len = 4 * n_samples; dev->prev_is_cs16 = 1;
     return 0;
 }
 

@@ -471,6 +471,8 @@ static void *client_device_addr(cl_stream *st, void *out, size_t bytes)
 
 static void zc_drop_all(cl_stream *st)
 {
+    /* (the seam's persistent buffer may be standing on filtered samples in a registered client buffer: taken over before it goes) */
+    if (st->zc_n && st->dev && st->dev->smi && st->dev->smi->prev_is_cs16) cl_smi_restore_prev_words(st->dev->smi, st->dev->channel);
     for (int i = 0; i < st->zc_n; i++) clhip_host_unregister(st->zc[i].base);
     st->zc_n = 0;
 }
@@ -524,6 +526,8 @@ static int sink_open(cl_stream *st, void *out, size_t bytes, cl_sink *sk)
 {
     sk->d_dst = client_device_addr(st, out, bytes);
     if (sk->d_dst) { sk->kind = CL_SINK_CLIENT; return 0; }
+    /* (the seam's persistent buffer may be standing on filtered samples in one of the buffers that is about to grow) */
+    if ((bytes + 64 > st->h_conv_cap || bytes + 64 > st->conv_cap) && st->dev->smi->prev_is_cs16 && cl_smi_restore_prev_words(st->dev->smi, st->dev->channel)) return -1;
     if (cl_ensure((void **)&st->h_conv, &st->h_conv_cap, bytes + 64, 1, 1)) return -1;
     if (bytes <= CL_MIRROR_MAX_BYTES && (sk->d_dst = clhip_host_device_ptr(st->h_conv)) != NULL) { sk->kind = CL_SINK_MIRROR; return 0; }
     if (cl_ensure(&st->d_conv, &st->conv_cap, bytes + 64, 1, 0)) return -1;
@@ -564,12 +568,14 @@ static const int16_t *filter_source(cl_device *dev, cl_stream *st, const cl_sour
          * conversion -- no unpack launch, no int16 intermediate.  Only when the filter is on its scan path (it has overrun before,
          * or its memory is too long for the single-pass kernel: -2) are the words unpacked first. */
         const int rc = clhip_iir_run_smi(flt, dev->channel, src->d_words, d_dst, n, n, src->hs);
-        if (rc == 0) return d_dst;
+        if (rc == 0) return cl_smi_set_prev_cs16(smi, dev->channel, d_dst, n) ? NULL : d_dst;
         if (rc != -2 || clhip_smi_unpack_aligned(dev->channel, src->d_words, n * 4, CL_FORMAT_CS16, smi->d_iq, NULL, src->hs)) return NULL;
         smi->prev_words = NULL;                            /* (the persistent int16 buffer is current now) */
         d_raw = smi->d_iq;
     }
-    return clhip_iir_run(flt, d_raw, d_dst, n, n, src->hs) ? NULL : d_dst;
+    if (clhip_iir_run(flt, d_raw, d_dst, n, n, src->hs)) return NULL;
+    /* what the call delivers IS the persistent buffer from now on: the reference filters in place in the buffer it read into */
+    return cl_smi_set_prev_cs16(smi, dev->channel, d_dst, n) ? NULL : d_dst;
 }
 
 /* queue the call's stages on src->hs, the last one storing into the sink; *got = elements the call yields.  0 or -1 */
