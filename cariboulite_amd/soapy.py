@@ -104,6 +104,7 @@ _SIGS = {
     "cl_group_readStream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t, C.POINTER(C.c_int), C.c_long]),
     "cl_group_writeStream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t, C.POINTER(C.c_int), C.c_long]),
     "cl_group_set_iir_poll_bound": (None, [C.c_void_p, C.c_int]),
+    "cl_group_flush": (C.c_int, [C.c_void_p]),
     "cl_group_last_error": (C.c_char_p, [C.c_void_p]),
     "cl_group_getStats": (None, [C.c_void_p, C.c_void_p]),
     "cl_group_register_buffers": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t]),
@@ -419,6 +420,9 @@ class Group:
 
     def lastError(self):
         return lib().cl_group_last_error(self.h).decode()
+
+    def flush(self):
+        return lib().cl_group_flush(self.h)
 
     def setIirPollBound(self, polls):
         lib().cl_group_set_iir_poll_bound(self.h, polls)

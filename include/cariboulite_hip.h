@@ -635,6 +635,7 @@ int         cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems
  * group is unmade.  Returns the number of members that consumed elements, or -1 (cl_group_last_error).  cl_group_getStats:
  * batched_reads / single_reads count the writes. */
 int         cl_group_writeStream(cl_group *g, const void *const *buffs, size_t numElems, int *rets, long timeoutUs);
+int         cl_group_flush(cl_group *g);                      /* a TX group: wait for what cl_group_writeStream has in flight and commit it (0 / -1); a no-op for an RX group */
 const char *cl_group_last_error(const cl_group *g);
 void        cl_group_getStats(const cl_group *g, cl_group_stats *out);
 void        cl_group_set_iir_poll_bound(cl_group *g, int polls);      /* test hook: clhip_iir_set_poll_bound for the group's own filter objects */

@@ -77,6 +77,8 @@ def run_tx_case(name, a):
                 else:
                     for i in range(n):
                         assert devs[i].writeStream(sts[i], [bufs[i]], MTU).ret == MTU
+            if grp is not None:
+                assert grp.flush() == 0                    # (write-behind: the last call's launches belong to the timed region)
             dt_s = time.perf_counter() - t0
             for d in devs:
                 assert d.drainSmiBytes().size == K * MTU * 4
