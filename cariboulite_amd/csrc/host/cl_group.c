@@ -71,6 +71,7 @@ typedef struct {
     /* the reference's low-pass over whole sub-batches (lanes without extension stages): one multi-stream filter object per (filter,
      * sub-batch), made when first needed; a member's carried state lives EITHER in its stream's own objects or here (iir_own) */
     clhip_iir **giir; int n_subs; uint8_t *iir_own; int16_t *d_f[2]; uint8_t *sub_ft; uint8_t *how;   /* (d_f: filtered int16 rows of this call's / the next call's set) */
+    size_t f_stride;                            /* int16 pairs per row of d_f (= the input rows' stride in words) */
     uint8_t *ahead_ft;                         /* per sub-batch: the filter of a filter launch made AHEAD (its results in the other mirror; 0: none) */
     uint8_t *sub_verdict;                      /* per call and sub-batch: 0 = its filter launch has not been asked yet; 1 = good; 2 = gave up twice (nothing to deliver); 3 = runtime error */
     int epoch_open;                            /* the pipe's epoch of the NEXT call was opened by the read-ahead */
@@ -441,10 +442,11 @@ cl_group *cl_group_make(cl_device *const *devs, size_t n, const char *const *key
         l->sub = g->sub ? g->sub : l->out_stride * l->elem_bytes >= ((size_t)3 << 19) ? 4 : 8;
         n_sub += ((size_t)l->n + (size_t)l->sub - 1) / (size_t)l->sub;
         l->n_subs = (l->n + l->sub - 1) / l->sub;
-        if (l->route == ROUTE_PLAIN) {
+        if (l->route == ROUTE_PLAIN || l->route == ROUTE_PIPE) {
+            l->f_stride = l->in_stride / 4;
             l->giir = (clhip_iir **)calloc((size_t)3 * (size_t)l->n_subs, sizeof(clhip_iir *)); l->iir_own = (uint8_t *)calloc((size_t)3 * (size_t)l->n, 1);
             l->sub_ft = (uint8_t *)calloc((size_t)l->n_subs, 1); l->ahead_ft = (uint8_t *)calloc((size_t)l->n_subs, 1); l->sub_verdict = (uint8_t *)calloc((size_t)l->n_subs, 1);
-            l->d_f[0] = (int16_t *)clhip_malloc((size_t)l->n * l->out_stride * 4 + 256); l->d_f[1] = (int16_t *)clhip_malloc((size_t)l->n * l->out_stride * 4 + 256);
+            l->d_f[0] = (int16_t *)clhip_malloc((size_t)l->n * l->f_stride * 4 + 256); l->d_f[1] = (int16_t *)clhip_malloc((size_t)l->n * l->f_stride * 4 + 256);
             if (!l->giir || !l->iir_own || !l->sub_ft || !l->ahead_ft || !l->sub_verdict || !l->d_f[0] || !l->d_f[1]) { cl_seterr(g_make_err, sizeof g_make_err, "cl_group_make: filter buffers"); cl_group_unmake(g); return NULL; }
             for (int r = 0; r < l->n; r++) {
                 cl_stream *st = g->dev[l->member[r]]->stream;
