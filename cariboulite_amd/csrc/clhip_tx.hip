@@ -1184,6 +1184,36 @@ extern "C" size_t clhip_tx_pipe_out_count(const clhip_tx_pipe *p, size_t n_in)
     return (size_t)((n1 * p->L + p->M - 1) / p->M - (n0 * p->L + p->M - 1) / p->M);
 }
 
+// The carried state of ONE stream -- the modulator's phase and the resampler's history -- moves from one pipe to another of the same
+// configuration (a stream group's multi-stream pipe <-> a member's own: cl_group_writeStream).  The polyphase position is the PIPE's
+// (its streams advance together): _position / _set_position.  Both pipes idle: their last runs synchronised and asked for their verdict.
+extern "C" unsigned long long clhip_tx_pipe_position(const clhip_tx_pipe *p) { return p ? p->n_total : 0; }
+extern "C" int clhip_tx_pipe_pack_mode(const clhip_tx_pipe *p) { return p ? p->pack_mode : -1; }
+
+extern "C" int clhip_tx_pipe_set_position(clhip_tx_pipe *p, unsigned long long n_total)
+{
+    if (!p) { clhip_set_error("clhip_tx_pipe_set_position: null pipe"); return -1; }
+    p->n_total = n_total; p->can_undo = false;
+    return 0;
+}
+
+extern "C" int clhip_tx_pipe_move_stream(clhip_tx_pipe *dst, int ds, clhip_tx_pipe *src, int ss, void *stream)
+{
+    if (!dst || !src || ds < 0 || ss < 0 || ds >= dst->n_streams || ss >= src->n_streams) { clhip_set_error("clhip_tx_pipe_move_stream: bad arguments"); return -1; }
+    if (dst->L != src->L || dst->M != src->M || dst->n_rs != src->n_rs || dst->w != src->w || memcmp(dst->rs, src->rs, sizeof(float) * (size_t)src->n_rs)) {
+        clhip_set_error("clhip_tx_pipe_move_stream: the pipes are configured differently");
+        return -1;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int H = src->kp - 1;
+    if (H > 0)
+        CLHIP_CHECK(hipMemcpyAsync(dst->hist[dst->cur] + (size_t)ds * H, src->hist[src->cur] + (size_t)ss * H, sizeof(f32x2) * (size_t)H, hipMemcpyDeviceToDevice, s));
+    CLHIP_CHECK(hipMemcpyAsync(dst->d_phase + ds, src->d_phase + ss, sizeof(double), hipMemcpyDeviceToDevice, s));
+    CLHIP_CHECK(hipStreamSynchronize(s));
+    dst->can_undo = false; src->can_undo = false;      // (a roll-back would bring the other halves of the ping-pong state back)
+    return 0;
+}
+
 extern "C" long clhip_tx_pipe_run(clhip_tx_pipe *p, int in_kind, const void *d_in, size_t in_stride, size_t n_in,
                                   uint8_t *d_bytes, size_t out_stride_bytes, float *d_iq_tap, size_t iq_tap_stride,
                                   void *stream)

@@ -35,7 +35,7 @@
 
 #include "cl_internal.h"
 
-enum { ROUTE_PIPE = 1, ROUTE_PLAIN = 2, ROUTE_TX_PLAIN = 3, ROUTE_TX_SINGLE = 4 };
+enum { ROUTE_PIPE = 1, ROUTE_PLAIN = 2, ROUTE_TX_PLAIN = 3, ROUTE_TX_SINGLE = 4, ROUTE_TX_PIPE = 5 };
 
 typedef struct { uint8_t *dst; const uint8_t *src; size_t bytes; } copy_job;
 
@@ -84,6 +84,12 @@ typedef struct {
     /* a TX group's lane (cl_group_writeStream): the clients' samples, row by row, in pinned memory and on the device */
     uint8_t *tx_h_in, *tx_d_in; size_t tx_row;      /* two sets of rows each: this call's and the previous call's (still in flight) */
     uint8_t *tx_pend; int tx_pend_set; size_t tx_pend_want;   /* per row: words launched over and not committed yet (write-behind) */
+    /* a modulator lane (ROUTE_TX_PIPE: members with MOD=FM / RESAMP of one configuration): ONE multi-stream TX pipe per sub-batch, made when
+     * first needed; a member's carried state (modulator phase, resampler history) lives EITHER in its stream's own pipe or here (tx_own) */
+    clhip_tx_pipe **tx_gp; uint8_t *tx_own;
+    float *tx_d_msg; size_t tx_msg_stride;          /* FM: the I rails as dense messages, two sets of rows */
+    uint8_t *tx_d_words; size_t tx_words_row;       /* the packed words on the device, two sets of rows: they leave for the members' FIFOs by a copy each */
+    uint8_t **tx_room; long *tx_packed;             /* per row: the room reserved in the member's FIFO for the call in flight; per sub-batch: its words per row */
 } lane_t;
 
 struct cl_group {
@@ -97,6 +103,7 @@ struct cl_group {
                                            * 2 (default) = ... and launched over, into the second mirror */
     size_t n_sub;                         /* sub-batches over all lanes */
     int iir_polls; int iir_polls_set;     /* test hook (cl_group_set_iir_poll_bound): the poll bound of the group's filter objects */
+    int tx_polls; int tx_polls_set;       /* test hook (cl_group_set_tx_poll_bound): the look-back poll bound of the group's modulator pipes */
     pthread_mutex_t tx_mu; int tx_mu_ok; int tx_pending;      /* a TX group: the call and the members' seams' call-backs (any thread) */
     int stale;                            /* work made ahead has just been given up: it is waited for before anything takes its place (settle) */
     int sink_mapped;                      /* kwarg SINK: "mapped" (default) = the sub-batch's kernel stores into the mapped pinned mirror itself; "copy" = device buffer + copy engine */
@@ -242,6 +249,13 @@ static int same_dsp(const cl_dsp_cfg *a, const cl_dsp_cfg *b)
            !memcmp(a->rs, b->rs, sizeof(float) * (size_t)a->n_rs);
 }
 
+/* TX: one modulator configuration (the words do not depend on the channel type) */
+static int same_tx_dsp(const cl_dsp_cfg *a, const cl_dsp_cfg *b)
+{
+    return a->enabled && b->enabled && a->up == b->up && a->down == b->down && a->n_rs == b->n_rs && a->mod_fm == b->mod_fm &&
+           (!a->mod_fm || a->mod_kf == b->mod_kf) && !memcmp(a->rs, b->rs, sizeof(float) * (size_t)a->n_rs);
+}
+
 static void ahead_cancel_all(cl_group *g);
 static void tx_settle_hook(void *ctx, int member);
 static void tx_finish(cl_group *g);
@@ -249,6 +263,7 @@ static void settle(cl_group *g);
 static void giir_ahead_drop(cl_group *g, lane_t *l, int sb);
 static void **ev_of(const cl_group *g, const lane_t *l, int set, int a);
 static void iir_home(void *ctx, int member);
+static void tx_home(void *ctx, int member);
 
 static void lane_free(lane_t *l)
 {
@@ -257,6 +272,8 @@ static void lane_free(lane_t *l)
     clhip_event_destroy(l->ev_primed); free(l->primed); free(l->primed_epoch);
     clhip_host_free(l->h_out[0]); clhip_host_free(l->h_out[1]); clhip_host_free(l->h_offs[0]);
     clhip_host_free(l->tx_h_in); clhip_free(l->tx_d_in); free(l->tx_pend);
+    for (int i = 0; l->tx_gp && i < l->n_subs; i++) clhip_tx_pipe_destroy(l->tx_gp[i]);
+    free(l->tx_gp); free(l->tx_own); clhip_free(l->tx_d_msg); clhip_free(l->tx_d_words); free(l->tx_room); free(l->tx_packed);
     free(l->done_ahead); free(l->ahead_got); free(l->direct); free(l->ctx);
     for (int i = 0; l->giir && i < 3 * l->n_subs; i++) clhip_iir_destroy(l->giir[i]);
     free(l->giir); free(l->iir_own); free(l->sub_ft); free(l->ahead_ft); free(l->sub_verdict); free(l->how); clhip_free(l->d_f[0]); clhip_free(l->d_f[1]);
@@ -271,6 +288,10 @@ void cl_group_unmake(cl_group *g)
     if (g->tx_mu_ok) {                                         /* a TX group: what is in flight lands, the members' seams stop calling back */
         pthread_mutex_lock(&g->tx_mu);
         tx_finish(g);
+        for (size_t i = 0; g->dev && g->lane_of && i < g->n; i++) {   /* the modulators' carried state goes back to the streams' own pipes */
+            cl_stream *st = g->dev[i] ? g->dev[i]->stream : NULL;
+            if (st && st->tx_home_ctx == g) { tx_home(g, (int)i); st->tx_home = NULL; st->tx_home_ctx = NULL; }
+        }
         for (size_t i = 0; g->dev && i < g->n; i++)
             if (g->dev[i] && g->dev[i]->smi->tx_settle_ctx == g) { g->dev[i]->smi->tx_settle = NULL; g->dev[i]->smi->tx_settle_ctx = NULL; }
         pthread_mutex_unlock(&g->tx_mu);
@@ -357,14 +378,16 @@ cl_group *cl_group_make(cl_device *const *devs, size_t n, const char *const *key
         int li = -1;
         for (int k = 0; k < g->n_lanes && li < 0; k++) {
             const cl_stream *s0 = devs[g->lane[k].member[0]]->stream;
-            if (g->dir == CL_SOAPY_SDR_TX) { if (s0->format == st->format && !s0->dsp.enabled && !st->dsp.enabled) li = k; }      /* (the TX words do not depend on the channel type) */
+            if (g->dir == CL_SOAPY_SDR_TX) {                       /* (the TX words do not depend on the channel type) */
+                if (s0->format == st->format && ((!s0->dsp.enabled && !st->dsp.enabled) || (s0->tx_pipe && st->tx_pipe && same_tx_dsp(&s0->dsp, &st->dsp)))) li = k;
+            }
             else if (g->lane[k].channel == devs[i]->channel && s0->format == st->format && same_dsp(&s0->dsp, &st->dsp)) li = k;
         }
         if (li < 0) {
             li = g->n_lanes++;
             lane_t *l = &g->lane[li];
             l->channel = devs[i]->channel; l->format = st->format; l->dsp = st->dsp;
-            l->route = g->dir == CL_SOAPY_SDR_TX ? (st->dsp.enabled ? ROUTE_TX_SINGLE : ROUTE_TX_PLAIN) : st->dsp.enabled ? ROUTE_PIPE : ROUTE_PLAIN;
+            l->route = g->dir == CL_SOAPY_SDR_TX ? (st->dsp.enabled ? (st->tx_pipe ? ROUTE_TX_PIPE : ROUTE_TX_SINGLE) : ROUTE_TX_PLAIN) : st->dsp.enabled ? ROUTE_PIPE : ROUTE_PLAIN;
             l->member = (int *)calloc(n, sizeof(int));
             if (!l->member) { cl_group_unmake(g); return NULL; }
         }
@@ -382,7 +405,9 @@ cl_group *cl_group_make(cl_device *const *devs, size_t n, const char *const *key
             n_sub += ((size_t)l->n + (size_t)l->sub - 1) / (size_t)l->sub;
             l->fast = (uint8_t *)calloc((size_t)l->n, 1); l->src = (uint8_t **)calloc((size_t)l->n, sizeof(uint8_t *));
             if (!l->fast || !l->src) { cl_group_unmake(g); return NULL; }
-            if (l->route != ROUTE_TX_PLAIN) continue;
+            if (l->route == ROUTE_TX_PIPE && l->n < 2) l->route = ROUTE_TX_SINGLE;      /* (one modulator alone gains nothing from a pipe of the group's) */
+            if (l->route != ROUTE_TX_PLAIN && l->route != ROUTE_TX_PIPE) continue;
+            l->n_subs = (l->n + l->sub - 1) / l->sub;
             l->elem_bytes = fmt_bytes(l->format);
             l->tx_row = mtu * l->elem_bytes + 256;
             l->tx_h_in = (uint8_t *)clhip_host_alloc(2 * (size_t)l->n * l->tx_row); l->tx_d_in = (uint8_t *)clhip_malloc(2 * (size_t)l->n * l->tx_row);
@@ -392,6 +417,19 @@ cl_group *cl_group_make(cl_device *const *devs, size_t n, const char *const *key
                 smi->tx_settle = tx_settle_hook; smi->tx_settle_ctx = g; smi->tx_settle_member = l->member[r];
             }
             if (!l->tx_h_in || !l->tx_d_in || !l->tx_pend) { cl_seterr(g_make_err, sizeof g_make_err, "cl_group_make: buffers for %d TX streams could not be allocated", l->n); cl_group_unmake(g); return NULL; }
+            if (l->route == ROUTE_TX_PIPE) {
+                l->tx_msg_stride = mtu + 64;
+                l->tx_words_row = 4 * (mtu * (size_t)l->dsp.up + 64);                /* (the most a call can produce: every message `up` words) */
+                l->tx_gp = (clhip_tx_pipe **)calloc((size_t)l->n_subs, sizeof(clhip_tx_pipe *)); l->tx_own = (uint8_t *)calloc((size_t)l->n, 1);
+                l->tx_room = (uint8_t **)calloc((size_t)l->n, sizeof(uint8_t *)); l->tx_packed = (long *)calloc((size_t)l->n_subs, sizeof(long));
+                l->tx_d_msg = l->dsp.mod_fm ? (float *)clhip_malloc(sizeof(float) * 2 * (size_t)l->n * l->tx_msg_stride) : NULL;
+                l->tx_d_words = (uint8_t *)clhip_malloc(2 * (size_t)l->n * l->tx_words_row);
+                if (!l->tx_gp || !l->tx_own || !l->tx_room || !l->tx_packed || (l->dsp.mod_fm && !l->tx_d_msg) || !l->tx_d_words) { cl_seterr(g_make_err, sizeof g_make_err, "cl_group_make: buffers for %d modulator streams could not be allocated", l->n); cl_group_unmake(g); return NULL; }
+                for (int r = 0; r < l->n; r++) {
+                    cl_stream *st = g->dev[l->member[r]]->stream;
+                    st->tx_home = tx_home; st->tx_home_ctx = g; st->tx_home_member = l->member[r];
+                }
+            }
             continue;
         }
         l->in_stride = nb + 256;

@@ -183,6 +183,9 @@ struct cl_stream {
     cl_dsp_cfg dsp;
     clhip_rx_pipe *rx_pipe;
     clhip_tx_pipe *tx_pipe;
+    /* a TX stream group may hold this stream's modulator phase and resampler history in a multi-stream pipe of its own: before the
+     * stream's own pipe is used (or destroyed) the group lands what it has in flight and hands the state back */
+    void (*tx_home)(void *ctx, int member); void *tx_home_ctx; int tx_home_member;
     /* ASYNC mode: reader thread + ring (CaribouliteStream.cpp:16-49,70-75).  The ring's storage is DEVICE memory:
      * the reader thread's unpacked samples go device-to-device into it while the next native batch is already
      * being copied host-to-device on a second HIP stream (cl_smi_read_device_ra); the consumer's stages read

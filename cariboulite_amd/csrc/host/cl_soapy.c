@@ -290,6 +290,7 @@ cl_stream *cl_setupStream(cl_device *dev, int direction, const char *format, con
     }
     clhip_set_device(dev->smi->device);
     if (st->rx_pipe) { clhip_rx_pipe_destroy(st->rx_pipe); st->rx_pipe = NULL; }
+    if (st->tx_home) st->tx_home(st->tx_home_ctx, st->tx_home_member);     /* (a stream group lets go of the pipe's state first) */
     if (st->tx_pipe) { clhip_tx_pipe_destroy(st->tx_pipe); st->tx_pipe = NULL; }
     st->dsp = d;
     if (d.enabled && st->native_dir == CL_SOAPY_SDR_RX) {
@@ -779,6 +780,7 @@ static int write_stream(cl_device *dev, cl_stream *st, const void *const *buffs,
     }
     if (numElems > st->mtu_size) numElems = st->mtu_size;                          /* :201,217,234 */
     if (numElems == 0) return 0;
+    if (st->tx_pipe && st->tx_home) st->tx_home(st->tx_home_ctx, st->tx_home_member);   /* (a stream group hands the modulator's state back first) */
     const size_t n = numElems, ib = fmt_bytes(st->format);
     if (cl_ensure(&st->d_conv, &st->conv_cap, n * 16 + 64, 1, 0) ||
         cl_smi_ensure_iq(smi, n + 8) ||

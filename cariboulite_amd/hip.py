@@ -62,6 +62,7 @@ _SIGS = {
     "clhip_convert_pack": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]),
     "clhip_convert_pack_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "clhip_take_i_rail": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "clhip_take_i_rail_rows": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "clhip_sync_tags_ws_bytes": (C.c_size_t, [C.c_size_t]),
     "clhip_sync_tags": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "clhip_iir_create": (C.c_void_p, [C.c_void_p, C.c_int, C.c_int]),
@@ -110,6 +111,10 @@ _SIGS = {
                                      C.c_void_p, C.c_size_t, C.c_void_p]),
     "clhip_tx_pipe_status": (C.c_int, [C.c_void_p]),
     "clhip_tx_pipe_set_poll_bound": (None, [C.c_void_p, C.c_int]),
+    "clhip_tx_pipe_position": (C.c_ulonglong, [C.c_void_p]),
+    "clhip_tx_pipe_pack_mode": (C.c_int, [C.c_void_p]),
+    "clhip_tx_pipe_set_position": (C.c_int, [C.c_void_p, C.c_ulonglong]),
+    "clhip_tx_pipe_move_stream": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "clhip_fm_demod": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "clhip_fm_mod": (C.c_int, [C.c_void_p, C.c_size_t, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "clhip_fm_mod_workspace_bytes": (C.c_size_t, [C.c_size_t]),
@@ -400,6 +405,16 @@ class TxPipe:
 
     def set_poll_bound(self, polls):
         lib().clhip_tx_pipe_set_poll_bound(self.h, polls)
+
+    def position(self):
+        return int(lib().clhip_tx_pipe_position(self.h))
+
+    def set_position(self, n_total):
+        _check(lib().clhip_tx_pipe_set_position(self.h, int(n_total)), "clhip_tx_pipe_set_position")
+
+    def take_stream_from(self, dst_stream, src, src_stream, stream=None):
+        """the carried state of src's stream `src_stream` moves into this pipe's stream `dst_stream`"""
+        _check(lib().clhip_tx_pipe_move_stream(self.h, dst_stream, src.h, src_stream, stream), "clhip_tx_pipe_move_stream")
 
     def run(self, in_kind, d_in, in_stride, n_in, d_bytes, out_stride_bytes, d_tap=None, tap_stride=0, stream=None):
         return _check(lib().clhip_tx_pipe_run(self.h, in_kind, ptr(d_in), in_stride, n_in, ptr(d_bytes),

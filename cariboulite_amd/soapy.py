@@ -104,6 +104,7 @@ _SIGS = {
     "cl_group_readStream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t, C.POINTER(C.c_int), C.c_long]),
     "cl_group_writeStream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t, C.POINTER(C.c_int), C.c_long]),
     "cl_group_set_iir_poll_bound": (None, [C.c_void_p, C.c_int]),
+    "cl_group_set_tx_poll_bound": (None, [C.c_void_p, C.c_int]),
     "cl_group_flush": (C.c_int, [C.c_void_p]),
     "cl_group_last_error": (C.c_char_p, [C.c_void_p]),
     "cl_group_getStats": (None, [C.c_void_p, C.c_void_p]),
@@ -403,7 +404,7 @@ class Group:
         last = getattr(self, "_last_buffs", ())
         if len(last) != len(buffs) or any(x is not y for x, y in zip(last, buffs)):
             for i, b in enumerate(buffs):
-                self._ptrs[i] = b.ctypes.data
+                self._ptrs[i] = b.ctypes.data if b is not None else None      # (None: the member is left out of the call)
             self._last_buffs = tuple(buffs)
         n = lib().cl_group_writeStream(self.h, self._ptrs, numElems, self._rets, timeoutUs)
         return n, list(self._rets)
@@ -426,6 +427,9 @@ class Group:
 
     def setIirPollBound(self, polls):
         lib().cl_group_set_iir_poll_bound(self.h, polls)
+
+    def setTxPollBound(self, polls):
+        lib().cl_group_set_tx_poll_bound(self.h, polls)
 
     def stats(self):
         out = (C.c_uint64 * 11)()

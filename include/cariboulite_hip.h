@@ -206,6 +206,9 @@ int clhip_convert_pack_rows(const void *const *d_in_rows, int format, size_t n_s
 /* The I rail of interleaved CF32 samples as a dense fp32 message: what Stream::WriteSamples would hand an FM modulator
  * ("if given I/Q, use I"), taken on the device instead of in a host loop. */
 int clhip_take_i_rail(const float *d_cf32, size_t n_samples, float *d_msg, void *stream);
+/* ... of n_rows streams in one launch (the modulator lanes of cl_group_writeStream): row r's samples at d_cf32 + 2 * r * in_stride_elems
+ * floats, its message at d_msg + r * msg_stride */
+int clhip_take_i_rail_rows(const float *d_cf32, size_t in_stride_elems, size_t n_samples, int n_rows, float *d_msg, size_t msg_stride, void *stream);
 
 /* TX pack -- replaces caribou_smi_generate_data (caribou_smi.c:684-717) */
 int clhip_smi_pack(int mode, const int16_t *d_iq, size_t n_samples, uint8_t *d_bytes, void *stream);
@@ -386,6 +389,16 @@ long   clhip_tx_pipe_run(clhip_tx_pipe *p, int in_kind, const void *d_in, size_t
 int    clhip_tx_pipe_status(clhip_tx_pipe *p);
 /* diagnostic knob: polls of a predecessor before the look-back gives up (tests force the failure with 0); < 0 = default */
 void   clhip_tx_pipe_set_poll_bound(clhip_tx_pipe *p, int polls);
+/* The carried state of ONE stream -- what a Stream object with a modulator keeps between two WriteSamples calls: the modulator's phase
+ * and the resampler's history -- moves from one pipe to another of the same configuration: a stream group's multi-stream pipe and a
+ * member's own (cl_group_writeStream: one Soapy device per channel, soapy_api/SoapyCariboulite.cpp:46-69, written together).  Both pipes
+ * idle (last runs synchronised, verdicts asked); synchronises `stream`.  The polyphase position (messages taken so far; only its
+ * remainder mod `down` matters) is the PIPE's, its streams advance together: _position reads it, _set_position places a pipe none of
+ * whose streams carries state yet. */
+unsigned long long clhip_tx_pipe_position(const clhip_tx_pipe *p);
+int    clhip_tx_pipe_pack_mode(const clhip_tx_pipe *p);            /* the pack mode the pipe was created with */
+int    clhip_tx_pipe_set_position(clhip_tx_pipe *p, unsigned long long n_total);
+int    clhip_tx_pipe_move_stream(clhip_tx_pipe *dst, int dst_stream, clhip_tx_pipe *src, int src_stream, void *stream);
 
 /* standalone FM / CW stages on device buffers */
 int clhip_fm_demod(const float *d_iq, size_t n, float *d_prev_iq /*2 floats, in/out*/, float *d_out, void *stream);
@@ -627,8 +640,12 @@ int         cl_group_readStream(cl_group *g, void *const *buffs, size_t numElems
  * one -- rets[i] is what cl_writeStream(devs[i], stream_i, &buffs[i], numElems, ...) returns, and on return every member's packed
  * words are in its TX FIFO behind what it held (Stream::WriteSamplesGen, CaribouliteStream.cpp:199-258, over caribou_smi_write,
  * caribou_smi.c:720-762).  Members without a modulator share launches of up to eight streams (conversion + caribou_smi_generate_data,
- * words stored straight into the room reserved in each pinned FIFO) while the next sub-batch's samples are copied in; a member with
- * MOD / RESAMP kwargs, or a CS16 call above one MTU, takes its own device's writeStream inside the call.  The call returns with the
+ * words stored straight into the room reserved in each pinned FIFO) while the next sub-batch's samples are copied in; members with
+ * MOD / RESAMP kwargs of ONE configuration share launches too (a multi-stream TX pipe of the group's per sub-batch: I rails -> FM
+ * modulator -> resampler -> quantiser -> pack; a member's modulator phase and resampler history move between its own pipe and the
+ * group's as it changes routes, clhip_tx_pipe_move_stream; all of a sub-batch or none -- members whose polyphase positions differ mod
+ * `down`, or one of whom has no buffer in the call, go through their own devices); a CS16 call above one MTU takes the member's own
+ * device's writeStream inside the call.  The call returns with the
  * launches queued (write-behind by one call); the members' seams land what is in flight before anything looks at or adds to a TX
  * FIFO (cl_smi_drain_bytes / _drain_to_fd from any thread, cl_writeStream on a member), so the words are there for whoever asks.  A
  * runtime error of launches already reported as consumed is returned by the NEXT call.  No thread may be draining a member while the
@@ -639,6 +656,7 @@ int         cl_group_flush(cl_group *g);                      /* a TX group: wai
 const char *cl_group_last_error(const cl_group *g);
 void        cl_group_getStats(const cl_group *g, cl_group_stats *out);
 void        cl_group_set_iir_poll_bound(cl_group *g, int polls);      /* test hook: clhip_iir_set_poll_bound for the group's own filter objects */
+void        cl_group_set_tx_poll_bound(cl_group *g, int polls);       /* test hook: clhip_tx_pipe_set_poll_bound for the group's own modulator pipes (made or yet to be made) */
 /* Explicit zero-copy: one client buffer per member (bytes_each long), registered with the GPU here and kept registered until
  * _unregister_buffers / cl_group_unmake -- the client keeps them allocated that long.  A call whose buffs[i] lies inside
  * member i's registered buffer has the copy engine write it directly (no pinned mirror, no memcpy); any other pointer takes

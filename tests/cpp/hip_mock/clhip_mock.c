@@ -444,3 +444,10 @@ void clhip_tx_pipe_destroy(clhip_tx_pipe *p) { (void)p; }
 long clhip_tx_pipe_run(clhip_tx_pipe *p, int kind, const void *in, size_t is, size_t n, uint8_t *w, size_t ws, float *iq, size_t iqs, void *s)
 { (void)p; (void)kind; (void)in; (void)is; (void)n; (void)w; (void)ws; (void)iq; (void)iqs; (void)s; return -1; }
 int clhip_tx_pipe_status(clhip_tx_pipe *p) { (void)p; return -1; }
+unsigned long long clhip_tx_pipe_position(const clhip_tx_pipe *p) { (void)p; return 0; }
+int clhip_tx_pipe_pack_mode(const clhip_tx_pipe *p) { (void)p; return -1; }
+int clhip_tx_pipe_set_position(clhip_tx_pipe *p, unsigned long long n) { (void)p; (void)n; return -1; }
+int clhip_tx_pipe_move_stream(clhip_tx_pipe *d, int ds, clhip_tx_pipe *s, int ss, void *st) { (void)d; (void)ds; (void)s; (void)ss; (void)st; return -1; }
+int clhip_take_i_rail_rows(const float *in, size_t is, size_t n, int rows, float *out, size_t os, void *s)
+{ (void)in; (void)is; (void)n; (void)rows; (void)out; (void)os; (void)s; set_err("clhip_mock: no TX"); return -1; }
+void clhip_tx_pipe_set_poll_bound(clhip_tx_pipe *p, int polls) { (void)p; (void)polls; }

@@ -168,3 +168,122 @@ def test_random_walk_of_writes_against_lone_devices_and_the_oracle(S, orc, seed,
     grp.close()
     for d in gdevs + sdevs:
         d.close()
+
+
+MOD_CASES = {"fm_2_3": {"MOD": "FM:75000", "RESAMP": "2/3"}, "rs_2_3": {"RESAMP": "2/3"}, "fm": {"MOD": "FM:25000"}, "rs_3_2": {"RESAMP": "3/2"}}
+
+
+def drain_equal(gdevs, sdevs, tag):
+    for i, (gd, sd) in enumerate(zip(gdevs, sdevs)):
+        g, s = gd.drainSmiBytes(), sd.drainSmiBytes()
+        assert g.size == s.size and g.tobytes() == s.tobytes(), (tag, i, g.size, s.size)
+
+
+@pytest.mark.parametrize("case", list(MOD_CASES))
+def test_modulator_lanes_equal_lone_devices(S, case):
+    """11 members with one modulator configuration (two launches: 8 + 3 streams through the group's own multi-stream TX pipes), six
+    calls -- whole MTUs, ragged lengths, a call above the MTU (clamped), a tiny one: the modulator's phase, the resampler's history
+    and the polyphase position carry from call to call inside the group's pipes, and every member's FIFO holds, call after call,
+    byte for byte what its lone twin produces (which tests/test_gpu_soapy.py and test_gpu_walk_oracle.py hold against the oracle)."""
+    n = 11
+    args = MOD_CASES[case]
+    gdevs, gsts = make_tx(S, n, "CF32", lambda i: args)
+    sdevs, ssts = make_tx(S, n, "CF32", lambda i: args)
+    grp = S.Group(gdevs)
+    rng = np.random.default_rng(21)
+    calls = (MTU, 1000, MTU - 1, MTU + 4096, 4, MTU)
+    for k, num in enumerate(calls):
+        bufs = [(samples(rng, "CF32", num) * 0.5).astype(np.float32) for _ in range(n)]
+        nd, rets = grp.writeStream(bufs, num)
+        srets = [sdevs[i].writeStream(ssts[i], [bufs[i]], num).ret for i in range(n)]
+        assert rets == srets == [min(num, MTU)] * n and nd == n, (num, rets, srets)
+        if k % 2:
+            drain_equal(gdevs, sdevs, (case, k))                      # (the other calls' words pile up behind one another)
+    drain_equal(gdevs, sdevs, (case, "end"))
+    st = grp.stats()
+    assert st["errors"] == 0 and st["single_reads"] == 0 and st["batched_reads"] == n * len(calls) and st["launches"] == 2 * len(calls), st
+    for i in range(n):
+        gs, ss = gdevs[i].streamStats(gsts[i]), sdevs[i].streamStats(ssts[i])
+        for key in ("write_calls", "elements_written", "writes_empty", "tx_overruns"):
+            assert gs[key] == ss[key], (i, key, gs, ss)
+    # the group goes: the state is the streams' own again, and they carry on as their twins do
+    grp.close()
+    bufs = [(samples(rng, "CF32", 5000) * 0.5).astype(np.float32) for _ in range(n)]
+    for i in range(n):
+        assert gdevs[i].writeStream(gsts[i], [bufs[i]], 5000).ret == sdevs[i].writeStream(ssts[i], [bufs[i]], 5000).ret == 5000
+    drain_equal(gdevs, sdevs, (case, "after the group"))
+    for d in gdevs + sdevs:
+        d.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_random_walk_of_modulated_writes_against_lone_devices(S, seed):
+    """A seeded walk over two modulator lanes in one group (FM + 2/3 x 10, 2/3 alone x 3) and two plain CF32 members: every call another
+    length; now and then a member written through its own device between two group calls -- with the length its mates were written
+    (it rejoins its sub-batch: the state moves home and back) or with another one (its polyphase position differs from its mates':
+    the sub-batch goes through the members' own devices until the positions meet again); a member left out of a call (no buffer);
+    drains at random moments.  After every drain every member's bytes equal its lone twin's."""
+    rng = np.random.default_rng(900 + seed)
+    cfg = [MOD_CASES["fm_2_3"]] * 10 + [MOD_CASES["rs_2_3"]] * 3 + [None] * 2
+    n = len(cfg)
+    gdevs, gsts = make_tx(S, n, "CF32", lambda i: cfg[i])
+    sdevs, ssts = make_tx(S, n, "CF32", lambda i: cfg[i])
+    grp = S.Group(gdevs)
+    last = MTU
+    for step in range(24):
+        op = rng.choice(["call"] * 5 + ["lone_same", "lone_other", "skip", "drain"])
+        if op in ("lone_same", "lone_other"):
+            i = int(rng.integers(0, n)); num = last if op == "lone_same" else int(rng.choice([777, 1000, MTU - 2]))
+            b = (samples(rng, "CF32", num) * 0.5).astype(np.float32)
+            assert gdevs[i].writeStream(gsts[i], [b], num).ret == sdevs[i].writeStream(ssts[i], [b], num).ret == min(num, MTU)
+        elif op == "drain":
+            drain_equal(gdevs, sdevs, (seed, step))
+        num = int(rng.choice([MTU] * 3 + [MTU - 1, 1000, 3, MTU + 5000]))
+        last = num
+        bufs = [(samples(rng, "CF32", num) * 0.5).astype(np.float32) for _ in range(n)]
+        left_out = int(rng.integers(0, n)) if op == "skip" else -1
+        gb = [None if i == left_out else b for i, b in enumerate(bufs)]
+        nd, rets = grp.writeStream(gb, num)
+        srets = [0 if i == left_out else sdevs[i].writeStream(ssts[i], [bufs[i]], num).ret for i in range(n)]
+        assert rets == srets and nd == n - (left_out >= 0), (step, num, rets, srets)
+    drain_equal(gdevs, sdevs, (seed, "end"))
+    st = grp.stats()
+    assert st["errors"] == 0 and st["batched_reads"] > 40, st
+    grp.close()
+    for d in gdevs + sdevs:
+        d.close()
+
+
+def test_a_modulator_launch_that_gives_up_loses_nothing_but_its_own_words(S):
+    """The group asks its modulator launches for their verdict when their words are committed (clhip_tx_pipe_status; a look-back that
+    gave up): the sub-batch is launched again in ticket order, and a second failure -- forced here with a poll bound of 0, which holds
+    in both orders -- commits nothing, is reported by the flush (the call itself had returned already: write-behind) and leaves the
+    pipes where they were before the call: the members carry on exactly like twins that never saw the lost call."""
+    n = 9
+    args = MOD_CASES["fm_2_3"]
+    gdevs, gsts = make_tx(S, n, "CF32", lambda i: args)
+    sdevs, ssts = make_tx(S, n, "CF32", lambda i: args)
+    grp = S.Group(gdevs)
+    rng = np.random.default_rng(31)
+
+    def both(num, twins=True):
+        bufs = [(samples(rng, "CF32", num) * 0.5).astype(np.float32) for _ in range(n)]
+        nd, rets = grp.writeStream(bufs, num)
+        if twins:
+            assert rets == [sdevs[i].writeStream(ssts[i], [bufs[i]], num).ret for i in range(n)]
+        return nd, rets
+
+    both(MTU); both(5000)
+    assert grp.flush() == 0
+    grp.setTxPollBound(0)
+    nd, rets = both(60000, twins=False)
+    assert nd == n and rets == [60000] * n                                # told before the launches ran
+    assert grp.flush() == -1 and "lost" in grp.lastError()
+    assert all(gdevs[i].streamStats(gsts[i])["tx_overruns"] == 2 for i in range(n))      # (both attempts, as cl_writeStream counts them)
+    grp.setTxPollBound(-1)
+    both(MTU - 3); both(MTU)
+    assert grp.flush() == 0
+    drain_equal(gdevs, sdevs, "after the lost call")
+    grp.close()
+    for d in gdevs + sdevs:
+        d.close()
