@@ -569,6 +569,45 @@ extern "C" int clhip_convert_pack_rows(const void *const *d_in_rows, int format,
     return 0;
 }
 
+// Rows of packed words (one stride apart on the device) to n_rows destinations of their own -- the rooms reserved in the members' pinned
+// TX FIFOs, stored across PCIe by the launch itself: one launch per sub-batch instead of a copy-engine call per member
+struct WordRows { uint32_t *out[CLHIP_PACK_ROWS]; };
+
+__global__ __launch_bounds__(256) void words_to_rows_kernel(const uint32_t *__restrict__ in, size_t in_stride_words, size_t n, WordRows rows)
+{
+    const uint32_t *__restrict__ src = in + (size_t)blockIdx.y * in_stride_words;
+    uint32_t *__restrict__ dst = rows.out[blockIdx.y];
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (((((uintptr_t)dst) | ((uintptr_t)src)) & 15) == 0) {
+        const size_t n4 = n / 4;
+        for (size_t j = k; j < n4; j += step) ((u32x4 *)dst)[j] = ((const u32x4 *)src)[j];
+        for (size_t j = 4 * n4 + k; j < n; j += step) dst[j] = src[j];
+    } else {
+        for (size_t j = k; j < n; j += step) dst[j] = src[j];
+    }
+}
+
+extern "C" int clhip_words_to_rows(const uint8_t *d_words, size_t in_stride_bytes, size_t n_words, int n_rows, uint8_t *const *d_dst_rows, void *stream)
+{
+    if (n_words == 0 || n_rows == 0) return 0;
+    if (!d_words || !d_dst_rows || n_rows < 0 || n_rows > CLHIP_PACK_ROWS || (in_stride_bytes & 3) || (((uintptr_t)d_words) & 3)) {
+        clhip_set_error("clhip_words_to_rows: bad arguments (1 .. %d rows)", CLHIP_PACK_ROWS);
+        return -1;
+    }
+    WordRows rows;
+    for (int r = 0; r < CLHIP_PACK_ROWS; r++) {
+        rows.out[r] = r < n_rows ? (uint32_t *)d_dst_rows[r] : nullptr;
+        if (r < n_rows && (!rows.out[r] || (((uintptr_t)rows.out[r]) & 3))) { clhip_set_error("clhip_words_to_rows: bad row %d", r); return -1; }
+    }
+    unsigned gx = (unsigned)clhip_div_up(clhip_div_up(n_words, 4), 256);
+    if (gx > 256) gx = 256;
+    hipLaunchKernelGGL(words_to_rows_kernel, dim3(gx, (unsigned)n_rows), dim3(256), 0, (hipStream_t)stream, (const uint32_t *)d_words, in_stride_bytes / 4,
+                       n_words, rows);
+    CLHIP_CHECK_LAUNCH();
+    return 0;
+}
+
 // the I rail of interleaved CF32 as a dense fp32 message (the FM modulator's input: SURVEY.md a13 "if given I/Q, use I")
 __global__ __launch_bounds__(256) void take_i_rail_kernel(const f32x2 *__restrict__ in, size_t n, float *__restrict__ out)
 {

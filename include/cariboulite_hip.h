@@ -203,6 +203,10 @@ int clhip_convert_pack(const void *d_in, int format, size_t n_samples, int mode,
  * d_bytes_rows[r] (host arrays of device-visible addresses, read at the call). */
 #define CLHIP_PACK_ROWS 8
 int clhip_convert_pack_rows(const void *const *d_in_rows, int format, size_t n_samples, int n_rows, int mode, uint8_t *const *d_bytes_rows, void *stream);
+/* Rows of packed words on the device (row r at d_words + r * in_stride_bytes) stored by ONE launch into up to CLHIP_PACK_ROWS destinations
+ * of their own -- device addresses of the rooms reserved in the members' pinned TX FIFOs (cl_group_writeStream's modulator lanes: the
+ * appends of caribou_smi_write's chunk loop, caribou_smi.c:738-759, for a whole sub-batch). */
+int clhip_words_to_rows(const uint8_t *d_words, size_t in_stride_bytes, size_t n_words, int n_rows, uint8_t *const *d_dst_rows, void *stream);
 /* The I rail of interleaved CF32 samples as a dense fp32 message: what Stream::WriteSamples would hand an FM modulator
  * ("if given I/Q, use I"), taken on the device instead of in a host loop. */
 int clhip_take_i_rail(const float *d_cf32, size_t n_samples, float *d_msg, void *stream);

@@ -451,3 +451,5 @@ int clhip_tx_pipe_move_stream(clhip_tx_pipe *d, int ds, clhip_tx_pipe *s, int ss
 int clhip_take_i_rail_rows(const float *in, size_t is, size_t n, int rows, float *out, size_t os, void *s)
 { (void)in; (void)is; (void)n; (void)rows; (void)out; (void)os; (void)s; set_err("clhip_mock: no TX"); return -1; }
 void clhip_tx_pipe_set_poll_bound(clhip_tx_pipe *p, int polls) { (void)p; (void)polls; }
+int clhip_words_to_rows(const uint8_t *w, size_t is, size_t n, int rows, uint8_t *const *dst, void *s)
+{ (void)w; (void)is; (void)n; (void)rows; (void)dst; (void)s; set_err("clhip_mock: no TX"); return -1; }

@@ -43,7 +43,10 @@ def pcie_shape(in_mib, out_mib):
         return None
 
 
-TX_CASES = {"tx_cs16": ("CS16", "int16", 4), "tx_cf32": ("CF32", "float32", 8)}
+# name: (format, dtype, input bytes per element, stream kwargs, words out per element)
+TX_CASES = {"tx_cs16": ("CS16", "int16", 4, None, 1.0), "tx_cf32": ("CF32", "float32", 8, None, 1.0),
+            "tx_cf32_fm_rs_2_3": ("CF32", "float32", 8, {"MOD": "FM:75000", "RESAMP": "2/3"}, 2.0 / 3.0),      # config 5's stages behind writeStream
+            "tx_cf32_rs_2_3": ("CF32", "float32", 8, {"RESAMP": "2/3"}, 2.0 / 3.0)}
 
 
 def run_tx_case(name, a):
@@ -51,7 +54,8 @@ def run_tx_case(name, a):
     the timed repetitions), against the same devices written one by one."""
     import numpy as np
     from cariboulite_amd import soapy as S
-    fmt, dt, in_b = TX_CASES[name]
+    fmt, dt, in_b, args, out_per = TX_CASES[name]
+    out_words = lambda k: -(-k * MTU * 2 // 3) if out_per < 1.0 else k * MTU          # (2/3: ceil over the whole run of messages)
     n, K = a.streams, a.calls
     rng = np.random.default_rng(5)
     res = {}
@@ -59,7 +63,7 @@ def run_tx_case(name, a):
         devs, sts = [], []
         for i in range(n):
             d = S.Device(dict(driver="Cariboulite", channel="S1G" if i % 2 == 0 else "HiF"))
-            sts.append(d.setupStream(S.SOAPY_SDR_TX, fmt))
+            sts.append(d.setupStream(S.SOAPY_SDR_TX, fmt, args=args))
             d.activateStream(sts[-1])
             devs.append(d)
         bufs = [(rng.integers(-4096, 4096, (MTU, 2)).astype(np.int16) if fmt == "CS16" else (rng.random((MTU, 2), dtype=np.float32) - 0.5)) for _ in range(n)]
@@ -81,7 +85,8 @@ def run_tx_case(name, a):
                 assert grp.flush() == 0                    # (write-behind: the last call's launches belong to the timed region)
             dt_s = time.perf_counter() - t0
             for d in devs:
-                assert d.drainSmiBytes().size == K * MTU * 4
+                got = d.drainSmiBytes().size
+                assert got == 4 * (out_words((rep + 1) * K) - out_words(rep * K)), (got, rep)
             if rep and (best is None or dt_s < best):
                 best = dt_s
         res[mode] = {"msps_in": round(n * K * MTU / best / 1e6, 1), "ms_per_group_call": round(best / K * 1e3, 4), "us_per_stream_call": round(best / K / n * 1e6, 2)}
@@ -90,7 +95,7 @@ def run_tx_case(name, a):
             grp.close()
         for d in devs:
             d.close()
-    in_mib, out_mib = n * MTU * in_b >> 20, n * MTU * 4 >> 20
+    in_mib, out_mib = n * MTU * in_b >> 20, int(n * MTU * 4 * out_per) >> 20
     sh = pcie_shape(in_mib, out_mib)
     if sh:
         ceiling = n * MTU / (sh["duplex_ms"] * 1e-3) / 1e6
