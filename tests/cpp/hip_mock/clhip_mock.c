@@ -12,8 +12,9 @@
  * The "kernels" compute with the oracle (oracle/cl_oracle.c: orc_find_buffer_offset, orc_rx_data_analyze, orc_cs16_to_*): the RX
  * unpack family exactly; the RX pipe as a two-tap stand-in with the real pipe's STATE contract (ping-pong history, per-stream
  * input counters, epochs of range runs, unrun) -- y[n] = i[n]/4096 + i[n-1]/8192, q[n]/4096 -- so that a run made twice, not at
- * all, or from the wrong history shows in the output; TX without a modulator (conversion + pack).  IIR, the TX modulator pipe and the
- * debug modes are not modelled (the calls fail loudly). */
+ * all, or from the wrong history shows in the output; TX without a modulator (conversion + pack); the TX modulator pipe as a prefix-sum stand-in
+ * with the real pipe's state contract (below).  IIR and the debug modes are not modelled (the calls fail loudly). */
+#include <math.h>
 #include <pthread.h>
 #include <stdarg.h>
 #include <stdint.h>
@@ -437,19 +438,117 @@ int clhip_convert_pack(const void *in, int fmt, size_t n, int mode, uint8_t *b, 
     job *j = new_job(job_pack); j->p[0] = (void *)in; j->p[1] = b; j->z[0] = n; j->i[0] = fmt; j->i[1] = mode;
     return enqueue(s, j);
 }
-int clhip_take_i_rail(const float *in, size_t n, float *out, void *s) { (void)in; (void)n; (void)out; (void)s; set_err("clhip_mock: no TX"); return -1; }
-clhip_tx_pipe *clhip_tx_pipe_create(int n_streams, double kf, double fs, const float *rs, int n_rs, int up, int down, int mode)
-{ (void)n_streams; (void)kf; (void)fs; (void)rs; (void)n_rs; (void)up; (void)down; (void)mode; set_err("clhip_mock: no TX"); return NULL; }
-void clhip_tx_pipe_destroy(clhip_tx_pipe *p) { (void)p; }
-long clhip_tx_pipe_run(clhip_tx_pipe *p, int kind, const void *in, size_t is, size_t n, uint8_t *w, size_t ws, float *iq, size_t iqs, void *s)
-{ (void)p; (void)kind; (void)in; (void)is; (void)n; (void)w; (void)ws; (void)iq; (void)iqs; (void)s; return -1; }
-int clhip_tx_pipe_status(clhip_tx_pipe *p) { (void)p; return -1; }
-unsigned long long clhip_tx_pipe_position(const clhip_tx_pipe *p) { (void)p; return 0; }
-int clhip_tx_pipe_pack_mode(const clhip_tx_pipe *p) { (void)p; return -1; }
-int clhip_tx_pipe_set_position(clhip_tx_pipe *p, unsigned long long n) { (void)p; (void)n; return -1; }
-int clhip_tx_pipe_move_stream(clhip_tx_pipe *d, int ds, clhip_tx_pipe *s, int ss, void *st) { (void)d; (void)ds; (void)s; (void)ss; (void)st; return -1; }
+/* ---- the TX modulator pipe: a stand-in with the real pipe's STATE contract (per-stream carried state in ping-pong halves flipped by the
+ * host at the call, a verdict asked after the run, roll-back, streams moving between pipes; only up == down == 1).  Per message m:
+ * v = lrintf(m * 4096); acc += v (the "phase": a prefix sum over the whole stream); word = pack(I = acc mod 8191 - 4095, Q = clamp(v + v_prev))
+ * -- so that a run made twice, not at all, or from the wrong state shows in every later word.  clhip_mock_tx_fail_every(k): every k-th
+ * run of a pipe "gives up" once (its words are garbage, clhip_tx_pipe_status says so and puts the state back). */
+#define MOCK_TX_MAXS 16
+struct clhip_tx_pipe {
+    int n, mode, fm;
+    long long acc[2][MOCK_TX_MAXS]; int prev[2][MOCK_TX_MAXS]; int cur;
+    unsigned long long n_total, undo_n_total; int undo_cur, can_undo;
+    int lb_err;                                      /* written by the run's job, read after the stream has been synchronised */
+    long runs; int forced;
+};
+static int g_tx_fail_every;
+void clhip_mock_tx_fail_every(int k) { g_tx_fail_every = k; }
+
+static void job_take_i(job *j)
+{
+    for (size_t r = 0; r < j->z[3]; r++) {
+        const float *in = (const float *)j->p[0] + 2 * r * j->z[1]; float *out = (float *)j->p[1] + r * j->z[2];
+        for (size_t k = 0; k < j->z[0]; k++) out[k] = in[2 * k];
+    }
+}
+int clhip_take_i_rail(const float *in, size_t n, float *out, void *s)
+{
+    job *j = new_job(job_take_i); j->p[0] = (void *)in; j->p[1] = out; j->z[0] = n; j->z[1] = n; j->z[2] = n; j->z[3] = 1;
+    return enqueue(s, j);
+}
 int clhip_take_i_rail_rows(const float *in, size_t is, size_t n, int rows, float *out, size_t os, void *s)
-{ (void)in; (void)is; (void)n; (void)rows; (void)out; (void)os; (void)s; set_err("clhip_mock: no TX"); return -1; }
-void clhip_tx_pipe_set_poll_bound(clhip_tx_pipe *p, int polls) { (void)p; (void)polls; }
+{
+    job *j = new_job(job_take_i); j->p[0] = (void *)in; j->p[1] = out; j->z[0] = n; j->z[1] = is; j->z[2] = os; j->z[3] = (size_t)rows;
+    return enqueue(s, j);
+}
+static void job_words_rows(job *j)
+{
+    uint8_t **dst = (uint8_t **)j->p[1];
+    for (size_t r = 0; r < j->z[2]; r++) memcpy(dst[r], (const uint8_t *)j->p[0] + r * j->z[0], 4 * j->z[1]);
+    free(dst);
+}
 int clhip_words_to_rows(const uint8_t *w, size_t is, size_t n, int rows, uint8_t *const *dst, void *s)
-{ (void)w; (void)is; (void)n; (void)rows; (void)dst; (void)s; set_err("clhip_mock: no TX"); return -1; }
+{
+    if (rows < 0 || rows > CLHIP_PACK_ROWS) { set_err("clhip_words_to_rows: 1 .. 8 rows"); return -1; }
+    uint8_t **d = (uint8_t **)malloc(sizeof(uint8_t *) * (size_t)(rows ? rows : 1));       /* (the addresses are read at the call) */
+    memcpy(d, dst, sizeof(uint8_t *) * (size_t)rows);
+    job *j = new_job(job_words_rows); j->p[0] = (void *)w; j->p[1] = d; j->z[0] = is; j->z[1] = n; j->z[2] = (size_t)rows;
+    return enqueue(s, j);
+}
+clhip_tx_pipe *clhip_tx_pipe_create(int n_streams, double kf, double fs, const float *rs, int n_rs, int up, int down, int mode)
+{
+    (void)fs; (void)rs; (void)n_rs;
+    if (n_streams < 1 || n_streams > MOCK_TX_MAXS || up != 1 || down != 1) { set_err("clhip_mock: TX pipes of 1 .. %d streams without a resampler", MOCK_TX_MAXS); return NULL; }
+    clhip_tx_pipe *p = (clhip_tx_pipe *)calloc(1, sizeof *p);
+    p->n = n_streams; p->mode = mode; p->fm = kf != 0.0;
+    return p;
+}
+void clhip_tx_pipe_destroy(clhip_tx_pipe *p) { if (p) { sync_all(); free(p); } }
+static void job_tx_run(job *j)
+{
+    clhip_tx_pipe *p = (clhip_tx_pipe *)j->p[0];
+    const int from = (int)j->i[0], kind = (int)j->i[1], fail = (int)j->i[2];
+    const size_t n = j->z[0], is = j->z[1], ws = j->z[2];
+    int16_t *iq = (int16_t *)malloc(4 * (n ? n : 1));
+    for (int s = 0; s < p->n; s++) {
+        long long acc = p->acc[from][s]; int prev = p->prev[from][s];
+        for (size_t k = 0; k < n; k++) {
+            const float m = kind == CL_TXPIPE_IN_FM_MESSAGE ? ((const float *)j->p[1])[(size_t)s * is + k] : ((const float *)j->p[1])[2 * ((size_t)s * is + k)];
+            const int v = (int)lrintf(m * 4096.0f);
+            acc += v;
+            int q = v + prev; if (q > 4095) q = 4095; if (q < -4096) q = -4096;
+            iq[2 * k] = (int16_t)((int)(((acc % 8191) + 8191) % 8191) - 4095); iq[2 * k + 1] = (int16_t)q;
+            prev = v;
+        }
+        p->acc[from ^ 1][s] = acc; p->prev[from ^ 1][s] = prev;
+        if (fail) memset((uint8_t *)j->p[2] + (size_t)s * ws, 0xEE, 4 * n);
+        else orc_generate_data(p->mode == CL_TX_AS_WRITTEN ? ORC_TX_AS_WRITTEN : ORC_TX_DOCUMENTED, iq, n, (uint8_t *)j->p[2] + (size_t)s * ws);
+    }
+    free(iq);
+    if (fail) __atomic_store_n(&p->lb_err, 1, __ATOMIC_RELEASE);
+}
+long clhip_tx_pipe_run(clhip_tx_pipe *p, int kind, const void *in, size_t is, size_t n, uint8_t *w, size_t ws, float *iq, size_t iqs, void *s)
+{
+    (void)iq; (void)iqs;
+    if (!p || !in || !w) { set_err("clhip_tx_pipe_run: bad arguments"); return -1; }
+    if (!n) return 0;
+    p->undo_n_total = p->n_total; p->undo_cur = p->cur; p->can_undo = 1;
+    p->runs++;
+    const int fail = g_tx_fail_every && !p->forced && p->runs % g_tx_fail_every == 0;
+    job *j = new_job(job_tx_run); j->p[0] = p; j->p[1] = (void *)in; j->p[2] = w; j->z[0] = n; j->z[1] = is; j->z[2] = ws; j->i[0] = p->cur; j->i[1] = kind; j->i[2] = fail;
+    if (enqueue(s, j)) return -1;
+    p->cur ^= 1; p->n_total += n;
+    return (long)n;
+}
+int clhip_tx_pipe_status(clhip_tx_pipe *p)
+{
+    if (!p) return -1;
+    if (!__atomic_load_n(&p->lb_err, __ATOMIC_ACQUIRE)) return 0;
+    p->lb_err = 0; p->forced = 1;
+    if (p->can_undo) { p->cur = p->undo_cur; p->n_total = p->undo_n_total; p->can_undo = 0; }
+    set_err("clhip_tx_pipe_status: look-back poll overran (mock)");
+    return -1;
+}
+void clhip_tx_pipe_set_poll_bound(clhip_tx_pipe *p, int polls) { (void)p; (void)polls; }
+unsigned long long clhip_tx_pipe_position(const clhip_tx_pipe *p) { return p ? p->n_total : 0; }
+int clhip_tx_pipe_pack_mode(const clhip_tx_pipe *p) { return p ? p->mode : -1; }
+int clhip_tx_pipe_set_position(clhip_tx_pipe *p, unsigned long long n) { if (!p) return -1; p->n_total = n; p->can_undo = 0; return 0; }
+int clhip_tx_pipe_move_stream(clhip_tx_pipe *d, int ds, clhip_tx_pipe *sp, int ss, void *st)
+{
+    if (!d || !sp || ds < 0 || ss < 0 || ds >= d->n || ss >= sp->n) { set_err("clhip_tx_pipe_move_stream: bad arguments"); return -1; }
+    clhip_stream_sync(st);
+    /* (both pipes idle: a run in flight on either would race with these plain accesses -- which is what ThreadSanitizer is here to see) */
+    d->acc[d->cur][ds] = sp->acc[sp->cur][ss]; d->prev[d->cur][ds] = sp->prev[sp->cur][ss];
+    d->can_undo = 0; sp->can_undo = 0;
+    return 0;
+}

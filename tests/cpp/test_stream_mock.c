@@ -6,7 +6,9 @@
  *   B  readStream on the calling thread with the seam's read-ahead, CF32, plain and into a registered buffer (ZEROCOPY=1), with a
  *      flush in between;
  *   C  writeStream CS16 / CF32 (conversion + caribou_smi_generate_data into the pinned TX FIFO) against a drainer thread;
- *   D  cl_group_writeStream over eleven TX devices, a drainer thread per member.
+ *   D  cl_group_writeStream over eleven TX devices, a drainer thread per member;
+ *   E  the same with a modulator on every member (the group's multi-stream TX pipes: carried state moving between the members' own
+ *      pipes and the group's, a launch that gives up and is repeated at commit time), a drainer thread per member.
  * Sample n of a stream carries n in its 24 payload bits, so every delivered block names its own place in the stream: blocks must be
  * contiguous inside and strictly ascending across calls (an overwrite-oldest ring may skip, never repeat or reorder). */
 #include <assert.h>
@@ -228,10 +230,98 @@ static int part_d(const char *fmt, int n_mtus)
     return bad || gs.errors || gs.single_reads ? -1 : 0;
 }
 
+/* E: a group of TX devices WITH A MODULATOR (cl_group_writeStream's modulator lanes: one multi-stream TX pipe per sub-batch; the mock's
+ * pipe is a prefix sum over the whole stream, so every word names the state it was made from) against one drainer thread per member.
+ * Every member is written the same samples; every fifth call one member is written through its own device instead and left out of the
+ * group's call (buffs[i] = NULL) -- its carried state goes home and comes back, its sub-batch goes one by one for that call; every
+ * seventh run of a pipe "gives up" once (clhip_mock_tx_fail_every): the group repeats the sub-batch when it commits its words. */
+void clhip_mock_tx_fail_every(int k);
+typedef struct { cl_smi *smi; volatile uint64_t total; volatile int bad; } mdrain_arg;
+static void *mod_drainer(void *arg)
+{
+    mdrain_arg *a = (mdrain_arg *)arg;
+    uint8_t *got = (uint8_t *)malloc(NB), *want = (uint8_t *)malloc(NB);
+    int16_t *iq = (int16_t *)malloc(NB);
+    uint64_t g = 0; long long acc = 0; int prev = 0;
+    while (g < a->total && !a->bad) {
+        const size_t n = cl_smi_drain_bytes(a->smi, got, NB);
+        if (!n) { sched_yield(); usleep(20); continue; }
+        assert(n % 4 == 0);
+        for (size_t k = 0; k < n / 4; k++) {
+            int I, Q; sample_of(g + k, &I, &Q);
+            acc += I;
+            int q = I + prev; if (q > 4095) q = 4095; if (q < -4096) q = -4096;
+            iq[2 * k] = (int16_t)((int)(((acc % 8191) + 8191) % 8191) - 4095); iq[2 * k + 1] = (int16_t)q;
+            prev = I;
+        }
+        orc_generate_data(ORC_TX_DOCUMENTED, iq, n / 4, want);
+        if (memcmp(got, want, n)) { fprintf(stderr, "modulated TX bytes differ behind message %llu\n", (unsigned long long)g); a->bad = 1; }
+        g += n / 4;
+    }
+    free(got); free(want); free(iq);
+    return NULL;
+}
+
+static int part_e(int n_mtus)
+{
+    cl_device *d[N_TX]; cl_stream *st[N_TX]; mdrain_arg da[N_TX]; pthread_t th[N_TX];
+    const char *sk[] = {"MOD"}, *sv[] = {"FM:75000"};
+    for (int i = 0; i < N_TX; i++) {
+        cl_smi *smi0;
+        {   /* (the pack mode is the pipe's, taken when the stream is set up) */
+            const char *dk[] = {"driver", "channel"}, *dv[] = {"Cariboulite", "S1G"};
+            d[i] = cl_device_make(dk, dv, 2); assert(d[i]);
+            smi0 = cl_device_smi(d[i]);
+            cl_smi_set_tx_mode(smi0, CL_TX_DOCUMENTED);
+            st[i] = cl_setupStream(d[i], CL_SOAPY_SDR_TX, "CF32", NULL, 0, sk, sv, 1);
+            if (!st[i]) { fprintf(stderr, "setupStream: %s\n", cl_device_last_error(d[i])); abort(); }
+            assert(cl_activateStream(d[i], st[i], 0, 0, 0) == 0);
+        }
+        da[i] = (mdrain_arg){smi0, (uint64_t)n_mtus * MTU, 0};
+    }
+    const char *gk[] = {"COPY_THREADS"}, *gv[] = {"2"};
+    cl_group *grp = cl_group_make(d, N_TX, gk, gv, 1);
+    if (!grp) { fprintf(stderr, "cl_group_make: %s\n", cl_group_last_error(NULL)); return -1; }
+    clhip_mock_tx_fail_every(7);
+    for (int i = 0; i < N_TX; i++) pthread_create(&th[i], NULL, mod_drainer, &da[i]);
+    float *buf = (float *)malloc(MTU * 8);                          /* (every member is written the same samples: one buffer) */
+    const void *bufs[N_TX]; int rets[N_TX];
+    uint64_t g = 0; long calls = 0, lone = 0; int bad = 0;
+    while (g < da[0].total && !bad) {
+        const size_t num = calls % 3 == 2 ? MTU / 2 : MTU;
+        for (size_t k = 0; k < num; k++) { int I, Q; sample_of(g + k, &I, &Q); buf[2 * k] = (float)I / 4096.0f; buf[2 * k + 1] = (float)Q / 4096.0f; }
+        const int out = calls % 5 == 4 ? (int)(calls / 5) % N_TX : -1;
+        for (int i = 0; i < N_TX; i++) bufs[i] = i == out ? NULL : buf;
+        if (out >= 0) {
+            const void *b[1] = {buf};
+            if (cl_writeStream(d[out], st[out], b, num, NULL, 0, 1000) != (int)num) { fprintf(stderr, "writeStream: %s\n", cl_device_last_error(d[out])); bad = 1; break; }
+            lone++;
+        }
+        const int nd = cl_group_writeStream(grp, bufs, num, rets, 1000);
+        calls++;
+        if (nd != N_TX - (out >= 0)) { fprintf(stderr, "cl_group_writeStream: %d (%s)\n", nd, cl_group_last_error(grp)); bad = 1; break; }
+        for (int i = 0; i < N_TX; i++) if (rets[i] != (i == out ? 0 : (int)num)) bad = 1;
+        for (int i = 0; i < N_TX; i++) bad |= da[i].bad;
+        g += num;
+    }
+    if (bad) for (int i = 0; i < N_TX; i++) da[i].total = 0;         /* (let the drainers go) */
+    for (int i = 0; i < N_TX; i++) { pthread_join(th[i], NULL); bad |= da[i].bad; }
+    cl_group_stats gs; cl_group_getStats(grp, &gs);
+    uint64_t overruns = 0;
+    for (int i = 0; i < N_TX; i++) { cl_stream_stats ss; cl_getStreamStats(d[i], st[i], &ss); overruns += ss.tx_overruns; }
+    cl_group_unmake(grp);
+    clhip_mock_tx_fail_every(0);
+    for (int i = 0; i < N_TX; i++) cl_device_unmake(d[i]);
+    free(buf);
+    printf("E: %ld calls, %llu batched writes, %llu one by one, %ld lone, %llu launches, %llu repeated member-calls\n", calls, (unsigned long long)gs.batched_reads,
+           (unsigned long long)gs.single_reads, lone, (unsigned long long)gs.launches, (unsigned long long)overruns);
+    return bad || gs.errors || !gs.batched_reads || !gs.single_reads || !overruns || !lone ? -1 : 0;
+}
+
 int main(int argc, char **argv)
 {
     const int n = argc > 1 ? atoi(argv[1]) : 24;
-    if (part_a("CS16", n) || part_a("CF32", n) || part_b(n) || part_c("CS16", n) || part_c("CF32", n) || part_d("CS16", n / 2) || part_d("CF32", n / 2)) {
+    if (part_a("CS16", n) || part_a("CF32", n) || part_b(n) || part_c("CS16", n) || part_c("CF32", n) || part_d("CS16", n / 2) || part_d("CF32", n / 2) || part_e(n)) {
         fprintf(stderr, "stream mock harness FAILED\n"); return 1;
     }
     printf("stream mock harness ok\n");
