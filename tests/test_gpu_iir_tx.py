@@ -761,3 +761,78 @@ def test_iir_last_call_can_be_taken_back(G, orc):
         assert f.status() == 0 and ref.status() == 0
         assert torch.equal(a1, a2) and torch.equal(c1, c2), onepass
         assert f.unrun() == 0 and f.unrun() != 0                    # one level
+
+
+def test_tx_pipe_stream_state_moves_between_pipes(G, orc):
+    """clhip_tx_pipe_move_stream / _position / _set_position (what a stream group's modulator lanes rest on): a stream run for a while
+    in a pipe of its own, moved into stream 2 of a four-stream pipe, run on there beside three others, moved home and run again yields,
+    piece by piece and bit for bit, the words ONE pipe yields over the same calls -- phase, resampler history and polyphase position carried; the
+    pieces' lengths leave every residue mod 3 at the moves.  Pipes of another configuration refuse."""
+    import torch
+    from cariboulite_amd import hip
+    t = load_golden("taps.npz")
+    rng = np.random.default_rng(78)
+    n = 90_000
+    msg = (0.4 * np.sin(2 * np.pi * 3e3 * np.arange(n) / 4e6) + 0.3 * rng.standard_normal(n)).astype(np.float32)
+    others = (0.5 * rng.standard_normal((4, n))).astype(np.float32)
+    d = torch.from_numpy(msg).to(G.DEV)
+    plan = (("own", 10_001), ("grp", 20_000), ("grp", 7), ("own", 30_001), ("grp", 12_345), ("own", n - 72_354))
+    one = hip.TxPipe(1, 75e3, 4e6, t["rs_2_3"], 2, 3, hip.TX_DOCUMENTED)      # (the same calls: another split re-associates the fp64 phase sums)
+    want, pos = [], 0
+    for _, cn in plan:
+        k = one.out_count(cn)
+        by = torch.zeros(4 * max(k, 1), dtype=torch.uint8, device=G.DEV)
+        assert one.run(hip.TXPIPE_IN_FM_MESSAGE, d[pos:], 0, cn, by, 4 * max(k, 1)) == k
+        want.append(by[:4 * k].cpu().numpy()); pos += cn
+    want = np.concatenate(want)
+    own = hip.TxPipe(1, 75e3, 4e6, t["rs_2_3"], 2, 3, hip.TX_DOCUMENTED)
+    grp = hip.TxPipe(4, 75e3, 4e6, t["rs_2_3"], 2, 3, hip.TX_DOCUMENTED)
+    got, pos = [], 0
+    for where, cn in plan:
+        if where == "grp" and pos and got[-1][0] == "own":
+            grp.set_position(own.position()); grp.take_stream_from(2, own, 0)
+        if where == "own" and got and got[-1][0] == "grp":
+            own.set_position(grp.position()); own.take_stream_from(0, grp, 2)
+        if where == "own":
+            kk = own.out_count(cn)
+            by = torch.zeros(4 * max(kk, 1), dtype=torch.uint8, device=G.DEV)
+            assert own.run(hip.TXPIPE_IN_FM_MESSAGE, d[pos:], 0, cn, by, 4 * max(kk, 1)) == kk
+            torch.cuda.synchronize(); assert own.status() == 0
+            got.append(("own", by[:4 * kk].cpu().numpy()))
+        else:
+            kk = grp.out_count(cn)
+            rows = torch.from_numpy(others[:, pos:pos + cn].copy()).to(G.DEV)
+            rows[2] = d[pos:pos + cn]
+            by = torch.zeros((4, 4 * max(kk, 1)), dtype=torch.uint8, device=G.DEV)
+            assert grp.run(hip.TXPIPE_IN_FM_MESSAGE, rows, cn, cn, by, 4 * max(kk, 1)) == kk
+            torch.cuda.synchronize(); assert grp.status() == 0
+            got.append(("grp", by[2, :4 * kk].cpu().numpy()))
+        pos += cn
+    assert pos == n
+    assert np.array_equal(np.concatenate([g for _, g in got]), want)
+    other_cfg = hip.TxPipe(1, 25e3, 4e6, t["rs_2_3"], 2, 3, hip.TX_DOCUMENTED)
+    with pytest.raises(RuntimeError, match="configured differently"):
+        other_cfg.take_stream_from(0, own, 0)
+
+
+def test_i_rail_rows_and_words_to_rows(G):
+    """The two row launches of the modulator lanes: the I rails of n_rows strided CF32 rows as dense messages, and rows of words stored
+    into n_rows destinations of their own (16-byte aligned and not)."""
+    import ctypes as C
+    import torch
+    from cariboulite_amd import hip
+    rng = np.random.default_rng(79)
+    rows, n, stride = 5, 10_007, 10_040
+    x = torch.from_numpy(rng.standard_normal((rows, stride, 2)).astype(np.float32)).to(G.DEV)
+    msg = torch.zeros((rows, n + 9), dtype=torch.float32, device=G.DEV)
+    assert hip.lib().clhip_take_i_rail_rows(x.data_ptr(), stride, n, rows, msg.data_ptr(), n + 9, None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(msg[:, :n], x[:, :n, 0]) and float(msg[:, n:].abs().max()) == 0.0
+    w = torch.from_numpy(rng.integers(0, 2**32, (rows, stride), dtype=np.uint64).astype(np.uint32).view(np.int32)).to(G.DEV)
+    dst = torch.zeros((rows, n + 16), dtype=torch.int32, device=G.DEV)
+    ptrs = (C.c_void_p * rows)(*[dst[r].data_ptr() + 4 * (r % 3) for r in range(rows)])      # offsets of 0 / 4 / 8 bytes
+    assert hip.lib().clhip_words_to_rows(w.data_ptr(), 4 * stride, n, rows, ptrs, None) == 0
+    torch.cuda.synchronize()
+    for r in range(rows):
+        o = r % 3
+        assert torch.equal(dst[r, o:o + n], w[r, :n]) and int(dst[r, :o].abs().sum()) == 0 and int(dst[r, o + n:].abs().sum()) == 0
