@@ -119,32 +119,45 @@ SoapySDR::KwargsList findCaribouliteHip(const SoapySDR::Kwargs &args)
 SoapySDR::Device *makeCaribouliteHip(const SoapySDR::Kwargs &args) { return new CaribouliteHip(args); }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Many boards on one GPU as ONE multi-channel Soapy device: driver=CaribouliteGroup, channels="S1G,HiF,S1G,..." (one entry per
-// underlying Cariboulite device, i.e. per board and channel type).  SoapySDR's own multi-channel stream shape --
+// Many boards as ONE multi-channel Soapy device: driver=CaribouliteGroup, channels="S1G,HiF,S1G,..." (one entry per
+// underlying Cariboulite device, i.e. per board and channel type); gpus="0,1,...,7" spreads them over the GPUs of the node, channel i on
+// gpus[i mod N] (independent streams, no data-path collective: cl_node runs one cl_group per GPU, all at once); without it they all
+// live on the GPU the `gpu` kwarg names (default 0).  SoapySDR's own multi-channel stream shape --
 // setupStream(dir, fmt, {0 .. N-1}) and readStream(stream, buffs[N], numElems, ...) -- which the reference declines (one channel per
-// device, Cariboulite.hpp:59) maps one-to-one onto cl_group_readStream / cl_group_writeStream: every channel is exactly the
+// device, Cariboulite.hpp:59) maps one-to-one onto cl_node_readStream / cl_node_writeStream (= cl_group_* per GPU): every channel is exactly the
 // reference's device for that board, all of them read (or written) in one call.  readStream returns the LARGEST count any channel
 // delivered (SoapySDR has one return value for all channels); readSetting("GROUP_RETS") gives the last call's count per channel
 // ("131072,131072,0,..."): a channel that re-synchronised or timed out says so there, exactly as its own readStream would have.
 class CaribouliteGroupHip : public SoapySDR::Device {
     std::vector<cl_device *> devs_;
     std::vector<cl_stream *> streams_;
-    cl_group *grp_ = nullptr;
+    cl_node *grp_ = nullptr;
     SoapySDR::Kwargs group_args_;
     mutable std::vector<int> rets_;
 
-    void drop_group() { if (grp_) { cl_group_unmake(grp_); grp_ = nullptr; } }
+    void drop_group() { if (grp_) { cl_node_unmake(grp_); grp_ = nullptr; } }
 
 public:
     explicit CaribouliteGroupHip(const SoapySDR::Kwargs &args)
     {
         const std::string list = args.count("channels") ? args.at("channels") : "";
+        std::vector<std::string> gpus;
+        if (args.count("gpus")) {
+            const std::string g = args.at("gpus");
+            for (size_t p = 0; p <= g.size();) {
+                const size_t c = g.find(',', p);
+                gpus.push_back(g.substr(p, c == std::string::npos ? std::string::npos : c - p));
+                if (c == std::string::npos) break;
+                p = c + 1;
+            }
+        }
         size_t pos = 0;
         while (pos <= list.size() && !list.empty()) {
             const size_t comma = list.find(',', pos);
             const std::string ch = list.substr(pos, comma == std::string::npos ? std::string::npos : comma - pos);
             SoapySDR::Kwargs one = args;
-            one.erase("channels"); one["driver"] = "Cariboulite"; one["channel"] = ch;
+            one.erase("channels"); one.erase("gpus"); one["driver"] = "Cariboulite"; one["channel"] = ch;
+            if (!gpus.empty()) one["gpu"] = gpus[devs_.size() % gpus.size()];
             KwArrays a(one);
             cl_device *d = cl_device_make(a.k.data(), a.v.data(), a.k.size());
             if (!d) { for (cl_device *x : devs_) cl_device_unmake(x); throw std::runtime_error("CaribouliteGroup: channels=\"S1G,HiF,...\""); }
@@ -154,7 +167,7 @@ public:
         }
         if (devs_.empty()) throw std::runtime_error("CaribouliteGroup: channels=\"S1G,HiF,...\"");
         for (const auto &it : args)                          // group kwargs (SUBBATCH, COPY_THREADS, READAHEAD, ...) pass through
-            if (it.first != "driver" && it.first != "channels" && it.first != "gpu") group_args_[it.first] = it.second;
+            if (it.first != "driver" && it.first != "channels" && it.first != "gpu" && it.first != "gpus") group_args_[it.first] = it.second;
         rets_.assign(devs_.size(), 0);
     }
     ~CaribouliteGroupHip() override
@@ -196,8 +209,8 @@ public:
             streams_.push_back(s);
         }
         KwArrays ga(group_args_);
-        grp_ = cl_group_make(devs_.data(), devs_.size(), ga.k.data(), ga.v.data(), ga.k.size());
-        if (!grp_) throw std::runtime_error(cl_group_last_error(nullptr));
+        grp_ = cl_node_make(devs_.data(), devs_.size(), ga.k.data(), ga.v.data(), ga.k.size());
+        if (!grp_) throw std::runtime_error(cl_node_last_error(nullptr));
         return reinterpret_cast<SoapySDR::Stream *>(grp_);
     }
     void closeStream(SoapySDR::Stream *) override
@@ -220,7 +233,7 @@ public:
     int readStream(SoapySDR::Stream *, void *const *buffs, const size_t numElems, int &, long long &, const long timeoutUs) override
     {
         if (!grp_) return -5;
-        if (cl_group_readStream(grp_, buffs, numElems, rets_.data(), timeoutUs) < 0) return -1;      // SOAPY_SDR_TIMEOUT where the runtime failed
+        if (cl_node_readStream(grp_, buffs, numElems, rets_.data(), timeoutUs) < 0) return -1;      // SOAPY_SDR_TIMEOUT where the runtime failed
         int most = 0, wrong = 0;
         for (int r : rets_) { if (r > most) most = r; if (r < 0) wrong = r; }
         return wrong ? wrong : most;                         // (NOT_SUPPORTED: a group set up for TX)
@@ -228,7 +241,7 @@ public:
     int writeStream(SoapySDR::Stream *, const void *const *buffs, const size_t numElems, int &, const long long, const long timeoutUs) override
     {
         if (!grp_) return -5;
-        if (cl_group_writeStream(grp_, buffs, numElems, rets_.data(), timeoutUs) < 0) return -1;
+        if (cl_node_writeStream(grp_, buffs, numElems, rets_.data(), timeoutUs) < 0) return -1;
         int most = 0, wrong = 0;
         for (int r : rets_) { if (r > most) most = r; if (r < 0) wrong = r; }
         return wrong ? wrong : most;
@@ -240,6 +253,7 @@ public:
         std::string out;
         if (key == "GROUP_RETS")
             for (size_t i = 0; i < rets_.size(); i++) out += (i ? "," : "") + std::to_string(rets_[i]);
+        if (key == "GROUP_SHARDS") out = std::to_string(grp_ ? cl_node_shards(grp_) : 0);      // groups the calls run at once (GPUs x SHARDS)
         return out;
     }
     void writeSetting(const std::string &key, const std::string &value) override

@@ -106,6 +106,16 @@ _SIGS = {
     "cl_group_set_iir_poll_bound": (None, [C.c_void_p, C.c_int]),
     "cl_group_set_tx_poll_bound": (None, [C.c_void_p, C.c_int]),
     "cl_group_flush": (C.c_int, [C.c_void_p]),
+    "cl_node_make": (C.c_void_p, [C.POINTER(C.c_void_p), C.c_size_t, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_size_t]),
+    "cl_node_unmake": (None, [C.c_void_p]),
+    "cl_node_size": (C.c_size_t, [C.c_void_p]),
+    "cl_node_shards": (C.c_size_t, [C.c_void_p]),
+    "cl_node_group": (C.c_void_p, [C.c_void_p, C.c_size_t]),
+    "cl_node_shard_of": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "cl_node_readStream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t, C.POINTER(C.c_int), C.c_long]),
+    "cl_node_writeStream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t, C.POINTER(C.c_int), C.c_long]),
+    "cl_node_flush": (C.c_int, [C.c_void_p]),
+    "cl_node_last_error": (C.c_char_p, [C.c_void_p]),
     "cl_group_last_error": (C.c_char_p, [C.c_void_p]),
     "cl_group_getStats": (None, [C.c_void_p, C.c_void_p]),
     "cl_group_register_buffers": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t]),
@@ -440,6 +450,75 @@ class Group:
     def close(self):
         if getattr(self, "h", None) and _lib is not None:
             _lib.cl_group_unmake(self.h)
+            for d in getattr(self, "devices", ()):
+                d._group = None
+        self.h = None
+
+    __del__ = close
+
+
+class Node:
+    """cl_node: devices of SEVERAL GPUs (their `gpu` kwarg) read or written in one call -- one cl_group per GPU, every group's call at
+    once on a thread of its own (include/cariboulite_hip.h, "ONE call over the stream groups of SEVERAL GPUs").  args: SHARDS=<k> groups
+    per GPU (rehearsal on one GPU), the rest are the groups' kwargs."""
+
+    def __init__(self, devices, args=None):
+        self.devices = list(devices)
+        K, V, n = _kwargs(args)
+        arr = (C.c_void_p * len(self.devices))(*[d.h for d in self.devices])
+        self.h = lib().cl_node_make(arr, len(self.devices), K, V, n)
+        if not self.h:
+            raise RuntimeError(lib().cl_node_last_error(None).decode())
+        self._rets = (C.c_int * len(self.devices))()
+        self._ptrs = (C.c_void_p * len(self.devices))()
+        import weakref
+        for d in self.devices:
+            d._group = weakref.ref(self)
+
+    def _set(self, buffs):
+        last = getattr(self, "_last_buffs", ())
+        if len(last) != len(buffs) or any(x is not y for x, y in zip(last, buffs)):
+            for i, b in enumerate(buffs):
+                self._ptrs[i] = b.ctypes.data if b is not None else None
+            self._last_buffs = tuple(buffs)
+
+    def readStream(self, buffs, numElems, timeoutUs=100000):
+        self._set(buffs)
+        n = lib().cl_node_readStream(self.h, self._ptrs, numElems, self._rets, timeoutUs)
+        return n, list(self._rets)
+
+    def writeStream(self, buffs, numElems, timeoutUs=100000):
+        self._set(buffs)
+        n = lib().cl_node_writeStream(self.h, self._ptrs, numElems, self._rets, timeoutUs)
+        return n, list(self._rets)
+
+    def flush(self):
+        return lib().cl_node_flush(self.h)
+
+    def shards(self):
+        return int(lib().cl_node_shards(self.h))
+
+    def shardOf(self, member):
+        return int(lib().cl_node_shard_of(self.h, member))
+
+    def lastError(self):
+        return lib().cl_node_last_error(self.h).decode()
+
+    def stats(self):
+        """the groups' statistics, summed (the three last_*_us fields: the slowest group's)"""
+        names = ("calls", "batched_reads", "single_reads", "direct_reads", "launches", "errors", "copies_2d", "last_queue_us",
+                 "last_arrive_us", "last_total_us", "ahead_reads")
+        tot = dict.fromkeys(names, 0)
+        for s in range(self.shards()):
+            out = (C.c_uint64 * 11)()
+            lib().cl_group_getStats(lib().cl_node_group(self.h, s), out)
+            for k, v in zip(names, out):
+                tot[k] = max(tot[k], int(v)) if k.startswith("last_") else tot[k] + int(v)
+        return tot
+
+    def close(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.cl_node_unmake(self.h)
             for d in getattr(self, "devices", ()):
                 d._group = None
         self.h = None

@@ -668,6 +668,26 @@ void        cl_group_set_tx_poll_bound(cl_group *g, int polls);       /* test ho
 int         cl_group_register_buffers(cl_group *g, void *const *buffs, size_t bytes_each);
 void        cl_group_unregister_buffers(cl_group *g);
 
+/* ---- ONE call over the stream groups of SEVERAL GPUs (csrc/host/cl_node.c) ----
+ * Independent channel streams shard over the GPUs of a node with no data-path collective (one SoapySDR device per channel,
+ * soapy_api/SoapyCariboulite.cpp:46-69): the devices are made with their `gpu` kwarg, cl_node_make sorts them into
+ * one cl_group per GPU and a call runs every group's call at once, each on a thread of its own (shard 0 on the caller's).  buffs[i] /
+ * rets[i] are member i's, in the order the devices were given, exactly as in cl_group_readStream / cl_group_writeStream; the return value
+ * is the groups' sum, or -1 if a group failed (cl_node_last_error; NULL node = the last cl_node_make failure).  kwarg SHARDS=<k> cuts every
+ * GPU's members into k groups (contiguous blocks): the several-groups-at-once shape on a one-GPU box (tests); every other kwarg is
+ * cl_group_make's.  cl_node_unmake BEFORE cl_device_unmake of any member. */
+typedef struct cl_node cl_node;
+cl_node    *cl_node_make(cl_device *const *devs, size_t n_devs, const char *const *keys, const char *const *vals, size_t n_kwargs);
+void        cl_node_unmake(cl_node *nd);
+size_t      cl_node_size(const cl_node *nd);
+size_t      cl_node_shards(const cl_node *nd);                       /* groups the node runs (GPUs x SHARDS, none empty) */
+cl_group   *cl_node_group(const cl_node *nd, size_t shard);          /* (its statistics, registered buffers, test hooks) */
+int         cl_node_shard_of(const cl_node *nd, size_t member);      /* the shard member i went to (-1: none) */
+int         cl_node_readStream(cl_node *nd, void *const *buffs, size_t numElems, int *rets, long timeoutUs);
+int         cl_node_writeStream(cl_node *nd, const void *const *buffs, size_t numElems, int *rets, long timeoutUs);
+int         cl_node_flush(cl_node *nd);                              /* cl_group_flush of every group (0 / -1) */
+const char *cl_node_last_error(const cl_node *nd);
+
 /* host helper: scipy.signal.firwin(ntaps, cutoff, window="hamming", fs=fs)
  * (the tap design SURVEY.md section 8 a13 specifies), rounded to fp32 */
 int    cl_design_lowpass(int n_taps, double cutoff_hz, double fs_hz, double gain, float *taps_out);

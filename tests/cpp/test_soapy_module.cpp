@@ -76,6 +76,26 @@ int main()
     }
     grp->deactivateStream(gs);
     delete grp;
+    // ---- the same over the node layer's several-groups-at-once shape: gpus="0" + SHARDS=2 (two groups on GPU 0, their calls on two threads)
+    gq["gpus"] = "0"; gq["SHARDS"] = "2";
+    grp = tab[1].make(gq);
+    gs = grp->setupStream(SOAPY_SDR_RX, SOAPY_SDR_CS16, std::vector<size_t>{0, 1, 2});
+    grp->activateStream(gs);
+    if (grp->readSetting("GROUP_SHARDS") != "2") { printf("FAIL group shards [%s]\n", grp->readSetting("GROUP_SHARDS").c_str()); return 1; }
+    for (int c = 1; c < 3; c++) {                                   // channels 1 and 2 (one in each shard) get a batch
+        snprintf(val, sizeof val, "%llx:%llu", (unsigned long long)(uintptr_t)words, (unsigned long long)sizeof words);
+        char key[32]; snprintf(key, sizeof key, "SMI_FEED_PTR:%d", c);
+        grp->writeSetting(key, val);
+    }
+    memset(gbuf, 0, sizeof gbuf);
+    const int gn2 = grp->readStream(gs, gb, 131072, flags, t, 100000);
+    if (gn2 != 131072 || grp->readSetting("GROUP_RETS") != "0,131072,131072") { printf("FAIL sharded group readStream %d [%s]\n", gn2, grp->readSetting("GROUP_RETS").c_str()); return 1; }
+    for (int i = 0; i < 8; i++) {
+        if (gbuf[2][i][0] != want[i][0] || gbuf[2][i][1] != want[i][1]) { printf("FAIL sharded group S1G sample %d\n", i); return 1; }
+        if (gbuf[1][i][0] != want[i][1] || gbuf[1][i][1] != want[i][0]) { printf("FAIL sharded group HiF sample %d\n", i); return 1; }
+    }
+    grp->deactivateStream(gs);
+    delete grp;
     printf("OK soapy module: find/make/setup/feed/read through the Device virtuals\n");
     return 0;
 }

@@ -6,7 +6,8 @@
  *   B  readStream on the calling thread with the seam's read-ahead, CF32, plain and into a registered buffer (ZEROCOPY=1), with a
  *      flush in between;
  *   C  writeStream CS16 / CF32 (conversion + caribou_smi_generate_data into the pinned TX FIFO) against a drainer thread;
- *   D  cl_group_writeStream over eleven TX devices, a drainer thread per member;
+ *   D  cl_group_writeStream over eleven TX devices, a drainer thread per member -- and the same through a cl_node that cuts them into three
+ *      groups, each call's three group calls running at once on threads of their own;
  *   E  the same with a modulator on every member (the group's multi-stream TX pipes: carried state moving between the members' own
  *      pipes and the group's, a launch that gives up and is repeated at commit time), a drainer thread per member.
  * Sample n of a stream carries n in its 24 payload bits, so every delivered block names its own place in the stream: blocks must be
@@ -189,7 +190,7 @@ static int part_c(const char *fmt, int n_mtus)
 /* D: a group of TX devices (cl_group_writeStream: copy threads -> pinned rows -> device rows -> one launch per sub-batch that stores into
  * the room reserved in every member's TX FIFO) against one drainer thread per member */
 #define N_TX 11
-static int part_d(const char *fmt, int n_mtus)
+static int part_d(const char *fmt, int n_mtus, int shards)       /* shards > 0: through a cl_node that cuts the members into that many groups, one thread each */
 {
     cl_device *d[N_TX]; cl_stream *st[N_TX]; drain_arg da[N_TX]; pthread_t th[N_TX];
     for (int i = 0; i < N_TX; i++) {
@@ -197,9 +198,11 @@ static int part_d(const char *fmt, int n_mtus)
         cl_smi_set_tx_mode(cl_device_smi(d[i]), CL_TX_DOCUMENTED);
         da[i] = (drain_arg){cl_device_smi(d[i]), (uint64_t)n_mtus * MTU, 0};
     }
-    const char *gk[] = {"COPY_THREADS"}, *gv[] = {"2"};
-    cl_group *grp = cl_group_make(d, N_TX, gk, gv, 1);
-    if (!grp) { fprintf(stderr, "cl_group_make: %s\n", cl_group_last_error(NULL)); return -1; }
+    const char *gk[] = {"COPY_THREADS", "SHARDS"}, *gv[] = {"2", shards == 3 ? "3" : "2"};
+    cl_group *grp = shards ? NULL : cl_group_make(d, N_TX, gk, gv, 1);
+    cl_node *node = shards ? cl_node_make(d, N_TX, gk, gv, 2) : NULL;
+    if (!grp && !node) { fprintf(stderr, "cl_group_make / cl_node_make: %s / %s\n", cl_group_last_error(NULL), cl_node_last_error(NULL)); return -1; }
+    if (node && (int)cl_node_shards(node) != shards) { fprintf(stderr, "cl_node_shards: %zu\n", cl_node_shards(node)); return -1; }
     for (int i = 0; i < N_TX; i++) pthread_create(&th[i], NULL, drainer, &da[i]);
     const int f32 = !strcmp(fmt, "CF32");
     void *buf = malloc(MTU * 8);                                    /* (every member is written the same samples: one buffer) */
@@ -213,20 +216,24 @@ static int part_d(const char *fmt, int n_mtus)
             if (f32) { ((float *)buf)[2 * k] = (float)I / 4096.0f; ((float *)buf)[2 * k + 1] = (float)Q / 4096.0f; }
             else { ((int16_t *)buf)[2 * k] = (int16_t)I; ((int16_t *)buf)[2 * k + 1] = (int16_t)Q; }
         }
-        const int nd = cl_group_writeStream(grp, bufs, num, rets, 1000);
+        const int nd = node ? cl_node_writeStream(node, bufs, num, rets, 1000) : cl_group_writeStream(grp, bufs, num, rets, 1000);
         calls++;
-        if (nd != N_TX) { fprintf(stderr, "cl_group_writeStream: %d (%s)\n", nd, cl_group_last_error(grp)); bad = 1; break; }
+        if (nd != N_TX) { fprintf(stderr, "cl_group_writeStream: %d (%s)\n", nd, node ? cl_node_last_error(node) : cl_group_last_error(grp)); bad = 1; break; }
         for (int i = 0; i < N_TX; i++) if (rets[i] != (int)num) bad = 1;
         for (int i = 0; i < N_TX; i++) bad |= da[i].bad;
         g += num;
     }
     if (bad) for (int i = 0; i < N_TX; i++) da[i].total = 0;         /* (let the drainers go) */
     for (int i = 0; i < N_TX; i++) { pthread_join(th[i], NULL); bad |= da[i].bad; }
-    cl_group_stats gs; cl_group_getStats(grp, &gs);
-    cl_group_unmake(grp);
+    cl_group_stats gs; memset(&gs, 0, sizeof gs);
+    for (int s = 0; s < (node ? shards : 1); s++) {
+        cl_group_stats one; cl_group_getStats(node ? cl_node_group(node, (size_t)s) : grp, &one);
+        gs.batched_reads += one.batched_reads; gs.launches += one.launches; gs.errors += one.errors; gs.single_reads += one.single_reads;
+    }
+    cl_group_unmake(grp); cl_node_unmake(node);
     for (int i = 0; i < N_TX; i++) cl_device_unmake(d[i]);
     free(buf);
-    printf("D %s: %ld calls, %llu batched writes, %llu launches\n", fmt, calls, (unsigned long long)gs.batched_reads, (unsigned long long)gs.launches);
+    printf("D %s (%d shards): %ld calls, %llu batched writes, %llu launches\n", fmt, shards, calls, (unsigned long long)gs.batched_reads, (unsigned long long)gs.launches);
     return bad || gs.errors || gs.single_reads ? -1 : 0;
 }
 
@@ -321,7 +328,7 @@ static int part_e(int n_mtus)
 int main(int argc, char **argv)
 {
     const int n = argc > 1 ? atoi(argv[1]) : 24;
-    if (part_a("CS16", n) || part_a("CF32", n) || part_b(n) || part_c("CS16", n) || part_c("CF32", n) || part_d("CS16", n / 2) || part_d("CF32", n / 2) || part_e(n)) {
+    if (part_a("CS16", n) || part_a("CF32", n) || part_b(n) || part_c("CS16", n) || part_c("CF32", n) || part_d("CS16", n / 2, 0) || part_d("CF32", n / 2, 0) || part_d("CS16", n / 2, 3) || part_e(n)) {
         fprintf(stderr, "stream mock harness FAILED\n"); return 1;
     }
     printf("stream mock harness ok\n");

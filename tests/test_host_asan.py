@@ -72,7 +72,7 @@ def test_stream_group_host_side_over_a_threaded_hip_model(tmp_path, sanitizer):
     exe = str(tmp_path / "group_mock")
     cmd = ["gcc", "-std=gnu11", "-O1", "-g", f"-fsanitize={sanitizer}", "-fno-omit-frame-pointer",
            os.path.join(ROOT, "tests", "cpp", "test_group_mock.c"), os.path.join(ROOT, "tests", "cpp", "hip_mock", "clhip_mock.c"),
-           os.path.join(ROOT, "oracle", "cl_oracle.c")] + [os.path.join(host, f) for f in ("cl_group.c", "cl_smi.c", "cl_soapy.c", "cl_ring.c")] + \
+           os.path.join(ROOT, "oracle", "cl_oracle.c")] + [os.path.join(host, f) for f in ("cl_group.c", "cl_node.c", "cl_smi.c", "cl_soapy.c", "cl_ring.c")] + \
           ["-I", host, "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "oracle"), "-lpthread", "-lm", "-o", exe]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -91,7 +91,7 @@ def test_single_stream_host_paths_over_a_threaded_hip_model(tmp_path, sanitizer)
     exe = str(tmp_path / "stream_mock")
     cmd = ["gcc", "-std=gnu11", "-O1", "-g", f"-fsanitize={sanitizer}", "-fno-omit-frame-pointer",
            os.path.join(ROOT, "tests", "cpp", "test_stream_mock.c"), os.path.join(ROOT, "tests", "cpp", "hip_mock", "clhip_mock.c"),
-           os.path.join(ROOT, "oracle", "cl_oracle.c")] + [os.path.join(host, f) for f in ("cl_group.c", "cl_smi.c", "cl_soapy.c", "cl_ring.c")] + \
+           os.path.join(ROOT, "oracle", "cl_oracle.c")] + [os.path.join(host, f) for f in ("cl_group.c", "cl_node.c", "cl_smi.c", "cl_soapy.c", "cl_ring.c")] + \
           ["-I", host, "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "oracle"), "-lpthread", "-lm", "-o", exe]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
