@@ -608,6 +608,50 @@ extern "C" int clhip_words_to_rows(const uint8_t *d_words, size_t in_stride_byte
     return 0;
 }
 
+// Rows of results on the device to destinations of their own, lengths of their own -- the clients' REGISTERED buffers of a stream group's
+// sub-batch (cl_group_register_buffers), stored across PCIe by one launch instead of a copy-engine call per member
+struct ByteRows { const uint8_t *src[CLHIP_PACK_ROWS]; uint8_t *dst[CLHIP_PACK_ROWS]; size_t bytes[CLHIP_PACK_ROWS]; };
+
+__global__ __launch_bounds__(256) void rows_to_rows_kernel(ByteRows rows)
+{
+    const uint8_t *__restrict__ src = rows.src[blockIdx.y];
+    uint8_t *__restrict__ dst = rows.dst[blockIdx.y];
+    const size_t n = rows.bytes[blockIdx.y];
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (((((uintptr_t)dst) | ((uintptr_t)src)) & 15) == 0) {
+        const size_t n16 = n / 16;
+        for (size_t j = k; j < n16; j += step) ((u32x4 *)dst)[j] = ((const u32x4 *)src)[j];
+        for (size_t j = 16 * n16 + k; j < n; j += step) dst[j] = src[j];
+    } else if (((((uintptr_t)dst) | ((uintptr_t)src)) & 3) == 0) {
+        const size_t n4 = n / 4;
+        for (size_t j = k; j < n4; j += step) ((uint32_t *)dst)[j] = ((const uint32_t *)src)[j];
+        for (size_t j = 4 * n4 + k; j < n; j += step) dst[j] = src[j];
+    } else {
+        for (size_t j = k; j < n; j += step) dst[j] = src[j];
+    }
+}
+
+extern "C" int clhip_rows_to_rows(const void *const *d_src_rows, void *const *d_dst_rows, const size_t *row_bytes, int n_rows, void *stream)
+{
+    if (n_rows == 0) return 0;
+    if (!d_src_rows || !d_dst_rows || !row_bytes || n_rows < 0 || n_rows > CLHIP_PACK_ROWS) { clhip_set_error("clhip_rows_to_rows: bad arguments (1 .. %d rows)", CLHIP_PACK_ROWS); return -1; }
+    ByteRows rows;
+    size_t most = 0;
+    for (int r = 0; r < CLHIP_PACK_ROWS; r++) {
+        rows.src[r] = r < n_rows ? (const uint8_t *)d_src_rows[r] : nullptr; rows.dst[r] = r < n_rows ? (uint8_t *)d_dst_rows[r] : nullptr;
+        rows.bytes[r] = r < n_rows ? row_bytes[r] : 0;
+        if (r < n_rows && rows.bytes[r] && (!rows.src[r] || !rows.dst[r])) { clhip_set_error("clhip_rows_to_rows: bad row %d", r); return -1; }
+        if (rows.bytes[r] > most) most = rows.bytes[r];
+    }
+    if (!most) return 0;
+    unsigned gx = (unsigned)clhip_div_up(clhip_div_up(most, 16), 256);
+    if (gx > 256) gx = 256;
+    hipLaunchKernelGGL(rows_to_rows_kernel, dim3(gx, (unsigned)n_rows), dim3(256), 0, (hipStream_t)stream, rows);
+    CLHIP_CHECK_LAUNCH();
+    return 0;
+}
+
 // the I rail of interleaved CF32 as a dense fp32 message (the FM modulator's input: SURVEY.md a13 "if given I/Q, use I")
 __global__ __launch_bounds__(256) void take_i_rail_kernel(const f32x2 *__restrict__ in, size_t n, float *__restrict__ out)
 {

@@ -115,6 +115,7 @@ struct cl_group {
     void **ev; size_t n_ev;               /* ev_per per sub-batch and set */
     copy_pool pool;
     uint8_t **reg_base; size_t *reg_len; size_t n_reg;   /* page ranges of client buffers registered with the GPU (cl_group_register_buffers), merged where they touch */
+    uint8_t **reg_dev;                                    /* ... and the device's addresses of them (a launch stores into them across PCIe) */
     uint8_t *has_reg;                                     /* per member: it has a registered buffer */
     uint8_t *slab; size_t slab_slice;     /* ONE pinned allocation the members' byte FIFOs live in, a slice each, lane after lane in row order: batches
                                            * of neighbouring rows that lie at the same offset of their slices are `slab_slice` apart -- one 2-D copy */
@@ -324,7 +325,7 @@ void cl_group_unmake(cl_group *g)
     for (int k = 0; k < GRP_MAX_IN; k++) clhip_stream_destroy(g->s_in[k]);
     clhip_stream_destroy(g->s_k); clhip_stream_destroy(g->s_out);
     free(g->ev); free(g->lane); free(g->dev); free(g->lane_of); free(g->row_of);
-    free(g->reg_base); free(g->reg_len); free(g->has_reg);
+    free(g->reg_base); free(g->reg_len); free(g->has_reg); free(g->reg_dev);
     if (g->tx_mu_ok) pthread_mutex_destroy(&g->tx_mu);
     free(g);
 }
@@ -357,7 +358,8 @@ cl_group *cl_group_make(cl_device *const *devs, size_t n, const char *const *key
     g->lane = (lane_t *)calloc(n, sizeof *g->lane);
     g->reg_base = (uint8_t **)calloc(n, sizeof *g->reg_base);
     g->reg_len = (size_t *)calloc(n, sizeof *g->reg_len); g->has_reg = (uint8_t *)calloc(n, 1);
-    if (!g->dev || !g->lane_of || !g->row_of || !g->lane || !g->reg_base || !g->reg_len || !g->has_reg) { cl_group_unmake(g); return NULL; }
+    g->reg_dev = (uint8_t **)calloc(n, sizeof *g->reg_dev);
+    if (!g->dev || !g->lane_of || !g->row_of || !g->lane || !g->reg_base || !g->reg_len || !g->has_reg || !g->reg_dev) { cl_group_unmake(g); return NULL; }
     memcpy(g->dev, devs, n * sizeof *g->dev);
     const char *sub = kwget(keys, vals, n_kwargs, "SUBBATCH"), *ct = kwget(keys, vals, n_kwargs, "COPY_THREADS");
     g->sub = sub && atoi(sub) > 0 ? atoi(sub) : 0;     /* 0: by the lane's route (below) */
@@ -579,7 +581,7 @@ int cl_group_register_buffers(cl_group *g, void *const *buffs, size_t bytes_each
         g->reg_base[g->n_reg] = (uint8_t *)lo; g->reg_len[g->n_reg] = hi - lo; g->n_reg++;
     }
     for (size_t k = 0; k < g->n_reg; k++)
-        if (!clhip_host_register(g->reg_base[k], g->reg_len[k])) {
+        if (!(g->reg_dev[k] = (uint8_t *)clhip_host_register(g->reg_base[k], g->reg_len[k]))) {
             cl_seterr(g->err, sizeof g->err, "cl_group_register_buffers: %zu bytes at %p could not be registered (%s)", g->reg_len[k], (void *)g->reg_base[k],
                       clhip_last_error());
             for (size_t q = 0; q < k; q++) clhip_host_unregister(g->reg_base[q]);
@@ -609,6 +611,15 @@ static int registered(const cl_group *g, int m, const void *p, size_t bytes)
     for (size_t k = 0; k < g->n_reg; k++)
         if (q >= g->reg_base[k] && q + bytes <= g->reg_base[k] + g->reg_len[k]) return 1;
     return 0;
+}
+
+/* the device's address of a byte of a registered client buffer (registered() said yes) */
+static uint8_t *registered_dev(const cl_group *g, const void *p)
+{
+    const uint8_t *q = (const uint8_t *)p;
+    for (size_t k = 0; k < g->n_reg; k++)
+        if (q >= g->reg_base[k] && q < g->reg_base[k] + g->reg_len[k]) return g->reg_dev[k] + (q - g->reg_base[k]);
+    return NULL;
 }
 
 /* the two calls (same translation unit: everything above is file-local) */

@@ -207,6 +207,9 @@ int clhip_convert_pack_rows(const void *const *d_in_rows, int format, size_t n_s
  * of their own -- device addresses of the rooms reserved in the members' pinned TX FIFOs (cl_group_writeStream's modulator lanes: the
  * appends of caribou_smi_write's chunk loop, caribou_smi.c:738-759, for a whole sub-batch). */
 int clhip_words_to_rows(const uint8_t *d_words, size_t in_stride_bytes, size_t n_words, int n_rows, uint8_t *const *d_dst_rows, void *stream);
+/* ... and rows of results of any element size (lengths of their own) into destinations of their own: the clients' registered buffers of
+ * a sub-batch (cl_group_register_buffers; cl_group_readStream's direct route).  Any alignment. */
+int clhip_rows_to_rows(const void *const *d_src_rows, void *const *d_dst_rows, const size_t *row_bytes, int n_rows, void *stream);
 /* The I rail of interleaved CF32 samples as a dense fp32 message: what Stream::WriteSamples would hand an FM modulator
  * ("if given I/Q, use I"), taken on the device instead of in a host loop. */
 int clhip_take_i_rail(const float *d_cf32, size_t n_samples, float *d_msg, void *stream);

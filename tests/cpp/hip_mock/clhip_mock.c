@@ -477,6 +477,22 @@ static void job_words_rows(job *j)
     for (size_t r = 0; r < j->z[2]; r++) memcpy(dst[r], (const uint8_t *)j->p[0] + r * j->z[0], 4 * j->z[1]);
     free(dst);
 }
+static void job_rows_rows(job *j)
+{
+    void **t = (void **)j->p[0];                       /* [src x n][dst x n][bytes x n] */
+    const size_t n = j->z[0];
+    for (size_t r = 0; r < n; r++) memcpy(t[n + r], t[r], (size_t)(uintptr_t)t[2 * n + r]);
+    free(t);
+}
+int clhip_rows_to_rows(const void *const *src, void *const *dst, const size_t *bytes, int rows, void *s)
+{
+    if (rows < 0 || rows > CLHIP_PACK_ROWS) { set_err("clhip_rows_to_rows: 1 .. 8 rows"); return -1; }
+    if (!rows) return 0;
+    void **t = (void **)malloc(sizeof(void *) * 3 * (size_t)rows);       /* (the addresses are read at the call) */
+    for (int r = 0; r < rows; r++) { t[r] = (void *)src[r]; t[rows + r] = dst[r]; t[2 * rows + r] = (void *)(uintptr_t)bytes[r]; }
+    job *j = new_job(job_rows_rows); j->p[0] = t; j->z[0] = (size_t)rows;
+    return enqueue(s, j);
+}
 int clhip_words_to_rows(const uint8_t *w, size_t is, size_t n, int rows, uint8_t *const *dst, void *s)
 {
     if (rows < 0 || rows > CLHIP_PACK_ROWS) { set_err("clhip_words_to_rows: 1 .. 8 rows"); return -1; }

@@ -144,9 +144,10 @@ def run_case(name, a):
             grp = S.Group(devs, kw)
             if mode == "registered":
                 grp.registerBuffers(bufs)
-        best, got_total = None, 0
+        best, got_total, cpu_best = None, 0, None
         for rep in range(a.reps + 1):
             feed(devs)
+            c0 = sum(os.times()[:2])                       # user + system seconds of the process, all threads: what the calls cost the HOST
             t0 = time.perf_counter()
             got = 0
             for k in range(K):
@@ -161,9 +162,10 @@ def run_case(name, a):
                         got += r
             dt_s = time.perf_counter() - t0
             if rep and (best is None or dt_s < best):
-                best, got_total = dt_s, got
+                best, got_total, cpu_best = dt_s, got, sum(os.times()[:2]) - c0
         res[mode] = {"msps_in": round(n * K * MTU / best / 1e6, 1), "ms_per_group_call": round(best / K * 1e3, 4),
-                     "us_per_stream_call": round(best / K / n * 1e6, 2), "out_elems_per_call": got_total // K}
+                     "us_per_stream_call": round(best / K / n * 1e6, 2), "out_elems_per_call": got_total // K,
+                     "host_cpu_s_per_wall_s": round(cpu_best / best, 2)}
         if grp is not None:
             res[mode]["stats"] = grp.stats()
             grp.close()
