@@ -12,7 +12,8 @@ case, reps, K = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 axes = [(a.split("=")[0], a.split("=")[1].split(",")) for a in sys.argv[4:]]
 fmt, dt, width, args = {"cs16": ("CS16", np.int16, 2, None), "cf32": ("CF32", np.float32, 2, None),
                         "c2": ("CF32", np.float32, 2, {"FIR": "64:1000000", "RESAMP": "3/2"}),
-                        "fm": ("CF32", np.float32, 1, {"FIR": "64:100000", "DEMOD": "FM"})}[case]
+                        "fm": ("CF32", np.float32, 1, {"FIR": "64:100000", "DEMOD": "FM"}),
+                        "cs16_iir": ("CS16", np.int16, 2, None), "cf32_iir": ("CF32", np.float32, 2, None)}[case]      # (_iir: the reference's 100 kHz low-pass on every stream)
 n = 32
 words = [synth.smi_stream_bytes(K * MTU, i % 2, stream=i)[0] for i in range(4)]
 cfgs = []
@@ -22,6 +23,8 @@ for combo in itertools.product(*[v for _, v in axes]):
     for i in range(n):
         d = S.Device(dict(driver="Cariboulite", channel="S1G" if i % 2 == 0 else "HiF"))
         d.activateStream(d.setupStream(S.SOAPY_SDR_RX, fmt, args=args))
+        if case.endswith("_iir"):
+            d.setBandwidth(S.SOAPY_SDR_RX, 0, 100e3)
         devs.append(d)
     cfgs.append((kw, devs, S.Group(devs, kw), [np.zeros((MTU * 3 // 2 + 8, width) if width > 1 else (MTU * 3 // 2 + 8,), dt) for _ in range(n)], []))
 for rep in range(reps + 1):
