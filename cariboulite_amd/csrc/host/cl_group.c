@@ -61,6 +61,9 @@ typedef struct {
     void *ev_primed;                      /* behind the read-ahead's copies */
     size_t out_stride;                    /* elements per row of d_out / h_out */
     uint8_t *d_out;
+    uint8_t *d_out_alt; uint8_t *ahead_dev;    /* READAHEAD=2: the device rows the NEXT call's results are computed into when a sub-batch has registered client buffers among
+                                               * its members (no mirror to store to ahead of the client's pointer): the two swap at every call; per sub-batch: its rows made
+                                               * ahead lie there */
     uint8_t *h_out[2], *m_out[2]; int cur_m;   /* two pinned mirrors (this call's results / the next call's, computed ahead) and the device's addresses of
                                                * them (mapped pinned): kernels may store into a mirror themselves */
     int32_t *h_offs[4]; int32_t *d_offs[4];    /* ROUTE_PLAIN: per row 0 (unpack) / -1 (skip), mapped pinned: one table per (event set, launched ahead | in the
@@ -269,7 +272,7 @@ static void tx_home(void *ctx, int member);
 static void lane_free(lane_t *l)
 {
     if (l->pipe) clhip_rx_pipe_destroy(l->pipe);
-    clhip_free(l->d_in[0]); clhip_free(l->d_in[1]); clhip_free(l->d_in[2]); clhip_free(l->d_out);
+    clhip_free(l->d_in[0]); clhip_free(l->d_in[1]); clhip_free(l->d_in[2]); clhip_free(l->d_out); clhip_free(l->d_out_alt); free(l->ahead_dev);
     clhip_event_destroy(l->ev_primed); free(l->primed); free(l->primed_epoch);
     clhip_host_free(l->h_out[0]); clhip_host_free(l->h_out[1]); clhip_host_free(l->h_offs[0]);
     clhip_host_free(l->tx_h_in); clhip_free(l->tx_d_in); free(l->tx_pend);
@@ -453,6 +456,7 @@ cl_group *cl_group_make(cl_device *const *devs, size_t n, const char *const *key
         l->primed = (size_t *)calloc((size_t)l->n, sizeof(size_t)); l->primed_epoch = (unsigned *)calloc((size_t)l->n, sizeof(unsigned));
         l->ev_primed = clhip_event_create();
         l->d_out = (uint8_t *)clhip_malloc(out_bytes);
+        l->d_out_alt = g->readahead == 2 ? (uint8_t *)clhip_malloc(out_bytes) : NULL;
         l->h_out[0] = (uint8_t *)clhip_host_alloc(out_bytes);
         l->h_out[1] = g->readahead == 2 ? (uint8_t *)clhip_host_alloc(out_bytes) : NULL;
         const size_t offs_each = ((size_t)l->n + 15) & ~(size_t)15;
@@ -471,7 +475,7 @@ cl_group *cl_group_make(cl_device *const *devs, size_t n, const char *const *key
         l->got = (long *)calloc((size_t)l->n, sizeof(long));
         l->src = (uint8_t **)calloc((size_t)l->n, sizeof(uint8_t *));
         l->ahead_mark = (uint8_t *)calloc((size_t)l->n, 1);
-        if (!l->d_in[0] || !l->d_in[1] || !l->d_in[2] || !l->primed || !l->primed_epoch || !l->ev_primed || !l->d_out || !l->h_out[0] || (g->readahead == 2 && !l->h_out[1]) || !l->h_offs[0] || !l->d_offs[0] || !l->m_out[0] || !l->done_ahead || !l->ahead_got || !l->direct || !l->ctx || !l->how || !l->fast || !l->len || !l->got || !l->src || !l->ahead_mark) {
+        if (!l->d_in[0] || !l->d_in[1] || !l->d_in[2] || !l->primed || !l->primed_epoch || !l->ev_primed || !l->d_out || !l->h_out[0] || (g->readahead == 2 && (!l->h_out[1] || !l->d_out_alt)) || !l->h_offs[0] || !l->d_offs[0] || !l->m_out[0] || !l->done_ahead || !l->ahead_got || !l->direct || !l->ctx || !l->how || !l->fast || !l->len || !l->got || !l->src || !l->ahead_mark) {
             cl_seterr(g_make_err, sizeof g_make_err, "cl_group_make: buffers for %d streams could not be allocated", l->n);
             cl_group_unmake(g);
             return NULL;
@@ -482,6 +486,8 @@ cl_group *cl_group_make(cl_device *const *devs, size_t n, const char *const *key
         l->sub = g->sub ? g->sub : l->out_stride * l->elem_bytes >= ((size_t)3 << 19) ? 4 : 8;
         n_sub += ((size_t)l->n + (size_t)l->sub - 1) / (size_t)l->sub;
         l->n_subs = (l->n + l->sub - 1) / l->sub;
+        l->ahead_dev = (uint8_t *)calloc((size_t)l->n_subs, 1);
+        if (!l->ahead_dev) { cl_group_unmake(g); return NULL; }
         if (l->route == ROUTE_PLAIN || l->route == ROUTE_PIPE) {
             l->f_stride = l->in_stride / 4;
             l->giir = (clhip_iir **)calloc((size_t)3 * (size_t)l->n_subs, sizeof(clhip_iir *)); l->iir_own = (uint8_t *)calloc((size_t)3 * (size_t)l->n, 1);
@@ -550,6 +556,7 @@ static void ahead_cancel_all(cl_group *g)
             l->primed[r] = 0; l->done_ahead[r] = 0;
             g->stale = 1;
         }
+        if (l->ahead_dev) memset(l->ahead_dev, 0, (size_t)l->n_subs);
     }
     settle(g);
     for (int k = 0; k < g->n_lanes; k++)
