@@ -69,7 +69,7 @@ typedef struct {
     int32_t *h_offs[4]; int32_t *d_offs[4];    /* ROUTE_PLAIN: per row 0 (unpack) / -1 (skip), mapped pinned: one table per (event set, launched ahead | in the
                                                * call) -- a launch reads its table when it RUNS */
     uint8_t *done_ahead; long *ahead_got;      /* per row: the previous call launched over the batch it read ahead, results in h_out[cur_m ^ 1] then; elements */
-    uint8_t *direct;                           /* per call and row: the copy engine wrote the client's registered buffer */
+    uint8_t *direct;                           /* per call and row: a launch stores the row into the client's registered buffer */
     cl_read_ctx *ctx;                          /* per call and row: a one-by-one member's read in flight (lanes without extension stages) */
     /* the reference's low-pass over whole sub-batches (lanes without extension stages): one multi-stream filter object per (filter,
      * sub-batch), made when first needed; a member's carried state lives EITHER in its stream's own objects or here (iir_own) */
@@ -563,7 +563,7 @@ static void ahead_cancel_all(cl_group *g)
         for (int sb = 0; g->lane[k].ahead_ft && sb < g->lane[k].n_subs; sb++) giir_ahead_drop(g, &g->lane[k], sb);
 }
 
-/* Client buffers the members' outputs may be written into by the copy engine directly (no pinned mirror, no memcpy): one
+/* Client buffers the members' outputs are stored into directly, across PCIe, by a launch (no pinned mirror, no memcpy): one
  * buffer per member, registered with the GPU HERE, explicitly, for as long as the registration stands -- the client keeps them
  * allocated until cl_group_unregister_buffers / cl_group_unmake.  A call whose buffs[i] lies inside member i's registered
  * range takes the direct route; any other pointer takes the mirror route. */

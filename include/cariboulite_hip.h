@@ -630,7 +630,7 @@ typedef struct {
     uint64_t calls;              /* cl_group_readStream calls                                                      */
     uint64_t batched_reads;      /* member reads that took the batched route                                       */
     uint64_t single_reads;       /* member reads that took their device's single-stream route                      */
-    uint64_t direct_reads;       /* batched reads the copy engine wrote into a registered client buffer            */
+    uint64_t direct_reads;       /* batched reads stored straight into a registered client buffer (one launch per sub-batch) */
     uint64_t launches;           /* kernel launches of the batched route                                           */
     uint64_t errors;             /* calls that ended with a runtime error                                          */
     uint64_t copies_2d;          /* copies in that carried several members' batches at once (one slab stride apart) */
@@ -666,7 +666,7 @@ void        cl_group_set_iir_poll_bound(cl_group *g, int polls);      /* test ho
 void        cl_group_set_tx_poll_bound(cl_group *g, int polls);       /* test hook: clhip_tx_pipe_set_poll_bound for the group's own modulator pipes (made or yet to be made) */
 /* Explicit zero-copy: one client buffer per member (bytes_each long), registered with the GPU here and kept registered until
  * _unregister_buffers / cl_group_unmake -- the client keeps them allocated that long.  A call whose buffs[i] lies inside
- * member i's registered buffer has the copy engine write it directly (no pinned mirror, no memcpy); any other pointer takes
+ * member i's registered buffer is stored there across PCIe by a launch (no pinned mirror, no memcpy: clhip_rows_to_rows); any other pointer takes
  * the default route.  Nothing is ever registered behind the client's back. */
 int         cl_group_register_buffers(cl_group *g, void *const *buffs, size_t bytes_each);
 void        cl_group_unregister_buffers(cl_group *g);
