@@ -200,8 +200,8 @@ def test_fm_demod_lane_and_copy_on_the_calling_thread(S):
 
 
 def test_registered_client_buffers_take_the_direct_route(S):
-    """cl_group_register_buffers: the copy engine writes the clients' buffers itself -- same bytes as the mirror route, which a
-    pointer outside the registered range still takes"""
+    """cl_group_register_buffers: a launch stores the sub-batch's rows into the clients' buffers itself -- same bytes as the mirror
+    route, which a pointer outside the registered range still takes"""
     script = {(1, 2): ("slip", 3)}
     args = {"FIR": "64:1000000", "RESAMP": "3/2"}
     log, st = run_script(S, 6, S.SOAPY_SDR_CF32, args, np.float32, (MTU * 3 // 2 + 8, 2), script, 3, register=True)
@@ -714,6 +714,46 @@ def test_a_member_with_a_reader_thread_is_read_through_its_ring(S):
             assert same(gb[i], sb[i]), (c, i)
     st = grp.stats()
     assert st["single_reads"] == 4 and st["batched_reads"] == 12 and st["errors"] == 0
+    grp.close()
+    for d in gdevs + sdevs:
+        d.close()
+
+
+@pytest.mark.parametrize("fmt,dtype,args,shape", [("CF32", np.float32, {"FIR": "64:1000000", "RESAMP": "3/2"}, (MTU * 3 // 2 + 8, 2)),
+                                                   ("CS16", np.int16, None, (MTU + 2, 2))])
+def test_results_made_ahead_for_registered_buffers_leave_by_the_route_the_call_names(S, fmt, dtype, args, shape):
+    """With registered client buffers the NEXT call's results are computed ahead into device rows (no mirror to store to, no client
+    pointer yet) and the call only scatters: into the registered buffers -- or, for a member the client hands ANOTHER buffer in that
+    call, into the mirror and on by the last hop; a member whose slipped batch is found after its row was read ahead goes through its own
+    device; a call of another length gives the work back.  Eleven members (sub-batches of 4 / 8 and a rest), six calls with every
+    batch pending beforehand, against lone twins bit for bit; the untouched tails of the buffers included."""
+    n, calls = 11, 6
+    gdevs, _ = make_devices(S, n, fmt, args, lambda i: "S1G" if i % 3 else "HiF")
+    sdevs, ssts = make_devices(S, n, fmt, args, lambda i: "S1G" if i % 3 else "HiF")
+    grp = S.Group(gdevs)
+    reg = sentinel_buffers(n, shape, dtype)
+    grp.registerBuffers(reg)
+    for c in range(calls):
+        for i in range(n):
+            b = batch_bytes(i, c, 0 if i % 3 else 1)
+            if (c, i) == (3, 5):
+                b = slipped(b, 6)
+            gdevs[i].feedSmiBytes(b); sdevs[i].feedSmiBytes(b)
+    foreign = {2: (1, 7), 4: (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10)}      # call -> members that get an unregistered buffer in it
+    for c in range(calls):
+        num = MTU // 2 if c == 5 else MTU                      # (the last call asks for half a batch: what was made ahead for a whole one is given back)
+        other = sentinel_buffers(n, shape, dtype)
+        gb = [other[i] if i in foreign.get(c, ()) else reg[i] for i in range(n)]
+        for b in gb:
+            b[...] = np.nan if np.issubdtype(dtype, np.floating) else SENT
+        sb = sentinel_buffers(n, shape, dtype)
+        nd, rets = grp.readStream(gb, num)
+        srets = [sdevs[i].readStream(ssts[i], [sb[i]], num).ret for i in range(n)]
+        assert rets == srets, (c, rets, srets)
+        for i in range(n):
+            assert same(gb[i], sb[i]), (c, i)
+    st = grp.stats()
+    assert st["errors"] == 0 and st["direct_reads"] >= (calls - 1) * n - 2 - 11 - 2 and st["ahead_reads"] >= 3 * n
     grp.close()
     for d in gdevs + sdevs:
         d.close()
