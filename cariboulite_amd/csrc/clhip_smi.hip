@@ -670,28 +670,6 @@ extern "C" int clhip_take_i_rail(const float *d_cf32, size_t n, float *d_msg, vo
     return 0;
 }
 
-// ... of n_rows streams in one launch (cl_group_writeStream's modulator lanes): row r of the samples at d_cf32 + r * in_stride complex
-// elements, its message at d_msg + r * msg_stride floats
-__global__ __launch_bounds__(256) void take_i_rail_rows_kernel(const f32x2 *__restrict__ in, size_t in_stride, size_t n, float *__restrict__ out, size_t out_stride)
-{
-    const f32x2 *src = in + (size_t)blockIdx.y * in_stride;
-    float *dst = out + (size_t)blockIdx.y * out_stride;
-    const size_t step = (size_t)gridDim.x * blockDim.x;
-    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += step) dst[k] = src[k].x;
-}
-
-extern "C" int clhip_take_i_rail_rows(const float *d_cf32, size_t in_stride_elems, size_t n, int n_rows, float *d_msg, size_t msg_stride, void *stream)
-{
-    if (n == 0 || n_rows <= 0) return 0;
-    if (!d_cf32 || !d_msg || in_stride_elems < n || msg_stride < n) { clhip_set_error("clhip_take_i_rail_rows: bad arguments"); return -1; }
-    unsigned gx = (unsigned)clhip_div_up(n, 256);
-    if (gx > 1024) gx = 1024;
-    hipLaunchKernelGGL(take_i_rail_rows_kernel, dim3(gx, (unsigned)n_rows), dim3(256), 0, (hipStream_t)stream, (const f32x2 *)d_cf32, in_stride_elems, n,
-                       d_msg, msg_stride);
-    CLHIP_CHECK_LAUNCH();
-    return 0;
-}
-
 // ---------------------------------------------------------------------------
 // link-integrity (debug) modes: caribou_smi.c:172-215 (analyse), :266-283 (search)
 //   LFSR  : every byte must be lfsr(previous byte) and non-zero (smi_utils.c:220-224)

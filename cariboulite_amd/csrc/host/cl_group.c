@@ -37,7 +37,7 @@
 
 enum { ROUTE_PIPE = 1, ROUTE_PLAIN = 2, ROUTE_TX_PLAIN = 3, ROUTE_TX_SINGLE = 4, ROUTE_TX_PIPE = 5 };
 
-typedef struct { uint8_t *dst; const uint8_t *src; size_t bytes; } copy_job;
+typedef struct { uint8_t *dst; const uint8_t *src; size_t bytes; int take_i; } copy_job;     /* take_i: `bytes` of dst from every other float of src (below) */
 
 typedef struct {
     pthread_t *th; int n_threads;
@@ -146,6 +146,30 @@ __attribute__((target("avx2"))) static void copy_stream_avx2(uint8_t *dst, const
     if (i < n) memcpy(dst + i, src + i, n - i);
 }
 
+/* The clients' samples on their way into pinned memory for a modulator lane with MOD=FM: the modulator reads the I rail only (SURVEY.md
+ * a13: "if given I/Q, use I"), so only the I rail is copied -- half the bytes cross PCIe, and the device needs no launch to pick them
+ * out.  n floats of dst from src[0], src[2], src[4], ... */
+__attribute__((target("avx2"))) static void take_i_avx2(float *dst, const float *src, size_t n)
+{
+    size_t i = 0;
+    while (i < n && ((uintptr_t)(dst + i) & 31)) { dst[i] = src[2 * i]; i++; }
+    for (; i + 8 <= n; i += 8) {
+        const __m256 a = _mm256_loadu_ps(src + 2 * i), b = _mm256_loadu_ps(src + 2 * i + 8);
+        const __m256 s = _mm256_shuffle_ps(a, b, 0x88);                                   /* a0 a2 b0 b2 | a4 a6 b4 b6 */
+        _mm256_stream_ps(dst + i, _mm256_castpd_ps(_mm256_permute4x64_pd(_mm256_castps_pd(s), 0xD8)));   /* a0 a2 a4 a6 b0 b2 b4 b6 */
+    }
+    _mm_sfence();
+    for (; i < n; i++) dst[i] = src[2 * i];
+}
+
+static void take_i(uint8_t *dst, const uint8_t *src, size_t bytes)
+{
+    float *d = (float *)dst; const float *s = (const float *)src;
+    const size_t n = bytes / 4;
+    if (__builtin_cpu_supports("avx2")) take_i_avx2(d, s, n);
+    else for (size_t i = 0; i < n; i++) d[i] = s[2 * i];
+}
+
 static void copy_out(uint8_t *dst, const uint8_t *src, size_t n)
 {
     static int avx2_known = -1;                             /* (several threads may find out at once: the same answer, stored atomically) */
@@ -164,7 +188,7 @@ static void *pool_thread(void *arg)
         const copy_job j = p->q[p->q_head];
         p->q_head = (p->q_head + 1) % p->q_cap; p->q_len--;
         pthread_mutex_unlock(&p->mu);
-        copy_out(j.dst, j.src, j.bytes);
+        if (j.take_i) take_i(j.dst, j.src, j.bytes); else copy_out(j.dst, j.src, j.bytes);
         pthread_mutex_lock(&p->mu);
         if (--p->in_flight == 0) pthread_cond_broadcast(&p->idle);
     }
@@ -198,26 +222,30 @@ static void pool_stop(copy_pool *p)
     memset(p, 0, sizeof *p);
 }
 
-/* queue [src, src + bytes) -> dst in pieces; without worker threads the caller copies */
-static void pool_submit(copy_pool *p, uint8_t *dst, const uint8_t *src, size_t bytes)
+/* queue [src, src + bytes) -> dst in pieces; without worker threads the caller copies.  take: `bytes` of dst from twice as many of src
+ * (take_i) */
+static void pool_submit_kind(copy_pool *p, uint8_t *dst, const uint8_t *src, size_t bytes, int take)
 {
-    const size_t piece = (size_t)512 << 10;
-    if (!p->n_threads) { copy_out(dst, src, bytes); return; }
+    const size_t piece = (size_t)(take ? 256 : 512) << 10;
+    const size_t sm = take ? 2 : 1;                     /* source bytes per destination byte */
+    if (!p->n_threads) { if (take) take_i(dst, src, bytes); else copy_out(dst, src, bytes); return; }
     pthread_mutex_lock(&p->mu);
     for (size_t o = 0; o < bytes; o += piece) {
         const size_t n = bytes - o < piece ? bytes - o : piece;
         if (p->q_len == p->q_cap) {                     /* full: do this piece here */
             pthread_mutex_unlock(&p->mu);
-            copy_out(dst + o, src + o, n);
+            if (take) take_i(dst + o, src + sm * o, n); else copy_out(dst + o, src + o, n);
             pthread_mutex_lock(&p->mu);
             continue;
         }
-        p->q[(p->q_head + p->q_len) % p->q_cap] = (copy_job){dst + o, src + o, n};
+        p->q[(p->q_head + p->q_len) % p->q_cap] = (copy_job){dst + o, src + sm * o, n, take};
         p->q_len++; p->in_flight++;
     }
     pthread_cond_broadcast(&p->work);
     pthread_mutex_unlock(&p->mu);
 }
+
+static void pool_submit(copy_pool *p, uint8_t *dst, const uint8_t *src, size_t bytes) { pool_submit_kind(p, dst, src, bytes, 0); }
 
 /* the caller helps until the queue is empty, then waits for the pieces still being copied */
 static void pool_drain(copy_pool *p)
@@ -228,7 +256,7 @@ static void pool_drain(copy_pool *p)
         const copy_job j = p->q[p->q_head];
         p->q_head = (p->q_head + 1) % p->q_cap; p->q_len--;
         pthread_mutex_unlock(&p->mu);
-        copy_out(j.dst, j.src, j.bytes);
+        if (j.take_i) take_i(j.dst, j.src, j.bytes); else copy_out(j.dst, j.src, j.bytes);
         pthread_mutex_lock(&p->mu);
         if (--p->in_flight == 0) pthread_cond_broadcast(&p->idle);
     }

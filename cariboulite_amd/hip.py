@@ -64,7 +64,6 @@ _SIGS = {
     "clhip_take_i_rail": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "clhip_rows_to_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "clhip_words_to_rows": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]),
-    "clhip_take_i_rail_rows": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "clhip_sync_tags_ws_bytes": (C.c_size_t, [C.c_size_t]),
     "clhip_sync_tags": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "clhip_iir_create": (C.c_void_p, [C.c_void_p, C.c_int, C.c_int]),

@@ -213,9 +213,6 @@ int clhip_rows_to_rows(const void *const *d_src_rows, void *const *d_dst_rows, c
 /* The I rail of interleaved CF32 samples as a dense fp32 message: what Stream::WriteSamples would hand an FM modulator
  * ("if given I/Q, use I"), taken on the device instead of in a host loop. */
 int clhip_take_i_rail(const float *d_cf32, size_t n_samples, float *d_msg, void *stream);
-/* ... of n_rows streams in one launch (the modulator lanes of cl_group_writeStream): row r's samples at d_cf32 + 2 * r * in_stride_elems
- * floats, its message at d_msg + r * msg_stride */
-int clhip_take_i_rail_rows(const float *d_cf32, size_t in_stride_elems, size_t n_samples, int n_rows, float *d_msg, size_t msg_stride, void *stream);
 
 /* TX pack -- replaces caribou_smi_generate_data (caribou_smi.c:684-717) */
 int clhip_smi_pack(int mode, const int16_t *d_iq, size_t n_samples, uint8_t *d_bytes, void *stream);

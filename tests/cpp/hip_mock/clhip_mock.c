@@ -456,19 +456,11 @@ void clhip_mock_tx_fail_every(int k) { g_tx_fail_every = k; }
 
 static void job_take_i(job *j)
 {
-    for (size_t r = 0; r < j->z[3]; r++) {
-        const float *in = (const float *)j->p[0] + 2 * r * j->z[1]; float *out = (float *)j->p[1] + r * j->z[2];
-        for (size_t k = 0; k < j->z[0]; k++) out[k] = in[2 * k];
-    }
+    for (size_t k = 0; k < j->z[0]; k++) ((float *)j->p[1])[k] = ((const float *)j->p[0])[2 * k];
 }
 int clhip_take_i_rail(const float *in, size_t n, float *out, void *s)
 {
-    job *j = new_job(job_take_i); j->p[0] = (void *)in; j->p[1] = out; j->z[0] = n; j->z[1] = n; j->z[2] = n; j->z[3] = 1;
-    return enqueue(s, j);
-}
-int clhip_take_i_rail_rows(const float *in, size_t is, size_t n, int rows, float *out, size_t os, void *s)
-{
-    job *j = new_job(job_take_i); j->p[0] = (void *)in; j->p[1] = out; j->z[0] = n; j->z[1] = is; j->z[2] = os; j->z[3] = (size_t)rows;
+    job *j = new_job(job_take_i); j->p[0] = (void *)in; j->p[1] = out; j->z[0] = n;
     return enqueue(s, j);
 }
 static void job_words_rows(job *j)

@@ -815,19 +815,15 @@ def test_tx_pipe_stream_state_moves_between_pipes(G, orc):
         other_cfg.take_stream_from(0, own, 0)
 
 
-def test_i_rail_rows_and_words_to_rows(G):
-    """The two row launches of the modulator lanes: the I rails of n_rows strided CF32 rows as dense messages, and rows of words stored
-    into n_rows destinations of their own (16-byte aligned and not)."""
+def test_words_to_rows_and_rows_to_rows(G):
+    """The row launches of the stream group: rows of packed words stored into n_rows destinations of their own (the members' pinned TX
+    FIFOs: 16-byte aligned and not), and rows of results of any length and alignment into destinations of their own (registered client
+    buffers)."""
     import ctypes as C
     import torch
     from cariboulite_amd import hip
     rng = np.random.default_rng(79)
     rows, n, stride = 5, 10_007, 10_040
-    x = torch.from_numpy(rng.standard_normal((rows, stride, 2)).astype(np.float32)).to(G.DEV)
-    msg = torch.zeros((rows, n + 9), dtype=torch.float32, device=G.DEV)
-    assert hip.lib().clhip_take_i_rail_rows(x.data_ptr(), stride, n, rows, msg.data_ptr(), n + 9, None) == 0
-    torch.cuda.synchronize()
-    assert torch.equal(msg[:, :n], x[:, :n, 0]) and float(msg[:, n:].abs().max()) == 0.0
     w = torch.from_numpy(rng.integers(0, 2**32, (rows, stride), dtype=np.uint64).astype(np.uint32).view(np.int32)).to(G.DEV)
     dst = torch.zeros((rows, n + 16), dtype=torch.int32, device=G.DEV)
     ptrs = (C.c_void_p * rows)(*[dst[r].data_ptr() + 4 * (r % 3) for r in range(rows)])      # offsets of 0 / 4 / 8 bytes
@@ -836,3 +832,17 @@ def test_i_rail_rows_and_words_to_rows(G):
     for r in range(rows):
         o = r % 3
         assert torch.equal(dst[r, o:o + n], w[r, :n]) and int(dst[r, :o].abs().sum()) == 0 and int(dst[r, o + n:].abs().sum()) == 0
+    # byte rows: lengths and alignments of their own (16-byte, 4-byte and odd addresses)
+    src = torch.from_numpy(rng.integers(0, 256, (rows, 70_000), dtype=np.uint8)).to(G.DEV)
+    out = torch.zeros((rows, 70_064), dtype=torch.uint8, device=G.DEV)
+    lens = [65_536, 70_000, 3, 33_333, 0]
+    so, do = [0, 4, 1, 16, 0], [0, 8, 3, 5, 0]
+    sp = (C.c_void_p * rows)(*[src[r].data_ptr() + so[r] for r in range(rows)])
+    dp = (C.c_void_p * rows)(*[out[r].data_ptr() + do[r] for r in range(rows)])
+    ln = (C.c_size_t * rows)(*[min(l, 70_000 - so[r]) for r, l in enumerate(lens)])
+    assert hip.lib().clhip_rows_to_rows(sp, dp, ln, rows, None) == 0
+    torch.cuda.synchronize()
+    for r in range(rows):
+        k = int(ln[r])
+        assert torch.equal(out[r, do[r]:do[r] + k], src[r, so[r]:so[r] + k]), r
+        assert int(out[r, :do[r]].sum()) == 0 and int(out[r, do[r] + k:].sum()) == 0, r

@@ -95,7 +95,8 @@ def run_tx_case(name, a):
             grp.close()
         for d in devs:
             d.close()
-    in_mib, out_mib = n * MTU * in_b >> 20, int(n * MTU * 4 * out_per) >> 20
+    link_in_b = 4 if args and "MOD" in args else in_b      # (MOD=FM: only the I rail, the message, crosses PCIe -- the copy threads take it out of the clients' samples)
+    in_mib, out_mib = n * MTU * link_in_b >> 20, int(n * MTU * 4 * out_per) >> 20
     sh = pcie_shape(in_mib, out_mib)
     if sh:
         ceiling = n * MTU / (sh["duplex_ms"] * 1e-3) / 1e6
