@@ -79,6 +79,8 @@ def parse():
                     help="initialise torch.distributed even at world size 1 (under torch.distributed.run --nproc-per-node 1): the "
                          "RCCL calls of the N > 1 path -- init with a device id, barrier, max-reduction on a device tensor, destroy -- "
                          "on a one-GPU box")
+    ap.add_argument("--no-pcie-extra", action="store_true",
+                    help="default run only: do not append the PCIe-inclusive figure (`pcie_inclusive`, a child `bench.py --pcie` behind the timed region)")
     ap.add_argument("--print-launch", action="store_true",
                     help="with --gpus N > 1 and no WORLD_SIZE: print the launcher command this process would start, and exit")
     return ap.parse_args()
@@ -540,6 +542,22 @@ def main():
             torch.cuda.synchronize()
             g = out[: cpu_out.shape[0]].cpu().numpy()
             res["max_abs_diff_vs_cpu_port"] = float(np.max(np.abs(g - cpu_out)))
+        if world == 1 and not a.no_cpu and not a.no_pcie_extra and full:
+            # The other truth of the same stages, next to the headline and never in its place (`value` is the HBM-resident figure):
+            # host SMI bytes in -> host CF32 samples out through the drop-in boundary (32 Soapy devices, cl_group_readStream), against
+            # this box's own PCIe ceiling -- `python bench.py --pcie` in a child process, after the timed region, its line condensed.
+            try:
+                o = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--pcie", "--no-cpu", "--steps", "24", "--warmup", "6"],
+                                   capture_output=True, text=True, timeout=240,
+                                   env={k: v for k, v in os.environ.items() if not (k.startswith("ROCP") or k in ("LD_PRELOAD", "HSA_TOOLS_LIB"))})   # (a profiler around this run profiles this run)
+                line = [ln for ln in o.stdout.splitlines() if ln.startswith("{")][-1]
+                c = json.loads(line)
+                res["pcie_inclusive"] = {"value": c["value"], "unit": c["unit"], "ms_per_step": c["ms_per_step"], "streams": c["config"]["streams_per_gpu"],
+                                         "what": "the same stages behind the SoapySDR boundary: host SMI bytes in (pinned FIFOs) -> cl_group_readStream -> host CF32 samples in pageable "
+                                                 "buffers; python bench.py --pcie prints the full line",
+                                         "roofline": {k: c["roofline"].get(k) for k in ("bound", "achieved", "peak", "unit", "frac")}}
+            except Exception as e:                             # (the headline line stands whatever happens here)
+                res["pcie_inclusive"] = {"error": f"{type(e).__name__}: {e}"[:200]}
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.destroy_process_group()
