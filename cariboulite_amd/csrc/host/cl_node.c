@@ -192,3 +192,26 @@ int cl_node_writeStream(cl_node *nd, const void *const *buffs, size_t numElems, 
 }
 
 int cl_node_flush(cl_node *nd) { return node_call(nd, 2, NULL, 0, NULL, 0) < 0 ? -1 : 0; }
+
+/* cl_group_register_buffers / _unregister_buffers of every group: buffs[i] is member i's buffer (bytes_each long), in the order the
+ * devices were given.  0, or -1 with every registration made by this call taken back (cl_node_last_error). */
+int cl_node_register_buffers(cl_node *nd, void *const *buffs, size_t bytes_each)
+{
+    if (!nd || !buffs || !bytes_each) return -1;
+    nd->err[0] = 0;
+    for (size_t s = 0; s < nd->n_shards; s++) {
+        node_shard *sh = &nd->sh[s];
+        for (size_t j = 0; j < sh->n; j++) sh->buffs[j] = buffs[sh->member[j]];
+        if (cl_group_register_buffers(sh->g, (void *const *)sh->buffs, bytes_each)) {
+            cl_seterr(nd->err, sizeof nd->err, "shard %zu (GPU %d): %s", s, sh->devs[0]->smi->device, cl_group_last_error(sh->g));
+            for (size_t q = 0; q < s; q++) cl_group_unregister_buffers(nd->sh[q].g);
+            return -1;
+        }
+    }
+    return 0;
+}
+
+void cl_node_unregister_buffers(cl_node *nd)
+{
+    for (size_t s = 0; nd && s < nd->n_shards; s++) cl_group_unregister_buffers(nd->sh[s].g);
+}

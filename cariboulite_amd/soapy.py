@@ -115,6 +115,8 @@ _SIGS = {
     "cl_node_readStream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t, C.POINTER(C.c_int), C.c_long]),
     "cl_node_writeStream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t, C.POINTER(C.c_int), C.c_long]),
     "cl_node_flush": (C.c_int, [C.c_void_p]),
+    "cl_node_register_buffers": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t]),
+    "cl_node_unregister_buffers": (None, [C.c_void_p]),
     "cl_node_last_error": (C.c_char_p, [C.c_void_p]),
     "cl_group_last_error": (C.c_char_p, [C.c_void_p]),
     "cl_group_getStats": (None, [C.c_void_p, C.c_void_p]),
@@ -494,6 +496,16 @@ class Node:
 
     def flush(self):
         return lib().cl_node_flush(self.h)
+
+    def registerBuffers(self, buffs):
+        arr = (C.c_void_p * len(buffs))(*[b.ctypes.data for b in buffs])
+        if lib().cl_node_register_buffers(self.h, arr, buffs[0].nbytes) != 0:
+            raise RuntimeError(self.lastError())
+        self._registered = list(buffs)              # the client keeps them allocated while registered
+
+    def unregisterBuffers(self):
+        lib().cl_node_unregister_buffers(self.h)
+        self._registered = None
 
     def shards(self):
         return int(lib().cl_node_shards(self.h))

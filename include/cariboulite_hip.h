@@ -686,6 +686,8 @@ int         cl_node_shard_of(const cl_node *nd, size_t member);      /* the shar
 int         cl_node_readStream(cl_node *nd, void *const *buffs, size_t numElems, int *rets, long timeoutUs);
 int         cl_node_writeStream(cl_node *nd, const void *const *buffs, size_t numElems, int *rets, long timeoutUs);
 int         cl_node_flush(cl_node *nd);                              /* cl_group_flush of every group (0 / -1) */
+int         cl_node_register_buffers(cl_node *nd, void *const *buffs, size_t bytes_each);   /* cl_group_register_buffers of every group: buffs[i] is member i's (0 / -1) */
+void        cl_node_unregister_buffers(cl_node *nd);
 const char *cl_node_last_error(const cl_node *nd);
 
 /* host helper: scipy.signal.firwin(ntaps, cutoff, window="hamming", fs=fs)

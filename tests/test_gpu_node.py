@@ -45,7 +45,10 @@ def test_node_read_equals_lone_devices(S):
     node = S.Node(ndevs, {"SHARDS": "3"})
     assert node.shards() == 3 and [node.shardOf(i) for i in range(n)] == [0] * 5 + [1] * 5 + [2] * 4
     shape = lambda i: (MTU * 3 // 2 + 8, 2)
+    held = [np.full(shape(i), np.nan, np.float32) if cfg[i][0] == "CF32" else np.full((MTU * 3 // 2 + 8, 2), -21846, np.int16) for i in range(n)]
     for call in range(5):
+        if call == 2:
+            node.registerBuffers(held)                     # (cl_node_register_buffers: every shard's members write their buffers directly from now on)
         for i in range(n):
             b = synth.smi_stream_bytes(MTU, 0 if i % 2 else 1, stream=300 + i, n0=call * MTU)[0].copy()
             if (call, i) == (1, 3):
@@ -57,6 +60,10 @@ def test_node_read_equals_lone_devices(S):
             ndevs[i].feedSmiBytes(b); sdevs[i].feedSmiBytes(b)
         nb = [np.full(shape(i), np.nan, np.float32) if cfg[i][0] == "CF32" else np.full((MTU + 8, 2), -21846, np.int16) for i in range(n)]
         sb = [x.copy() for x in nb]
+        if call >= 2:                                          # the registered buffers (the int16 ones are longer than a call needs: only its slots compare)
+            for i in range(n):
+                held[i][...] = np.nan if cfg[i][0] == "CF32" else -21846
+            nb = [held[i] if cfg[i][0] == "CF32" else held[i][: MTU + 8] for i in range(n)]
         nd, rets = node.readStream(nb, MTU)
         srets = [sdevs[i].readStream(ssts[i], [sb[i]], MTU, timeoutUs=1000).ret for i in range(n)]
         assert rets == srets, (call, rets, srets)
@@ -64,7 +71,8 @@ def test_node_read_equals_lone_devices(S):
         for i in range(n):
             assert nb[i].tobytes() == sb[i].tobytes(), (call, i)
     st = node.stats()
-    assert st["errors"] == 0 and st["batched_reads"] >= 5 * n - 6 and st["calls"] == 15
+    assert st["errors"] == 0 and st["batched_reads"] >= 5 * n - 6 and st["calls"] == 15 and st["direct_reads"] >= 3 * n - 6
+    node.unregisterBuffers()
     node.close()
     for d in ndevs + sdevs:
         d.close()
