@@ -846,3 +846,33 @@ def test_words_to_rows_and_rows_to_rows(G):
         k = int(ln[r])
         assert torch.equal(out[r, do[r]:do[r] + k], src[r, so[r]:so[r] + k]), r
         assert int(out[r, :do[r]].sum()) == 0 and int(out[r, do[r] + k:].sum()) == 0, r
+
+
+def test_tx_lookback_epoch_wrap_in_a_long_lived_pipe(G):
+    """The single-launch FM path tags its look-back words with a 14-bit launch epoch (no reset between launches) and forgets every old
+    entry when the epoch wraps, after 16 383 runs -- nine minutes of MTU calls at 4 MS/s.  A pipe is run up to its 16 000th call; its
+    stream's state then moves into a fresh pipe (epoch 1) and both run on in lock step across the first one's wrap: bit for bit the same
+    words, call after call."""
+    import torch
+    from cariboulite_amd import hip
+    t = load_golden("taps.npz")
+    rng = np.random.default_rng(80)
+    n = 6_150                                                # (three look-back units per call; not a multiple of 3: every polyphase start)
+    msgs = torch.from_numpy((0.4 * rng.standard_normal((7, n))).astype(np.float32)).to(G.DEV)
+    old = hip.TxPipe(1, 75e3, 4e6, t["rs_2_3"], 2, 3, hip.TX_DOCUMENTED)
+    by = torch.zeros(4 * (n * 2 // 3 + 2), dtype=torch.uint8, device=G.DEV)
+    for k in range(16_000):
+        old.run(hip.TXPIPE_IN_FM_MESSAGE, msgs[k % 7], 0, n, by, by.numel())
+    torch.cuda.synchronize()
+    assert old.status() == 0
+    new = hip.TxPipe(1, 75e3, 4e6, t["rs_2_3"], 2, 3, hip.TX_DOCUMENTED)
+    new.set_position(old.position()); new.take_stream_from(0, old, 0)
+    by2 = torch.zeros_like(by)
+    for k in range(16_000, 16_800):                          # the wrap is at the old pipe's 16 384th run
+        ka = old.run(hip.TXPIPE_IN_FM_MESSAGE, msgs[k % 7], 0, n, by, by.numel())
+        kb = new.run(hip.TXPIPE_IN_FM_MESSAGE, msgs[k % 7], 0, n, by2, by2.numel())
+        assert ka == kb
+        if k % 16 == 0 or 16_376 <= k <= 16_392:
+            torch.cuda.synchronize()
+            assert old.status() == 0 and new.status() == 0
+            assert torch.equal(by[:4 * ka], by2[:4 * kb]), k
