@@ -106,6 +106,7 @@ struct cl_group {
                                            * 2 (default) = ... and launched over, into the second mirror */
     size_t n_sub;                         /* sub-batches over all lanes */
     int iir_polls; int iir_polls_set;     /* test hook (cl_group_set_iir_poll_bound): the poll bound of the group's filter objects */
+    size_t tx_copy_bytes;                 /* kwarg TX_COPY_MB (default 8): a TX group's copies in carry neighbouring sub-batches until they are this long (0: one copy per sub-batch) */
     int tx_polls; int tx_polls_set;       /* test hook (cl_group_set_tx_poll_bound): the look-back poll bound of the group's modulator pipes */
     pthread_mutex_t tx_mu; int tx_mu_ok; int tx_pending;      /* a TX group: the call and the members' seams' call-backs (any thread) */
     int stale;                            /* work made ahead has just been given up: it is waited for before anything takes its place (settle) */
@@ -400,6 +401,7 @@ cl_group *cl_group_make(cl_device *const *devs, size_t n, const char *const *key
     const char *sk = kwget(keys, vals, n_kwargs, "SINK");
     g->sink_mapped = !(sk && !strcmp(sk, "copy"));
     { const char *ra = kwget(keys, vals, n_kwargs, "READAHEAD"); g->readahead = ra ? atoi(ra) : 2; }
+    { const char *cm = kwget(keys, vals, n_kwargs, "TX_COPY_MB"); g->tx_copy_bytes = (size_t)(cm && atoi(cm) >= 0 ? atoi(cm) : 8) << 20; }
     if (g->readahead < 0 || g->readahead > 2) g->readahead = 2;
     if (g->readahead == 2 && !g->sink_mapped) g->readahead = 1;     /* (results ahead are stored into the second mirror by the launches themselves) */
     int threads = ct ? atoi(ct) : 2;                     /* tools/group_ab.py (interleaved medians, FIR64 + 3/2 x 32): 0 / 1 / 2 / 3 / 4 / 8 threads -> 2099 / 2556 / 3158 / 3034 / 2925 / 2783 Msamples/s */

@@ -70,6 +70,8 @@ def run_tx_case(name, a):
         kw = {"COPY_THREADS": str(a.threads), "INGEST_STREAMS": str(a.ingest)}
         if a.sub:
             kw["SUBBATCH"] = str(a.sub)
+        if a.tx_copy_mb >= 0:
+            kw["TX_COPY_MB"] = str(a.tx_copy_mb)
         grp = S.Group(devs, kw) if mode == "default" else None
         best = None
         for rep in range(a.reps + 1):
@@ -192,6 +194,7 @@ def main():
     ap.add_argument("--threads", type=int, default=2)
     ap.add_argument("--sink", default="mapped", choices=["mapped", "copy"])
     ap.add_argument("--ingest", type=int, default=2, help="ingest HIP streams (1 .. 8)")
+    ap.add_argument("--tx-copy-mb", type=int, default=-1, help="TX cases: the group's TX_COPY_MB kwarg (0: one copy in per sub-batch; default: the group's, 8)")
     ap.add_argument("--cases", default="cf32_fir64_rs_3_2,cs16,cf32")
     ap.add_argument("--modes", default="default,registered,one_by_one")
     ap.add_argument("--only", default=None, help="(internal) one case in this process")
