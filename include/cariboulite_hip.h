@@ -620,7 +620,8 @@ void   cl_stream_set_iir_poll_bound(cl_stream *stream, int polls);
  * computed and the GPU does not wait for the host between two calls; 1: staged and copied in only; 0: nothing ahead.  Bytes read
  * ahead count as pending until that call takes them, and any other reader of the member's device -- its own readStream, a flush, a
  * call with another numElems -- finds them pending, in order; a run made ahead of a client who then goes another way is taken
- * back).  Returns the number of streams that delivered (> 0 elements), or -1 on a
+ * back); a TX group: TX_COPY_MB=<MiB> (8: the copies in carry neighbouring sub-batches until they are that long -- 4 MiB copies cross PCIe
+ * one at a time, two 8 MiB copies share the link; 0 = one copy per sub-batch).  Returns the number of streams that delivered (> 0 elements), or -1 on a
  * runtime error (cl_group_last_error; NULL group = the last cl_group_make failure). */
 typedef struct cl_group cl_group;
 typedef struct {
