@@ -129,3 +129,78 @@ def test_a_node_reads_or_writes_and_reports_its_shards_errors(S):
     assert node.readStream(buf, MTU, timeoutUs=1000) == (0, [0, 0])       # nothing pending: N empty reads
     assert node.writeStream(buf, MTU)[0] == -1 and "RX" in node.lastError() and "shard 0" in node.lastError()
     node.close(); rx.close(); rx2.close(); tx.close()
+
+
+def test_config4_256_streams_fir128_resample_5_4_in_eight_shards(S, orc):
+    """BASELINE config 4 at the drop-in boundary: 256 independent 4 MS/s streams, 128-tap FIR + 5/4 polyphase, sharded eight ways with
+    nothing exchanged between the shards -- here the eight shards are eight groups of 32 on GPU 0 (SHARDS=8; on a node `gpus="0,..,7"`
+    puts them on eight GPUs, the calls are the same).  Three calls of one MTU per stream; member 40's second batch arrives five bytes
+    late, member 200's second batch carries no sync word, member 255 has half a batch pending in the last call.  A member of every shard
+    and every damaged one equal their own lone devices bit for bit, call after call (the twins are made one at a time afterwards and
+    fed the same bytes); three of them also equal the oracle chain within 1e-5."""
+    from cariboulite_amd import synth
+    from conftest import load_golden
+    n, calls, shards = 256, 3, 8
+    args = {"FIR": "128:1200000", "RESAMP": "5/4"}
+    n_full = MTU * 5 // 4
+    ch_of = lambda i: 0 if i % 2 else 1
+
+    def batch(i, c):
+        b = synth.smi_stream_bytes(MTU, ch_of(i), stream=1000 + i, n0=c * MTU)[0].copy()
+        if (c, i) == (1, 40):
+            b = np.concatenate([np.full(5, 0x11, np.uint8), b[:-5]])
+        if (c, i) == (1, 200):
+            b[:] = 0
+        if (c, i) == (2, 255):
+            b = b[: NB // 2]
+        return b
+
+    ndevs, _ = rx_devices(S, [("CF32", args)] * n)
+    node = S.Node(ndevs, {"SHARDS": str(shards)})
+    assert node.shards() == shards and [node.shardOf(i) for i in (0, 31, 32, 255)] == [0, 0, 1, 7]
+    watched = sorted(set(range(3, n, 32)) | {40, 200, 255, 0})
+    bufs = [np.empty((n_full + 8, 2), np.float32) for _ in range(n)]
+    log = []
+    for c in range(calls):
+        for i in range(n):
+            ndevs[i].feedSmiBytes(batch(i, c))
+        for x in bufs:
+            x[...] = np.nan
+        nd, rets = node.readStream(bufs, MTU)
+        assert nd == sum(r > 0 for r in rets)
+        assert all(r == n_full for i, r in enumerate(rets) if (c, i) not in ((1, 40), (1, 200), (2, 255))), (c, rets)
+        log.append((rets, {i: bufs[i].copy() for i in watched}))
+    st = node.stats()
+    assert st["errors"] == 0 and st["calls"] == calls * shards and st["batched_reads"] >= n * calls - 6
+    node.close()
+    for d in ndevs:
+        d.close()
+
+    for i in watched:                                          # the lone twins, one at a time, member i's channel
+        d = S.Device(dict(driver="Cariboulite", channel="S1G" if i % 2 else "HiF", gpu="0"))
+        s = d.setupStream(S.SOAPY_SDR_RX, "CF32", args=args)
+        d.activateStream(s)
+        for c in range(calls):
+            d.feedSmiBytes(batch(i, c))
+            sb = np.full((n_full + 8, 2), np.nan, np.float32)
+            r = d.readStream(s, [sb], MTU, timeoutUs=1000).ret
+            assert r == log[c][0][i], (c, i, r, log[c][0][i])
+            assert sb.tobytes() == log[c][1][i].tobytes(), (c, i)
+        d.close()
+
+    t = load_golden("taps.npz")
+    for i in (0, 40, 200):                                     # the oracle chain: smi_read -> persistent buffer -> /4096 -> FIR128 -> 5/4
+        fir, rs = orc.FIR(t["fir128_c4"]), orc.Resampler(t["rs_5_4"], 5, 4)
+        interm = np.zeros((MTU + 2, 2), np.int16)
+        for c in range(calls):
+            ret, iq, _ = orc.smi_read(ch_of(i), batch(i, c), MTU, NB, fill=-21846)
+            rets, kept = log[c]
+            if ret < 0:
+                assert rets[i] == 0 and np.isnan(kept[i]).all()
+                continue
+            touched = (iq != -21846).any(axis=1)
+            interm[touched] = iq[touched]
+            want = rs.f64(fir.f64(orc.cs16_to_cf32(interm[:MTU])))
+            assert rets[i] == want.shape[0]
+            assert np.max(np.abs(kept[i][: rets[i]] - want)) <= 1e-5 * np.max(np.abs(want)), (i, c)
+            assert np.isnan(kept[i][rets[i]:]).all()

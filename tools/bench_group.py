@@ -25,6 +25,8 @@ CASES = {
     "cf32": ("CF32", "float32", 2, None, 8.0),
     "cf32_fir64_rs_3_2": ("CF32", "float32", 2, {"FIR": "64:1000000", "RESAMP": "3/2"}, 12.0),
     "cf32_fir64_fm_demod": ("CF32", "float32", 1, {"FIR": "64:100000", "DEMOD": "FM"}, 4.0),
+    # BASELINE config 4's per-GPU share (256 streams over 8 GPUs = 32 per GPU) behind the boundary: 128-tap FIR + 5/4
+    "cf32_fir128_rs_5_4": ("CF32", "float32", 2, {"FIR": "128:1200000", "RESAMP": "5/4"}, 10.0),
     # the reference's own low-pass selected on every member (setBandwidth 100 kHz: Butterworth-6, CaribouliteStream.cpp:282-301): such
     # members are read through their own devices inside the group call, their chains queued together
     "cs16_iir": ("CS16", "int16", 2, None, 4.0, 100e3),
@@ -118,7 +120,8 @@ def run_case(name, a):
     n, K = a.streams, a.calls
     words = [synth.smi_stream_bytes(K * MTU, i % 2, stream=i)[0] for i in range(min(n, 4))]      # a few distinct streams, reused
     res = {}
-    n_out = MTU * 3 // 2 + 8 if args and "RESAMP" in args else MTU
+    up, down = (int(x) for x in args["RESAMP"].split("/")) if args and "RESAMP" in args else (1, 1)
+    n_out = MTU * up // down + 8 if up != down else MTU
     shape = (n_out, width) if width > 1 else (n_out,)
 
     def devices():
