@@ -172,30 +172,38 @@ def bench_pcie(a, world, rank, dev, dist, red_dev, arch, taps):
     from cariboulite_amd import soapy as S, synth, shard
     MTU, NB = NATIVE_CHUNK_SAMPLES, 4 * NATIVE_CHUNK_SAMPLES
     n, K, W = a.pcie_streams, a.steps, a.warmup
-    devs = []
-    for i in range(n):
-        d = S.Device(dict(driver="Cariboulite", channel="S1G" if i % 2 == 0 else "HiF", gpu=str(dev.index or 0)))
-        d.activateStream(d.setupStream(S.SOAPY_SDR_RX, S.SOAPY_SDR_CF32, args={"FIR": "64:1000000", "RESAMP": "3/2"}))
-        devs.append(d)
-    # (every step's bytes are queued beforehand: room for all of them in the group's pinned slab, so that the members' FIFOs stay in it)
-    grp = S.Group(devs, {"SLAB_MB": str(((K + W) * NB >> 20) + 1)})
-    bufs = [np.zeros((MTU * 3 // 2 + 8, 2), np.float32) for _ in range(n)]
     words = [synth.smi_stream_bytes((K + W) * MTU, i % 2, stream=1000 * rank + i)[0] for i in range(min(n, 4))]
-    for i, d in enumerate(devs):
-        d.feedSmiBytes(words[i % len(words)])
 
-    def step():
-        nd, rets = grp.readStream(bufs, MTU)
-        assert nd == n, (nd, grp.lastError())
+    def leg(registered):
+        devs = []
+        for i in range(n):
+            d = S.Device(dict(driver="Cariboulite", channel="S1G" if i % 2 == 0 else "HiF", gpu=str(dev.index or 0)))
+            d.activateStream(d.setupStream(S.SOAPY_SDR_RX, S.SOAPY_SDR_CF32, args={"FIR": "64:1000000", "RESAMP": "3/2"}))
+            devs.append(d)
+        # (every step's bytes are queued beforehand: room for all of them in the group's pinned slab, so that the members' FIFOs stay in it)
+        grp = S.Group(devs, {"SLAB_MB": str(((K + W) * NB >> 20) + 1)})
+        bufs = [np.zeros((MTU * 3 // 2 + 8, 2), np.float32) for _ in range(n)]
+        if registered:
+            grp.registerBuffers(bufs)                       # cl_group_register_buffers: the launches store into the clients' buffers themselves
+        for i, d in enumerate(devs):
+            d.feedSmiBytes(words[i % len(words)])
 
-    for _ in range(W):
-        step()
-    dt = shard.timed_steps(step, K, sync_fn=torch.cuda.synchronize, dist=dist, device=red_dev)
-    st = grp.stats()
-    got0 = bufs[0][: MTU * 3 // 2].copy()
-    grp.close()
-    for d in devs:
-        d.close()
+        def step():
+            nd, rets = grp.readStream(bufs, MTU)
+            assert nd == n, (nd, grp.lastError())
+
+        for _ in range(W):
+            step()
+        t = shard.timed_steps(step, K, sync_fn=torch.cuda.synchronize, dist=dist, device=red_dev)
+        stats = grp.stats()
+        first = bufs[0][: MTU * 3 // 2].copy()
+        grp.close()
+        for d in devs:
+            d.close()
+        return t, stats, first
+
+    dt, st, got0 = leg(False)
+    dt_reg, st_reg, got0_reg = leg(True) if not a.no_pcie_extra else (None, None, None)
     if rank == 0:
         value = world * n * MTU * K / dt / 1e6
         res = {"metric": "Msamples/s through unpack+FIR(64)+resample(3/2) pipe, host bytes in -> host samples out (PCIe-inclusive)",
@@ -215,6 +223,12 @@ def bench_pcie(a, world, rank, dev, dist, red_dev, arch, taps):
             except Exception:
                 sh = None
         per_gpu = value / world
+        if dt_reg is not None:
+            # the same calls with the clients' buffers registered beforehand (cl_group_register_buffers): no mirror, no last-hop memcpy on
+            # the host -- the figure that does not depend on how busy the box's cores are; never `value`
+            assert got0_reg.tobytes() == got0.tobytes(), "registered route delivered other samples than the default route"
+            res["registered_client_buffers"] = {"value": round(world * n * MTU * K / dt_reg / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(dt_reg / K * 1e3, 4),
+                                                "direct_reads": st_reg.get("direct_reads"), "same_samples_as_default_route": True}
         if sh:
             peak = n * MTU / (sh["duplex_ms"] * 1e-3) / 1e6
             res["roofline"] = {"bound": "pcie", "achieved": round(per_gpu, 1), "peak": round(peak, 1), "unit": "Msamples/s per GPU", "frac": round(per_gpu / peak, 4),
@@ -223,6 +237,8 @@ def bench_pcie(a, world, rank, dev, dist, red_dev, arch, taps):
                                             f"take {sh['duplex_ms']:.3f} ms; alone {sh['h2d_GBs']} / {sh['d2h_GBs']} GB/s",
                                "kernel": "rx_pipe_fused_kernel over sub-batches of 4 streams, stores into the mapped pinned mirror",
                                "algorithmic_bytes_per_sample": 16.0}
+            if dt_reg is not None:
+                res["registered_client_buffers"]["frac"] = round(res["registered_client_buffers"]["value"] / world / peak, 4)
         else:
             res["roofline"] = {"bound": "pcie", "achieved": round(per_gpu, 1), "peak": None, "unit": "Msamples/s per GPU", "frac": None, "traffic": None,
                                "peak_note": "tools/microbench/pcie_duplex not built: __graft_entry__.build() compiles it"}
@@ -555,7 +571,8 @@ def main():
                 res["pcie_inclusive"] = {"value": c["value"], "unit": c["unit"], "ms_per_step": c["ms_per_step"], "streams": c["config"]["streams_per_gpu"],
                                          "what": "the same stages behind the SoapySDR boundary: host SMI bytes in (pinned FIFOs) -> cl_group_readStream -> host CF32 samples in pageable "
                                                  "buffers; python bench.py --pcie prints the full line",
-                                         "roofline": {k: c["roofline"].get(k) for k in ("bound", "achieved", "peak", "unit", "frac")}}
+                                         "roofline": {k: c["roofline"].get(k) for k in ("bound", "achieved", "peak", "unit", "frac")},
+                                         "registered_client_buffers": c.get("registered_client_buffers")}
             except Exception as e:                             # (the headline line stands whatever happens here)
                 res["pcie_inclusive"] = {"error": f"{type(e).__name__}: {e}"[:200]}
         print(json.dumps(res), flush=True)
