@@ -143,8 +143,34 @@ def cpu_baseline(taps, d_words, budget_s):
         if dt > 1.5:
             break
     res["unpack_1t"] = reps * n / dt / 1e6
+    # the same plumbing through the REFERENCE's own code where it has been compiled (oracle/_ref/libref_smi.so = its caribou_smi.c:
+    # caribou_smi_read's chunk loop -- read() of 512 KiB native batches from a file that stands where /dev/smi stands, sync search,
+    # caribou_smi_rx_data_analyze), then the plugin's /4096 loop (restated: the Soapy plugin itself cannot be compiled here); one thread
+    ref_1t = None
+    if orc.have_ref():
+        import ctypes as C
+        import tempfile
+        try:
+            with tempfile.NamedTemporaryFile(suffix=".smi", dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as f:
+                f.write(b.tobytes()); f.flush()
+                iq = np.zeros((n + 2, 2), np.int16)
+                meta = np.zeros(n + 2, np.uint8)
+                reps, t0 = 0, time.perf_counter()
+                while True:
+                    ret = orc.ref().ref_smi_read_file(f.name.encode(), 0, orc._p(iq, C.c_int16), orc._p(meta, C.c_uint8), C.c_size_t(n), C.c_size_t(524288))
+                    if ret <= 0:
+                        raise RuntimeError(f"caribou_smi_read returned {ret}")
+                    _ = orc.cs16_to_cf32(iq[:n])
+                    reps += 1
+                    dt = time.perf_counter() - t0
+                    if dt > 1.5:
+                        break
+                ref_1t = round(reps * n / dt / 1e6, 1)
+        except Exception as e:                                 # (a reported extra: the line stands without it)
+            ref_1t = f"{type(e).__name__}: {e}"[:120]
     return {"value": round(res["all"], 1), "unit": "Msamples/s", "cores": cores, "kind": "port",
             "value_1_thread": round(res["1t"], 1), "unpack_scale_only_1_thread": round(res["unpack_1t"], 1),
+            "reference_caribou_smi_read_plus_scale_1_thread": ref_1t,
             "sample": f"first 2^24 samples (128 native chunks) of the GPU input, oracle/cl_oracle.c "
                       f"orc_rx_pipe_f32_mt (unpack+sync -> /4096 -> FIR64 -> 3/2, fp32 AVX2, OpenMP)"}, out
 
