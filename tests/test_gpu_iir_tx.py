@@ -324,8 +324,6 @@ def test_tx_pipe_long_message_lookback(G, orc):
 def test_tx_lookback_overrun_is_reported_by_the_same_call(G, orc):
     """The look-back's bounded poll: forced to give up (poll bound 0), the call's verdict is -1 right after its own
     stream sync, the pipe is back in its pre-call state, and repeating the call gives a fresh pipe's bytes."""
-    if os.environ.get("CLHIP_TX_FAST") == "0" or os.environ.get("CLHIP_TX_CHAIN") == "0":
-        pytest.skip("the A/B switch in force replaces the single-launch look-back this test forces to overrun")
     import torch
     from cariboulite_amd import hip
     t = load_golden("taps.npz")
@@ -689,7 +687,7 @@ def test_two_large_iir_launches_share_the_gpu(G, orc):
 def test_tx_pipe_calls_on_either_side_of_the_kernel_choice_equal_one_shot(G, orc):
     """clhip_tx_pipe_run picks its kernel by the call's size (up to 2^22 messages: one sub-block per workgroup; above: superblocks
     of eight).  One pipe fed calls on either side of that line, in turn, gives the SMI words of one call over the whole message
-    (and of a pipe held to either kernel by the A/B switch: the suite runs under CLHIP_TX_CHAIN=1 and =3 too) -- phase,
+    -- phase,
     resampler history and polyphase phase are one state whatever kernel wrote it."""
     import torch
     from cariboulite_amd import hip
@@ -731,7 +729,7 @@ def test_tx_pipe_calls_on_either_side_of_the_kernel_choice_equal_one_shot(G, orc
     d = torch.minimum(d, 8192 - d)       # 13-bit words: a unit phasor's 4096 and 4095 sit on either side of the wrap
     assert int(d.max()) <= 1, int(d.max())
     # (how often: a sub-block worked relative to its own start is rotated into place in fp32, so where the calls cut the message
-    # moves 1e-7-sized roundings around: 3e-4 of the samples with the one-sub-block kernel on both sides, CLHIP_TX_CHAIN=3)
+    # moves 1e-7-sized roundings around: 3e-4 of the samples with the one-sub-block kernel on both sides)
     assert float((d != 0).float().mean()) < 1e-3, float((d != 0).float().mean())
     assert torch.equal(got.view(-1, 4)[:, 0] & 0xE0, want.view(-1, 4)[:, 0] & 0xE0)
 

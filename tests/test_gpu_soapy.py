@@ -400,8 +400,6 @@ def test_write_stream_refuses_bytes_of_an_overrun_lookback(S, orc, monkeypatch):
     """cl_writeStream asks the modulator for its verdict before anything reaches the TX FIFO: with the look-back
     forced to give up, the same call returns 0 (errors are squashed, CaribouliteStream.cpp:185-194) and the FIFO
     stays empty; the stream then works normally again."""
-    if os.environ.get("CLHIP_TX_FAST") == "0" or os.environ.get("CLHIP_TX_CHAIN") == "0":
-        pytest.skip("the A/B switch in force replaces the single-launch look-back this test forces to overrun")
     g = load_golden("dsp_float.npz")
     m = np.tile(g["fm_msg"], 8)[:60000]
     msg_iq = np.stack([m, np.zeros_like(m)], 1)
