@@ -174,7 +174,9 @@ def fanout_streams(root_buf, n_streams, dist, world, rank, root=0, device=None, 
         comm.scatter(root, root_buf.data_ptr() if rank == root else None, row, row, n_streams,
                      local.data_ptr() if len(mine) else None, row, torch.cuda.current_stream().cuda_stream)
         return local
-    ops = []
+    # (gloo moves host memory only: device tensors of the one-GPU rehearsal -- every rank on GPU 0, where RCCL refuses -- go through
+    # host copies of the messages; the schedule is the same)
+    ops, landing = [], None
     if rank == root:
         for peer in range(world):
             rows = assign_streams(n_streams, world, peer)
@@ -184,12 +186,15 @@ def fanout_streams(root_buf, n_streams, dist, world, rank, root=0, device=None, 
             if peer == root:
                 local.copy_(block)
             else:
-                ops.append(dist.P2POp(dist.isend, block, peer))
+                ops.append(dist.P2POp(dist.isend, block.cpu() if on_gpu else block, peer))
     elif mine:
-        ops.append(dist.P2POp(dist.irecv, local, root))
+        landing = torch.empty(local.shape, dtype=dtype, device="cpu") if on_gpu else local
+        ops.append(dist.P2POp(dist.irecv, landing, root))
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
+    if landing is not None and landing is not local:
+        local.copy_(landing)
     return local
 
 
@@ -207,6 +212,7 @@ def gather_streams(local, n_streams, dist, world, rank, root=0):
                     out.data_ptr() if rank == root else None, row, torch.cuda.current_stream().cuda_stream)
         return out
     ops, parts = [], {}
+    on_gpu = local.device.type == "cuda"                # (a CPU backend under device tensors: messages through host copies, as in fanout_streams)
     if rank == root:
         for peer in range(world):
             rows = assign_streams(n_streams, world, peer)
@@ -215,13 +221,13 @@ def gather_streams(local, n_streams, dist, world, rank, root=0):
             if peer == root:
                 out[rows] = local
             else:
-                parts[peer] = torch.empty((len(rows), n_elems), dtype=local.dtype, device=local.device)
+                parts[peer] = torch.empty((len(rows), n_elems), dtype=local.dtype, device="cpu" if on_gpu else local.device)
                 ops.append(dist.P2POp(dist.irecv, parts[peer], peer))
     elif mine:
-        ops.append(dist.P2POp(dist.isend, local.contiguous(), root))
+        ops.append(dist.P2POp(dist.isend, local.cpu() if on_gpu else local.contiguous(), root))
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
     for peer, blk in parts.items():
-        out[assign_streams(n_streams, world, peer)] = blk
+        out[assign_streams(n_streams, world, peer)] = blk.to(out.device)
     return out

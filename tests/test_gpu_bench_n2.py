@@ -42,6 +42,17 @@ def test_two_ranks_sharded_config4():
 
 
 @pytest.mark.gpu
+def test_two_ranks_sharded_config4_with_the_fan_out_step():
+    """--fanout: rank 0 holds every stream's raw buffer and hands each rank its own before the timed region (the one real exchange step,
+    SURVEY.md section 8e).  On a node that is clfan_scatter_streams over RCCL; in this one-GPU rehearsal the same schedule goes through
+    torch.distributed's point-to-point calls (gloo, the messages through host copies) -- bench.py's own code around it, the barriers and
+    the scatter's separate clock, is what runs here for real."""
+    d = _run(["--workload", "c4", "--streams", "6", "--log2-samples", "17", "--fanout"])
+    assert d["n_gpus"] == 2 and d["config"]["streams_per_gpu"] == 3
+    assert d["config"]["fanout_scatter_s"] is not None and 0 < d["config"]["fanout_scatter_s"] < 60
+
+
+@pytest.mark.gpu
 def test_two_ranks_at_the_soapy_boundary():
     """--pcie: each rank owns a stream group of its own (8 Soapy devices here), feeds it host bytes and reads host samples; the
     line's value is both ranks' samples over the max-over-ranks time."""
